@@ -1,0 +1,172 @@
+/*
+ * lecone.h -- C ABI of liblecone.so: the MI355X (gfx950) kernels + host sampler behind the reference's
+ * joint image+label hyperbolic entailment-cone training step (ankitdhall/learning_embeddings).
+ *
+ * The reference has NO FFI: the path sits behind duck-typed Python objects.  These entry points are
+ * therefore the layer a maintainer would bind with ctypes from inside the reference's own classes; each one names the
+ * reference code it replaces (file:line relative to the reference root).  INTEGRATION.md shows the binding stubs.
+ *
+ * Conventions
+ *   - extern "C", plain pointers + sizes, no torch types, no exceptions across the boundary, no ownership transfer.
+ *   - every function returns 0 on success, a negative LEC_E_* code on failure; lec_last_error() gives the message
+ *     (thread-local).  Python raises on nonzero.
+ *   - all device pointers are caller-owned HBM buffers; every GPU entry takes the hipStream_t to enqueue on (pass
+ *     torch's current stream) and is asynchronous with respect to the host.
+ *   - float tensors are fp32 row-major with an explicit leading dimension (ld, in elements).
+ *   - "node code" (int32): c >= 0 is a row of the label table; c < 0 is row (-1 - c) of the per-step image-feature
+ *     buffer (raw CNN outputs).
+ */
+#ifndef LECONE_H
+#define LECONE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* lec_stream_t;              /* a hipStream_t, passed as an opaque pointer (0 = default stream) */
+
+#define LEC_OK            0
+#define LEC_E_ARG        -1              /* bad argument (null pointer, size/ld out of range, unsupported D)     */
+#define LEC_E_HIP        -2              /* a HIP runtime call or kernel launch failed                            */
+#define LEC_E_EMPTY      -3              /* sampler: empty candidate list (python's random.choice raises there)   */
+#define LEC_E_STATE      -4              /* bad handle / not initialised                                          */
+
+/* which energy E(x, y) a kernel evaluates */
+#define LEC_ENERGY_HYP_CONE  0           /* network/oe_h.py:811-833  (Poincare-ball entailment cone, parameter K) */
+#define LEC_ENERGY_ORDER     1           /* network/order_embeddings.py:818-824  sum_d max(0, x_d - y_d)^2        */
+
+/* how a label-table row becomes a point (the Embedder.forward of the trainer in use) */
+#define LEC_LABEL_RAW        0           /* order_embeddings.py:188-193 with K=None: the row itself               */
+#define LEC_LABEL_HYP        1           /* oe_h.py:77-104: +1e-15, tanh(clamp(atanh(r_in)+|e|))*e/|e|, then the
+                                            no-grad clip of rows into [r_in, 1-1e-5] (straight-through)           */
+/* how a raw CNN output row becomes a point */
+#define LEC_IMAGE_RAW        0
+#define LEC_IMAGE_SOFTCLIP   1           /* oe_h.py:323-328 FeatCNN18.soft_clip: x/|x| * (|x| + r_in)             */
+
+const char* lec_last_error(void);
+int         lec_abi_version(void);       /* bumped on any signature change; checked by the Python loader           */
+/* Bytes of device workspace the fused loss needs for a launch of (B, K): per-block loss partials + arrival counter. */
+int64_t     lec_loss_workspace_bytes(int B, int K, int D);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * (1) Pair energies on dense rows.  Replaces E_operator (oe_h.py:811-833 / order_embeddings.py:818-824) and its
+ *     autograd.  x, y: [P, D] (ldx, ldy);  E, gE: [P];  gx, gy: [P, D] (ldg).  gx/gy are overwritten.
+ * ------------------------------------------------------------------------------------------------------------- */
+int lec_pair_energy_fwd(int energy, const float* x, int64_t ldx, const float* y, int64_t ldy, int64_t P, int D,
+                        float K_cone, float* E, lec_stream_t stream);
+int lec_pair_energy_bwd(int energy, const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gE,
+                        int64_t P, int D, float K_cone, float* gx, float* gy, int64_t ldg, lec_stream_t stream);
+/* All-pairs scoring used by calculate_classification_metrics (oe_h.py:2018-2036): E[i, j] = E(x_j, y_i) for
+ * x: [N, D] (apexes, e.g. every label), y: [M, D] (e.g. every image).  E: [M, N] (ldE). */
+int lec_pair_energy_matrix(int energy, const float* x, int64_t ldx, int64_t N, const float* y, int64_t ldy, int64_t M,
+                           int D, float K_cone, float* E, int64_t ldE, lec_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * (2) Fused joint loss, forward + backward in one launch.  Replaces criterion.forward's train branch AFTER negative
+ *     sampling (oe_h.py:929-967: calculate_from_and_to_emb for positives and negatives, positive_pair, negative_pair,
+ *     get_image_label_loss), Embedder.forward (oe_h.py:77-104) and FeatCNN18.soft_clip (oe_h.py:323-328) for the rows
+ *     involved, and loss.backward() down to the label table and the raw CNN outputs.
+ *
+ *       loss = sum_b w_b E(u_b, v_b) + sum_b w_b sum_{k<2K} max(0, alpha - E_neg[b,k])         (oe_h.py:846)
+ *       negative slot k <  K : (u_b, neg[b,k])        ("to" end corrupted,   oe_h.py:951-952)
+ *       negative slot k >= K : (neg[b,k], v_b)        ("from" end corrupted, oe_h.py:955-957)
+ *
+ *     table    [n_labels, D] (ld_table)   label parameters (nn.Embedding weight)
+ *     feat     [n_feat,   D] (ld_feat)    raw CNN outputs of this step's distinct images (may be NULL if n_feat == 0)
+ *     pos_from, pos_to [B] node codes;  neg [B, 2K] node codes;  weights [B] or NULL (all 1.0)
+ *     e_pos [B], e_neg [B, 2K], loss [1]: outputs (overwritten)
+ *     grad_table [n_labels, D] (ld_table), grad_feat [n_feat, D] (ld_feat): d loss / d table, d loss / d feat are
+ *       ADDED into these buffers (float atomics) -- zero them first for a plain gradient.  Pass NULL for both to run
+ *       forward only.
+ *     workspace: >= lec_loss_workspace_bytes(B, K, D) bytes of device memory, caller-owned, reused across calls.
+ * ------------------------------------------------------------------------------------------------------------- */
+int lec_joint_loss_fwd_bwd(int energy, int label_proj, int image_proj,
+                           const float* table, int64_t ld_table, int n_labels,
+                           const float* feat, int64_t ld_feat, int n_feat,
+                           const int32_t* pos_from, const int32_t* pos_to, const int32_t* neg, const float* weights,
+                           int B, int K, int D, float K_cone, float alpha,
+                           float* e_pos, float* e_neg, float* loss,
+                           float* grad_table, float* grad_feat,
+                           void* workspace, int64_t workspace_bytes, lec_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * (3) Stand-alone projections (used outside the fused loss: evaluation, metrics, FeatCNN18.forward itself).
+ *     lec_label_project_fwd  = Embedder.forward (oe_h.py:77-104): out[i] = project(table[idx[i]]).
+ *     lec_label_project_bwd  adds d/d table into grad_table (dense, sparse=False semantics; float atomics).
+ *     lec_image_softclip_fwd/bwd = FeatCNN18.soft_clip (oe_h.py:323-328) and its autograd.
+ * ------------------------------------------------------------------------------------------------------------- */
+int lec_label_project_fwd(const float* table, int64_t ld_table, int n_labels, const int64_t* idx, int64_t n, int D,
+                          float K_cone, float* out, int64_t ld_out, lec_stream_t stream);
+int lec_label_project_bwd(const float* table, int64_t ld_table, int n_labels, const int64_t* idx, int64_t n, int D,
+                          float K_cone, const float* gout, int64_t ld_gout, float* grad_table, lec_stream_t stream);
+int lec_image_softclip_fwd(const float* raw, int64_t ld_raw, int64_t n, int D, float K_cone, float* out, int64_t ld_out,
+                           lec_stream_t stream);
+int lec_image_softclip_bwd(const float* raw, int64_t ld_raw, const float* gout, int64_t ld_gout, int64_t n, int D,
+                           float K_cone, float* graw, int64_t ld_graw, lec_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * (4) Label-table maintenance, one pass over [n_labels, D].
+ *     lec_table_step_adam replaces oe_h.py:1768-1771: grad *= ((1-|w|)/2)^2 (lambda_x :1632-1636) -> torch.optim.Adam
+ *       step `step` (1-based; betas/eps as given, no weight decay/amsgrad) -> soft_clip rows into [r_in, 1-1e-5]
+ *       (:1604-1617).  `riemannian` = 0 skips the rescale and `clip` = 0 skips the clip (Euclidean trainers).
+ *     lec_table_step_rsgd replaces oe_h.py:1761-1762 / order_embeddings_h.py:764-775: exp_map_x(w, -lr * rescaled grad)
+ *       with Mobius addition (:1619-1644), then the same clip.
+ * ------------------------------------------------------------------------------------------------------------- */
+int lec_table_step_adam(float* table, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t ld, int n_labels,
+                        int D, float lr, float beta1, float beta2, float eps, int step, float K_cone, int riemannian,
+                        int clip, lec_stream_t stream);
+int lec_table_step_rsgd(float* table, const float* grad, int64_t ld, int n_labels, int D, float lr, float K_cone,
+                        lec_stream_t stream);
+/* Adam over a flat fp32 parameter arena (the CNN's parameters live in one buffer so that the data-parallel gradient
+ * all-reduce is ONE collective and the optimizer ONE launch).  Replaces optimizer_labels.step() for the CNN half of
+ * oe_h.py:1523,1769.  grad_scale multiplies the gradient first (1.0 for the reference's SUM semantics). */
+int lec_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int step, float grad_scale, lec_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * (5) Negative sampler (HOST, bit-exact).  Replaces set_negative_graph + sample_negative_edge (oe_h.py:799-809,
+ *     849-902; labels-only variant order_embeddings.py:797-816) WITHOUT the dense (N+M)^2 bool matrix: the candidate
+ *     list "ascending indices j in the level window with A[u,j] == 1" is the window minus the node's sorted
+ *     transitive-closure neighbours, and random.choice's pick is the r-th survivor with r drawn from CPython's
+ *     MT19937 `_randbelow` stream.
+ *
+ *     Graph: nodes 0..n_labels-1 are labels in level order (level_sizes[L]); nodes n_labels..n_labels+n_images-1 are
+ *     images.  label_edges: [n_label_edges, 2] (parent, child) pairs of the label DAG (not closed);
+ *     image_parents: CSR (image_ptr [n_images+1], image_adj) listing, per image, the labels it hangs under directly
+ *     (the reference adds one edge per level, oe_h.py:524-531).  The transitive closure is taken here.
+ *     mode: 0 = joint trainer rules (level_id % (L+1), slot L = "labels only if an endpoint is an image, else images
+ *     only", oe_h.py:880-898); 1 = labels-only trainer rules (level_id % L, order_embeddings.py:799).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct lec_sampler lec_sampler;
+int  lec_sampler_create(lec_sampler** out, const int32_t* level_sizes, int n_levels,
+                        const int32_t* label_edges, int64_t n_label_edges,
+                        const int64_t* image_ptr, const int32_t* image_adj, int64_t n_images,
+                        int pick_per_level, int mode, uint64_t seed);
+void lec_sampler_destroy(lec_sampler* s);
+int  lec_sampler_seed(lec_sampler* s, uint64_t seed);                    /* random.seed(seed)                       */
+int  lec_sampler_set_levels_to_hide(lec_sampler* s, const int32_t* levels, int n);   /* oe_h.py:764-765, 850-854   */
+/* One call of sample_negative_edge: side 0 = `u` fixed (corrupt the "to" end), side 1 = `v` fixed. */
+int  lec_sampler_draw(lec_sampler* s, int side, int32_t node, int32_t level_id, int32_t* out);
+/* The criterion's host loop (oe_h.py:940-957): for b < B: for p < K: draw(0, from[b], p) -> neg[b,p];
+ * draw(1, to[b], p) -> neg[b,K+p].  Consumes the RNG in exactly that order. */
+int  lec_sampler_draw_batch(lec_sampler* s, const int32_t* pos_from, const int32_t* pos_to, int B, int K, int32_t* neg);
+int  lec_sampler_next_u32(lec_sampler* s, uint32_t* out);                /* raw MT19937 word (known-answer tests)   */
+int64_t lec_sampler_tc_edges(const lec_sampler* s);                      /* |TC| (label-label + label-image)        */
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * (6) Multi-level cross-entropy, forward + backward in one launch.  Replaces MultiLevelCELoss.forward
+ *     (network/loss.py:29-38) and its autograd:  loss = mean_b sum_l w_l CE(logits[b, s_l:e_l], labels[b, l]).
+ *     logits [B, C] (ld), level_labels [B, L] int64, level_sizes [L] (sum = C), level_weights [L] or NULL.
+ *     glogits [B, C] (ld) is overwritten with d loss / d logits (pass NULL for forward only).
+ * ------------------------------------------------------------------------------------------------------------- */
+int lec_multilevel_ce_fwd_bwd(const float* logits, int64_t ld, const int64_t* level_labels, int B, int C,
+                              const int32_t* level_sizes, const float* level_weights, int L,
+                              float* loss, float* glogits, void* workspace, int64_t workspace_bytes,
+                              lec_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LECONE_H */

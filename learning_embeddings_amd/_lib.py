@@ -1,0 +1,90 @@
+"""ctypes binding of liblecone.so (include/lecone.h).  There is NO fallback: if the library is missing or a call fails,
+this module raises.  The product never routes through oracle/ or any CPU re-implementation."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'liblecone.so')
+ABI_VERSION = 1
+
+OK, E_ARG, E_HIP, E_EMPTY, E_STATE = 0, -1, -2, -3, -4
+ENERGY_HYP_CONE, ENERGY_ORDER = 0, 1
+LABEL_RAW, LABEL_HYP = 0, 1
+IMAGE_RAW, IMAGE_SOFTCLIP = 0, 1
+
+
+class LeconeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('liblecone error %d: %s' % (code, msg))
+        self.code = code
+
+
+class EmptyCandidates(LeconeError, IndexError):
+    """The reference's random.choice raises IndexError on an empty candidate list (oe_h.py:901)."""
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'liblecone.so not found at %s -- build it first: `python -c "import __graft_entry__ as g; g.build()"` '
+            'or `make -C learning_embeddings_amd/csrc`.  There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.lec_last_error.restype = C.c_char_p
+    lib.lec_abi_version.restype = C.c_int
+    if lib.lec_abi_version() != ABI_VERSION:
+        raise ImportError('liblecone.so ABI %d != expected %d: rebuild' % (lib.lec_abi_version(), ABI_VERSION))
+    p, i32, i64, f32, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
+    sig = {
+        'lec_loss_workspace_bytes': (i64, [i32, i32, i32]),
+        'lec_pair_energy_fwd': (i32, [i32, p, i64, p, i64, i64, i32, f32, p, p]),
+        'lec_pair_energy_bwd': (i32, [i32, p, i64, p, i64, p, i64, i32, f32, p, p, i64, p]),
+        'lec_pair_energy_matrix': (i32, [i32, p, i64, i64, p, i64, i64, i32, f32, p, i64, p]),
+        'lec_joint_loss_fwd_bwd': (i32, [i32, i32, i32, p, i64, i32, p, i64, i32, p, p, p, p, i32, i32, i32, f32, f32,
+                                         p, p, p, p, p, p, i64, p]),
+        'lec_label_project_fwd': (i32, [p, i64, i32, p, i64, i32, f32, p, i64, p]),
+        'lec_label_project_bwd': (i32, [p, i64, i32, p, i64, i32, f32, p, i64, p, p]),
+        'lec_image_softclip_fwd': (i32, [p, i64, i64, i32, f32, p, i64, p]),
+        'lec_image_softclip_bwd': (i32, [p, i64, p, i64, i64, i32, f32, p, i64, p]),
+        'lec_table_step_adam': (i32, [p, p, p, p, i64, i32, i32, f32, f32, f32, f32, i32, f32, i32, i32, p]),
+        'lec_table_step_rsgd': (i32, [p, p, i64, i32, i32, f32, f32, p]),
+        'lec_adam_flat': (i32, [p, p, p, p, i64, f32, f32, f32, f32, i32, f32, p]),
+        'lec_sampler_create': (i32, [C.POINTER(p), p, i32, p, i64, p, p, i64, i32, i32, u64]),
+        'lec_sampler_destroy': (None, [p]),
+        'lec_sampler_seed': (i32, [p, u64]),
+        'lec_sampler_set_levels_to_hide': (i32, [p, p, i32]),
+        'lec_sampler_draw': (i32, [p, i32, i32, i32, p]),
+        'lec_sampler_draw_batch': (i32, [p, p, p, i32, i32, p]),
+        'lec_sampler_next_u32': (i32, [p, p]),
+        'lec_sampler_tc_edges': (i64, [p]),
+        'lec_multilevel_ce_fwd_bwd': (i32, [p, i64, p, i32, i32, p, p, i32, p, p, p, i64, p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)           # AttributeError here = header and library disagree: fail loudly
+        fn.restype = res; fn.argtypes = args
+    return lib, sorted(sig)
+
+
+lib, EXPORTS = _load()
+
+
+def check(rc):
+    if rc == OK:
+        return
+    msg = lib.lec_last_error().decode('utf-8', 'replace')
+    if rc == E_EMPTY:
+        raise EmptyCandidates(rc, msg)
+    raise LeconeError(rc, msg)
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dptr(t):
+    """Raw device pointer of a CUDA(HIP) tensor (or None)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('liblecone kernels run on the MI355X only: got a %s tensor (there is no CPU fallback)' % t.device)
+    return C.c_void_p(t.data_ptr())

@@ -1,0 +1,310 @@
+// Fused joint (label, image) entailment-cone loss: forward + backward in ONE launch (lec_joint_loss_fwd_bwd).
+//
+// Replaces, for one training step after negative sampling (reference file:line):
+//   oe_h.py:929-967   criterion.forward train branch (embedding of positives and negatives, E+, E-, hinge, sum)
+//   oe_h.py:77-104    Embedder.forward + no-grad clip, for the label rows the step touches
+//   oe_h.py:323-328   FeatCNN18.soft_clip for the image rows
+//   loss.backward()   down to d/d table (dense, accumulated) and d/d raw CNN outputs
+//
+// Work decomposition (MI355X: 256 CUs x 4 SIMDs, 64-lane waves).  A "positive group" b owns the rows
+// {u_b, v_b, K corrupt v', K corrupt u'} and the 1+2K pairs built from them.  A wave takes one TASK = (group b,
+// chunk c of its pair list); T lanes cooperate on one pair (row elements d = t, t+T, ... live in registers, EPL per
+// lane), so a wave evaluates 64/T pairs per iteration.  Row statistics (|x|^2, |y|^2, <x,y>, |x-y|^2) and the
+// projection norms are reduced with xor-butterflies inside the T-lane group; the gradient of u_b / v_b is accumulated
+// in registers across the chunk, reduced across the wave's pair slots by butterflies, and leaves the wave as ONE
+// atomic row-add per task.  Corrupt rows get one atomic row-add per live pair (dead hinges add nothing).  The loss
+// is reduced wave -> block -> grid deterministically (lec_common.h block_publish_and_finalize).
+//
+// Roofline: HBM / L2 bound gather + scatter; algorithmic bytes per positive (fwd+bwd, rows de-duplicated inside a
+// group) = (2+2K)(2*D*4 + 4*D + 4) + (1+2K)*8   (SURVEY.md 8d).
+#include "lec_common.h"
+
+namespace lec {
+
+struct JointParams {
+  const float* table; int64_t ld_table; int n_labels;
+  const float* feat; int64_t ld_feat; int n_feat;
+  const int32_t* pos_from; const int32_t* pos_to; const int32_t* neg; const float* weights;
+  int B, K, D;
+  float K_cone, alpha, r_in, r_in_h;
+  int label_proj, image_proj;
+  float* e_pos; float* e_neg; float* loss;
+  float* grad_table; float* grad_feat;
+  float* partials; unsigned int* counter;
+  int iters;            // pair iterations per task
+  int tasks_per_group;
+};
+
+// One projected row held across T lanes: raw e (after the +1e-15 of Embedder.forward), projected p, and the two
+// scalars of the projection's Jacobian:  d/d e = A * go + Bc * <e, go> * e.
+template <int EPL>
+struct Row {
+  float e[EPL];
+  float p[EPL];
+  float A, Bc;
+};
+
+template <int T, int EPL>
+__device__ __forceinline__ void load_project(const JointParams& P, int code, bool valid, int t, Row<EPL>& r) {
+  const bool is_label = code >= 0;
+  const float* src = nullptr;
+  if (valid) src = is_label ? P.table + (int64_t)code * P.ld_table : P.feat + (int64_t)(-1 - code) * P.ld_feat;
+  const bool hyp = valid && is_label && P.label_proj == LEC_LABEL_HYP;
+  const bool img = valid && !is_label && P.image_proj == LEC_IMAGE_SOFTCLIP;
+  float nn = 0.0f;
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) {
+    int d = t + i * T;
+    float v = 0.0f;
+    if (valid && d < P.D) { v = src[d]; if (hyp) v += 1e-15f; }                    // oe_h.py:79
+    r.e[i] = v; nn += v * v;
+  }
+  nn = group_sum<T>(nn);
+  const float n = sqrtf(nn);                                                       // oe_h.py:81 / :327
+  const float den = fmaxf(n, 1e-12f);                                              // F.normalize eps
+  const float denp = n >= 1e-12f ? 1.0f : 0.0f;
+  float mul = 1.0f, A = 1.0f, Bc = 0.0f;
+  if (hyp) {
+    float arg = P.r_in_h + n;
+    float argc = arg < -15.0f ? -15.0f : (arg > 15.0f ? 15.0f : arg);
+    float th = tanhf(argc);                                                        // oe_h.py:83
+    float tp = (arg >= -15.0f && arg <= 15.0f) ? 1.0f - th * th : 0.0f;
+    mul = th; A = th / den;
+    Bc = n > 0.0f ? (tp / den - th * denp / (den * den)) / n : 0.0f;
+  } else if (img) {
+    float sc = n + P.r_in;                                                         // oe_h.py:328
+    mul = sc; A = sc / den;
+    Bc = n > 0.0f ? (1.0f / den - sc * denp / (den * den)) / n : 0.0f;
+  }
+  float pp = 0.0f;
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) {
+    float v = (hyp || img) ? mul * (r.e[i] / den) : r.e[i];
+    r.p[i] = v; pp += v * v;
+  }
+  // no-grad clip of label points into [r_in, 1-1e-5] (oe_h.py:100-103); images are NOT clipped (:323-328)
+  pp = group_sum<T>(pp);
+  if (hyp) {
+    float no = sqrtf(pp);
+    if (no <= P.r_in) {
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) r.p[i] = r.p[i] / no * P.r_in;
+    } else if (no >= 1.0f) {
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) r.p[i] = r.p[i] / no * (float)(1.0 - 1e-5);
+    }
+  }
+  r.A = A; r.Bc = Bc;
+}
+
+// chain a gradient w.r.t. the projected row back to the raw row and add it to the owner buffer
+template <int T, int EPL>
+__device__ __forceinline__ void scatter_row_grad(const JointParams& P, int code, bool active, int t,
+                                                 const Row<EPL>& r, const float (&go)[EPL]) {
+  float dot = 0.0f;
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) dot += r.e[i] * go[i];
+  dot = group_sum<T>(dot);
+  if (!active) return;
+  float* dst = code >= 0 ? P.grad_table + (int64_t)code * P.ld_table : P.grad_feat + (int64_t)(-1 - code) * P.ld_feat;
+  const float c = r.Bc * dot;
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) {
+    int d = t + i * T;
+    if (d < P.D) atomicAdd(dst + d, r.A * go[i] + c * r.e[i]);
+  }
+}
+
+template <int T, int EPL, int ENERGY, bool GRAD>
+__global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
+  constexpr int PPW = kWave / T;                      // pairs per wave iteration
+  const int lane = threadIdx.x & 63;
+  const int t = lane % T, slot = lane / T;
+  const int wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int b = wave_global / P.tasks_per_group;
+  const int c = wave_global - b * P.tasks_per_group;
+  const bool task_valid = b < P.B;
+  const int NP = 1 + 2 * P.K;
+  float lsum = 0.0f;
+
+  // NOTE: every lane of the wave walks the same control flow (butterflies need all 64 lanes); validity is a predicate.
+  int ucode = 0, vcode = 0; float w = 1.0f;
+  if (task_valid) {
+    ucode = P.pos_from[b]; vcode = P.pos_to[b];
+    if (P.weights) w = P.weights[b];
+  }
+  Row<EPL> U, V;
+  load_project<T, EPL>(P, ucode, task_valid, t, U);
+  load_project<T, EPL>(P, vcode, task_valid, t, V);
+  float gu[EPL], gv[EPL];
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) { gu[i] = 0.0f; gv[i] = 0.0f; }
+
+  const int q0 = c * P.iters * PPW;
+  for (int it = 0; it < P.iters; ++it) {
+    const int q = q0 + it * PPW + slot;               // pair index in the group: 0 = positive, 1+k = negative slot k
+    const bool valid = task_valid && q < NP;
+    const int kind = !valid ? 0 : (q == 0 ? 0 : (q - 1 < P.K ? 1 : 2));   // 1: u fixed (corrupt `to`), 2: v fixed
+    int ocode = 0;
+    if (valid && q > 0) ocode = P.neg[(int64_t)b * 2 * P.K + (q - 1)];
+    Row<EPL> O;
+    load_project<T, EPL>(P, ocode, valid && q > 0, t, O);
+
+    float x[EPL], y[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+      x[i] = kind == 2 ? O.p[i] : U.p[i];
+      y[i] = kind == 1 ? O.p[i] : V.p[i];
+    }
+    float E, g = 0.0f;
+    float gx[EPL], gy[EPL];
+    if (ENERGY == LEC_ENERGY_HYP_CONE) {
+      float xx = 0.f, yy = 0.f, s = 0.f, dd = 0.f;
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) {
+        float df = x[i] - y[i];
+        xx += x[i] * x[i]; yy += y[i] * y[i]; s += x[i] * y[i]; dd += df * df;
+      }
+      xx = group_sum<T>(xx); yy = group_sum<T>(yy); s = group_sum<T>(s); dd = group_sum<T>(dd);
+      ConeEval ev = cone_eval<GRAD>(xx, yy, s, dd, P.K_cone);
+      E = ev.E;
+      if (GRAD) {
+        g = q == 0 ? w : ((P.alpha - E) >= 0.0f ? -w : 0.0f);                      // oe_h.py:846 (+ clamp mask)
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) {
+          gx[i] = g * (ev.cxx * x[i] + ev.cxy * y[i]);
+          gy[i] = g * (ev.cxy * x[i] + ev.cyy * y[i]);
+        }
+      }
+    } else {                                                                       // order_embeddings.py:818-824
+      float e = 0.0f;
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) { float m = fmaxf(x[i] - y[i], 0.0f); e += m * m; }
+      E = group_sum<T>(e);
+      if (GRAD) {
+        g = q == 0 ? w : ((P.alpha - E) >= 0.0f ? -w : 0.0f);
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) {
+          float m = 2.0f * fmaxf(x[i] - y[i], 0.0f) * g;
+          gx[i] = m; gy[i] = -m;
+        }
+      }
+    }
+    if (valid && t == 0) {
+      if (q == 0) { P.e_pos[b] = E; lsum += w * E; }
+      else {
+        P.e_neg[(int64_t)b * 2 * P.K + (q - 1)] = E;
+        float h = P.alpha - E;
+        lsum += w * (h < 0.0f ? 0.0f : h);                                         // oe_h.py:839,846
+      }
+    }
+    if (GRAD) {
+      const bool act = valid && g != 0.0f;
+      float go[EPL];
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) {
+        if (act && kind != 2) gu[i] += gx[i];
+        if (act && kind != 1) gv[i] += gy[i];
+        go[i] = kind == 1 ? gy[i] : gx[i];
+      }
+      scatter_row_grad<T, EPL>(P, ocode, act && kind != 0, t, O, go);
+    }
+  }
+
+  if (GRAD) {
+    // sum the per-slot partial gradients of u_b and v_b across the wave's pair slots, then one row-add each
+#pragma unroll
+    for (int m = T; m < kWave; m <<= 1) {
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) { gu[i] += __shfl_xor(gu[i], m, kWave); gv[i] += __shfl_xor(gv[i], m, kWave); }
+    }
+    scatter_row_grad<T, EPL>(P, ucode, task_valid && slot == 0, t, U, gu);
+    scatter_row_grad<T, EPL>(P, vcode, task_valid && slot == 0, t, V, gv);
+  }
+
+  lsum = group_sum<64>(lsum);
+  block_publish_and_finalize(lsum, P.partials, P.counter, P.loss, 1.0f);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <int T, int EPL>
+static int launch(const JointParams& P, bool grad, int energy, int nblocks, hipStream_t st) {
+#define LEC_JL(E_, G_) hipLaunchKernelGGL((joint_loss_kernel<T, EPL, E_, G_>), dim3(nblocks), dim3(256), 0, st, P)
+  if (energy == LEC_ENERGY_HYP_CONE) { if (grad) LEC_JL(LEC_ENERGY_HYP_CONE, true); else LEC_JL(LEC_ENERGY_HYP_CONE, false); }
+  else { if (grad) LEC_JL(LEC_ENERGY_ORDER, true); else LEC_JL(LEC_ENERGY_ORDER, false); }
+#undef LEC_JL
+  LEC_CHECK_LAUNCH("joint_loss_kernel");
+  return LEC_OK;
+}
+
+struct JointGeom { int T, EPL, iters, tasks_per_group, nblocks; };
+
+static bool joint_geometry(int B, int K, int D, JointGeom& g) {
+  if (D <= 4) { g.T = 1; g.EPL = 4; }
+  else if (D <= 16) { g.T = 4; g.EPL = 4; }
+  else if (D <= 64) { g.T = 16; g.EPL = 4; }
+  else if (D <= 256) { g.T = 64; g.EPL = 4; }
+  else if (D <= 1024) { g.T = 64; g.EPL = 16; }
+  else return false;
+  const int ppw = 64 / g.T, NP = 1 + 2 * K;
+  // enough waves to fill 256 CUs several times over, but at least 2 iterations per task when the group is long
+  int iters = (NP + ppw - 1) / ppw;
+  if (iters > 2) iters = 2;
+  g.iters = iters;
+  g.tasks_per_group = (NP + ppw * iters - 1) / (ppw * iters);
+  int64_t waves = (int64_t)B * g.tasks_per_group;
+  g.nblocks = (int)((waves + 3) / 4);
+  return true;
+}
+
+}  // namespace lec
+
+extern "C" int64_t lec_loss_workspace_bytes(int B, int K, int D) {
+  lec::JointGeom g;
+  if (B < 0 || K < 0 || !lec::joint_geometry(B > 0 ? B : 1, K, D > 0 ? D : 1, g)) return LEC_E_ARG;
+  return 256 + (int64_t)g.nblocks * sizeof(float);
+}
+
+extern "C" int lec_joint_loss_fwd_bwd(int energy, int label_proj, int image_proj,
+                                      const float* table, int64_t ld_table, int n_labels,
+                                      const float* feat, int64_t ld_feat, int n_feat,
+                                      const int32_t* pos_from, const int32_t* pos_to, const int32_t* neg,
+                                      const float* weights, int B, int K, int D, float K_cone, float alpha,
+                                      float* e_pos, float* e_neg, float* loss, float* grad_table, float* grad_feat,
+                                      void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+  using namespace lec;
+  LEC_CHECK_ARG(energy == LEC_ENERGY_HYP_CONE || energy == LEC_ENERGY_ORDER, "joint_loss: unknown energy %d", energy);
+  LEC_CHECK_ARG(label_proj == LEC_LABEL_RAW || label_proj == LEC_LABEL_HYP, "joint_loss: unknown label_proj %d", label_proj);
+  LEC_CHECK_ARG(image_proj == LEC_IMAGE_RAW || image_proj == LEC_IMAGE_SOFTCLIP, "joint_loss: unknown image_proj %d", image_proj);
+  LEC_CHECK_ARG(B > 0 && K >= 0 && D > 0, "joint_loss: B=%d K=%d D=%d must be positive (K >= 0)", B, K, D);
+  LEC_CHECK_ARG(table && n_labels > 0 && ld_table >= D, "joint_loss: table null or ld_table < D");
+  LEC_CHECK_ARG(n_feat == 0 || (feat && ld_feat >= D), "joint_loss: feat null or ld_feat < D");
+  LEC_CHECK_ARG(pos_from && pos_to && (K == 0 || neg), "joint_loss: null index arrays");
+  LEC_CHECK_ARG(e_pos && (K == 0 || e_neg) && loss, "joint_loss: null outputs");
+  LEC_CHECK_ARG((grad_table == nullptr) == (grad_feat == nullptr) || n_feat == 0,
+                "joint_loss: pass both grad_table and grad_feat, or neither");
+  JointGeom g;
+  LEC_CHECK_ARG(joint_geometry(B, K, D, g), "joint_loss: embedding_dim %d not supported (max 1024)", D);
+  const int64_t need = 256 + (int64_t)g.nblocks * sizeof(float);
+  LEC_CHECK_ARG(workspace && workspace_bytes >= need, "joint_loss: workspace too small (%lld < %lld)",
+                (long long)workspace_bytes, (long long)need);
+  hipStream_t st = (hipStream_t)stream;
+  JointParams P;
+  P.table = table; P.ld_table = ld_table; P.n_labels = n_labels;
+  P.feat = feat; P.ld_feat = ld_feat; P.n_feat = n_feat;
+  P.pos_from = pos_from; P.pos_to = pos_to; P.neg = neg; P.weights = weights;
+  P.B = B; P.K = K; P.D = D; P.K_cone = K_cone; P.alpha = alpha;
+  P.r_in = inner_radius_f(K_cone); P.r_in_h = inner_radius_h_f(K_cone);
+  P.label_proj = label_proj; P.image_proj = image_proj;
+  P.e_pos = e_pos; P.e_neg = e_neg; P.loss = loss; P.grad_table = grad_table; P.grad_feat = grad_feat;
+  P.counter = (unsigned int*)workspace; P.partials = (float*)((char*)workspace + 256);
+  P.iters = g.iters; P.tasks_per_group = g.tasks_per_group;
+  hipError_t e = hipMemsetAsync(workspace, 0, 256, st);
+  if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(workspace)");
+  const bool grad = grad_table != nullptr;
+  if (g.T == 1) return launch<1, 4>(P, grad, energy, g.nblocks, st);
+  if (g.T == 4) return launch<4, 4>(P, grad, energy, g.nblocks, st);
+  if (g.T == 16) return launch<16, 4>(P, grad, energy, g.nblocks, st);
+  if (g.EPL == 4) return launch<64, 4>(P, grad, energy, g.nblocks, st);
+  return launch<64, 16>(P, grad, energy, g.nblocks, st);
+}

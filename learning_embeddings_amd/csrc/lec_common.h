@@ -1,0 +1,143 @@
+// Shared host/device helpers for liblecone.so (gfx950 only: 64-wide wavefronts are assumed everywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/lecone.h"
+
+namespace lec {
+
+void set_error(const char* fmt, ...);                      // abi.cpp (thread-local message for lec_last_error)
+int hip_fail(hipError_t e, const char* what);               // records + returns LEC_E_HIP
+
+#define LEC_CHECK_ARG(cond, ...)                                                                   \
+  do { if (!(cond)) { ::lec::set_error(__VA_ARGS__); return LEC_E_ARG; } } while (0)
+#define LEC_CHECK_LAUNCH(name)                                                                     \
+  do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return ::lec::hip_fail(e__, name); } while (0)
+
+// reference constants (oe_h.py:59,66,75,79,83,826-827)
+__host__ __device__ inline float inner_radius_f(float K) {
+  double k = (double)K;                                     // the reference evaluates this in python float64
+  return (float)(2.0 * k / (1.0 + sqrt(1.0 + 4.0 * k * k)));
+}
+inline float inner_radius_h_f(float K) {                    // Embedder.arctanh on the float32 radius (oe_h.py:106-110)
+  float x = inner_radius_f(K);
+  const float lo = (float)(-1.0 + 1e-5), hi = (float)(1.0 - 1e-5);
+  x = x < lo ? lo : (x > hi ? hi : x);
+  return 0.5f * (logf(1.0f + x) - logf(1.0f - x));
+}
+
+#if defined(__HIPCC__)
+constexpr int kWave = 64;
+
+// all-reduce (sum) inside aligned groups of T lanes; every lane ends with the bit-identical total
+template <int T>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int m = T >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+  return v;
+}
+template <int T>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int m = T >> 1; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, kWave));
+  return v;
+}
+
+__device__ __forceinline__ float clampf_nanprop(float a, float lo, float hi) {   // torch.clamp keeps NaN
+  return a < lo ? lo : (a > hi ? hi : a);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Hyperbolic entailment-cone energy from the four row statistics (oe_h.py:817-833), float32 in the reference's
+// operation order, plus the coefficients of its gradient:
+//     dE/dx = cxx * x + cxy * y ,   dE/dy = cxy * x + cyy * y
+// (E depends on x, y only through |x|, |y|, |x-y| and <x,y>; autograd's chain through those four collapses to this.)
+// ---------------------------------------------------------------------------------------------------------
+struct ConeEval { float E, cxx, cxy, cyy; };
+
+template <bool GRAD>
+__device__ __forceinline__ ConeEval cone_eval(float xx, float yy, float s, float dd, float K) {
+  const float lo = (float)(-1.0 + 1e-5), hi = (float)(1.0 - 1e-5);
+  float xn = sqrtf(xx), yn = sqrtf(yy), dist = sqrtf(dd);
+  float xn2 = xn * xn, yn2 = yn * yn;
+  float num = s * (1.0f + xn2) - xn2 * (1.0f + yn2);
+  float xy = xn * yn;
+  float rad = 1.0f + xy * xy - 2.0f * s;
+  float sq = sqrtf(rad);
+  float den = xn * dist * sq;
+  float a = num / den;                                                            // oe_h.py:823
+  float pa = K * (1.0f - xn2) / xn;
+  float ac = clampf_nanprop(a, lo, hi), pc = clampf_nanprop(pa, lo, hi);
+  float diff = acosf(ac) - asinf(pc);                                             // :826-827
+  ConeEval r;
+  r.E = diff < 0.0f ? 0.0f : diff;                                                // :833 (NaN stays NaN)
+  r.cxx = r.cxy = r.cyy = 0.0f;
+  if (GRAD) {
+    bool live = diff >= 0.0f;
+    bool a_in = live && (a >= lo) && (a <= hi);
+    bool p_in = live && (pa >= lo) && (pa <= hi);
+    float g_s = 0.f, g_d = 0.f, g_xn = 0.f, g_yn = 0.f;
+    if (a_in) {
+      float dth = -1.0f / sqrtf(1.0f - ac * ac);
+      float a_rad = a / rad;
+      g_s = dth * ((1.0f + xn2) / den + a_rad);
+      g_d = dth * (-a / dist);
+      g_xn = dth * ((2.0f * xn * s - 2.0f * xn * (1.0f + yn2)) / den - a * (1.0f / xn) - a_rad * (xn * yn2));
+      g_yn = dth * (-2.0f * xn2 * yn / den - a_rad * (xn2 * yn));
+    }
+    if (p_in) {
+      float dps = 1.0f / sqrtf(1.0f - pc * pc);
+      g_xn += dps * (K * (1.0f + xn2) / xn2);                                     // -dpsi/dxn, dpa/dxn = -K(1+xn^2)/xn^2
+    }
+    if (a_in || p_in) {
+      float gd_over = a_in ? g_d / dist : 0.0f;
+      r.cxx = g_xn / xn + gd_over;
+      r.cxy = g_s - gd_over;
+      r.cyy = (a_in ? g_yn / yn : 0.0f) + gd_over;
+    }
+  }
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Deterministic scalar reduction across blocks (one launch): every block publishes one partial; the block whose
+// ticket is last sums all partials in a fixed order and writes `out`.  Agent-scope release/acquire hand-off
+// (per-CU L1s and per-XCD L2s are not coherent): publish = store -> vmcnt(0) -> release fence -> vmcnt(0) ->
+// relaxed agent ticket; last arriver = acquire fence -> vmcnt(0) -> barrier -> plain loads.
+// `counter` must be zero at launch (the host wrappers memset it on the stream before every launch).
+// Must be called by ALL threads of the block (contains __syncthreads).  blockDim.x multiple of 64, <= 1024.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_publish_and_finalize(float wave_value /*valid in lane 0 of each wave*/,
+                                                           float* partials, unsigned int* counter, float* out,
+                                                           float scale) {
+  __shared__ float s_wave[16];
+  __shared__ int s_last;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  if (lane == 0) s_wave[wave] = wave_value;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float acc = 0.0f;
+    for (int w = 0; w < nwave; ++w) acc += s_wave[w];
+    partials[blockIdx.x] = acc;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned int prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int last = (prev == gridDim.x - 1) ? 1 : 0;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (s_last && wave == 0) {
+    float acc = 0.0f;
+    for (unsigned int i = lane; i < gridDim.x; i += 64) acc += partials[i];       // fixed order per lane
+    acc = group_sum<64>(acc);                                                      // fixed butterfly
+    if (lane == 0) out[0] = acc * scale;
+  }
+}
+#endif  // __HIPCC__
+
+}  // namespace lec

@@ -1,0 +1,259 @@
+"""Tensor-level wrappers + autograd Functions over the C ABI (include/lecone.h).  PyTorch is plumbing here: device
+memory, the current HIP stream and autograd bookkeeping.  All arithmetic happens in liblecone.so on the MI355X."""
+import ctypes as C
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check, dptr, stream_ptr
+
+ENERGY = {'hyp_cone': _lib.ENERGY_HYP_CONE, 'order': _lib.ENERGY_ORDER}
+
+_workspaces = {}
+
+
+def _workspace(device, nbytes):
+    key = (device.type, device.index)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _rows(t, name):
+    if t.dtype != torch.float32:
+        raise TypeError('%s must be float32, got %s' % (name, t.dtype))
+    if t.dim() != 2:
+        raise ValueError('%s must be 2-D [rows, D]' % name)
+    if t.stride(1) != 1 and t.shape[1] > 1:
+        t = t.contiguous()
+    return t
+
+
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+
+
+# ------------------------------------------------------------------------------------------------ pair energies
+class PairEnergyFn(torch.autograd.Function):
+    """E_operator (oe_h.py:811-833 / order_embeddings.py:818-824) with its autograd."""
+
+    @staticmethod
+    def forward(ctx, x, y, K_cone, energy):
+        shp = x.shape
+        x2 = _rows(x.reshape(-1, shp[-1]), 'x'); y2 = _rows(y.reshape(-1, shp[-1]), 'y')
+        if x2.shape != y2.shape:
+            raise ValueError('x and y must have the same shape')
+        P, D = x2.shape
+        E = torch.empty(P, dtype=torch.float32, device=x.device)
+        check(lib.lec_pair_energy_fwd(energy, dptr(x2), _ld(x2), dptr(y2), _ld(y2), P, D, float(K_cone), dptr(E), stream_ptr()))
+        ctx.save_for_backward(x2, y2)
+        ctx.meta = (float(K_cone), energy, shp)
+        return E.view(shp[:-1])
+
+    @staticmethod
+    def backward(ctx, gE):
+        x2, y2 = ctx.saved_tensors
+        K_cone, energy, shp = ctx.meta
+        P, D = x2.shape
+        g = gE.reshape(-1).contiguous().float()
+        gx = torch.empty(P, D, dtype=torch.float32, device=x2.device); gy = torch.empty_like(gx)
+        check(lib.lec_pair_energy_bwd(energy, dptr(x2), _ld(x2), dptr(y2), _ld(y2), dptr(g), P, D, K_cone, dptr(gx), dptr(gy), D, stream_ptr()))
+        return gx.view(shp), gy.view(shp), None, None
+
+
+def pair_energy(x, y, K_cone=0.1, energy='hyp_cone'):
+    return PairEnergyFn.apply(x, y, 0.0 if K_cone is None else K_cone, ENERGY[energy])
+
+
+def energy_matrix(apex, points, K_cone=0.1, energy='hyp_cone'):
+    """E[i, j] = E(apex_j, points_i): every image against every label (oe_h.py:2018-2036 done in one launch)."""
+    a = _rows(apex, 'apex'); p = _rows(points, 'points')
+    N, D = a.shape; M = p.shape[0]
+    E = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    check(lib.lec_pair_energy_matrix(ENERGY[energy], dptr(a), _ld(a), N, dptr(p), _ld(p), M, D, float(K_cone or 0.0), dptr(E), N, stream_ptr()))
+    return E
+
+
+# ------------------------------------------------------------------------------------------------ projections
+class LabelProjectFn(torch.autograd.Function):
+    """Embedder.forward (oe_h.py:77-104): gather + exp-map style tanh projection + straight-through clip."""
+
+    @staticmethod
+    def forward(ctx, weight, idx, K_cone):
+        w = _rows(weight, 'weight')
+        idx = idx.reshape(-1).to(torch.int64).contiguous()
+        n, D = idx.numel(), w.shape[1]
+        out = torch.empty(n, D, dtype=torch.float32, device=w.device)
+        check(lib.lec_label_project_fwd(dptr(w), _ld(w), w.shape[0], dptr(idx), n, D, float(K_cone), dptr(out), D, stream_ptr()))
+        ctx.save_for_backward(w, idx); ctx.K = float(K_cone)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        w, idx = ctx.saved_tensors
+        g = gout.contiguous().float()
+        gW = torch.zeros(w.shape, dtype=torch.float32, device=w.device)        # dense (sparse=False semantics)
+        check(lib.lec_label_project_bwd(dptr(w), _ld(w), w.shape[0], dptr(idx), idx.numel(), w.shape[1], ctx.K, dptr(g), g.shape[1], dptr(gW), stream_ptr()))
+        return gW, None, None
+
+
+class ImageSoftClipFn(torch.autograd.Function):
+    """FeatCNN18.soft_clip (oe_h.py:323-328)."""
+
+    @staticmethod
+    def forward(ctx, raw, K_cone):
+        shp = raw.shape
+        r = _rows(raw.reshape(-1, shp[-1]).float(), 'raw')
+        n, D = r.shape
+        out = torch.empty(n, D, dtype=torch.float32, device=r.device)
+        check(lib.lec_image_softclip_fwd(dptr(r), _ld(r), n, D, float(K_cone), dptr(out), D, stream_ptr()))
+        ctx.save_for_backward(r); ctx.meta = (float(K_cone), shp, raw.dtype)
+        return out.view(shp)
+
+    @staticmethod
+    def backward(ctx, gout):
+        (r,) = ctx.saved_tensors
+        K_cone, shp, dt = ctx.meta
+        g = gout.reshape(r.shape).contiguous().float()
+        graw = torch.empty_like(r)
+        check(lib.lec_image_softclip_bwd(dptr(r), _ld(r), dptr(g), g.shape[1], r.shape[0], r.shape[1], K_cone, dptr(graw), r.shape[1], stream_ptr()))
+        return graw.view(shp).to(dt), None
+
+
+# ------------------------------------------------------------------------------------------------ fused joint loss
+def joint_loss_raw(table, feat, pos_from, pos_to, neg, weights, K_cone, alpha, energy, label_proj, image_proj,
+                   grad_table=None, grad_feat=None):
+    """One launch of lec_joint_loss_fwd_bwd.  table [N,D], feat [n_feat,D] (or None): contiguous float32; index tensors:
+    contiguous int32 device tensors of node codes (>= 0 label row, < 0 feature row -1-code).  Gradients are ADDED into
+    grad_table / grad_feat when given (same shapes, contiguous).  Returns (loss[1], e_pos[B], e_neg[B,2K])."""
+    def chk(t, name, like=None):
+        if t.dtype != torch.float32 or t.dim() != 2 or not t.is_contiguous():
+            raise ValueError('%s must be a contiguous 2-D float32 tensor' % name)
+        if like is not None and t.shape != like.shape:
+            raise ValueError('%s must have the shape of its parameter' % name)
+    chk(table, 'table')
+    N, D = table.shape
+    dev = table.device
+    n_feat = 0
+    if feat is not None and feat.numel():
+        chk(feat, 'feat'); n_feat = feat.shape[0]
+        if feat.shape[1] != D:
+            raise ValueError('feat rows must have the table\'s embedding_dim')
+    else:
+        feat = None
+    if grad_table is not None:
+        chk(grad_table, 'grad_table', table)
+        if feat is not None:
+            if grad_feat is None:
+                raise ValueError('grad_feat is required when grad_table is given and image rows exist')
+            chk(grad_feat, 'grad_feat', feat)
+    B = pos_from.numel(); K = (neg.shape[1] // 2) if (neg is not None and neg.numel()) else 0
+    for name, t in (('pos_from', pos_from), ('pos_to', pos_to), ('neg', neg)):
+        if t is not None and (t.dtype != torch.int32 or not t.is_contiguous()):
+            raise TypeError('%s must be a contiguous int32 tensor of node codes' % name)
+    if weights is not None and (weights.dtype != torch.float32 or weights.numel() != B or not weights.is_contiguous()):
+        raise ValueError('weights must be float32 [B]')
+    e_pos = torch.empty(B, dtype=torch.float32, device=dev)
+    e_neg = torch.empty(B, 2 * K, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    need = lib.lec_loss_workspace_bytes(B, K, D)
+    if need < 0:
+        check(int(need))
+    ws = _workspace(dev, need)
+    check(lib.lec_joint_loss_fwd_bwd(energy, label_proj, image_proj, dptr(table), D, N,
+                                     dptr(feat), D, n_feat, dptr(pos_from), dptr(pos_to), dptr(neg) if K else None,
+                                     dptr(weights), B, K, D, float(K_cone), float(alpha),
+                                     dptr(e_pos), dptr(e_neg) if K else None, dptr(loss),
+                                     dptr(grad_table), dptr(grad_feat) if feat is not None else dptr(grad_table),
+                                     dptr(ws), ws.numel(), stream_ptr()))
+    return loss, e_pos, e_neg
+
+
+class JointLossFn(torch.autograd.Function):
+    """criterion.forward's train branch after sampling (oe_h.py:929-967) + backward, one kernel.
+    The gradients are produced by the same launch as the forward and handed to autograd in backward()."""
+
+    @staticmethod
+    def forward(ctx, table, feat, pos_from, pos_to, neg, weights, K_cone, alpha, energy, label_proj, image_proj):
+        need_grad = table.requires_grad or (feat is not None and feat.requires_grad)
+        tb = table.detach().float().contiguous()
+        ft = feat.detach().float().contiguous() if (feat is not None and feat.numel()) else None
+        gt = gf = None
+        if need_grad:
+            gt = torch.zeros_like(tb)
+            gf = torch.zeros_like(ft) if ft is not None else None
+        loss, e_pos, e_neg = joint_loss_raw(tb, ft, pos_from, pos_to, neg, weights, K_cone, alpha, energy, label_proj,
+                                            image_proj, gt, gf)
+        ctx.grads = (gt, gf)
+        ctx.dts = (table.dtype, feat.dtype if feat is not None else None)
+        ctx.mark_non_differentiable(e_pos, e_neg)
+        return loss.view(()), e_pos, e_neg
+
+    @staticmethod
+    def backward(ctx, gl, _gp, _gn):
+        gt, gf = ctx.grads
+        if gt is None:
+            return (None,) * 11
+        gt = (gt * gl).to(ctx.dts[0])
+        if gf is not None:
+            gf = (gf * gl).to(ctx.dts[1])
+        return gt, gf, None, None, None, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ table / optimiser steps
+def table_step_adam(table, grad, exp_avg, exp_avg_sq, step, lr, K_cone=0.1, betas=(0.9, 0.999), eps=1e-8,
+                    riemannian=True, clip=True):
+    """oe_h.py:1768-1771 in one pass: grad *= (1/lambda_x)^2 -> Adam -> clip into [r_in, 1-1e-5].  In place."""
+    for t in (table, grad, exp_avg, exp_avg_sq):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != table.shape:
+            raise ValueError('table_step_adam: all buffers must be contiguous float32 of the table\'s shape')
+    N, D = table.shape
+    check(lib.lec_table_step_adam(dptr(table), dptr(grad), dptr(exp_avg), dptr(exp_avg_sq), D, N, D, float(lr),
+                                  float(betas[0]), float(betas[1]), float(eps), int(step), float(K_cone or 0.0),
+                                  int(bool(riemannian)), int(bool(clip)), stream_ptr()))
+
+
+def table_step_rsgd(table, grad, lr, K_cone=0.1):
+    """oe_h.py:1761-1762 / order_embeddings_h.py:764-775: exp_map_x(w, -lr * (1/lambda_x)^2 grad) then clip.  In place."""
+    N, D = table.shape
+    if not (table.is_contiguous() and grad.is_contiguous() and table.dtype == grad.dtype == torch.float32):
+        raise ValueError('table_step_rsgd: contiguous float32 buffers required')
+    check(lib.lec_table_step_rsgd(dptr(table), dptr(grad), D, N, D, float(lr), float(K_cone), stream_ptr()))
+
+
+def adam_flat(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+    """torch.optim.Adam arithmetic over one flat fp32 arena, one launch."""
+    n = param.numel()
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+            raise ValueError('adam_flat: contiguous float32 buffers of equal length required')
+    check(lib.lec_adam_flat(dptr(param), dptr(grad), dptr(exp_avg), dptr(exp_avg_sq), n, float(lr), float(betas[0]),
+                            float(betas[1]), float(eps), int(step), float(grad_scale), stream_ptr()))
+
+
+# ------------------------------------------------------------------------------------------------ multi-level CE
+class MultiLevelCEFn(torch.autograd.Function):
+    """MultiLevelCELoss.forward (network/loss.py:29-38) + backward in one launch."""
+
+    @staticmethod
+    def forward(ctx, logits, level_labels, levels, level_weights):
+        z = _rows(logits.float(), 'logits')
+        B, Cc = z.shape
+        lab = level_labels.to(torch.int64).contiguous()
+        L = len(levels)
+        sizes = (C.c_int32 * L)(*[int(v) for v in levels])
+        wts = (C.c_float * L)(*[float(v) for v in level_weights]) if level_weights is not None else None
+        loss = torch.empty(1, dtype=torch.float32, device=z.device)
+        g = torch.empty(B, Cc, dtype=torch.float32, device=z.device) if logits.requires_grad else None
+        ws = _workspace(z.device, 256 + 4 * 2048)
+        check(lib.lec_multilevel_ce_fwd_bwd(dptr(z), _ld(z), dptr(lab), B, Cc, C.cast(sizes, C.c_void_p),
+                                            C.cast(wts, C.c_void_p) if wts is not None else None, L, dptr(loss),
+                                            dptr(g), dptr(ws), ws.numel(), stream_ptr()))
+        ctx.g = g; ctx.dt = logits.dtype
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        return (ctx.g * gl).to(ctx.dt), None, None, None

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the fused joint-loss kernel and the table step (HIP events on the launch stream).
+Algorithmic bytes per positive (fwd+bwd): (2+2K)(2*D*4 + 4*D + 4) + (1+2K)*8."""
+import argparse, json, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from learning_embeddings_amd import ops, _lib
+
+
+def alg_bytes(B, K, D):
+    return B * ((2 + 2 * K) * (2 * D * 4 + 4 * D + 4) + (1 + 2 * K) * 8)
+
+
+def time_joint(B, K, D, N, M, iters=50, grad=True):
+    dev = 'cuda'
+    g = torch.Generator(device='cpu').manual_seed(0)
+    W = torch.randn(N, D, generator=g); W = (W / W.norm(dim=1, keepdim=True) * (0.1 + 0.05 * torch.rand(N, 1, generator=g))).to(dev)
+    R = (torch.randn(M, D, generator=g) * 0.3).to(dev)
+    frm = torch.randint(0, N, (B,), generator=g, dtype=torch.int32).to(dev)
+    to = (-1 - torch.randint(0, M, (B,), generator=g, dtype=torch.int32)).to(dev)
+    neg = torch.randint(0, N, (B, 2 * K), generator=g, dtype=torch.int32).to(dev)
+    gt = torch.zeros_like(W) if grad else None; gf = torch.zeros_like(R) if grad else None
+    for _ in range(5):
+        ops.joint_loss_raw(W, R, frm, to, neg, None, 0.1, 0.01, 0, 1, 1, gt, gf)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record(); ops.joint_loss_raw(W, R, frm, to, neg, None, 0.1, 0.01, 0, 1, 1, gt, gf); b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) * 1e-3 for a, b in evs)
+    t = ts[len(ts) // 2]
+    return {'B': B, 'K': K, 'D': D, 'N': N, 'pairs': B * (1 + 2 * K), 'us': t * 1e6, 'alg_MB': alg_bytes(B, K, D) / 1e6,
+            'GBps': alg_bytes(B, K, D) / t / 1e9, 'Mpairs_s': B * (1 + 2 * K) / t / 1e6}
+
+
+def time_table(N, D, iters=50):
+    dev = 'cuda'
+    W = torch.randn(N, D, device=dev) * 0.05; g = torch.randn(N, D, device=dev); m = torch.zeros_like(W); v = torch.zeros_like(W)
+    for _ in range(5):
+        ops.table_step_adam(W, g, m, v, 1, 1e-4, 0.1)
+    torch.cuda.synchronize()
+    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    for i in range(iters):
+        ops.table_step_adam(W, g, m, v, i + 1, 1e-4, 0.1)
+    b.record(); torch.cuda.synchronize()
+    t = a.elapsed_time(b) * 1e-3 / iters
+    return {'N': N, 'D': D, 'us': t * 1e6, 'GBps': 7 * N * D * 4 / t / 1e9}
+
+
+if __name__ == '__main__':
+    out = []
+    for B, K, D, N, M in ((128, 5, 10, 723, 128), (256, 5, 10, 2000, 256), (256, 256, 10, 50000, 256), (256, 256, 128, 50000, 256),
+                          (4096, 256, 10, 50000, 4096), (4096, 64, 128, 50000, 4096), (16384, 5, 10, 2000, 16384)):
+        r = time_joint(B, K, D, N, M); out.append(r); print(json.dumps(r))
+    for N, D in ((723, 10), (50000, 10), (50000, 128), (1000000, 128)):
+        r = time_table(N, D); print(json.dumps(r))
