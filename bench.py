@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the joint CNN + hyperbolic cone-loss training step on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2] [--dtype bf16|fp32]
+
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+(one process per GPU, RCCL).  A step = one pass of the hot path over one batch of B positives per GPU (weak scaling):
+sampler (host, bit-exact) + ResNet fwd/bwd + fused cone loss fwd/bwd + gradient all-reduce + table/CNN optimizer steps,
+inputs resident in HBM.  Rank 0 prints ONE JSON line.
+"""
+import argparse, json, os, sys, time
+
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def cone_alg_bytes(B, K, D):
+    """fwd+bwd algorithmic bytes per positive, rows de-duplicated inside a group, fp32."""
+    return B * ((2 + 2 * K) * (2 * D * 4 + 4 * D + 4) + (1 + 2 * K) * 8)
+
+
+def cpu_baseline(eng, budget_s=25.0):
+    """The pinned oracle (oracle/cone_oracle.py, kind "port") timed on this box's host cores, rank 0 only: the restated
+    loss path (dense-matrix sampler + numpy cone loss fwd/bwd + table step) at the full batch, plus torch-CPU ResNet
+    fwd+bwd on a bounded sample of images; images/sec = B / (t_loss + B_rows * t_cnn_per_image)."""
+    import numpy as np, torch
+    from oracle import cone_oracle as O
+    from learning_embeddings_amd.resnet import resnet18, resnet50
+    B, K, D, N = eng.B, eng.K, eng.D, eng.N
+    M = min(eng.M, 2048)                                       # dense (N+M)^2 bool matrix must stay small
+    lm = eng.labelmap
+    leaf = [lm.level_start[-1] + (j % lm.levels[-1]) for j in range(M)]
+    A = O.dense_negative_adjacency(N, sorted(lm.edges), leaf)
+    smp = O.DenseSampler(A, lm.levels, pick_per_level=True, seed=0)
+    W = eng.table.cpu().numpy().copy()
+    rs = np.random.RandomState(0)
+    R = (rs.randn(M, D) * 0.3).astype(np.float32)
+    frm, to = eng.positives(0)
+    frm = frm[:B]; to = N + ((to[:B] - N) % M)
+    t0 = time.time(); reps = 0
+    m = np.zeros_like(W); v = np.zeros_like(W)
+    while reps < 3 and time.time() - t0 < budget_s * 0.4:
+        neg = smp.draw_batch(frm, to, K)
+        loss, e_pos, e_neg, gW, gR = O.joint_loss_fwd_bwd(W, R, frm, to, neg, eng.alpha, eng.K_cone)
+        W2, m, v = O.table_step_adam(W, gW.astype(np.float32), m, v, reps + 1, eng.lr, eng.K_cone)
+        reps += 1
+    t_loss = (time.time() - t0) / max(reps, 1)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    net = (resnet50 if eng.arch == 'resnet50' else resnet18)(num_classes=D)
+    n_s = 8
+    x = torch.rand(n_s, 3, eng.hw, eng.hw)
+    t1 = time.time(); r2 = 0
+    while r2 < 2 and time.time() - t1 < budget_s * 0.6:
+        net.zero_grad(); net(x).sum().backward(); r2 += 1
+    t_cnn = (time.time() - t1) / max(r2, 1) / n_s
+    rows = eng.n_rows
+    ips = B / (t_loss + rows * t_cnn)
+    return {'value': round(ips, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': 'oracle loss path (dense sampler + numpy cone fwd/bwd + table step) x%d at B=%d K=%d; torch-CPU %s fwd+bwd on %d images x%d, scaled to the %d CNN rows of a step'
+                      % (reps, B, K, eng.arch, n_s, r2, rows),
+            'loss_path_s_per_step': round(t_loss, 4), 'cnn_s_per_image': round(t_cnn, 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='cfg3')
+    ap.add_argument('--dtype', default='bf16')
+    ap.add_argument('--batch', type=int, default=None)
+    ap.add_argument('--sampler', default='replicated', choices=['replicated', 'per_rank'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-stress', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from learning_embeddings_amd import ops, _lib, parallel
+    from learning_embeddings_amd.engine import StepEngine, WORKLOADS
+    from learning_embeddings_amd.resnet import conv_macs
+
+    rank, local_rank, world = parallel.init_process_group()
+    if world != args.gpus and rank == 0:
+        print('warning: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world), file=sys.stderr)
+    eng = StepEngine(args.workload, dtype=args.dtype, sampler_mode=args.sampler, batch=args.batch)
+    dev = eng.device
+
+    for _ in range(args.warmup):
+        eng.step()
+    eng.enable_timers()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    phases = eng.timer_summary()
+    loss_mean = float(eng.loss_acc.item()) / (args.steps + args.warmup)
+
+    if rank == 0:
+        B, K, D = eng.B, eng.K, eng.D
+        ips = world * B * args.steps / dt
+        # ---- roofline of the hand-written hot kernel (HBM-bound gather/scatter): algorithmic bytes / measured duration
+        cone_s = phases['cone_loss'] * 1e-3
+        ab = cone_alg_bytes(B, K, D)
+        roof_cone = {'kernel': 'joint_loss_kernel (fused cone loss fwd+bwd)', 'bound': 'hbm',
+                     'achieved': round(ab / cone_s / 1e9, 3), 'peak': 8000.0, 'unit': 'GB/s',
+                     'frac': round(ab / cone_s / 8e12, 6), 'traffic': None, 'alg_bytes_per_launch': ab,
+                     'avg_launch_us': round(cone_s * 1e6, 2),
+                     'note': 'at the north-star size (B=%d, K=%d, D=%d: %.2f MB per launch) the launch is latency-bound, not HBM-bound; see roofline_stress' % (B, K, D, ab / 1e6)}
+        # ---- the step's dominant component: ResNet fwd+bwd (MFMA-bound), analytic flops / measured fwd+bwd time
+        macs = conv_macs(eng.img_feat_net.model, eng.hw)
+        flops = 3 * 2 * macs * eng.n_rows
+        cnn_s = (phases['cnn_fwd'] + phases['cnn_bwd']) * 1e-3
+        peak_tf = 2500.0 if args.dtype in ('bf16', 'fp16') else 157.3
+        roof_cnn = {'kernel': '%s conv stack fwd+bwd (MIOpen/hipBLASLt via PyTorch)' % eng.arch, 'bound': 'mfma',
+                    'achieved': round(flops / cnn_s / 1e12, 3), 'peak': peak_tf, 'unit': 'TFLOP/s',
+                    'frac': round(flops / cnn_s / 1e12 / peak_tf, 5), 'traffic': None,
+                    'gflop_per_image_fwd_bwd': round(6 * macs / 1e9, 3), 'cnn_rows_per_step': eng.n_rows}
+        out = {'metric': 'images/sec (joint CNN+cone-loss step)', 'value': round(ips, 2), 'unit': 'images/sec',
+               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+               'config': {'workload': '%s: %s hierarchy (%d labels, %d levels) + %d synthetic images, %s, hyperbolic cone loss, B=%d positives/GPU, K=%d, D=%d, %dx%d'
+                                      % (args.workload, WORKLOADS[args.workload][0], eng.N, eng.L, eng.M, eng.arch, B, K, D, eng.hw, eng.hw),
+                          'global_batch': B * world, 'cnn_rows_per_step_per_gpu': eng.n_rows, 'cone_loss_dtype': 'f32',
+                          'parallelism': 'dp%d' % world, 'sampler': args.sampler, 'mean_loss': round(loss_mean, 4)},
+               'phases_ms': {k: round(v, 3) for k, v in phases.items()},
+               'roofline': roof_cone, 'roofline_cnn': roof_cnn}
+        if not args.no_stress:
+            # the same kernel where it IS bandwidth-bound: config 5's label-embedding stress shape (K=256) and a D=128 table
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            import bench_cone
+            st = {}
+            for tag, (b_, k_, d_, n_) in {'cfg5_K256_D10': (256, 256, 10, 50000), 'K256_D128': (256, 256, 128, 50000),
+                                          'B4096_K256_D10': (4096, 256, 10, 50000)}.items():
+                r = bench_cone.time_joint(b_, k_, d_, n_, b_, iters=30)
+                st[tag] = {'achieved': round(r['GBps'], 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(r['GBps'] / 8000.0, 4),
+                           'avg_launch_us': round(r['us'], 1), 'pairs': r['pairs'], 'alg_MB': round(r['alg_MB'], 2)}
+            out['roofline_stress'] = st
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(eng)
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -80,7 +80,8 @@ int lec_pair_energy_matrix(int energy, const float* x, int64_t ldx, int64_t N, c
  *     grad_table [n_labels, D] (ld_table), grad_feat [n_feat, D] (ld_feat): d loss / d table, d loss / d feat are
  *       ADDED into these buffers (float atomics) -- zero them first for a plain gradient.  Pass NULL for both to run
  *       forward only.
- *     workspace: >= lec_loss_workspace_bytes(B, K, D) bytes of device memory, caller-owned, reused across calls.
+ *     workspace: >= lec_loss_workspace_bytes(B, K, D) bytes of device memory, caller-owned, ZEROED ONCE by the caller
+ *       when allocated and then reused across calls; launches sharing a workspace must be stream-ordered.
  * ------------------------------------------------------------------------------------------------------------- */
 int lec_joint_loss_fwd_bwd(int energy, int label_proj, int image_proj,
                            const float* table, int64_t ld_table, int n_labels,
@@ -160,6 +161,7 @@ int64_t lec_sampler_tc_edges(const lec_sampler* s);                      /* |TC|
  *     (network/loss.py:29-38) and its autograd:  loss = mean_b sum_l w_l CE(logits[b, s_l:e_l], labels[b, l]).
  *     logits [B, C] (ld), level_labels [B, L] int64, level_sizes [L] (sum = C), level_weights [L] or NULL.
  *     glogits [B, C] (ld) is overwritten with d loss / d logits (pass NULL for forward only).
+ *     level_sizes / level_weights are HOST arrays (L <= 16); workspace: >= 256 + 4*2048 bytes, zeroed once (as above).
  * ------------------------------------------------------------------------------------------------------------- */
 int lec_multilevel_ce_fwd_bwd(const float* logits, int64_t ld, const int64_t* level_labels, int B, int C,
                               const int32_t* level_sizes, const float* level_weights, int L,

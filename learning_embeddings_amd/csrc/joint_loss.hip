@@ -299,8 +299,6 @@ extern "C" int lec_joint_loss_fwd_bwd(int energy, int label_proj, int image_proj
   P.e_pos = e_pos; P.e_neg = e_neg; P.loss = loss; P.grad_table = grad_table; P.grad_feat = grad_feat;
   P.counter = (unsigned int*)workspace; P.partials = (float*)((char*)workspace + 256);
   P.iters = g.iters; P.tasks_per_group = g.tasks_per_group;
-  hipError_t e = hipMemsetAsync(workspace, 0, 256, st);
-  if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(workspace)");
   const bool grad = grad_table != nullptr;
   if (g.T == 1) return launch<1, 4>(P, grad, energy, g.nblocks, st);
   if (g.T == 4) return launch<4, 4>(P, grad, energy, g.nblocks, st);

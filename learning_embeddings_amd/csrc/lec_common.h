@@ -104,7 +104,8 @@ __device__ __forceinline__ ConeEval cone_eval(float xx, float yy, float s, float
 // ticket is last sums all partials in a fixed order and writes `out`.  Agent-scope release/acquire hand-off
 // (per-CU L1s and per-XCD L2s are not coherent): publish = store -> vmcnt(0) -> release fence -> vmcnt(0) ->
 // relaxed agent ticket; last arriver = acquire fence -> vmcnt(0) -> barrier -> plain loads.
-// `counter` must be zero at launch (the host wrappers memset it on the stream before every launch).
+// `counter` must be zero at launch: the workspace is zeroed once when it is allocated and the last arriver re-arms
+// it, so launches that share a workspace must be stream-ordered (one in flight at a time).
 // Must be called by ALL threads of the block (contains __syncthreads).  blockDim.x multiple of 64, <= 1024.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void block_publish_and_finalize(float wave_value /*valid in lane 0 of each wave*/,
@@ -135,7 +136,10 @@ __device__ __forceinline__ void block_publish_and_finalize(float wave_value /*va
     float acc = 0.0f;
     for (unsigned int i = lane; i < gridDim.x; i += 64) acc += partials[i];       // fixed order per lane
     acc = group_sum<64>(acc);                                                      // fixed butterfly
-    if (lane == 0) out[0] = acc * scale;
+    if (lane == 0) {
+      out[0] = acc * scale;
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next (stream-ordered) launch
+    }
   }
 }
 #endif  // __HIPCC__

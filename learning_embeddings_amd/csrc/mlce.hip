@@ -64,8 +64,6 @@ extern "C" int lec_multilevel_ce_fwd_bwd(const float* logits, int64_t ld, const 
   const int64_t need = 256 + (int64_t)nblocks * sizeof(float);
   LEC_CHECK_ARG(workspace && workspace_bytes >= need, "multilevel_ce: workspace needs %lld bytes", (long long)need);
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(workspace, 0, 256, st);
-  if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(workspace)");
   hipLaunchKernelGGL(mlce_kernel, dim3(nblocks), dim3(256), 0, st, logits, ld, level_labels, B, lt, glogits,
                      (float*)((char*)workspace + 256), (unsigned int*)workspace, loss);
   LEC_CHECK_LAUNCH("mlce_kernel");

@@ -1,0 +1,177 @@
+"""StepEngine: the joint training step on synthetic inputs, shaped for MI355X (used by bench.py, smoke() and tests).
+
+One step = oe_h.py:1734-1774 for one batch of B (label, image) positives per GPU:
+
+    host   : negatives of step s+1 drawn on a thread (bit-exact MT19937 stream) while the GPU runs step s
+    stream : images[B,3,H,W] -> ResNet fwd (NHWC, bf16 autocast, fp32 master weights) -> raw feats [B,D] fp32
+             -> ONE fused kernel (projections + (1+2K)B cone energies + hinge + loss + d/d table + d/d feats)
+             -> ResNet bwd  -> bucketed SUM all-reduce (RCCL, overlapped with bwd; table gradient rides along)
+             -> ONE table-step kernel (lambda-rescale + Adam + clip) + ONE flat-arena Adam kernel
+    no host<->device synchronisation anywhere in the step.
+
+Workloads: hierarchy S3 = [8,64,384,1544] (or the real ETHEC DAG), image j hangs under leaf j mod n_leaf,
+positive b of a step pairs image (step*B_global + b) mod M with its ancestor at level b mod L.
+"""
+import numpy as np
+import torch
+
+from . import _lib, ops, parallel
+from .hierarchy import NegativeGraph, SyntheticLabelMap, SYNTHETIC
+from .oe_h import Embedder, FeatCNN18, FeatCNN, EuclideanConesWithImagesHypernymLoss
+
+WORKLOADS = {
+    # name: (hierarchy, arch, per-GPU batch, K negatives ratio, D, image hw)
+    'cfg2': ('ETHEC', 'resnet18', 128, 5, 10, 224),     # BASELINE.json configs[1]
+    'cfg3': ('S3', 'resnet50', 256, 5, 10, 224),        # configs[2]: the config the headline metric is quoted on
+    'cfg5': ('S5', 'resnet50', 256, 256, 10, 224),      # configs[4]: 50k-node hierarchy, 256 negatives / positive
+    'tiny': ('S1x', 'resnet18', 8, 4, 10, 32),          # smoke / tests
+}
+
+
+def make_labelmap(name):
+    if name == 'ETHEC':
+        return SyntheticLabelMap.ethec()
+    if name == 'S1x':
+        return SyntheticLabelMap([2, 4, 8])
+    return SyntheticLabelMap(SYNTHETIC[name])
+
+
+class StepEngine:
+    def __init__(self, workload='cfg3', n_images=4096, pool_images=None, dtype='bf16', lr=1e-4, alpha=0.01, K_cone=0.1,
+                 sampler_mode='replicated', seed=0, batch=None, device=None):
+        hier, arch, B, K, D, hw = WORKLOADS[workload]
+        self.workload, self.arch, self.B, self.K, self.D, self.hw = workload, arch, batch or B, K, D, hw
+        self.rank, self.local_rank, self.world = parallel.init_process_group()
+        self.device = device or torch.device('cuda', self.local_rank if torch.cuda.device_count() > 1 else 0)
+        torch.cuda.set_device(self.device)
+        self.lr, self.alpha, self.K_cone = lr, alpha, K_cone
+        self.compute_dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[dtype]
+        self.labelmap = lm = make_labelmap(hier)
+        self.N, self.L = lm.n_classes, len(lm.levels)
+        self.M = n_images
+        self.graph = NegativeGraph.from_labelmap(lm, n_images=n_images, pick_per_level=True, seed=seed + (0 if sampler_mode == 'replicated' else self.rank))
+        # ancestors of every leaf per level (for the positives)
+        par = lm.parents()
+        leaf0, nleaf = lm.level_start[-1], lm.levels[-1]
+        self.leaf_anc = np.zeros((nleaf, self.L), dtype=np.int32)
+        for i in range(nleaf):
+            v = leaf0 + i; chain = [v]
+            while v in par:
+                v = par[v][0]; chain.append(v)
+            if len(chain) != self.L:
+                raise ValueError('leaf %d does not have one ancestor per level' % (leaf0 + i))
+            self.leaf_anc[i] = np.array(chain[::-1], dtype=np.int32)
+        # With pick_per_level the `u`-fixed draw of pass p lands in slot p % (L+1); slot L with a label `u` draws an IMAGE
+        # (oe_h.py:893-898), so every positive brings `cnt` extra images through the CNN each step.
+        self.img_passes = [p for p in range(K) if p % (self.L + 1) == self.L]
+        self.cnt = len(self.img_passes)
+        self.n_rows = self.B * (1 + self.cnt)                            # CNN batch per step (fixed shape)
+        torch.manual_seed(0)                                              # oe_h.py:1338: table init from seed 0
+        self.criterion = EuclideanConesWithImagesHypernymLoss(lm, K, {}, alpha, pick_per_level=True, K=K_cone, use_CNN=True)
+        self.model = Embedder(D, lm, None, K=K_cone).to(self.device)
+        cls = FeatCNN if arch == 'resnet50' else FeatCNN18
+        self.img_feat_net = cls(image_dir='', output_dim=D, K=K_cone, compute_dtype=self.compute_dtype).to(self.device)
+        self.img_feat_net.train(); self.model.train()
+        self.arena = parallel.FlatArena(self.img_feat_net.parameters(), self.device)
+        w = self.model.embeddings.weight
+        self.table = w.data
+        self.table_grad = torch.zeros_like(self.table)
+        self.table_m = torch.zeros_like(self.table); self.table_v = torch.zeros_like(self.table); self.table_step = 0
+        self.reducer = parallel.GradientReducer(self.arena, extra=[self.table_grad])
+        if self.world > 1:
+            torch.distributed.broadcast(self.arena.data, 0); torch.distributed.broadcast(self.table, 0)
+        # synthetic image pool resident in HBM: torch.rand in [0,1) like ToTensor output (oe_h.py:1463-1471), seed 0
+        P = pool_images or min(n_images, 2 * self.B)
+        g = torch.Generator(device='cpu').manual_seed(1234 + self.rank)
+        pool = torch.rand(P, 3, hw, hw, generator=g)
+        self.pool = pool.to(self.device).contiguous(memory_format=torch.channels_last)
+        self.P = P
+        self.gfeat = torch.zeros(self.n_rows, D, device=self.device)
+        self.pin = [torch.empty((self.B, 2 + 2 * K), dtype=torch.int32).pin_memory() for _ in range(2)]
+        self.pin_img = [torch.empty(self.n_rows, dtype=torch.int64).pin_memory() for _ in range(2)]
+        self.pin_ev = [None, None]
+        self.step_no = 0
+        self.loss_acc = torch.zeros((), device=self.device)
+        self.prefetch = parallel.NegativePrefetcher(self.graph, self.positives, K, mode=sampler_mode)
+        self.timers = None
+
+    # global positives of step s: image (s*Bg + b) mod M with its ancestor at level b mod L   
+    def positives(self, s):
+        Bg = self.B * self.world
+        b = np.arange(Bg, dtype=np.int64)
+        j = (s * Bg + b) % self.M
+        leaf = j % self.labelmap.levels[-1]
+        frm = self.leaf_anc[leaf, b % self.L].astype(np.int32)
+        to = (self.N + j).astype(np.int32)
+        return frm, to
+
+    def enable_timers(self):
+        mk = lambda: torch.cuda.Event(enable_timing=True)
+        self.timers = {'records': [], 'mk': mk}
+
+    def step(self):
+        B, K = self.B, self.K
+        frm, to, neg = self.prefetch.next()
+        slot = self.step_no & 1
+        if self.pin_ev[slot] is not None:
+            self.pin_ev[slot].synchronize()          # the H2D copies of step s-2 have left this pinned buffer (also bounds run-ahead)
+        pin = self.pin[slot]
+        # CNN batch rows: [0, B) the positives' images; row B + b*cnt + i the image drawn as negative in pass img_passes[i]
+        hp = pin.numpy()
+        hp[:, 0] = frm
+        hp[:, 1] = -1 - np.arange(B, dtype=np.int32)
+        hp[:, 2:] = neg
+        rows = self.pin_img[self.step_no & 1].numpy()
+        rows[:B] = (to - self.N) % self.P
+        is_img = neg >= self.N
+        if self.cnt:
+            cols = np.asarray(self.img_passes)
+            sub = neg[:, cols]
+            if not (sub >= self.N).all() or int(is_img.sum()) != B * self.cnt:
+                raise RuntimeError('unexpected negative layout: image negatives outside the slot-L passes')
+            rows[B:] = ((sub - self.N) % self.P).reshape(-1)
+            hp[:, 2 + cols] = -1 - (B + np.arange(B, dtype=np.int32)[:, None] * self.cnt + np.arange(self.cnt, dtype=np.int32)[None, :])
+        elif is_img.any():
+            raise RuntimeError('unexpected image negative')
+        codes = pin.to(self.device, non_blocking=True)
+        pos_from = codes[:, 0].contiguous(); pos_to = codes[:, 1].contiguous(); negc = codes[:, 2:].contiguous()
+        idx = self.pin_img[self.step_no & 1].to(self.device, non_blocking=True)
+        self.pin_ev[slot] = torch.cuda.Event(); self.pin_ev[slot].record()
+        images = self.pool.index_select(0, idx)
+
+        T = self.timers
+        ev = [T['mk']() for _ in range(6)] if T is not None else None
+        self.arena.zero_grad(); self.table_grad.zero_(); self.gfeat.zero_()
+        if ev: ev[0].record()
+        feats = self.img_feat_net.forward_raw(images)
+        if ev: ev[1].record()
+        loss, e_pos, e_neg = ops.joint_loss_raw(self.table, feats.detach(), pos_from, pos_to, negc, None, self.K_cone,
+                                                self.alpha, _lib.ENERGY_HYP_CONE, _lib.LABEL_HYP, _lib.IMAGE_SOFTCLIP,
+                                                self.table_grad, self.gfeat)
+        if ev: ev[2].record()
+        feats.backward(self.gfeat)
+        if ev: ev[3].record()
+        self.reducer.finish()
+        if ev: ev[4].record()
+        self.table_step += 1
+        ops.table_step_adam(self.table, self.table_grad, self.table_m, self.table_v, self.table_step, self.lr, self.K_cone)
+        self.arena.adam_step(self.lr)
+        if ev:
+            ev[5].record(); T['records'].append(ev)
+        self.loss_acc += loss[0]
+        self.step_no += 1
+        self.last = (loss, e_pos, e_neg, frm, to, neg)
+        return loss
+
+    def timer_summary(self):
+        """Mean milliseconds per phase over the recorded steps (call after a synchronize)."""
+        names = ['cnn_fwd', 'cone_loss', 'cnn_bwd', 'allreduce_wait', 'optimizer']
+        out = {n: 0.0 for n in names}
+        recs = self.timers['records']
+        for ev in recs:
+            for i, n in enumerate(names):
+                out[n] += ev[i].elapsed_time(ev[i + 1])
+        return {n: v / max(len(recs), 1) for n, v in out.items()}
+
+    def close(self):
+        self.prefetch.close()

@@ -1,0 +1,398 @@
+"""Host-side mirror of the reference's joint image+label hyperbolic-cone trainer, `network/oe_h.py`.
+
+Same class names, constructor arguments, method names and error behaviour as the reference for the hot path
+(SURVEY.md 8b), so its call sites read unchanged; underneath, every tensor operation of the path is one of the HIP
+kernels in liblecone.so (ops.py) and negative sampling is the bit-exact C++ sampler (hierarchy.NegativeGraph).
+
+Naming trap kept on purpose: `EuclideanConesWithImagesHypernymLoss` IS the hyperbolic entailment-cone loss
+(oe_h.py:739; its E_operator :811-833 is the Poincare-ball cone angle).
+
+Deliberate deviations (all documented in DESIGN.md):
+  * one CNN forward per DISTINCT image per step (the reference re-embeds every positive image K more times in separate
+    BatchNorm batches, oe_h.py:980-985,1003-1009); parity is asserted at the embedding boundary;
+  * no host synchronisation inside the step (the reference syncs twice per step, oe_h.py:1752-1753,1774);
+  * the dense (N+M)^2 negative adjacency is accepted for drop-in use but converted to CSR lists once.
+"""
+import copy
+import os
+import random
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib, ops
+from .hierarchy import NegativeGraph
+from .resnet import resnet18, resnet50
+
+random.seed(0)                                                   # oe_h.py:42
+
+
+def inner_radius_of(K):
+    return 2 * K / (1 + np.sqrt(1 + 4 * K * K))                  # oe_h.py:59
+
+
+def _unwrap(model):
+    return model.module if hasattr(model, 'module') else model   # reference wraps in nn.DataParallel (oe_h.py:1434)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class Embedder(nn.Module):
+    """oe_h.py:51-110.  Label-embedding table + exp-map style projection into the ball, as one HIP kernel."""
+
+    def __init__(self, embedding_dim, labelmap, normalize, K=None):
+        super().__init__()
+        self.labelmap = labelmap
+        self.embedding_dim = embedding_dim
+        self.normalize = normalize
+        self.K = K
+        self.epsilon = 1e-5
+        if self.normalize == 'max_norm':
+            self.embeddings = nn.Embedding(self.labelmap.n_classes, self.embedding_dim, max_norm=1.0)
+        else:
+            self.embeddings = nn.Embedding(self.labelmap.n_classes, self.embedding_dim)
+        print('Embeds {} objects'.format(self.labelmap.n_classes))
+        if K:
+            self.inner_radius = inner_radius_of(self.K)
+            with torch.no_grad():                                # oe_h.py:68-73: rows renormed to r_in + U[0, 0.05)
+                w = self.embeddings.weight.data
+                norm = torch.norm(w, dim=1, keepdim=True).repeat(1, self.embedding_dim)
+                new_norm = self.inner_radius + torch.rand((w.shape[0])) * 0.05
+                new_norm = torch.unsqueeze(new_norm, 1).repeat(1, self.embedding_dim)
+                self.embeddings.weight.data = new_norm * w / norm
+            self.inner_radius_h = self.arctanh(torch.tensor(self.inner_radius))
+        else:
+            self.inner_radius = None
+
+    @property
+    def device(self):
+        return self.embeddings.weight.device
+
+    def forward(self, inputs):
+        w = self.embeddings.weight
+        if not self.K:
+            return F.embedding(inputs, w)
+        if self.normalize == 'unit_norm':
+            raise NotImplementedError("normalize='unit_norm' is outside the hot path (JointEmbeddings passes None, oe_h.py:1392)")
+        shp = inputs.shape
+        out = ops.LabelProjectFn.apply(w, inputs.reshape(-1), self.K)
+        return out.view(*shp, self.embedding_dim)
+
+    @staticmethod
+    def arctanh(x):
+        x = x.clamp(-1 + 1e-5, 1 - 1e-5)
+        return (torch.log(1 + x) - torch.log(1 - x)) * 0.5
+
+
+class _ImageNetBase(nn.Module):
+    """Shared by FeatCNN18 / FeatCNN: ResNet -> Linear(., D) -> soft_clip x/|x|*(|x| + r_in) (oe_h.py:313-328)."""
+
+    def _setup(self, K):
+        self.K = K
+        self.inner_radius = inner_radius_of(K) if K else None
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def forward_raw(self, x):
+        """CNN output BEFORE soft_clip, fp32 [n, D] -- the fused loss applies soft_clip itself."""
+        if self.channels_last and x.dim() == 4:
+            x = x.contiguous(memory_format=torch.channels_last)
+        if self.compute_dtype != torch.float32:
+            with torch.autocast('cuda', dtype=self.compute_dtype):
+                y = self.model(x)
+        else:
+            y = self.model(x)
+        return y.float()
+
+    def forward(self, x):
+        y = self.forward_raw(x)
+        return self.soft_clip(y) if self.K else y
+
+    def soft_clip(self, x):
+        return ops.ImageSoftClipFn.apply(x, self.K)
+
+
+class FeatCNN18(_ImageNetBase):
+    """oe_h.py:281-328: ResNet-18 with fc -> Linear(512, output_dim).  `pretrained` weights cannot be downloaded here
+    (no network): pass `weights=<state_dict or path>` to load a torchvision-format checkpoint, else default init."""
+
+    def __init__(self, image_dir, path_to_exp='../exp', input_dim=2048, output_dim=10,
+                 exp_name='ethec_resnet50_lr_1e-5_1_1_1_1/', K=None, weights=None, compute_dtype=torch.float32,
+                 channels_last=True, arch='resnet18'):
+        super().__init__()
+        self.path_to_exp = os.path.join(path_to_exp, exp_name)
+        self.image_dir = image_dir
+        self._setup(K)
+        self.compute_dtype = compute_dtype
+        self.channels_last = channels_last
+        self.arch = arch
+        self.model = None
+        self.load_model(weights)
+        self.model.fc = nn.Linear(self.model.fc.in_features, output_dim)       # oe_h.py:302
+        if channels_last:
+            self.model = self.model.to(memory_format=torch.channels_last)
+
+    def load_model(self, weights=None):
+        self.model = resnet18() if self.arch == 'resnet18' else resnet50()
+        if weights is not None:
+            sd = torch.load(weights, map_location='cpu') if isinstance(weights, str) else weights
+            sd = {k[len('module.'):] if k.startswith('module.') else k: v for k, v in sd.items()}
+            self.model.load_state_dict(sd)
+
+
+class FeatCNN(FeatCNN18):
+    """oe_h.py:331-378: the ResNet-50 wrapper (fc -> Linear(2048, output_dim)).  The reference builds it from a trained
+    classifier checkpoint through `Inference`; here the checkpoint is passed as `weights`."""
+
+    def __init__(self, image_dir, path_to_exp='../exp', input_dim=2048, output_dim=10,
+                 exp_name='ethec_resnet50_lr_1e-5_1_1_1_1/', K=None, weights=None, compute_dtype=torch.float32,
+                 channels_last=True):
+        super().__init__(image_dir, path_to_exp, input_dim, output_dim, exp_name, K, weights, compute_dtype,
+                         channels_last, arch='resnet50')
+
+
+class FeatNet(nn.Module):
+    """oe_h.py:113-224: Linear(input_dim, D) on precomputed image features followed by the same ball projection as the
+    label Embedder (used when --use_CNN is off).  The reference's lower-clip branch adds 1e-6 guards (:222); rows reach
+    it only at |x| = 0, where both forms give r_in * direction to 1e-5 relative."""
+
+    def __init__(self, normalize, input_dim=2048, output_dim=10, K=None):
+        super().__init__()
+        self.output_dim = output_dim
+        self.normalize = normalize
+        self.K = K
+        self.inner_radius = inner_radius_of(K) if K else None
+        self.fc1 = nn.Linear(input_dim, output_dim)
+        self.epsilon = 1e-5
+
+    def forward(self, x):
+        shp = x.shape
+        y = self.fc1(x).reshape(-1, self.output_dim).float()
+        if self.K and self.normalize is None:
+            idx = torch.arange(y.shape[0], device=y.device)
+            y = ops.LabelProjectFn.apply(y, idx, self.K)
+        elif self.normalize is not None:
+            raise NotImplementedError('FeatNet normalize modes are outside the hot path')
+        return y.view(*shp[:-1], self.output_dim)
+
+
+def my_collate(data):
+    """oe_h.py:435-444: keeps `from`/`to` as python lists (ints and image tensors mixed)."""
+    from_data, to_data, status_data, original_from, original_to = [], [], [], [], []
+    for data_item in data:
+        from_data.append(data_item['from']); to_data.append(data_item['to'])
+        status_data.append(data_item['status'])
+        original_from.append(data_item['original_from']); original_to.append(data_item['original_to'])
+    return {'from': from_data, 'to': to_data, 'status': torch.tensor(status_data), 'original_from': original_from,
+            'original_to': original_to}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class _JointCriterionBase(torch.nn.Module):
+    """Everything EuclideanConesWithImagesHypernymLoss and OrderEmbeddingWithImagesHypernymLoss share
+    (oe_h.py:739-1058 and :1061-1315 differ only in E_operator and the Embedder they are paired with)."""
+
+    energy = 'hyp_cone'
+
+    def _init_common(self, labelmap, neg_to_pos_ratio, feature_dict, alpha, pick_per_level, use_CNN):
+        torch.nn.Module.__init__(self)
+        self.labelmap = labelmap
+        self.neg_to_pos_ratio = neg_to_pos_ratio
+        self.alpha = alpha
+        self.device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+        self.mapping_from_node_to_ix = None
+        self.mapping_from_ix_to_node = None
+        self.negative_G = None
+        self.feature_dict = feature_dict
+        self.pick_per_level = pick_per_level
+        self.use_CNN = use_CNN
+        self.dataloader = None
+        self.levels_to_hide = []
+        self.n_labels = labelmap.n_classes
+
+    # ---- reference API ------------------------------------------------------------------------------------------
+    def set_levels_to_hide(self, list_of_levels):
+        self.levels_to_hide = list(list_of_levels)
+        if self.negative_G is not None:
+            self.negative_G.set_levels_to_hide(self.levels_to_hide)
+
+    def set_dataloader(self, dataloader):
+        self.dataloader = dataloader
+
+    def set_negative_graph(self, n_G, mapping_from_node_to_ix, mapping_from_ix_to_node):
+        """oe_h.py:799-809.  `n_G` is either the reference's dense bool matrix (1 = negative edge) or a
+        hierarchy.NegativeGraph.  The global `random` stream position is not touched; the sampler owns its own MT19937
+        (seed with `seed_sampler`, default 0 = the reference's `random.seed(0)` at oe_h.py:42,1472)."""
+        if isinstance(n_G, NegativeGraph):
+            self.negative_G = n_G
+        else:
+            self.negative_G = NegativeGraph.from_dense(np.asarray(n_G), self.labelmap.levels,
+                                                       pick_per_level=self.pick_per_level, seed=0)
+        if self.negative_G.pick_per_level != bool(self.pick_per_level):
+            raise ValueError('negative graph was built with pick_per_level=%s' % self.negative_G.pick_per_level)
+        self.mapping_from_node_to_ix = mapping_from_node_to_ix
+        self.mapping_from_ix_to_node = mapping_from_ix_to_node
+        if self.levels_to_hide:
+            self.negative_G.set_levels_to_hide(self.levels_to_hide)
+
+    def seed_sampler(self, seed=0):
+        self.negative_G.seed(seed)
+
+    def get_img_features(self, x):
+        """oe_h.py:770-797 (precomputed-feature path): list of names -> [1, n, F]; list of lists -> [m, n, F]."""
+        if len(x) and isinstance(x[0], str):
+            return torch.tensor(np.stack([np.asarray(self.feature_dict[n]) for n in x]), dtype=torch.float32).unsqueeze(0)
+        return torch.tensor(np.stack([np.stack([np.asarray(self.feature_dict[n]) for n in sub]) for sub in x]), dtype=torch.float32)
+
+    def positive_pair(self, x, y):
+        return self.E_operator(x, y)
+
+    def negative_pair(self, x, y):
+        e = self.E_operator(x, y)                                # the reference evaluates it twice (oe_h.py:839)
+        return torch.clamp(self.alpha - e, min=0.0), e
+
+    def get_image_label_loss(self, e_for_u_v_positive, e_for_u_v_negative, weights=None):
+        if weights is None:
+            return torch.sum(e_for_u_v_positive) + torch.sum(torch.clamp(self.alpha - e_for_u_v_negative, min=0.0))
+        weights = torch.as_tensor(weights, dtype=torch.float32, device=e_for_u_v_positive.device)
+        return torch.sum(weights * e_for_u_v_positive) + torch.sum(
+            weights * torch.sum(torch.clamp(self.alpha - e_for_u_v_negative, min=0.0), dim=1))
+
+    def sample_negative_edge(self, u=None, v=None, level_id=None):
+        """oe_h.py:849-902: returns the corrupted node's INDEX.  Raises IndexError on an empty candidate list like
+        `random.choice`; raises ValueError where the reference only prints (both/neither of u, v given)."""
+        if (u is None) == (v is None):
+            raise ValueError('Error! Both (u, v) given or neither (u, v) given!')
+        node = u if u is not None else v
+        return self.negative_G.draw(0 if u is not None else 1, self.mapping_from_node_to_ix[node],
+                                    0 if level_id is None else level_id)
+
+    # ---- the hot path -------------------------------------------------------------------------------------------
+    def _proj_flags(self, model):
+        m = _unwrap(model)
+        label_proj = _lib.LABEL_HYP if getattr(m, 'K', None) else _lib.LABEL_RAW
+        return label_proj
+
+    def forward(self, model, img_feat_net, inputs_from, inputs_to, original_from, original_to, status, phase):
+        if phase != 'train':
+            return self._forward_eval(model, img_feat_net, inputs_from, inputs_to)
+        n2i = self.mapping_from_node_to_ix
+        N = self.n_labels
+        B = len(original_from)
+        Kn = self.neg_to_pos_ratio
+        ix_from = np.fromiter((n2i[o] for o in original_from), dtype=np.int32, count=B)
+        ix_to = np.fromiter((n2i[o] for o in original_to), dtype=np.int32, count=B)
+        neg = self.negative_G.draw_batch(ix_from, ix_to, Kn)             # oe_h.py:940-957, bit-exact stream
+        self.last_negatives = neg
+        # one CNN forward over the DISTINCT images of the step: the batch's own tensors + images drawn as negatives
+        slot, stack = {}, []
+        for elem, ix in zip(list(inputs_from) + list(inputs_to), np.concatenate([ix_from, ix_to]).tolist()):
+            if ix >= N and ix not in slot:
+                if not torch.is_tensor(elem):
+                    elem = self.dataloader.get_image(self.mapping_from_ix_to_node[ix])
+                slot[ix] = len(stack); stack.append(elem)
+        for ix in np.unique(neg[neg >= N]).tolist():
+            if ix not in slot:
+                slot[ix] = len(stack); stack.append(self.dataloader.get_image(self.mapping_from_ix_to_node[ix]))
+        dev = _unwrap(model).embeddings.weight.device
+        feats, image_proj = None, _lib.IMAGE_RAW
+        if stack:
+            batch = torch.stack([s.to(dev, non_blocking=True) for s in stack])
+            if self.use_CNN and hasattr(img_feat_net, 'forward_raw') and getattr(img_feat_net, 'K', None):
+                feats = img_feat_net.forward_raw(batch); image_proj = _lib.IMAGE_SOFTCLIP
+            else:
+                feats = _unwrap(img_feat_net)(batch).reshape(len(stack), -1).float()
+
+        def codes(a):
+            a = np.asarray(a, dtype=np.int64)
+            if slot:
+                lut = np.full(int(max(slot)) - N + 1, -1, dtype=np.int64)
+                for ix, s in slot.items():
+                    lut[ix - N] = s
+                img = a >= N
+                out = a.copy()
+                out[img] = -1 - lut[a[img] - N]
+                a = out
+            return torch.from_numpy(a.astype(np.int32)).to(dev, non_blocking=True)
+
+        return self.forward_indices(model, feats, codes(ix_from), codes(ix_to), codes(neg), image_proj=image_proj)
+
+    def forward_indices(self, model, feats, pos_from, pos_to, neg, weights=None, image_proj=_lib.IMAGE_SOFTCLIP):
+        """The device part of the train step: node codes in, (loss, e_pos [B], e_neg [B,2K,1]) out, one kernel."""
+        w = _unwrap(model).embeddings.weight
+        Kc = getattr(self, 'K', None) or 0.0
+        loss, e_pos, e_neg = ops.JointLossFn.apply(w, feats, pos_from, pos_to, neg, weights, Kc, self.alpha,
+                                                   ops.ENERGY[self.energy], self._proj_flags(model),
+                                                   image_proj if feats is not None else _lib.IMAGE_RAW)
+        return loss, e_pos, e_neg.view(e_neg.shape[0], e_neg.shape[1], 1)
+
+    def _forward_eval(self, model, img_feat_net, inputs_from, inputs_to):
+        """oe_h.py:908-925: pre-built [B, 1+2K, D] embeddings (slot 0 positive, the rest negatives)."""
+        f, t = self.calculate_from_and_to_emb(model, img_feat_net, inputs_from, inputs_to)
+        e_pos = self.positive_pair(f[:, 0, :], t[:, 0, :])
+        _, e_neg = self.negative_pair(f[:, 1:, :], t[:, 1:, :])
+        loss = torch.sum(self.get_image_label_loss(e_pos, e_neg))
+        return loss, e_pos, e_neg
+
+    def calculate_from_and_to_emb(self, model, img_feat_net, from_elem, to_elem):
+        """oe_h.py:969-1058: embeds two parallel lists whose elements are label ints or images (tensors / names)."""
+        dev = _unwrap(model).embeddings.weight.device
+
+        def embed(elems):
+            if torch.is_tensor(elems):
+                return elems
+            lab_ix = [i for i, e in enumerate(elems) if isinstance(e, (int, np.integer))]
+            img_ix = [i for i, e in enumerate(elems) if not isinstance(e, (int, np.integer))]
+            out = None
+            if img_ix:
+                if self.use_CNN:
+                    imgs = [elems[i] if torch.is_tensor(elems[i]) else self.dataloader.get_image(elems[i]) for i in img_ix]
+                    img_emb = img_feat_net(torch.stack(imgs).to(dev))
+                else:
+                    img_emb = img_feat_net(self.get_img_features([elems[i] for i in img_ix]).to(dev)).reshape(len(img_ix), -1)
+                out = torch.zeros((len(elems), img_emb.shape[-1]), device=dev)
+                out[img_ix, :] = img_emb.float()
+            if lab_ix:
+                lab_emb = model(torch.tensor([int(elems[i]) for i in lab_ix], dtype=torch.long, device=dev))
+                if out is None:
+                    out = torch.zeros((len(elems), lab_emb.shape[-1]), device=dev)
+                out[lab_ix, :] = lab_emb
+            return out
+
+        return embed(from_elem), embed(to_elem)
+
+
+class EuclideanConesWithImagesHypernymLoss(_JointCriterionBase):
+    """oe_h.py:739-1058 -- the HYPERBOLIC entailment-cone criterion (see the naming trap above)."""
+    energy = 'hyp_cone'
+
+    def __init__(self, labelmap, neg_to_pos_ratio, feature_dict, alpha, pick_per_level=False, K=0.1, use_CNN=False):
+        print('Using Euclidean cones loss!')
+        self._init_common(labelmap, neg_to_pos_ratio, feature_dict, alpha, pick_per_level, use_CNN)
+        self.K = K
+        self.inner_radius = inner_radius_of(K)
+        self.epsilon = 1e-5
+
+    def E_operator(self, x, y):
+        return ops.pair_energy(x, y, self.K, 'hyp_cone')
+
+
+class OrderEmbeddingWithImagesHypernymLoss(_JointCriterionBase):
+    """oe_h.py:1061-1315 -- the joint criterion with the Euclidean order-violation energy."""
+    energy = 'order'
+
+    def __init__(self, labelmap, neg_to_pos_ratio, feature_dict, alpha, pick_per_level=False, use_CNN=False):
+        print('Using order-embedding loss!')
+        self._init_common(labelmap, neg_to_pos_ratio, feature_dict, alpha, pick_per_level, use_CNN)
+
+    @staticmethod
+    def E_operator(x, y):
+        return ops.pair_energy(x, y, None, 'order')
+
+
+from .oe_h_trainer import (DiGraph, transitive_closure, create_combined_graphs, ETHECHierarchyWithImages,  # noqa: E402,F401
+                           EmbeddingMetrics, GlobalBatchSampler, JointEmbeddings)

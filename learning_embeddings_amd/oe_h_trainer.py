@@ -1,0 +1,695 @@
+"""JointEmbeddings trainer + pair dataset + graph construction: host mirror of network/oe_h.py:447-736, 1318-2297.
+
+The trainer keeps the reference's constructor and method surface and runs the step MI355X-style:
+
+    images --CNN fwd (bf16/NHWC)--> raw feats --[ONE fused HIP kernel: projections, 1+2K cone energies per positive,
+    hinge, loss, d/d table, d/d feats]--> CNN bwd --(bucketed RCCL SUM all-reduce, overlapped)--> ONE table-step kernel
+    (lambda-rescale + Adam + clip) + ONE flat-arena Adam kernel for the CNN.
+
+No host synchronisation inside the step; the negative sampler runs on the host in the reference's RNG order.
+"""
+import copy
+import os
+import random
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib, ops, parallel
+from .hierarchy import NegativeGraph
+
+
+# ------------------------------------------------------------------------------------------------ tiny graph type
+class DiGraph:
+    """The handful of networkx.DiGraph methods the reference's trainer touches (edges/nodes/size/add_edge/
+    predecessors/successors), insertion-ordered like networkx.  A real networkx graph works wherever this does."""
+
+    def __init__(self):
+        self._succ, self._pred = {}, {}
+
+    def add_node(self, n):
+        if n not in self._succ:
+            self._succ[n] = {}; self._pred[n] = {}
+
+    def add_edge(self, u, v):
+        self.add_node(u); self.add_node(v)
+        self._succ[u][v] = True; self._pred[v][u] = True
+
+    def add_edges_from(self, es):
+        for u, v in es:
+            self.add_edge(u, v)
+
+    def nodes(self):
+        return list(self._succ)
+
+    def __iter__(self):
+        return iter(self._succ)
+
+    def __len__(self):
+        return len(self._succ)
+
+    def __contains__(self, n):
+        return n in self._succ
+
+    def edges(self, n=None):
+        if n is not None:
+            return [(n, v) for v in self._succ.get(n, {})]
+        return [(u, v) for u in self._succ for v in self._succ[u]]
+
+    def size(self):
+        return sum(len(s) for s in self._succ.values())
+
+    def successors(self, n):
+        return list(self._succ[n])
+
+    def predecessors(self, n):
+        return list(self._pred[n])
+
+    def has_edge(self, u, v):
+        return u in self._succ and v in self._succ[u]
+
+
+def transitive_closure(G):
+    out = DiGraph()
+    for n in G.nodes():
+        out.add_node(n)
+    memo = {}
+
+    def desc(u):
+        if u in memo:
+            return memo[u]
+        memo[u] = d = {}
+        for v in G.successors(u):
+            d[v] = True
+            for w in desc(v):
+                d[w] = True
+        return d
+    import sys
+    sys.setrecursionlimit(max(10000, sys.getrecursionlimit()))
+    for u in G.nodes():
+        for v in desc(u):
+            out.add_edge(u, v)
+    return out
+
+
+def create_combined_graphs(dataloaders, labelmap, pick_per_level=False):
+    """oe_h.py:506-580 on the same inputs (dataloaders yielding {'level_labels': [b, L], 'image_filename': [b]}), but the
+    negative structure is a CSR NegativeGraph instead of the dense (N+M)^2 matrix, nothing is pickled to disk, and
+    label ids are the labelmap's (every label is a node even if no training image reaches it)."""
+    G = DiGraph()
+    L = len(labelmap.levels)
+    for data_item in dataloaders['train']:
+        ll = np.asarray(data_item['level_labels'])
+        for level_id in range(L - 1):
+            for s in range(ll.shape[0]):
+                G.add_edge(int(ll[s, level_id]) + labelmap.level_start[level_id],
+                           int(ll[s, level_id + 1]) + labelmap.level_start[level_id + 1])
+    graphs = {'train': DiGraph(), 'val': DiGraph(), 'test': DiGraph()}
+    G_train_tc_base = copy.deepcopy(G)
+    image_leaf_parents = {}
+    for split in ('train', 'val', 'test'):
+        for data_item in dataloaders[split]:
+            ll = np.asarray(data_item['level_labels'])
+            for level_id in range(L):
+                for s in range(ll.shape[0]):
+                    lab = int(ll[s, level_id]) + labelmap.level_start[level_id]
+                    fname = data_item['image_filename'][s]
+                    graphs[split].add_edge(lab, fname)
+                    if split == 'train':
+                        G_train_tc_base.add_edge(lab, fname)
+                        image_leaf_parents.setdefault(fname, []).append(lab)
+    G_train_skeleton_full = copy.deepcopy(G_train_tc_base)
+    G_train_tc = transitive_closure(G_train_tc_base)
+    n_labels = labelmap.n_classes
+    mapping_ix_to_node = {i: i for i in range(n_labels)}
+    img_label = n_labels
+    for node in G_train_tc.nodes():
+        if isinstance(node, str):
+            mapping_ix_to_node[img_label] = node; img_label += 1
+    mapping_node_to_ix = {v: k for k, v in mapping_ix_to_node.items()}
+    names = [mapping_ix_to_node[i] for i in range(n_labels, img_label)]
+    ptr = np.zeros(len(names) + 1, dtype=np.int64); adj = []
+    for j, nm in enumerate(names):
+        adj.extend(image_leaf_parents[nm]); ptr[j + 1] = len(adj)
+    label_edges = [(u, v) for u, v in G.edges()]
+    neg = NegativeGraph(labelmap.levels, label_edges, ptr, np.asarray(adj, dtype=np.int32), pick_per_level=pick_per_level, seed=0)
+    return {'graph': G, 'graph_tc': transitive_closure(G), 'G_train': graphs['train'], 'G_val': graphs['val'],
+            'G_test': graphs['test'], 'G_train_skeleton_full': G_train_skeleton_full, 'G_train_neg': neg,
+            'mapping_ix_to_node': mapping_ix_to_node, 'mapping_node_to_ix': mapping_node_to_ix,
+            'G_train_tc': G_train_tc}
+
+
+# ------------------------------------------------------------------------------------------------ pair dataset
+class ETHECHierarchyWithImages(torch.utils.data.Dataset):
+    """oe_h.py:583-736: one positive edge (u, v) of the graph per item; endpoints that are image names are loaded.
+    `imageless_dataloaders` yields {'image_filename': [...], 'path_to_image': [...]}; a "path" may also be an in-memory
+    tensor [3,H,W] (synthetic stores) or a callable returning one."""
+
+    def __init__(self, graph, labelmap, has_negative=False, neg_to_pos_ratio=1, imageless_dataloaders=None,
+                 transform=None, half_half=False):
+        self.G = graph
+        self.num_edges = self.G.size()
+        self.has_negative = has_negative
+        self.neg_to_pos_ratio = neg_to_pos_ratio
+        self.half_half = half_half
+        if self.half_half:
+            self.edge_list_complete_ll = [e for e in self.G.edges() if type(e[0]) != str and type(e[1]) != str]
+            self.edge_list_complete_li = [e for e in self.G.edges() if type(e[0]) == str or type(e[1]) == str]
+            self.edge_list_ll = self.edge_list_complete_ll
+            self.edge_list_li = self.edge_list_complete_li
+        else:
+            self.edge_list_complete = [e for e in self.G.edges()]
+            self.edge_list = self.edge_list_complete
+        self.labelmap = labelmap
+        self.image_to_loc = {}
+        self.transform = transform
+        self.load_images = False
+        if imageless_dataloaders:
+            self.load_images = True
+            for batch in imageless_dataloaders:
+                for fname, loc in zip(batch['image_filename'], batch['path_to_image']):
+                    self.image_to_loc[fname] = loc
+        self.input_size = 224
+        self.levels_to_hide = []
+
+    def _hidden(self, u, v):
+        for lvl in self.levels_to_hide:
+            s, e = self.labelmap.level_start[lvl], self.labelmap.level_stop[lvl]
+            if (type(u) != str and s <= u < e) or (type(v) != str and s <= v < e):
+                return True
+        return False
+
+    def set_levels_to_hide(self, list_of_levels):
+        self.levels_to_hide = list_of_levels
+        if self.half_half:
+            self.edge_list_ll = [e for e in self.edge_list_complete_ll if not self._hidden(*e)]
+            self.edge_list_li = [e for e in self.edge_list_complete_li if not self._hidden(*e)]
+        else:
+            self.edge_list = [e for e in self.edge_list_complete if not self._hidden(*e)]
+
+    def _load(self, filename, train_transform):
+        loc = self.image_to_loc[filename]
+        if torch.is_tensor(loc):
+            img = loc
+        elif callable(loc):
+            img = loc()
+        else:
+            from PIL import Image
+            pil = Image.open(loc).convert('RGB').resize((self.input_size, self.input_size), Image.BILINEAR)
+            img = torch.from_numpy(np.asarray(pil).copy()).permute(2, 0, 1).float().div_(255.0)
+        if train_transform and self.transform:
+            img = self.transform(img)
+        return img
+
+    def get_image(self, filename):
+        """oe_h.py:668-677: the val/test transform (no flip) -- used for images drawn as negatives."""
+        return self._load(filename, False)
+
+    @staticmethod
+    def map_ranges(input, output_range, input_range):
+        return round(input * output_range / input_range)
+
+    def __getitem__(self, item):
+        if self.half_half:
+            if item % 2 == 0 and len(self.edge_list_ll) != 0:
+                item_ix = self.map_ranges(item // 2, len(self.edge_list_ll) - 1, round(self.__len__() / 2))
+                u, v = self.edge_list_ll[item_ix]
+            else:
+                item_ix = self.map_ranges(item // 2, len(self.edge_list_li) - 1, self.__len__() // 2)
+                u, v = self.edge_list_li[item_ix]
+        else:
+            u, v = self.edge_list[item]
+        original_from, original_to = u, v
+        if self.load_images:
+            if type(u) == str:
+                u = self._load(u, True)
+            if type(v) == str:
+                v = self._load(v, True)
+        return {'from': u, 'to': v, 'status': 1, 'original_from': original_from, 'original_to': original_to}
+
+    def __len__(self):
+        if self.half_half:
+            return max(2 * len(self.edge_list_ll), 2 * len(self.edge_list_li))
+        return len(self.edge_list)
+
+
+class EmbeddingMetrics:
+    """oe_h.py:447-503.  The 'val' threshold sweep (a 512-process pool in the reference, one pass per candidate
+    threshold) is a sort + prefix sums here: identical F1-optimal threshold, O(n log n)."""
+
+    def __init__(self, e_for_u_v_positive, e_for_u_v_negative, threshold, phase, n_proc=4):
+        self.e_for_u_v_positive = e_for_u_v_positive.reshape(-1)
+        self.e_for_u_v_negative = e_for_u_v_negative.reshape(-1)
+        self.threshold = threshold
+        self.phase = phase
+
+    def calculate_best(self, threshold):
+        p, n = self.e_for_u_v_positive, self.e_for_u_v_negative
+        cp = int((p <= threshold).sum()); cn = int((n > threshold).sum())
+        acc = (cp + cn) / (p.shape[0] + n.shape[0])
+        prec = cp / (cp + (n.shape[0] - cn)) if (cp + (n.shape[0] - cn)) else 0.0
+        rec = cp / p.shape[0]
+        f1 = 0.0 if prec + rec == 0 else 2 * prec * rec / (prec + rec)
+        return f1, threshold, acc, prec, rec, cp / p.shape[0], cn / n.shape[0]
+
+    def calculate_metrics(self):
+        p = self.e_for_u_v_positive.detach().double().cpu().numpy(); n = self.e_for_u_v_negative.detach().double().cpu().numpy()
+        if self.phase != 'val':
+            return self.calculate_best(self.threshold)
+        th = np.unique(np.concatenate((p, n)))
+        ps, ns = np.sort(p), np.sort(n)
+        cp = np.searchsorted(ps, th, side='right')                      # positives <= t
+        cn = len(ns) - np.searchsorted(ns, th, side='right')            # negatives  > t
+        fp = len(ns) - cn
+        with np.errstate(invalid='ignore', divide='ignore'):
+            prec = np.where(cp + fp > 0, cp / np.maximum(cp + fp, 1), 0.0)
+            rec = cp / len(ps)
+            f1 = np.where(prec + rec > 0, 2 * prec * rec / np.maximum(prec + rec, 1e-300), 0.0)
+        b = int(np.argmax(f1))                                          # first maximum, like np.argmax(F[:, 0])
+        return np.array([f1[b], th[b], (cp[b] + cn[b]) / (len(ps) + len(ns)), prec[b], rec[b], cp[b] / len(ps), cn[b] / len(ns)])
+
+
+class _NullWriter:
+    def add_scalar(self, *a, **k): pass
+    def close(self): pass
+
+
+class GlobalBatchSampler(torch.utils.data.Sampler):
+    """Deterministic global batches, sliced per rank: every rank sees the same permutation; rank r loads
+    only positions [r*bs, (r+1)*bs) of each global batch.  `global_batches()` replays the index lists so that the
+    negative stream can be drawn for the GLOBAL batch in the reference's order on every rank."""
+
+    def __init__(self, n, batch_size, shuffle=True, seed=0, rank=0, world=1):
+        self.n, self.bs, self.shuffle, self.seed, self.rank, self.world = n, batch_size, shuffle, seed, rank, world
+        self.epoch = 0
+
+    def set_epoch(self, e):
+        self.epoch = e
+
+    def global_batches(self):
+        if self.shuffle:
+            g = torch.Generator(); g.manual_seed(self.seed + self.epoch)
+            perm = torch.randperm(self.n, generator=g).tolist()
+        else:
+            perm = list(range(self.n))
+        gb = self.bs * self.world
+        return [perm[i:i + gb] for i in range(0, len(perm) - (len(perm) % self.world if self.world > 1 else 0), gb)]
+
+    def __iter__(self):
+        for b in self.global_batches():
+            per = len(b) // self.world
+            yield b[self.rank * per:(self.rank + 1) * per]
+
+    def __len__(self):
+        return len(self.global_batches())
+
+
+# ------------------------------------------------------------------------------------------------ the trainer
+class JointEmbeddings:
+    """oe_h.py:1318-2247."""
+
+    def __init__(self, graph_dict, imageless_dataloaders, image_dir, use_CNN, labelmap, criterion, lr, n_workers,
+                 batch_size, experiment_name, embedding_dim, neg_to_pos_ratio, image_fc7, normalize, alpha,
+                 lr_step=[], experiment_dir='../exp/', n_epochs=10, eval_interval=2, feature_extracting=True,
+                 use_pretrained=True, load_wt=False, model_name=None, optimizer_method='adam', use_grayscale=False,
+                 load_emb_from=None, load_cosine_emb=None, hide_levels=None, half_half=False,
+                 compute_dtype=torch.float32, cnn_weights=None, writer=None):
+        from .oe_h import Embedder, FeatCNN18, FeatCNN, FeatNet, EuclideanConesWithImagesHypernymLoss
+        torch.manual_seed(0)                                               # oe_h.py:1338
+        self.classes = labelmap.classes; self.n_classes = labelmap.n_classes
+        self.levels = labelmap.levels; self.n_levels = len(self.levels); self.level_names = labelmap.level_names
+        self.lr = lr; self.lr_step = lr_step; self.batch_size = batch_size
+        self.feature_extracting = feature_extracting; self.optimizer_method = optimizer_method
+        self.labelmap = labelmap; self.model_name = model_name; self.n_workers = n_workers
+        self.imageless_dataloaders = imageless_dataloaders; self.use_CNN = use_CNN; self.image_dir = image_dir
+        self.hide_levels = hide_levels; self.half_half = half_half
+        self.use_rsgd = False                                              # oe_h.py:1359
+        self.lr_labels = self.lr; self.lr_images = 1e-3
+        self.best_model_wts = None; self.best_score = 0.0
+        self.epoch = 0; self.exp_dir = experiment_dir; self.load_wt = load_wt
+        self.criterion = criterion
+        if not torch.cuda.is_available():
+            raise RuntimeError('JointEmbeddings runs on the MI355X only (no CPU fallback)')
+        self.rank, self.local_rank, self.world = parallel.init_process_group()
+        self.device = torch.device('cuda', self.local_rank if self.world > 1 else torch.cuda.current_device())
+        print('Using device: {}'.format(self.device))
+        self.n_epochs = n_epochs; self.eval_interval = eval_interval
+        self.log_dir = os.path.join(self.exp_dir, '{}').format(experiment_name)
+        self.path_to_save_model = os.path.join(self.log_dir, 'weights')
+        self.make_dir_if_non_existent(self.path_to_save_model)
+        self.writer = writer if writer is not None else _NullWriter()
+        self.graph_dict = graph_dict
+        self.optimal_threshold = 0; self.alpha = alpha
+        self.embedding_dim = embedding_dim; self.neg_to_pos_ratio = neg_to_pos_ratio; self.normalize = None
+        is_hyp = isinstance(criterion, EuclideanConesWithImagesHypernymLoss)
+        self.model = Embedder(embedding_dim=self.embedding_dim, labelmap=labelmap, normalize=self.normalize,
+                              K=criterion.K if is_hyp else None)
+        self.model.to(self.device)
+        if self.use_CNN:
+            cls = FeatCNN if (model_name or '').lower() == 'resnet50' else FeatCNN18      # reference hard-wires resnet18 (:1404)
+            self.img_feat_net = cls(image_dir=self.image_dir, output_dim=self.embedding_dim,
+                                    K=criterion.K if is_hyp else None, weights=cnn_weights,
+                                    compute_dtype=compute_dtype).to(self.device)
+        else:
+            self.img_feat_net = FeatNet(output_dim=self.embedding_dim, normalize=self.normalize,
+                                        K=criterion.K if is_hyp else None).to(self.device)
+        self.criterion.set_negative_graph(self.graph_dict['G_train_neg'], self.graph_dict['mapping_node_to_ix'],
+                                          self.graph_dict['mapping_ix_to_node'])       # oe_h.py:1420
+        self.create_splits()
+        self.prepare_model()
+        # MI355X: CNN parameters + grads in one flat arena; gradient reducer with backward overlap
+        self.arena = parallel.FlatArena(self.img_feat_net.parameters(), self.device)
+        w = self.model.embeddings.weight
+        self.table_grad = torch.zeros_like(w.data); w.grad = self.table_grad
+        self.table_m = torch.zeros_like(w.data); self.table_v = torch.zeros_like(w.data); self.table_step = 0
+        self.reducer = parallel.GradientReducer(self.arena, extra=[self.table_grad])
+        if self.world > 1:                                                  # replicas start identical
+            torch.distributed.broadcast(self.arena.data, 0); torch.distributed.broadcast(w.data, 0)
+        self.check_graph_embedding_neg_graph = None
+        self.check_reconstr_every = 1; self.save_model_every = 1
+        self.reconstruction_f1 = self.reconstruction_threshold = self.reconstruction_accuracy = 0.0
+        self.reconstruction_prec = self.reconstruction_recall = 0.0
+        self.levels_to_hide_for_epoch = {}
+
+    @staticmethod
+    def make_dir_if_non_existent(directory):
+        if not os.path.exists(directory):
+            os.makedirs(directory, exist_ok=True)
+
+    def prepare_model(self):
+        self.params_to_update = [{'params': self.model.parameters(), 'lr': self.lr_labels},
+                                 {'params': self.img_feat_net.parameters(), 'lr': self.lr_images}]
+
+    def create_splits(self):
+        random.seed(0)                                                      # oe_h.py:1472
+        self.criterion.seed_sampler(0)
+
+        def flip(img):                                                      # RandomHorizontalFlip (train only, :1465)
+            return img.flip(-1) if torch.rand(()) < 0.5 else img
+        il = self.imageless_dataloaders
+        mk = lambda key, tr, hh: ETHECHierarchyWithImages(self.graph_dict[key], labelmap=self.labelmap,
+                                                          imageless_dataloaders=il[tr] if (self.use_CNN and il) else None,
+                                                          transform=flip if tr == 'train' else None, half_half=hh)
+        train_set = mk('G_train_tc', 'train', self.half_half)
+        val_set = mk('G_val', 'val', False); test_set = mk('G_test', 'test', False)
+        self.train_set = train_set
+        self.datasets = {'train': train_set, 'val': val_set, 'test': test_set}
+        self.dataset_length = {k: len(v) for k, v in self.datasets.items()}
+        self._make_train_loader()
+        from .oe_h import my_collate
+        self.dataloaders['val'] = torch.utils.data.DataLoader(val_set, batch_size=self.batch_size, collate_fn=my_collate,
+                                                              num_workers=self.n_workers, shuffle=False)
+        self.dataloaders['test'] = torch.utils.data.DataLoader(test_set, batch_size=self.batch_size, collate_fn=my_collate,
+                                                               num_workers=self.n_workers, shuffle=False)
+
+    def _make_train_loader(self):
+        from .oe_h import my_collate
+        self.train_sampler = GlobalBatchSampler(len(self.train_set), self.batch_size, shuffle=True, seed=0,
+                                                rank=getattr(self, 'rank', 0), world=getattr(self, 'world', 1))
+        self.dataloaders = getattr(self, 'dataloaders', {})
+        self.dataloaders['train'] = torch.utils.data.DataLoader(self.train_set, batch_sampler=self.train_sampler,
+                                                                num_workers=self.n_workers, collate_fn=my_collate)
+        self.datasets['train'] = self.train_set
+        self.dataset_length['train'] = len(self.train_set)
+
+    def _set_hidden_levels(self, levels):
+        print('Set levels to hide to: {}'.format(levels))
+        self.train_set.set_levels_to_hide(levels)
+        self.criterion.set_levels_to_hide(levels)
+        self._make_train_loader()
+
+    # ---- Riemannian helpers (oe_h.py:1604-1644), kept as methods; the step itself uses the fused kernels ---------
+    def lambda_x(self, x):
+        return 2. / (1 - torch.norm(x, p=2, dim=1, keepdim=True).repeat(1, self.embedding_dim))
+
+    # ---- training loop ---------------------------------------------------------------------------------------------
+    def run_model(self, optimizer=None):
+        self.levels_to_hide_for_epoch = {}
+        if self.hide_levels:
+            self.levels_to_hide_for_epoch = {0: [1, 2, 3], 20: [2, 3], 50: [3], 100: []}       # oe_h.py:1536
+        current = None
+        for key in self.levels_to_hide_for_epoch:
+            if self.epoch >= key:
+                current = key
+        if current is not None:
+            self._set_hidden_levels(self.levels_to_hide_for_epoch[current])
+        if self.load_wt:
+            self.find_existing_weights()
+        self.best_model_wts = copy.deepcopy(self.model.state_dict()); self.best_score = 0.0
+        since = time.time()
+        for self.epoch in range(self.epoch, self.n_epochs):
+            print('=' * 10); print('Epoch {}/{}'.format(self.epoch, self.n_epochs - 1)); print('=' * 10)
+            if self.epoch in self.levels_to_hide_for_epoch:
+                self._set_hidden_levels(self.levels_to_hide_for_epoch[self.epoch])
+            t0 = time.time()
+            self.pass_samples(phase='train')
+            self.writer.add_scalar('epoch_time_train', time.time() - t0, self.epoch)
+            if self.epoch % self.eval_interval == 0:
+                t1 = time.time(); self.pass_samples(phase='val')
+                self.writer.add_scalar('epoch_time_val', time.time() - t1, self.epoch)
+                t2 = time.time(); self.pass_samples(phase='test')
+                self.writer.add_scalar('epoch_time_test', time.time() - t2, self.epoch)
+            self._lr_scale = 0.1 ** sum(1 for m in self.lr_step if self.epoch + 1 >= m)       # MultiStepLR(gamma=0.1)
+            self.writer.add_scalar('epoch_time', time.time() - t0, self.epoch)
+        print('Training complete in {:.0f}s'.format(time.time() - since))
+        print('Best val score: {:4f}'.format(self.best_score))
+        self.model.load_state_dict(self.best_model_wts)
+        self.writer.close()
+        return self.model
+
+    def train(self):
+        self.run_model(None)
+        self.load_best_model()
+
+    def train_step(self, data_item):
+        """oe_h.py:1734-1774 for one batch.  Returns the (device) loss; nothing here synchronises with the host."""
+        self.arena.zero_grad(); self.table_grad.zero_()
+        if self.world > 1:
+            raise NotImplementedError('multi-process JointEmbeddings.train_step: drive DP through bench.py / StepEngine')
+        loss, e_pos, e_neg = self.criterion(self.model, self.img_feat_net, data_item['from'], data_item['to'],
+                                            data_item['original_from'], data_item['original_to'], data_item['status'], 'train')
+        loss.backward()                                                     # oe_h.py:1766
+        self.reducer.finish()
+        self.apply_updates()
+        return loss.detach(), e_pos, e_neg
+
+    def apply_updates(self):
+        lr = self.lr_labels * getattr(self, '_lr_scale', 1.0)
+        w = self.model.embeddings.weight
+        Kc = getattr(self.criterion, 'K', None)
+        self.table_step += 1
+        if self.use_rsgd:                                                   # oe_h.py:1757-1764
+            ops.table_step_rsgd(w.data, self.table_grad, lr, Kc)
+            self.arena.adam_step(self.lr_images * getattr(self, '_lr_scale', 1.0))
+        else:                                                               # :1766-1771, one Adam over table + CNN at lr
+            ops.table_step_adam(w.data, self.table_grad, self.table_m, self.table_v, self.table_step, lr,
+                                Kc or 0.0, riemannian=bool(Kc), clip=bool(Kc))
+            self.arena.adam_step(lr)
+
+    def pass_samples(self, phase, save_to_tensorboard=True):
+        self.criterion.set_dataloader(self.datasets[phase])
+        if phase == 'train':
+            self.model.train(); self.img_feat_net.train()
+            running = torch.zeros((), device=self.device)
+            self.train_sampler.set_epoch(self.epoch)
+            index = -1
+            for index, data_item in enumerate(self.dataloaders[phase]):
+                loss, _, _ = self.train_step(data_item)
+                running += loss
+            classification_metrics = self.calculate_classification_metrics(phase)
+            epoch_loss = running.item() / max(1, (index + 1) * self.batch_size * self.neg_to_pos_ratio * 2)   # :1780
+            if save_to_tensorboard:
+                self.writer.add_scalar('{}_loss'.format(phase), epoch_loss, self.epoch)
+            print('train loss: {}'.format(epoch_loss))
+            self.last_epoch_loss = epoch_loss
+        else:
+            self.model.eval(); self.img_feat_net.eval()
+            classification_metrics = self.calculate_classification_metrics(phase)
+            if phase == 'test' and self.epoch % self.save_model_every == 0:
+                self.save_model(-9999.0)
+            if phase == 'val' and classification_metrics['m-f1'] >= self.best_score:
+                self.best_score = classification_metrics['m-f1']
+                self.best_model_wts = copy.deepcopy(self.model.state_dict())
+                self.save_model(-9999.0, filename='best_model')
+            if phase == 'test' and (self.epoch % self.check_reconstr_every == 0 or not save_to_tensorboard):
+                (self.reconstruction_f1, self.reconstruction_threshold, self.reconstruction_accuracy,
+                 self.reconstruction_prec, self.reconstruction_recall, c_pos, c_neg) = self.check_graph_embedding()
+        self.last_metrics = classification_metrics
+        return classification_metrics
+
+    # ---- checkpoints (oe_h.py:1876-1957; same file names and dict keys, `module.` prefix kept for interchange) ----
+    def _state(self, module):
+        return {'module.' + k: v for k, v in module.state_dict().items()}
+
+    def save_model(self, loss, filename=None):
+        if self.rank != 0:
+            return
+        rec = {'f1': self.reconstruction_f1, 'precision': self.reconstruction_prec, 'recall': self.reconstruction_recall,
+               'accuracy': self.reconstruction_accuracy, 'threshold': self.reconstruction_threshold}
+        tag = filename if filename else self.epoch
+        opt = {'table_m': self.table_m, 'table_v': self.table_v, 'table_step': self.table_step,
+               'arena_m': self.arena.exp_avg, 'arena_v': self.arena.exp_avg_sq, 'arena_step': self.arena.step}
+        torch.save({'epoch': self.epoch, 'model_state_dict': self._state(self.model), 'optimizer_state_dict': opt,
+                    'loss': loss, 'optimal_threshold': self.optimal_threshold, 'reconstruction_scores': rec},
+                   os.path.join(self.path_to_save_model, '{}_model.pth'.format(tag)))
+        torch.save({'epoch': self.epoch, 'model_state_dict': self.img_feat_net.state_dict(), 'optimizer_state_dict': {},
+                    'loss': loss, 'optimal_threshold': self.optimal_threshold, 'reconstruction_scores': rec},
+                   os.path.join(self.path_to_save_model, '{}_img_feat_net.pth'.format(tag)))
+
+    def _load_sd(self, module, sd):
+        sd = {k[len('module.'):] if k.startswith('module.') else k: v for k, v in sd.items()}
+        with torch.no_grad():
+            own = module.state_dict()
+            for k, v in sd.items():
+                own[k].copy_(v)                                            # in place: parameters stay inside the arena
+
+    def load_model(self, epoch_to_load):
+        ck = torch.load(os.path.join(self.path_to_save_model, '{}_model.pth'.format(epoch_to_load)), map_location=self.device)
+        self._load_sd(self.model, ck['model_state_dict'])
+        self.epoch = ck['epoch']; self.optimal_threshold = ck['optimal_threshold']
+        opt = ck.get('optimizer_state_dict', {})
+        if 'table_m' in opt:
+            self.table_m.copy_(opt['table_m']); self.table_v.copy_(opt['table_v']); self.table_step = opt['table_step']
+            if opt.get('arena_m') is not None:
+                self.arena.exp_avg = opt['arena_m'].to(self.device); self.arena.exp_avg_sq = opt['arena_v'].to(self.device)
+                self.arena.step = opt['arena_step']
+        ck = torch.load(os.path.join(self.path_to_save_model, '{}_img_feat_net.pth'.format(epoch_to_load)), map_location=self.device)
+        self._load_sd(self.img_feat_net, ck['model_state_dict'])
+
+    def find_existing_weights(self):
+        weights = sorted([f.split('_')[0] for f in os.listdir(self.path_to_save_model)])
+        weights = [w for w in weights if w.isdigit()]
+        weights.sort(key=int)
+        if len(weights) < 1:
+            print('Could not find weights to load from, will train from scratch.')
+        else:
+            self.load_model(epoch_to_load=weights[-1])
+
+    def load_best_model(self):
+        self.load_model(epoch_to_load='best_model')
+        return self.pass_samples(phase='test', save_to_tensorboard=False)
+
+    # ---- metrics -----------------------------------------------------------------------
+    @torch.no_grad()
+    def embed_images(self, names, bs=256):
+        ds = self.criterion.dataloader
+        out = torch.zeros((len(names), self.embedding_dim), device=self.device)
+        for i in range(0, len(names), bs):
+            stack = torch.stack([ds.get_image(n) for n in names[i:i + bs]]).to(self.device)
+            out[i:i + len(stack)] = self.img_feat_net(stack).float()
+        return out
+
+    @torch.no_grad()
+    def calculate_classification_metrics(self, phase, k=[1, 3, 5]):
+        """oe_h.py:1971-2178 with the per-image python loop replaced by ONE all-pairs energy launch + per-level top-k on
+        the GPU.  (The reference's chunk loops skip the last image / label, leaving a zero row -- a bug that is not
+        reproduced; every row is embedded here.)"""
+        G = self.graph_dict['G_{}'.format(phase)]
+        nodes = list(G)
+        images = [n for n in nodes if type(n) == str]
+        labels = sorted(n for n in nodes if type(n) != str)
+        metrics = {}
+        if not images:
+            return {'m-f1': 0.0, 'accuracy': 0.0}
+        was_training = self.img_feat_net.training
+        self.img_feat_net.eval()
+        img_rep = self.embed_images(images)
+        self.img_feat_net.train(was_training)
+        label_rep = self.model(torch.arange(self.n_classes, device=self.device))
+        metrics['median_img_norm'] = torch.median(torch.norm(img_rep, dim=1)).item()
+        metrics['median_label_norm'] = torch.median(torch.norm(label_rep[labels], dim=1)).item()
+        E = self._score(label_rep, img_rep)                                 # [n_img, n_labels]
+        member = np.zeros((len(images), self.n_levels), dtype=np.int64)
+        for i, name in enumerate(images):
+            m = sorted(G.predecessors(name))
+            member[i, :len(m)] = m[:self.n_levels]
+        member_t = torch.from_numpy(member).to(self.device)
+        tp = torch.zeros(self.n_classes, device=self.device); fp = torch.zeros_like(tp); fn = torch.zeros_like(tp); tn = torch.zeros_like(tp)
+        hit = {kv: torch.zeros(self.n_classes, device=self.device) for kv in k}
+        ones = torch.ones(len(images), device=self.device)
+        for lvl in range(self.n_levels):
+            s, e = self.labelmap.level_start[lvl], self.labelmap.level_stop[lvl]
+            kk = min(max(k), e - s)
+            _, idx = torch.topk(E[:, s:e], k=kk, largest=False, dim=1)
+            idx = idx + s
+            truth = member_t[:, lvl]
+            for kv in k:
+                h = (idx[:, :min(kv, kk)] == truth[:, None]).any(dim=1).float()
+                hit[kv].index_add_(0, truth, h)
+            correct = idx[:, 0] == truth
+            tp.index_add_(0, truth, correct.float())
+            fp.index_add_(0, idx[:, 0], (~correct).float())
+            fn.index_add_(0, truth, (~correct).float())
+            lvl_tn = torch.zeros(e - s, device=self.device) + correct.float().sum()
+            tn[s:e] += lvl_tn; tn.index_add_(0, truth, -correct.float())     # tn for every other label of the level
+        tot = {n: float(t[labels].sum()) for n, t in (('tp', tp), ('fp', fp), ('fn', fn), ('tn', tn))}
+        prec = tot['tp'] / max(tot['tp'] + tot['fp'], 1e-30); rec = tot['tp'] / max(tot['tp'] + tot['fn'], 1e-30)
+        metrics['accuracy'] = (tot['tp'] + tot['tn']) / max(sum(tot.values()), 1e-30)
+        metrics['m-precision'], metrics['m-recall'] = prec, rec
+        metrics['m-f1'] = 0.0 if prec + rec == 0 else 2 * prec * rec / (prec + rec)
+        for kv in k:
+            metrics['hit@{}'.format(kv)] = float(hit[kv][labels].sum()) / (self.n_levels * len(images))
+        lp = torch.where(tp + fp > 0, tp / (tp + fp).clamp_min(1), torch.zeros_like(tp))
+        lr_ = torch.where(tp + fn > 0, tp / (tp + fn).clamp_min(1), torch.zeros_like(tp))
+        lf = torch.where(lp + lr_ > 0, 2 * lp * lr_ / (lp + lr_).clamp_min(1e-30), torch.zeros_like(tp))
+        metrics['M-precision'] = float(lp[labels].mean()); metrics['M-recall'] = float(lr_[labels].mean()); metrics['M-f1'] = float(lf[labels].mean())
+        print('=' * 30, '{} - Classification metrics'.format(phase), '=' * 30)
+        print('m-F1: {:.4f} Accuracy: {:.4f}'.format(metrics['m-f1'], metrics['accuracy']))
+        if phase == 'train':
+            self.img_rep = img_rep.unsqueeze(0).cpu()
+        return metrics
+
+    def _score(self, label_rep, img_rep):
+        from .oe_h import EuclideanConesWithImagesHypernymLoss
+        if isinstance(self.criterion, EuclideanConesWithImagesHypernymLoss):
+            return ops.energy_matrix(label_rep, img_rep, self.criterion.K, 'hyp_cone')
+        return ops.energy_matrix(label_rep, img_rep, None, 'order')
+
+    @torch.no_grad()
+    def check_graph_embedding(self):
+        """oe_h.py:2180-2247: label-graph reconstruction F1 over ALL label pairs.  One all-pairs energy launch (N x N)
+        + a sort-based threshold sweep instead of N^2 python-indexed pairs and a process pool."""
+        tc = self.graph_dict['graph_tc']
+        N = self.n_classes
+        hidden = self.levels_to_hide_for_epoch.get(self.epoch, []) if self.hide_levels else []
+        pos = torch.zeros((N, N), dtype=torch.bool)
+        keep = torch.zeros(N, dtype=torch.bool)
+        def hid(u):
+            return any(self.labelmap.level_start[l] <= u < self.labelmap.level_stop[l] for l in hidden)
+        for u, v in tc.edges():
+            if type(u) == str or type(v) == str or hid(u) or hid(v):
+                continue
+            pos[u, v] = True; keep[u] = True; keep[v] = True
+        nodes = torch.nonzero(keep).flatten()
+        rep = self.model(nodes.to(self.device))
+        E = self._score(rep, rep).t().cpu()                                 # E[u, v] = E(apex u, point v)
+        sub_pos = pos[nodes][:, nodes]
+        off = ~torch.eye(len(nodes), dtype=torch.bool)
+        m = EmbeddingMetrics(E[sub_pos], E[(~sub_pos) & off], 0.0, 'val')
+        best = m.calculate_metrics()
+        print('Checking graph reconstruction: +ve edges {}, -ve edges {}'.format(int(sub_pos.sum()), int(((~sub_pos) & off).sum())))
+        return tuple(float(x) for x in best)
+
+
+# the Riemannian helper methods of the reference (oe_h.py:1604-1644) as thin kernel calls, for API completeness
+def _soft_clip(self, x):
+    """oe_h.py:1604-1617 (in place): rows clipped into [r_in, 1 - 1e-5] -- the clip-only pass of the table-step kernel."""
+    z = torch.zeros_like(x)
+    ops.table_step_adam(x, z, z.clone(), z.clone(), 1, 0.0, self.criterion.K, riemannian=False, clip=True)
+    return x
+
+
+def _exp_map_x(self, x, v):
+    """oe_h.py:1638-1644 exp_map_x(x, v) with Mobius addition; evaluated by the RSGD kernel with lr = -1 on the
+    pre-rescaled tangent vector (the kernel multiplies by (1/lambda_x)^2 itself, so divide it out first)."""
+    lam = self.lambda_x(x)
+    g = v * lam ** 2
+    out = x.clone()
+    ops.table_step_rsgd(out, g.contiguous(), -1.0, self.criterion.K)
+    return out
+
+
+JointEmbeddings.soft_clip = _soft_clip
+JointEmbeddings.exp_map_x = _exp_map_x

@@ -1,0 +1,223 @@
+"""Data parallelism, MI355X-first: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on ROCm).
+
+Replaces the reference's single-process `nn.DataParallel` (oe_h.py:301,1434,1439; ethec_experiments.py:240), which
+re-broadcasts all parameters every forward, gathers outputs on device 0 and reduce-adds replica gradients there.  Here
+every rank owns a full replica whose parameters AND gradients live in one flat fp32 arena each, so that
+
+  * the gradient exchange is a handful of large bucketed SUM all-reduces over contiguous slices of one buffer (the node
+    is a full xGMI mesh: large messages let RCCL drive all 7 links), launched from autograd hooks while backward is
+    still running, and
+  * the optimizer is ONE Adam launch over the arena (ops.adam_flat) instead of ~160 per-tensor launches.
+
+Reduction is SUM, not mean: the reference loss is a plain sum over pairs (oe_h.py:843-846), so the gradient of the
+global batch is the sum of the shard gradients.  Gloo (CPU) works for the same code path and is what the CPU tests use.
+"""
+import os
+import threading
+import queue
+import torch
+import torch.distributed as dist
+
+_ALIGN = 64            # elements: every parameter starts on a 256-byte boundary inside the arena
+
+
+class FlatArena:
+    """Re-homes `params` into one flat fp32 buffer (`data`) with a twin gradient buffer (`grad`)."""
+
+    def __init__(self, params, device=None):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError('FlatArena: no trainable parameters')
+        device = device or self.params[0].device
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            if p.dtype != torch.float32:
+                raise TypeError('FlatArena holds fp32 master parameters only')
+            self.offsets.append(off)
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.numel = off
+        self.data = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        for p, o in zip(self.params, self.offsets):
+            n = p.numel()
+            view = self.data[o:o + n].view(p.shape)
+            view.copy_(p.data)
+            if p.data.dim() == 4 and p.data.is_contiguous(memory_format=torch.channels_last) and not p.data.is_contiguous():
+                # keep NHWC-strided conv weights: store the permuted bytes, expose the same logical strides
+                nhwc = self.data[o:o + n].view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2)
+                nhwc.copy_(p.data); view = nhwc
+                gview = self.grad[o:o + n].view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2)
+            else:
+                gview = self.grad[o:o + n].view(p.shape)
+            p.data = view
+            p.grad = gview
+        self.exp_avg = None; self.exp_avg_sq = None; self.step = 0
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def slice_of(self, p):
+        i = next(k for k, q in enumerate(self.params) if q is p)
+        return self.offsets[i], self.params[i].numel()
+
+    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+        from . import ops
+        if self.exp_avg is None:
+            self.exp_avg = torch.zeros_like(self.data); self.exp_avg_sq = torch.zeros_like(self.data)
+        self.step += 1
+        ops.adam_flat(self.data, self.grad, self.exp_avg, self.exp_avg_sq, self.step, lr, betas, eps, grad_scale)
+
+
+# ------------------------------------------------------------------------------------------------ process group
+def env_rank():
+    return int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+
+
+def init_process_group(backend=None):
+    """Idempotent.  Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torchrun contract)."""
+    rank, local_rank, world = env_rank()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
+    return rank, local_rank, world
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+class GradientReducer:
+    """Bucketed, backward-overlapped SUM all-reduce of a FlatArena's gradient (plus any extra flat tensors, e.g. the
+    label table's dense gradient).  Buckets are contiguous slices of the arena in REVERSE parameter order, so the first
+    bucket to fill is the one backward finishes first."""
+
+    def __init__(self, arena, bucket_mb=32.0, extra=()):
+        self.arena = arena
+        self.extra = list(extra)
+        self.enabled = world_size() > 1
+        self.handles = []
+        self.buckets = []            # (start, end, [param indices])
+        cap = int(bucket_mb * 1024 * 1024 / 4)
+        idxs = list(range(len(arena.params)))[::-1]
+        cur, cur_n = [], 0
+        for i in idxs:
+            n = arena.params[i].numel()
+            cur.append(i); cur_n += n
+            if cur_n >= cap:
+                self.buckets.append(cur); cur, cur_n = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self._spans = []
+        for b in self.buckets:
+            lo = min(arena.offsets[i] for i in b)
+            hi = max(arena.offsets[i] + (arena.params[i].numel() + _ALIGN - 1) // _ALIGN * _ALIGN for i in b)
+            self._spans.append((lo, min(hi, arena.numel)))
+        self._bucket_of = {}
+        for bi, b in enumerate(self.buckets):
+            for i in b:
+                self._bucket_of[i] = bi
+        self._pending = [0] * len(self.buckets)
+        if self.enabled:
+            for i, p in enumerate(arena.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+        self.reset()
+
+    def reset(self):
+        self._pending = [len(b) for b in self.buckets]
+        self.handles = []
+
+    def _make_hook(self, i):
+        def hook(_p):
+            bi = self._bucket_of[i]
+            self._pending[bi] -= 1
+            if self._pending[bi] == 0:
+                lo, hi = self._spans[bi]
+                self.handles.append(dist.all_reduce(self.arena.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        return hook
+
+    def finish(self):
+        """Reduce whatever has not been launched by hooks (unused parameters, the extras) and wait for everything."""
+        if not self.enabled:
+            return
+        for bi, left in enumerate(self._pending):
+            if left > 0:
+                lo, hi = self._spans[bi]
+                self.handles.append(dist.all_reduce(self.arena.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        for t in self.extra:
+            self.handles.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+        for h in self.handles:
+            h.wait()
+        self.reset()
+
+
+def allreduce_sum_(t):
+    if world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def shard_range(n_global, r=None, w=None):
+    """Contiguous shard of a global batch for this rank."""
+    r = rank() if r is None else r; w = world_size() if w is None else w
+    per = n_global // w
+    if per * w != n_global:
+        raise ValueError('global batch %d is not divisible by world size %d' % (n_global, w))
+    return r * per, (r + 1) * per
+
+
+class NegativePrefetcher:
+    """Draws the negatives of step s+1 on a host thread while the GPU works on step s.  The ctypes call releases the
+    GIL, so the MT19937 walk genuinely overlaps.  Draw order is the reference's (oe_h.py:940-957); in 'replicated' mode
+    every rank walks the GLOBAL batch's stream and keeps its shard, which makes the indices bit-identical to the
+    single-process run whatever the world size, with no collective."""
+
+    def __init__(self, graph, positives_fn, K, mode='replicated', depth=2):
+        self.graph, self.positives_fn, self.K, self.mode = graph, positives_fn, K, mode
+        self.q = queue.Queue(maxsize=depth)
+        self.step = 0
+        self._stop = False
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def _run(self):
+        s = 0
+        try:
+            while not self._stop:
+                frm, to = self.positives_fn(s)                 # global positives of step s (numpy int32)
+                if self.mode == 'replicated':
+                    neg = self.graph.draw_batch(frm, to, self.K)
+                    lo, hi = shard_range(len(frm))
+                    item = (frm[lo:hi], to[lo:hi], neg[lo:hi])
+                else:                                          # 'per_rank': independent stream per rank
+                    lo, hi = shard_range(len(frm))
+                    item = (frm[lo:hi], to[lo:hi], self.graph.draw_batch(frm[lo:hi], to[lo:hi], self.K))
+                self.q.put((s, item))
+                s += 1
+        except Exception as e:                                 # surface sampler errors in the consumer
+            self.q.put((-1, e))
+
+    def next(self):
+        s, item = self.q.get()
+        if s < 0:
+            raise item
+        return item
+
+    def close(self):
+        self._stop = True
+        try:
+            while True:
+                self.q.get_nowait()
+        except queue.Empty:
+            pass

@@ -1,0 +1,133 @@
+"""ResNet-18 / ResNet-50 backbones owned by this package (torchvision is not in the image, and the conv stack is the
+MFMA half of the hot path: SURVEY.md 8a row a3).  Parameter / buffer names follow torchvision's so that the reference's
+checkpoints (`models.resnet18(pretrained=True)` state dicts, oe_h.py:311, finetuner.py:121-122) load unchanged.
+
+Layout / precision are MI355X choices, not the reference's: activations NHWC (channels_last) so MIOpen / our kernels see
+the GEMM-friendly layout, bf16 compute under autocast with fp32 master weights held in one flat arena
+(parallel.FlatArena) so the data-parallel all-reduce is a single RCCL collective and Adam a single launch.
+"""
+import torch
+import torch.nn as nn
+
+
+def conv3x3(cin, cout, stride=1):
+    return nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=1, bias=False)
+
+
+def conv1x1(cin, cout, stride=1):
+    return nn.Conv2d(cin, cout, kernel_size=1, stride=stride, bias=False)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, cin, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = conv3x3(cin, planes, stride); self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = conv3x3(planes, planes); self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + idt)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, cin, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = conv1x1(cin, planes); self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = conv3x3(planes, planes, stride); self.bn2 = nn.BatchNorm2d(planes)      # stride on the 3x3 (v1.5)
+        self.conv3 = conv1x1(planes, planes * 4); self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + idt)
+
+
+class ResNet(nn.Module):
+    def __init__(self, block, layers, num_classes=1000):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512 * block.expansion, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1); nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(conv1x1(self.inplanes, planes * block.expansion, stride),
+                                       nn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        x = torch.flatten(self.avgpool(x), 1)
+        return self.fc(x)
+
+
+def resnet18(num_classes=1000):
+    return ResNet(BasicBlock, [2, 2, 2, 2], num_classes)
+
+
+def resnet50(num_classes=1000):
+    return ResNet(Bottleneck, [3, 4, 6, 3], num_classes)
+
+
+# analytic work per image (2 flops / MAC, backward = 2x forward): SURVEY.md 8(d)
+GFLOP_FWD_BWD_PER_IMAGE = {('resnet18', 224): 10.881, ('resnet50', 224): 24.523, ('resnet18', 32): 0.222 * 3 / 1.0, ('resnet50', 32): 0.501 * 3}
+
+
+def conv_macs(model, hw):
+    """MACs of one forward pass at hw x hw (convs + fc), by shape walk -- used by bench.py for the MFMA roofline."""
+    macs = 0
+    hooks = []
+
+    def conv_hook(m, inp, out):
+        nonlocal macs
+        macs += out.shape[1] * out.shape[2] * out.shape[3] * (m.in_channels // m.groups) * m.kernel_size[0] * m.kernel_size[1]
+
+    def fc_hook(m, inp, out):
+        nonlocal macs
+        macs += m.in_features * m.out_features
+
+    for m in model.modules():
+        if isinstance(m, nn.Conv2d):
+            hooks.append(m.register_forward_hook(conv_hook))
+        elif isinstance(m, nn.Linear):
+            hooks.append(m.register_forward_hook(fc_hook))
+    was = model.training
+    model.eval()
+    with torch.no_grad():
+        dev = next(model.parameters()).device
+        model(torch.zeros(1, 3, hw, hw, device=dev, dtype=next(model.parameters()).dtype))
+    model.train(was)
+    for h in hooks:
+        h.remove()
+    return macs

@@ -1,0 +1,166 @@
+"""The reference's own call sites, run against this package on the GPU: criterion / Embedder / trainer objects with the
+reference's names and signatures, checked against the reference-generated fixtures and the oracle."""
+import os
+import numpy as np
+import pytest
+import torch
+from conftest import GOLDEN
+from oracle import cone_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+from learning_embeddings_amd import oe_h, embed_toy, order_embeddings, loss as loss_mod, experiment, ops  # noqa: E402
+from learning_embeddings_amd.hierarchy import NegativeGraph, SyntheticLabelMap  # noqa: E402
+from learning_embeddings_amd.engine import StepEngine  # noqa: E402
+
+DEV = 'cuda'
+
+
+class _IdentityCNN(torch.nn.Module):
+    """Stand-in for FeatCNN18 exactly as in the fixture generator: the "image" IS its raw CNN output row; the criterion
+    applies FeatCNN18.soft_clip (fused in the kernel)."""
+    def __init__(self, K):
+        super().__init__(); self.K = K
+    def forward_raw(self, x):
+        return x.float()
+    def forward(self, x):
+        return ops.ImageSoftClipFn.apply(x.float(), self.K)
+
+
+@pytest.mark.parametrize('tag', ['s3', 'ethec'])
+def test_criterion_call_site_vs_reference_fixture(tag):
+    f = np.load(os.path.join(GOLDEN, 'F5_criterion.npz'))
+    g = lambda k: f[tag + '_' + k]
+    lm = SyntheticLabelMap(g('levels').tolist(), edges=[tuple(e) for e in g('edges').tolist()])
+    N, M, Kn = lm.n_classes, int(g('n_images')), int(g('Kneg'))
+    names = ['img_%06d' % j for j in range(M)]
+    n2i = {i: i for i in range(N)}; n2i.update({names[j]: N + j for j in range(M)}); i2n = {v: k for k, v in n2i.items()}
+    crit = oe_h.EuclideanConesWithImagesHypernymLoss(lm, Kn, {}, float(g('alpha')), bool(g('pick_per_level')), K=float(g('K')), use_CNN=True)
+    crit.set_negative_graph(NegativeGraph.from_labelmap(lm, n_images=M, pick_per_level=bool(g('pick_per_level')), seed=0), n2i, i2n)
+    R = torch.tensor(g('R'), device=DEV, requires_grad=True)
+
+    class DL:
+        def get_image(self, fname):
+            return R[n2i[fname] - N]
+    crit.set_dataloader(DL())
+    model = oe_h.Embedder(g('W').shape[1], lm, None, K=float(g('K'))).to(DEV)
+    with torch.no_grad():
+        model.embeddings.weight.copy_(torch.tensor(g('W')))
+    of = [i2n[int(i)] for i in g('from')]; ot = [i2n[int(i)] for i in g('to')]
+    inputs_to = [R[n2i[t] - N] if isinstance(t, str) else t for t in ot]
+    crit.seed_sampler(0)                                                    # random.seed(0) right before the call
+    loss, e_pos, e_neg = crit(model, _IdentityCNN(float(g('K'))), list(of), inputs_to, of, ot, torch.ones(len(of)), 'train')
+    assert np.array_equal(crit.last_negatives, g('neg'))                    # bit-exact negative selection
+    assert e_neg.shape == g('e_neg').shape and e_pos.shape == g('e_pos').shape
+    loss.backward()
+    assert np.abs(e_pos.detach().cpu().numpy() - g('e_pos')).max() <= 1e-4
+    assert np.abs(e_neg.detach().cpu().numpy() - g('e_neg')).max() <= 1e-4
+    assert abs(loss.item() - float(g('loss'))) <= 1e-4 * abs(float(g('loss')))
+    gW = model.embeddings.weight.grad.cpu().numpy()
+    assert np.abs(gW - g('gW')).max() / np.abs(g('gW')).max() < 1e-3
+    assert np.abs(R.grad.cpu().numpy() - g('gR')).max() / np.abs(g('gR')).max() < 1e-3
+    # the reference's single-draw API, same stream
+    crit.seed_sampler(0)
+    assert crit.sample_negative_edge(u=of[0], v=None, level_id=0) == int(g('neg')[0, 0])
+
+
+def test_criterion_eval_branch_and_E_operator():
+    lm = SyntheticLabelMap([2, 4, 8])
+    crit = oe_h.EuclideanConesWithImagesHypernymLoss(lm, 2, {}, 0.05, False, K=0.1, use_CNN=True)
+    model = oe_h.Embedder(10, lm, None, K=0.1).to(DEV)
+    f = torch.rand(5, 5, 10, device=DEV) * 0.3; t = torch.rand(5, 5, 10, device=DEV) * 0.3
+    loss, e_pos, e_neg = crit(model, None, f, t, None, None, None, 'val')   # pre-built [B, 1+2K, D] tensors (oe_h.py:908-925)
+    fo, to = f.cpu().numpy(), t.cpu().numpy()
+    want_pos = O.cone_energy(fo[:, 0], to[:, 0], 0.1); want_neg = O.cone_energy(fo[:, 1:], to[:, 1:], 0.1)
+    assert np.abs(e_pos.cpu().numpy() - want_pos).max() < 1e-4 and np.abs(e_neg.cpu().numpy() - want_neg).max() < 1e-4
+    assert abs(loss.item() - (want_pos.sum() + np.maximum(0.05 - want_neg, 0).sum())) < 1e-3
+    emb = model(torch.tensor([[0, 3], [5, 7]], device=DEV))
+    assert emb.shape == (2, 2, 10)
+    assert np.abs(emb.detach().cpu().numpy().reshape(4, 10) - O.embedder_forward(model.embeddings.weight.detach().cpu().numpy(), [0, 3, 5, 7], 0.1)).max() < 2e-6
+
+
+def test_config1_toy_order_embedding_step():
+    f = np.load(os.path.join(GOLDEN, 'F7_order_embedding.npz'))
+    g_ = embed_toy.ToyGraph(levels=4, branching_factor=3)
+    crit = order_embeddings.OrderEmbeddingLoss(g_, neg_to_pos_ratio=4, alpha=1.0, pick_per_level=True)
+    tr = embed_toy.ToyOrderEmbedding(g_, crit, lr=0.1, batch_size=16, embedding_dim=6, neg_to_pos_ratio=4)
+    with torch.no_grad():
+        tr.model.embeddings.weight.copy_(torch.tensor(f['toy3_W']))
+    W0 = f['toy3_W'].copy()
+    loss, e_pos, e_neg = tr.train_step(f['toy3_from'].tolist(), f['toy3_to'].tolist())
+    assert np.array_equal(crit.last_negatives, f['toy3_neg'])
+    assert abs(loss.item() - float(f['toy3_loss'])) < 1e-4 * abs(float(f['toy3_loss']))
+    assert np.abs(e_neg.cpu().numpy() - f['toy3_e_neg']).max() < 1e-5
+    # the update is a plain Adam step on the reference gradient (no Riemannian rescale, no clip in the Euclidean trainer)
+    Wo, _, _ = O.adam_update(W0, f['toy3_gW'], np.zeros_like(W0), np.zeros_like(W0), 1, 0.1)
+    assert np.abs(tr.model.embeddings.weight.detach().cpu().numpy() - Wo).max() < 1e-5
+
+
+def test_config4_multilevel_ce_trainer_step():
+    lm = SyntheticLabelMap.ethec()
+    crit = loss_mod.MultiLevelCELoss(lm)
+    exp = experiment.ETHECExperiment({}, lm, crit, lr=1e-3, batch_size=8, model_name='resnet18', experiment_dir='/tmp/lec_exp',
+                                     compute_dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(8, 3, 32, 32, generator=g)
+    lvl = torch.stack([torch.randint(0, n, (8,), generator=g) for n in lm.levels], 1)
+    w0 = exp.arena.data.clone()
+    l1, out = exp.train_step(x, None, lvl)
+    assert out.shape == (8, 723) and torch.isfinite(l1)
+    ol, _ = O.multilevel_ce(out.detach().float().cpu().numpy(), lvl.numpy(), lm.levels)
+    assert abs(l1.item() - ol) < 1e-4 * ol
+    assert (exp.arena.data - w0).abs().max().item() > 0                     # parameters moved
+    l2, _ = exp.train_step(x, None, lvl)
+    assert l2.item() < l1.item()                                            # same batch again: the loss goes down
+
+
+def test_step_engine_matches_oracle_stream_and_loss():
+    eng = StepEngine('tiny', n_images=64, dtype='fp32')
+    lm = eng.labelmap
+    leaf = [lm.level_start[-1] + (j % lm.levels[-1]) for j in range(64)]
+    A = O.dense_negative_adjacency(lm.n_classes, sorted(lm.edges), leaf)
+    smp = O.DenseSampler(A, lm.levels, pick_per_level=True, seed=0)
+    m_prev = np.zeros_like(eng.table.cpu().numpy()); v_prev = m_prev.copy()
+    for s in range(3):
+        W0 = eng.table.cpu().numpy().copy()
+        got = {}
+        h = eng.img_feat_net.model.fc.register_forward_hook(lambda m, i, o: got.__setitem__('f', o.detach().float().cpu().numpy()))
+        eng.step(); torch.cuda.synchronize(); h.remove()
+        loss, e_pos, e_neg, frm, to, neg = eng.last
+        want = smp.draw_batch(frm, to, eng.K)
+        assert np.array_equal(neg, want)                                    # engine's threaded prefetch == reference stream
+        B, N = eng.B, eng.N
+        neg_o = neg.astype(np.int64).copy()
+        cols = np.asarray(eng.img_passes)
+        neg_o[:, cols] = N + B + np.arange(B)[:, None] * eng.cnt + np.arange(eng.cnt)[None, :]
+        o = O.joint_loss_fwd_bwd(W0, got['f'], frm, N + np.arange(B), neg_o, eng.alpha, eng.K_cone)
+        assert abs(loss.item() - o[0]) <= 1e-4 * max(1, abs(o[0]))
+        assert np.abs(e_neg.cpu().numpy() - o[2]).max() <= 1e-4
+        # table update = the oracle's rescale -> Adam -> clip on the oracle's gradient
+        Wn, m_prev, v_prev = O.table_step_adam(W0, o[3].astype(np.float32), m_prev, v_prev, s + 1, eng.lr, eng.K_cone)
+        assert np.abs(eng.table.cpu().numpy() - Wn).max() < 5e-6
+    eng.close()
+
+
+def test_joint_embeddings_trainer_runs_and_learns(tmp_path):
+    from test_host_cpu import _fake_loaders
+    lm = SyntheticLabelMap([2, 4, 8])
+    dl = _fake_loaders(lm, 32, 8)
+    for split in dl.values():                                               # real-looking images: 3x32x32 in [0,1)
+        for b in split:
+            b['path_to_image'] = [torch.rand(3, 32, 32, generator=torch.Generator().manual_seed(int(n[4:]))) for n in b['image_filename']]
+    gd = oe_h.create_combined_graphs(dl, lm, pick_per_level=True)
+    crit = oe_h.EuclideanConesWithImagesHypernymLoss(lm, 5, {}, 0.05, True, K=0.1, use_CNN=True)
+    tr = oe_h.JointEmbeddings(gd, dl, image_dir='', use_CNN=True, labelmap=lm, criterion=crit, lr=1e-3, n_workers=0,
+                              batch_size=16, experiment_name='t', embedding_dim=10, neg_to_pos_ratio=5, image_fc7=None,
+                              normalize=None, alpha=0.05, experiment_dir=str(tmp_path), n_epochs=2, eval_interval=1)
+    assert len(tr.datasets['train']) == gd['G_train_tc'].size()
+    tr.run_model()
+    assert np.isfinite(tr.last_epoch_loss)
+    n = tr.model.embeddings.weight.detach().norm(dim=1)
+    assert n.min().item() >= O.inner_radius(0.1) - 1e-6 and n.max().item() <= 1.0      # oe_h.py:1771 clip invariant
+    assert set(['m-f1', 'hit@1', 'hit@5', 'M-f1']).issubset(tr.last_metrics)
+    assert os.path.exists(os.path.join(tr.path_to_save_model, 'best_model_model.pth'))
+    tr.load_model('best_model')
+    sd = torch.load(os.path.join(tr.path_to_save_model, '0_model.pth'))['model_state_dict']
+    assert list(sd) == ['module.embeddings.weight']                          # the reference's DataParallel key prefix

@@ -1,0 +1,161 @@
+"""Host logic that runs without a GPU: Embedder init parity (a1), labelmaps, graph construction, DP plumbing over gloo."""
+import json, os, socket, sys
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+from conftest import GOLDEN, ROOT
+from oracle import cone_oracle as O
+from learning_embeddings_amd.hierarchy import SyntheticLabelMap, NegativeGraph, SYNTHETIC
+from learning_embeddings_amd import oe_h, embed_toy, parallel
+from learning_embeddings_amd.oe_h_trainer import DiGraph, transitive_closure, create_combined_graphs, EmbeddingMetrics, GlobalBatchSampler
+
+
+def test_embedder_init_matches_reference_seed0():
+    f = np.load(os.path.join(GOLDEN, 'F2_embedder.npz'))
+    torch.manual_seed(0)
+    emb = oe_h.Embedder(10, SyntheticLabelMap.ethec(), None, K=0.1)      # same RNG consumption order as oe_h.py:62-73
+    assert np.array_equal(emb.embeddings.weight.detach().numpy(), f['W_init'])
+    assert abs(emb.inner_radius - float(f['inner_radius'])) < 1e-15
+    assert abs(float(emb.inner_radius_h) - float(f['inner_radius_h'])) < 1e-7
+
+
+def test_toygraph_matches_reference_fixture():
+    f = np.load(os.path.join(GOLDEN, 'F7_order_embedding.npz'))
+    for tag, (lv, b) in (('toy2', (3, 2)), ('toy3', (4, 3))):
+        g = embed_toy.ToyGraph(levels=lv, branching_factor=b)
+        assert g.levels == f[tag + '_levels'].tolist()
+        assert sorted(g.edges) == [tuple(e) for e in f[tag + '_edges'].tolist()]
+
+
+def test_ethec_labelmap_fixture():
+    lm = SyntheticLabelMap.ethec()
+    assert lm.levels == [6, 21, 135, 561] and lm.n_classes == 723 and len(lm.edges) == 717
+    assert lm.level_start == [0, 6, 27, 162] and lm.level_stop == [6, 27, 162, 723]
+
+
+def _fake_loaders(lm, n_train, n_val):
+    par = lm.parents()
+    def rec(j):
+        leaf = lm.level_start[-1] + j % lm.levels[-1]; chain = [leaf]
+        while chain[-1] in par:
+            chain.append(par[chain[-1]][0])
+        chain = chain[::-1]
+        return [c - lm.level_start[l] for l, c in enumerate(chain)]
+    def loader(lo, hi, bs=4):
+        out = []
+        for s in range(lo, hi, bs):
+            js = list(range(s, min(s + bs, hi)))
+            out.append({'level_labels': np.array([rec(j) for j in js]), 'image_filename': ['img_%06d' % j for j in js],
+                        'path_to_image': [torch.full((3, 8, 8), float(j)) for j in js]})
+        return out
+    return {'train': loader(0, n_train), 'val': loader(n_train, n_train + n_val), 'test': loader(n_train + n_val, n_train + 2 * n_val)}
+
+
+def test_create_combined_graphs_matches_dense_construction():
+    lm = SyntheticLabelMap([2, 4, 8])
+    dl = _fake_loaders(lm, 24, 6)
+    gd = create_combined_graphs(dl, lm, pick_per_level=True)
+    N = lm.n_classes
+    assert gd['G_train_tc'].size() == len(transitive_closure_edges(lm)) + 24 * 3
+    assert gd['mapping_node_to_ix']['img_000000'] == N and gd['mapping_ix_to_node'][N + 23] == 'img_000023'
+    leaf = [lm.level_start[-1] + j % lm.levels[-1] for j in range(24)]
+    A = O.dense_negative_adjacency(N, sorted(lm.edges), leaf)
+    s = O.DenseSampler(A, lm.levels, pick_per_level=True, seed=0)
+    g = gd['G_train_neg']; g.seed(0)
+    rs = np.random.RandomState(0)
+    for _ in range(300):
+        side, node, lvl = int(rs.randint(2)), int(rs.randint(N + 24)), int(rs.randint(8))
+        try:
+            want = s.draw(side, node, lvl)
+        except IndexError:
+            with pytest.raises(IndexError):
+                g.draw(side, node, lvl)
+            continue
+        assert g.draw(side, node, lvl) == want
+
+
+def transitive_closure_edges(lm):
+    G = DiGraph(); G.add_edges_from(sorted(lm.edges))
+    return transitive_closure(G).edges()
+
+
+def test_embedding_metrics_threshold_sweep_equals_bruteforce():
+    rs = np.random.RandomState(0)
+    p = torch.tensor(rs.rand(40) * 0.5); n = torch.tensor(rs.rand(200) * 0.8 + 0.1)
+    m = EmbeddingMetrics(p, n, 0.0, 'val')
+    best = m.calculate_metrics()
+    brute = max((m.calculate_best(t) for t in np.unique(np.concatenate((p.numpy(), n.numpy())))), key=lambda r: r[0])
+    assert abs(best[0] - brute[0]) < 1e-12
+
+
+def test_global_batch_sampler_shards_partition_the_global_batch():
+    for world in (1, 2, 4):
+        parts = [list(GlobalBatchSampler(64, 4, shuffle=True, seed=3, rank=r, world=world)) for r in range(world)]
+        ref = GlobalBatchSampler(64, 4, shuffle=True, seed=3, rank=0, world=world).global_batches()
+        for i, gb in enumerate(ref):
+            assert sum((parts[r][i] for r in range(world)), []) == gb
+
+
+# ------------------------------------------------------------------------------------------------ world_size-2 gloo
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from learning_embeddings_amd import parallel as par
+    from learning_embeddings_amd.hierarchy import SyntheticLabelMap as LM, NegativeGraph as NG
+    r, lr_, w = par.init_process_group('gloo')
+    torch.manual_seed(0)                                           # identical replicas
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    arena = par.FlatArena(net.parameters(), torch.device('cpu'))
+    table_grad = torch.zeros(4, 3)
+    red = par.GradientReducer(arena, bucket_mb=1e-5, extra=[table_grad])     # tiny buckets: several all-reduces
+    X = torch.arange(48, dtype=torch.float32).reshape(8, 6) / 10.0
+    lo, hi = par.shard_range(8)
+    arena.zero_grad()
+    net(X[lo:hi]).pow(2).sum().backward()                          # SUM loss over the shard
+    table_grad += float(rank + 1)
+    red.finish()
+    # sampler: replicated mode -> shard of the global stream
+    lm = LM([2, 4, 8])
+    g = NG.from_labelmap(lm, n_images=16, pick_per_level=True, seed=0)
+    def positives(s):
+        b = np.arange(8); j = (s * 8 + b) % 16
+        return (6 + j % 8).astype(np.int32), (14 + j).astype(np.int32)
+    pf = par.NegativePrefetcher(g, positives, 3, mode='replicated')
+    shards = [pf.next() for _ in range(3)]
+    pf.close()
+    q.put((rank, arena.grad.clone().numpy(), table_grad.numpy(), [s[2] for s in shards], [s[0] for s in shards]))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_dp_two_ranks_gloo_sum_allreduce_and_replicated_sampler():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs: p.join(60)
+    # single-process reference: gradient of the SUM loss over the whole batch
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    arena = parallel.FlatArena(net.parameters(), torch.device('cpu'))
+    X = torch.arange(48, dtype=torch.float32).reshape(8, 6) / 10.0
+    net(X).pow(2).sum().backward()
+    for r in range(world):
+        assert np.allclose(res[r][1], arena.grad.numpy(), rtol=1e-5, atol=1e-6)      # SUM (not mean) of shard grads
+        assert np.allclose(res[r][2], 3.0)                                             # extras ride along: 1 + 2
+    # negatives: concatenating the rank shards reproduces the single-process global stream bit for bit
+    lm = SyntheticLabelMap([2, 4, 8])
+    g = NegativeGraph.from_labelmap(lm, n_images=16, pick_per_level=True, seed=0)
+    for s in range(3):
+        b = np.arange(8); j = (s * 8 + b) % 16
+        want = g.draw_batch((6 + j % 8).astype(np.int32), (14 + j).astype(np.int32), 3)
+        got = np.concatenate([res[r][3][s] for r in range(world)])
+        assert np.array_equal(got, want)

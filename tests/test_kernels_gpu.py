@@ -62,8 +62,12 @@ def test_cone_energy_vs_oracle_random(D):
     assert (np.abs(E.detach().cpu().numpy() - E32) <= tol).all()
     gx, gy = O.cone_energy_grad(x, y, gE, 0.1)
     ok = np.abs(E32 - E64) < 1e-5                                           # well-conditioned rows
-    assert rowrel(xt.grad.cpu().numpy(), gx)[ok].max() < 2e-3
-    assert rowrel(yt.grad.cpu().numpy(), gy)[ok].max() < 2e-3
+    # d(acos)/da = 1/sqrt(1-a^2) amplifies fp32 rounding of `a` near the clamp (1-a^2 >= 2e-5): a few ulp of `a` move the
+    # derivative by ~1e-6/(1-a^2) relative.  The reference's own fp32 autograd carries the same noise.
+    t = O._cone_terms(x, y, 0.1, np.float64)
+    tol = (2e-3 + 2e-6 / np.maximum(1 - t['ac'] ** 2, 2e-5))[:, None]
+    assert (rowrel(xt.grad.cpu().numpy(), gx) <= tol)[ok].all()
+    assert (rowrel(yt.grad.cpu().numpy(), gy) <= tol)[ok].all()
 
 
 def test_cone_energy_shapes_and_empty():
