@@ -168,6 +168,26 @@ int lec_multilevel_ce_fwd_bwd(const float* logits, int64_t ld, const int64_t* le
                               float* loss, float* glogits, void* workspace, int64_t workspace_bytes,
                               lec_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * (7) Fused BatchNorm (+ residual add) (+ ReLU) on NHWC bf16 activations -- the HBM-bound half of the ResNet backbone
+ *     behind FeatCNN18 / FeatCNN (oe_h.py:311,317 -> torchvision BasicBlock/Bottleneck: `relu(bn(conv(x)))`,
+ *     `relu(bn(conv(x)) + identity)`, downsample `bn(conv(x))`) and their autograd.
+ *     x, residual, y, dy, dx, dresidual: bf16 [M, C], C innermost (M = N*H*W), C % 8 == 0, C <= 2048.
+ *     gamma, beta, running_mean/var, save_mean/invstd: fp32 [C].  training != 0: batch statistics (biased variance for normalisation,
+ *     unbiased for the running estimate, running = (1-momentum)*running + momentum*batch; running stats may be NULL);
+ *     training == 0: running statistics.  y = [relu](x*scale + shift [+ residual]).
+ *     Backward: g = dy * [y > 0] (relu) ; dbeta = sum g ; dgamma = sum g*xhat ; dx = gamma*invstd*(g - mean(g) -
+ *     xhat*mean(g*xhat)) ; dresidual = g (pass NULL when the layer had no residual).
+ *     workspace: >= lec_bn_workspace_bytes(C) bytes, reusable across layers on one stream.
+ * ------------------------------------------------------------------------------------------------------------- */
+int64_t lec_bn_workspace_bytes(int C);
+int lec_bn_fwd(const void* x, const void* residual, int64_t M, int C, const float* gamma, const float* beta, float eps,
+               float momentum, float* running_mean, float* running_var, int training, float* save_mean,
+               float* save_invstd, void* y, int relu, void* workspace, int64_t workspace_bytes, lec_stream_t stream);
+int lec_bn_bwd(const void* dy, const void* y, const void* x, int64_t M, int C, const float* gamma,
+               const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma,
+               float* dbeta, int relu, void* workspace, int64_t workspace_bytes, lec_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

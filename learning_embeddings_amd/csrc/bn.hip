@@ -1,0 +1,334 @@
+// Fused BatchNorm (+ residual add) (+ ReLU) for NHWC bf16 activations: the HBM-bound half of the ResNet backbone.
+//
+// In the reference these are torchvision ResNet's `bn(conv(x))`, `relu(...)`, `out += identity` inside FeatCNN18's
+// backbone (oe_h.py:311,317 -> torchvision BasicBlock/Bottleneck.forward): 3-4 separate framework kernels per layer in
+// each direction.  The rocprof trace of the first end-to-end step (profiles/r01_bench_cfg3_steady_state.md) put
+// batchnorm at 37 % and relu/add at a further ~17 % of the step, all streaming work running at 2.4-3.4 TB/s.
+// Here a layer is   stats pass (read x) -> apply pass (read x [+ residual], write y = relu(x*scale+shift [+ r]))
+// and backward is   reduce pass (read dy, y, x) -> apply pass (read dy, y, x; write dx [+ d residual]).
+//
+// Layout: x is [M, C] with C innermost (NHWC, M = N*H*W), bf16; C % 8 == 0.  One thread owns 8 consecutive channels
+// (one 16-byte load); a 256-thread block covers 256/(C/8) rows per sweep and strides the row range with several
+// independent 16-byte loads in flight.  Per-channel reductions: registers -> LDS across the block's row groups ->
+// one fp32 partial per block and channel -> finalize kernel (double accumulation over <= 1024 partials).
+// Roofline: HBM. Algorithmic bytes per element (bf16): fwd 2+2+2 (+2 residual); bwd 6 (reduce) + 6+2 (+2 d residual).
+#include <hip/hip_bf16.h>
+#include "lec_common.h"
+
+namespace lec {
+
+struct alignas(16) bf16x8 { unsigned short v[8]; };
+
+__device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float(((unsigned int)u) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  __hip_bfloat16 h = __float2bfloat16(f);                 // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+  return *reinterpret_cast<unsigned short*>(&h);
+}
+
+constexpr int kBnThreads = 256;
+constexpr int kBnMaxBlocks = 1024;
+
+struct BnGeom { int CV, RPI, nblk; };
+static inline BnGeom bn_geom(int64_t M, int C) {
+  BnGeom g; g.CV = C / 8; g.RPI = kBnThreads / g.CV;
+  int64_t nb = (M + g.RPI - 1) / g.RPI;
+  // >= 4 sweeps per block so that partial sums amortise; <= 1024 blocks (4 per CU)
+  int64_t want = (nb + 3) / 4;
+  g.nblk = (int)(want < 1 ? 1 : (want > kBnMaxBlocks ? kBnMaxBlocks : want));
+  return g;
+}
+
+// block-level reduction of NV per-thread float[8] accumulators over the RPI row groups; result valid for threads
+// of row group 0 (tid < CV).  smem must hold kBnThreads * 8 floats.
+template <int NV>
+__device__ __forceinline__ void block_reduce_rows(float (&acc)[NV][8], int CV, int RPI, float* smem) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int a = 0; a < NV; ++a) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) smem[j * kBnThreads + tid] = acc[a][j];       // [j][tid]: conflict-free
+    __syncthreads();
+    if (tid < CV) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float s = 0.0f;
+        for (int r = 0; r < RPI; ++r) s += smem[j * kBnThreads + r * CV + tid];
+        acc[a][j] = s;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward, pass 1: per-block partial sum / sum of squares per channel -> part[blk][2][C]
+__global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const bf16x8* __restrict__ x, int64_t M, int C, int CV, int RPI,
+                                                              float* __restrict__ part) {
+  __shared__ float smem[kBnThreads * 8];
+  const int tid = threadIdx.x;
+  const int cv = tid % CV, rg = tid / CV;
+  const bool live = rg < RPI;
+  float acc[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; }
+  const int64_t stride = (int64_t)gridDim.x * RPI;
+  if (live) {
+    int64_t r = (int64_t)blockIdx.x * RPI + rg;
+    for (; r + 3 * stride < M; r += 4 * stride) {                            // 4 independent 16-byte loads in flight
+      bf16x8 a = x[r * CV + cv], b = x[(r + stride) * CV + cv], c = x[(r + 2 * stride) * CV + cv], d = x[(r + 3 * stride) * CV + cv];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float fa = bf2f(a.v[j]), fb = bf2f(b.v[j]), fc = bf2f(c.v[j]), fd = bf2f(d.v[j]);
+        acc[0][j] += (fa + fb) + (fc + fd);
+        acc[1][j] += (fa * fa + fb * fb) + (fc * fc + fd * fd);
+      }
+    }
+    for (; r < M; r += stride) {
+      bf16x8 a = x[r * CV + cv];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float fa = bf2f(a.v[j]); acc[0][j] += fa; acc[1][j] += fa * fa; }
+    }
+  }
+  block_reduce_rows<2>(acc, CV, RPI, smem);
+  if (tid < CV) {
+    float* p = part + (int64_t)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { p[cv * 8 + j] = acc[0][j]; p[C + cv * 8 + j] = acc[1][j]; }
+  }
+}
+
+// forward, pass 1b: reduce the partials (double), produce scale/shift, saved mean/invstd, running statistics
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nblk, int C, int64_t M,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                         float momentum, float* running_mean, float* running_var,
+                                         float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                         float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblk; ++b) { s += (double)part[(int64_t)b * 2 * C + c]; q += (double)part[(int64_t)b * 2 * C + C + c]; }
+  const double mean = s / (double)M;
+  double var = q / (double)M - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  save_mean[c] = (float)mean; save_invstd[c] = invstd;
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc; shift[c] = beta[c] - (float)mean * sc;
+  if (running_mean) {
+    const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// eval mode: scale/shift from the running statistics
+__global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                     const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                     float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(running_var[c] + eps);
+  scale[c] = sc; shift[c] = beta[c] - running_mean[c] * sc;
+}
+
+// forward, pass 2: y = [relu]( x * scale + shift [+ residual] )
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const bf16x8* __restrict__ x, const bf16x8* __restrict__ res,
+                                                              int64_t M, int CV, int RPI, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, bf16x8* __restrict__ y) {
+  const int tid = threadIdx.x;
+  const int cv = tid % CV, rg = tid / CV;
+  if (rg >= RPI) return;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = scale[cv * 8 + j]; sh[j] = shift[cv * 8 + j]; }
+  const int64_t stride = (int64_t)gridDim.x * RPI;
+  auto one = [&](bf16x8 a, bf16x8 r) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = bf2f(a.v[j]) * sc[j] + sh[j];
+      if (RES) v += bf2f(r.v[j]);
+      if (RELU) v = v > 0.0f ? v : 0.0f;
+      o.v[j] = f2bf(v);
+    }
+    return o;
+  };
+  int64_t r = (int64_t)blockIdx.x * RPI + rg;
+  for (; r + 3 * stride < M; r += 4 * stride) {
+    const int64_t i0 = r * CV + cv, i1 = (r + stride) * CV + cv, i2 = (r + 2 * stride) * CV + cv, i3 = (r + 3 * stride) * CV + cv;
+    bf16x8 a = x[i0], b = x[i1], c = x[i2], d = x[i3];
+    bf16x8 ra = a, rb = a, rc = a, rd = a;
+    if (RES) { ra = res[i0]; rb = res[i1]; rc = res[i2]; rd = res[i3]; }
+    y[i0] = one(a, ra); y[i1] = one(b, rb); y[i2] = one(c, rc); y[i3] = one(d, rd);
+  }
+  for (; r < M; r += stride) {
+    const int64_t i0 = r * CV + cv;
+    bf16x8 a = x[i0], ra = a;
+    if (RES) ra = res[i0];
+    y[i0] = one(a, ra);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward, pass 1: per-block partials of  dbeta = sum g,  dgamma = sum g * xhat,   g = dy * [y > 0]
+template <bool RELU>
+__global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const bf16x8* __restrict__ dy, const bf16x8* __restrict__ y,
+                                                                   const bf16x8* __restrict__ x, int64_t M, int C, int CV,
+                                                                   int RPI, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, float* __restrict__ part) {
+  __shared__ float smem[kBnThreads * 8];
+  const int tid = threadIdx.x;
+  const int cv = tid % CV, rg = tid / CV;
+  const bool live = rg < RPI;
+  float acc[2][8], mu[8], is[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; mu[j] = mean[cv * 8 + j]; is[j] = invstd[cv * 8 + j]; }
+  const int64_t stride = (int64_t)gridDim.x * RPI;
+  if (live) {
+    int64_t r = (int64_t)blockIdx.x * RPI + rg;
+    for (; r + stride < M; r += 2 * stride) {
+      const int64_t i0 = r * CV + cv, i1 = (r + stride) * CV + cv;
+      bf16x8 g0 = dy[i0], g1 = dy[i1], x0 = x[i0], x1 = x[i1];
+      bf16x8 y0 = g0, y1 = g1;
+      if (RELU) { y0 = y[i0]; y1 = y[i1]; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float a = bf2f(g0.v[j]), b = bf2f(g1.v[j]);
+        if (RELU) { a = bf2f(y0.v[j]) > 0.0f ? a : 0.0f; b = bf2f(y1.v[j]) > 0.0f ? b : 0.0f; }
+        acc[0][j] += a + b;
+        acc[1][j] += a * ((bf2f(x0.v[j]) - mu[j]) * is[j]) + b * ((bf2f(x1.v[j]) - mu[j]) * is[j]);
+      }
+    }
+    for (; r < M; r += stride) {
+      const int64_t i0 = r * CV + cv;
+      bf16x8 g0 = dy[i0], x0 = x[i0], y0 = g0;
+      if (RELU) y0 = y[i0];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float a = bf2f(g0.v[j]);
+        if (RELU) a = bf2f(y0.v[j]) > 0.0f ? a : 0.0f;
+        acc[0][j] += a; acc[1][j] += a * ((bf2f(x0.v[j]) - mu[j]) * is[j]);
+      }
+    }
+  }
+  block_reduce_rows<2>(acc, CV, RPI, smem);
+  if (tid < CV) {
+    float* p = part + (int64_t)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { p[cv * 8 + j] = acc[0][j]; p[C + cv * 8 + j] = acc[1][j]; }
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, int64_t M,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ c1, float* __restrict__ c2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblk; ++b) { s += (double)part[(int64_t)b * 2 * C + c]; q += (double)part[(int64_t)b * 2 * C + C + c]; }
+  dbeta[c] = (float)s; dgamma[c] = (float)q;
+  c1[c] = (float)(s / (double)M); c2[c] = (float)(q / (double)M);
+}
+
+// backward, pass 2: dx = gamma*invstd * (g - mean(g) - xhat * mean(g*xhat));  d residual = g
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(const bf16x8* __restrict__ dy, const bf16x8* __restrict__ y,
+                                                                  const bf16x8* __restrict__ x, int64_t M, int CV, int RPI,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd, const float* __restrict__ c1,
+                                                                  const float* __restrict__ c2, bf16x8* __restrict__ dx,
+                                                                  bf16x8* __restrict__ dres) {
+  const int tid = threadIdx.x;
+  const int cv = tid % CV, rg = tid / CV;
+  if (rg >= RPI) return;
+  float gs[8], mu[8], is[8], k1[8], k2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cv * 8 + j;
+    is[j] = invstd[c]; mu[j] = mean[c]; gs[j] = gamma[c] * is[j]; k1[j] = c1[c]; k2[j] = c2[c];
+  }
+  const int64_t stride = (int64_t)gridDim.x * RPI;
+  auto one = [&](int64_t i) {
+    bf16x8 g0 = dy[i], x0 = x[i], y0 = g0, o, gr;
+    if (RELU) y0 = y[i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a = bf2f(g0.v[j]);
+      if (RELU) a = bf2f(y0.v[j]) > 0.0f ? a : 0.0f;
+      const float xh = (bf2f(x0.v[j]) - mu[j]) * is[j];
+      o.v[j] = f2bf(gs[j] * (a - k1[j] - xh * k2[j]));
+      if (RES) gr.v[j] = f2bf(a);
+    }
+    dx[i] = o;
+    if (RES) dres[i] = gr;
+  };
+  int64_t r = (int64_t)blockIdx.x * RPI + rg;
+  for (; r + stride < M; r += 2 * stride) { one(r * CV + cv); one((r + stride) * CV + cv); }
+  for (; r < M; r += stride) one(r * CV + cv);
+}
+
+static int bn_check(const char* who, int64_t M, int C) {
+  LEC_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "%s: need M > 0 and C a multiple of 8 up to 2048 (M=%lld C=%d)", who, (long long)M, C);
+  return LEC_OK;
+}
+
+}  // namespace lec
+
+extern "C" int64_t lec_bn_workspace_bytes(int C) {
+  if (C <= 0) return LEC_E_ARG;
+  return ((int64_t)lec::kBnMaxBlocks * 2 * C + 4 * (int64_t)C) * sizeof(float);
+}
+
+extern "C" int lec_bn_fwd(const void* x, const void* residual, int64_t M, int C, const float* gamma, const float* beta,
+                          float eps, float momentum, float* running_mean, float* running_var, int training,
+                          float* save_mean, float* save_invstd, void* y, int relu, void* workspace,
+                          int64_t workspace_bytes, lec_stream_t stream) {
+  using namespace lec;
+  if (int rc = bn_check("bn_fwd", M, C)) return rc;
+  LEC_CHECK_ARG(x && gamma && beta && y && workspace, "bn_fwd: null pointer");
+  LEC_CHECK_ARG(workspace_bytes >= lec_bn_workspace_bytes(C), "bn_fwd: workspace too small");
+  LEC_CHECK_ARG(training ? (save_mean && save_invstd) : (running_mean && running_var), "bn_fwd: statistics buffers missing");
+  hipStream_t st = (hipStream_t)stream;
+  BnGeom g = bn_geom(M, C);
+  float* part = (float*)workspace;
+  float* scale = part + (int64_t)kBnMaxBlocks * 2 * C; float* shift = scale + C;
+  if (training) {
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(g.nblk), dim3(kBnThreads), 0, st, (const bf16x8*)x, M, C, g.CV, g.RPI, part);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, g.nblk, C, M, gamma, beta, eps,
+                       momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
+  } else {
+    hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3((C + 255) / 256), dim3(256), 0, st, C, gamma, beta, eps, running_mean, running_var, scale, shift);
+  }
+  int64_t nb = (M + g.RPI - 1) / g.RPI; nb = (nb + 3) / 4;
+  const int nblk = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
+#define A(RES_, RELU_) hipLaunchKernelGGL((bn_apply_kernel<RES_, RELU_>), dim3(nblk), dim3(kBnThreads), 0, st, (const bf16x8*)x, (const bf16x8*)residual, M, g.CV, g.RPI, scale, shift, (bf16x8*)y)
+  if (residual) { if (relu) A(true, true); else A(true, false); } else { if (relu) A(false, true); else A(false, false); }
+#undef A
+  LEC_CHECK_LAUNCH("bn_fwd kernels");
+  return LEC_OK;
+}
+
+extern "C" int lec_bn_bwd(const void* dy, const void* y, const void* x, int64_t M, int C, const float* gamma,
+                          const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma,
+                          float* dbeta, int relu, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+  using namespace lec;
+  if (int rc = bn_check("bn_bwd", M, C)) return rc;
+  LEC_CHECK_ARG(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && workspace, "bn_bwd: null pointer");
+  LEC_CHECK_ARG(!relu || y, "bn_bwd: the forward output y is needed for the ReLU mask");
+  LEC_CHECK_ARG(workspace_bytes >= lec_bn_workspace_bytes(C), "bn_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  BnGeom g = bn_geom(M, C);
+  float* part = (float*)workspace;
+  float* c1 = part + (int64_t)kBnMaxBlocks * 2 * C; float* c2 = c1 + C;
+  if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), dim3(g.nblk), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)y, (const bf16x8*)x, M, C, g.CV, g.RPI, save_mean, save_invstd, part);
+  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), dim3(g.nblk), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)y, (const bf16x8*)x, M, C, g.CV, g.RPI, save_mean, save_invstd, part);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, g.nblk, C, M, dgamma, dbeta, c1, c2);
+  int64_t nb = (M + g.RPI - 1) / g.RPI; nb = (nb + 1) / 2;
+  const int nblk = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
+#define A(RES_, RELU_) hipLaunchKernelGGL((bn_bwd_apply_kernel<RES_, RELU_>), dim3(nblk), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)y, (const bf16x8*)x, M, g.CV, g.RPI, gamma, save_mean, save_invstd, c1, c2, (bf16x8*)dx, (bf16x8*)dresidual)
+  if (dresidual) { if (relu) A(true, true); else A(true, false); } else { if (relu) A(false, true); else A(false, false); }
+#undef A
+  LEC_CHECK_LAUNCH("bn_bwd kernels");
+  return LEC_OK;
+}

@@ -257,3 +257,60 @@ class MultiLevelCEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gl):
         return (ctx.g * gl).to(ctx.dt), None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ fused BN (+add) (+ReLU)
+def _nhwc_rows(t, name):
+    """[N, C, H, W] channels_last bf16 tensor -> (M, C); raises unless the memory really is [M, C] with C innermost."""
+    if t.dtype != torch.bfloat16:
+        raise TypeError('%s must be bf16' % name)
+    if t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError('%s must be a 4-D channels_last tensor' % name)
+    N, Cc, H, W = t.shape
+    return N * H * W, Cc
+
+
+class BNActFn(torch.autograd.Function):
+    """y = [relu](batch_norm(x) [+ residual]) on NHWC bf16, two streaming passes forward, two backward."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+        M, Cc = _nhwc_rows(x, 'x')
+        if residual is not None and (_nhwc_rows(residual, 'residual') != (M, Cc)):
+            raise ValueError('residual shape mismatch')
+        y = torch.empty_like(x)                       # preserves channels_last
+        save_mean = torch.empty(Cc, dtype=torch.float32, device=x.device); save_invstd = torch.empty_like(save_mean)
+        ws = _bn_workspace(x.device)
+        check(lib.lec_bn_fwd(dptr(x), dptr(residual), M, Cc, dptr(weight), dptr(bias), float(eps), float(momentum),
+                             dptr(running_mean), dptr(running_var), int(bool(training)), dptr(save_mean), dptr(save_invstd),
+                             dptr(y), int(bool(relu)), dptr(ws), ws.numel(), stream_ptr()))
+        if training:
+            ctx.save_for_backward(x, y if relu else None, weight, save_mean, save_invstd)
+            ctx.meta = (M, Cc, bool(relu), residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, save_mean, save_invstd = ctx.saved_tensors
+        M, Cc, relu, has_res = ctx.meta
+        if not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device); dbeta = torch.empty_like(dgamma)
+        ws = _bn_workspace(x.device)
+        check(lib.lec_bn_bwd(dptr(dy), dptr(y), dptr(x), M, Cc, dptr(weight), dptr(save_mean), dptr(save_invstd), dptr(dx),
+                             dptr(dres), dptr(dgamma), dptr(dbeta), int(relu), dptr(ws), ws.numel(), stream_ptr()))
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
+
+
+_bn_ws = {}
+
+
+def _bn_workspace(device):
+    key = (device.type, device.index)
+    ws = _bn_ws.get(key)
+    if ws is None:
+        ws = torch.zeros(int(lib.lec_bn_workspace_bytes(2048)), dtype=torch.uint8, device=device)
+        _bn_ws[key] = ws
+    return ws

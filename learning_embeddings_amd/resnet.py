@@ -8,6 +8,32 @@ the GEMM-friendly layout, bf16 compute under autocast with fp32 master weights h
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
+
+
+class BatchNormAct2d(nn.BatchNorm2d):
+    """BatchNorm2d [+ residual add] [+ ReLU] as ONE op.  Same parameters / buffers / state-dict keys as nn.BatchNorm2d.
+    On the MI355X with NHWC bf16 activations it runs the fused HIP kernels of liblecone.so (csrc/bn.hip: two streaming
+    passes forward, two backward, instead of BN + add + ReLU framework kernels); fp32 activations (``--dtype fp32``) and
+    the CPU baseline leg of bench.py take the stock torch ops.  `num_batches_tracked` is not advanced (it only matters
+    for momentum=None, which the reference never uses)."""
+
+    def __init__(self, num_features, relu=False):
+        super().__init__(num_features)
+        self.fuse_relu = relu
+
+    def forward(self, x, residual=None):
+        if (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and self.num_features % 8 == 0
+                and self.num_features <= 2048 and x.is_contiguous(memory_format=torch.channels_last)
+                and (residual is None or (residual.dtype == torch.bfloat16 and residual.shape == x.shape
+                                          and residual.is_contiguous(memory_format=torch.channels_last)))):
+            from . import ops
+            return ops.BNActFn.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var,
+                                     self.training, self.momentum, self.eps, self.fuse_relu)
+        y = F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, self.training, self.momentum, self.eps)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if self.fuse_relu else y
 
 
 def conv3x3(cin, cout, stride=1):
@@ -23,16 +49,14 @@ class BasicBlock(nn.Module):
 
     def __init__(self, cin, planes, stride=1, downsample=None):
         super().__init__()
-        self.conv1 = conv3x3(cin, planes, stride); self.bn1 = nn.BatchNorm2d(planes)
-        self.relu = nn.ReLU(inplace=True)
-        self.conv2 = conv3x3(planes, planes); self.bn2 = nn.BatchNorm2d(planes)
+        self.conv1 = conv3x3(cin, planes, stride); self.bn1 = BatchNormAct2d(planes, relu=True)
+        self.conv2 = conv3x3(planes, planes); self.bn2 = BatchNormAct2d(planes, relu=True)     # relu(bn2(.) + identity)
         self.downsample = downsample
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        return self.relu(out + idt)
+        out = self.bn1(self.conv1(x))
+        return self.bn2(self.conv2(out), idt)
 
 
 class Bottleneck(nn.Module):
@@ -40,18 +64,16 @@ class Bottleneck(nn.Module):
 
     def __init__(self, cin, planes, stride=1, downsample=None):
         super().__init__()
-        self.conv1 = conv1x1(cin, planes); self.bn1 = nn.BatchNorm2d(planes)
-        self.conv2 = conv3x3(planes, planes, stride); self.bn2 = nn.BatchNorm2d(planes)      # stride on the 3x3 (v1.5)
-        self.conv3 = conv1x1(planes, planes * 4); self.bn3 = nn.BatchNorm2d(planes * 4)
-        self.relu = nn.ReLU(inplace=True)
+        self.conv1 = conv1x1(cin, planes); self.bn1 = BatchNormAct2d(planes, relu=True)
+        self.conv2 = conv3x3(planes, planes, stride); self.bn2 = BatchNormAct2d(planes, relu=True)   # stride on the 3x3 (v1.5)
+        self.conv3 = conv1x1(planes, planes * 4); self.bn3 = BatchNormAct2d(planes * 4, relu=True)  # relu(bn3(.) + identity)
         self.downsample = downsample
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        return self.relu(out + idt)
+        out = self.bn1(self.conv1(x))
+        out = self.bn2(self.conv2(out))
+        return self.bn3(self.conv3(out), idt)
 
 
 class ResNet(nn.Module):
@@ -59,8 +81,7 @@ class ResNet(nn.Module):
         super().__init__()
         self.inplanes = 64
         self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
-        self.relu = nn.ReLU(inplace=True)
+        self.bn1 = BatchNormAct2d(64, relu=True)
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
         self.layer1 = self._make_layer(block, 64, layers[0])
         self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
@@ -78,7 +99,7 @@ class ResNet(nn.Module):
         downsample = None
         if stride != 1 or self.inplanes != planes * block.expansion:
             downsample = nn.Sequential(conv1x1(self.inplanes, planes * block.expansion, stride),
-                                       nn.BatchNorm2d(planes * block.expansion))
+                                       BatchNormAct2d(planes * block.expansion, relu=False))
         layers = [block(self.inplanes, planes, stride, downsample)]
         self.inplanes = planes * block.expansion
         for _ in range(1, blocks):
@@ -86,7 +107,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(self.bn1(self.conv1(x)))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = torch.flatten(self.avgpool(x), 1)
         return self.fc(x)
