@@ -26,15 +26,20 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 }
 
 constexpr int kBnThreads = 256;
-constexpr int kBnMaxBlocks = 1024;
+constexpr int kBnMaxBlocks = 512;
 
-struct BnGeom { int CV, RPI, nblk; };
+// Reduction passes: a block owns a channel chunk of CVB 16-byte vectors (<= 64: up to 1 KiB contiguous per row) and a
+// strided set of rows; grid = (nrb row blocks, NCH channel chunks), nrb * NCH <= 512 blocks (2 per CU, 8 loads in flight
+// per thread).  Per channel there are nrb partials, reduced by a 1024-thread finalize kernel (32 channels x 32 splits).
+// Apply passes: a block covers whole rows (CV vectors), up to 2048 blocks.
+struct BnGeom { int CV, RPI, CVB, NCH, RPIB, nrb; };
 static inline BnGeom bn_geom(int64_t M, int C) {
   BnGeom g; g.CV = C / 8; g.RPI = kBnThreads / g.CV;
-  int64_t nb = (M + g.RPI - 1) / g.RPI;
-  // >= 4 sweeps per block so that partial sums amortise; <= 1024 blocks (4 per CU)
-  int64_t want = (nb + 3) / 4;
-  g.nblk = (int)(want < 1 ? 1 : (want > kBnMaxBlocks ? kBnMaxBlocks : want));
+  g.CVB = g.CV > 64 ? 64 : g.CV; g.NCH = g.CV / g.CVB; g.RPIB = kBnThreads / g.CVB;
+  int64_t nb = (M + g.RPIB - 1) / g.RPIB;
+  int64_t want = (nb + 7) / 8;                              // >= 8 sweeps per block
+  int64_t cap = kBnMaxBlocks / g.NCH;
+  g.nrb = (int)(want < 1 ? 1 : (want > cap ? cap : want));
   return g;
 }
 
@@ -61,26 +66,28 @@ __device__ __forceinline__ void block_reduce_rows(float (&acc)[NV][8], int CV, i
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// forward, pass 1: per-block partial sum / sum of squares per channel -> part[blk][2][C]
-__global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const bf16x8* __restrict__ x, int64_t M, int C, int CV, int RPI,
-                                                              float* __restrict__ part) {
+// forward, pass 1: per-block partial sum / sum of squares per channel -> part[rb][2][C]
+__global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const bf16x8* __restrict__ x, int64_t M, int C, int CV, int CVB,
+                                                              int RPIB, float* __restrict__ part) {
   __shared__ float smem[kBnThreads * 8];
   const int tid = threadIdx.x;
-  const int cv = tid % CV, rg = tid / CV;
-  const bool live = rg < RPI;
+  const int cvl = tid % CVB, rg = tid / CVB;
+  const int cv = blockIdx.y * CVB + cvl;
+  const bool live = rg < RPIB;
   float acc[2][8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; }
-  const int64_t stride = (int64_t)gridDim.x * RPI;
+  const int64_t stride = (int64_t)gridDim.x * RPIB;
   if (live) {
-    int64_t r = (int64_t)blockIdx.x * RPI + rg;
-    for (; r + 3 * stride < M; r += 4 * stride) {                            // 4 independent 16-byte loads in flight
-      bf16x8 a = x[r * CV + cv], b = x[(r + stride) * CV + cv], c = x[(r + 2 * stride) * CV + cv], d = x[(r + 3 * stride) * CV + cv];
+    int64_t r = (int64_t)blockIdx.x * RPIB + rg;
+    for (; r + 7 * stride < M; r += 8 * stride) {                            // 8 independent 16-byte loads in flight
+      bf16x8 v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float fa = bf2f(a.v[j]), fb = bf2f(b.v[j]), fc = bf2f(c.v[j]), fd = bf2f(d.v[j]);
-        acc[0][j] += (fa + fb) + (fc + fd);
-        acc[1][j] += (fa * fa + fb * fb) + (fc * fc + fd * fd);
+      for (int u = 0; u < 8; ++u) v[u] = x[(r + u * stride) * CV + cv];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { float f = bf2f(v[u].v[j]); acc[0][j] += f; acc[1][j] += f * f; }
       }
     }
     for (; r < M; r += stride) {
@@ -89,11 +96,27 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const bf16x8* __re
       for (int j = 0; j < 8; ++j) { float fa = bf2f(a.v[j]); acc[0][j] += fa; acc[1][j] += fa * fa; }
     }
   }
-  block_reduce_rows<2>(acc, CV, RPI, smem);
-  if (tid < CV) {
+  block_reduce_rows<2>(acc, CVB, RPIB, smem);
+  if (tid < CVB) {
     float* p = part + (int64_t)blockIdx.x * 2 * C;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { p[cv * 8 + j] = acc[0][j]; p[C + cv * 8 + j] = acc[1][j]; }
+  }
+}
+
+// sum of the nblk partials of two statistics for 32 channels per 1024-thread block (32 channels x 32 splits), double
+__device__ __forceinline__ void reduce_partials_1024(const float* __restrict__ part, int nblk, int C, int c, int split,
+                                                     double& s, double& q) {
+  __shared__ double sh[2][32][33];
+  double a = 0.0, b = 0.0;
+  if (c < C) {
+    for (int p = split; p < nblk; p += 32) { a += (double)part[(int64_t)p * 2 * C + c]; b += (double)part[(int64_t)p * 2 * C + C + c]; }
+  }
+  sh[0][split][threadIdx.x & 31] = a; sh[1][split][threadIdx.x & 31] = b;
+  __syncthreads();
+  s = 0.0; q = 0.0;
+  if (split == 0) {
+    for (int k = 0; k < 32; ++k) { s += sh[0][k][threadIdx.x & 31]; q += sh[1][k][threadIdx.x & 31]; }
   }
 }
 
@@ -103,10 +126,10 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nbl
                                          float momentum, float* running_mean, float* running_var,
                                          float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                          float* __restrict__ scale, float* __restrict__ shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; ++b) { s += (double)part[(int64_t)b * 2 * C + c]; q += (double)part[(int64_t)b * 2 * C + C + c]; }
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), split = threadIdx.x >> 5;
+  double s, q;
+  reduce_partials_1024(part, nblk, C, c, split, s, q);
+  if (split != 0 || c >= C) return;
   const double mean = s / (double)M;
   double var = q / (double)M - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -175,11 +198,12 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const bf16x8* __re
 template <bool RELU>
 __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const bf16x8* __restrict__ dy, const bf16x8* __restrict__ y,
                                                                    const bf16x8* __restrict__ x, int64_t M, int C, int CV,
-                                                                   int RPI, const float* __restrict__ mean,
+                                                                   int CVB, int RPI, const float* __restrict__ mean,
                                                                    const float* __restrict__ invstd, float* __restrict__ part) {
   __shared__ float smem[kBnThreads * 8];
   const int tid = threadIdx.x;
-  const int cv = tid % CV, rg = tid / CV;
+  const int cvl = tid % CVB, rg = tid / CVB;
+  const int cv = blockIdx.y * CVB + cvl;
   const bool live = rg < RPI;
   float acc[2][8], mu[8], is[8];
 #pragma unroll
@@ -212,8 +236,8 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const bf16x8*
       }
     }
   }
-  block_reduce_rows<2>(acc, CV, RPI, smem);
-  if (tid < CV) {
+  block_reduce_rows<2>(acc, CVB, RPI, smem);
+  if (tid < CVB) {
     float* p = part + (int64_t)blockIdx.x * 2 * C;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { p[cv * 8 + j] = acc[0][j]; p[C + cv * 8 + j] = acc[1][j]; }
@@ -223,10 +247,10 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const bf16x8*
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, int64_t M,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ c1, float* __restrict__ c2) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; ++b) { s += (double)part[(int64_t)b * 2 * C + c]; q += (double)part[(int64_t)b * 2 * C + C + c]; }
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), split = threadIdx.x >> 5;
+  double s, q;
+  reduce_partials_1024(part, nblk, C, c, split, s, q);
+  if (split != 0 || c >= C) return;
   dbeta[c] = (float)s; dgamma[c] = (float)q;
   c1[c] = (float)(s / (double)M); c2[c] = (float)(q / (double)M);
 }
@@ -269,7 +293,8 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(const bf16x8* 
 }
 
 static int bn_check(const char* who, int64_t M, int C) {
-  LEC_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "%s: need M > 0 and C a multiple of 8 up to 2048 (M=%lld C=%d)", who, (long long)M, C);
+  LEC_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0 && C <= 2048 && (C <= 512 || C % 512 == 0),
+                "%s: need M > 0 and C a multiple of 8 up to 512, or 1024 / 1536 / 2048 (M=%lld C=%d)", who, (long long)M, C);
   return LEC_OK;
 }
 
@@ -294,8 +319,8 @@ extern "C" int lec_bn_fwd(const void* x, const void* residual, int64_t M, int C,
   float* part = (float*)workspace;
   float* scale = part + (int64_t)kBnMaxBlocks * 2 * C; float* shift = scale + C;
   if (training) {
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(g.nblk), dim3(kBnThreads), 0, st, (const bf16x8*)x, M, C, g.CV, g.RPI, part);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, g.nblk, C, M, gamma, beta, eps,
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(g.nrb, g.NCH), dim3(kBnThreads), 0, st, (const bf16x8*)x, M, C, g.CV, g.CVB, g.RPIB, part);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, part, g.nrb, C, M, gamma, beta, eps,
                        momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
   } else {
     hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3((C + 255) / 256), dim3(256), 0, st, C, gamma, beta, eps, running_mean, running_var, scale, shift);
@@ -321,9 +346,9 @@ extern "C" int lec_bn_bwd(const void* dy, const void* y, const void* x, int64_t 
   BnGeom g = bn_geom(M, C);
   float* part = (float*)workspace;
   float* c1 = part + (int64_t)kBnMaxBlocks * 2 * C; float* c2 = c1 + C;
-  if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), dim3(g.nblk), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)y, (const bf16x8*)x, M, C, g.CV, g.RPI, save_mean, save_invstd, part);
-  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), dim3(g.nblk), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)y, (const bf16x8*)x, M, C, g.CV, g.RPI, save_mean, save_invstd, part);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, g.nblk, C, M, dgamma, dbeta, c1, c2);
+  if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), dim3(g.nrb, g.NCH), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)y, (const bf16x8*)x, M, C, g.CV, g.CVB, g.RPIB, save_mean, save_invstd, part);
+  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), dim3(g.nrb, g.NCH), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)y, (const bf16x8*)x, M, C, g.CV, g.CVB, g.RPIB, save_mean, save_invstd, part);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, part, g.nrb, C, M, dgamma, dbeta, c1, c2);
   int64_t nb = (M + g.RPI - 1) / g.RPI; nb = (nb + 1) / 2;
   const int nblk = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
 #define A(RES_, RELU_) hipLaunchKernelGGL((bn_bwd_apply_kernel<RES_, RELU_>), dim3(nblk), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)y, (const bf16x8*)x, M, g.CV, g.RPI, gamma, save_mean, save_invstd, c1, c2, (bf16x8*)dx, (bf16x8*)dresidual)

@@ -18,12 +18,14 @@ class BatchNormAct2d(nn.BatchNorm2d):
     the CPU baseline leg of bench.py take the stock torch ops.  `num_batches_tracked` is not advanced (it only matters
     for momentum=None, which the reference never uses)."""
 
+    fused_enabled = True            # class-wide switch (tests / A-B profiling): False -> stock torch ops everywhere
+
     def __init__(self, num_features, relu=False):
         super().__init__(num_features)
         self.fuse_relu = relu
 
     def forward(self, x, residual=None):
-        if (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and self.num_features % 8 == 0
+        if (BatchNormAct2d.fused_enabled and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and self.num_features % 8 == 0
                 and self.num_features <= 2048 and x.is_contiguous(memory_format=torch.channels_last)
                 and (residual is None or (residual.dtype == torch.bfloat16 and residual.shape == x.shape
                                           and residual.is_contiguous(memory_format=torch.channels_last)))):
