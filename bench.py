@@ -77,22 +77,33 @@ def main():
     ap.add_argument('--sampler', default='replicated', choices=['replicated', 'per_rank'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stress', action='store_true')
+    ap.add_argument('--cudnn-benchmark', action='store_true', help='let MIOpen benchmark every solver per conv shape (slow start)')
     args = ap.parse_args()
 
+    t_start = time.time()
+    def stamp(what):
+        if int(os.environ.get('RANK', 0)) == 0:
+            print('[bench %7.1f s] %s' % (time.time() - t_start, what), file=sys.stderr, flush=True)
+    from learning_embeddings_amd import miopen_tuning
+    miopen_tuning.setup()                                       # before the first convolution
     import torch
     import torch.distributed as dist
+    stamp('torch imported')
     from learning_embeddings_amd import ops, _lib, parallel
     from learning_embeddings_amd.engine import StepEngine, WORKLOADS
     from learning_embeddings_amd.resnet import conv_macs
 
+    torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
     rank, local_rank, world = parallel.init_process_group()
     if world != args.gpus and rank == 0:
         print('warning: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world), file=sys.stderr)
     eng = StepEngine(args.workload, dtype=args.dtype, sampler_mode=args.sampler, batch=args.batch)
     dev = eng.device
-
-    for _ in range(args.warmup):
+    stamp('engine built')
+    for i in range(args.warmup):
         eng.step()
+        if i < 2:
+            torch.cuda.synchronize(); stamp('warm-up step %d done' % i)
     eng.enable_timers()
     if world > 1:
         dist.barrier()
@@ -107,6 +118,7 @@ def main():
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    stamp('timed steps done')
     phases = eng.timer_summary()
     loss_mean = float(eng.loss_acc.item()) / (args.steps + args.warmup)
 

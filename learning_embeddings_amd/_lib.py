@@ -24,6 +24,10 @@ class EmptyCandidates(LeconeError, IndexError):
 
 
 def _load():
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so).  Import it FIRST so that liblecone.so binds to the
+    # runtime that owns torch's device context and streams; loading /opt/rocm's copy beside it gives a second runtime
+    # with no device ("no ROCm-capable device is detected" at the first launch).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             'liblecone.so not found at %s -- build it first: `python -c "import __graft_entry__ as g; g.build()"` '
