@@ -17,6 +17,9 @@
 //
 // Roofline: HBM / L2 bound gather + scatter; algorithmic bytes per positive (fwd+bwd, rows de-duplicated inside a
 // group) = (2+2K)(2*D*4 + 4*D + 4) + (1+2K)*8   (SURVEY.md 8d).
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include "lec_common.h"
 
 namespace lec {
@@ -33,6 +36,7 @@ struct JointParams {
   float* partials; unsigned int* counter;
   int iters;            // pair iterations per task
   int tasks_per_group;
+  int lds_stage;        // T == 1 only: move rows through LDS (coalesced gather/scatter)
 };
 
 // One projected row held across T lanes: raw e (after the +1e-15 of Embedder.forward), projected p, and the two
@@ -44,20 +48,104 @@ struct Row {
   float A, Bc;
 };
 
+// ---- T == 1 (one lane per pair, D <= 16): rows move between HBM/L2 and registers THROUGH LDS.  A lane-per-row global
+// access makes every load/atomic instruction touch 64 different cache lines (one dword each); staged, consecutive lanes
+// move consecutive elements of the gathered row list, so an instruction touches ~64/D rows in D-element runs, and each
+// lane then reads its own row from LDS at an odd stride (conflict-free).
+constexpr int kNoRow = INT_MIN;
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int EPL>
+__device__ __forceinline__ void wave_gather_rows(const JointParams& P, int code_or_norow, float* stage, float (&e)[EPL]) {
+  constexpr int LDW = EPL + 1;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) {
+    const int eidx = k * 64 + lane;
+    const int r = eidx / EPL, d = eidx - r * EPL;
+    const int rc = __shfl(code_or_norow, r, kWave);
+    float v = 0.0f;
+    if (rc != kNoRow && d < P.D) {
+      const float* src = rc >= 0 ? P.table + (int64_t)rc * P.ld_table : P.feat + (int64_t)(-1 - rc) * P.ld_feat;
+      v = src[d];
+    }
+    stage[r * LDW + d] = v;
+  }
+  wave_sync();
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) e[i] = stage[lane * LDW + i];
+  wave_sync();
+}
+
+template <int EPL>
+__device__ __forceinline__ void wave_scatter_rows(const JointParams& P, int code_or_norow, float* stage, const float (&g)[EPL]) {
+  constexpr int LDW = EPL + 1;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) stage[lane * LDW + i] = g[i];
+  wave_sync();
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) {
+    const int eidx = k * 64 + lane;
+    const int r = eidx / EPL, d = eidx - r * EPL;
+    const int rc = __shfl(code_or_norow, r, kWave);
+    if (rc != kNoRow && d < P.D) {
+      float* dst = rc >= 0 ? P.grad_table + (int64_t)rc * P.ld_table : P.grad_feat + (int64_t)(-1 - rc) * P.ld_feat;
+      atomicAdd(dst + d, stage[r * LDW + d]);
+    }
+  }
+  wave_sync();
+}
+
+// raw row elements of node `code` owned by this lane (d = t, t+T, ...); kNoRow -> zeros, no memory access
 template <int T, int EPL>
-__device__ __forceinline__ void load_project(const JointParams& P, int code, bool valid, int t, Row<EPL>& r) {
+__device__ __forceinline__ void fetch_row(const JointParams& P, int code, int t, float (&raw)[EPL]) {
+  const float* src = P.table;
+  if (code != kNoRow) src = code >= 0 ? P.table + (int64_t)code * P.ld_table : P.feat + (int64_t)(-1 - code) * P.ld_feat;
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) {
+    const int d = t + i * T;
+    raw[i] = (code != kNoRow && d < P.D) ? src[d] : 0.0f;
+  }
+}
+
+template <int T, int EPL>
+__device__ __forceinline__ void load_project(const JointParams& P, int code, bool valid, int t, Row<EPL>& r, float* stage,
+                                             const float* prefetched = nullptr) {
   const bool is_label = code >= 0;
   const float* src = nullptr;
   if (valid) src = is_label ? P.table + (int64_t)code * P.ld_table : P.feat + (int64_t)(-1 - code) * P.ld_feat;
   const bool hyp = valid && is_label && P.label_proj == LEC_LABEL_HYP;
   const bool img = valid && !is_label && P.image_proj == LEC_IMAGE_SOFTCLIP;
   float nn = 0.0f;
+  if (prefetched != nullptr) {
 #pragma unroll
-  for (int i = 0; i < EPL; ++i) {
-    int d = t + i * T;
-    float v = 0.0f;
-    if (valid && d < P.D) { v = src[d]; if (hyp) v += 1e-15f; }                    // oe_h.py:79
-    r.e[i] = v; nn += v * v;
+    for (int i = 0; i < EPL; ++i) {
+      float v = prefetched[i];
+      if (hyp && (t + i * T) < P.D) v += 1e-15f;                                    // oe_h.py:79
+      r.e[i] = v; nn += v * v;
+    }
+  } else if (T == 1 && stage != nullptr) {
+    wave_gather_rows<EPL>(P, valid ? code : kNoRow, stage, r.e);
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+      float v = r.e[i];
+      if (hyp && i < P.D) v += 1e-15f;                                              // oe_h.py:79
+      r.e[i] = v; nn += v * v;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+      int d = t + i * T;
+      float v = 0.0f;
+      if (valid && d < P.D) { v = src[d]; if (hyp) v += 1e-15f; }                  // oe_h.py:79
+      r.e[i] = v; nn += v * v;
+    }
   }
   nn = group_sum<T>(nn);
   const float n = sqrtf(nn);                                                       // oe_h.py:81 / :327
@@ -77,9 +165,10 @@ __device__ __forceinline__ void load_project(const JointParams& P, int code, boo
     Bc = n > 0.0f ? (1.0f / den - sc * denp / (den * den)) / n : 0.0f;
   }
   float pp = 0.0f;
+  const float mul_over_den = mul / den;                 // one correctly rounded divide per row, then multiplies
 #pragma unroll
   for (int i = 0; i < EPL; ++i) {
-    float v = (hyp || img) ? mul * (r.e[i] / den) : r.e[i];
+    float v = (hyp || img) ? r.e[i] * mul_over_den : r.e[i];
     r.p[i] = v; pp += v * v;
   }
   // no-grad clip of label points into [r_in, 1-1e-5] (oe_h.py:100-103); images are NOT clipped (:323-328)
@@ -87,11 +176,13 @@ __device__ __forceinline__ void load_project(const JointParams& P, int code, boo
   if (hyp) {
     float no = sqrtf(pp);
     if (no <= P.r_in) {
+      const float k = P.r_in / no;
 #pragma unroll
-      for (int i = 0; i < EPL; ++i) r.p[i] = r.p[i] / no * P.r_in;
+      for (int i = 0; i < EPL; ++i) r.p[i] = r.p[i] * k;
     } else if (no >= 1.0f) {
+      const float k = (float)(1.0 - 1e-5) / no;
 #pragma unroll
-      for (int i = 0; i < EPL; ++i) r.p[i] = r.p[i] / no * (float)(1.0 - 1e-5);
+      for (int i = 0; i < EPL; ++i) r.p[i] = r.p[i] * k;
     }
   }
   r.A = A; r.Bc = Bc;
@@ -100,11 +191,20 @@ __device__ __forceinline__ void load_project(const JointParams& P, int code, boo
 // chain a gradient w.r.t. the projected row back to the raw row and add it to the owner buffer
 template <int T, int EPL>
 __device__ __forceinline__ void scatter_row_grad(const JointParams& P, int code, bool active, int t,
-                                                 const Row<EPL>& r, const float (&go)[EPL]) {
+                                                 const Row<EPL>& r, const float (&go)[EPL], float* stage) {
   float dot = 0.0f;
 #pragma unroll
   for (int i = 0; i < EPL; ++i) dot += r.e[i] * go[i];
   dot = group_sum<T>(dot);
+  if (T == 1 && stage != nullptr) {
+    if (__ballot(active) == 0ull) return;                                           // wave-uniform: nothing to add
+    float graw[EPL];
+    const float cc = r.Bc * dot;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) graw[i] = r.A * go[i] + cc * r.e[i];
+    wave_scatter_rows<EPL>(P, active ? code : kNoRow, stage, graw);
+    return;
+  }
   if (!active) return;
   float* dst = code >= 0 ? P.grad_table + (int64_t)code * P.ld_table : P.grad_feat + (int64_t)(-1 - code) * P.ld_feat;
   const float c = r.Bc * dot;
@@ -115,7 +215,7 @@ __device__ __forceinline__ void scatter_row_grad(const JointParams& P, int code,
   }
 }
 
-template <int T, int EPL, int ENERGY, bool GRAD>
+template <int T, int EPL, int ENERGY, bool GRAD, bool STAGE>
 __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
   constexpr int PPW = kWave / T;                      // pairs per wave iteration
   const int lane = threadIdx.x & 63;
@@ -126,6 +226,9 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
   const bool task_valid = b < P.B;
   const int NP = 1 + 2 * P.K;
   float lsum = 0.0f;
+  constexpr int kStage = (T == 1 && STAGE) ? kWave * (EPL + 1) : 1;
+  __shared__ float s_stage[4 * kStage];
+  float* stage = (T == 1 && STAGE) ? s_stage + (threadIdx.x >> 6) * kStage : nullptr;
 
   // NOTE: every lane of the wave walks the same control flow (butterflies need all 64 lanes); validity is a predicate.
   int ucode = 0, vcode = 0; float w = 1.0f;
@@ -134,21 +237,39 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
     if (P.weights) w = P.weights[b];
   }
   Row<EPL> U, V;
-  load_project<T, EPL>(P, ucode, task_valid, t, U);
-  load_project<T, EPL>(P, vcode, task_valid, t, V);
+  load_project<T, EPL>(P, ucode, task_valid, t, U, nullptr);     // every lane needs u_b, v_b: broadcast loads
+  load_project<T, EPL>(P, vcode, task_valid, t, V, nullptr);
   float gu[EPL], gv[EPL];
 #pragma unroll
   for (int i = 0; i < EPL; ++i) { gu[i] = 0.0f; gv[i] = 0.0f; }
 
   const int q0 = c * P.iters * PPW;
+  // Software pipeline: node codes are fetched two iterations ahead and raw rows one iteration ahead, so the
+  // code -> row -> arithmetic dependency chain of iteration `it` overlaps the arithmetic of iteration `it - 1`
+  // (the waves of this kernel spent 65 % of their cycles in s_waitcnt before this: profiles/r01_cone_pmc.md).
+  auto fetch_code = [&](int it) -> int {
+    const int q = q0 + it * PPW + slot;
+    return (task_valid && it < P.iters && q > 0 && q < NP) ? P.neg[(int64_t)b * 2 * P.K + (q - 1)] : kNoRow;
+  };
+  constexpr bool pipelined = !(T == 1 && STAGE);
+  int code_a = fetch_code(0), code_b = fetch_code(1);
+  float raw_a[EPL];
+  if (pipelined) fetch_row<T, EPL>(P, code_a, t, raw_a);
   for (int it = 0; it < P.iters; ++it) {
     const int q = q0 + it * PPW + slot;               // pair index in the group: 0 = positive, 1+k = negative slot k
     const bool valid = task_valid && q < NP;
     const int kind = !valid ? 0 : (q == 0 ? 0 : (q - 1 < P.K ? 1 : 2));   // 1: u fixed (corrupt `to`), 2: v fixed
-    int ocode = 0;
-    if (valid && q > 0) ocode = P.neg[(int64_t)b * 2 * P.K + (q - 1)];
+    const int code_c = fetch_code(it + 2);
+    float raw_b[EPL];
+    if (pipelined) fetch_row<T, EPL>(P, code_b, t, raw_b);
+    const int ocode = code_a == kNoRow ? 0 : code_a;
     Row<EPL> O;
-    load_project<T, EPL>(P, ocode, valid && q > 0, t, O);
+    load_project<T, EPL>(P, ocode, valid && q > 0, t, O, stage, pipelined ? raw_a : nullptr);
+    code_a = code_b; code_b = code_c;
+    if (pipelined) {
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) raw_a[i] = raw_b[i];
+    }
 
     float x[EPL], y[EPL];
 #pragma unroll
@@ -156,8 +277,9 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
       x[i] = kind == 2 ? O.p[i] : U.p[i];
       y[i] = kind == 1 ? O.p[i] : V.p[i];
     }
-    float E, g = 0.0f;
-    float gx[EPL], gy[EPL];
+    // ---- forward: energy of every pair of this iteration
+    float E;
+    ConeFwd cf;
     if (ENERGY == LEC_ENERGY_HYP_CONE) {
       float xx = 0.f, yy = 0.f, s = 0.f, dd = 0.f;
 #pragma unroll
@@ -166,29 +288,13 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
         xx += x[i] * x[i]; yy += y[i] * y[i]; s += x[i] * y[i]; dd += df * df;
       }
       xx = group_sum<T>(xx); yy = group_sum<T>(yy); s = group_sum<T>(s); dd = group_sum<T>(dd);
-      ConeEval ev = cone_eval<GRAD>(xx, yy, s, dd, P.K_cone);
-      E = ev.E;
-      if (GRAD) {
-        g = q == 0 ? w : ((P.alpha - E) >= 0.0f ? -w : 0.0f);                      // oe_h.py:846 (+ clamp mask)
-#pragma unroll
-        for (int i = 0; i < EPL; ++i) {
-          gx[i] = g * (ev.cxx * x[i] + ev.cxy * y[i]);
-          gy[i] = g * (ev.cxy * x[i] + ev.cyy * y[i]);
-        }
-      }
+      cf = cone_forward(xx, yy, s, dd, P.K_cone);
+      E = cf.E;
     } else {                                                                       // order_embeddings.py:818-824
       float e = 0.0f;
 #pragma unroll
       for (int i = 0; i < EPL; ++i) { float m = fmaxf(x[i] - y[i], 0.0f); e += m * m; }
       E = group_sum<T>(e);
-      if (GRAD) {
-        g = q == 0 ? w : ((P.alpha - E) >= 0.0f ? -w : 0.0f);
-#pragma unroll
-        for (int i = 0; i < EPL; ++i) {
-          float m = 2.0f * fmaxf(x[i] - y[i], 0.0f) * g;
-          gx[i] = m; gy[i] = -m;
-        }
-      }
     }
     if (valid && t == 0) {
       if (q == 0) { P.e_pos[b] = E; lsum += w * E; }
@@ -198,16 +304,35 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
         lsum += w * (h < 0.0f ? 0.0f : h);                                         // oe_h.py:839,846
       }
     }
+    // ---- backward: only pairs whose loss term is live carry gradient (positives; negatives inside the margin).
+    // The whole wave skips the gradient arithmetic, the Jacobian chain and the scatter when none of its pairs is live.
     if (GRAD) {
+      const float g = !valid ? 0.0f : (q == 0 ? w : ((P.alpha - E) >= 0.0f ? -w : 0.0f));   // oe_h.py:846 (+ clamp mask)
       const bool act = valid && g != 0.0f;
-      float go[EPL];
+      if (__ballot(act) != 0ull) {
+        float go[EPL];
+        if (ENERGY == LEC_ENERGY_HYP_CONE) {
+          float cxx, cxy, cyy;
+          cone_grad_coeffs(cf, P.K_cone, cxx, cxy, cyy);
+          cxx *= g; cxy *= g; cyy *= g;
 #pragma unroll
-      for (int i = 0; i < EPL; ++i) {
-        if (act && kind != 2) gu[i] += gx[i];
-        if (act && kind != 1) gv[i] += gy[i];
-        go[i] = kind == 1 ? gy[i] : gx[i];
+          for (int i = 0; i < EPL; ++i) {
+            const float gxi = cxx * x[i] + cxy * y[i], gyi = cxy * x[i] + cyy * y[i];
+            if (act && kind != 2) gu[i] += gxi;
+            if (act && kind != 1) gv[i] += gyi;
+            go[i] = kind == 1 ? gyi : gxi;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < EPL; ++i) {
+            const float m = 2.0f * fmaxf(x[i] - y[i], 0.0f) * g;
+            if (act && kind != 2) gu[i] += m;
+            if (act && kind != 1) gv[i] -= m;
+            go[i] = kind == 1 ? -m : m;
+          }
+        }
+        scatter_row_grad<T, EPL>(P, ocode, act && kind != 0, t, O, go, stage);
       }
-      scatter_row_grad<T, EPL>(P, ocode, act && kind != 0, t, O, go);
     }
   }
 
@@ -218,8 +343,8 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
 #pragma unroll
       for (int i = 0; i < EPL; ++i) { gu[i] += __shfl_xor(gu[i], m, kWave); gv[i] += __shfl_xor(gv[i], m, kWave); }
     }
-    scatter_row_grad<T, EPL>(P, ucode, task_valid && slot == 0, t, U, gu);
-    scatter_row_grad<T, EPL>(P, vcode, task_valid && slot == 0, t, V, gv);
+    scatter_row_grad<T, EPL>(P, ucode, task_valid && slot == 0, t, U, gu, stage);
+    scatter_row_grad<T, EPL>(P, vcode, task_valid && slot == 0, t, V, gv, stage);
   }
 
   lsum = group_sum<64>(lsum);
@@ -229,9 +354,14 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
 // ---------------------------------------------------------------------------------------------------------
 template <int T, int EPL>
 static int launch(const JointParams& P, bool grad, int energy, int nblocks, hipStream_t st) {
-#define LEC_JL(E_, G_) hipLaunchKernelGGL((joint_loss_kernel<T, EPL, E_, G_>), dim3(nblocks), dim3(256), 0, st, P)
-  if (energy == LEC_ENERGY_HYP_CONE) { if (grad) LEC_JL(LEC_ENERGY_HYP_CONE, true); else LEC_JL(LEC_ENERGY_HYP_CONE, false); }
-  else { if (grad) LEC_JL(LEC_ENERGY_ORDER, true); else LEC_JL(LEC_ENERGY_ORDER, false); }
+#define LEC_JL(E_, G_, S_) hipLaunchKernelGGL((joint_loss_kernel<T, EPL, E_, G_, S_>), dim3(nblocks), dim3(256), 0, st, P)
+  if (T == 1 && P.lds_stage) {
+    if (energy == LEC_ENERGY_HYP_CONE) { if (grad) LEC_JL(LEC_ENERGY_HYP_CONE, true, (T == 1)); else LEC_JL(LEC_ENERGY_HYP_CONE, false, (T == 1)); }
+    else { if (grad) LEC_JL(LEC_ENERGY_ORDER, true, (T == 1)); else LEC_JL(LEC_ENERGY_ORDER, false, (T == 1)); }
+  } else {
+    if (energy == LEC_ENERGY_HYP_CONE) { if (grad) LEC_JL(LEC_ENERGY_HYP_CONE, true, false); else LEC_JL(LEC_ENERGY_HYP_CONE, false, false); }
+    else { if (grad) LEC_JL(LEC_ENERGY_ORDER, true, false); else LEC_JL(LEC_ENERGY_ORDER, false, false); }
+  }
 #undef LEC_JL
   LEC_CHECK_LAUNCH("joint_loss_kernel");
   return LEC_OK;
@@ -239,22 +369,51 @@ static int launch(const JointParams& P, bool grad, int energy, int nblocks, hipS
 
 struct JointGeom { int T, EPL, iters, tasks_per_group, nblocks; };
 
+// (T lanes per pair, EPL row elements per lane) candidates: T*EPL >= D.  Small T = less redundant scalar math per pair
+// (the cone evaluation is computed by every lane of the T-group) and fewer butterflies; large T = coalesced row loads
+// for long rows and fewer registers.
+static const int kGeoms[][2] = {{1, 4}, {1, 12}, {1, 16}, {2, 8}, {4, 4}, {4, 8}, {8, 8}, {16, 4}, {16, 8}, {32, 8}, {64, 4}, {64, 8}, {64, 16}};
+
 static bool joint_geometry(int B, int K, int D, JointGeom& g) {
   if (D <= 4) { g.T = 1; g.EPL = 4; }
-  else if (D <= 16) { g.T = 4; g.EPL = 4; }
-  else if (D <= 64) { g.T = 16; g.EPL = 4; }
-  else if (D <= 256) { g.T = 64; g.EPL = 4; }
+  else if (D <= 12) { g.T = 1; g.EPL = 12; }
+  else if (D <= 16) { g.T = 2; g.EPL = 8; }
+  else if (D <= 32) { g.T = 4; g.EPL = 8; }
+  else if (D <= 64) { g.T = 8; g.EPL = 8; }
+  else if (D <= 128) { g.T = 16; g.EPL = 8; }
+  else if (D <= 256) { g.T = 32; g.EPL = 8; }
+  else if (D <= 512) { g.T = 64; g.EPL = 8; }
   else if (D <= 1024) { g.T = 64; g.EPL = 16; }
   else return false;
+  int iters_override = 0;
+  if (const char* e = getenv("LEC_JOINT_GEOM")) {            // tuning hook: "T,EPL[,iters]"
+    int t = 0, epl = 0, it = 0;
+    if (sscanf(e, "%d,%d,%d", &t, &epl, &it) >= 2 && t * epl >= D) {
+      for (auto& c : kGeoms) if (c[0] == t && c[1] == epl) { g.T = t; g.EPL = epl; iters_override = it; }
+    }
+  }
   const int ppw = 64 / g.T, NP = 1 + 2 * K;
-  // enough waves to fill 256 CUs several times over, but at least 2 iterations per task when the group is long
-  int iters = (NP + ppw - 1) / ppw;
-  if (iters > 2) iters = 2;
-  g.iters = iters;
-  g.tasks_per_group = (NP + ppw * iters - 1) / (ppw * iters);
+  const int64_t group_iters = (NP + ppw - 1) / ppw;                      // wave iterations one group needs
+  // aim for ~6k waves (a few residency rounds of 256 CUs x 4 SIMDs) but never more than 8 iterations per task
+  int64_t iters = ((int64_t)B * group_iters + 6143) / 6144;
+  if (iters > 8) iters = 8;
+  if (iters > group_iters) iters = group_iters;
+  if (iters < 1) iters = 1;
+  if (iters_override > 0) iters = iters_override;
+  g.iters = (int)iters;
+  g.tasks_per_group = (int)((group_iters + iters - 1) / iters);
   int64_t waves = (int64_t)B * g.tasks_per_group;
   g.nblocks = (int)((waves + 3) / 4);
   return true;
+}
+
+static int dispatch(const JointGeom& g, const JointParams& P, bool grad, int energy, hipStream_t st) {
+#define LEC_G(T_, E_) if (g.T == T_ && g.EPL == E_) return launch<T_, E_>(P, grad, energy, g.nblocks, st)
+  LEC_G(1, 4); LEC_G(1, 12); LEC_G(1, 16); LEC_G(2, 8); LEC_G(4, 4); LEC_G(4, 8); LEC_G(8, 8); LEC_G(16, 4); LEC_G(16, 8);
+  LEC_G(32, 8); LEC_G(64, 4); LEC_G(64, 8); LEC_G(64, 16);
+#undef LEC_G
+  set_error("joint_loss: no kernel for geometry T=%d EPL=%d", g.T, g.EPL);
+  return LEC_E_ARG;
 }
 
 }  // namespace lec
@@ -299,10 +458,7 @@ extern "C" int lec_joint_loss_fwd_bwd(int energy, int label_proj, int image_proj
   P.e_pos = e_pos; P.e_neg = e_neg; P.loss = loss; P.grad_table = grad_table; P.grad_feat = grad_feat;
   P.counter = (unsigned int*)workspace; P.partials = (float*)((char*)workspace + 256);
   P.iters = g.iters; P.tasks_per_group = g.tasks_per_group;
+  { const char* e = getenv("LEC_JOINT_STAGE"); P.lds_stage = e ? atoi(e) : 0; }
   const bool grad = grad_table != nullptr;
-  if (g.T == 1) return launch<1, 4>(P, grad, energy, g.nblocks, st);
-  if (g.T == 4) return launch<4, 4>(P, grad, energy, g.nblocks, st);
-  if (g.T == 16) return launch<16, 4>(P, grad, energy, g.nblocks, st);
-  if (g.EPL == 4) return launch<64, 4>(P, grad, energy, g.nblocks, st);
-  return launch<64, 16>(P, grad, energy, g.nblocks, st);
+  return dispatch(g, P, grad, energy, st);
 }

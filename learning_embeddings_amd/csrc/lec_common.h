@@ -29,11 +29,24 @@ inline float inner_radius_h_f(float K) {                    // Embedder.arctanh 
 #if defined(__HIPCC__)
 constexpr int kWave = 64;
 
-// all-reduce (sum) inside aligned groups of T lanes; every lane ends with the bit-identical total
+// DPP lane exchange inside a 16-lane row (no LDS crossbar round trip, unlike ds_bpermute behind __shfl_xor)
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+// all-reduce (sum) inside aligned groups of T lanes; every lane ends with the bit-identical total.
+// Steps inside a 16-lane row are DPP butterflies: quad_perm[1,0,3,2] (xor 1), quad_perm[2,3,0,1] (xor 2), then
+// row_half_mirror / row_mirror -- once every lane of a quad (of an 8-group) already holds that group's sum, the mirror
+// pairs each group with its sibling exactly as xor 4 (xor 8) would.  Wider groups finish with ds_bpermute butterflies.
 template <int T>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int m = T >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+  if (T >= 2) v += dpp_move<0xB1>(v);
+  if (T >= 4) v += dpp_move<0x4E>(v);
+  if (T >= 8) v += dpp_move<0x141>(v);
+  if (T >= 16) v += dpp_move<0x140>(v);
+  if (T >= 32) v += __shfl_xor(v, 16, kWave);
+  if (T >= 64) v += __shfl_xor(v, 32, kWave);
   return v;
 }
 template <int T>
@@ -54,48 +67,60 @@ __device__ __forceinline__ float clampf_nanprop(float a, float lo, float hi) {  
 // (E depends on x, y only through |x|, |y|, |x-y| and <x,y>; autograd's chain through those four collapses to this.)
 // ---------------------------------------------------------------------------------------------------------
 struct ConeEval { float E, cxx, cxy, cyy; };
+struct ConeFwd { float E, xn, yn, dist, xn2, yn2, s, rad, den, a, pa, ac, pc, diff; };
+
+__device__ __forceinline__ ConeFwd cone_forward(float xx, float yy, float s, float dd, float K) {
+  const float lo = (float)(-1.0 + 1e-5), hi = (float)(1.0 - 1e-5);
+  ConeFwd f;
+  f.xn = sqrtf(xx); f.yn = sqrtf(yy); f.dist = sqrtf(dd); f.s = s;
+  f.xn2 = f.xn * f.xn; f.yn2 = f.yn * f.yn;
+  float num = s * (1.0f + f.xn2) - f.xn2 * (1.0f + f.yn2);
+  float xy = f.xn * f.yn;
+  f.rad = 1.0f + xy * xy - 2.0f * s;
+  f.den = f.xn * f.dist * sqrtf(f.rad);
+  f.a = num / f.den;                                                              // oe_h.py:823
+  f.pa = K * (1.0f - f.xn2) / f.xn;
+  f.ac = clampf_nanprop(f.a, lo, hi); f.pc = clampf_nanprop(f.pa, lo, hi);
+  f.diff = acosf(f.ac) - asinf(f.pc);                                             // :826-827
+  f.E = f.diff < 0.0f ? 0.0f : f.diff;                                            // :833 (NaN stays NaN)
+  return f;
+}
+
+// gradient coefficients from the forward intermediates.  Divisions here use reciprocals (1-2 ulp): the coefficients feed
+// gradients whose parity bar is relative 1e-3; the energy itself keeps correctly rounded arithmetic.
+__device__ __forceinline__ void cone_grad_coeffs(const ConeFwd& f, float K, float& cxx, float& cxy, float& cyy) {
+  const float lo = (float)(-1.0 + 1e-5), hi = (float)(1.0 - 1e-5);
+  cxx = cxy = cyy = 0.0f;
+  const bool live = f.diff >= 0.0f;
+  const bool a_in = live && (f.a >= lo) && (f.a <= hi);
+  const bool p_in = live && (f.pa >= lo) && (f.pa <= hi);
+  float g_s = 0.f, g_d = 0.f, g_xn = 0.f, g_yn = 0.f;
+  const float r_xn = __frcp_rn(f.xn);
+  if (a_in) {
+    const float dth = -__frsqrt_rn(1.0f - f.ac * f.ac);
+    const float r_den = __frcp_rn(f.den), a_rad = f.a * __frcp_rn(f.rad);
+    g_s = dth * ((1.0f + f.xn2) * r_den + a_rad);
+    g_d = dth * (-f.a * __frcp_rn(f.dist));
+    g_xn = dth * ((2.0f * f.xn * f.s - 2.0f * f.xn * (1.0f + f.yn2)) * r_den - f.a * r_xn - a_rad * (f.xn * f.yn2));
+    g_yn = dth * (-2.0f * f.xn2 * f.yn * r_den - a_rad * (f.xn2 * f.yn));
+  }
+  if (p_in) {
+    const float dps = __frsqrt_rn(1.0f - f.pc * f.pc);
+    g_xn += dps * (K * (1.0f + f.xn2) * (r_xn * r_xn));                            // -dpsi/dxn, dpa/dxn = -K(1+xn^2)/xn^2
+  }
+  if (a_in || p_in) {
+    const float gd_over = a_in ? g_d * __frcp_rn(f.dist) : 0.0f;
+    cxx = g_xn * r_xn + gd_over;
+    cxy = g_s - gd_over;
+    cyy = (a_in ? g_yn * __frcp_rn(f.yn) : 0.0f) + gd_over;
+  }
+}
 
 template <bool GRAD>
 __device__ __forceinline__ ConeEval cone_eval(float xx, float yy, float s, float dd, float K) {
-  const float lo = (float)(-1.0 + 1e-5), hi = (float)(1.0 - 1e-5);
-  float xn = sqrtf(xx), yn = sqrtf(yy), dist = sqrtf(dd);
-  float xn2 = xn * xn, yn2 = yn * yn;
-  float num = s * (1.0f + xn2) - xn2 * (1.0f + yn2);
-  float xy = xn * yn;
-  float rad = 1.0f + xy * xy - 2.0f * s;
-  float sq = sqrtf(rad);
-  float den = xn * dist * sq;
-  float a = num / den;                                                            // oe_h.py:823
-  float pa = K * (1.0f - xn2) / xn;
-  float ac = clampf_nanprop(a, lo, hi), pc = clampf_nanprop(pa, lo, hi);
-  float diff = acosf(ac) - asinf(pc);                                             // :826-827
-  ConeEval r;
-  r.E = diff < 0.0f ? 0.0f : diff;                                                // :833 (NaN stays NaN)
-  r.cxx = r.cxy = r.cyy = 0.0f;
-  if (GRAD) {
-    bool live = diff >= 0.0f;
-    bool a_in = live && (a >= lo) && (a <= hi);
-    bool p_in = live && (pa >= lo) && (pa <= hi);
-    float g_s = 0.f, g_d = 0.f, g_xn = 0.f, g_yn = 0.f;
-    if (a_in) {
-      float dth = -1.0f / sqrtf(1.0f - ac * ac);
-      float a_rad = a / rad;
-      g_s = dth * ((1.0f + xn2) / den + a_rad);
-      g_d = dth * (-a / dist);
-      g_xn = dth * ((2.0f * xn * s - 2.0f * xn * (1.0f + yn2)) / den - a * (1.0f / xn) - a_rad * (xn * yn2));
-      g_yn = dth * (-2.0f * xn2 * yn / den - a_rad * (xn2 * yn));
-    }
-    if (p_in) {
-      float dps = 1.0f / sqrtf(1.0f - pc * pc);
-      g_xn += dps * (K * (1.0f + xn2) / xn2);                                     // -dpsi/dxn, dpa/dxn = -K(1+xn^2)/xn^2
-    }
-    if (a_in || p_in) {
-      float gd_over = a_in ? g_d / dist : 0.0f;
-      r.cxx = g_xn / xn + gd_over;
-      r.cxy = g_s - gd_over;
-      r.cyy = (a_in ? g_yn / yn : 0.0f) + gd_over;
-    }
-  }
+  ConeFwd f = cone_forward(xx, yy, s, dd, K);
+  ConeEval r; r.E = f.E; r.cxx = r.cxy = r.cyy = 0.0f;
+  if (GRAD) cone_grad_coeffs(f, K, r.cxx, r.cxy, r.cyy);
   return r;
 }
 
