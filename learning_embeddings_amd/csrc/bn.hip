@@ -155,10 +155,12 @@ __global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, con
 }
 
 // forward, pass 2: y = [relu]( x * scale + shift [+ residual] )
+// `mask` (optional, RELU only): one byte per thread-vector, bit j = [y_j > 0] -- backward reads it instead of y (1/16 the bytes)
 template <bool RES, bool RELU>
 __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const bf16x8* __restrict__ x, const bf16x8* __restrict__ res,
                                                               int64_t M, int CV, int RPI, const float* __restrict__ scale,
-                                                              const float* __restrict__ shift, bf16x8* __restrict__ y) {
+                                                              const float* __restrict__ shift, bf16x8* __restrict__ y,
+                                                              unsigned char* __restrict__ mask) {
   const int tid = threadIdx.x;
   const int cv = tid % CV, rg = tid / CV;
   if (rg >= RPI) return;
@@ -166,15 +168,18 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const bf16x8* __re
 #pragma unroll
   for (int j = 0; j < 8; ++j) { sc[j] = scale[cv * 8 + j]; sh[j] = shift[cv * 8 + j]; }
   const int64_t stride = (int64_t)gridDim.x * RPI;
-  auto one = [&](bf16x8 a, bf16x8 r) {
+  auto one = [&](bf16x8 a, bf16x8 r, int64_t idx) {
     bf16x8 o;
+    unsigned int bits = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = bf2f(a.v[j]) * sc[j] + sh[j];
       if (RES) v += bf2f(r.v[j]);
       if (RELU) v = v > 0.0f ? v : 0.0f;
       o.v[j] = f2bf(v);
+      if (RELU) bits |= (bf2f(o.v[j]) > 0.0f ? 1u : 0u) << j;       // decided on the ROUNDED output, like a y-based mask
     }
+    if (RELU && mask) mask[idx] = (unsigned char)bits;
     return o;
   };
   int64_t r = (int64_t)blockIdx.x * RPI + rg;
@@ -183,19 +188,20 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const bf16x8* __re
     bf16x8 a = x[i0], b = x[i1], c = x[i2], d = x[i3];
     bf16x8 ra = a, rb = a, rc = a, rd = a;
     if (RES) { ra = res[i0]; rb = res[i1]; rc = res[i2]; rd = res[i3]; }
-    y[i0] = one(a, ra); y[i1] = one(b, rb); y[i2] = one(c, rc); y[i3] = one(d, rd);
+    y[i0] = one(a, ra, i0); y[i1] = one(b, rb, i1); y[i2] = one(c, rc, i2); y[i3] = one(d, rd, i3);
   }
   for (; r < M; r += stride) {
     const int64_t i0 = r * CV + cv;
     bf16x8 a = x[i0], ra = a;
     if (RES) ra = res[i0];
-    y[i0] = one(a, ra);
+    y[i0] = one(a, ra, i0);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // backward, pass 1: per-block partials of  dbeta = sum g,  dgamma = sum g * xhat,   g = dy * [y > 0]
-template <bool RELU>
+// RELU: 0 none, 1 mask from the saved output y, 2 mask from the saved bitmask (y is then a byte array [M, C/8])
+template <int RELU>
 __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const bf16x8* __restrict__ dy, const bf16x8* __restrict__ y,
                                                                    const bf16x8* __restrict__ x, int64_t M, int C, int CV,
                                                                    int CVB, int RPI, const float* __restrict__ mean,
@@ -215,11 +221,14 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const bf16x8*
       const int64_t i0 = r * CV + cv, i1 = (r + stride) * CV + cv;
       bf16x8 g0 = dy[i0], g1 = dy[i1], x0 = x[i0], x1 = x[i1];
       bf16x8 y0 = g0, y1 = g1;
-      if (RELU) { y0 = y[i0]; y1 = y[i1]; }
+      unsigned int m0 = 0xff, m1 = 0xff;
+      if (RELU == 1) { y0 = y[i0]; y1 = y[i1]; }
+      if (RELU == 2) { m0 = ((const unsigned char*)y)[i0]; m1 = ((const unsigned char*)y)[i1]; }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float a = bf2f(g0.v[j]), b = bf2f(g1.v[j]);
-        if (RELU) { a = bf2f(y0.v[j]) > 0.0f ? a : 0.0f; b = bf2f(y1.v[j]) > 0.0f ? b : 0.0f; }
+        if (RELU == 1) { a = bf2f(y0.v[j]) > 0.0f ? a : 0.0f; b = bf2f(y1.v[j]) > 0.0f ? b : 0.0f; }
+        if (RELU == 2) { a = (m0 >> j) & 1u ? a : 0.0f; b = (m1 >> j) & 1u ? b : 0.0f; }
         acc[0][j] += a + b;
         acc[1][j] += a * ((bf2f(x0.v[j]) - mu[j]) * is[j]) + b * ((bf2f(x1.v[j]) - mu[j]) * is[j]);
       }
@@ -227,11 +236,14 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const bf16x8*
     for (; r < M; r += stride) {
       const int64_t i0 = r * CV + cv;
       bf16x8 g0 = dy[i0], x0 = x[i0], y0 = g0;
-      if (RELU) y0 = y[i0];
+      unsigned int m0 = 0xff;
+      if (RELU == 1) y0 = y[i0];
+      if (RELU == 2) m0 = ((const unsigned char*)y)[i0];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float a = bf2f(g0.v[j]);
-        if (RELU) a = bf2f(y0.v[j]) > 0.0f ? a : 0.0f;
+        if (RELU == 1) a = bf2f(y0.v[j]) > 0.0f ? a : 0.0f;
+        if (RELU == 2) a = (m0 >> j) & 1u ? a : 0.0f;
         acc[0][j] += a; acc[1][j] += a * ((bf2f(x0.v[j]) - mu[j]) * is[j]);
       }
     }
@@ -256,7 +268,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk,
 }
 
 // backward, pass 2: dx = gamma*invstd * (g - mean(g) - xhat * mean(g*xhat));  d residual = g
-template <bool RES, bool RELU>
+template <bool RES, int RELU>
 __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(const bf16x8* __restrict__ dy, const bf16x8* __restrict__ y,
                                                                   const bf16x8* __restrict__ x, int64_t M, int CV, int RPI,
                                                                   const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -275,11 +287,14 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(const bf16x8* 
   const int64_t stride = (int64_t)gridDim.x * RPI;
   auto one = [&](int64_t i) {
     bf16x8 g0 = dy[i], x0 = x[i], y0 = g0, o, gr;
-    if (RELU) y0 = y[i];
+    unsigned int m0 = 0xff;
+    if (RELU == 1) y0 = y[i];
+    if (RELU == 2) m0 = ((const unsigned char*)y)[i];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float a = bf2f(g0.v[j]);
-      if (RELU) a = bf2f(y0.v[j]) > 0.0f ? a : 0.0f;
+      if (RELU == 1) a = bf2f(y0.v[j]) > 0.0f ? a : 0.0f;
+      if (RELU == 2) a = (m0 >> j) & 1u ? a : 0.0f;
       const float xh = (bf2f(x0.v[j]) - mu[j]) * is[j];
       o.v[j] = f2bf(gs[j] * (a - k1[j] - xh * k2[j]));
       if (RES) gr.v[j] = f2bf(a);
@@ -307,8 +322,8 @@ extern "C" int64_t lec_bn_workspace_bytes(int C) {
 
 extern "C" int lec_bn_fwd(const void* x, const void* residual, int64_t M, int C, const float* gamma, const float* beta,
                           float eps, float momentum, float* running_mean, float* running_var, int training,
-                          float* save_mean, float* save_invstd, void* y, int relu, void* workspace,
-                          int64_t workspace_bytes, lec_stream_t stream) {
+                          float* save_mean, float* save_invstd, void* y, int relu, uint8_t* relu_mask,
+                          void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
   using namespace lec;
   if (int rc = bn_check("bn_fwd", M, C)) return rc;
   LEC_CHECK_ARG(x && gamma && beta && y && workspace, "bn_fwd: null pointer");
@@ -327,32 +342,37 @@ extern "C" int lec_bn_fwd(const void* x, const void* residual, int64_t M, int C,
   }
   int64_t nb = (M + g.RPI - 1) / g.RPI; nb = (nb + 3) / 4;
   const int nblk = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
-#define A(RES_, RELU_) hipLaunchKernelGGL((bn_apply_kernel<RES_, RELU_>), dim3(nblk), dim3(kBnThreads), 0, st, (const bf16x8*)x, (const bf16x8*)residual, M, g.CV, g.RPI, scale, shift, (bf16x8*)y)
+#define A(RES_, RELU_) hipLaunchKernelGGL((bn_apply_kernel<RES_, RELU_>), dim3(nblk), dim3(kBnThreads), 0, st, (const bf16x8*)x, (const bf16x8*)residual, M, g.CV, g.RPI, scale, shift, (bf16x8*)y, (unsigned char*)relu_mask)
   if (residual) { if (relu) A(true, true); else A(true, false); } else { if (relu) A(false, true); else A(false, false); }
 #undef A
   LEC_CHECK_LAUNCH("bn_fwd kernels");
   return LEC_OK;
 }
 
-extern "C" int lec_bn_bwd(const void* dy, const void* y, const void* x, int64_t M, int C, const float* gamma,
-                          const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma,
-                          float* dbeta, int relu, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+extern "C" int lec_bn_bwd(const void* dy, const void* y, const uint8_t* relu_mask, const void* x, int64_t M, int C,
+                          const float* gamma, const float* save_mean, const float* save_invstd, void* dx,
+                          void* dresidual, float* dgamma, float* dbeta, int relu, void* workspace,
+                          int64_t workspace_bytes, lec_stream_t stream) {
   using namespace lec;
   if (int rc = bn_check("bn_bwd", M, C)) return rc;
   LEC_CHECK_ARG(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && workspace, "bn_bwd: null pointer");
-  LEC_CHECK_ARG(!relu || y, "bn_bwd: the forward output y is needed for the ReLU mask");
+  LEC_CHECK_ARG(!relu || y || relu_mask, "bn_bwd: the forward output y or its bitmask is needed for the ReLU mask");
+  const int rm = !relu ? 0 : (relu_mask ? 2 : 1);
+  const void* ym = rm == 2 ? (const void*)relu_mask : y;
   LEC_CHECK_ARG(workspace_bytes >= lec_bn_workspace_bytes(C), "bn_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   BnGeom g = bn_geom(M, C);
   float* part = (float*)workspace;
   float* c1 = part + (int64_t)kBnMaxBlocks * 2 * C; float* c2 = c1 + C;
-  if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), dim3(g.nrb, g.NCH), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)y, (const bf16x8*)x, M, C, g.CV, g.CVB, g.RPIB, save_mean, save_invstd, part);
-  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), dim3(g.nrb, g.NCH), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)y, (const bf16x8*)x, M, C, g.CV, g.CVB, g.RPIB, save_mean, save_invstd, part);
+#define R(M_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<M_>), dim3(g.nrb, g.NCH), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)ym, (const bf16x8*)x, M, C, g.CV, g.CVB, g.RPIB, save_mean, save_invstd, part)
+  if (rm == 0) R(0); else if (rm == 1) R(1); else R(2);
+#undef R
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, part, g.nrb, C, M, dgamma, dbeta, c1, c2);
   int64_t nb = (M + g.RPI - 1) / g.RPI; nb = (nb + 1) / 2;
   const int nblk = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
-#define A(RES_, RELU_) hipLaunchKernelGGL((bn_bwd_apply_kernel<RES_, RELU_>), dim3(nblk), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)y, (const bf16x8*)x, M, g.CV, g.RPI, gamma, save_mean, save_invstd, c1, c2, (bf16x8*)dx, (bf16x8*)dresidual)
-  if (dresidual) { if (relu) A(true, true); else A(true, false); } else { if (relu) A(false, true); else A(false, false); }
+#define A(RES_, RELU_) hipLaunchKernelGGL((bn_bwd_apply_kernel<RES_, RELU_>), dim3(nblk), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)ym, (const bf16x8*)x, M, g.CV, g.RPI, gamma, save_mean, save_invstd, c1, c2, (bf16x8*)dx, (bf16x8*)dresidual)
+  if (dresidual) { if (rm == 0) A(true, 0); else if (rm == 1) A(true, 1); else A(true, 2); }
+  else { if (rm == 0) A(false, 0); else if (rm == 1) A(false, 1); else A(false, 2); }
 #undef A
   LEC_CHECK_LAUNCH("bn_bwd kernels");
   return LEC_OK;

@@ -281,17 +281,19 @@ class BNActFn(torch.autograd.Function):
         y = torch.empty_like(x)                       # preserves channels_last
         save_mean = torch.empty(Cc, dtype=torch.float32, device=x.device); save_invstd = torch.empty_like(save_mean)
         ws = _bn_workspace(x.device)
+        # ReLU bitmask for backward: 1/16 of the bytes of y (y itself stays alive only as the next conv's input)
+        mask = torch.empty(M * (Cc // 8), dtype=torch.uint8, device=x.device) if (relu and training) else None
         check(lib.lec_bn_fwd(dptr(x), dptr(residual), M, Cc, dptr(weight), dptr(bias), float(eps), float(momentum),
                              dptr(running_mean), dptr(running_var), int(bool(training)), dptr(save_mean), dptr(save_invstd),
-                             dptr(y), int(bool(relu)), dptr(ws), ws.numel(), stream_ptr()))
+                             dptr(y), int(bool(relu)), dptr(mask), dptr(ws), ws.numel(), stream_ptr()))
         if training:
-            ctx.save_for_backward(x, y if relu else None, weight, save_mean, save_invstd)
+            ctx.save_for_backward(x, mask, weight, save_mean, save_invstd)
             ctx.meta = (M, Cc, bool(relu), residual is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, weight, save_mean, save_invstd = ctx.saved_tensors
+        x, mask, weight, save_mean, save_invstd = ctx.saved_tensors
         M, Cc, relu, has_res = ctx.meta
         if not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.contiguous(memory_format=torch.channels_last)
@@ -299,7 +301,7 @@ class BNActFn(torch.autograd.Function):
         dres = torch.empty_like(x) if has_res else None
         dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device); dbeta = torch.empty_like(dgamma)
         ws = _bn_workspace(x.device)
-        check(lib.lec_bn_bwd(dptr(dy), dptr(y), dptr(x), M, Cc, dptr(weight), dptr(save_mean), dptr(save_invstd), dptr(dx),
+        check(lib.lec_bn_bwd(dptr(dy), None, dptr(mask), dptr(x), M, Cc, dptr(weight), dptr(save_mean), dptr(save_invstd), dptr(dx),
                              dptr(dres), dptr(dgamma), dptr(dbeta), int(relu), dptr(ws), ws.numel(), stream_ptr()))
         return dx, dres, dgamma, dbeta, None, None, None, None, None, None
 
