@@ -77,6 +77,7 @@ def main():
     ap.add_argument('--sampler', default='replicated', choices=['replicated', 'per_rank'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stress', action='store_true')
+    ap.add_argument('--check-replicas', action='store_true', help='after the run, assert that every rank holds identical parameters')
     ap.add_argument('--cudnn-benchmark', action='store_true', help='let MIOpen benchmark every solver per conv shape (slow start)')
     args = ap.parse_args()
 
@@ -119,6 +120,13 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
     stamp('timed steps done')
+    if args.check_replicas and world > 1:
+        for name, t in (('label table', eng.table), ('cnn arena', eng.arena.data)):
+            ref = t.clone(); dist.broadcast(ref, 0)
+            same = torch.tensor([float(torch.equal(ref, t))], device=dev); dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            if rank == 0:
+                print('[bench] replicas identical (%s): %s' % (name, bool(same.item())), file=sys.stderr)
+            assert same.item() == 1.0, 'replicas diverged: ' + name
     phases = eng.timer_summary()
     loss_mean = float(eng.loss_acc.item()) / (args.steps + args.warmup)
 

@@ -376,7 +376,7 @@ static const int kGeoms[][2] = {{1, 4}, {1, 12}, {1, 16}, {2, 8}, {4, 4}, {4, 8}
 
 static bool joint_geometry(int B, int K, int D, JointGeom& g) {
   if (D <= 4) { g.T = 1; g.EPL = 4; }
-  else if (D <= 12) { g.T = 1; g.EPL = 12; }
+  else if (D <= 12) { if (1 + 2 * K <= 32) { g.T = 4; g.EPL = 4; } else { g.T = 1; g.EPL = 12; } }   // short groups: keep lanes busy
   else if (D <= 16) { g.T = 2; g.EPL = 8; }
   else if (D <= 32) { g.T = 4; g.EPL = 8; }
   else if (D <= 64) { g.T = 8; g.EPL = 8; }

@@ -42,7 +42,7 @@ class StepEngine:
         hier, arch, B, K, D, hw = WORKLOADS[workload]
         self.workload, self.arch, self.B, self.K, self.D, self.hw = workload, arch, batch or B, K, D, hw
         self.rank, self.local_rank, self.world = parallel.init_process_group()
-        self.device = device or torch.device('cuda', self.local_rank if torch.cuda.device_count() > 1 else 0)
+        self.device = device or torch.device('cuda', self.local_rank % max(torch.cuda.device_count(), 1))
         torch.cuda.set_device(self.device)
         self.lr, self.alpha, self.K_cone = lr, alpha, K_cone
         self.compute_dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[dtype]

@@ -28,7 +28,7 @@ class Experiment:
         self.classes = classes; self.criterion = criterion; self.batch_size = batch_size
         if not torch.cuda.is_available():
             raise RuntimeError('Experiment runs on the MI355X only (no CPU fallback)')
-        self.device = torch.device('cuda')
+        self.device = torch.device('cuda', torch.cuda.current_device())
         print('Using device: {}'.format(self.device))
         self.model = model.to(self.device)
         self.n_epochs = n_epochs; self.eval_interval = eval_interval; self.dataloaders = dataloaders
@@ -109,6 +109,9 @@ class ETHECExperiment(Experiment):
                  load_wt=False, model_name='resnet50', optimizer_method='adam', compute_dtype=torch.bfloat16, weights=None):
         self.labelmap = labelmap; self.lr = lr; self.model_name = model_name
         self.n_classes = labelmap.n_classes; self.levels = labelmap.levels; self.n_levels = len(labelmap.levels)
+        self.rank, self.local_rank, self.world = parallel.init_process_group()
+        if self.world > 1:
+            torch.cuda.set_device(self.local_rank % torch.cuda.device_count())
         model = {'resnet18': resnet18, 'resnet50': resnet50}[model_name]()
         if weights is not None:
             model.load_state_dict(weights)
@@ -117,7 +120,6 @@ class ETHECExperiment(Experiment):
         Experiment.__init__(self, model, data_loaders, criterion, labelmap.classes, experiment_name, n_epochs,
                             eval_interval, batch_size, experiment_dir, load_wt, evaluator)
         self.compute_dtype = compute_dtype
-        self.rank, self.local_rank, self.world = parallel.init_process_group()
         self.arena = parallel.FlatArena(self.model.parameters(), self.device)
         self.reducer = parallel.GradientReducer(self.arena)
         if self.world > 1:

@@ -286,7 +286,16 @@ class _JointCriterionBase(torch.nn.Module):
         Kn = self.neg_to_pos_ratio
         ix_from = np.fromiter((n2i[o] for o in original_from), dtype=np.int32, count=B)
         ix_to = np.fromiter((n2i[o] for o in original_to), dtype=np.int32, count=B)
-        neg = self.negative_G.draw_batch(ix_from, ix_to, Kn)             # oe_h.py:940-957, bit-exact stream
+        dp = getattr(self, 'dp_global', None)
+        if dp is None:
+            neg = self.negative_G.draw_batch(ix_from, ix_to, Kn)         # oe_h.py:940-957, bit-exact stream
+        else:
+            # data parallel: every rank walks the GLOBAL batch's stream (same order as a single process would) and keeps
+            # its shard, so the negatives do not depend on the world size and no collective is needed
+            g_from, g_to, lo, hi = dp
+            if not (np.array_equal(g_from[lo:hi], ix_from) and np.array_equal(g_to[lo:hi], ix_to)):
+                raise RuntimeError('data-parallel shard does not match the global batch order')
+            neg = self.negative_G.draw_batch(g_from, g_to, Kn)[lo:hi]
         self.last_negatives = neg
         # one CNN forward over the DISTINCT images of the step: the batch's own tensors + images drawn as negatives
         slot, stack = {}, []

@@ -333,7 +333,8 @@ class JointEmbeddings:
         if not torch.cuda.is_available():
             raise RuntimeError('JointEmbeddings runs on the MI355X only (no CPU fallback)')
         self.rank, self.local_rank, self.world = parallel.init_process_group()
-        self.device = torch.device('cuda', self.local_rank if self.world > 1 else torch.cuda.current_device())
+        self.device = torch.device('cuda', self.local_rank % torch.cuda.device_count() if self.world > 1 else torch.cuda.current_device())
+        torch.cuda.set_device(self.device)
         print('Using device: {}'.format(self.device))
         self.n_epochs = n_epochs; self.eval_interval = eval_interval
         self.log_dir = os.path.join(self.exp_dir, '{}').format(experiment_name)
@@ -466,8 +467,6 @@ class JointEmbeddings:
     def train_step(self, data_item):
         """oe_h.py:1734-1774 for one batch.  Returns the (device) loss; nothing here synchronises with the host."""
         self.arena.zero_grad(); self.table_grad.zero_()
-        if self.world > 1:
-            raise NotImplementedError('multi-process JointEmbeddings.train_step: drive DP through bench.py / StepEngine')
         loss, e_pos, e_neg = self.criterion(self.model, self.img_feat_net, data_item['from'], data_item['to'],
                                             data_item['original_from'], data_item['original_to'], data_item['status'], 'train')
         loss.backward()                                                     # oe_h.py:1766
@@ -495,11 +494,25 @@ class JointEmbeddings:
             running = torch.zeros((), device=self.device)
             self.train_sampler.set_epoch(self.epoch)
             index = -1
+            global_batches = self.train_sampler.global_batches() if self.world > 1 else None
+            n2i = self.graph_dict['mapping_node_to_ix']
             for index, data_item in enumerate(self.dataloaders[phase]):
+                if global_batches is not None:                      # this rank's slice of the global batch
+                    gb = global_batches[index]
+                    edges = [self.train_set[i_] if False else self.train_set.edge_list[i_] for i_ in gb] if not self.half_half else None
+                    if edges is None:
+                        raise NotImplementedError('half_half sampling under data parallelism')
+                    g_from = np.fromiter((n2i[u] for u, _ in edges), dtype=np.int32, count=len(edges))
+                    g_to = np.fromiter((n2i[v] for _, v in edges), dtype=np.int32, count=len(edges))
+                    per = len(gb) // self.world
+                    self.criterion.dp_global = (g_from, g_to, self.rank * per, (self.rank + 1) * per)
                 loss, _, _ = self.train_step(data_item)
                 running += loss
+            self.criterion.dp_global = None
+            if self.world > 1:
+                torch.distributed.all_reduce(running)
             classification_metrics = self.calculate_classification_metrics(phase)
-            epoch_loss = running.item() / max(1, (index + 1) * self.batch_size * self.neg_to_pos_ratio * 2)   # :1780
+            epoch_loss = running.item() / max(1, (index + 1) * self.batch_size * self.world * self.neg_to_pos_ratio * 2)   # :1780
             if save_to_tensorboard:
                 self.writer.add_scalar('{}_loss'.format(phase), epoch_loss, self.epoch)
             print('train loss: {}'.format(epoch_loss))

@@ -79,7 +79,8 @@ def init_process_group(backend=None):
     rank, local_rank, world = env_rank()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            # LEC_DIST_BACKEND=gloo lets several ranks share ONE GPU (tests on a 1-GPU box): gloo reduces CUDA tensors
+            backend = os.environ.get('LEC_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend == 'nccl':

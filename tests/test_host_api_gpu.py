@@ -164,3 +164,50 @@ def test_joint_embeddings_trainer_runs_and_learns(tmp_path):
     tr.load_model('best_model')
     sd = torch.load(os.path.join(tr.path_to_save_model, '0_model.pth'))['model_state_dict']
     assert list(sd) == ['module.embeddings.weight']                          # the reference's DataParallel key prefix
+
+
+# ------------------------------------------------------------------------------------------------ DP on one GPU (gloo)
+def _dp_trainer_worker(rank, world, port, tmp, q):
+    import os, sys
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port), LEC_DIST_BACKEND='gloo')
+    from conftest import ROOT
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import torch as t
+    from test_host_cpu import _fake_loaders
+    from learning_embeddings_amd import oe_h as m
+    from learning_embeddings_amd.hierarchy import SyntheticLabelMap as LM
+    lm = LM([2, 4, 8])
+    dl = _fake_loaders(lm, 32, 8)
+    for split in dl.values():
+        for b in split:
+            b['path_to_image'] = [t.rand(3, 32, 32, generator=t.Generator().manual_seed(int(n[4:]))) for n in b['image_filename']]
+    gd = m.create_combined_graphs(dl, lm, pick_per_level=True)
+    crit = m.EuclideanConesWithImagesHypernymLoss(lm, 5, {}, 0.05, True, K=0.1, use_CNN=True)
+    tr = m.JointEmbeddings(gd, dl, image_dir='', use_CNN=True, labelmap=lm, criterion=crit, lr=1e-3, n_workers=0,
+                           batch_size=8, experiment_name='dp', embedding_dim=10, neg_to_pos_ratio=5, image_fc7=None,
+                           normalize=None, alpha=0.05, experiment_dir=os.path.join(tmp, 'r%d' % rank), n_epochs=1, eval_interval=5)
+    negs = []
+    orig = crit.negative_G.draw_batch
+    def spy(f, t_, k):
+        out = orig(f, t_, k); negs.append(out.copy()); return out
+    crit.negative_G.draw_batch = spy
+    tr.pass_samples('train')
+    q.put((rank, tr.model.embeddings.weight.detach().cpu().numpy(), tr.arena.data[:4096].cpu().numpy(), negs[:3], tr.last_epoch_loss))
+    t.distributed.barrier(); t.distributed.destroy_process_group()
+
+
+def test_joint_embeddings_data_parallel_two_ranks_share_one_gpu(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn'); q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_trainer_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda r: r[0])
+    for p in procs: p.join(120)
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])     # replicas stay identical
+    assert np.isfinite(res[0][4]) and res[0][4] == res[1][4]
+    # both ranks walked the SAME global negative stream (global batch of 16 edges), i.e. the single-process stream
+    for a, b in zip(res[0][3], res[1][3]):
+        assert a.shape[0] == 16 and np.array_equal(a, b)

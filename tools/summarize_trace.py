@@ -6,7 +6,7 @@ stress sweep.   usage: summarize_trace.py <kernel_trace.csv> [--steps 4] > profi
 import argparse, collections, csv, re, sys
 
 ap = argparse.ArgumentParser(); ap.add_argument('trace'); ap.add_argument('--steps', type=int, default=4)
-ap.add_argument('--marker', default='joint_loss_kernel<4, 4, 0, true>'); ap.add_argument('--grid', type=int, default=16384, help='Grid_Size_X of the bench step launch of the marker kernel')
+ap.add_argument('--marker', default='joint_loss_kernel<'); ap.add_argument('--grid', type=int, default=16384, help='Grid_Size_X of the bench step launch of the marker kernel')
 a = ap.parse_args()
 rows = list(csv.DictReader(open(a.trace)))
 # the stress sweep launches the same kernel with other grids: keep the bench-step launches only
