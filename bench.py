@@ -164,11 +164,18 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
             import bench_cone
             st = {}
-            for tag, (b_, k_, d_, n_) in {'cfg5_K256_D10': (256, 256, 10, 50000), 'K256_D128': (256, 256, 128, 50000),
+            pmc = {}
+            try:                                                # HBM bytes per launch measured with rocprofv3 --pmc (profiles/)
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_cone_stress_pmc.json')))
+            except Exception:
+                pass
+            for tag, (b_, k_, d_, n_) in {'cfg5_B256_K256_D10': (256, 256, 10, 50000), 'B256_K256_D128': (256, 256, 128, 50000),
                                           'B4096_K256_D10': (4096, 256, 10, 50000)}.items():
                 r = bench_cone.time_joint(b_, k_, d_, n_, b_, iters=30)
-                st[tag] = {'achieved': round(r['GBps'], 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(r['GBps'] / 8000.0, 4),
-                           'avg_launch_us': round(r['us'], 1), 'pairs': r['pairs'], 'alg_MB': round(r['alg_MB'], 2)}
+                rec = pmc.get('%d_%d_%d_%d' % (b_, k_, d_, n_), {})
+                st[tag] = {'bound': 'hbm', 'achieved': round(r['GBps'], 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(r['GBps'] / 8000.0, 4),
+                           'traffic': rec.get('traffic_bytes_fetch_x2'), 'avg_launch_us': round(r['us'], 1), 'pairs': r['pairs'],
+                           'alg_bytes_per_launch': int(r['alg_MB'] * 1e6)}
             out['roofline_stress'] = st
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(eng)

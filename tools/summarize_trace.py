@@ -26,7 +26,7 @@ tot = sum(v[0] for v in agg.values())
 def cat(k):
     if 'lec::' in k: return 'liblecone (this repo)'
     if 'BatchNorm' in k: return 'batchnorm'
-    if 'igemm' in k or 'conv' in k or 'gemm' in k.lower() or k.startswith('Cijk'): return 'conv/gemm'
+    if 'igemm' in k or 'conv' in k or 'gemm' in k.lower() or k.startswith('Cijk') or '2ck' in k or 'ck::' in k: return 'conv/gemm'
     if 'elementwise' in k or 'SubTensor' in k or 'fillBuffer' in k or 'copyBuffer' in k: return 'elementwise/copies'
     return 'other'
 cats = collections.defaultdict(float)
