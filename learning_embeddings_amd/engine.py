@@ -18,6 +18,7 @@ import torch
 from . import _lib, ops, parallel
 from .hierarchy import NegativeGraph, SyntheticLabelMap, SYNTHETIC
 from .oe_h import Embedder, FeatCNN18, FeatCNN, EuclideanConesWithImagesHypernymLoss
+from .resnet import WgradOverlap
 
 WORKLOADS = {
     # name: (hierarchy, arch, per-GPU batch, K negatives ratio, D, image hw)
@@ -38,7 +39,7 @@ def make_labelmap(name):
 
 class StepEngine:
     def __init__(self, workload='cfg3', n_images=4096, pool_images=None, dtype='bf16', lr=1e-4, alpha=0.01, K_cone=0.1,
-                 sampler_mode='replicated', seed=0, batch=None, device=None):
+                 sampler_mode='replicated', seed=0, batch=None, device=None, overlap_wgrad=False):
         hier, arch, B, K, D, hw = WORKLOADS[workload]
         self.workload, self.arch, self.B, self.K, self.D, self.hw = workload, arch, batch or B, K, D, hw
         self.rank, self.local_rank, self.world = parallel.init_process_group()
@@ -80,6 +81,11 @@ class StepEngine:
         self.reducer = parallel.GradientReducer(self.arena, extra=[self.table_grad])
         if self.world > 1:
             torch.distributed.broadcast(self.arena.data, 0); torch.distributed.broadcast(self.table, 0)
+        self.overlap = None
+        if overlap_wgrad and self.compute_dtype != torch.float32:
+            self.overlap = WgradOverlap.instance = WgradOverlap(self.reducer)
+        else:
+            WgradOverlap.instance = None
         # synthetic image pool resident in HBM: torch.rand in [0,1) like ToTensor output (oe_h.py:1463-1471), seed 0
         P = pool_images or min(n_images, 2 * self.B)
         g = torch.Generator(device='cpu').manual_seed(1234 + self.rank)
@@ -150,6 +156,8 @@ class StepEngine:
                                                 self.table_grad, self.gfeat)
         if ev: ev[2].record()
         feats.backward(self.gfeat)
+        if self.overlap is not None:
+            self.overlap.join()                       # weight gradients from the side stream
         if ev: ev[3].record()
         self.reducer.finish()
         if ev: ev[4].record()

@@ -130,9 +130,11 @@ class GradientReducer:
             for i in b:
                 self._bucket_of[i] = bi
         self._pending = [0] * len(self.buckets)
+        self._index_of = {id(p): i for i, p in enumerate(arena.params)}
+        self._hooks = [self._make_hook(i) for i in range(len(arena.params))]
         if self.enabled:
             for i, p in enumerate(arena.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+                p.register_post_accumulate_grad_hook(self._hooks[i])
         self.reset()
 
     def reset(self):
@@ -147,6 +149,15 @@ class GradientReducer:
                 lo, hi = self._spans[bi]
                 self.handles.append(dist.all_reduce(self.arena.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
         return hook
+
+    def mark_ready(self, p):
+        """Manual form of the post-accumulate hook, for gradients written outside autograd (e.g. weight gradients computed
+        on a side stream): call it on the stream that produced the gradient."""
+        if not self.enabled:
+            return
+        i = self._index_of.get(id(p))
+        if i is not None:
+            self._hooks[i](p)
 
     def finish(self):
         """Reduce whatever has not been launched by hooks (unused parameters, the extras) and wait for everything."""

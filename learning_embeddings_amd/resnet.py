@@ -38,12 +38,82 @@ class BatchNormAct2d(nn.BatchNorm2d):
         return F.relu(y) if self.fuse_relu else y
 
 
+class WgradOverlap:
+    """Runs every convolution's weight-gradient kernel on a second HIP stream, concurrently with the rest of backward.
+
+    Backward of the backbone is a chain  ... -> BN backward (HBM-bound) -> conv data-gradient (MFMA-bound) -> ...; the
+    weight gradients hang off that chain and nothing downstream needs them until the all-reduce / optimizer step.
+    Issuing them on a side stream lets MFMA-bound wgrad kernels share the GPU with the HBM-bound BatchNorm kernels of the
+    following layers instead of lengthening the chain.  The side stream adds the result into the parameter's `.grad`
+    (the flat arena view) and tells the gradient reducer the parameter is ready; `join()` makes the main stream wait."""
+
+    instance = None
+
+    def __init__(self, reducer=None):
+        self.side = torch.cuda.Stream()
+        self.reducer = reducer
+        self.enabled = True
+
+    def submit(self, gy, x, w16, conv):
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event(); ev.record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            gw = torch.ops.aten.convolution_backward(gy, x, w16, None, conv.stride, conv.padding, conv.dilation, False,
+                                                     [0, 0], conv.groups, [False, True, False])[1]
+            for t in (gy, x, w16):
+                t.record_stream(self.side)                 # the caching allocator must not recycle them under the side stream
+            w = conv.weight
+            if w.grad is None:
+                w.grad = gw.to(w.dtype)
+            else:
+                w.grad.add_(gw)
+            if self.reducer is not None:
+                self.reducer.mark_ready(w)
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self.side)
+
+
+class _OverlapConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, conv):
+        w16 = w.to(x.dtype)
+        if x.is_contiguous(memory_format=torch.channels_last) and w16.dim() == 4:
+            w16 = w16.contiguous(memory_format=torch.channels_last)
+        y = torch.ops.aten.convolution(x, w16, None, conv.stride, conv.padding, conv.dilation, False, [0, 0], conv.groups)
+        ctx.save_for_backward(x, w16); ctx.conv = conv
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w16 = ctx.saved_tensors; conv = ctx.conv
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(gy, x, w16, None, conv.stride, conv.padding, conv.dilation, False,
+                                                     [0, 0], conv.groups, [True, False, False])[0]
+        WgradOverlap.instance.submit(gy, x, w16, conv)
+        return gx, None, None
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d whose weight gradient can be computed on the side stream of `WgradOverlap.instance` (GPU, low-precision
+    activations, training).  Same parameters and state-dict keys as nn.Conv2d."""
+
+    def forward(self, x):
+        ov = WgradOverlap.instance
+        if (ov is not None and ov.enabled and x.is_cuda and self.training and torch.is_grad_enabled() and self.bias is None
+                and x.dtype in (torch.bfloat16, torch.float16) and self.weight.requires_grad):
+            return _OverlapConvFn.apply(x, self.weight, self)
+        return super().forward(x)
+
+
 def conv3x3(cin, cout, stride=1):
-    return nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=1, bias=False)
+    return Conv2d(cin, cout, kernel_size=3, stride=stride, padding=1, bias=False)
 
 
 def conv1x1(cin, cout, stride=1):
-    return nn.Conv2d(cin, cout, kernel_size=1, stride=stride, bias=False)
+    return Conv2d(cin, cout, kernel_size=1, stride=stride, bias=False)
 
 
 class BasicBlock(nn.Module):
@@ -82,7 +152,7 @@ class ResNet(nn.Module):
     def __init__(self, block, layers, num_classes=1000):
         super().__init__()
         self.inplanes = 64
-        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.conv1 = Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = BatchNormAct2d(64, relu=True)
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
         self.layer1 = self._make_layer(block, 64, layers[0])
@@ -109,6 +179,8 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
+        if x.is_cuda and torch.is_autocast_enabled() and x.dtype == torch.float32:
+            x = x.to(torch.get_autocast_gpu_dtype())          # the stem conv sees low-precision input like every other layer
         x = self.maxpool(self.bn1(self.conv1(x)))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = torch.flatten(self.avgpool(x), 1)
