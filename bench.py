@@ -137,9 +137,15 @@ def main():
         # ---- roofline of the hand-written hot kernel (HBM-bound gather/scatter): algorithmic bytes / measured duration
         cone_s = phases['cone_loss'] * 1e-3
         ab = cone_alg_bytes(B, K, D)
+        pmc_all = {}
+        try:                                                    # HBM bytes per launch from rocprofv3 --pmc passes (profiles/)
+            pmc_all = json.load(open(os.path.join(ROOT, 'profiles', 'r01_cone_stress_pmc.json')))
+        except Exception:
+            pass
+        traffic = pmc_all.get('%d_%d_%d_%d' % (B, K, D, eng.N), {}).get('traffic_bytes_fetch_x2')
         roof_cone = {'kernel': 'joint_loss_kernel (fused cone loss fwd+bwd)', 'bound': 'hbm',
                      'achieved': round(ab / cone_s / 1e9, 3), 'peak': 8000.0, 'unit': 'GB/s',
-                     'frac': round(ab / cone_s / 8e12, 6), 'traffic': None, 'alg_bytes_per_launch': ab,
+                     'frac': round(ab / cone_s / 8e12, 6), 'traffic': traffic, 'alg_bytes_per_launch': ab,
                      'avg_launch_us': round(cone_s * 1e6, 2),
                      'note': 'at the north-star size (B=%d, K=%d, D=%d: %.2f MB per launch) the launch is latency-bound, not HBM-bound; see roofline_stress' % (B, K, D, ab / 1e6)}
         # ---- the step's dominant component: ResNet fwd+bwd (MFMA-bound), analytic flops / measured fwd+bwd time

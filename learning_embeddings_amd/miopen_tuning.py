@@ -20,6 +20,8 @@ def setup():
         for f in os.listdir(src):
             target = os.path.join(dst, f)
             if not os.path.exists(target):                # keep records a previous run on this box has added
-                shutil.copy(os.path.join(src, f), target)
+                tmp = '%s.%d.tmp' % (target, os.getpid())  # atomic: several ranks start at once
+                shutil.copy(os.path.join(src, f), tmp)
+                os.replace(tmp, target)
     os.environ['MIOPEN_USER_DB_PATH'] = dst
     return dst
