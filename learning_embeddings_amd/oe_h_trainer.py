@@ -542,8 +542,7 @@ class JointEmbeddings:
         rec = {'f1': self.reconstruction_f1, 'precision': self.reconstruction_prec, 'recall': self.reconstruction_recall,
                'accuracy': self.reconstruction_accuracy, 'threshold': self.reconstruction_threshold}
         tag = filename if filename else self.epoch
-        opt = {'table_m': self.table_m, 'table_v': self.table_v, 'table_step': self.table_step,
-               'arena_m': self.arena.exp_avg, 'arena_v': self.arena.exp_avg_sq, 'arena_step': self.arena.step}
+        opt = self._optimizer_state_dict()
         torch.save({'epoch': self.epoch, 'model_state_dict': self._state(self.model), 'optimizer_state_dict': opt,
                     'loss': loss, 'optimal_threshold': self.optimal_threshold, 'reconstruction_scores': rec},
                    os.path.join(self.path_to_save_model, '{}_model.pth'.format(tag)))
@@ -562,14 +561,37 @@ class JointEmbeddings:
         ck = torch.load(os.path.join(self.path_to_save_model, '{}_model.pth'.format(epoch_to_load)), map_location=self.device)
         self._load_sd(self.model, ck['model_state_dict'])
         self.epoch = ck['epoch']; self.optimal_threshold = ck['optimal_threshold']
-        opt = ck.get('optimizer_state_dict', {})
-        if 'table_m' in opt:
-            self.table_m.copy_(opt['table_m']); self.table_v.copy_(opt['table_v']); self.table_step = opt['table_step']
-            if opt.get('arena_m') is not None:
-                self.arena.exp_avg = opt['arena_m'].to(self.device); self.arena.exp_avg_sq = opt['arena_v'].to(self.device)
-                self.arena.step = opt['arena_step']
+        self._load_optimizer_state_dict(ck.get('optimizer_state_dict') or {})
         ck = torch.load(os.path.join(self.path_to_save_model, '{}_img_feat_net.pth'.format(epoch_to_load)), map_location=self.device)
         self._load_sd(self.img_feat_net, ck['model_state_dict'])
+
+    def _optimizer_state_dict(self):
+        """torch.optim.Adam state-dict layout of the reference's `optimizer_labels` (oe_h.py:1523: ONE group holding the
+        label table followed by the CNN's parameters), so that checkpoints move between the two code bases."""
+        state = {0: {'step': torch.tensor(float(self.table_step)), 'exp_avg': self.table_m.clone(), 'exp_avg_sq': self.table_v.clone()}}
+        state.update(self.arena.export_adam_state(first_index=1))
+        n = 1 + len(self.arena.params)
+        group = {'lr': self.lr_labels, 'betas': (0.9, 0.999), 'eps': 1e-8, 'weight_decay': 0, 'amsgrad': False,
+                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                 'params': list(range(n))}
+        return {'state': state, 'param_groups': [group]}
+
+    def _load_optimizer_state_dict(self, sd):
+        state = sd.get('state') or {}
+        if 0 in state:
+            self.table_m.copy_(state[0]['exp_avg']); self.table_v.copy_(state[0]['exp_avg_sq'])
+            self.table_step = int(float(state[0]['step']))
+        self.arena.import_adam_state(state, first_index=1)
+
+    def load_emb_model(self, path_to_weights):
+        """oe_h.py:1904-1916: label embeddings (+ threshold / reconstruction scores) from another run."""
+        ck = torch.load(path_to_weights, map_location=self.device)
+        self._load_sd(self.model, ck['model_state_dict'])
+        self.optimal_threshold = ck['optimal_threshold']
+        if 'reconstruction_scores' in ck:
+            r = ck['reconstruction_scores']
+            (self.reconstruction_f1, self.reconstruction_threshold, self.reconstruction_accuracy, self.reconstruction_prec,
+             self.reconstruction_recall) = r['f1'], r['threshold'], r['accuracy'], r['precision'], r['recall']
 
     def find_existing_weights(self):
         weights = sorted([f.split('_')[0] for f in os.listdir(self.path_to_save_model)])

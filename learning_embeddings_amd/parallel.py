@@ -61,6 +61,42 @@ class FlatArena:
         i = next(k for k, q in enumerate(self.params) if q is p)
         return self.offsets[i], self.params[i].numel()
 
+    def view_of(self, buf, k):
+        """View of flat buffer `buf` over parameter k's slot with the parameter's own shape AND memory layout (conv weights
+        kept channels_last are stored as their NHWC bytes)."""
+        p, o = self.params[k], self.offsets[k]
+        flat = buf[o:o + p.numel()]
+        if p.dim() == 4 and not p.data.is_contiguous() and p.data.is_contiguous(memory_format=torch.channels_last):
+            return flat.view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2)
+        return flat.view(p.shape)
+
+    # ---- interchange with torch.optim.Adam checkpoints (the reference saves optimizer_labels.state_dict(), oe_h.py:1880)
+    def export_adam_state(self, first_index=0):
+        """{param index: {'step', 'exp_avg', 'exp_avg_sq'}} in this arena's parameter order, torch.optim.Adam layout."""
+        out = {}
+        for k, p in enumerate(self.params):
+            if self.exp_avg is not None:
+                m = self.view_of(self.exp_avg, k).clone(); v = self.view_of(self.exp_avg_sq, k).clone()
+            else:
+                m = torch.zeros_like(p.data); v = torch.zeros_like(p.data)
+            out[first_index + k] = {'step': torch.tensor(float(self.step)), 'exp_avg': m, 'exp_avg_sq': v}
+        return out
+
+    def import_adam_state(self, state, first_index=0):
+        if self.exp_avg is None:
+            self.exp_avg = torch.zeros_like(self.data); self.exp_avg_sq = torch.zeros_like(self.data)
+        steps = set()
+        for k, p in enumerate(self.params):
+            st = state.get(first_index + k)
+            if st is None:
+                continue
+            self.view_of(self.exp_avg, k).copy_(st['exp_avg']); self.view_of(self.exp_avg_sq, k).copy_(st['exp_avg_sq'])
+            steps.add(int(float(st['step'])))
+        if len(steps) > 1:
+            raise ValueError('the flat Adam keeps ONE step counter; the checkpoint has %s' % sorted(steps))
+        if steps:
+            self.step = steps.pop()
+
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
         from . import ops
         if self.exp_avg is None:

@@ -281,3 +281,58 @@ def test_config5_deep_hierarchy_256_negatives_loss_path():
     assert np.abs(e_neg.cpu().numpy() - o[2]).max() <= 1e-4 and abs(loss.item() - o[0]) <= 1e-4 * abs(o[0])
     assert np.abs(Wt.grad.cpu().numpy() - o[3]).max() / (np.abs(o[3]).max() + 1e-12) < 2e-3
     assert np.abs(Rt.grad.cpu().numpy() - o[4]).max() / (np.abs(o[4]).max() + 1e-12) < 2e-3
+
+
+def test_checkpoint_interchange_with_torch_adam(tmp_path):
+    """The reference saves/loads `torch.optim.Adam` state (oe_h.py:1876-1957).  A trainer restored from a checkpoint whose
+    optimizer state was produced by torch.optim.Adam continues exactly like torch.optim.Adam would, and our own
+    checkpoints load into torch.optim.Adam."""
+    from test_host_cpu import _fake_loaders
+    lm = SyntheticLabelMap([2, 4, 8])
+    dl = _fake_loaders(lm, 16, 4)
+    for split in dl.values():
+        for b in split:
+            b['path_to_image'] = [torch.rand(3, 32, 32, generator=torch.Generator().manual_seed(int(n[4:]))) for n in b['image_filename']]
+    gd = oe_h.create_combined_graphs(dl, lm, pick_per_level=True)
+    def make(name):
+        crit = oe_h.EuclideanConesWithImagesHypernymLoss(lm, 5, {}, 0.05, True, K=0.1, use_CNN=True)
+        return oe_h.JointEmbeddings(gd, dl, image_dir='', use_CNN=True, labelmap=lm, criterion=crit, lr=1e-3, n_workers=0,
+                                    batch_size=16, experiment_name=name, embedding_dim=10, neg_to_pos_ratio=5, image_fc7=None,
+                                    normalize=None, alpha=0.05, experiment_dir=str(tmp_path), n_epochs=1, eval_interval=5)
+    tr = make('a')
+    # a torch.optim.Adam over [table] + cnn params, stepped twice on random gradients = "reference-trained" state
+    params = [tr.model.embeddings.weight] + list(tr.img_feat_net.parameters())
+    ref = [p.detach().clone().requires_grad_(True) for p in params]
+    opt = torch.optim.Adam([{'params': ref}], lr=1e-3)
+    g = torch.Generator(device='cpu').manual_seed(0)
+    grads = [[torch.randn(p.shape, generator=g).to(DEV) for p in ref] for _ in range(3)]
+    for s in range(2):
+        for p, gr in zip(ref, grads[s]): p.grad = gr.clone()
+        opt.step()
+    torch.save({'epoch': 0, 'model_state_dict': {'module.embeddings.weight': ref[0].detach()}, 'optimizer_state_dict': opt.state_dict(),
+                'loss': 0.0, 'optimal_threshold': 0.0, 'reconstruction_scores': {'f1': 0, 'precision': 0, 'recall': 0, 'accuracy': 0, 'threshold': 0}},
+               os.path.join(tr.path_to_save_model, '7_model.pth'))
+    sd = {k: v for k, v in tr.img_feat_net.state_dict().items()}
+    names = [n for n, _ in tr.img_feat_net.named_parameters()]
+    for n, p in zip(names, ref[1:]): sd[n] = p.detach()
+    torch.save({'epoch': 0, 'model_state_dict': sd, 'optimizer_state_dict': {}, 'loss': 0.0, 'optimal_threshold': 0.0,
+                'reconstruction_scores': {}}, os.path.join(tr.path_to_save_model, '7_img_feat_net.pth'))
+    tr.load_model(7)
+    assert tr.table_step == 2 and tr.arena.step == 2
+    # third step on both sides with the same gradients (plain Adam on the table: no Riemannian rescale / clip here)
+    for p, gr in zip(ref, grads[2]): p.grad = gr.clone()
+    opt.step()
+    tr.table_grad.copy_(grads[2][0])
+    for p, gr in zip(tr.arena.params, grads[2][1:]): p.grad.copy_(gr)
+    tr.table_step += 1
+    ops.table_step_adam(tr.model.embeddings.weight.data, tr.table_grad, tr.table_m, tr.table_v, tr.table_step, 1e-3, 0.0, riemannian=False, clip=False)
+    tr.arena.adam_step(1e-3)
+    assert (tr.model.embeddings.weight.data - ref[0].detach()).abs().max().item() < 1e-6
+    for p, r in zip(tr.arena.params, ref[1:]):
+        assert (p.data - r.detach()).abs().max().item() < 1e-6
+    # and back: our checkpoint's optimizer state loads into torch.optim.Adam
+    tr.save_model(0.0, filename='out')
+    ck = torch.load(os.path.join(tr.path_to_save_model, 'out_model.pth'))
+    opt2 = torch.optim.Adam([{'params': [p.detach().clone().requires_grad_(True) for p in params]}], lr=1e-3)
+    opt2.load_state_dict(ck['optimizer_state_dict'])
+    assert int(opt2.state_dict()['state'][0]['step']) == 3
