@@ -499,9 +499,9 @@ class JointEmbeddings:
             for index, data_item in enumerate(self.dataloaders[phase]):
                 if global_batches is not None:                      # this rank's slice of the global batch
                     gb = global_batches[index]
-                    edges = [self.train_set[i_] if False else self.train_set.edge_list[i_] for i_ in gb] if not self.half_half else None
-                    if edges is None:
+                    if self.half_half:
                         raise NotImplementedError('half_half sampling under data parallelism')
+                    edges = [self.train_set.edge_list[i_] for i_ in gb]
                     g_from = np.fromiter((n2i[u] for u, _ in edges), dtype=np.int32, count=len(edges))
                     g_to = np.fromiter((n2i[v] for _, v in edges), dtype=np.int32, count=len(edges))
                     per = len(gb) // self.world
