@@ -366,3 +366,65 @@ def test_order_embeddings_images_legacy_trainer_step_vs_oracle():
     assert (tr.model.embeddings.weight.detach().cpu().numpy() != W0).any()      # the table moved
     l2, _, _ = tr.train_step(frm, to)
     assert torch.isfinite(l2)
+
+
+def test_classification_metrics_and_reconstruction_vs_bruteforce(tmp_path):
+    """calculate_classification_metrics (oe_h.py:1971-2178) and check_graph_embedding (:2180-2247): the batched GPU
+    versions against a direct per-image / per-pair restatement of the reference's loops on the oracle's energies."""
+    from test_host_cpu import _fake_loaders
+    lm = SyntheticLabelMap([2, 4, 8])
+    dl = _fake_loaders(lm, 24, 8)
+    for split in dl.values():
+        for b in split:
+            b['path_to_image'] = [torch.rand(3, 32, 32, generator=torch.Generator().manual_seed(int(n[4:]))) for n in b['image_filename']]
+    gd = oe_h.create_combined_graphs(dl, lm, pick_per_level=True)
+    crit = oe_h.EuclideanConesWithImagesHypernymLoss(lm, 5, {}, 0.05, True, K=0.1, use_CNN=True)
+    tr = oe_h.JointEmbeddings(gd, dl, image_dir='', use_CNN=True, labelmap=lm, criterion=crit, lr=1e-3, n_workers=0,
+                              batch_size=16, experiment_name='m', embedding_dim=10, neg_to_pos_ratio=5, image_fc7=None,
+                              normalize=None, alpha=0.05, experiment_dir=str(tmp_path), n_epochs=1, eval_interval=1)
+    tr.criterion.set_dataloader(tr.datasets['val'])
+    tr.model.eval(); tr.img_feat_net.eval()
+    got = tr.calculate_classification_metrics('val', k=[1, 3])
+    # ---- brute force on the same embeddings
+    G = gd['G_val']
+    images = [n for n in G if type(n) == str]; labels = sorted(n for n in G if type(n) != str)
+    with torch.no_grad():
+        img = tr.embed_images(images).cpu().numpy()
+        lab = tr.model(torch.arange(lm.n_classes, device=DEV)).cpu().numpy()
+    tp = {l: 0 for l in range(lm.n_classes)}; fp = dict(tp); fn = dict(tp); tn = dict(tp); hit = {1: 0, 3: 0}
+    for i, name in enumerate(images):
+        member = sorted(G.predecessors(name))
+        e = O.cone_energy(lab, np.repeat(img[i:i + 1], lm.n_classes, 0), 0.1)
+        for lvl in range(3):
+            s, t = lm.level_start[lvl], lm.level_stop[lvl]
+            order = np.argsort(e[s:t], kind='stable') + s
+            for kv in (1, 3):
+                hit[kv] += int(member[lvl] in order[:kv])
+            if order[0] == member[lvl]:
+                tp[member[lvl]] += 1
+                for o_ in range(s, t):
+                    if o_ != member[lvl]: tn[o_] += 1
+            else:
+                fp[int(order[0])] += 1; fn[member[lvl]] += 1
+    T = {k: sum(d[l] for l in labels) for k, d in (('tp', tp), ('fp', fp), ('fn', fn), ('tn', tn))}
+    prec = T['tp'] / max(T['tp'] + T['fp'], 1e-30); rec = T['tp'] / max(T['tp'] + T['fn'], 1e-30)
+    f1 = 0.0 if prec + rec == 0 else 2 * prec * rec / (prec + rec)
+    assert abs(got['m-f1'] - f1) < 1e-6 and abs(got['accuracy'] - (T['tp'] + T['tn']) / sum(T.values())) < 1e-6
+    assert abs(got['hit@1'] - hit[1] / (3 * len(images))) < 1e-6 and abs(got['hit@3'] - hit[3] / (3 * len(images))) < 1e-6
+    # ---- reconstruction: best-F1 threshold over all label pairs
+    best = tr.check_graph_embedding()
+    tc = gd['graph_tc']
+    pos_pairs = [(u, v) for u, v in tc.edges()]
+    nodes = sorted(set(u for u, _ in pos_pairs) | set(v for _, v in pos_pairs))
+    E = O.cone_energy(np.repeat(lab[nodes][:, None], len(nodes), 1), np.repeat(lab[nodes][None], len(nodes), 0), 0.1)
+    isp = np.zeros((len(nodes), len(nodes)), bool)
+    ix = {n: i for i, n in enumerate(nodes)}
+    for u, v in pos_pairs: isp[ix[u], ix[v]] = True
+    off = ~np.eye(len(nodes), dtype=bool)
+    p = E[isp]; n = E[(~isp) & off]
+    f1s = []
+    for t_ in np.unique(np.concatenate((p, n))):
+        cp = (p <= t_).sum(); cn = (n > t_).sum()
+        pr = cp / max(cp + (len(n) - cn), 1); rc = cp / len(p)
+        f1s.append(0.0 if pr + rc == 0 else 2 * pr * rc / (pr + rc))
+    assert abs(best[0] - max(f1s)) < 1e-4

@@ -159,3 +159,31 @@ def test_dp_two_ranks_gloo_sum_allreduce_and_replicated_sampler():
         want = g.draw_batch((6 + j % 8).astype(np.int32), (14 + j).astype(np.int32), 3)
         got = np.concatenate([res[r][3][s] for r in range(world)])
         assert np.array_equal(got, want)
+
+
+def test_pair_dataset_loads_image_files_and_collates(tmp_path):
+    """ETHECHierarchyWithImages (oe_h.py:583-736) on real files: resize to 224, [0,1] float CHW, train-time transform only
+    in __getitem__, get_image() without it; my_collate keeps python lists (oe_h.py:435-444)."""
+    from PIL import Image
+    lm = SyntheticLabelMap([2, 4])
+    G = DiGraph()
+    paths = {}
+    for j in range(3):
+        arr = (np.random.RandomState(j).rand(40, 60, 3) * 255).astype(np.uint8)
+        p = os.path.join(str(tmp_path), 'im%d.png' % j); Image.fromarray(arr).save(p); paths['im%d' % j] = p
+        G.add_edge(2 + j, 'im%d' % j); G.add_edge(0, 'im%d' % j)
+    G.add_edge(0, 2)
+    loaders = [{'image_filename': list(paths), 'path_to_image': list(paths.values())}]
+    ds = oe_h.ETHECHierarchyWithImages(G, lm, imageless_dataloaders=loaders, transform=lambda t: t.flip(-1))
+    assert len(ds) == G.size() == 7
+    item = ds[0]
+    assert item['original_to'] == 'im0' and item['from'] == 2 and item['to'].shape == (3, 224, 224)
+    plain = ds.get_image('im0')
+    assert plain.dtype == torch.float32 and 0.0 <= plain.min() and plain.max() <= 1.0
+    assert torch.equal(item['to'], plain.flip(-1))                       # train transform applied only in __getitem__
+    batch = oe_h.my_collate([ds[i] for i in range(len(ds))])
+    assert isinstance(batch['from'], list) and batch['status'].tolist() == [1] * 7
+    lab_edge = [i for i in range(len(ds)) if not isinstance(ds[i]['original_to'], str)]
+    assert len(lab_edge) == 1 and ds[lab_edge[0]]['to'] == 2
+    ds.set_levels_to_hide([1])                                           # hides every edge touching level 1 (labels 2..5)
+    assert all(not (isinstance(u, int) and 2 <= u < 6) and not (isinstance(v, int) and 2 <= v < 6) for u, v in ds.edge_list)
