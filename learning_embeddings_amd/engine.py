@@ -114,6 +114,7 @@ class StepEngine:
     def enable_timers(self):
         mk = lambda: torch.cuda.Event(enable_timing=True)
         self.timers = {'records': [], 'mk': mk}
+        ops.BN_TIMER = []
 
     def step(self):
         B, K = self.B, self.K
@@ -179,7 +180,12 @@ class StepEngine:
         for ev in recs:
             for i, n in enumerate(names):
                 out[n] += ev[i].elapsed_time(ev[i + 1])
-        return {n: v / max(len(recs), 1) for n, v in out.items()}
+        res = {n: v / max(len(recs), 1) for n, v in out.items()}
+        if ops.BN_TIMER:
+            res['fused_bn'] = sum(a.elapsed_time(b) for a, b, _ in ops.BN_TIMER) / max(len(recs), 1)
+            self.bn_bytes_per_step = sum(n for _, _, n in ops.BN_TIMER) / max(len(recs), 1)
+            self.bn_launch_groups_per_step = len(ops.BN_TIMER) / max(len(recs), 1)
+        return res
 
     def close(self):
         self.prefetch.close()

@@ -270,6 +270,17 @@ def _nhwc_rows(t, name):
     return N * H * W, Cc
 
 
+BN_TIMER = None     # set to a list to record (start_event, end_event, algorithmic_bytes) per fused-BN launch group (bench.py)
+
+
+def _bn_timed(call, nbytes):
+    if BN_TIMER is None:
+        return call()
+    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+    a.record(); call(); b.record()
+    BN_TIMER.append((a, b, nbytes))
+
+
 class BNActFn(torch.autograd.Function):
     """y = [relu](batch_norm(x) [+ residual]) on NHWC bf16, two streaming passes forward, two backward."""
 
@@ -283,9 +294,12 @@ class BNActFn(torch.autograd.Function):
         ws = _bn_workspace(x.device)
         # ReLU bitmask for backward: 1/16 of the bytes of y (y itself stays alive only as the next conv's input)
         mask = torch.empty(M * (Cc // 8), dtype=torch.uint8, device=x.device) if (relu and training) else None
-        check(lib.lec_bn_fwd(dptr(x), dptr(residual), M, Cc, dptr(weight), dptr(bias), float(eps), float(momentum),
-                             dptr(running_mean), dptr(running_var), int(bool(training)), dptr(save_mean), dptr(save_invstd),
-                             dptr(y), int(bool(relu)), dptr(mask), dptr(ws), ws.numel(), stream_ptr()))
+        el = M * Cc                                   # algorithmic bytes: x (stats) + x + y [+ residual] [+ mask]
+        nbytes = el * ((4 if training else 2) + 2 + (2 if residual is not None else 0)) + (el // 8 if mask is not None else 0)
+        _bn_timed(lambda: check(lib.lec_bn_fwd(dptr(x), dptr(residual), M, Cc, dptr(weight), dptr(bias), float(eps), float(momentum),
+                                               dptr(running_mean), dptr(running_var), int(bool(training)), dptr(save_mean),
+                                               dptr(save_invstd), dptr(y), int(bool(relu)), dptr(mask), dptr(ws), ws.numel(),
+                                               stream_ptr())), nbytes)
         if training:
             ctx.save_for_backward(x, mask, weight, save_mean, save_invstd)
             ctx.meta = (M, Cc, bool(relu), residual is not None)
@@ -301,8 +315,11 @@ class BNActFn(torch.autograd.Function):
         dres = torch.empty_like(x) if has_res else None
         dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device); dbeta = torch.empty_like(dgamma)
         ws = _bn_workspace(x.device)
-        check(lib.lec_bn_bwd(dptr(dy), None, dptr(mask), dptr(x), M, Cc, dptr(weight), dptr(save_mean), dptr(save_invstd), dptr(dx),
-                             dptr(dres), dptr(dgamma), dptr(dbeta), int(relu), dptr(ws), ws.numel(), stream_ptr()))
+        el = M * Cc                                   # 2 x (dy + x [+ mask]) + dx [+ d residual]
+        nbytes = el * (2 * 4 + 2 + (2 if has_res else 0)) + (2 * (el // 8) if relu else 0)
+        _bn_timed(lambda: check(lib.lec_bn_bwd(dptr(dy), None, dptr(mask), dptr(x), M, Cc, dptr(weight), dptr(save_mean),
+                                               dptr(save_invstd), dptr(dx), dptr(dres), dptr(dgamma), dptr(dbeta), int(relu),
+                                               dptr(ws), ws.numel(), stream_ptr())), nbytes)
         return dx, dres, dgamma, dbeta, None, None, None, None, None, None
 
 

@@ -71,10 +71,44 @@ def time_table(N, D, iters=50):
     return {'N': N, 'D': D, 'us': t * 1e6, 'GBps': 7 * N * D * 4 / t / 1e9}
 
 
+def time_bn(N=512, C=256, H=56, W=56, residual=True, iters=20):
+    """Fused BatchNorm(+residual)+ReLU forward and backward on one ResNet-50 layer shape (NHWC bf16): achieved HBM GB/s
+    against the algorithmic bytes  fwd: x (stats) + x + y [+ residual] + mask ; bwd: 2 x (dy + x + mask) + dx [+ d residual]."""
+    dev = 'cuda'
+    x = torch.randn(N, C, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    r = torch.randn(N, C, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if residual else None
+    dy = torch.randn(N, C, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.ones(C, device=dev); b = torch.zeros(C, device=dev)
+    rm = torch.zeros(C, device=dev); rv = torch.ones(C, device=dev)
+    el = N * C * H * W
+    fwd_b = el * (2 + 2 + 2 + (2 if residual else 0) + 0.125); bwd_b = el * (2 * (2 + 2 + 0.125) + 2 + (2 if residual else 0))
+    from learning_embeddings_amd._lib import lib, check, dptr, stream_ptr
+    y = torch.empty_like(x); dx = torch.empty_like(x); dr = torch.empty_like(x) if residual else None
+    mask = torch.empty(el // 8, dtype=torch.uint8, device=dev)
+    sm = torch.empty(C, device=dev); si = torch.empty(C, device=dev); dg = torch.empty(C, device=dev); db = torch.empty(C, device=dev)
+    ws = ops._bn_workspace(x.device)
+    M = N * H * W
+    def run():                                                  # straight through the C ABI: no autograd bookkeeping in the timing
+        check(lib.lec_bn_fwd(dptr(x), dptr(r), M, C, dptr(w), dptr(b), 1e-5, 0.1, dptr(rm), dptr(rv), 1, dptr(sm), dptr(si), dptr(y), 1,
+                             dptr(mask), dptr(ws), ws.numel(), stream_ptr()))
+        check(lib.lec_bn_bwd(dptr(dy), None, dptr(mask), dptr(x), M, C, dptr(w), dptr(sm), dptr(si), dptr(dx), dptr(dr), dptr(dg), dptr(db), 1,
+                             dptr(ws), ws.numel(), stream_ptr()))
+    for _ in range(3): run()
+    torch.cuda.synchronize()
+    a = torch.cuda.Event(enable_timing=True); c = torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters): run()
+    c.record(); torch.cuda.synchronize()
+    t = a.elapsed_time(c) * 1e-3 / iters
+    return {'shape': [N, C, H, W], 'residual': residual, 'us_fwd_bwd': t * 1e6, 'alg_MB': (fwd_b + bwd_b) / 1e6, 'GBps': (fwd_b + bwd_b) / t / 1e9}
+
+
 if __name__ == '__main__':
     out = []
     for B, K, D, N, M in ((128, 5, 10, 723, 128), (256, 5, 10, 2000, 256), (256, 256, 10, 50000, 256), (256, 256, 128, 50000, 256),
                           (4096, 256, 10, 50000, 4096), (4096, 64, 128, 50000, 4096), (16384, 5, 10, 2000, 16384)):
         r = time_joint(B, K, D, N, M); out.append(r); print(json.dumps(r))
+    for shp in ((512, 256, 56, 56), (512, 64, 112, 112), (512, 1024, 14, 14)):
+        print(json.dumps(time_bn(*shp)))
     for N, D in ((723, 10), (50000, 10), (50000, 128), (1000000, 128)):
         r = time_table(N, D); print(json.dumps(r))
