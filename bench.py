@@ -146,9 +146,15 @@ def main():
         roof_bn = None
         if 'fused_bn' in phases and getattr(eng, 'bn_bytes_per_step', 0):
             bn_s = phases['fused_bn'] * 1e-3
+            bn_traffic = None
+            try:                                                # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/r01_bn_pmc.md)
+                if args.workload == 'cfg3' and B == 256:
+                    bn_traffic = json.load(open(os.path.join(ROOT, 'profiles', 'r01_bn_pmc.json')))['traffic_bytes_per_step_fetch_x2']
+            except Exception:
+                pass
             roof_bn = {'kernel': 'fused BatchNorm(+residual)(+ReLU) family (bn_stats/bn_apply/bn_bwd_reduce/bn_bwd_apply, bn.hip): all %d layer launches of the step' % int(eng.bn_launch_groups_per_step),
                        'bound': 'hbm', 'achieved': round(eng.bn_bytes_per_step / bn_s / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
-                       'frac': round(eng.bn_bytes_per_step / bn_s / 8e12, 4), 'traffic': None,
+                       'frac': round(eng.bn_bytes_per_step / bn_s / 8e12, 4), 'traffic': bn_traffic,
                        'alg_bytes_per_step': int(eng.bn_bytes_per_step), 'ms_per_step': round(phases['fused_bn'], 3)}
         roof_cone = {'kernel': 'joint_loss_kernel (fused cone loss fwd+bwd)', 'bound': 'hbm',
                      'achieved': round(ab / cone_s / 1e9, 3), 'peak': 8000.0, 'unit': 'GB/s',
