@@ -191,6 +191,15 @@ int lec_bn_bwd(const void* dy, const void* y, const uint8_t* relu_mask, const vo
                const float* gamma, const float* save_mean, const float* save_invstd, void* dx, void* dresidual,
                float* dgamma, float* dbeta, int relu, void* workspace, int64_t workspace_bytes, lec_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * (8) 3x3 / stride 2 / pad 1 max pooling on NHWC bf16 (the ResNet stem's `maxpool`, oe_h.py:311 -> torchvision).
+ *     x: [N, H, W, C] bf16 (H, W even, C % 8 == 0); y: [N, H/2, W/2, C]; argmax: one byte per pooled element (window
+ *     position kh*3+kw; first maximum wins, NaN propagates, like the framework op).  Backward is a gather over the <= 4
+ *     windows covering an input position: dx is overwritten, no atomics.
+ * ------------------------------------------------------------------------------------------------------------- */
+int lec_maxpool3x3s2_fwd(const void* x, int N, int H, int W, int C, void* y, uint8_t* argmax, lec_stream_t stream);
+int lec_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, int N, int H, int W, int C, void* dx, lec_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

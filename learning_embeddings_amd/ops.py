@@ -333,3 +333,27 @@ def _bn_workspace(device):
         ws = torch.zeros(int(lib.lec_bn_workspace_bytes(2048)), dtype=torch.uint8, device=device)
         _bn_ws[key] = ws
     return ws
+
+
+# ------------------------------------------------------------------------------------------------ stem max pooling
+class MaxPool3x3s2Fn(torch.autograd.Function):
+    """3x3 / stride 2 / pad 1 max pooling on NHWC bf16 with a one-byte argmax and a gather backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, Cc, H, W = x.shape
+        y = torch.empty((N, Cc, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        arg = torch.empty(N * (H // 2) * (W // 2) * Cc, dtype=torch.uint8, device=x.device)
+        check(lib.lec_maxpool3x3s2_fwd(dptr(x), N, H, W, Cc, dptr(y), dptr(arg), stream_ptr()))
+        ctx.save_for_backward(arg); ctx.shape = (N, Cc, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        N, Cc, H, W = ctx.shape
+        if not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty((N, Cc, H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+        check(lib.lec_maxpool3x3s2_bwd(dptr(dy), dptr(arg), N, H, W, Cc, dptr(dx), stream_ptr()))
+        return dx

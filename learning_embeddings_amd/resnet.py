@@ -108,6 +108,21 @@ class Conv2d(nn.Conv2d):
         return super().forward(x)
 
 
+class MaxPool3x3s2(nn.MaxPool2d):
+    """The stem's MaxPool2d(3, stride=2, padding=1): on the MI355X with NHWC bf16 input it runs liblecone's kernel
+    (one-byte argmax instead of int64 indices, gather backward); anything else takes the stock op."""
+
+    def __init__(self):
+        super().__init__(kernel_size=3, stride=2, padding=1)
+
+    def forward(self, x):
+        if (BatchNormAct2d.fused_enabled and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0
+                and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.is_contiguous(memory_format=torch.channels_last)):
+            from . import ops
+            return ops.MaxPool3x3s2Fn.apply(x)
+        return super().forward(x)
+
+
 def conv3x3(cin, cout, stride=1):
     return Conv2d(cin, cout, kernel_size=3, stride=stride, padding=1, bias=False)
 
@@ -154,7 +169,7 @@ class ResNet(nn.Module):
         self.inplanes = 64
         self.conv1 = Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = BatchNormAct2d(64, relu=True)
-        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.maxpool = MaxPool3x3s2()
         self.layer1 = self._make_layer(block, 64, layers[0])
         self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
         self.layer3 = self._make_layer(block, 256, layers[2], stride=2)

@@ -136,3 +136,20 @@ def test_wgrad_side_stream_overlap_matches_inline_and_fp32():
         assert torch.allclose(a, b, rtol=1e-2, atol=1e-2 * a.abs().max().item())
     for a, b in zip(out['overlap'], (yr.detach(), xr.grad, wr.grad)):
         assert (a - b).abs().max().item() < 0.02 * b.abs().max().item()
+
+
+@pytest.mark.parametrize('N,C,H,W', [(4, 64, 16, 16), (2, 8, 6, 10), (16, 64, 112, 112)])
+def test_maxpool3x3s2_vs_torch(N, C, H, W):
+    from learning_embeddings_amd.resnet import MaxPool3x3s2
+    g = torch.Generator(device='cpu').manual_seed(N + C)
+    x = torch.randn(N, C, H, W, generator=g).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x[0, 0, :4, :4] = 1.0                                                     # ties: the first maximum of a window wins
+    dy = torch.randn(N, C, H // 2, W // 2, generator=g).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    xa = x.clone().requires_grad_(True)
+    y = MaxPool3x3s2()(xa); y.backward(dy)
+    xb = x.clone().float().requires_grad_(True)
+    yr = F.max_pool2d(xb, 3, 2, 1); yr.backward(dy.float())
+    assert torch.equal(y.float(), yr)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    # gradients: bf16 accumulation of up to 4 window contributions vs fp32
+    assert (xa.grad.float() - xb.grad).abs().max().item() <= 0.02 * (xb.grad.abs().max().item() + 1e-6)
