@@ -178,6 +178,9 @@ int lec_multilevel_ce_fwd_bwd(const float* logits, int64_t ld, const int64_t* le
  *     training == 0: running statistics.  y = [relu](x*scale + shift [+ residual]).
  *     Backward: g = dy * [y > 0] (relu) ; dbeta = sum g ; dgamma = sum g*xhat ; dx = gamma*invstd*(g - mean(g) -
  *     xhat*mean(g*xhat)) ; dresidual = g (pass NULL when the layer had no residual).
+ *     dy2 (optional): a second gradient stream for the same activation (an activation consumed by two branches -- the
+ *     next block's conv path and its identity / downsample path); the kernels add the two on the fly instead of the
+ *     framework materialising their sum.
  *     relu_mask (optional, [M, C/8] bytes): forward writes bit j of byte (row, c/8) = [y > 0]; backward given the mask
  *     reads it instead of y (1/16 of the bytes).  Pass NULL to mask from y.
  *     workspace: >= lec_bn_workspace_bytes(C) bytes, reusable across layers on one stream.
@@ -187,7 +190,7 @@ int lec_bn_fwd(const void* x, const void* residual, int64_t M, int C, const floa
                float momentum, float* running_mean, float* running_var, int training, float* save_mean,
                float* save_invstd, void* y, int relu, uint8_t* relu_mask, void* workspace, int64_t workspace_bytes,
                lec_stream_t stream);
-int lec_bn_bwd(const void* dy, const void* y, const uint8_t* relu_mask, const void* x, int64_t M, int C,
+int lec_bn_bwd(const void* dy, const void* dy2, const void* y, const uint8_t* relu_mask, const void* x, int64_t M, int C,
                const float* gamma, const float* save_mean, const float* save_invstd, void* dx, void* dresidual,
                float* dgamma, float* dbeta, int relu, void* workspace, int64_t workspace_bytes, lec_stream_t stream);
 

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblecone.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OK, E_ARG, E_HIP, E_EMPTY, E_STATE = 0, -1, -2, -3, -4
 ENERGY_HYP_CONE, ENERGY_ORDER = 0, 1
@@ -63,7 +63,7 @@ def _load():
         'lec_multilevel_ce_fwd_bwd': (i32, [p, i64, p, i32, i32, p, p, i32, p, p, p, i64, p]),
         'lec_bn_workspace_bytes': (i64, [i32]),
         'lec_bn_fwd': (i32, [p, p, i64, i32, p, p, f32, f32, p, p, i32, p, p, p, i32, p, p, i64, p]),
-        'lec_bn_bwd': (i32, [p, p, p, p, i64, i32, p, p, p, p, p, p, p, i32, p, i64, p]),
+        'lec_bn_bwd': (i32, [p, p, p, p, p, i64, i32, p, p, p, p, p, p, p, i32, p, i64, p]),
         'lec_maxpool3x3s2_fwd': (i32, [p, i32, i32, i32, i32, p, p, p]),
         'lec_maxpool3x3s2_bwd': (i32, [p, p, i32, i32, i32, i32, p, p]),
     }

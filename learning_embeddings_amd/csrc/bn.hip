@@ -225,7 +225,8 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const bf16x8* __re
 // backward, pass 1: per-block partials of  dbeta = sum g,  dgamma = sum g * xhat,   g = dy * [y > 0]
 // RELU: 0 none, 1 mask from the saved output y, 2 mask from the saved bitmask (y is then a byte array [M, C/8])
 template <int RELU>
-__global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const bf16x8* __restrict__ dy, const bf16x8* __restrict__ y,
+__global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const bf16x8* __restrict__ dy, const bf16x8* __restrict__ dy2,
+                                                                   const bf16x8* __restrict__ y,
                                                                    const bf16x8* __restrict__ x, int64_t M, int C, int CV,
                                                                    int CVB, int RPI, const float* __restrict__ mean,
                                                                    const float* __restrict__ invstd, float* __restrict__ part) {
@@ -243,6 +244,8 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const bf16x8*
     for (; r + stride < M; r += 2 * stride) {
       const int64_t i0 = r * CV + cv, i1 = (r + stride) * CV + cv;
       bf16x8 g0 = ld8(dy, i0), g1 = ld8(dy, i1), x0 = ld8(x, i0), x1 = ld8(x, i1);
+      bf16x8 h0 = g0, h1 = g1;
+      if (dy2) { h0 = ld8(dy2, i0); h1 = ld8(dy2, i1); }                      // second gradient stream of a forked activation
       bf16x8 y0 = g0, y1 = g1;
       unsigned int m0 = 0xff, m1 = 0xff;
       if (RELU == 1) { y0 = ld8(y, i0); y1 = ld8(y, i1); }
@@ -250,6 +253,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const bf16x8*
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float a = bf2f(g0.v[j]), b = bf2f(g1.v[j]);
+        if (dy2) { a += bf2f(h0.v[j]); b += bf2f(h1.v[j]); }
         if (RELU == 1) { a = bf2f(y0.v[j]) > 0.0f ? a : 0.0f; b = bf2f(y1.v[j]) > 0.0f ? b : 0.0f; }
         if (RELU == 2) { a = (m0 >> j) & 1u ? a : 0.0f; b = (m1 >> j) & 1u ? b : 0.0f; }
         acc[0][j] += a + b;
@@ -258,13 +262,15 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const bf16x8*
     }
     for (; r < M; r += stride) {
       const int64_t i0 = r * CV + cv;
-      bf16x8 g0 = ld8(dy, i0), x0 = ld8(x, i0), y0 = g0;
+      bf16x8 g0 = ld8(dy, i0), x0 = ld8(x, i0), y0 = g0, h0 = g0;
+      if (dy2) h0 = ld8(dy2, i0);
       unsigned int m0 = 0xff;
       if (RELU == 1) y0 = ld8(y, i0);
       if (RELU == 2) m0 = ((const unsigned char*)y)[i0];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float a = bf2f(g0.v[j]);
+        if (dy2) a += bf2f(h0.v[j]);
         if (RELU == 1) a = bf2f(y0.v[j]) > 0.0f ? a : 0.0f;
         if (RELU == 2) a = (m0 >> j) & 1u ? a : 0.0f;
         acc[0][j] += a; acc[1][j] += a * ((bf2f(x0.v[j]) - mu[j]) * is[j]);
@@ -292,7 +298,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk,
 
 // backward, pass 2: dx = gamma*invstd * (g - mean(g) - xhat * mean(g*xhat));  d residual = g
 template <bool RES, int RELU>
-__global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(const bf16x8* __restrict__ dy, const bf16x8* __restrict__ y,
+__global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(const bf16x8* __restrict__ dy, const bf16x8* __restrict__ dy2,
+                                                                  const bf16x8* __restrict__ y,
                                                                   const bf16x8* __restrict__ x, int64_t M, int CV, int RPI,
                                                                   const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                   const float* __restrict__ invstd, const float* __restrict__ c1,
@@ -309,13 +316,15 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(const bf16x8* 
   }
   const int64_t stride = (int64_t)gridDim.x * RPI;
   auto one = [&](int64_t i) {
-    bf16x8 g0 = ld8(dy, i), x0 = ld8(x, i), y0 = g0, o, gr;
+    bf16x8 g0 = ld8(dy, i), x0 = ld8(x, i), y0 = g0, h0 = g0, o, gr;
+    if (dy2) h0 = ld8(dy2, i);
     unsigned int m0 = 0xff;
     if (RELU == 1) y0 = ld8(y, i);
     if (RELU == 2) m0 = ((const unsigned char*)y)[i];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float a = bf2f(g0.v[j]);
+      if (dy2) a += bf2f(h0.v[j]);
       if (RELU == 1) a = bf2f(y0.v[j]) > 0.0f ? a : 0.0f;
       if (RELU == 2) a = (m0 >> j) & 1u ? a : 0.0f;
       const float xh = (bf2f(x0.v[j]) - mu[j]) * is[j];
@@ -372,7 +381,7 @@ extern "C" int lec_bn_fwd(const void* x, const void* residual, int64_t M, int C,
   return LEC_OK;
 }
 
-extern "C" int lec_bn_bwd(const void* dy, const void* y, const uint8_t* relu_mask, const void* x, int64_t M, int C,
+extern "C" int lec_bn_bwd(const void* dy, const void* dy2, const void* y, const uint8_t* relu_mask, const void* x, int64_t M, int C,
                           const float* gamma, const float* save_mean, const float* save_invstd, void* dx,
                           void* dresidual, float* dgamma, float* dbeta, int relu, void* workspace,
                           int64_t workspace_bytes, lec_stream_t stream) {
@@ -387,13 +396,13 @@ extern "C" int lec_bn_bwd(const void* dy, const void* y, const uint8_t* relu_mas
   BnGeom g = bn_geom(M, C);
   float* part = (float*)workspace;
   float* c1 = part + (int64_t)kBnMaxBlocks * 2 * C; float* c2 = c1 + C;
-#define R(M_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<M_>), dim3(g.nrb, g.NCH), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)ym, (const bf16x8*)x, M, C, g.CV, g.CVB, g.RPIB, save_mean, save_invstd, part)
+#define R(M_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<M_>), dim3(g.nrb, g.NCH), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)dy2, (const bf16x8*)ym, (const bf16x8*)x, M, C, g.CV, g.CVB, g.RPIB, save_mean, save_invstd, part)
   if (rm == 0) R(0); else if (rm == 1) R(1); else R(2);
 #undef R
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, part, g.nrb, C, M, dgamma, dbeta, c1, c2);
   int64_t nb = (M + g.RPI - 1) / g.RPI; nb = (nb + 1) / 2;
   const int nblk = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
-#define A(RES_, RELU_) hipLaunchKernelGGL((bn_bwd_apply_kernel<RES_, RELU_>), dim3(nblk), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)ym, (const bf16x8*)x, M, g.CV, g.RPI, gamma, save_mean, save_invstd, c1, c2, (bf16x8*)dx, (bf16x8*)dresidual)
+#define A(RES_, RELU_) hipLaunchKernelGGL((bn_bwd_apply_kernel<RES_, RELU_>), dim3(nblk), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)dy2, (const bf16x8*)ym, (const bf16x8*)x, M, g.CV, g.RPI, gamma, save_mean, save_invstd, c1, c2, (bf16x8*)dx, (bf16x8*)dresidual)
   if (dresidual) { if (rm == 0) A(true, 0); else if (rm == 1) A(true, 1); else A(true, 2); }
   else { if (rm == 0) A(false, 0); else if (rm == 1) A(false, 1); else A(false, 2); }
 #undef A

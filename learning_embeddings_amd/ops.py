@@ -285,7 +285,9 @@ class BNActFn(torch.autograd.Function):
     """y = [relu](batch_norm(x) [+ residual]) on NHWC bf16, two streaming passes forward, two backward."""
 
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu, fork=False):
+        """fork=True returns (y, y_alias): two handles on the SAME memory for an activation that feeds two branches, so
+        that backward receives the two branch gradients separately and the kernels add them on the fly."""
         M, Cc = _nhwc_rows(x, 'x')
         if residual is not None and (_nhwc_rows(residual, 'residual') != (M, Cc)):
             raise ValueError('residual shape mismatch')
@@ -303,24 +305,32 @@ class BNActFn(torch.autograd.Function):
         if training:
             ctx.save_for_backward(x, mask, weight, save_mean, save_invstd)
             ctx.meta = (M, Cc, bool(relu), residual is not None)
+        if fork:
+            return y, y.as_strided(y.size(), y.stride())
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy2=None):
         x, mask, weight, save_mean, save_invstd = ctx.saved_tensors
         M, Cc, relu, has_res = ctx.meta
+        if dy is None:
+            dy, dy2 = dy2, None
+        if dy is None:
+            raise RuntimeError('BNActFn.backward: no incoming gradient')
         if not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.contiguous(memory_format=torch.channels_last)
+        if dy2 is not None and not dy2.is_contiguous(memory_format=torch.channels_last):
+            dy2 = dy2.contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
         dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device); dbeta = torch.empty_like(dgamma)
         ws = _bn_workspace(x.device)
-        el = M * Cc                                   # 2 x (dy + x [+ mask]) + dx [+ d residual]
-        nbytes = el * (2 * 4 + 2 + (2 if has_res else 0)) + (2 * (el // 8) if relu else 0)
-        _bn_timed(lambda: check(lib.lec_bn_bwd(dptr(dy), None, dptr(mask), dptr(x), M, Cc, dptr(weight), dptr(save_mean),
+        el = M * Cc                                   # 2 x (dy [+ dy2] + x [+ mask]) + dx [+ d residual]
+        nbytes = el * (2 * (4 + (2 if dy2 is not None else 0)) + 2 + (2 if has_res else 0)) + (2 * (el // 8) if relu else 0)
+        _bn_timed(lambda: check(lib.lec_bn_bwd(dptr(dy), dptr(dy2), None, dptr(mask), dptr(x), M, Cc, dptr(weight), dptr(save_mean),
                                                dptr(save_invstd), dptr(dx), dptr(dres), dptr(dgamma), dptr(dbeta), int(relu),
                                                dptr(ws), ws.numel(), stream_ptr())), nbytes)
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 _bn_ws = {}

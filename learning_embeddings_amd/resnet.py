@@ -24,18 +24,21 @@ class BatchNormAct2d(nn.BatchNorm2d):
         super().__init__(num_features)
         self.fuse_relu = relu
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, fork=False):
+        """fork=True: return TWO handles (y, y_alias) on the output, one per consuming branch of the next block (its conv
+        path and its identity / downsample path): the fused backward then adds the two branch gradients on the fly."""
         if (BatchNormAct2d.fused_enabled and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and self.num_features % 8 == 0
                 and self.num_features <= 2048 and x.is_contiguous(memory_format=torch.channels_last)
                 and (residual is None or (residual.dtype == torch.bfloat16 and residual.shape == x.shape
                                           and residual.is_contiguous(memory_format=torch.channels_last)))):
             from . import ops
             return ops.BNActFn.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var,
-                                     self.training, self.momentum, self.eps, self.fuse_relu)
+                                     self.training, self.momentum, self.eps, self.fuse_relu, fork and self.training)
         y = F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, self.training, self.momentum, self.eps)
         if residual is not None:
             y = y + residual
-        return F.relu(y) if self.fuse_relu else y
+        y = F.relu(y) if self.fuse_relu else y
+        return (y, y) if fork else y
 
 
 class WgradOverlap:
@@ -140,10 +143,11 @@ class BasicBlock(nn.Module):
         self.conv2 = conv3x3(planes, planes); self.bn2 = BatchNormAct2d(planes, relu=True)     # relu(bn2(.) + identity)
         self.downsample = downsample
 
-    def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x))
-        return self.bn2(self.conv2(out), idt)
+    def forward(self, x, fork=False):
+        xa, xb = x if isinstance(x, tuple) else (x, x)          # two handles on the block input: conv path / identity path
+        idt = xb if self.downsample is None else self.downsample(xb)
+        out = self.bn1(self.conv1(xa))
+        return self.bn2(self.conv2(out), idt, fork)
 
 
 class Bottleneck(nn.Module):
@@ -156,11 +160,12 @@ class Bottleneck(nn.Module):
         self.conv3 = conv1x1(planes, planes * 4); self.bn3 = BatchNormAct2d(planes * 4, relu=True)  # relu(bn3(.) + identity)
         self.downsample = downsample
 
-    def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x))
+    def forward(self, x, fork=False):
+        xa, xb = x if isinstance(x, tuple) else (x, x)          # two handles on the block input: conv path / identity path
+        idt = xb if self.downsample is None else self.downsample(xb)
+        out = self.bn1(self.conv1(xa))
         out = self.bn2(self.conv2(out))
-        return self.bn3(self.conv3(out), idt)
+        return self.bn3(self.conv3(out), idt, fork)
 
 
 class ResNet(nn.Module):
@@ -197,7 +202,9 @@ class ResNet(nn.Module):
         if x.is_cuda and torch.is_autocast_enabled() and x.dtype == torch.float32:
             x = x.to(torch.get_autocast_gpu_dtype())          # the stem conv sees low-precision input like every other layer
         x = self.maxpool(self.bn1(self.conv1(x)))
-        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
+        for i, b in enumerate(blocks):
+            x = b(x, fork=i + 1 < len(blocks))                  # every block output but the last feeds two branches
         x = torch.flatten(self.avgpool(x), 1)
         return self.fc(x)
 

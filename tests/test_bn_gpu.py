@@ -153,3 +153,26 @@ def test_maxpool3x3s2_vs_torch(N, C, H, W):
     assert y.is_contiguous(memory_format=torch.channels_last)
     # gradients: bf16 accumulation of up to 4 window contributions vs fp32
     assert (xa.grad.float() - xb.grad).abs().max().item() <= 0.02 * (xb.grad.abs().max().item() + 1e-6)
+
+
+def test_bn_forked_output_two_gradient_streams():
+    """fork=True: two handles on one activation; backward with two branch gradients == backward with their sum."""
+    C = 64
+    g = torch.Generator(device='cpu').manual_seed(5)
+    mk = lambda: torch.randn(4, C, 12, 12, generator=g).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x, r, ga, gb = mk(), mk(), mk(), mk()
+    w = (torch.rand(C, generator=g) + 0.5).to(DEV); b = torch.zeros(C, device=DEV)
+    outs = []
+    for fork in (True, False):
+        xa = x.clone().requires_grad_(True); ra = r.clone().requires_grad_(True); wa = w.clone().requires_grad_(True); ba = b.clone().requires_grad_(True)
+        rm = torch.zeros(C, device=DEV); rv = torch.ones(C, device=DEV)
+        res = ops.BNActFn.apply(xa, ra, wa, ba, rm, rv, True, 0.1, 1e-5, True, fork)
+        if fork:
+            y1, y2 = res
+            assert y1.data_ptr() == y2.data_ptr()
+            torch.autograd.backward([y1, y2], [ga, gb])
+        else:
+            res.backward((ga.float() + gb.float()).to(torch.bfloat16))
+        outs.append((xa.grad.float(), ra.grad.float(), wa.grad, ba.grad))
+    for a, b_ in zip(*outs):
+        assert (a - b_).abs().max().item() <= 0.02 * (b_.abs().max().item() + 1e-6)      # bf16 rounding of the pre-summed gradient
