@@ -280,3 +280,71 @@ def test_multilevel_ce_batch512():
     loss.backward()
     ol, og = O.multilevel_ce(z, lab, levels)
     assert abs(loss.item() - ol) < 1e-5 * ol and np.abs(zt.grad.cpu().numpy() - og).max() < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------- full-size properties
+@pytest.mark.parametrize('B,K,D,N', [(256, 5, 10, 2000), (256, 256, 10, 50000)])
+def test_joint_loss_full_size_properties(B, K, D, N):
+    """At BASELINE.json's sizes (config 3: B=256, K=5; config 5: K=256, 50k labels) the oracle is too slow to run per
+    element, so the kernel is checked through size-independent properties:
+      * checksum: loss == sum_b e_pos + sum max(0, alpha - e_neg) from the kernel's own energy outputs;
+      * permutation: shuffling the positives (with their negatives) leaves the loss and the gradients unchanged;
+      * linearity in the weights: loss(w) with w = 2 doubles loss and gradients;
+      * locality: rows that appear in no pair get exactly zero gradient;
+      * sampled oracle: 64 random pairs agree with the oracle to 1e-4."""
+    rs = np.random.RandomState(B + K)
+    M = B
+    W = rs.randn(N, D).astype(np.float32); W *= (rs.uniform(0.1, 0.5, (N, 1)) / np.linalg.norm(W, axis=1, keepdims=True)).astype(np.float32)
+    R = (rs.randn(M, D) * 0.3).astype(np.float32)
+    used = rs.choice(N, N // 2, replace=False)                       # only half of the labels ever appear
+    frm = used[rs.randint(0, len(used), B)]; to = N + rs.permutation(M)[:B]
+    neg = used[rs.randint(0, len(used), (B, 2 * K))]
+    clash = neg[:, :K] == frm[:, None]                                # (u, u) cannot be sampled: A has a zero diagonal
+    while clash.any():
+        neg[:, :K][clash] = used[rs.randint(0, len(used), int(clash.sum()))]; clash = neg[:, :K] == frm[:, None]
+    alpha = 1.2
+    def run(order, w=None):
+        Wt = T(W).requires_grad_(True); Rt = T(R).requires_grad_(True)
+        loss, e_pos, e_neg = ops.JointLossFn.apply(Wt, Rt, _codes(frm[order], N), _codes(to[order], N),
+                                                   _codes(neg[order], N).reshape(B, -1).contiguous(),
+                                                   None if w is None else T(w[order]), 0.1, alpha, 0, 1, 1)
+        loss.backward()
+        return loss.item(), e_pos.cpu().numpy(), e_neg.cpu().numpy(), Wt.grad.cpu().numpy(), Rt.grad.cpu().numpy()
+    ident = np.arange(B)
+    l0, ep, en, gW, gR = run(ident)
+    chk = ep.astype(np.float64).sum() + np.maximum(alpha - en.astype(np.float64), 0).sum()
+    assert abs(l0 - chk) <= 1e-4 * abs(chk)
+    perm = rs.permutation(B)
+    l1, ep1, en1, gW1, gR1 = run(perm)
+    assert abs(l1 - l0) <= 1e-5 * abs(l0) and np.array_equal(ep1, ep[perm]) and np.array_equal(en1, en[perm])
+    assert np.abs(gW1 - gW).max() <= 1e-4 * np.abs(gW).max() and np.abs(gR1 - gR).max() <= 1e-4 * np.abs(gR).max()
+    l2, _, _, gW2, gR2 = run(ident, np.full(B, 2.0, np.float32))
+    assert abs(l2 - 2 * l0) <= 1e-5 * abs(l0) and np.abs(gW2 - 2 * gW).max() <= 1e-4 * np.abs(gW).max()
+    untouched = np.setdiff1d(np.arange(N), used)
+    assert (gW[untouched] == 0).all()
+    # a sample of pairs against the oracle
+    bs = rs.randint(0, B, 64); ks = rs.randint(0, 2 * K, 64)
+    xs = np.where(ks < K, frm[bs], neg[bs, ks]); ys = np.where(ks < K, neg[bs, ks], to[bs])
+    def emb(ix):
+        out = np.zeros((len(ix), D), np.float32); lab = ix < N
+        out[lab] = O.embedder_forward(W, ix[lab], 0.1); out[~lab] = O.image_soft_clip(R[ix[~lab] - N], 0.1)
+        return out
+    want = O.cone_energy(emb(xs), emb(ys), 0.1)
+    assert np.abs(en[bs, ks] - want).max() <= 1e-4
+
+
+def test_table_step_full_size_invariants():
+    """config-5 table (50 000 x 10) and a 1M x 128 table: after the step every row norm lies in [r_in, 1 - 1e-5] (the clip
+    invariant of oe_h.py:1604-1617), rows with zero gradient and zero moments do not move, and the step is idempotent on a
+    zero gradient with zero moments."""
+    for N, D in ((50000, 10), (1000000, 128)):
+        g = torch.Generator(device='cpu').manual_seed(N)
+        W = torch.randn(N, D, generator=g); W = (W / W.norm(dim=1, keepdim=True) * (0.12 + 0.8 * torch.rand(N, 1, generator=g))).to(DEV)
+        grad = torch.randn(N, D, generator=g).to(DEV); grad[::2] = 0
+        m = torch.zeros_like(W); v = torch.zeros_like(W)
+        W0 = W.clone()
+        ops.table_step_adam(W, grad, m, v, 1, 1e-3, 0.1)
+        n = W.norm(dim=1)
+        assert n.min().item() >= O.inner_radius(0.1) - 1e-6 and n.max().item() <= 1.0
+        assert torch.equal(W[::2], W0[::2])                              # untouched rows (already inside the shell) are bit-identical
+        assert (W[1::2] != W0[1::2]).any()
