@@ -122,9 +122,10 @@ int lec_table_step_rsgd(float* table, const float* grad, int64_t ld, int n_label
                         lec_stream_t stream);
 /* Adam over a flat fp32 parameter arena (the CNN's parameters live in one buffer so that the data-parallel gradient
  * all-reduce is ONE collective and the optimizer ONE launch).  Replaces optimizer_labels.step() for the CNN half of
- * oe_h.py:1523,1769.  grad_scale multiplies the gradient first (1.0 for the reference's SUM semantics). */
+ * oe_h.py:1523,1769.  grad_scale multiplies the gradient first (1.0 for the reference's SUM semantics).  param_bf16
+ * (optional, n bf16 values): a low-precision shadow of the updated parameters written in the same pass. */
 int lec_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                  float beta2, float eps, int step, float grad_scale, lec_stream_t stream);
+                  float beta2, float eps, int step, float grad_scale, void* param_bf16, lec_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * (5) Negative sampler (HOST, bit-exact).  Replaces set_negative_graph + sample_negative_edge (oe_h.py:799-809,

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblecone.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 OK, E_ARG, E_HIP, E_EMPTY, E_STATE = 0, -1, -2, -3, -4
 ENERGY_HYP_CONE, ENERGY_ORDER = 0, 1
@@ -51,7 +51,7 @@ def _load():
         'lec_image_softclip_bwd': (i32, [p, i64, p, i64, i64, i32, f32, p, i64, p]),
         'lec_table_step_adam': (i32, [p, p, p, p, i64, i32, i32, f32, f32, f32, f32, i32, f32, i32, i32, p]),
         'lec_table_step_rsgd': (i32, [p, p, i64, i32, i32, f32, f32, p]),
-        'lec_adam_flat': (i32, [p, p, p, p, i64, f32, f32, f32, f32, i32, f32, p]),
+        'lec_adam_flat': (i32, [p, p, p, p, i64, f32, f32, f32, f32, i32, f32, p, p]),
         'lec_sampler_create': (i32, [C.POINTER(p), p, i32, p, i64, p, p, i64, i32, i32, u64]),
         'lec_sampler_destroy': (None, [p]),
         'lec_sampler_seed': (i32, [p, u64]),

@@ -6,6 +6,7 @@
 //   lec_image_softclip_*: FeatCNN18.soft_clip (oe_h.py:323-328) and its autograd
 // All are one pass over [rows, D]; T lanes per row, xor-butterfly row norms.  HBM-bound: the Adam step moves
 // 7*N*D*4 bytes (read w, g, m, v; write w, m, v).
+#include <hip/hip_bf16.h>
 #include "lec_common.h"
 
 namespace lec {
@@ -121,9 +122,16 @@ __global__ __launch_bounds__(256) void table_rsgd_kernel(float* __restrict__ W, 
   }
 }
 
+// `lp` (optional): a bf16 shadow of the updated parameters, written in the same pass -- the conv layers read it directly,
+// so no per-layer fp32 -> bf16 cast kernels run in the forward pass.
+__device__ __forceinline__ unsigned short f2bf_rn(float f) {
+  __hip_bfloat16 h = __float2bfloat16(f);
+  return *reinterpret_cast<unsigned short*>(&h);
+}
+
 __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                        AdamConsts c, float grad_scale) {
+                                                        AdamConsts c, float grad_scale, unsigned short* __restrict__ lp) {
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   float4* p4 = (float4*)p; const float4* g4 = (const float4*)g; float4* m4 = (float4*)m; float4* v4 = (float4*)v;
@@ -132,11 +140,16 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, c
     adam_elem(P.x, G.x * grad_scale, M.x, V.x, c); adam_elem(P.y, G.y * grad_scale, M.y, V.y, c);
     adam_elem(P.z, G.z * grad_scale, M.z, V.z, c); adam_elem(P.w, G.w * grad_scale, M.w, V.w, c);
     p4[i] = P; m4[i] = M; v4[i] = V;
+    if (lp) {
+      ushort4 o; o.x = f2bf_rn(P.x); o.y = f2bf_rn(P.y); o.z = f2bf_rn(P.z); o.w = f2bf_rn(P.w);
+      ((ushort4*)lp)[i] = o;
+    }
   }
   for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float P = p[i], M = m[i], V = v[i];
     adam_elem(P, g[i] * grad_scale, M, V, c);
     p[i] = P; m[i] = M; v[i] = V;
+    if (lp) lp[i] = f2bf_rn(P);
   }
 }
 
@@ -258,7 +271,8 @@ extern "C" int lec_table_step_rsgd(float* table, const float* grad, int64_t ld, 
 }
 
 extern "C" int lec_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                             float beta1, float beta2, float eps, int step, float grad_scale, lec_stream_t stream) {
+                             float beta1, float beta2, float eps, int step, float grad_scale, void* param_bf16,
+                             lec_stream_t stream) {
   using namespace lec;
   LEC_CHECK_ARG(n >= 0 && step >= 1, "adam_flat: bad n/step");
   if (n == 0) return LEC_OK;
@@ -268,7 +282,7 @@ extern "C" int lec_adam_flat(float* param, const float* grad, float* exp_avg, fl
   AdamConsts c = adam_consts(lr, beta1, beta2, eps, step);
   int64_t blocks = ((n >> 2) + 255) / 256;
   int nblocks = (int)(blocks > 2048 ? 2048 : (blocks < 1 ? 1 : blocks));
-  hipLaunchKernelGGL(adam_flat_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, c, grad_scale);
+  hipLaunchKernelGGL(adam_flat_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, c, grad_scale, (unsigned short*)param_bf16);
   LEC_CHECK_LAUNCH("adam_flat_kernel");
   return LEC_OK;
 }

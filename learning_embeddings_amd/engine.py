@@ -39,7 +39,7 @@ def make_labelmap(name):
 
 class StepEngine:
     def __init__(self, workload='cfg3', n_images=4096, pool_images=None, dtype='bf16', lr=1e-4, alpha=0.01, K_cone=0.1,
-                 sampler_mode='replicated', seed=0, batch=None, device=None, overlap_wgrad=False):
+                 sampler_mode='replicated', seed=0, batch=None, device=None, overlap_wgrad=True):
         hier, arch, B, K, D, hw = WORKLOADS[workload]
         self.workload, self.arch, self.B, self.K, self.D, self.hw = workload, arch, batch or B, K, D, hw
         self.rank, self.local_rank, self.world = parallel.init_process_group()
@@ -81,9 +81,12 @@ class StepEngine:
         self.reducer = parallel.GradientReducer(self.arena, extra=[self.table_grad])
         if self.world > 1:
             torch.distributed.broadcast(self.arena.data, 0); torch.distributed.broadcast(self.table, 0)
+        # low-precision shadow weights (no per-layer cast kernels) + gradients written straight into the arena; the
+        # weight-gradient kernels optionally run on a second stream (overlap_wgrad)
         self.overlap = None
-        if overlap_wgrad and self.compute_dtype != torch.float32:
-            self.overlap = WgradOverlap.instance = WgradOverlap(self.reducer)
+        if self.compute_dtype == torch.bfloat16:
+            self.arena.enable_lowp_shadow()
+            self.overlap = WgradOverlap.instance = WgradOverlap(self.reducer, self.arena, side_stream=overlap_wgrad)
         else:
             WgradOverlap.instance = None
         # synthetic image pool resident in HBM: torch.rand in [0,1) like ToTensor output (oe_h.py:1463-1471), seed 0
@@ -91,6 +94,8 @@ class StepEngine:
         g = torch.Generator(device='cpu').manual_seed(1234 + self.rank)
         pool = torch.rand(P, 3, hw, hw, generator=g)
         self.pool = pool.to(self.device).contiguous(memory_format=torch.channels_last)
+        if self.compute_dtype != torch.float32:
+            self.pool = self.pool.to(self.compute_dtype)      # the backbone's first op would cast it anyway; same values
         self.P = P
         self.gfeat = torch.zeros(self.n_rows, D, device=self.device)
         self.pin = [torch.empty((self.B, 2 + 2 * K), dtype=torch.int32).pin_memory() for _ in range(2)]
@@ -189,3 +194,5 @@ class StepEngine:
 
     def close(self):
         self.prefetch.close()
+        if WgradOverlap.instance is self.overlap:
+            WgradOverlap.instance = None

@@ -317,6 +317,8 @@ class JointEmbeddings:
                  load_emb_from=None, load_cosine_emb=None, hide_levels=None, half_half=False,
                  compute_dtype=torch.float32, cnn_weights=None, writer=None):
         from .oe_h import Embedder, FeatCNN18, FeatCNN, FeatNet, EuclideanConesWithImagesHypernymLoss
+        from .resnet import WgradOverlap
+        WgradOverlap.instance = None            # this trainer drives gradients through plain autograd
         torch.manual_seed(0)                                               # oe_h.py:1338
         self.classes = labelmap.classes; self.n_classes = labelmap.n_classes
         self.levels = labelmap.levels; self.n_levels = len(self.levels); self.level_names = labelmap.level_names

@@ -223,14 +223,17 @@ def table_step_rsgd(table, grad, lr, K_cone=0.1):
     check(lib.lec_table_step_rsgd(dptr(table), dptr(grad), D, N, D, float(lr), float(K_cone), stream_ptr()))
 
 
-def adam_flat(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
-    """torch.optim.Adam arithmetic over one flat fp32 arena, one launch."""
+def adam_flat(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, param_lp=None):
+    """torch.optim.Adam arithmetic over one flat fp32 arena, one launch.  `param_lp`: optional flat bf16 shadow of the
+    parameters, refreshed in the same pass."""
     n = param.numel()
     for t in (param, grad, exp_avg, exp_avg_sq):
         if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
             raise ValueError('adam_flat: contiguous float32 buffers of equal length required')
+    if param_lp is not None and (param_lp.dtype != torch.bfloat16 or param_lp.numel() != n or not param_lp.is_contiguous()):
+        raise ValueError('adam_flat: param_lp must be a contiguous bf16 buffer of the same length')
     check(lib.lec_adam_flat(dptr(param), dptr(grad), dptr(exp_avg), dptr(exp_avg_sq), n, float(lr), float(betas[0]),
-                            float(betas[1]), float(eps), int(step), float(grad_scale), stream_ptr()))
+                            float(betas[1]), float(eps), int(step), float(grad_scale), dptr(param_lp), stream_ptr()))
 
 
 # ------------------------------------------------------------------------------------------------ multi-level CE
@@ -285,7 +288,7 @@ class BNActFn(torch.autograd.Function):
     """y = [relu](batch_norm(x) [+ residual]) on NHWC bf16, two streaming passes forward, two backward."""
 
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu, fork=False):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu, fork=False, sink=None):
         """fork=True returns (y, y_alias): two handles on the SAME memory for an activation that feeds two branches, so
         that backward receives the two branch gradients separately and the kernels add them on the fly."""
         M, Cc = _nhwc_rows(x, 'x')
@@ -305,6 +308,7 @@ class BNActFn(torch.autograd.Function):
         if training:
             ctx.save_for_backward(x, mask, weight, save_mean, save_invstd)
             ctx.meta = (M, Cc, bool(relu), residual is not None)
+            ctx.sink = sink                       # (weight Parameter, bias Parameter, reducer or None): write d gamma / d beta in place
         if fork:
             return y, y.as_strided(y.size(), y.stride())
         return y
@@ -323,14 +327,23 @@ class BNActFn(torch.autograd.Function):
             dy2 = dy2.contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
-        dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device); dbeta = torch.empty_like(dgamma)
+        sink = ctx.sink
+        if sink is not None and sink[0].grad is not None and sink[1].grad is not None:
+            dgamma, dbeta = sink[0].grad, sink[1].grad           # the flat arena's slots: no AccumulateGrad kernels
+        else:
+            sink = None
+            dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device); dbeta = torch.empty_like(dgamma)
         ws = _bn_workspace(x.device)
         el = M * Cc                                   # 2 x (dy [+ dy2] + x [+ mask]) + dx [+ d residual]
         nbytes = el * (2 * (4 + (2 if dy2 is not None else 0)) + 2 + (2 if has_res else 0)) + (2 * (el // 8) if relu else 0)
         _bn_timed(lambda: check(lib.lec_bn_bwd(dptr(dy), dptr(dy2), None, dptr(mask), dptr(x), M, Cc, dptr(weight), dptr(save_mean),
                                                dptr(save_invstd), dptr(dx), dptr(dres), dptr(dgamma), dptr(dbeta), int(relu),
                                                dptr(ws), ws.numel(), stream_ptr())), nbytes)
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None
+        if sink is not None:
+            if sink[2] is not None:
+                sink[2].mark_ready(sink[0]); sink[2].mark_ready(sink[1])
+            return dx, dres, None, None, None, None, None, None, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 _bn_ws = {}

@@ -53,6 +53,22 @@ class FlatArena:
             p.data = view
             p.grad = gview
         self.exp_avg = None; self.exp_avg_sq = None; self.step = 0
+        self.data_lp = None
+
+    def enable_lowp_shadow(self):
+        """Keep a flat bf16 copy of the parameters, refreshed by the Adam kernel itself; `lowp_view(p)` is parameter p's
+        slot in it (same shape and memory layout as p)."""
+        if self.data_lp is None:
+            self.data_lp = self.data.to(torch.bfloat16)
+            self._lp_views = {id(p): self.view_of(self.data_lp, k) for k, p in enumerate(self.params)}
+        return self
+
+    def lowp_view(self, p):
+        return self._lp_views.get(id(p)) if self.data_lp is not None else None
+
+    def refresh_lowp(self):
+        if self.data_lp is not None:
+            self.data_lp.copy_(self.data)
 
     def zero_grad(self):
         self.grad.zero_()
@@ -102,7 +118,7 @@ class FlatArena:
         if self.exp_avg is None:
             self.exp_avg = torch.zeros_like(self.data); self.exp_avg_sq = torch.zeros_like(self.data)
         self.step += 1
-        ops.adam_flat(self.data, self.grad, self.exp_avg, self.exp_avg_sq, self.step, lr, betas, eps, grad_scale)
+        ops.adam_flat(self.data, self.grad, self.exp_avg, self.exp_avg_sq, self.step, lr, betas, eps, grad_scale, self.data_lp)
 
 
 # ------------------------------------------------------------------------------------------------ process group
@@ -175,10 +191,14 @@ class GradientReducer:
 
     def reset(self):
         self._pending = [len(b) for b in self.buckets]
+        self._ready = set()
         self.handles = []
 
     def _make_hook(self, i):
         def hook(_p):
+            if i in self._ready:             # a parameter counts once per step, whoever reports it (autograd's
+                return                       # AccumulateGrad hook, a manual mark_ready from a fused backward, or both)
+            self._ready.add(i)
             bi = self._bucket_of[i]
             self._pending[bi] -= 1
             if self._pending[bi] == 0:

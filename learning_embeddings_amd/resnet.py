@@ -32,8 +32,10 @@ class BatchNormAct2d(nn.BatchNorm2d):
                 and (residual is None or (residual.dtype == torch.bfloat16 and residual.shape == x.shape
                                           and residual.is_contiguous(memory_format=torch.channels_last)))):
             from . import ops
+            ov = WgradOverlap.instance
+            sink = (self.weight, self.bias, ov.reducer) if (ov is not None and ov.enabled and ov.arena is not None and self.training) else None
             return ops.BNActFn.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var,
-                                     self.training, self.momentum, self.eps, self.fuse_relu, fork and self.training)
+                                     self.training, self.momentum, self.eps, self.fuse_relu, fork and self.training, sink)
         y = F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, self.training, self.momentum, self.eps)
         if residual is not None:
             y = y + residual
@@ -52,12 +54,36 @@ class WgradOverlap:
 
     instance = None
 
-    def __init__(self, reducer=None):
-        self.side = torch.cuda.Stream()
+    def __init__(self, reducer=None, arena=None, side_stream=True):
+        """`arena` (a FlatArena with a bf16 shadow) lets convolutions read their weights in low precision without a cast
+        kernel and write their weight gradient straight into the arena; `side_stream=False` keeps the wgrad kernels on
+        the main stream (only the cast/accumulate kernels are saved)."""
+        self.side = torch.cuda.Stream() if side_stream else None
         self.reducer = reducer
+        self.arena = arena
         self.enabled = True
 
+    def weight_lp(self, conv, dtype):
+        w16 = self.arena.lowp_view(conv.weight) if (self.arena is not None and dtype == torch.bfloat16) else None
+        return w16 if w16 is not None else conv.weight.to(dtype)
+
+    def _finish_wgrad(self, gw, conv):
+        w = conv.weight
+        if w.grad is None:
+            w.grad = gw.to(w.dtype)
+        elif self.arena is not None:
+            w.grad.copy_(gw)                                # each parameter gets exactly one gradient per step: overwrite
+        else:
+            w.grad.add_(gw)
+        if self.reducer is not None:
+            self.reducer.mark_ready(w)
+
     def submit(self, gy, x, w16, conv):
+        if self.side is None:
+            gw = torch.ops.aten.convolution_backward(gy, x, w16, None, conv.stride, conv.padding, conv.dilation, False,
+                                                     [0, 0], conv.groups, [False, True, False])[1]
+            self._finish_wgrad(gw, conv)
+            return
         main = torch.cuda.current_stream()
         ev = torch.cuda.Event(); ev.record(main)
         with torch.cuda.stream(self.side):
@@ -66,23 +92,18 @@ class WgradOverlap:
                                                      [0, 0], conv.groups, [False, True, False])[1]
             for t in (gy, x, w16):
                 t.record_stream(self.side)                 # the caching allocator must not recycle them under the side stream
-            w = conv.weight
-            if w.grad is None:
-                w.grad = gw.to(w.dtype)
-            else:
-                w.grad.add_(gw)
-            if self.reducer is not None:
-                self.reducer.mark_ready(w)
+            self._finish_wgrad(gw, conv)
 
     def join(self):
-        torch.cuda.current_stream().wait_stream(self.side)
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
 
 
 class _OverlapConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, conv):
-        w16 = w.to(x.dtype)
-        if x.is_contiguous(memory_format=torch.channels_last) and w16.dim() == 4:
+        w16 = WgradOverlap.instance.weight_lp(conv, x.dtype)
+        if x.is_contiguous(memory_format=torch.channels_last) and w16.dim() == 4 and not w16.is_contiguous(memory_format=torch.channels_last):
             w16 = w16.contiguous(memory_format=torch.channels_last)
         y = torch.ops.aten.convolution(x, w16, None, conv.stride, conv.padding, conv.dilation, False, [0, 0], conv.groups)
         ctx.save_for_backward(x, w16); ctx.conv = conv
