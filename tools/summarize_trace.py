@@ -6,11 +6,14 @@ stress sweep.   usage: summarize_trace.py <kernel_trace.csv> [--steps 4] > profi
 import argparse, collections, csv, re, sys
 
 ap = argparse.ArgumentParser(); ap.add_argument('trace'); ap.add_argument('--steps', type=int, default=4)
-ap.add_argument('--marker', default='joint_loss_kernel<'); ap.add_argument('--grid', type=int, default=16384, help='Grid_Size_X of the bench step launch of the marker kernel')
+ap.add_argument('--marker', default='joint_loss_kernel<'); ap.add_argument('--skip-last', type=int, default=3, help='trailing steps to ignore (bench.py appends 3 single-stream steps for the isolated BN measurement)')
+ap.add_argument('--grid', type=int, default=16384, help='Grid_Size_X of the bench step launch of the marker kernel')
 a = ap.parse_args()
 rows = list(csv.DictReader(open(a.trace)))
 # the stress sweep launches the same kernel with other grids: keep the bench-step launches only
 step_marks = [int(r['Start_Timestamp']) for r in rows if a.marker in r['Kernel_Name'] and int(r['Grid_Size_X']) == a.grid]
+if a.skip_last:
+    step_marks = step_marks[:-a.skip_last]
 lo, hi = step_marks[-a.steps - 1], step_marks[-1]
 n = a.steps
 sel = [r for r in rows if lo <= int(r['Start_Timestamp']) < hi]
