@@ -36,14 +36,18 @@ typedef void* lec_stream_t;              /* a hipStream_t, passed as an opaque p
 /* which energy E(x, y) a kernel evaluates */
 #define LEC_ENERGY_HYP_CONE  0           /* network/oe_h.py:811-833  (Poincare-ball entailment cone, parameter K) */
 #define LEC_ENERGY_ORDER     1           /* network/order_embeddings.py:818-824  sum_d max(0, x_d - y_d)^2        */
+#define LEC_ENERGY_EUC_CONE  2           /* network/oe.py:721-739  Euclidean entailment cone in cosine space:
+                                            max(0, -<x/|x|, (y-x)/|y-x|> + sqrt(1 - K^2/|x|^2)), parameter K        */
 
 /* how a label-table row becomes a point (the Embedder.forward of the trainer in use) */
 #define LEC_LABEL_RAW        0           /* order_embeddings.py:188-193 with K=None: the row itself               */
 #define LEC_LABEL_HYP        1           /* oe_h.py:77-104: +1e-15, tanh(clamp(atanh(r_in)+|e|))*e/|e|, then the
                                             no-grad clip of rows into [r_in, 1-1e-5] (straight-through)           */
+#define LEC_LABEL_SOFTCLIP_K 2           /* oe.py:65-80 Embedder.forward with K: x/|x| * (|x| + K)                 */
 /* how a raw CNN output row becomes a point */
 #define LEC_IMAGE_RAW        0
 #define LEC_IMAGE_SOFTCLIP   1           /* oe_h.py:323-328 FeatCNN18.soft_clip: x/|x| * (|x| + r_in)             */
+#define LEC_IMAGE_SOFTCLIP_K 2           /* oe.py:225-240   FeatCNN18.soft_clip: x/|x| * (|x| + K)                 */
 
 const char* lec_last_error(void);
 int         lec_abi_version(void);       /* bumped on any signature change; checked by the Python loader           */
@@ -62,6 +66,15 @@ int lec_pair_energy_bwd(int energy, const float* x, int64_t ldx, const float* y,
  * x: [N, D] (apexes, e.g. every label), y: [M, D] (e.g. every image).  E: [M, N] (ldE). */
 int lec_pair_energy_matrix(int energy, const float* x, int64_t ldx, int64_t N, const float* y, int64_t ldy, int64_t M,
                            int D, float K_cone, float* E, int64_t ldE, lec_stream_t stream);
+
+/* Fused all-pairs scoring + per-level top-k for calculate_classification_metrics (oe_h.py:2018-2036: E_operator of one
+ * image against every label, then torch.topk(k, largest=False) per level), without writing the M x N matrix.
+ * level_start: DEVICE int32 [L+1], level l = apex rows [level_start[l], level_start[l+1]); level_start[L] <= N.
+ * out_idx, out_val: [M, L, k]; ascending energy, ties by lowest index, NaN energies never selected; when a level has
+ * fewer than k rows the tail is (-1, +inf).  1 <= k <= 8, D <= 256. */
+int lec_level_topk(int energy, const float* x, int64_t ldx, int64_t N, const float* y, int64_t ldy, int64_t M, int D,
+                   const int32_t* level_start, int L, int k, float K_cone, int32_t* out_idx, float* out_val,
+                   lec_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * (2) Fused joint loss, forward + backward in one launch.  Replaces criterion.forward's train branch AFTER negative
@@ -97,15 +110,18 @@ int lec_joint_loss_fwd_bwd(int energy, int label_proj, int image_proj,
  *     lec_label_project_fwd  = Embedder.forward (oe_h.py:77-104): out[i] = project(table[idx[i]]).
  *     lec_label_project_bwd  adds d/d table into grad_table (dense, sparse=False semantics; float atomics).
  *     lec_image_softclip_fwd/bwd = FeatCNN18.soft_clip (oe_h.py:323-328) and its autograd.
+ *     label_proj is LEC_LABEL_HYP or LEC_LABEL_SOFTCLIP_K, image_proj LEC_IMAGE_SOFTCLIP or LEC_IMAGE_SOFTCLIP_K
+ *     (the oe.py forms, whose additive constant is K itself).
  * ------------------------------------------------------------------------------------------------------------- */
-int lec_label_project_fwd(const float* table, int64_t ld_table, int n_labels, const int64_t* idx, int64_t n, int D,
-                          float K_cone, float* out, int64_t ld_out, lec_stream_t stream);
-int lec_label_project_bwd(const float* table, int64_t ld_table, int n_labels, const int64_t* idx, int64_t n, int D,
-                          float K_cone, const float* gout, int64_t ld_gout, float* grad_table, lec_stream_t stream);
-int lec_image_softclip_fwd(const float* raw, int64_t ld_raw, int64_t n, int D, float K_cone, float* out, int64_t ld_out,
-                           lec_stream_t stream);
-int lec_image_softclip_bwd(const float* raw, int64_t ld_raw, const float* gout, int64_t ld_gout, int64_t n, int D,
-                           float K_cone, float* graw, int64_t ld_graw, lec_stream_t stream);
+int lec_label_project_fwd(int label_proj, const float* table, int64_t ld_table, int n_labels, const int64_t* idx,
+                          int64_t n, int D, float K_cone, float* out, int64_t ld_out, lec_stream_t stream);
+int lec_label_project_bwd(int label_proj, const float* table, int64_t ld_table, int n_labels, const int64_t* idx,
+                          int64_t n, int D, float K_cone, const float* gout, int64_t ld_gout, float* grad_table,
+                          lec_stream_t stream);
+int lec_image_softclip_fwd(int image_proj, const float* raw, int64_t ld_raw, int64_t n, int D, float K_cone, float* out,
+                           int64_t ld_out, lec_stream_t stream);
+int lec_image_softclip_bwd(int image_proj, const float* raw, int64_t ld_raw, const float* gout, int64_t ld_gout,
+                           int64_t n, int D, float K_cone, float* graw, int64_t ld_graw, lec_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * (4) Label-table maintenance, one pass over [n_labels, D].

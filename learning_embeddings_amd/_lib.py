@@ -5,12 +5,12 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblecone.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 OK, E_ARG, E_HIP, E_EMPTY, E_STATE = 0, -1, -2, -3, -4
-ENERGY_HYP_CONE, ENERGY_ORDER = 0, 1
-LABEL_RAW, LABEL_HYP = 0, 1
-IMAGE_RAW, IMAGE_SOFTCLIP = 0, 1
+ENERGY_HYP_CONE, ENERGY_ORDER, ENERGY_EUC_CONE = 0, 1, 2
+LABEL_RAW, LABEL_HYP, LABEL_SOFTCLIP_K = 0, 1, 2
+IMAGE_RAW, IMAGE_SOFTCLIP, IMAGE_SOFTCLIP_K = 0, 1, 2
 
 
 class LeconeError(RuntimeError):
@@ -43,12 +43,13 @@ def _load():
         'lec_pair_energy_fwd': (i32, [i32, p, i64, p, i64, i64, i32, f32, p, p]),
         'lec_pair_energy_bwd': (i32, [i32, p, i64, p, i64, p, i64, i32, f32, p, p, i64, p]),
         'lec_pair_energy_matrix': (i32, [i32, p, i64, i64, p, i64, i64, i32, f32, p, i64, p]),
+        'lec_level_topk': (i32, [i32, p, i64, i64, p, i64, i64, i32, p, i32, i32, f32, p, p, p]),
         'lec_joint_loss_fwd_bwd': (i32, [i32, i32, i32, p, i64, i32, p, i64, i32, p, p, p, p, i32, i32, i32, f32, f32,
                                          p, p, p, p, p, p, i64, p]),
-        'lec_label_project_fwd': (i32, [p, i64, i32, p, i64, i32, f32, p, i64, p]),
-        'lec_label_project_bwd': (i32, [p, i64, i32, p, i64, i32, f32, p, i64, p, p]),
-        'lec_image_softclip_fwd': (i32, [p, i64, i64, i32, f32, p, i64, p]),
-        'lec_image_softclip_bwd': (i32, [p, i64, p, i64, i64, i32, f32, p, i64, p]),
+        'lec_label_project_fwd': (i32, [i32, p, i64, i32, p, i64, i32, f32, p, i64, p]),
+        'lec_label_project_bwd': (i32, [i32, p, i64, i32, p, i64, i32, f32, p, i64, p, p]),
+        'lec_image_softclip_fwd': (i32, [i32, p, i64, i64, i32, f32, p, i64, p]),
+        'lec_image_softclip_bwd': (i32, [i32, p, i64, p, i64, i64, i32, f32, p, i64, p]),
         'lec_table_step_adam': (i32, [p, p, p, p, i64, i32, i32, f32, f32, f32, f32, i32, f32, i32, i32, p]),
         'lec_table_step_rsgd': (i32, [p, p, i64, i32, i32, f32, f32, p]),
         'lec_adam_flat': (i32, [p, p, p, p, i64, f32, f32, f32, f32, i32, f32, p, p]),

@@ -30,6 +30,7 @@ struct JointParams {
   const int32_t* pos_from; const int32_t* pos_to; const int32_t* neg; const float* weights;
   int B, K, D;
   float K_cone, alpha, r_in, r_in_h;
+  float lab_add, img_add;   // additive constant of the soft_clip forms (r_in for oe_h.py:328, K for oe.py:80,240)
   int label_proj, image_proj;
   float* e_pos; float* e_neg; float* loss;
   float* grad_table; float* grad_feat;
@@ -121,7 +122,7 @@ __device__ __forceinline__ void load_project(const JointParams& P, int code, boo
   const float* src = nullptr;
   if (valid) src = is_label ? P.table + (int64_t)code * P.ld_table : P.feat + (int64_t)(-1 - code) * P.ld_feat;
   const bool hyp = valid && is_label && P.label_proj == LEC_LABEL_HYP;
-  const bool img = valid && !is_label && P.image_proj == LEC_IMAGE_SOFTCLIP;
+  const bool img = valid && (is_label ? P.label_proj == LEC_LABEL_SOFTCLIP_K : P.image_proj != LEC_IMAGE_RAW);   // soft_clip forms
   float nn = 0.0f;
   if (prefetched != nullptr) {
 #pragma unroll
@@ -160,7 +161,7 @@ __device__ __forceinline__ void load_project(const JointParams& P, int code, boo
     mul = th; A = th / den;
     Bc = n > 0.0f ? (tp / den - th * denp / (den * den)) / n : 0.0f;
   } else if (img) {
-    float sc = n + P.r_in;                                                         // oe_h.py:328
+    float sc = n + (is_label ? P.lab_add : P.img_add);                             // oe_h.py:328 / oe.py:80,240
     mul = sc; A = sc / den;
     Bc = n > 0.0f ? (1.0f / den - sc * denp / (den * den)) / n : 0.0f;
   }
@@ -280,6 +281,7 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
     // ---- forward: energy of every pair of this iteration
     float E;
     ConeFwd cf;
+    ConeEval ev;
     if (ENERGY == LEC_ENERGY_HYP_CONE) {
       float xx = 0.f, yy = 0.f, s = 0.f, dd = 0.f;
 #pragma unroll
@@ -290,6 +292,16 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
       xx = group_sum<T>(xx); yy = group_sum<T>(yy); s = group_sum<T>(s); dd = group_sum<T>(dd);
       cf = cone_forward(xx, yy, s, dd, P.K_cone);
       E = cf.E;
+    } else if (ENERGY == LEC_ENERGY_EUC_CONE) {                                    // oe.py:721-739
+      float xx = 0.f, u = 0.f, dd = 0.f;
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) {
+        float df = y[i] - x[i];
+        xx += x[i] * x[i]; u += x[i] * df; dd += df * df;
+      }
+      xx = group_sum<T>(xx); u = group_sum<T>(u); dd = group_sum<T>(dd);
+      ev = euc_cone_eval<GRAD>(xx, dd, u, P.K_cone);
+      E = ev.E;
     } else {                                                                       // order_embeddings.py:818-824
       float e = 0.0f;
 #pragma unroll
@@ -311,9 +323,10 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
       const bool act = valid && g != 0.0f;
       if (__ballot(act) != 0ull) {
         float go[EPL];
-        if (ENERGY == LEC_ENERGY_HYP_CONE) {
+        if (ENERGY == LEC_ENERGY_HYP_CONE || ENERGY == LEC_ENERGY_EUC_CONE) {
           float cxx, cxy, cyy;
-          cone_grad_coeffs(cf, P.K_cone, cxx, cxy, cyy);
+          if (ENERGY == LEC_ENERGY_HYP_CONE) cone_grad_coeffs(cf, P.K_cone, cxx, cxy, cyy);
+          else { cxx = ev.cxx; cxy = ev.cxy; cyy = ev.cyy; }
           cxx *= g; cxy *= g; cyy *= g;
 #pragma unroll
           for (int i = 0; i < EPL; ++i) {
@@ -357,9 +370,11 @@ static int launch(const JointParams& P, bool grad, int energy, int nblocks, hipS
 #define LEC_JL(E_, G_, S_) hipLaunchKernelGGL((joint_loss_kernel<T, EPL, E_, G_, S_>), dim3(nblocks), dim3(256), 0, st, P)
   if (T == 1 && P.lds_stage) {
     if (energy == LEC_ENERGY_HYP_CONE) { if (grad) LEC_JL(LEC_ENERGY_HYP_CONE, true, (T == 1)); else LEC_JL(LEC_ENERGY_HYP_CONE, false, (T == 1)); }
+    else if (energy == LEC_ENERGY_EUC_CONE) { if (grad) LEC_JL(LEC_ENERGY_EUC_CONE, true, (T == 1)); else LEC_JL(LEC_ENERGY_EUC_CONE, false, (T == 1)); }
     else { if (grad) LEC_JL(LEC_ENERGY_ORDER, true, (T == 1)); else LEC_JL(LEC_ENERGY_ORDER, false, (T == 1)); }
   } else {
     if (energy == LEC_ENERGY_HYP_CONE) { if (grad) LEC_JL(LEC_ENERGY_HYP_CONE, true, false); else LEC_JL(LEC_ENERGY_HYP_CONE, false, false); }
+    else if (energy == LEC_ENERGY_EUC_CONE) { if (grad) LEC_JL(LEC_ENERGY_EUC_CONE, true, false); else LEC_JL(LEC_ENERGY_EUC_CONE, false, false); }
     else { if (grad) LEC_JL(LEC_ENERGY_ORDER, true, false); else LEC_JL(LEC_ENERGY_ORDER, false, false); }
   }
 #undef LEC_JL
@@ -432,9 +447,9 @@ extern "C" int lec_joint_loss_fwd_bwd(int energy, int label_proj, int image_proj
                                       float* e_pos, float* e_neg, float* loss, float* grad_table, float* grad_feat,
                                       void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
   using namespace lec;
-  LEC_CHECK_ARG(energy == LEC_ENERGY_HYP_CONE || energy == LEC_ENERGY_ORDER, "joint_loss: unknown energy %d", energy);
-  LEC_CHECK_ARG(label_proj == LEC_LABEL_RAW || label_proj == LEC_LABEL_HYP, "joint_loss: unknown label_proj %d", label_proj);
-  LEC_CHECK_ARG(image_proj == LEC_IMAGE_RAW || image_proj == LEC_IMAGE_SOFTCLIP, "joint_loss: unknown image_proj %d", image_proj);
+  LEC_CHECK_ARG(energy >= LEC_ENERGY_HYP_CONE && energy <= LEC_ENERGY_EUC_CONE, "joint_loss: unknown energy %d", energy);
+  LEC_CHECK_ARG(label_proj >= LEC_LABEL_RAW && label_proj <= LEC_LABEL_SOFTCLIP_K, "joint_loss: unknown label_proj %d", label_proj);
+  LEC_CHECK_ARG(image_proj >= LEC_IMAGE_RAW && image_proj <= LEC_IMAGE_SOFTCLIP_K, "joint_loss: unknown image_proj %d", image_proj);
   LEC_CHECK_ARG(B > 0 && K >= 0 && D > 0, "joint_loss: B=%d K=%d D=%d must be positive (K >= 0)", B, K, D);
   LEC_CHECK_ARG(table && n_labels > 0 && ld_table >= D, "joint_loss: table null or ld_table < D");
   LEC_CHECK_ARG(n_feat == 0 || (feat && ld_feat >= D), "joint_loss: feat null or ld_feat < D");
@@ -455,6 +470,7 @@ extern "C" int lec_joint_loss_fwd_bwd(int energy, int label_proj, int image_proj
   P.B = B; P.K = K; P.D = D; P.K_cone = K_cone; P.alpha = alpha;
   P.r_in = inner_radius_f(K_cone); P.r_in_h = inner_radius_h_f(K_cone);
   P.label_proj = label_proj; P.image_proj = image_proj;
+  P.lab_add = K_cone; P.img_add = image_proj == LEC_IMAGE_SOFTCLIP_K ? K_cone : P.r_in;
   P.e_pos = e_pos; P.e_neg = e_neg; P.loss = loss; P.grad_table = grad_table; P.grad_feat = grad_feat;
   P.counter = (unsigned int*)workspace; P.partials = (float*)((char*)workspace + 256);
   P.iters = g.iters; P.tasks_per_group = g.tasks_per_group;

@@ -125,6 +125,33 @@ __device__ __forceinline__ ConeEval cone_eval(float xx, float yy, float s, float
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Euclidean entailment cone (network/oe.py:721-739) from |x|^2, |y-x|^2 and u = <x, y-x>:
+//     theta = -u / (max(|x|,eps) max(|y-x|,eps))     (the two F.normalize calls, eps = 1e-12)
+//     psi   = -sqrt(1 - K^2/|x|^2) ,  E = max(theta - psi, 0)
+// Its gradient has the same shape as the hyperbolic one (E depends on x, y through |x|, |y-x|, u only):
+//     dE/dx = cxx x + cxy y ,  dE/dy = cxy x + cyy y .
+// ---------------------------------------------------------------------------------------------------------
+template <bool GRAD>
+__device__ __forceinline__ ConeEval euc_cone_eval(float xx, float dd, float u, float K) {
+  const float eps = 1e-12f;
+  const float xn = sqrtf(xx), dn = sqrtf(dd);
+  const float xc = fmaxf(xn, eps), dc = fmaxf(dn, eps);
+  const float KK = (float)((double)K * (double)K);          // python float K*K, then a float32 tensor op (oe.py:737)
+  const float theta = -(u / (xc * dc));
+  const float psi = -sqrtf(1.0f - KK / (xn * xn));
+  const float diff = theta - psi;
+  ConeEval r; r.E = diff < 0.0f ? 0.0f : diff;              // NaN stays NaN (torch.clamp)
+  r.cxx = r.cxy = r.cyy = 0.0f;
+  if (GRAD && diff >= 0.0f) {
+    const float A = -1.0f / (xc * dc);                                              // d theta / d u
+    const float Bx = (xn >= eps ? u / (xc * xc * dc) : 0.0f) - KK / (xn * xn * xn * psi);   // d theta/d|x| - d psi/d|x|
+    const float cd = dn >= eps ? u / (xc * dc * dc) / dc : 0.0f;                    // (d theta / d|y-x|) / |y-x|
+    r.cxx = -2.0f * A + Bx / xn + cd; r.cxy = A - cd; r.cyy = cd;
+  }
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Deterministic scalar reduction across blocks (one launch): every block publishes one partial; the block whose
 // ticket is last sums all partials in a fixed order and writes `out`.  Agent-scope release/acquire hand-off
 // (per-CU L1s and per-XCD L2s are not coherent): publish = store -> vmcnt(0) -> release fence -> vmcnt(0) ->

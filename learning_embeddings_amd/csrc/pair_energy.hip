@@ -23,12 +23,16 @@ __global__ __launch_bounds__(256) void pair_energy_fwd_kernel(const float* __res
     for (int d = t; d < D; d += T) {
       float a = xr[d], b = yr[d], df = a - b;
       if (ENERGY == LEC_ENERGY_HYP_CONE) { xx += a * a; yy += b * b; s += a * b; dd += df * df; }
+      else if (ENERGY == LEC_ENERGY_EUC_CONE) { xx += a * a; s -= a * df; dd += df * df; }        // s = <x, y-x>
       else { float m = fmaxf(df, 0.0f); xx += m * m; }
     }
     float e;
     if (ENERGY == LEC_ENERGY_HYP_CONE) {
       xx = group_sum<T>(xx); yy = group_sum<T>(yy); s = group_sum<T>(s); dd = group_sum<T>(dd);
       e = cone_eval<false>(xx, yy, s, dd, K).E;
+    } else if (ENERGY == LEC_ENERGY_EUC_CONE) {
+      xx = group_sum<T>(xx); s = group_sum<T>(s); dd = group_sum<T>(dd);
+      e = euc_cone_eval<false>(xx, dd, s, K).E;
     } else {
       e = group_sum<T>(xx);
     }
@@ -52,14 +56,16 @@ __global__ __launch_bounds__(256) void pair_energy_bwd_kernel(const float* __res
     const float* xr = x + (valid ? p : 0) * ldx;
     const float* yr = y + (valid ? p : 0) * ldy;
     const float g = valid ? gE[p] : 0.0f;
-    if (ENERGY == LEC_ENERGY_HYP_CONE) {
+    if (ENERGY == LEC_ENERGY_HYP_CONE || ENERGY == LEC_ENERGY_EUC_CONE) {
       float xx = 0.f, yy = 0.f, s = 0.f, dd = 0.f;
       for (int d = t; d < D; d += T) {
         float a = xr[d], b = yr[d], df = a - b;
-        xx += a * a; yy += b * b; s += a * b; dd += df * df;
+        xx += a * a; dd += df * df;
+        if (ENERGY == LEC_ENERGY_HYP_CONE) { yy += b * b; s += a * b; } else s -= a * df;
       }
-      xx = group_sum<T>(xx); yy = group_sum<T>(yy); s = group_sum<T>(s); dd = group_sum<T>(dd);
-      ConeEval ev = cone_eval<true>(xx, yy, s, dd, K);
+      xx = group_sum<T>(xx); s = group_sum<T>(s); dd = group_sum<T>(dd);
+      if (ENERGY == LEC_ENERGY_HYP_CONE) yy = group_sum<T>(yy);
+      ConeEval ev = ENERGY == LEC_ENERGY_HYP_CONE ? cone_eval<true>(xx, yy, s, dd, K) : euc_cone_eval<true>(xx, dd, s, K);
       if (valid) {
         for (int d = t; d < D; d += T) {
           float a = xr[d], b = yr[d];
@@ -117,9 +123,11 @@ __global__ __launch_bounds__(256) void pair_energy_matrix_kernel(const float* __
       for (int d = 0; d < D; ++d) {
         float a = xr[d], b = yr[d], df = a - b;
         if (ENERGY == LEC_ENERGY_HYP_CONE) { s += a * b; dd += df * df; }
+        else if (ENERGY == LEC_ENERGY_EUC_CONE) { s -= a * df; dd += df * df; }
         else { float m = fmaxf(df, 0.0f); s += m * m; }
       }
-      float e = ENERGY == LEC_ENERGY_HYP_CONE ? cone_eval<false>(xx, ystat[r], s, dd, K).E : s;
+      float e = ENERGY == LEC_ENERGY_HYP_CONE ? cone_eval<false>(xx, ystat[r], s, dd, K).E
+              : ENERGY == LEC_ENERGY_EUC_CONE ? euc_cone_eval<false>(xx, dd, s, K).E : s;
       if (j < N) E[(i0 + r) * ldE + j] = e;
     }
   }
@@ -132,7 +140,7 @@ static int pick_T(int D) { return D <= 4 ? 1 : (D <= 16 ? 4 : (D <= 64 ? 16 : 64
 extern "C" int lec_pair_energy_fwd(int energy, const float* x, int64_t ldx, const float* y, int64_t ldy, int64_t P,
                                    int D, float K_cone, float* E, lec_stream_t stream) {
   using namespace lec;
-  LEC_CHECK_ARG(energy == LEC_ENERGY_HYP_CONE || energy == LEC_ENERGY_ORDER, "pair_energy_fwd: unknown energy %d", energy);
+  LEC_CHECK_ARG(energy >= LEC_ENERGY_HYP_CONE && energy <= LEC_ENERGY_EUC_CONE, "pair_energy_fwd: unknown energy %d", energy);
   LEC_CHECK_ARG(P >= 0 && D > 0 && ldx >= D && ldy >= D, "pair_energy_fwd: bad sizes P=%lld D=%d", (long long)P, D);
   if (P == 0) return LEC_OK;
   LEC_CHECK_ARG(x && y && E, "pair_energy_fwd: null pointer");
@@ -141,6 +149,7 @@ extern "C" int lec_pair_energy_fwd(int energy, const float* x, int64_t ldx, cons
   int nblocks = (int)((waves + 3) / 4 > 4096 ? 4096 : (waves + 3) / 4);
   hipStream_t st = (hipStream_t)stream;
 #define L(T_) do { if (energy == LEC_ENERGY_HYP_CONE) hipLaunchKernelGGL((pair_energy_fwd_kernel<T_, LEC_ENERGY_HYP_CONE>), dim3(nblocks), dim3(256), 0, st, x, ldx, y, ldy, P, D, K_cone, E); \
+                   else if (energy == LEC_ENERGY_EUC_CONE) hipLaunchKernelGGL((pair_energy_fwd_kernel<T_, LEC_ENERGY_EUC_CONE>), dim3(nblocks), dim3(256), 0, st, x, ldx, y, ldy, P, D, K_cone, E); \
                    else hipLaunchKernelGGL((pair_energy_fwd_kernel<T_, LEC_ENERGY_ORDER>), dim3(nblocks), dim3(256), 0, st, x, ldx, y, ldy, P, D, K_cone, E); } while (0)
   if (T == 1) L(1); else if (T == 4) L(4); else if (T == 16) L(16); else L(64);
 #undef L
@@ -152,7 +161,7 @@ extern "C" int lec_pair_energy_bwd(int energy, const float* x, int64_t ldx, cons
                                    const float* gE, int64_t P, int D, float K_cone, float* gx, float* gy, int64_t ldg,
                                    lec_stream_t stream) {
   using namespace lec;
-  LEC_CHECK_ARG(energy == LEC_ENERGY_HYP_CONE || energy == LEC_ENERGY_ORDER, "pair_energy_bwd: unknown energy %d", energy);
+  LEC_CHECK_ARG(energy >= LEC_ENERGY_HYP_CONE && energy <= LEC_ENERGY_EUC_CONE, "pair_energy_bwd: unknown energy %d", energy);
   LEC_CHECK_ARG(P >= 0 && D > 0 && ldx >= D && ldy >= D && ldg >= D, "pair_energy_bwd: bad sizes");
   if (P == 0) return LEC_OK;
   LEC_CHECK_ARG(x && y && gE && gx && gy, "pair_energy_bwd: null pointer");
@@ -161,6 +170,7 @@ extern "C" int lec_pair_energy_bwd(int energy, const float* x, int64_t ldx, cons
   int nblocks = (int)((waves + 3) / 4 > 4096 ? 4096 : (waves + 3) / 4);
   hipStream_t st = (hipStream_t)stream;
 #define L(T_) do { if (energy == LEC_ENERGY_HYP_CONE) hipLaunchKernelGGL((pair_energy_bwd_kernel<T_, LEC_ENERGY_HYP_CONE>), dim3(nblocks), dim3(256), 0, st, x, ldx, y, ldy, gE, P, D, K_cone, gx, gy, ldg); \
+                   else if (energy == LEC_ENERGY_EUC_CONE) hipLaunchKernelGGL((pair_energy_bwd_kernel<T_, LEC_ENERGY_EUC_CONE>), dim3(nblocks), dim3(256), 0, st, x, ldx, y, ldy, gE, P, D, K_cone, gx, gy, ldg); \
                    else hipLaunchKernelGGL((pair_energy_bwd_kernel<T_, LEC_ENERGY_ORDER>), dim3(nblocks), dim3(256), 0, st, x, ldx, y, ldy, gE, P, D, K_cone, gx, gy, ldg); } while (0)
   if (T == 1) L(1); else if (T == 4) L(4); else if (T == 16) L(16); else L(64);
 #undef L
@@ -171,7 +181,7 @@ extern "C" int lec_pair_energy_bwd(int energy, const float* x, int64_t ldx, cons
 extern "C" int lec_pair_energy_matrix(int energy, const float* x, int64_t ldx, int64_t N, const float* y, int64_t ldy,
                                       int64_t M, int D, float K_cone, float* E, int64_t ldE, lec_stream_t stream) {
   using namespace lec;
-  LEC_CHECK_ARG(energy == LEC_ENERGY_HYP_CONE || energy == LEC_ENERGY_ORDER, "pair_energy_matrix: unknown energy %d", energy);
+  LEC_CHECK_ARG(energy >= LEC_ENERGY_HYP_CONE && energy <= LEC_ENERGY_EUC_CONE, "pair_energy_matrix: unknown energy %d", energy);
   LEC_CHECK_ARG(N >= 0 && M >= 0 && D > 0 && ldx >= D && ldy >= D && ldE >= N, "pair_energy_matrix: bad sizes");
   if (N == 0 || M == 0) return LEC_OK;
   LEC_CHECK_ARG(x && y && E, "pair_energy_matrix: null pointer");
@@ -184,6 +194,8 @@ extern "C" int lec_pair_energy_matrix(int energy, const float* x, int64_t ldx, i
   hipStream_t st = (hipStream_t)stream;
   if (energy == LEC_ENERGY_HYP_CONE)
     hipLaunchKernelGGL((pair_energy_matrix_kernel<LEC_ENERGY_HYP_CONE>), dim3(nblocks), dim3(256), smem, st, x, ldx, N, y, ldy, M, D, K_cone, E, ldE, TI);
+  else if (energy == LEC_ENERGY_EUC_CONE)
+    hipLaunchKernelGGL((pair_energy_matrix_kernel<LEC_ENERGY_EUC_CONE>), dim3(nblocks), dim3(256), smem, st, x, ldx, N, y, ldy, M, D, K_cone, E, ldE, TI);
   else
     hipLaunchKernelGGL((pair_energy_matrix_kernel<LEC_ENERGY_ORDER>), dim3(nblocks), dim3(256), smem, st, x, ldx, N, y, ldy, M, D, K_cone, E, ldE, TI);
   LEC_CHECK_LAUNCH("pair_energy_matrix_kernel");

@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, c
 }
 
 // ---- stand-alone projections --------------------------------------------------------------------------------------
-// MODE 0: label (Embedder.forward), rows gathered by idx;  MODE 1: image soft_clip, rows dense.
+// MODE 0: label (Embedder.forward of oe_h.py), rows gathered by idx;  MODE 1: soft_clip x/|x|(|x| + add), rows dense;
+// MODE 2: the same soft_clip on rows gathered by idx (Embedder.forward of oe.py).  `r_in` carries `add` for 1 and 2.
 template <int T, int MODE, bool BWD>
 __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ src, int64_t ld_src,
                                                       const int64_t* __restrict__ idx, int64_t n, int D, float r_in,
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
   for (int64_t base = wave * RPW; base < n; base += nwave * RPW) {
     const int64_t i = base + slot;
     const bool valid = i < n;
-    const int64_t srow = valid ? (MODE == 0 ? idx[i] : i) : 0;
+    const int64_t srow = valid ? (MODE != 1 ? idx[i] : i) : 0;
     const float* e = src + srow * ld_src;
     const float add = MODE == 0 ? 1e-15f : 0.0f;
     float nn = 0.0f;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
         const float c = Bc * dot;
         for (int d = t; d < D; d += T) {
           float gval = A * gout[i * ld_gout + d] + c * (e[d] + add);
-          if (MODE == 0) atomicAdd(gdst + srow * ld_gdst + d, gval);      // dense table gradient, duplicates add up
+          if (MODE != 1) atomicAdd(gdst + srow * ld_gdst + d, gval);      // dense table gradient, duplicates add up
           else gdst[i * ld_gdst + d] = gval;
         }
       }
@@ -221,11 +222,11 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
 template <int MODE, bool BWD>
 static int launch_project(const float* src, int64_t ld_src, const int64_t* idx, int64_t n, int D, float K,
                           float* out, int64_t ld_out, const float* gout, int64_t ld_gout, float* gdst, int64_t ld_gdst,
-                          hipStream_t st) {
+                          hipStream_t st, bool add_is_K = false) {
   const int T = pick_T(D);
   int64_t waves = (n + (64 / T) - 1) / (64 / T);
   int nblocks = (int)((waves + 3) / 4 > 4096 ? 4096 : (waves + 3) / 4);
-  const float r_in = inner_radius_f(K), r_in_h = inner_radius_h_f(K);
+  const float r_in = add_is_K ? K : inner_radius_f(K), r_in_h = inner_radius_h_f(K);
 #define L(T_) hipLaunchKernelGGL((project_kernel<T_, MODE, BWD>), dim3(nblocks), dim3(256), 0, st, src, ld_src, idx, n, D, r_in, r_in_h, out, ld_out, gout, ld_gout, gdst, ld_gdst)
   if (T == 1) L(1); else if (T == 4) L(4); else if (T == 16) L(16); else L(64);
 #undef L
@@ -287,39 +288,51 @@ extern "C" int lec_adam_flat(float* param, const float* grad, float* exp_avg, fl
   return LEC_OK;
 }
 
-extern "C" int lec_label_project_fwd(const float* table, int64_t ld_table, int n_labels, const int64_t* idx, int64_t n,
-                                     int D, float K_cone, float* out, int64_t ld_out, lec_stream_t stream) {
+extern "C" int lec_label_project_fwd(int label_proj, const float* table, int64_t ld_table, int n_labels,
+                                     const int64_t* idx, int64_t n, int D, float K_cone, float* out, int64_t ld_out,
+                                     lec_stream_t stream) {
   using namespace lec;
+  LEC_CHECK_ARG(label_proj == LEC_LABEL_HYP || label_proj == LEC_LABEL_SOFTCLIP_K, "label_project_fwd: unknown label_proj %d", label_proj);
   LEC_CHECK_ARG(n >= 0 && D > 0 && ld_table >= D && ld_out >= D && n_labels > 0, "label_project_fwd: bad sizes");
   if (n == 0) return LEC_OK;
   LEC_CHECK_ARG(table && idx && out, "label_project_fwd: null pointer");
+  if (label_proj == LEC_LABEL_SOFTCLIP_K)
+    return launch_project<2, false>(table, ld_table, idx, n, D, K_cone, out, ld_out, nullptr, 0, nullptr, 0, (hipStream_t)stream, true);
   return launch_project<0, false>(table, ld_table, idx, n, D, K_cone, out, ld_out, nullptr, 0, nullptr, 0, (hipStream_t)stream);
 }
 
-extern "C" int lec_label_project_bwd(const float* table, int64_t ld_table, int n_labels, const int64_t* idx, int64_t n,
-                                     int D, float K_cone, const float* gout, int64_t ld_gout, float* grad_table,
-                                     lec_stream_t stream) {
+extern "C" int lec_label_project_bwd(int label_proj, const float* table, int64_t ld_table, int n_labels,
+                                     const int64_t* idx, int64_t n, int D, float K_cone, const float* gout,
+                                     int64_t ld_gout, float* grad_table, lec_stream_t stream) {
   using namespace lec;
+  LEC_CHECK_ARG(label_proj == LEC_LABEL_HYP || label_proj == LEC_LABEL_SOFTCLIP_K, "label_project_bwd: unknown label_proj %d", label_proj);
   LEC_CHECK_ARG(n >= 0 && D > 0 && ld_table >= D && ld_gout >= D && n_labels > 0, "label_project_bwd: bad sizes");
   if (n == 0) return LEC_OK;
   LEC_CHECK_ARG(table && idx && gout && grad_table, "label_project_bwd: null pointer");
+  if (label_proj == LEC_LABEL_SOFTCLIP_K)
+    return launch_project<2, true>(table, ld_table, idx, n, D, K_cone, nullptr, 0, gout, ld_gout, grad_table, ld_table, (hipStream_t)stream, true);
   return launch_project<0, true>(table, ld_table, idx, n, D, K_cone, nullptr, 0, gout, ld_gout, grad_table, ld_table, (hipStream_t)stream);
 }
 
-extern "C" int lec_image_softclip_fwd(const float* raw, int64_t ld_raw, int64_t n, int D, float K_cone, float* out,
-                                      int64_t ld_out, lec_stream_t stream) {
+extern "C" int lec_image_softclip_fwd(int image_proj, const float* raw, int64_t ld_raw, int64_t n, int D, float K_cone,
+                                      float* out, int64_t ld_out, lec_stream_t stream) {
   using namespace lec;
+  LEC_CHECK_ARG(image_proj == LEC_IMAGE_SOFTCLIP || image_proj == LEC_IMAGE_SOFTCLIP_K, "image_softclip_fwd: unknown image_proj %d", image_proj);
   LEC_CHECK_ARG(n >= 0 && D > 0 && ld_raw >= D && ld_out >= D, "image_softclip_fwd: bad sizes");
   if (n == 0) return LEC_OK;
   LEC_CHECK_ARG(raw && out, "image_softclip_fwd: null pointer");
-  return launch_project<1, false>(raw, ld_raw, nullptr, n, D, K_cone, out, ld_out, nullptr, 0, nullptr, 0, (hipStream_t)stream);
+  return launch_project<1, false>(raw, ld_raw, nullptr, n, D, K_cone, out, ld_out, nullptr, 0, nullptr, 0, (hipStream_t)stream,
+                                  image_proj == LEC_IMAGE_SOFTCLIP_K);
 }
 
-extern "C" int lec_image_softclip_bwd(const float* raw, int64_t ld_raw, const float* gout, int64_t ld_gout, int64_t n,
-                                      int D, float K_cone, float* graw, int64_t ld_graw, lec_stream_t stream) {
+extern "C" int lec_image_softclip_bwd(int image_proj, const float* raw, int64_t ld_raw, const float* gout,
+                                      int64_t ld_gout, int64_t n, int D, float K_cone, float* graw, int64_t ld_graw,
+                                      lec_stream_t stream) {
   using namespace lec;
+  LEC_CHECK_ARG(image_proj == LEC_IMAGE_SOFTCLIP || image_proj == LEC_IMAGE_SOFTCLIP_K, "image_softclip_bwd: unknown image_proj %d", image_proj);
   LEC_CHECK_ARG(n >= 0 && D > 0 && ld_raw >= D && ld_gout >= D && ld_graw >= D, "image_softclip_bwd: bad sizes");
   if (n == 0) return LEC_OK;
   LEC_CHECK_ARG(raw && gout && graw, "image_softclip_bwd: null pointer");
-  return launch_project<1, true>(raw, ld_raw, nullptr, n, D, K_cone, nullptr, 0, gout, ld_gout, graw, ld_graw, (hipStream_t)stream);
+  return launch_project<1, true>(raw, ld_raw, nullptr, n, D, K_cone, nullptr, 0, gout, ld_gout, graw, ld_graw, (hipStream_t)stream,
+                                 image_proj == LEC_IMAGE_SOFTCLIP_K);
 }

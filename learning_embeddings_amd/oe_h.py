@@ -197,6 +197,7 @@ class _JointCriterionBase(torch.nn.Module):
     (oe_h.py:739-1058 and :1061-1315 differ only in E_operator and the Embedder they are paired with)."""
 
     energy = 'hyp_cone'
+    default_image_proj = _lib.IMAGE_SOFTCLIP         # which soft_clip the fused kernel applies to raw CNN outputs
 
     def _init_common(self, labelmap, neg_to_pos_ratio, feature_dict, alpha, pick_per_level, use_CNN):
         torch.nn.Module.__init__(self)
@@ -312,7 +313,7 @@ class _JointCriterionBase(torch.nn.Module):
         if stack:
             batch = torch.stack([s.to(dev, non_blocking=True) for s in stack])
             if self.use_CNN and hasattr(img_feat_net, 'forward_raw') and getattr(img_feat_net, 'K', None):
-                feats = img_feat_net.forward_raw(batch); image_proj = _lib.IMAGE_SOFTCLIP
+                feats = img_feat_net.forward_raw(batch); image_proj = self.default_image_proj
             else:
                 feats = _unwrap(img_feat_net)(batch).reshape(len(stack), -1).float()
 
@@ -330,8 +331,10 @@ class _JointCriterionBase(torch.nn.Module):
 
         return self.forward_indices(model, feats, codes(ix_from), codes(ix_to), codes(neg), image_proj=image_proj)
 
-    def forward_indices(self, model, feats, pos_from, pos_to, neg, weights=None, image_proj=_lib.IMAGE_SOFTCLIP):
+    def forward_indices(self, model, feats, pos_from, pos_to, neg, weights=None, image_proj=None):
         """The device part of the train step: node codes in, (loss, e_pos [B], e_neg [B,2K,1]) out, one kernel."""
+        if image_proj is None:
+            image_proj = self.default_image_proj
         w = _unwrap(model).embeddings.weight
         Kc = getattr(self, 'K', None) or 0.0
         loss, e_pos, e_neg = ops.JointLossFn.apply(w, feats, pos_from, pos_to, neg, weights, Kc, self.alpha,

@@ -308,7 +308,14 @@ class GlobalBatchSampler(torch.utils.data.Sampler):
 
 # ------------------------------------------------------------------------------------------------ the trainer
 class JointEmbeddings:
-    """oe_h.py:1318-2247."""
+    """oe_h.py:1318-2247.  `oe.JointEmbeddings` (the Euclidean-cone sibling, oe.py:1224-1991) subclasses this with its
+    own model classes and a plain Adam table step."""
+    riemannian_table_step = True             # oe_h.py:1768-1771: lambda-rescale before and clip after Adam
+
+    @staticmethod
+    def _model_classes():
+        from .oe_h import Embedder, FeatCNN18, FeatCNN, FeatNet
+        return Embedder, FeatCNN18, FeatCNN, FeatNet
 
     def __init__(self, graph_dict, imageless_dataloaders, image_dir, use_CNN, labelmap, criterion, lr, n_workers,
                  batch_size, experiment_name, embedding_dim, neg_to_pos_ratio, image_fc7, normalize, alpha,
@@ -316,7 +323,7 @@ class JointEmbeddings:
                  use_pretrained=True, load_wt=False, model_name=None, optimizer_method='adam', use_grayscale=False,
                  load_emb_from=None, load_cosine_emb=None, hide_levels=None, half_half=False,
                  compute_dtype=torch.float32, cnn_weights=None, writer=None):
-        from .oe_h import Embedder, FeatCNN18, FeatCNN, FeatNet, EuclideanConesWithImagesHypernymLoss
+        Embedder, FeatCNN18, FeatCNN, FeatNet = self._model_classes()
         from .resnet import WgradOverlap
         WgradOverlap.instance = None            # this trainer drives gradients through plain autograd
         torch.manual_seed(0)                                               # oe_h.py:1338
@@ -346,7 +353,7 @@ class JointEmbeddings:
         self.graph_dict = graph_dict
         self.optimal_threshold = 0; self.alpha = alpha
         self.embedding_dim = embedding_dim; self.neg_to_pos_ratio = neg_to_pos_ratio; self.normalize = None
-        is_hyp = isinstance(criterion, EuclideanConesWithImagesHypernymLoss)
+        is_hyp = getattr(criterion, 'K', None) is not None              # cone criteria carry K; order embeddings do not
         self.model = Embedder(embedding_dim=self.embedding_dim, labelmap=labelmap, normalize=self.normalize,
                               K=criterion.K if is_hyp else None)
         self.model.to(self.device)
@@ -486,7 +493,8 @@ class JointEmbeddings:
             self.arena.adam_step(self.lr_images * getattr(self, '_lr_scale', 1.0))
         else:                                                               # :1766-1771, one Adam over table + CNN at lr
             ops.table_step_adam(w.data, self.table_grad, self.table_m, self.table_v, self.table_step, lr,
-                                Kc or 0.0, riemannian=bool(Kc), clip=bool(Kc))
+                                Kc or 0.0, riemannian=bool(Kc) and self.riemannian_table_step,
+                                clip=bool(Kc) and self.riemannian_table_step)
             self.arena.adam_step(lr)
 
     def pass_samples(self, phase, save_to_tensorboard=True):
@@ -637,7 +645,10 @@ class JointEmbeddings:
         label_rep = self.model(torch.arange(self.n_classes, device=self.device))
         metrics['median_img_norm'] = torch.median(torch.norm(img_rep, dim=1)).item()
         metrics['median_label_norm'] = torch.median(torch.norm(label_rep[labels], dim=1)).item()
-        E = self._score(label_rep, img_rep)                                 # [n_img, n_labels]
+        starts = list(self.labelmap.level_start[:self.n_levels]) + [self.labelmap.level_stop[self.n_levels - 1]]
+        kk_all = min(max(k), 8)
+        top_idx, _ = ops.level_topk(label_rep.detach(), img_rep, starts, kk_all, getattr(self.criterion, 'K', None),
+                                    self.criterion.energy)           # [n_img, n_levels, k]: scoring + top-k in one launch
         member = np.zeros((len(images), self.n_levels), dtype=np.int64)
         for i, name in enumerate(images):
             m = sorted(G.predecessors(name))
@@ -645,12 +656,10 @@ class JointEmbeddings:
         member_t = torch.from_numpy(member).to(self.device)
         tp = torch.zeros(self.n_classes, device=self.device); fp = torch.zeros_like(tp); fn = torch.zeros_like(tp); tn = torch.zeros_like(tp)
         hit = {kv: torch.zeros(self.n_classes, device=self.device) for kv in k}
-        ones = torch.ones(len(images), device=self.device)
         for lvl in range(self.n_levels):
             s, e = self.labelmap.level_start[lvl], self.labelmap.level_stop[lvl]
-            kk = min(max(k), e - s)
-            _, idx = torch.topk(E[:, s:e], k=kk, largest=False, dim=1)
-            idx = idx + s
+            kk = min(kk_all, e - s)
+            idx = top_idx[:, lvl, :kk].long().clamp_min(s)          # (-1 only where every energy of the level is NaN)
             truth = member_t[:, lvl]
             for kv in k:
                 h = (idx[:, :min(kv, kk)] == truth[:, None]).any(dim=1).float()
@@ -679,10 +688,7 @@ class JointEmbeddings:
         return metrics
 
     def _score(self, label_rep, img_rep):
-        from .oe_h import EuclideanConesWithImagesHypernymLoss
-        if isinstance(self.criterion, EuclideanConesWithImagesHypernymLoss):
-            return ops.energy_matrix(label_rep, img_rep, self.criterion.K, 'hyp_cone')
-        return ops.energy_matrix(label_rep, img_rep, None, 'order')
+        return ops.energy_matrix(label_rep, img_rep, getattr(self.criterion, 'K', None), self.criterion.energy)
 
     @torch.no_grad()
     def check_graph_embedding(self):

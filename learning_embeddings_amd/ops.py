@@ -7,7 +7,7 @@ import torch
 from . import _lib
 from ._lib import lib, check, dptr, stream_ptr
 
-ENERGY = {'hyp_cone': _lib.ENERGY_HYP_CONE, 'order': _lib.ENERGY_ORDER}
+ENERGY = {'hyp_cone': _lib.ENERGY_HYP_CONE, 'order': _lib.ENERGY_ORDER, 'euc_cone': _lib.ENERGY_EUC_CONE}
 
 _workspaces = {}
 
@@ -76,18 +76,35 @@ def energy_matrix(apex, points, K_cone=0.1, energy='hyp_cone'):
     return E
 
 
+def level_topk(apex, points, level_start, k, K_cone=0.1, energy='hyp_cone'):
+    """Per level l and point i, the k apexes of rows [level_start[l], level_start[l+1]) with the smallest E(apex, point_i)
+    (oe_h.py:2018-2036: E_operator + torch.topk(largest=False) per level), fused: no [M, N] matrix.  `level_start`: L+1
+    ints.  Returns (idx int32 [M, L, k], val float32 [M, L, k]); entries past a short level are (-1, +inf)."""
+    a = _rows(apex, 'apex'); p = _rows(points, 'points')
+    N, D = a.shape; M = p.shape[0]
+    ls = torch.as_tensor(np.asarray(level_start, dtype=np.int32), device=a.device)
+    L = ls.numel() - 1
+    if L < 1 or int(np.asarray(level_start)[-1]) > N or np.any(np.diff(np.asarray(level_start)) < 0):
+        raise ValueError('level_start must be L+1 non-decreasing offsets into the apex rows')
+    idx = torch.empty(M, L, k, dtype=torch.int32, device=a.device); val = torch.empty(M, L, k, dtype=torch.float32, device=a.device)
+    check(lib.lec_level_topk(ENERGY[energy], dptr(a), _ld(a), N, dptr(p), _ld(p), M, D, dptr(ls), L, int(k), float(K_cone or 0.0),
+                             dptr(idx), dptr(val), stream_ptr()))
+    return idx, val
+
+
 # ------------------------------------------------------------------------------------------------ projections
 class LabelProjectFn(torch.autograd.Function):
-    """Embedder.forward (oe_h.py:77-104): gather + exp-map style tanh projection + straight-through clip."""
+    """Embedder.forward (oe_h.py:77-104): gather + exp-map style tanh projection + straight-through clip; with
+    mode=LABEL_SOFTCLIP_K the Euclidean trainer's form (oe.py:65-80): gather + x/|x| (|x| + K)."""
 
     @staticmethod
-    def forward(ctx, weight, idx, K_cone):
+    def forward(ctx, weight, idx, K_cone, mode=_lib.LABEL_HYP):
         w = _rows(weight, 'weight')
         idx = idx.reshape(-1).to(torch.int64).contiguous()
         n, D = idx.numel(), w.shape[1]
         out = torch.empty(n, D, dtype=torch.float32, device=w.device)
-        check(lib.lec_label_project_fwd(dptr(w), _ld(w), w.shape[0], dptr(idx), n, D, float(K_cone), dptr(out), D, stream_ptr()))
-        ctx.save_for_backward(w, idx); ctx.K = float(K_cone)
+        check(lib.lec_label_project_fwd(mode, dptr(w), _ld(w), w.shape[0], dptr(idx), n, D, float(K_cone), dptr(out), D, stream_ptr()))
+        ctx.save_for_backward(w, idx); ctx.K = float(K_cone); ctx.mode = mode
         return out
 
     @staticmethod
@@ -95,21 +112,21 @@ class LabelProjectFn(torch.autograd.Function):
         w, idx = ctx.saved_tensors
         g = gout.contiguous().float()
         gW = torch.zeros(w.shape, dtype=torch.float32, device=w.device)        # dense (sparse=False semantics)
-        check(lib.lec_label_project_bwd(dptr(w), _ld(w), w.shape[0], dptr(idx), idx.numel(), w.shape[1], ctx.K, dptr(g), g.shape[1], dptr(gW), stream_ptr()))
-        return gW, None, None
+        check(lib.lec_label_project_bwd(ctx.mode, dptr(w), _ld(w), w.shape[0], dptr(idx), idx.numel(), w.shape[1], ctx.K, dptr(g), g.shape[1], dptr(gW), stream_ptr()))
+        return gW, None, None, None
 
 
 class ImageSoftClipFn(torch.autograd.Function):
-    """FeatCNN18.soft_clip (oe_h.py:323-328)."""
+    """FeatCNN18.soft_clip (oe_h.py:323-328: + r_in(K)); mode=IMAGE_SOFTCLIP_K is oe.py:235-240 (+ K itself)."""
 
     @staticmethod
-    def forward(ctx, raw, K_cone):
+    def forward(ctx, raw, K_cone, mode=_lib.IMAGE_SOFTCLIP):
         shp = raw.shape
         r = _rows(raw.reshape(-1, shp[-1]).float(), 'raw')
         n, D = r.shape
         out = torch.empty(n, D, dtype=torch.float32, device=r.device)
-        check(lib.lec_image_softclip_fwd(dptr(r), _ld(r), n, D, float(K_cone), dptr(out), D, stream_ptr()))
-        ctx.save_for_backward(r); ctx.meta = (float(K_cone), shp, raw.dtype)
+        check(lib.lec_image_softclip_fwd(mode, dptr(r), _ld(r), n, D, float(K_cone), dptr(out), D, stream_ptr()))
+        ctx.save_for_backward(r); ctx.meta = (float(K_cone), shp, raw.dtype); ctx.mode = mode
         return out.view(shp)
 
     @staticmethod
@@ -118,8 +135,8 @@ class ImageSoftClipFn(torch.autograd.Function):
         K_cone, shp, dt = ctx.meta
         g = gout.reshape(r.shape).contiguous().float()
         graw = torch.empty_like(r)
-        check(lib.lec_image_softclip_bwd(dptr(r), _ld(r), dptr(g), g.shape[1], r.shape[0], r.shape[1], K_cone, dptr(graw), r.shape[1], stream_ptr()))
-        return graw.view(shp).to(dt), None
+        check(lib.lec_image_softclip_bwd(ctx.mode, dptr(r), _ld(r), dptr(g), g.shape[1], r.shape[0], r.shape[1], K_cone, dptr(graw), r.shape[1], stream_ptr()))
+        return graw.view(shp).to(dt), None, None
 
 
 # ------------------------------------------------------------------------------------------------ fused joint loss

@@ -189,6 +189,68 @@ def order_energy_grad(x, y, gE):
 
 
 # --------------------------------------------------------------------------------------------
+# 8f rank 4: the Euclidean entailment-cone sibling (network/oe.py)
+#   soft_clip  oe.py:75-80 (Embedder) / :235-240 (FeatCNN18):  normalize(x) * (||x|| + K)
+#   E_operator oe.py:721-739:  theta = -<normalize(x), normalize(y - x)>,  psi = -sqrt(1 - K^2/||x||^2),  E = max(theta - psi, 0)
+# --------------------------------------------------------------------------------------------
+def soft_clip_add(raw, add):
+    raw = np.asarray(raw, dtype=F32)
+    n = _rownorm(raw)
+    den = np.maximum(n, F32(1e-12))
+    return ((raw / den[:, None]) * (n + F32(add))[:, None]).astype(F32)
+
+
+def soft_clip_add_backward(raw, gout, add):
+    x = np.asarray(raw, dtype=np.float64); go = np.asarray(gout, dtype=np.float64)
+    n = np.sqrt(np.sum(x * x, axis=1)); den = np.maximum(n, 1e-12)
+    denp = (n >= 1e-12).astype(np.float64)
+    nsafe = np.where(n > 0, n, 1.0)
+    dot = np.sum(x * go, axis=1)
+    coef = (1.0 / den - (n + add) * denp / (den * den)) * dot / nsafe
+    return ((n + add) / den)[:, None] * go + coef[:, None] * x
+
+
+def _euc_cone_terms(x, y, K, dt):
+    x = np.asarray(x, dtype=dt).reshape(-1, np.shape(x)[-1]); y = np.asarray(y, dtype=dt).reshape(x.shape)
+    xn = _rownorm(x)                                                      # oe.py:727
+    df = y - x
+    dn = _rownorm(df)
+    xh = x / np.maximum(xn, dt(1e-12))[:, None]; dh = df / np.maximum(dn, dt(1e-12))[:, None]   # F.normalize eps
+    theta = -np.sum(xh * dh, axis=1, dtype=dt)                            # :735
+    with np.errstate(invalid='ignore', divide='ignore'):
+        psi = -np.sqrt(1 - (dt(float(K) * float(K)) / xn ** 2))           # :737
+    return dict(x=x, y=y, xn=xn, dn=dn, df=df, theta=theta, psi=psi, diff=theta - psi)
+
+
+def euc_cone_energy(x, y, K, dtype=F32):
+    shp = np.shape(x)[:-1]
+    return np.maximum(_euc_cone_terms(x, y, K, dtype)['diff'], dtype(0)).reshape(shp)   # :739
+
+
+def euc_cone_energy_grad(x, y, gE, K):
+    """Analytic dE/dx, dE/dy (float64); the hinge mask comes from the float32 forward."""
+    f = _euc_cone_terms(x, y, K, F32)
+    d = _euc_cone_terms(x, y, K, np.float64)
+    g = np.asarray(gE, dtype=np.float64).reshape(-1) * (f['diff'] >= 0)
+    xn, dn, psi = d['xn'], d['dn'], d['psi']
+    u = np.sum(d['x'] * d['df'], axis=1)
+    ok_x = xn >= 1e-12; ok_d = dn >= 1e-12
+    xc = np.maximum(xn, 1e-12); dc = np.maximum(dn, 1e-12)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        A_ = -1.0 / (xc * dc)                                             # d theta / d u
+        Bx = np.where(ok_x, u / (xc * xc * dc), 0.0) - float(K) ** 2 / (xn ** 3 * psi)   # d theta/d|x| - d psi/d|x|
+        C_ = np.where(ok_d, u / (xc * dc * dc), 0.0)                      # d theta / d|y - x|
+        cd = C_ / dc
+        cxx = g * (-2 * A_ + Bx / xn + cd); cxy = g * (A_ - cd); cyy = g * cd
+    z = g == 0
+    cxx = np.where(z, 0.0, cxx); cxy = np.where(z, 0.0, cxy); cyy = np.where(z, 0.0, cyy)
+    gx = cxx[:, None] * d['x'] + cxy[:, None] * d['y']
+    gy = cxy[:, None] * d['x'] + cyy[:, None] * d['y']
+    shp = np.shape(x)
+    return gx.reshape(shp), gy.reshape(shp)
+
+
+# --------------------------------------------------------------------------------------------
 # a8/a9: the criterion's train-mode forward + backward given the sampled negatives
 #        (oe_h.py:904-967 with :835-847; negative slot layout :951-957)
 # --------------------------------------------------------------------------------------------
@@ -210,14 +272,18 @@ def joint_loss_fwd_bwd(W, R, pos_from, pos_to, neg, alpha, K, weights=None, ener
         out = np.zeros((len(ix), W.shape[1]), F32)
         lab = ix < N
         if lab.any():
-            out[lab] = embedder_forward(W, ix[lab], K) if energy == 'hyp_cone' else W[ix[lab]]
+            out[lab] = (embedder_forward(W, ix[lab], K) if energy == 'hyp_cone' else
+                        soft_clip_add(W[ix[lab]], K) if energy == 'euc_cone' else W[ix[lab]])      # oe.py:65-80
         if (~lab).any():
-            out[~lab] = image_soft_clip(R[ix[~lab] - N], K)
+            out[~lab] = (soft_clip_add(R[ix[~lab] - N], K) if energy == 'euc_cone' else       # oe.py:225-240
+                         image_soft_clip(R[ix[~lab] - N], K))
         return out
 
     x = embed(frm); y = embed(to)
     if energy == 'hyp_cone':
         E = cone_energy(x, y, K)
+    elif energy == 'euc_cone':
+        E = euc_cone_energy(x, y, K)
     else:
         E = order_energy(x, y)
     e_pos = E[:B]; e_neg = E[B:].reshape(B, K2)
@@ -228,6 +294,8 @@ def joint_loss_fwd_bwd(W, R, pos_from, pos_to, neg, alpha, K, weights=None, ener
                          (-(w[:, None].astype(np.float64)) * ((F32(alpha) - e_neg) >= 0)).reshape(-1)])
     if energy == 'hyp_cone':
         gx, gy = cone_energy_grad(x, y, gE, K)
+    elif energy == 'euc_cone':
+        gx, gy = euc_cone_energy_grad(x, y, gE, K)
     else:
         gx, gy = order_energy_grad(x, y, gE)
     gW = np.zeros(W.shape, np.float64); gR = np.zeros(R.shape, np.float64)
@@ -236,11 +304,14 @@ def joint_loss_fwd_bwd(W, R, pos_from, pos_to, neg, alpha, K, weights=None, ener
         if lab.any():
             if energy == 'hyp_cone':
                 gW += embedder_backward(W, ix[lab], gout[lab], K)
+            elif energy == 'euc_cone':
+                np.add.at(gW, ix[lab], soft_clip_add_backward(W[ix[lab]], gout[lab], K))
             else:
                 np.add.at(gW, ix[lab], gout[lab])
         if (~lab).any():
             j = ix[~lab] - N
-            np.add.at(gR, j, image_soft_clip_backward(R[j], gout[~lab], K))
+            np.add.at(gR, j, soft_clip_add_backward(R[j], gout[~lab], K) if energy == 'euc_cone' else
+                      image_soft_clip_backward(R[j], gout[~lab], K))
     return loss, e_pos, e_neg, gW, gR
 
 

@@ -475,3 +475,73 @@ def test_step_engine_data_parallel_replicas_stay_identical(overlap):
             frm.append(chain[::-1][bb % L])
         want = g.draw_batch(np.array(frm, dtype=np.int32), (N + j).astype(np.int32), 4)
         assert np.array_equal(np.concatenate([res[0][3][s_], res[1][3][s_]]), want)
+
+
+# ------------------------------------------------------------------------------------------------ oe.py (Euclidean cones)
+def test_euclidean_cones_call_site_vs_reference_fixture():
+    """network/oe.py's criterion / Embedder call site (K = 3.0) against fixture F10."""
+    from learning_embeddings_amd import oe, _lib
+    f = np.load(os.path.join(GOLDEN, 'F10_euclidean_cone.npz')); K = float(f['K'])
+    g = lambda k: f['c_' + k]
+    lm = SyntheticLabelMap(g('levels').tolist(), edges=[tuple(e) for e in g('edges').tolist()])
+    N, M, Kn = lm.n_classes, int(g('n_images')), int(g('Kneg'))
+    names = ['img_%06d' % j for j in range(M)]
+    n2i = {i: i for i in range(N)}; n2i.update({names[j]: N + j for j in range(M)}); i2n = {v: k for k, v in n2i.items()}
+    crit = oe.EuclideanConesWithImagesHypernymLoss(lm, Kn, {}, float(g('alpha')), True, K=K, use_CNN=True)
+    crit.set_negative_graph(NegativeGraph.from_labelmap(lm, n_images=M, pick_per_level=True, seed=0), n2i, i2n)
+    R = torch.tensor(g('R'), device=DEV, requires_grad=True)
+
+    class DL:
+        def get_image(self, fname):
+            return R[n2i[fname] - N]
+
+    class Net(torch.nn.Module):                                             # identity "CNN" + oe.py:235-240 soft_clip
+        def __init__(self):
+            super().__init__(); self.K = K
+        def forward_raw(self, x):
+            return x.float()
+        def forward(self, x):
+            return ops.ImageSoftClipFn.apply(x.float(), self.K, _lib.IMAGE_SOFTCLIP_K)
+    crit.set_dataloader(DL())
+    model = oe.Embedder(g('W').shape[1], lm, None, K=K).to(DEV)
+    with torch.no_grad():
+        model.embeddings.weight.copy_(torch.tensor(g('W')))
+    of = [i2n[int(i)] for i in g('from')]; ot = [i2n[int(i)] for i in g('to')]
+    inputs_to = [R[n2i[t] - N] if isinstance(t, str) else t for t in ot]
+    crit.seed_sampler(0)
+    loss, e_pos, e_neg = crit(model, Net(), list(of), inputs_to, of, ot, torch.ones(len(of)), 'train')
+    assert np.array_equal(crit.last_negatives, g('neg'))
+    loss.backward()
+    assert np.abs(e_pos.detach().cpu().numpy() - g('e_pos')).max() <= 1e-4
+    assert np.abs(e_neg.detach().cpu().numpy() - g('e_neg')).max() <= 1e-4
+    assert abs(loss.item() - float(g('loss'))) <= 1e-4 * abs(float(g('loss')))
+    assert np.abs(model.embeddings.weight.grad.cpu().numpy() - g('gW')).max() / np.abs(g('gW')).max() < 1e-3
+    assert np.abs(R.grad.cpu().numpy() - g('gR')).max() / np.abs(g('gR')).max() < 1e-3
+    # stand-alone modules: Embedder.forward, E_operator, eval branch
+    out = model(torch.tensor(f['emb_idx'][:50], device=DEV))
+    assert np.abs(out.detach().cpu().numpy() - O.soft_clip_add(g('W')[f['emb_idx'][:50]], K)).max() < 5e-6
+    E = crit.E_operator(torch.tensor(f['x10'], device=DEV), torch.tensor(f['y10'], device=DEV))
+    assert (np.abs(E.cpu().numpy() - f['E10']) <= np.maximum(1e-4, 4 * np.abs(f['E10'] - f['E64_10']))).all()
+
+
+def test_euclidean_cones_trainer_runs(tmp_path):
+    from test_host_cpu import _fake_loaders
+    from learning_embeddings_amd import oe
+    lm = SyntheticLabelMap([2, 4, 8])
+    dl = _fake_loaders(lm, 32, 8)
+    for split in dl.values():
+        for b in split:
+            b['path_to_image'] = [torch.rand(3, 32, 32, generator=torch.Generator().manual_seed(int(n[4:]))) for n in b['image_filename']]
+    gd = oe.create_combined_graphs(dl, lm, pick_per_level=True)
+    crit = oe.EuclideanConesWithImagesHypernymLoss(lm, 5, {}, 1.0, True, K=3.0, use_CNN=True)
+    tr = oe.JointEmbeddings(gd, dl, image_dir='', use_CNN=True, labelmap=lm, criterion=crit, lr=1e-2, n_workers=0,
+                            batch_size=16, experiment_name='e', embedding_dim=10, neg_to_pos_ratio=5, image_fc7=None,
+                            normalize=None, alpha=1.0, experiment_dir=str(tmp_path), n_epochs=2, eval_interval=1)
+    assert isinstance(tr.model, oe.Embedder) and isinstance(tr.img_feat_net, oe.FeatCNN18)
+    w0 = tr.model.embeddings.weight.detach().clone()
+    tr.run_model()
+    assert np.isfinite(tr.last_epoch_loss)
+    w1 = tr.model.embeddings.weight.detach()
+    assert (w1 - w0).abs().max().item() > 0                                  # plain Adam moved the table ...
+    assert w1.norm(dim=1).max().item() > 1.0                                 # ... and nothing clipped it into the unit ball
+    assert set(['m-f1', 'hit@1']).issubset(tr.last_metrics)

@@ -122,11 +122,11 @@ def run_joint(W, R, frm, to, neg, alpha, K, weights=None, energy='hyp_cone'):
     N = W.shape[0]
     Wt = T(W).requires_grad_(True)
     Rt = T(R).requires_grad_(True) if R is not None and len(R) else None
-    hyp = energy == 'hyp_cone'
+    lab, img = {'hyp_cone': (_lib.LABEL_HYP, _lib.IMAGE_SOFTCLIP), 'order': (_lib.LABEL_RAW, _lib.IMAGE_RAW),
+                'euc_cone': (_lib.LABEL_SOFTCLIP_K, _lib.IMAGE_SOFTCLIP_K)}[energy]
     loss, e_pos, e_neg = ops.JointLossFn.apply(
         Wt, Rt, _codes(frm, N), _codes(to, N), _codes(neg, N).reshape(len(frm), -1).contiguous(),
-        T(weights) if weights is not None else None, 0.0 if K is None else K, alpha, ops.ENERGY[energy],
-        _lib.LABEL_HYP if hyp else _lib.LABEL_RAW, _lib.IMAGE_SOFTCLIP if hyp else _lib.IMAGE_RAW)
+        T(weights) if weights is not None else None, 0.0 if K is None else K, alpha, ops.ENERGY[energy], lab, img)
     loss.backward()
     return (float(loss), e_pos.cpu().numpy(), e_neg.cpu().numpy(), Wt.grad.cpu().numpy(),
             Rt.grad.cpu().numpy() if Rt is not None else None)
@@ -348,3 +348,125 @@ def test_table_step_full_size_invariants():
         assert n.min().item() >= O.inner_radius(0.1) - 1e-6 and n.max().item() <= 1.0
         assert torch.equal(W[::2], W0[::2])                              # untouched rows (already inside the shell) are bit-identical
         assert (W[1::2] != W0[1::2]).any()
+
+
+# ---------------------------------------------------------------------------------------------- F10: Euclidean cones (oe.py)
+@pytest.mark.parametrize('D', [2, 10, 128])
+def test_euclidean_cone_energy_vs_reference_fixture(D):
+    f = load('F10_euclidean_cone.npz'); K = float(f['K'])
+    x = T(f['x%d' % D]).requires_grad_(True); y = T(f['y%d' % D]).requires_grad_(True)
+    E = ops.pair_energy(x, y, K, 'euc_cone')
+    (E * T(f['gE%d' % D])).sum().backward()
+    ref, ref64 = f['E%d' % D], f['E64_%d' % D]
+    assert (np.abs(E.detach().cpu().numpy() - ref) <= np.maximum(1e-4, 4 * np.abs(ref - ref64))).all()
+    for g, r, r64 in ((x.grad, f['gx%d' % D], f['gx64_%d' % D]), (y.grad, f['gy%d' % D], f['gy64_%d' % D])):
+        scale = np.abs(r).max(axis=1, keepdims=True) + 1e-3
+        noise = np.abs(r - r64).max(axis=1, keepdims=True) / scale            # the reference's own fp32 noise (psi ~ 0 rows)
+        assert (np.abs(g.cpu().numpy() - r) / scale <= np.maximum(1e-3, 4 * noise)).all()
+    # all-pairs form against the pairwise form
+    Em = ops.energy_matrix(x.detach()[:40], y.detach()[:30], K, 'euc_cone').cpu().numpy()
+    want = O.euc_cone_energy(np.repeat(f['x%d' % D][None, :40], 30, 0), np.repeat(f['y%d' % D][:30, None], 40, 1), K)
+    assert np.abs(Em - want).max() <= 1e-4
+
+
+def test_euclidean_projections_vs_reference_fixture():
+    f = load('F10_euclidean_cone.npz'); K = float(f['K'])
+    W = T(f['emb_W']).requires_grad_(True)
+    out = ops.LabelProjectFn.apply(W, T(f['emb_idx'], torch.int64), K, _lib.LABEL_SOFTCLIP_K)
+    assert np.abs(out.detach().cpu().numpy() - f['emb_out']).max() < 5e-6
+    (out * T(f['emb_gout'])).sum().backward()
+    assert np.abs(W.grad.cpu().numpy() - f['emb_gW']).max() / np.abs(f['emb_gW']).max() < 1e-5
+    raw = T(f['img_raw']).requires_grad_(True)
+    o2 = ops.ImageSoftClipFn.apply(raw, K, _lib.IMAGE_SOFTCLIP_K)
+    assert np.abs(o2.detach().cpu().numpy() - f['img_out']).max() < 5e-6
+    (o2 * T(f['img_gout'])).sum().backward()
+    assert rowrel(raw.grad.cpu().numpy(), f['img_graw']).max() < 1e-4
+
+
+def test_euclidean_joint_loss_vs_reference_fixture():
+    f = load('F10_euclidean_cone.npz'); K = float(f['K'])
+    g = lambda k: f['c_' + k]
+    lm = SyntheticLabelMap(g('levels').tolist(), edges=[tuple(e) for e in g('edges').tolist()])
+    ng = NegativeGraph.from_labelmap(lm, n_images=int(g('n_images')), pick_per_level=True, seed=0)
+    neg = ng.draw_batch(g('from'), g('to'), int(g('Kneg')))
+    assert np.array_equal(neg, g('neg'))                                     # oe.py:755-808 draws like oe_h.py:849-902
+    loss, e_pos, e_neg, gW, gR = run_joint(g('W'), g('R'), g('from'), g('to'), neg, float(g('alpha')), K, energy='euc_cone')
+    assert np.abs(e_pos - g('e_pos')).max() <= 1e-4
+    assert np.abs(e_neg - g('e_neg')[..., 0]).max() <= 1e-4
+    assert abs(loss - float(g('loss'))) <= 1e-4 * max(1.0, abs(float(g('loss'))))
+    assert np.abs(gW - g('gW')).max() / np.abs(g('gW')).max() < 1e-3
+    assert np.abs(gR - g('gR')).max() / np.abs(g('gR')).max() < 1e-3
+
+
+@pytest.mark.parametrize('B,K,D,M', [(7, 1, 2, 5), (64, 5, 10, 40), (16, 256, 10, 32), (12, 9, 128, 16), (5, 2, 300, 8)])
+def test_euclidean_joint_loss_vs_oracle_random(B, K, D, M):
+    rs = np.random.RandomState(B * 1000 + K + 7)
+    N = 500
+    W = rs.randn(N, D).astype(np.float32); R = (rs.randn(M, D) * 0.3).astype(np.float32)
+    frm = rs.randint(0, N, B); to = np.where(rs.rand(B) < 0.7, N + rs.randint(0, M, B), rs.randint(0, N, B))
+    neg = np.where(rs.rand(B, 2 * K) < 0.8, rs.randint(0, N, (B, 2 * K)), N + rs.randint(0, M, (B, 2 * K)))
+    for b in range(B):
+        while frm[b] == to[b]:
+            frm[b] = rs.randint(0, N)
+        for k in range(2 * K):
+            other = frm[b] if k < K else to[b]
+            while neg[b, k] == other:
+                neg[b, k] = rs.randint(0, N)
+    w = rs.uniform(0.5, 2.0, B).astype(np.float32)
+    loss, e_pos, e_neg, gW, gR = run_joint(W, R, frm, to, neg, 1.6, 3.0, weights=w, energy='euc_cone')
+    o_loss, o_pos, o_neg, o_gW, o_gR = O.joint_loss_fwd_bwd(W, R, frm, to, neg, 1.6, 3.0, weights=w, energy='euc_cone')
+    assert np.abs(e_pos - o_pos).max() <= 1e-4 and np.abs(e_neg - o_neg).max() <= 1e-4
+    assert abs(loss - o_loss) <= 1e-4 * max(1.0, abs(o_loss))
+    assert np.abs(gW - o_gW).max() / (np.abs(o_gW).max() + 1e-12) < 2e-3
+    assert np.abs(gR - o_gR).max() / (np.abs(o_gR).max() + 1e-12) < 2e-3
+
+
+# ---------------------------------------------------------------------------------------------- 8f-1: fused scoring + per-level top-k
+@pytest.mark.parametrize('energy,K,D,levels,M', [('hyp_cone', 0.1, 10, [6, 21, 135, 561], 300), ('hyp_cone', 0.1, 2, [2, 3, 9], 70),
+                                                  ('euc_cone', 3.0, 10, [8, 64, 384], 129), ('order', None, 16, [5, 40], 64),
+                                                  ('hyp_cone', 0.1, 100, [4, 30, 200], 65), ('hyp_cone', 0.1, 10, [2, 8, 32, 128, 512, 2048, 8192], 200)])
+def test_level_topk_vs_bruteforce(energy, K, D, levels, M):
+    rs = np.random.RandomState(D + M)
+    N = sum(levels)
+    lab = (rs.randn(N, D) * (0.2 if energy == 'hyp_cone' else 1.0)).astype(np.float32)
+    img = (rs.randn(M, D) * (0.3 if energy == 'hyp_cone' else 1.0)).astype(np.float32)
+    if energy == 'euc_cone':
+        lab = O.soft_clip_add(lab, K); img = O.soft_clip_add(img, K)
+    starts = np.concatenate([[0], np.cumsum(levels)])
+    k = 5
+    idx, val = ops.level_topk(T(lab), T(img), starts, k, K, energy)
+    idx = idx.cpu().numpy(); val = val.cpu().numpy()
+    X = np.repeat(lab[None], M, 0); Y = np.repeat(img[:, None], N, 1)
+    fn = {'hyp_cone': lambda dt: O.cone_energy(X, Y, K, dt), 'euc_cone': lambda dt: O.euc_cone_energy(X, Y, K, dt),
+          'order': lambda dt: O.order_energy(X, Y, dt)}[energy]
+    E = fn(np.float32); E64 = fn(np.float64)
+    Em = ops.energy_matrix(T(lab), T(img), K, energy).cpu().numpy()
+    for l, n in enumerate(levels):
+        s, e = starts[l], starts[l + 1]
+        kk = min(k, n)
+        order = np.argsort(E[:, s:e], axis=1, kind='stable')[:, :kk] + s
+        want = np.take_along_axis(E, order, 1)
+        got_i, got_v = idx[:, l, :kk], val[:, l, :kk]
+        assert (got_i >= s).all() and (got_i < e).all()
+        assert (np.diff(got_v, axis=1) >= 0).all()                               # ascending
+        tol = np.maximum(1e-4, 4 * np.abs(E - E64).max())
+        assert np.abs(got_v - want).max() <= tol                                 # the k smallest energies, to the parity bar
+        assert np.abs(np.take_along_axis(Em, got_i.astype(np.int64), 1) - got_v).max() <= 1e-5   # value belongs to the index
+        for i in range(M):
+            assert len(set(got_i[i].tolist())) == kk                             # no label twice
+        # where the oracle's ranking is unambiguous (gaps above the tolerance) the indices are the same
+        srt = np.sort(E[:, s:e], axis=1)[:, :min(kk + 1, n)]
+        clear = (np.diff(srt, axis=1) > 2 * tol).all(axis=1) if srt.shape[1] > 1 else np.ones(M, bool)
+        assert np.array_equal(got_i[clear], order[clear])
+        if n < k:
+            assert (idx[:, l, n:] == -1).all() and np.isinf(val[:, l, n:]).all()
+
+
+def test_level_topk_empty_and_argument_errors():
+    lab = torch.rand(10, 4, device=DEV) * 0.3; img = torch.rand(0, 4, device=DEV)
+    idx, val = ops.level_topk(lab, img, [0, 4, 10], 3, 0.1)
+    assert idx.shape == (0, 2, 3)
+    with pytest.raises(_lib.LeconeError):
+        ops.level_topk(lab, torch.rand(3, 4, device=DEV), [0, 4, 10], 9, 0.1)    # k > 8
+    with pytest.raises(ValueError):
+        ops.level_topk(lab, torch.rand(3, 4, device=DEV), [0, 4, 11], 3, 0.1)    # offsets past the table

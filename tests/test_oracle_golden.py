@@ -147,3 +147,41 @@ def test_F9_ethec_hierarchy():
     assert f['levels'] == [6, 21, 135, 561] and len(f['edges']) == 717
     A = O.dense_negative_adjacency(sum(f['levels']), f['edges'])
     assert int((~A).sum()) - sum(f['levels']) == 1974                      # transitive-closure edge count
+
+
+@pytest.mark.parametrize('D', [2, 10, 128])
+def test_F10_euclidean_cone_energy(D):
+    """network/oe.py:721-739 (the Euclidean-cone sibling)."""
+    f = load('F10_euclidean_cone.npz'); K = float(f['K'])
+    x, y = f['x%d' % D], f['y%d' % D]
+    E = O.euc_cone_energy(x, y, K)
+    assert (np.abs(E - f['E%d' % D]) <= np.maximum(1e-4, 4 * np.abs(f['E%d' % D] - f['E64_%d' % D]))).all()
+    assert (np.abs(O.euc_cone_energy(x, y, K, np.float64) - f['E64_%d' % D]) <= 1e-9).all()
+    gx, gy = O.euc_cone_energy_grad(x, y, f['gE%d' % D], K)
+    for g, r, r64 in ((gx, f['gx%d' % D], f['gx64_%d' % D]), (gy, f['gy%d' % D], f['gy64_%d' % D])):
+        scale = np.abs(r).max(axis=1, keepdims=True) + 1e-3
+        noise = np.abs(r - r64).max(axis=1, keepdims=True) / scale            # psi ~ 0 rows: 1 - K^2/|x|^2 cancels in fp32
+        assert (np.abs(g - r) / scale <= np.maximum(1e-3, 4 * noise)).all()
+        assert (np.abs(g - r64) / (np.abs(r64).max(axis=1, keepdims=True) + 1e-3)).max() < 1e-6
+
+
+def test_F10_euclidean_projections_and_criterion():
+    f = load('F10_euclidean_cone.npz'); K = float(f['K'])
+    rows = f['emb_W'][f['emb_idx']]
+    assert np.abs(O.soft_clip_add(rows, K) - f['emb_out']).max() < 2e-6                      # oe.py:65-80
+    gW = np.zeros(f['emb_W'].shape); np.add.at(gW, f['emb_idx'], O.soft_clip_add_backward(rows, f['emb_gout'], K))
+    assert np.abs(gW - f['emb_gW']).max() / np.abs(f['emb_gW']).max() < 1e-5
+    assert np.abs(O.soft_clip_add(f['img_raw'], K) - f['img_out']).max() < 2e-6              # oe.py:235-240
+    assert np.abs(O.soft_clip_add_backward(f['img_raw'], f['img_gout'], K) - f['img_graw']).max() < 1e-5
+    loss, e_pos, e_neg, gW, gR = O.joint_loss_fwd_bwd(f['c_W'], f['c_R'], f['c_from'], f['c_to'], f['c_neg'],
+                                                      float(f['c_alpha']), K, energy='euc_cone')   # oe.py:810-873
+    assert np.abs(e_pos - f['c_e_pos']).max() < 1e-5 and np.abs(e_neg - f['c_e_neg'][..., 0]).max() < 1e-5
+    assert abs(loss - float(f['c_loss'])) < 1e-4 * abs(float(f['c_loss']))
+    assert np.abs(gW - f['c_gW']).max() / np.abs(f['c_gW']).max() < 1e-5
+    assert np.abs(gR - f['c_gR']).max() / np.abs(f['c_gR']).max() < 1e-5
+    # the sampler stream is the one oe_h.py uses: the dense-matrix restatement reproduces the negatives
+    A = O.dense_negative_adjacency(int(f['c_W'].shape[0]), f['c_edges'],
+                                   image_leaf=[int(f['c_W'].shape[0]) - int(f['c_levels'][-1]) + (j % int(f['c_levels'][-1]))
+                                               for j in range(int(f['c_n_images']))])
+    smp = O.DenseSampler(A, f['c_levels'].tolist(), n_labels=int(f['c_W'].shape[0]), pick_per_level=True, seed=0)
+    assert np.array_equal(smp.draw_batch(f['c_from'], f['c_to'], int(f['c_Kneg'])), f['c_neg'])
