@@ -69,9 +69,9 @@ int lec_pair_energy_matrix(int energy, const float* x, int64_t ldx, int64_t N, c
 
 /* Fused all-pairs scoring + per-level top-k for calculate_classification_metrics (oe_h.py:2018-2036: E_operator of one
  * image against every label, then torch.topk(k, largest=False) per level), without writing the M x N matrix.
- * level_start: DEVICE int32 [L+1], level l = apex rows [level_start[l], level_start[l+1]); level_start[L] <= N.
- * out_idx, out_val: [M, L, k]; ascending energy, ties by lowest index, NaN energies never selected; when a level has
- * fewer than k rows the tail is (-1, +inf).  1 <= k <= 8, D <= 256. */
+ * level_start: HOST int32 [L+1] (L <= 32), level l = apex rows [level_start[l], level_start[l+1]); level_start[L] <= N.
+ * out_idx, out_val: DEVICE [M, L, k]; ascending energy, ties by lowest index, NaN energies never selected; when a level
+ * has fewer than k rows the tail is (-1, +inf).  1 <= k <= 8, D <= 224. */
 int lec_level_topk(int energy, const float* x, int64_t ldx, int64_t N, const float* y, int64_t ldy, int64_t M, int D,
                    const int32_t* level_start, int L, int k, float K_cone, int32_t* out_idx, float* out_val,
                    lec_stream_t stream);

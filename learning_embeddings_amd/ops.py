@@ -82,12 +82,12 @@ def level_topk(apex, points, level_start, k, K_cone=0.1, energy='hyp_cone'):
     ints.  Returns (idx int32 [M, L, k], val float32 [M, L, k]); entries past a short level are (-1, +inf)."""
     a = _rows(apex, 'apex'); p = _rows(points, 'points')
     N, D = a.shape; M = p.shape[0]
-    ls = torch.as_tensor(np.asarray(level_start, dtype=np.int32), device=a.device)
-    L = ls.numel() - 1
-    if L < 1 or int(np.asarray(level_start)[-1]) > N or np.any(np.diff(np.asarray(level_start)) < 0):
+    ls = np.ascontiguousarray(np.asarray(level_start, dtype=np.int32))
+    L = ls.size - 1
+    if L < 1 or int(ls[-1]) > N or int(ls[0]) < 0 or np.any(np.diff(ls) < 0):
         raise ValueError('level_start must be L+1 non-decreasing offsets into the apex rows')
     idx = torch.empty(M, L, k, dtype=torch.int32, device=a.device); val = torch.empty(M, L, k, dtype=torch.float32, device=a.device)
-    check(lib.lec_level_topk(ENERGY[energy], dptr(a), _ld(a), N, dptr(p), _ld(p), M, D, dptr(ls), L, int(k), float(K_cone or 0.0),
+    check(lib.lec_level_topk(ENERGY[energy], dptr(a), _ld(a), N, dptr(p), _ld(p), M, D, ls.ctypes.data_as(C.c_void_p), L, int(k), float(K_cone or 0.0),
                              dptr(idx), dptr(val), stream_ptr()))
     return idx, val
 
