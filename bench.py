@@ -79,6 +79,7 @@ def main():
     ap.add_argument('--no-stress', action='store_true')
     ap.add_argument('--no-overlap-wgrad', action='store_true', help='keep the conv weight-gradient kernels on the main stream (default: second HIP stream, +3.9 %%)')
     ap.add_argument('--check-replicas', action='store_true', help='after the run, assert that every rank holds identical parameters')
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying the captured hipGraph of forward+loss+backward')
     ap.add_argument('--cudnn-benchmark', action='store_true', help='let MIOpen benchmark every solver per conv shape (slow start)')
     args = ap.parse_args()
 
@@ -99,24 +100,33 @@ def main():
     rank, local_rank, world = parallel.init_process_group()
     if world != args.gpus and rank == 0:
         print('warning: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world), file=sys.stderr)
-    eng = StepEngine(args.workload, dtype=args.dtype, sampler_mode=args.sampler, batch=args.batch, overlap_wgrad=not args.no_overlap_wgrad)
+    eng = StepEngine(args.workload, dtype=args.dtype, sampler_mode=args.sampler, batch=args.batch, overlap_wgrad=not args.no_overlap_wgrad,
+                     use_graph=not args.no_graph)
     dev = eng.device
     stamp('engine built')
     for i in range(args.warmup):
         eng.step()
         if i < 2:
             torch.cuda.synchronize(); stamp('warm-up step %d done' % i)
+    while eng.use_graph and eng.hip_graph is None and eng.graph_error is None:
+        eng.step()                                              # fewer warm-up steps than the capture needs: finish them untimed
+    stamp('launch mode: %s' % ('hipGraph replay' if eng.hip_graph is not None else 'eager'))
     eng.enable_timers()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host_s = 0.0
+    eng.host_wait_s = 0.0
     for _ in range(args.steps):
+        th = time.perf_counter()
         eng.step()
+        host_s += time.perf_counter() - th          # host time to enqueue one step (no synchronisation inside)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    host_busy_s = host_s - eng.host_wait_s
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
@@ -128,6 +138,17 @@ def main():
             if rank == 0:
                 print('[bench] replicas identical (%s): %s' % (name, bool(same.item())), file=sys.stderr)
             assert same.item() == 1.0, 'replicas diverged: ' + name
+    graph_mode = eng.hip_graph is not None
+    if graph_mode:
+        # A replayed graph cannot carry timing events, so the per-kernel durations behind `roofline` come from eager
+        # launches of the SAME step (same kernels, same two-stream overlap) right after the timed region.
+        eng.set_launch_mode(False)
+        eng.step(); torch.cuda.synchronize()                    # let the host get ahead of the GPU again before timing
+        eng.timers['records'] = [r for r in eng.timers['records'] if len(r) == 4]
+        ops.BN_TIMER = []
+        for _ in range(5):
+            eng.step()
+        torch.cuda.synchronize()
     phases = eng.timer_summary()
     # The weight-gradient kernels run on a second stream next to the BatchNorm kernels, so per-kernel durations inside the
     # timed region include that sharing.  Three more steps with everything on ONE stream give the family's own duration.
@@ -143,7 +164,9 @@ def main():
         bn_isolated = sum(a.elapsed_time(b) for a, b, _ in ops.BN_TIMER) / n_iso
         eng.overlap.side = side
         ops.BN_TIMER = None
-    loss_mean = float(eng.loss_acc.item()) / (args.steps + args.warmup)
+    if graph_mode:
+        eng.set_launch_mode(True)
+    loss_mean = float(eng.loss_acc.item()) / max(eng.step_no, 1)
 
     if rank == 0:
         B, K, D = eng.B, eng.K, eng.D
@@ -171,7 +194,8 @@ def main():
                        'frac': round(eng.bn_bytes_per_step / bn_s / 8e12, 4), 'traffic': bn_traffic,
                        'alg_bytes_per_step': int(eng.bn_bytes_per_step), 'ms_per_step': round(phases['fused_bn'], 3)}
             if bn_isolated is not None:
-                roof_bn['note'] = ('inside the timed region the conv weight-gradient kernels run concurrently on a second stream and share HBM with this family; '
+                roof_bn['note'] = (('the timed region replays a hipGraph, which cannot carry timing events: these durations are HIP-event timings of 5 eager steps of the same workload run right after it; ' if graph_mode else '') +
+                                   'inside the step the conv weight-gradient kernels run concurrently on a second stream and share HBM with this family; '
                                    'alone on the GPU (3 extra steps, single stream) the same launches take %.2f ms = %.0f GB/s = %.3f of peak'
                                    % (bn_isolated, eng.bn_bytes_per_step / bn_isolated / 1e6, eng.bn_bytes_per_step / bn_isolated / 1e6 / 8000.0))
                 roof_bn['isolated'] = {'ms_per_step': round(bn_isolated, 3), 'achieved': round(eng.bn_bytes_per_step / bn_isolated / 1e6, 1),
@@ -184,7 +208,8 @@ def main():
         # ---- the step's dominant component: ResNet fwd+bwd (MFMA-bound), analytic flops / measured fwd+bwd time
         macs = conv_macs(eng.img_feat_net.model, eng.hw)
         flops = 3 * 2 * macs * eng.n_rows
-        cnn_s = (phases['cnn_fwd'] + phases['cnn_bwd']) * 1e-3
+        # graph mode: the replay's own duration (forward + 17 us of loss kernel + backward, no host gaps)
+        cnn_s = (phases['graph_fwd_loss_bwd'] if graph_mode else phases['cnn_fwd'] + phases['cnn_bwd']) * 1e-3
         peak_tf = 2500.0 if args.dtype in ('bf16', 'fp16') else 157.3
         roof_cnn = {'kernel': '%s conv stack fwd+bwd (MIOpen/hipBLASLt via PyTorch)' % eng.arch, 'bound': 'mfma',
                     'achieved': round(flops / cnn_s / 1e12, 3), 'peak': peak_tf, 'unit': 'TFLOP/s',
@@ -196,8 +221,10 @@ def main():
                'config': {'workload': '%s: %s hierarchy (%d labels, %d levels) + %d synthetic images, %s, hyperbolic cone loss, B=%d positives/GPU, K=%d, D=%d, %dx%d'
                                       % (args.workload, WORKLOADS[args.workload][0], eng.N, eng.L, eng.M, eng.arch, B, K, D, eng.hw, eng.hw),
                           'global_batch': B * world, 'cnn_rows_per_step_per_gpu': eng.n_rows, 'cone_loss_dtype': 'f32',
-                          'parallelism': 'dp%d' % world, 'sampler': args.sampler, 'mean_loss': round(loss_mean, 4)},
-               'phases_ms': {k: round(v, 3) for k, v in phases.items()},
+                          'parallelism': 'dp%d' % world, 'sampler': args.sampler,
+                          'launch_mode': 'hipgraph (forward + loss + backward of a step replayed as one graph)' if graph_mode else 'eager', 'mean_loss': round(loss_mean, 4)},
+               'phases_ms': dict({('eager_probe_' + k if graph_mode and k in ('cnn_fwd', 'cone_loss', 'cnn_bwd', 'allreduce_wait', 'fused_bn') else k): round(v, 3)
+                                  for k, v in phases.items()}, host_enqueue=round(host_busy_s / args.steps * 1e3, 3)),
                # `roofline`: the hand-written kernel family that dominates the step's time (HBM-bound BatchNorm passes);
                # `roofline_cone`: the fused cone-loss kernel the metric also names; `roofline_cnn`: the whole backbone pass
                'roofline': roof_bn if roof_bn is not None else roof_cone, 'roofline_cone': roof_cone, 'roofline_cnn': roof_cnn}

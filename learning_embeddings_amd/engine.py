@@ -9,9 +9,15 @@ One step = oe_h.py:1734-1774 for one batch of B (label, image) positives per GPU
              -> ONE table-step kernel (lambda-rescale + Adam + clip) + ONE flat-arena Adam kernel
     no host<->device synchronisation anywhere in the step.
 
+Launch mode: after a few eager steps the whole forward + loss + backward (both HIP streams, ~700 launches) is captured
+into ONE hipGraph and replayed per step (`use_graph`); index uploads, the gradient all-reduce and the two optimizer
+launches stay outside (the Adam step number is a launch argument).  Replays make the step immune to host-side jitter
+(the eager step needs 18-26 ms of host time against 49 ms of GPU time, and a busy host turns that around).
+
 Workloads: hierarchy S3 = [8,64,384,1544] (or the real ETHEC DAG), image j hangs under leaf j mod n_leaf,
 positive b of a step pairs image (step*B_global + b) mod M with its ancestor at level b mod L.
 """
+import time
 import numpy as np
 import torch
 
@@ -39,7 +45,8 @@ def make_labelmap(name):
 
 class StepEngine:
     def __init__(self, workload='cfg3', n_images=4096, pool_images=None, dtype='bf16', lr=1e-4, alpha=0.01, K_cone=0.1,
-                 sampler_mode='replicated', seed=0, batch=None, device=None, overlap_wgrad=True):
+                 sampler_mode='replicated', seed=0, batch=None, device=None, overlap_wgrad=True, use_graph=False,
+                 graph_after=3):
         hier, arch, B, K, D, hw = WORKLOADS[workload]
         self.workload, self.arch, self.B, self.K, self.D, self.hw = workload, arch, batch or B, K, D, hw
         self.rank, self.local_rank, self.world = parallel.init_process_group()
@@ -102,9 +109,19 @@ class StepEngine:
         self.pin_img = [torch.empty(self.n_rows, dtype=torch.int64).pin_memory() for _ in range(2)]
         self.pin_ev = [None, None]
         self.step_no = 0
+        self.host_wait_s = 0.0                       # host time spent waiting for the GPU (run-ahead bound), for bench.py
         self.loss_acc = torch.zeros((), device=self.device)
         self.prefetch = parallel.NegativePrefetcher(self.graph, self.positives, K, mode=sampler_mode)
         self.timers = None
+        # static device inputs of the step (the captured graph reads these addresses)
+        self.codes_dev = torch.zeros((self.B, 2 + 2 * K), dtype=torch.int32, device=self.device)
+        self.idx_dev = torch.zeros(self.n_rows, dtype=torch.int64, device=self.device)
+        self.use_graph = bool(use_graph) and self.compute_dtype != torch.float32
+        self.graph_after = graph_after
+        self.hip_graph = None
+        self.graph_out = None
+        self.graph_error = None
+        self._graph_saved = None
 
     # global positives of step s: image (s*Bg + b) mod M with its ancestor at level b mod L   
     def positives(self, s):
@@ -126,7 +143,9 @@ class StepEngine:
         frm, to, neg = self.prefetch.next()
         slot = self.step_no & 1
         if self.pin_ev[slot] is not None:
+            t_w = time.perf_counter()
             self.pin_ev[slot].synchronize()          # the H2D copies of step s-2 have left this pinned buffer (also bounds run-ahead)
+            self.host_wait_s += time.perf_counter() - t_w
         pin = self.pin[slot]
         # CNN batch rows: [0, B) the positives' images; row B + b*cnt + i the image drawn as negative in pass img_passes[i]
         hp = pin.numpy()
@@ -145,14 +164,43 @@ class StepEngine:
             hp[:, 2 + cols] = -1 - (B + np.arange(B, dtype=np.int32)[:, None] * self.cnt + np.arange(self.cnt, dtype=np.int32)[None, :])
         elif is_img.any():
             raise RuntimeError('unexpected image negative')
-        codes = pin.to(self.device, non_blocking=True)
-        pos_from = codes[:, 0].contiguous(); pos_to = codes[:, 1].contiguous(); negc = codes[:, 2:].contiguous()
-        idx = self.pin_img[self.step_no & 1].to(self.device, non_blocking=True)
+        self.codes_dev.copy_(pin, non_blocking=True)
+        self.idx_dev.copy_(self.pin_img[self.step_no & 1], non_blocking=True)
         self.pin_ev[slot] = torch.cuda.Event(); self.pin_ev[slot].record()
-        images = self.pool.index_select(0, idx)
 
         T = self.timers
-        ev = [T['mk']() for _ in range(6)] if T is not None else None
+        if (self.use_graph and self.hip_graph is None and self._graph_saved is None and self.graph_error is None
+                and self.step_no >= self.graph_after):
+            self._capture()
+        if self.hip_graph is not None:
+            ev = [T['mk']() for _ in range(4)] if T is not None else None
+            if ev: ev[0].record()
+            self.hip_graph.replay()
+            if ev: ev[1].record()
+            loss, e_pos, e_neg = self.graph_out
+            self.reducer.reduce_now()
+            if ev: ev[2].record()
+        else:
+            ev = [T['mk']() for _ in range(6)] if T is not None else None
+            loss, e_pos, e_neg = self._core(ev)
+            self.reducer.finish()
+            if ev: ev[4].record()
+        self.table_step += 1
+        ops.table_step_adam(self.table, self.table_grad, self.table_m, self.table_v, self.table_step, self.lr, self.K_cone)
+        self.arena.adam_step(self.lr)
+        if ev:
+            ev[-1].record(); T['records'].append(ev)
+        self.loss_acc += loss[0]
+        self.step_no += 1
+        self.last = (loss, e_pos, e_neg, frm, to, neg)
+        return loss
+
+    def _core(self, ev=None):
+        """Forward + fused loss + backward of one step on the static device inputs (codes_dev, idx_dev).  This is the
+        region the hipGraph captures."""
+        codes = self.codes_dev
+        pos_from = codes[:, 0].contiguous(); pos_to = codes[:, 1].contiguous(); negc = codes[:, 2:].contiguous()
+        images = self.pool.index_select(0, self.idx_dev)
         self.arena.zero_grad(); self.table_grad.zero_(); self.gfeat.zero_()
         if ev: ev[0].record()
         feats = self.img_feat_net.forward_raw(images)
@@ -165,27 +213,51 @@ class StepEngine:
         if self.overlap is not None:
             self.overlap.join()                       # weight gradients from the side stream
         if ev: ev[3].record()
-        self.reducer.finish()
-        if ev: ev[4].record()
-        self.table_step += 1
-        ops.table_step_adam(self.table, self.table_grad, self.table_m, self.table_v, self.table_step, self.lr, self.K_cone)
-        self.arena.adam_step(self.lr)
-        if ev:
-            ev[5].record(); T['records'].append(ev)
-        self.loss_acc += loss[0]
-        self.step_no += 1
-        self.last = (loss, e_pos, e_neg, frm, to, neg)
-        return loss
+        return loss, e_pos, e_neg
+
+    def _capture(self):
+        """Capture `_core` into a hipGraph (after eager steps have sized every workspace and MIOpen has settled on its
+        solvers).  Under capture the gradient reducer's per-parameter hooks are muted: the all-reduce runs after the
+        replay.  On any capture error the engine stays in eager launch mode and says so."""
+        try:
+            torch.cuda.synchronize()
+            self.reducer.live = False
+            ops.BN_TIMER, saved_timer = None, ops.BN_TIMER
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._core(None)
+            ops.BN_TIMER = saved_timer
+            torch.cuda.synchronize()
+            self.hip_graph, self.graph_out = g, out
+        except Exception as e:                                     # noqa: BLE001  (launch mode only; the kernels are the same)
+            self.graph_error = '%s: %s' % (type(e).__name__, e)
+            self.hip_graph = None
+            self.reducer.live = True
+            import sys
+            print('[StepEngine] hipGraph capture failed, staying in eager launch mode: %s' % self.graph_error, file=sys.stderr)
+            torch.cuda.synchronize()
+
+    def set_launch_mode(self, graph):
+        """Switch between replaying the captured graph and eager launches (bench.py times per-kernel phases with HIP
+        events on eager steps: a replay cannot carry timing events)."""
+        if graph and self._graph_saved is not None:
+            self.hip_graph, self._graph_saved = self._graph_saved, None
+            self.reducer.live = False
+        elif not graph and self.hip_graph is not None:
+            self._graph_saved, self.hip_graph = self.hip_graph, None
+            self.reducer.live = True
 
     def timer_summary(self):
         """Mean milliseconds per phase over the recorded steps (call after a synchronize)."""
         names = ['cnn_fwd', 'cone_loss', 'cnn_bwd', 'allreduce_wait', 'optimizer']
-        out = {n: 0.0 for n in names}
-        recs = self.timers['records']
-        for ev in recs:
-            for i, n in enumerate(names):
-                out[n] += ev[i].elapsed_time(ev[i + 1])
-        res = {n: v / max(len(recs), 1) for n, v in out.items()}
+        gnames = ['graph_fwd_loss_bwd', 'allreduce', 'optimizer']
+        recs = [r for r in self.timers['records'] if len(r) == 6]
+        grecs = [r for r in self.timers['records'] if len(r) == 4]
+        res = {}
+        for rs, ns in ((recs, names), (grecs, gnames)):
+            if rs:
+                for i, n in enumerate(ns):
+                    res[n] = sum(ev[i].elapsed_time(ev[i + 1]) for ev in rs) / len(rs)
         if ops.BN_TIMER:
             res['fused_bn'] = sum(a.elapsed_time(b) for a, b, _ in ops.BN_TIMER) / max(len(recs), 1)
             self.bn_bytes_per_step = sum(n for _, _, n in ops.BN_TIMER) / max(len(recs), 1)

@@ -160,6 +160,7 @@ class GradientReducer:
         self.arena = arena
         self.extra = list(extra)
         self.enabled = world_size() > 1
+        self.live = True             # False: hooks are muted (gradients produced by a hipGraph replay; see reduce_now)
         self.handles = []
         self.buckets = []            # (start, end, [param indices])
         cap = int(bucket_mb * 1024 * 1024 / 4)
@@ -196,6 +197,8 @@ class GradientReducer:
 
     def _make_hook(self, i):
         def hook(_p):
+            if not self.live:
+                return
             if i in self._ready:             # a parameter counts once per step, whoever reports it (autograd's
                 return                       # AccumulateGrad hook, a manual mark_ready from a fused backward, or both)
             self._ready.add(i)
@@ -215,6 +218,11 @@ class GradientReducer:
         if i is not None:
             self._hooks[i](p)
 
+    def reduce_now(self):
+        """All-reduce every bucket and the extras now (gradients already complete: after a hipGraph replay)."""
+        if self.enabled:
+            self._reduce_now()
+
     def finish(self):
         """Reduce whatever has not been launched by hooks (unused parameters, the extras) and wait for everything."""
         if not self.enabled:
@@ -223,6 +231,16 @@ class GradientReducer:
             if left > 0:
                 lo, hi = self._spans[bi]
                 self.handles.append(dist.all_reduce(self.arena.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        for t in self.extra:
+            self.handles.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+        for h in self.handles:
+            h.wait()
+        self.reset()
+
+
+    def _reduce_now(self):
+        for lo, hi in self._spans:
+            self.handles.append(dist.all_reduce(self.arena.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
         for t in self.extra:
             self.handles.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
         for h in self.handles:

@@ -6,6 +6,7 @@ Layout / precision are MI355X choices, not the reference's: activations NHWC (ch
 the GEMM-friendly layout, bf16 compute under autocast with fp32 master weights held in one flat arena
 (parallel.FlatArena) so the data-parallel all-reduce is a single RCCL collective and Adam a single launch.
 """
+import os
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -92,6 +93,7 @@ class WgradOverlap:
                                                      [0, 0], conv.groups, [False, True, False])[1]
             for t in (gy, x, w16):
                 t.record_stream(self.side)                 # the caching allocator must not recycle them under the side stream
+                                                           # (under hipGraph capture such blocks are held until the capture ends)
             self._finish_wgrad(gw, conv)
 
     def join(self):
@@ -99,13 +101,44 @@ class WgradOverlap:
             torch.cuda.current_stream().wait_stream(self.side)
 
 
+# A 1x1 stride-1 convolution on NHWC activations IS the GEMM [N*H*W, Cin] x [Cin, Cout].  Per shape and direction the step
+# calls whichever library kernel measured faster on the MI355X at the bench batch (tools/bench_conv1x1.py,
+# profiles/r01_conv1x1_gemm.md): hipBLASLt wins the data gradient from Cin >= 256 (e.g. 256->64 @56x56: 396 -> 267 us,
+# 256->1024 @14x14: 107 -> 60 us) and the forward from Cin >= 1024; MIOpen keeps the narrow layers and every weight
+# gradient (a transposed-A GEMM with K = N*H*W is 2-30x slower in hipBLASLt).
+GEMM_1X1 = os.environ.get('LEC_CONV1X1_GEMM', '1') != '0'
+GEMM_FWD_MIN_CIN = 1024
+GEMM_DGRAD_MIN_CIN = 256
+
+
+def _is_pointwise(conv):
+    return (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.dilation == (1, 1)
+            and conv.groups == 1)
+
+
+def _rows(t):
+    """[N, C, H, W] channels_last -> the [N*H*W, C] matrix it is in memory (a view)."""
+    n, c, h, w = t.shape
+    return t.permute(0, 2, 3, 1).reshape(n * h * w, c)
+
+
+def _from_rows(m, n, h, w):
+    return m.view(n, h, w, m.shape[1]).permute(0, 3, 1, 2)
+
+
 class _OverlapConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, conv):
         w16 = WgradOverlap.instance.weight_lp(conv, x.dtype)
-        if x.is_contiguous(memory_format=torch.channels_last) and w16.dim() == 4 and not w16.is_contiguous(memory_format=torch.channels_last):
+        nhwc = x.is_contiguous(memory_format=torch.channels_last)
+        if nhwc and w16.dim() == 4 and not w16.is_contiguous(memory_format=torch.channels_last):
             w16 = w16.contiguous(memory_format=torch.channels_last)
-        y = torch.ops.aten.convolution(x, w16, None, conv.stride, conv.padding, conv.dilation, False, [0, 0], conv.groups)
+        ctx.pointwise = GEMM_1X1 and nhwc and _is_pointwise(conv)
+        if ctx.pointwise and conv.in_channels >= GEMM_FWD_MIN_CIN:
+            n, _, h, wd = x.shape
+            y = _from_rows(torch.mm(_rows(x), w16.reshape(conv.out_channels, conv.in_channels).t()), n, h, wd)
+        else:
+            y = torch.ops.aten.convolution(x, w16, None, conv.stride, conv.padding, conv.dilation, False, [0, 0], conv.groups)
         ctx.save_for_backward(x, w16); ctx.conv = conv
         return y
 
@@ -114,8 +147,12 @@ class _OverlapConvFn(torch.autograd.Function):
         x, w16 = ctx.saved_tensors; conv = ctx.conv
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = torch.ops.aten.convolution_backward(gy, x, w16, None, conv.stride, conv.padding, conv.dilation, False,
-                                                     [0, 0], conv.groups, [True, False, False])[0]
+            if (ctx.pointwise and conv.in_channels >= GEMM_DGRAD_MIN_CIN and gy.is_contiguous(memory_format=torch.channels_last)):
+                n, _, h, wd = gy.shape
+                gx = _from_rows(torch.mm(_rows(gy), w16.reshape(conv.out_channels, conv.in_channels)), n, h, wd)
+            else:
+                gx = torch.ops.aten.convolution_backward(gy, x, w16, None, conv.stride, conv.padding, conv.dilation, False,
+                                                         [0, 0], conv.groups, [True, False, False])[0]
         WgradOverlap.instance.submit(gy, x, w16, conv)
         return gx, None, None
 

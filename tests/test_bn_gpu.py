@@ -138,6 +138,37 @@ def test_wgrad_side_stream_overlap_matches_inline_and_fp32():
         assert (a - b).abs().max().item() < 0.02 * b.abs().max().item()
 
 
+@pytest.mark.parametrize('cin,cout,hw', [(256, 64, 14), (1024, 256, 7), (64, 256, 14), (2048, 512, 7)])
+def test_pointwise_conv_gemm_dispatch_matches_fp32(cin, cout, hw):
+    """1x1 stride-1 convs: forward (Cin >= 1024) and data gradient (Cin >= 256) go out as hipBLASLt GEMMs on the NHWC
+    matrix view; results, memory format and the side-stream weight gradient agree with an fp32 convolution."""
+    from learning_embeddings_amd import resnet
+    from learning_embeddings_amd.resnet import WgradOverlap, Conv2d
+    assert resnet.GEMM_1X1
+    torch.manual_seed(cin)
+    conv = Conv2d(cin, cout, kernel_size=1, bias=False).to(DEV).to(memory_format=torch.channels_last)
+    conv.train()
+    x = torch.randn(8, cin, hw, hw, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(8, cout, hw, hw, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    conv.weight.grad = torch.zeros_like(conv.weight)
+    WgradOverlap.instance = WgradOverlap()
+    try:
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y = conv(xi)
+        assert y.shape == (8, cout, hw, hw) and y.is_contiguous(memory_format=torch.channels_last)
+        y.backward(g)
+        WgradOverlap.instance.join()
+        torch.cuda.synchronize()
+    finally:
+        WgradOverlap.instance = None
+    assert xi.grad.is_contiguous(memory_format=torch.channels_last)
+    xr = x.float().requires_grad_(True); wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    yr = F.conv2d(xr, wr); yr.backward(g.float())
+    for a, b in ((y.detach().float(), yr.detach()), (xi.grad.float(), xr.grad), (conv.weight.grad.float(), wr.grad)):
+        assert (a - b).abs().max().item() < 0.02 * b.abs().max().item()
+
+
 @pytest.mark.parametrize('N,C,H,W', [(4, 64, 16, 16), (2, 8, 6, 10), (16, 64, 112, 112)])
 def test_maxpool3x3s2_vs_torch(N, C, H, W):
     from learning_embeddings_amd.resnet import MaxPool3x3s2

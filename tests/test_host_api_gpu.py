@@ -142,6 +142,44 @@ def test_step_engine_matches_oracle_stream_and_loss():
     eng.close()
 
 
+def test_step_engine_hipgraph_replay_matches_eager_launches():
+    """Launch mode only.  (1) On the SAME parameters and the SAME uploaded batch a replay of the captured graph (forward +
+    loss + backward, two streams) and an eager run of the same region give the same loss, energies, table gradient and
+    CNN gradient (to the run-to-run noise of bf16 atomics).  (2) Over a short training run the replays see every fresh
+    index upload: same negatives as the eager engine, loss trajectory within the eager engine's own run-to-run drift."""
+    runs = {}
+    for mode in (False, True):
+        torch.manual_seed(0)
+        eng = StepEngine('tiny', n_images=64, dtype='bf16', use_graph=mode, graph_after=2)
+        losses, negs = [], []
+        for _ in range(6):
+            eng.step(); losses.append(eng.last[0].clone()); negs.append(eng.last[5].copy())
+        torch.cuda.synchronize()
+        assert (eng.hip_graph is not None) == mode, eng.graph_error
+        runs[mode] = (torch.stack(losses).flatten().cpu().numpy(), negs, eng.table.cpu().numpy().copy())
+        if mode:                                                            # (1): same state, same batch, both launch modes
+            eng.hip_graph.replay(); torch.cuda.synchronize()
+            l1, ep1, en1 = [t.clone() for t in eng.graph_out]
+            gt1, ga1 = eng.table_grad.clone(), eng.arena.grad.clone()
+            l2, ep2, en2 = eng._core(None); torch.cuda.synchronize()
+            assert abs(l1.item() - l2.item()) <= 2e-3 * abs(l2.item())
+            assert (en1 - en2).abs().max().item() <= 2e-3 and (ep1 - ep2).abs().max().item() <= 2e-3
+            assert (gt1 - eng.table_grad).abs().max().item() <= 1e-2 * eng.table_grad.abs().max().item() + 1e-6
+            cos = torch.nn.functional.cosine_similarity(ga1.flatten(), eng.arena.grad.flatten(), dim=0).item()
+            assert cos > 0.995, cos
+        eng.set_launch_mode(False)                                          # eager probe steps after replays (bench.py does this)
+        eng.step(); torch.cuda.synchronize()
+        assert torch.isfinite(eng.last[0]).all()
+        eng.set_launch_mode(True); eng.step(); torch.cuda.synchronize()
+        assert (eng.hip_graph is not None) == mode
+        eng.close()
+    le, lg = runs[False][0], runs[True][0]
+    assert all(np.array_equal(a, b) for a, b in zip(runs[False][1], runs[True][1]))
+    assert np.abs(le - lg).max() <= 0.15 * np.abs(le).max()                 # two eager runs drift by ~5 % here on their own
+    assert len(set(np.round(lg, 4).tolist())) > 3                           # not a stale batch replayed over and over
+    assert np.abs(runs[False][2] - runs[True][2]).max() < 5e-3
+
+
 def test_joint_embeddings_trainer_runs_and_learns(tmp_path):
     from test_host_cpu import _fake_loaders
     lm = SyntheticLabelMap([2, 4, 8])
@@ -430,7 +468,7 @@ def test_classification_metrics_and_reconstruction_vs_bruteforce(tmp_path):
     assert abs(best[0] - max(f1s)) < 1e-4
 
 
-def _dp_engine_worker(rank, world, port, overlap, q):
+def _dp_engine_worker(rank, world, port, overlap, q, graph=False):
     import os, sys
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
                       MASTER_PORT=str(port), LEC_DIST_BACKEND='gloo')
@@ -438,25 +476,27 @@ def _dp_engine_worker(rank, world, port, overlap, q):
     sys.path.insert(0, ROOT)
     import torch as t
     from learning_embeddings_amd.engine import StepEngine as SE
-    eng = SE('tiny', n_images=64, dtype='bf16', overlap_wgrad=overlap)
+    eng = SE('tiny', n_images=64, dtype='bf16', overlap_wgrad=overlap, use_graph=graph, graph_after=1)
     negs = []
     for _ in range(3):
         eng.step(); negs.append(eng.last[5].copy())
     t.cuda.synchronize()
+    assert (eng.hip_graph is not None) == graph, eng.graph_error
     q.put((rank, eng.arena.data.cpu().numpy(), eng.table.cpu().numpy(), negs))
     t.distributed.barrier(); eng.close(); t.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize('overlap', [False, True])
-def test_step_engine_data_parallel_replicas_stay_identical(overlap):
+@pytest.mark.parametrize('overlap,graph', [(False, False), (True, False), (True, True)])
+def test_step_engine_data_parallel_replicas_stay_identical(overlap, graph):
     """StepEngine under DP (2 ranks sharing the GPU over gloo), with the shadow-weight / direct-gradient path and with the
-    side-stream weight gradients: after 3 steps both ranks hold bit-identical CNN parameters and label table, and each
-    rank's negatives are its slice of the single-process global stream."""
+    side-stream weight gradients, and with the hipGraph launch mode (all-reduce after the replay): after 3 steps both ranks
+    hold bit-identical CNN parameters and label table, and each rank's negatives are its slice of the single-process
+    global stream."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context('spawn'); q = ctx.Queue()
-    procs = [ctx.Process(target=_dp_engine_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_engine_worker, args=(r, 2, port, overlap, q, graph)) for r in range(2)]
     for p in procs: p.start()
     res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda r: r[0])
     for p in procs: p.join(120)
