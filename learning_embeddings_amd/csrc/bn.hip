@@ -127,19 +127,37 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const bf16x8* __re
   }
 }
 
-// sum of the nblk partials of two statistics for 32 channels per 1024-thread block (32 channels x 32 splits), double
-__device__ __forceinline__ void reduce_partials_1024(const float* __restrict__ part, int nblk, int C, int c, int split,
-                                                     double& s, double& q) {
-  __shared__ double sh[2][32][33];
+// sum of the nblk partials of two statistics: a 256-thread block owns 8 channels x 32 splits (double accumulation).
+// Small blocks on purpose: these kernels are a few microseconds of latency-bound work that must find a free slot on a
+// GPU whose CUs are full of weight-gradient workgroups from the second stream; a 1024-thread block waited 30-60 us
+// for one CU to drain (rocprof, profiles/r01_*_final.md), a 4-wave block is placed at once.
+constexpr int kFinCh = 8, kFinSplit = 32, kFinThreads = kFinCh * kFinSplit;
+__device__ __forceinline__ void reduce_partials_256(const float* __restrict__ part, int nblk, int C, int c, int split,
+                                                    double& s, double& q) {
+  __shared__ double sh[2][kFinSplit][kFinCh + 1];
   double a = 0.0, b = 0.0;
   if (c < C) {
-    for (int p = split; p < nblk; p += 32) { a += (double)part[(int64_t)p * 2 * C + c]; b += (double)part[(int64_t)p * 2 * C + C + c]; }
+    // the partials were written by other CUs' blocks a moment ago (L2 / Infinity Cache round trips): issue a thread's
+    // loads as one independent batch instead of a load -> add -> load chain
+    for (int p0 = split; p0 < nblk; p0 += kFinSplit * 8) {
+      float va[8], vb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = p0 + kFinSplit * u;
+        const bool ok = p < nblk;
+        va[u] = ok ? part[(int64_t)p * 2 * C + c] : 0.0f;
+        vb[u] = ok ? part[(int64_t)p * 2 * C + C + c] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a += (double)va[u]; b += (double)vb[u]; }
+    }
   }
-  sh[0][split][threadIdx.x & 31] = a; sh[1][split][threadIdx.x & 31] = b;
+  const int cl = threadIdx.x % kFinCh;
+  sh[0][split][cl] = a; sh[1][split][cl] = b;
   __syncthreads();
   s = 0.0; q = 0.0;
   if (split == 0) {
-    for (int k = 0; k < 32; ++k) { s += sh[0][k][threadIdx.x & 31]; q += sh[1][k][threadIdx.x & 31]; }
+    for (int k = 0; k < kFinSplit; ++k) { s += sh[0][k][cl]; q += sh[1][k][cl]; }
   }
 }
 
@@ -149,9 +167,9 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nbl
                                          float momentum, float* running_mean, float* running_var,
                                          float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                          float* __restrict__ scale, float* __restrict__ shift) {
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), split = threadIdx.x >> 5;
+  const int c = blockIdx.x * kFinCh + threadIdx.x % kFinCh, split = threadIdx.x / kFinCh;
   double s, q;
-  reduce_partials_1024(part, nblk, C, c, split, s, q);
+  reduce_partials_256(part, nblk, C, c, split, s, q);
   if (split != 0 || c >= C) return;
   const double mean = s / (double)M;
   double var = q / (double)M - mean * mean;
@@ -224,12 +242,16 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const bf16x8* __re
 // ---------------------------------------------------------------------------------------------------------------
 // backward, pass 1: per-block partials of  dbeta = sum g,  dgamma = sum g * xhat,   g = dy * [y > 0]
 // RELU: 0 none, 1 mask from the saved output y, 2 mask from the saved bitmask (y is then a byte array [M, C/8])
+// gout (layers with a residual branch): the pass also WRITES g (bf16) -- it is the gradient of the identity branch, and
+// pass 2 then reads this one tensor instead of dy, dy2 and the mask again (8.1 -> 7.1 bytes-units per element on the
+// forked block outputs).  The sums are taken over the rounded g so that both passes see the same values.
 template <int RELU>
 __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const bf16x8* __restrict__ dy, const bf16x8* __restrict__ dy2,
                                                                    const bf16x8* __restrict__ y,
                                                                    const bf16x8* __restrict__ x, int64_t M, int C, int CV,
                                                                    int CVB, int RPI, const float* __restrict__ mean,
-                                                                   const float* __restrict__ invstd, float* __restrict__ part) {
+                                                                   const float* __restrict__ invstd, float* __restrict__ part,
+                                                                   bf16x8* __restrict__ gout) {
   __shared__ float smem[kBnThreads * 8];
   const int tid = threadIdx.x;
   const int cvl = tid % CVB, rg = tid / CVB;
@@ -256,9 +278,11 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const bf16x8*
         if (dy2) { a += bf2f(h0.v[j]); b += bf2f(h1.v[j]); }
         if (RELU == 1) { a = bf2f(y0.v[j]) > 0.0f ? a : 0.0f; b = bf2f(y1.v[j]) > 0.0f ? b : 0.0f; }
         if (RELU == 2) { a = (m0 >> j) & 1u ? a : 0.0f; b = (m1 >> j) & 1u ? b : 0.0f; }
+        if (gout) { g0.v[j] = f2bf(a); g1.v[j] = f2bf(b); a = bf2f(g0.v[j]); b = bf2f(g1.v[j]); }
         acc[0][j] += a + b;
         acc[1][j] += a * ((bf2f(x0.v[j]) - mu[j]) * is[j]) + b * ((bf2f(x1.v[j]) - mu[j]) * is[j]);
       }
+      if (gout) { st8(gout, i0, g0); st8(gout, i1, g1); }
     }
     for (; r < M; r += stride) {
       const int64_t i0 = r * CV + cv;
@@ -273,8 +297,10 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const bf16x8*
         if (dy2) a += bf2f(h0.v[j]);
         if (RELU == 1) a = bf2f(y0.v[j]) > 0.0f ? a : 0.0f;
         if (RELU == 2) a = (m0 >> j) & 1u ? a : 0.0f;
+        if (gout) { g0.v[j] = f2bf(a); a = bf2f(g0.v[j]); }
         acc[0][j] += a; acc[1][j] += a * ((bf2f(x0.v[j]) - mu[j]) * is[j]);
       }
+      if (gout) st8(gout, i0, g0);
     }
   }
   block_reduce_rows<2>(acc, CVB, RPI, smem);
@@ -288,9 +314,9 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const bf16x8*
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, int64_t M,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ c1, float* __restrict__ c2) {
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), split = threadIdx.x >> 5;
+  const int c = blockIdx.x * kFinCh + threadIdx.x % kFinCh, split = threadIdx.x / kFinCh;
   double s, q;
-  reduce_partials_1024(part, nblk, C, c, split, s, q);
+  reduce_partials_256(part, nblk, C, c, split, s, q);
   if (split != 0 || c >= C) return;
   dbeta[c] = (float)s; dgamma[c] = (float)q;
   c1[c] = (float)(s / (double)M); c2[c] = (float)(q / (double)M);
@@ -367,7 +393,7 @@ extern "C" int lec_bn_fwd(const void* x, const void* residual, int64_t M, int C,
   float* scale = part + (int64_t)kBnMaxBlocks * 2 * C; float* shift = scale + C;
   if (training) {
     hipLaunchKernelGGL(bn_stats_kernel, dim3(g.nrb, g.NCH), dim3(kBnThreads), 0, st, (const bf16x8*)x, M, C, g.CV, g.CVB, g.RPIB, part);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, part, g.nrb, C, M, gamma, beta, eps,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, g.nrb, C, M, gamma, beta, eps,
                        momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
   } else {
     hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3((C + 255) / 256), dim3(256), 0, st, C, gamma, beta, eps, running_mean, running_var, scale, shift);
@@ -396,15 +422,18 @@ extern "C" int lec_bn_bwd(const void* dy, const void* dy2, const void* y, const 
   BnGeom g = bn_geom(M, C);
   float* part = (float*)workspace;
   float* c1 = part + (int64_t)kBnMaxBlocks * 2 * C; float* c2 = c1 + C;
-#define R(M_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<M_>), dim3(g.nrb, g.NCH), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)dy2, (const bf16x8*)ym, (const bf16x8*)x, M, C, g.CV, g.CVB, g.RPIB, save_mean, save_invstd, part)
+#define R(M_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<M_>), dim3(g.nrb, g.NCH), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)dy2, (const bf16x8*)ym, (const bf16x8*)x, M, C, g.CV, g.CVB, g.RPIB, save_mean, save_invstd, part, (bf16x8*)dresidual)
   if (rm == 0) R(0); else if (rm == 1) R(1); else R(2);
 #undef R
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, part, g.nrb, C, M, dgamma, dbeta, c1, c2);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, g.nrb, C, M, dgamma, dbeta, c1, c2);
   int64_t nb = (M + g.RPI - 1) / g.RPI; nb = (nb + 1) / 2;
   const int nblk = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
 #define A(RES_, RELU_) hipLaunchKernelGGL((bn_bwd_apply_kernel<RES_, RELU_>), dim3(nblk), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)dy2, (const bf16x8*)ym, (const bf16x8*)x, M, g.CV, g.RPI, gamma, save_mean, save_invstd, c1, c2, (bf16x8*)dx, (bf16x8*)dresidual)
-  if (dresidual) { if (rm == 0) A(true, 0); else if (rm == 1) A(true, 1); else A(true, 2); }
-  else { if (rm == 0) A(false, 0); else if (rm == 1) A(false, 1); else A(false, 2); }
+  if (dresidual) {
+    // pass 1 has written g = masked(dy [+ dy2]) into dresidual: pass 2 reads that one tensor, no mask, no second stream
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<false, 0>), dim3(nblk), dim3(kBnThreads), 0, st, (const bf16x8*)dresidual, (const bf16x8*)nullptr,
+                       (const bf16x8*)nullptr, (const bf16x8*)x, M, g.CV, g.RPI, gamma, save_mean, save_invstd, c1, c2, (bf16x8*)dx, (bf16x8*)nullptr);
+  } else { if (rm == 0) A(false, 0); else if (rm == 1) A(false, 1); else A(false, 2); }
 #undef A
   LEC_CHECK_LAUNCH("bn_bwd kernels");
   return LEC_OK;

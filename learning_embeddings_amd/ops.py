@@ -352,7 +352,10 @@ class BNActFn(torch.autograd.Function):
             dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device); dbeta = torch.empty_like(dgamma)
         ws = _bn_workspace(x.device)
         el = M * Cc                                   # 2 x (dy [+ dy2] + x [+ mask]) + dx [+ d residual]
-        nbytes = el * (2 * (4 + (2 if dy2 is not None else 0)) + 2 + (2 if has_res else 0)) + (2 * (el // 8) if relu else 0)
+        if has_res:      # pass 1 reads dy [+ dy2], x, mask and writes g (= d residual); pass 2 reads g, x and writes dx
+            nbytes = el * ((4 + (2 if dy2 is not None else 0) + 2) + (4 + 2)) + (el // 8 if relu else 0)
+        else:            # both passes read dy [+ dy2], x, mask; pass 2 writes dx
+            nbytes = el * (2 * (4 + (2 if dy2 is not None else 0)) + 2) + (2 * (el // 8) if relu else 0)
         _bn_timed(lambda: check(lib.lec_bn_bwd(dptr(dy), dptr(dy2), None, dptr(mask), dptr(x), M, Cc, dptr(weight), dptr(save_mean),
                                                dptr(save_invstd), dptr(dx), dptr(dres), dptr(dgamma), dptr(dbeta), int(relu),
                                                dptr(ws), ws.numel(), stream_ptr())), nbytes)
