@@ -228,6 +228,7 @@ def main():
                                       % (args.workload, WORKLOADS[args.workload][0], eng.N, eng.L, eng.M, eng.arch, B, K, D, eng.hw, eng.hw),
                           'global_batch': B * world, 'cnn_rows_per_step_per_gpu': eng.n_rows, 'cone_loss_dtype': 'f32',
                           'parallelism': 'dp%d' % world, 'sampler': args.sampler,
+                          'hbm_peak_allocated_gb': round(torch.cuda.max_memory_allocated() / 1e9, 1),
                           'launch_mode': 'hipgraph (forward + loss + backward of a step replayed as one graph)' if graph_mode else 'eager', 'mean_loss': round(loss_mean, 4)},
                'phases_ms': dict({('eager_probe_' + k if graph_mode and k in ('cnn_fwd', 'cone_loss', 'cnn_bwd', 'allreduce_wait', 'fused_bn') else k): round(v, 3)
                                   for k, v in phases.items()}, host_enqueue=round(host_busy_s / args.steps * 1e3, 3)),

@@ -57,7 +57,14 @@ class StepEngine:
         self.labelmap = lm = make_labelmap(hier)
         self.N, self.L = lm.n_classes, len(lm.levels)
         self.M = n_images
-        self.graph = NegativeGraph.from_labelmap(lm, n_images=n_images, pick_per_level=True, seed=seed + (0 if sampler_mode == 'replicated' else self.rank))
+        # image j hangs under leaf j mod n_leaf.  With far fewer images than leaves (config 5: 39 078 leaves) that
+        # rule puts every image under the first top-level node, whose slot-L draw then has NO candidate (random.choice
+        # raises in the reference too): spread the images over the leaves instead.
+        nleaf_ = lm.levels[-1]
+        jj = np.arange(n_images, dtype=np.int64)
+        self.img_leaf = (jj % nleaf_) if 2 * n_images > nleaf_ else (jj * nleaf_) // n_images
+        self.graph = NegativeGraph.from_labelmap(lm, image_leaf=lm.level_start[-1] + self.img_leaf, pick_per_level=True,
+                                                 seed=seed + (0 if sampler_mode == 'replicated' else self.rank))
         # ancestors of every leaf per level (for the positives)
         par = lm.parents()
         leaf0, nleaf = lm.level_start[-1], lm.levels[-1]
@@ -74,6 +81,14 @@ class StepEngine:
         self.img_passes = [p for p in range(K) if p % (self.L + 1) == self.L]
         self.cnt = len(self.img_passes)
         self.n_rows = self.B * (1 + self.cnt)                            # CNN batch per step (fixed shape)
+        # one BatchNorm batch per step means every activation of the n_rows images is alive at once: 0.045 GB per image
+        # measured for ResNet-50 at 224x224 in bf16 (22.9 GB at 512 rows, 80.3 GB at 1 856).  Config 5 (K = 256 over 8 levels draws 28
+        # image negatives per positive: 7 424 rows at B = 256) does not fit 288 GB; say so instead of dying in hipMalloc.
+        per_row_gb = (0.05 if arch == 'resnet50' else 0.015) * (hw / 224.0) ** 2 * (2 if dtype == 'fp32' else 1)
+        if self.n_rows * per_row_gb > 240:
+            raise ValueError('workload %s at B=%d pushes %d images through %s per step (%d image negatives per positive): about %.0f GB of '
+                             'activations, more than one MI355X holds; pass a smaller `batch` (e.g. %d)'
+                             % (workload, self.B, self.n_rows, arch, self.cnt, self.n_rows * per_row_gb, max(1, int(200 / per_row_gb / (1 + self.cnt)))))
         torch.manual_seed(0)                                              # oe_h.py:1338: table init from seed 0
         self.criterion = EuclideanConesWithImagesHypernymLoss(lm, K, {}, alpha, pick_per_level=True, K=K_cone, use_CNN=True)
         self.model = Embedder(D, lm, None, K=K_cone).to(self.device)
@@ -128,7 +143,7 @@ class StepEngine:
         Bg = self.B * self.world
         b = np.arange(Bg, dtype=np.int64)
         j = (s * Bg + b) % self.M
-        leaf = j % self.labelmap.levels[-1]
+        leaf = self.img_leaf[j]
         frm = self.leaf_anc[leaf, b % self.L].astype(np.int32)
         to = (self.N + j).astype(np.int32)
         return frm, to
