@@ -53,42 +53,64 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const pbf16x8* __restr
   }
 }
 
+// One thread owns a 2x2 patch of input positions (h = 2i, 2i+1; w = 2j, 2j+1) of one channel vector.  The patch is
+// covered by the four windows (ho, wo) in {i, i+1} x {j, j+1}, each loaded ONCE for all four positions (a thread per
+// input position re-loaded them 9 times per patch and ran at 2 TB/s, L1-bound):
+//   position (2i,   2j  ) <- window (i,   j  ) code 1*3+1
+//   position (2i,   2j+1) <- windows (i, j) code 1*3+2, (i, j+1) code 1*3+0
+//   position (2i+1, 2j  ) <- windows (i, j) code 2*3+1, (i+1, j) code 0*3+1
+//   position (2i+1, 2j+1) <- windows (i, j) 2*3+2, (i, j+1) 2*3+0, (i+1, j) 0*3+2, (i+1, j+1) 0*3+0
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const pbf16x8* __restrict__ dy, const pu8x8* __restrict__ idx,
                                                           int N, int H, int W, int CV, pbf16x8* __restrict__ dx) {
   const int Ho = H / 2, Wo = W / 2;
-  const int64_t total = (int64_t)N * H * W * CV;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int cv = (int)(i % CV); int64_t r = i / CV;
-    const int w = (int)(r % W); r /= W;
-    const int h = (int)(r % H); const int n = (int)(r / H);
-    float acc[8];
+  const int64_t total = (int64_t)N * Ho * Wo * CV;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(t % CV); int64_t r = t / CV;
+    const int j = (int)(r % Wo); r /= Wo;
+    const int i = (int)(r % Ho); const int n = (int)(r / Ho);
+    float acc[4][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
-    // windows ho with 2ho-1 <= h <= 2ho+1: ho = h/2 for even h; (h-1)/2 and (h+1)/2 for odd h
-    const int ho0 = (h & 1) ? (h - 1) / 2 : h / 2, nho = (h & 1) ? 2 : 1;
-    const int wo0 = (w & 1) ? (w - 1) / 2 : w / 2, nwo = (w & 1) ? 2 : 1;
-    for (int a = 0; a < nho; ++a) {
-      const int ho = ho0 + a;
-      if (ho >= Ho) continue;
-      const int kh = h - (2 * ho - 1);
-      for (int b = 0; b < nwo; ++b) {
-        const int wo = wo0 + b;
-        if (wo >= Wo) continue;
-        const int code = kh * 3 + (w - (2 * wo - 1));
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[q][c] = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int ho = i + a, wo = j + b;
+        if (ho >= Ho || wo >= Wo) continue;
         const int64_t o = (((int64_t)n * Ho + ho) * Wo + wo) * CV + cv;
         const pu8x8 am = idx[o];
         const pbf16x8 g = dy[o];
+        // window (ho, wo) covers rows 2ho-1..2ho+1: patch row p (h = 2i+p) sits at kh = 2i + p - (2ho - 1) = p + 1 - 2a
 #pragma unroll
-        for (int j = 0; j < 8; ++j) if (am.v[j] == code) acc[j] += pbf2f(g.v[j]);
+        for (int p = 0; p < 2; ++p) {
+          const int kh = p + 1 - 2 * a;
+          if (kh < 0 || kh > 2) continue;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int kw = q + 1 - 2 * b;
+            if (kw < 0 || kw > 2) continue;
+            const int code = kh * 3 + kw;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) if (am.v[c] == code) acc[p * 2 + q][c] += pbf2f(g.v[c]);
+          }
+        }
       }
     }
-    pbf16x8 out;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      __hip_bfloat16 hb = __float2bfloat16(acc[j]);
-      out.v[j] = *reinterpret_cast<unsigned short*>(&hb);
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        pbf16x8 out;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          __hip_bfloat16 hb = __float2bfloat16(acc[p * 2 + q][c]);
+          out.v[c] = *reinterpret_cast<unsigned short*>(&hb);
+        }
+        dx[(((int64_t)n * H + 2 * i + p) * W + 2 * j + q) * CV + cv] = out;
+      }
     }
-    dx[i] = out;
   }
 }
 
@@ -109,7 +131,7 @@ extern "C" int lec_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, int N
   using namespace lec;
   LEC_CHECK_ARG(dy && dx && argmax, "maxpool_bwd: null pointer");
   LEC_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && H % 2 == 0 && W % 2 == 0, "maxpool_bwd: need even H, W and C %% 8 == 0");
-  const int64_t total = (int64_t)N * H * W * (C / 8);
+  const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 8);            // one thread per 2x2 input patch and channel vector
   int64_t nb = (total + 255) / 256; const int nblk = (int)(nb > 16384 ? 16384 : nb);
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const pbf16x8*)dy, (const pu8x8*)argmax, N, H, W, C / 8, (pbf16x8*)dx);
   LEC_CHECK_LAUNCH("maxpool_bwd_kernel");
