@@ -211,6 +211,23 @@ int lec_bn_bwd(const void* dy, const void* dy2, const void* y, const uint8_t* re
                const float* gamma, const float* save_mean, const float* save_invstd, void* dx, void* dresidual,
                float* dgamma, float* dbeta, int relu, void* workspace, int64_t workspace_bytes, lec_stream_t stream);
 
+/* 1x1 stride-1 convolution on NHWC bf16 as an HBM-bound MFMA GEMM, y[M, Cout] = x[M, Cin] * w[Cout, Cin]^T, optionally with
+ * the BatchNorm statistics of its output in the epilogue: replaces the library convolution AND the statistics pass of
+ * torchvision Bottleneck's bn(conv1x1(.)) pairs (oe_h.py:311,317) on the wide layers; with w := W^T it is also those
+ * layers' data gradient.  x: [M, Cin] bf16 (M = N*H*W), w: [Cout, Cin] bf16, y: [M, Cout] bf16.
+ * partials (optional): >= 512*2*Cout floats, receives n_partials (HOST int, <= 512) rows of [sum | sum of squares] per
+ * channel of the bf16-rounded y -- the layout lec_bn_fwd_prestat consumes; pass NULL, NULL for a plain product.
+ * Shapes with a kernel instance: lec_conv1x1_supported(Cin, Cout, M) != 0. */
+int lec_conv1x1_supported(int Cin, int Cout, int64_t M);
+int lec_conv1x1_fwd(const void* x, const void* w, int64_t M, int Cin, int Cout, void* y, float* partials,
+                    int64_t partials_bytes, int* n_partials, lec_stream_t stream);
+/* lec_bn_fwd in training mode with the statistics pass already done: the first n_partials rows of the workspace hold
+ * per-channel [sum | sum of squares] partials (written by lec_conv1x1_fwd into the SAME workspace). */
+int lec_bn_fwd_prestat(const void* x, const void* residual, int64_t M, int C, const float* gamma, const float* beta,
+                       float eps, float momentum, float* running_mean, float* running_var, int n_partials,
+                       float* save_mean, float* save_invstd, void* y, int relu, uint8_t* relu_mask, void* workspace,
+                       int64_t workspace_bytes, lec_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * (8) 3x3 / stride 2 / pad 1 max pooling on NHWC bf16 (the ResNet stem's `maxpool`, oe_h.py:311 -> torchvision).
  *     x: [N, H, W, C] bf16 (H, W even, C % 8 == 0); y: [N, H/2, W/2, C]; argmax: one byte per pooled element (window

@@ -391,7 +391,10 @@ extern "C" int lec_bn_fwd(const void* x, const void* residual, int64_t M, int C,
   BnGeom g = bn_geom(M, C);
   float* part = (float*)workspace;
   float* scale = part + (int64_t)kBnMaxBlocks * 2 * C; float* shift = scale + C;
-  if (training) {
+  if (training > 1) {                                      // statistics partials already in the workspace (training - 2 rows)
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, training - 2, C, M, gamma, beta, eps,
+                       momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
+  } else if (training) {
     hipLaunchKernelGGL(bn_stats_kernel, dim3(g.nrb, g.NCH), dim3(kBnThreads), 0, st, (const bf16x8*)x, M, C, g.CV, g.CVB, g.RPIB, part);
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, g.nrb, C, M, gamma, beta, eps,
                        momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
@@ -437,4 +440,13 @@ extern "C" int lec_bn_bwd(const void* dy, const void* dy2, const void* y, const 
 #undef A
   LEC_CHECK_LAUNCH("bn_bwd kernels");
   return LEC_OK;
+}
+
+extern "C" int lec_bn_fwd_prestat(const void* x, const void* residual, int64_t M, int C, const float* gamma, const float* beta,
+                                  float eps, float momentum, float* running_mean, float* running_var, int n_partials,
+                                  float* save_mean, float* save_invstd, void* y, int relu, uint8_t* relu_mask, void* workspace,
+                                  int64_t workspace_bytes, lec_stream_t stream) {
+  LEC_CHECK_ARG(n_partials >= 1 && n_partials <= lec::kBnMaxBlocks, "bn_fwd_prestat: n_partials=%d outside 1..%d", n_partials, lec::kBnMaxBlocks);
+  return lec_bn_fwd(x, residual, M, C, gamma, beta, eps, momentum, running_mean, running_var, 2 + n_partials, save_mean, save_invstd,
+                    y, relu, relu_mask, workspace, workspace_bytes, stream);
 }

@@ -1,0 +1,209 @@
+// 1x1 stride-1 convolution forward on NHWC bf16 activations WITH the BatchNorm statistics of its output in the epilogue
+// (lec_conv1x1_fwd).  In the reference this is torchvision Bottleneck's `bn3(conv3(out))` / `downsample` pair
+// inside FeatCNN18's backbone (oe_h.py:311,317): a library convolution that writes Y, then a statistics pass that reads
+// all of Y again.  For the wide block outputs of layer1 (Cin = 64 -> Cout = 256 at 56x56: 822 MB of Y at the bench batch)
+// both are HBM-bound, and the statistics pass costs as much as the convolution's own write.  Here the convolution is
+// Y[M, N] = X[M, K] * W[N, K]^T on MFMA (v_mfma_f32_32x32x16_bf16), HBM-bound by construction (K = 64: 640 B moved per
+// row against 32 K flop), and every workgroup leaves per-channel sum / sum-of-squares partials of the bf16-rounded Y in the
+// layout the BatchNorm finalize kernel consumes -- the statistics pass disappears.
+//
+// Work decomposition: a workgroup = 4 waves, W (N x K bf16, 32 KB) resident in LDS for the whole launch; a wave owns
+// 32-row strips of X.  Per strip: the strip's B fragments come straight from global memory (16 B per lane, prefetched one
+// strip ahead); 8 n-tiles x 4 k-steps of MFMA with A = W from LDS give D'[n][m] (n in registers, m on the lane), i.e. 4
+// consecutive output channels per lane and register group -- converted to bf16, transposed through a per-wave LDS tile
+// 64 channels at a time, read back as 16-byte row segments, accumulated into the statistics and stored coalesced
+// (non-temporal: Y is consumed by a later kernel and is far larger than the caches).
+//
+// Roofline: HBM.  Algorithmic bytes per output row: 2 K (read X) + 2 N (write Y); the weights and partials are noise.
+#include <hip/hip_bf16.h>
+#include "lec_common.h"
+
+namespace lec {
+
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));      // MFMA A/B fragment: 8 bf16 = 4 VGPRs
+typedef float f32x16_t __attribute__((ext_vector_type(16)));     // 32x32 accumulator tile: 16 VGPRs per lane
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned short c1_f2bf(float f) {
+  __hip_bfloat16 h = __float2bfloat16(f);
+  return *reinterpret_cast<unsigned short*>(&h);
+}
+__device__ __forceinline__ float c1_bf2f(unsigned short u) { return __uint_as_float(((unsigned int)u) << 16); }
+
+constexpr int kC1Threads = 256;
+constexpr int kC1MaxBlocks = 512;          // = kBnMaxBlocks: the partials land in the BatchNorm workspace
+
+// K: reduction width (input channels); N: output channels handled by ONE workgroup (blockIdx.y selects the N-wide column
+// block of an Ntot-wide output: a layer wider than its weights' LDS budget re-reads X once per column block);
+// STATS: leave the per-channel partials (forward) or not (the same kernel serves the data gradient: X := dY, W := W^T).
+template <int K, int N, bool STATS>
+__global__ __launch_bounds__(kC1Threads) void conv1x1_fwd_stats_kernel(const unsigned short* __restrict__ X,
+                                                                       const unsigned short* __restrict__ Wt, int64_t M, int Ntot,
+                                                                       unsigned short* __restrict__ Y, float* __restrict__ part) {
+  constexpr int KS = K / 16;                 // k-steps of one MFMA
+  constexpr int NC = N / 64;                 // 64-channel chunks of the epilogue
+  Wt += (int64_t)blockIdx.y * N * K; Y += (int64_t)blockIdx.y * N;
+  constexpr int WLD = K + 8;                 // padded LDS row (bf16 elements): 16-byte reads of 32 rows hit distinct banks
+  constexpr int YLD = 64 + 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  unsigned short* Ws = smem;                                     // [N][WLD]
+  unsigned short* Ys = Ws + N * WLD + (threadIdx.x >> 6) * 32 * YLD;   // per wave [32][YLD]
+  float* Ss = (float*)(smem + N * WLD + 4 * 32 * YLD);           // [4 waves][2][N] (end of the launch only)
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  // ---- weights -> LDS, once
+  for (int e = threadIdx.x; e < N * (K / 8); e += kC1Threads) {
+    const int n = e / (K / 8), c = e - n * (K / 8);
+    *(u32x4_t*)(Ws + n * WLD + c * 8) = *(const u32x4_t*)(Wt + (int64_t)n * K + c * 8);
+  }
+  __syncthreads();
+
+  float st_s[NC][8], st_q[NC][8];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { st_s[c][j] = 0.0f; st_q[c][j] = 0.0f; }
+
+  const int64_t nstrips = M / 32;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t s = (int64_t)blockIdx.x * 4 + wave;
+  bf16x8_t xb[KS], xn[KS];
+  if (s < nstrips) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xb[ks] = *(const bf16x8_t*)(X + (s * 32 + r) * K + ks * 16 + h * 8);
+  }
+  for (; s < nstrips; s += stride) {
+    const int64_t sn = s + stride;
+    if (sn < nstrips) {                                            // prefetch the next strip's fragments
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) xn[ks] = *(const bf16x8_t*)(X + (sn * 32 + r) * K + ks * 16 + h * 8);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      f32x16_t acc[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.0f;
+        const unsigned short* wrow = Ws + ((c * 2 + t) * 32 + r) * WLD + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8_t a = *(const bf16x8_t*)(wrow + ks * 16);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[ks], acc[t], 0, 0, 0);
+        }
+      }
+      // D'[n][m]: lane holds m = r, n = t*32 + 8g + 4h + (0..3) in registers 4g..4g+3  ->  Ys[m][n_local]
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u32x2_t pk;
+          pk.x = (unsigned int)c1_f2bf(acc[t][4 * g + 0]) | ((unsigned int)c1_f2bf(acc[t][4 * g + 1]) << 16);
+          pk.y = (unsigned int)c1_f2bf(acc[t][4 * g + 2]) | ((unsigned int)c1_f2bf(acc[t][4 * g + 3]) << 16);
+          *(u32x2_t*)(Ys + r * YLD + t * 32 + 8 * g + 4 * h) = pk;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // rows back out as 16-byte segments: lane -> rows (lane >> 3) + 8 i, channels c*64 + (lane & 7) * 8 .. + 8
+      const int cc = lane & 7, r0 = lane >> 3;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = r0 + 8 * i;
+        const u32x4_t v = *(const u32x4_t*)(Ys + row * YLD + cc * 8);
+        const unsigned int w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = c1_bf2f((unsigned short)(w4[j >> 1] >> ((j & 1) * 16)));
+          if (STATS) { st_s[c][j] += f; st_q[c][j] += f * f; }
+        }
+        __builtin_nontemporal_store(v, (u32x4_t*)(Y + (s * 32 + row) * Ntot + c * 64 + cc * 8));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xb[ks] = xn[ks];
+  }
+
+  if (!STATS) return;
+  // ---- statistics: lanes with equal (lane & 7) own the same 8 channels of a chunk: fold the 8 row groups, then the 4 waves
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a = st_s[c][j], b = st_q[c][j];
+      a += __shfl_xor(a, 8, 64); b += __shfl_xor(b, 8, 64);
+      a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+      a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+      st_s[c][j] = a; st_q[c][j] = b;
+    }
+  }
+  __syncthreads();                                                 // every wave is done with its Ys tile
+  if (lane < 8) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        Ss[(wave * 2 + 0) * N + c * 64 + lane * 8 + j] = st_s[c][j];
+        Ss[(wave * 2 + 1) * N + c * 64 + lane * 8 + j] = st_q[c][j];
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * N; e += kC1Threads) {
+    const int which = e / N, n = e - which * N;
+    part[(int64_t)blockIdx.x * 2 * Ntot + which * Ntot + blockIdx.y * N + n] =
+        Ss[(0 * 2 + which) * N + n] + Ss[(1 * 2 + which) * N + n] + Ss[(2 * 2 + which) * N + n] + Ss[(3 * 2 + which) * N + n];
+  }
+}
+
+template <int K, int N, bool STATS>
+static int launch_conv1x1(const void* x, const void* w, int64_t M, int Ntot, void* y, float* part, int* nblk_out, hipStream_t st) {
+  const size_t smem = ((size_t)N * (K + 8) + 4 * 32 * (64 + 8)) * sizeof(unsigned short) + (size_t)4 * 2 * N * sizeof(float);
+  static bool attr_set = false;
+  if (smem > 64 * 1024 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv1x1_fwd_stats_kernel<K, N, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv1x1)");
+    attr_set = true;
+  }
+  const int64_t nstrips = M / 32;
+  int64_t nb = (nstrips + 3) / 4;
+  const int cap = kC1MaxBlocks / (Ntot / N) > 0 ? kC1MaxBlocks / (Ntot / N) : 1;
+  const int nblk = (int)(nb > cap ? cap : nb);
+  hipLaunchKernelGGL((conv1x1_fwd_stats_kernel<K, N, STATS>), dim3(nblk, Ntot / N), dim3(kC1Threads), smem, st, (const unsigned short*)x,
+                     (const unsigned short*)w, M, Ntot, (unsigned short*)y, part);
+  if (nblk_out) *nblk_out = nblk;
+  LEC_CHECK_LAUNCH("conv1x1_fwd_stats_kernel");
+  return LEC_OK;
+}
+
+}  // namespace lec
+
+// (Cin, Cout) pairs with a kernel instance; M = N*H*W must be a multiple of 32
+extern "C" int lec_conv1x1_supported(int Cin, int Cout, int64_t M) {
+  const bool shape = (Cin == 64 && (Cout == 64 || Cout == 256)) || (Cin == 128 && (Cout == 256 || Cout == 512)) || (Cin == 256 && (Cout == 64 || Cout == 128));
+  return shape && M > 0 && M % 32 == 0;
+}
+
+extern "C" int lec_conv1x1_fwd(const void* x, const void* w, int64_t M, int Cin, int Cout, void* y, float* partials,
+                               int64_t partials_bytes, int* n_partials, lec_stream_t stream) {
+  using namespace lec;
+  LEC_CHECK_ARG(x && w && y, "conv1x1_fwd: null pointer");
+  LEC_CHECK_ARG(lec_conv1x1_supported(Cin, Cout, M), "conv1x1_fwd: unsupported shape Cin=%d Cout=%d M=%lld", Cin, Cout, (long long)M);
+  LEC_CHECK_ARG((partials == nullptr) == (n_partials == nullptr), "conv1x1_fwd: pass partials and n_partials together");
+  LEC_CHECK_ARG(!partials || partials_bytes >= (int64_t)kC1MaxBlocks * 2 * Cout * (int64_t)sizeof(float), "conv1x1_fwd: partials buffer too small");
+  hipStream_t st = (hipStream_t)stream;
+#define LEC_C1(K_, NB_) (partials ? launch_conv1x1<K_, NB_, true>(x, w, M, Cout, y, partials, n_partials, st) \
+                                  : launch_conv1x1<K_, NB_, false>(x, w, M, Cout, y, nullptr, nullptr, st))
+  if (Cin == 64 && Cout == 256) return LEC_C1(64, 256);
+  if (Cin == 64 && Cout == 64) return LEC_C1(64, 64);
+  if (Cin == 128) return LEC_C1(128, 256);                          // Cout = 512: two column blocks, X is read twice
+  if (Cin == 256 && Cout == 64) return LEC_C1(256, 64);
+  return LEC_C1(256, 128);
+#undef LEC_C1
+}

@@ -317,11 +317,20 @@ class BNActFn(torch.autograd.Function):
         # ReLU bitmask for backward: 1/16 of the bytes of y (y itself stays alive only as the next conv's input)
         mask = torch.empty(M * (Cc // 8), dtype=torch.uint8, device=x.device) if (relu and training) else None
         el = M * Cc                                   # algorithmic bytes: x (stats) + x + y [+ residual] [+ mask]
-        nbytes = el * ((4 if training else 2) + 2 + (2 if residual is not None else 0)) + (el // 8 if mask is not None else 0)
-        _bn_timed(lambda: check(lib.lec_bn_fwd(dptr(x), dptr(residual), M, Cc, dptr(weight), dptr(bias), float(eps), float(momentum),
-                                               dptr(running_mean), dptr(running_var), int(bool(training)), dptr(save_mean),
-                                               dptr(save_invstd), dptr(y), int(bool(relu)), dptr(mask), dptr(ws), ws.numel(),
-                                               stream_ptr())), nbytes)
+        # the convolution that produced x may have left its statistics partials in the workspace (conv1x1_rows)
+        prestat = _BN_WS_OWNER[1] if (training and _BN_WS_OWNER[0] == x.data_ptr()) else 0
+        _BN_WS_OWNER[0] = 0
+        nbytes = el * ((4 if (training and not prestat) else 2) + 2 + (2 if residual is not None else 0)) + (el // 8 if mask is not None else 0)
+        if prestat:
+            _bn_timed(lambda: check(lib.lec_bn_fwd_prestat(dptr(x), dptr(residual), M, Cc, dptr(weight), dptr(bias), float(eps), float(momentum),
+                                                           dptr(running_mean), dptr(running_var), prestat, dptr(save_mean),
+                                                           dptr(save_invstd), dptr(y), int(bool(relu)), dptr(mask), dptr(ws), ws.numel(),
+                                                           stream_ptr())), nbytes)
+        else:
+            _bn_timed(lambda: check(lib.lec_bn_fwd(dptr(x), dptr(residual), M, Cc, dptr(weight), dptr(bias), float(eps), float(momentum),
+                                                   dptr(running_mean), dptr(running_var), int(bool(training)), dptr(save_mean),
+                                                   dptr(save_invstd), dptr(y), int(bool(relu)), dptr(mask), dptr(ws), ws.numel(),
+                                                   stream_ptr())), nbytes)
         if training:
             ctx.save_for_backward(x, mask, weight, save_mean, save_invstd)
             ctx.meta = (M, Cc, bool(relu), residual is not None)
@@ -351,6 +360,7 @@ class BNActFn(torch.autograd.Function):
             sink = None
             dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device); dbeta = torch.empty_like(dgamma)
         ws = _bn_workspace(x.device)
+        _BN_WS_OWNER[0] = 0
         el = M * Cc                                   # 2 x (dy [+ dy2] + x [+ mask]) + dx [+ d residual]
         if has_res:      # pass 1 reads dy [+ dy2], x, mask and writes g (= d residual); pass 2 reads g, x and writes dx
             nbytes = el * ((4 + (2 if dy2 is not None else 0) + 2) + (4 + 2)) + (el // 8 if relu else 0)
@@ -367,6 +377,28 @@ class BNActFn(torch.autograd.Function):
 
 
 _bn_ws = {}
+_BN_WS_OWNER = [0, 0]        # (data_ptr of the tensor whose statistics partials sit in the BN workspace, number of partial rows)
+
+
+def conv1x1_supported(cin, cout, M):
+    return bool(lib.lec_conv1x1_supported(int(cin), int(cout), int(M)))
+
+
+def conv1x1_rows(x_rows, w2, want_stats=False):
+    """y[M, Cout] = x[M, Cin] @ w[Cout, Cin]^T on the hand-written MFMA kernel (lec_conv1x1_fwd); with want_stats the
+    per-channel sum / sum-of-squares partials of y are left in the BatchNorm workspace for the BN that follows
+    (BNActFn checks the ownership tag before trusting them)."""
+    M, cin = x_rows.shape
+    cout = w2.shape[0]
+    y = torch.empty((M, cout), dtype=torch.bfloat16, device=x_rows.device)
+    if want_stats:
+        ws = _bn_workspace(x_rows.device)
+        n = C.c_int(0)
+        check(lib.lec_conv1x1_fwd(dptr(x_rows), dptr(w2), M, cin, cout, dptr(y), dptr(ws), ws.numel(), C.byref(n), stream_ptr()))
+        _BN_WS_OWNER[0], _BN_WS_OWNER[1] = y.data_ptr(), n.value
+    else:
+        check(lib.lec_conv1x1_fwd(dptr(x_rows), dptr(w2), M, cin, cout, dptr(y), None, 0, None, stream_ptr()))
+    return y
 
 
 def _bn_workspace(device):

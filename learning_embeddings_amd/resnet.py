@@ -107,8 +107,18 @@ class WgradOverlap:
 # 256->1024 @14x14: 107 -> 60 us) and the forward from Cin >= 1024; MIOpen keeps the narrow layers and every weight
 # gradient (a transposed-A GEMM with K = N*H*W is 2-30x slower in hipBLASLt).
 GEMM_1X1 = os.environ.get('LEC_CONV1X1_GEMM', '1') != '0'
+# ... and the wide HBM-bound 1x1 layers (Cin 64 / 128 / 256 at 56x56 and 28x28) run liblecone's own MFMA kernel
+# (csrc/conv1x1.hip): forward with the BatchNorm statistics of the output in its epilogue, and the data gradient as the
+# same kernel on the transposed weights.  tools/bench_conv1x1_fused.py: 64->256 @56x56 169 us against MIOpen's 227 us,
+# and the BatchNorm that follows drops its statistics pass (447 -> 302 us).
+MFMA_1X1 = os.environ.get('LEC_CONV1X1_MFMA', '1') != '0'
 GEMM_FWD_MIN_CIN = 1024
 GEMM_DGRAD_MIN_CIN = 256
+
+
+def _ops():
+    from . import ops
+    return ops
 
 
 def _is_pointwise(conv):
@@ -134,7 +144,11 @@ class _OverlapConvFn(torch.autograd.Function):
         if nhwc and w16.dim() == 4 and not w16.is_contiguous(memory_format=torch.channels_last):
             w16 = w16.contiguous(memory_format=torch.channels_last)
         ctx.pointwise = GEMM_1X1 and nhwc and _is_pointwise(conv)
-        if ctx.pointwise and conv.in_channels >= GEMM_FWD_MIN_CIN:
+        ctx.own = ctx.pointwise and MFMA_1X1 and x.dtype == torch.bfloat16
+        if ctx.own and _ops().conv1x1_supported(conv.in_channels, conv.out_channels, x.shape[0] * x.shape[2] * x.shape[3]):
+            n, _, h, wd = x.shape
+            y = _from_rows(_ops().conv1x1_rows(_rows(x), w16.reshape(conv.out_channels, conv.in_channels), want_stats=True), n, h, wd)
+        elif ctx.pointwise and conv.in_channels >= GEMM_FWD_MIN_CIN:
             n, _, h, wd = x.shape
             y = _from_rows(torch.mm(_rows(x), w16.reshape(conv.out_channels, conv.in_channels).t()), n, h, wd)
         else:
@@ -147,7 +161,12 @@ class _OverlapConvFn(torch.autograd.Function):
         x, w16 = ctx.saved_tensors; conv = ctx.conv
         gx = None
         if ctx.needs_input_grad[0]:
-            if (ctx.pointwise and conv.in_channels >= GEMM_DGRAD_MIN_CIN and gy.is_contiguous(memory_format=torch.channels_last)):
+            nhwc_g = gy.is_contiguous(memory_format=torch.channels_last)
+            if (ctx.own and nhwc_g and _ops().conv1x1_supported(conv.out_channels, conv.in_channels, gy.shape[0] * gy.shape[2] * gy.shape[3])):
+                n, _, h, wd = gy.shape                          # dX = dY * W: the same kernel on W^T [Cin, Cout]
+                wt = w16.reshape(conv.out_channels, conv.in_channels).t().contiguous()
+                gx = _from_rows(_ops().conv1x1_rows(_rows(gy), wt), n, h, wd)
+            elif (ctx.pointwise and conv.in_channels >= GEMM_DGRAD_MIN_CIN and nhwc_g):
                 n, _, h, wd = gy.shape
                 gx = _from_rows(torch.mm(_rows(gy), w16.reshape(conv.out_channels, conv.in_channels)), n, h, wd)
             else:

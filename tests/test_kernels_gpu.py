@@ -470,3 +470,51 @@ def test_level_topk_empty_and_argument_errors():
         ops.level_topk(lab, torch.rand(3, 4, device=DEV), [0, 4, 10], 9, 0.1)    # k > 8
     with pytest.raises(ValueError):
         ops.level_topk(lab, torch.rand(3, 4, device=DEV), [0, 4, 11], 3, 0.1)    # offsets past the table
+
+
+# ---------------------------------------------------------------------------------------------- MFMA 1x1 convolution (+ BN statistics)
+@pytest.mark.parametrize('cin,cout,M', [(64, 256, 32 * 301), (64, 64, 32 * 40), (128, 512, 32 * 97), (128, 256, 32 * 64),
+                                        (256, 64, 32 * 129), (256, 128, 32 * 33), (64, 256, 512 * 56 * 56)])
+def test_conv1x1_mfma_vs_fp32_matmul_and_statistics(cin, cout, M):
+    """lec_conv1x1_fwd: y = x w^T (bf16 in, fp32 accumulate, bf16 out) against an fp32 matmul, and the per-channel
+    sum / sum-of-squares partials it leaves for BatchNorm against sums over the rounded output."""
+    assert ops.conv1x1_supported(cin, cout, M) and not ops.conv1x1_supported(cin, cout, M + 1) and not ops.conv1x1_supported(96, 256, M)
+    g = torch.Generator(device='cpu').manual_seed(cin * 7 + cout)
+    rows = min(M, 32 * 512)
+    x = (torch.randn(rows, cin, generator=g) * 0.7).to(DEV).to(torch.bfloat16)
+    if M > rows:
+        x = x.repeat(M // rows, 1)
+    w = (torch.randn(cout, cin, generator=g) * 0.2).to(DEV).to(torch.bfloat16)
+    y = ops.conv1x1_rows(x, w, want_stats=True)
+    n = ops._BN_WS_OWNER[1]
+    assert ops._BN_WS_OWNER[0] == y.data_ptr() and 1 <= n <= 512
+    part = ops._bn_workspace(x.device)[:n * 2 * cout * 4].view(torch.float32).view(n, 2, cout).double().sum(0)
+    ref = x[:rows].float() @ w.float().t()
+    assert (y[:rows].float() - ref).abs().max().item() <= 6e-3 * ref.abs().max().item()      # bf16 rounding of the output
+    assert torch.equal(y[:rows], y[-rows:])                                                   # every strip of a long input
+    yd = y.float().double()
+    assert ((part[0] - yd.sum(0)).abs().max() / (yd.sum(0).abs().max() + 1e-9)).item() < 1e-4
+    assert ((part[1] - (yd * yd).sum(0)).abs().max() / (yd * yd).sum(0).abs().max()).item() < 1e-5
+    y2 = ops.conv1x1_rows(x, w)                                                               # plain product (the dgrad form)
+    assert torch.equal(y, y2)
+    ops._BN_WS_OWNER[0] = 0
+
+
+def test_conv1x1_statistics_feed_batchnorm():
+    """conv (MFMA kernel, statistics in the epilogue) -> BatchNorm (no statistics pass) equals conv -> full BatchNorm."""
+    g = torch.Generator(device='cpu').manual_seed(5)
+    N, H, W, cin, cout = 4, 16, 16, 64, 256
+    x = torch.randn(N * H * W, cin, generator=g).to(DEV).to(torch.bfloat16)
+    w = (torch.randn(cout, cin, generator=g) * 0.2).to(DEV).to(torch.bfloat16)
+    gam = (torch.rand(cout, generator=g) + 0.5).to(DEV); bet = torch.randn(cout, generator=g).to(DEV)
+    outs = []
+    for fused in (True, False):
+        y = ops.conv1x1_rows(x, w, want_stats=fused)
+        y4 = y.view(N, H, W, cout).permute(0, 3, 1, 2)
+        rm = torch.zeros(cout, device=DEV); rv = torch.ones(cout, device=DEV)
+        assert (ops._BN_WS_OWNER[0] == y.data_ptr()) == fused
+        z = ops.BNActFn.apply(y4, None, gam, bet, rm, rv, True, 0.1, 1e-5, True)
+        assert ops._BN_WS_OWNER[0] == 0
+        outs.append((z.float(), rm.clone(), rv.clone()))
+    assert (outs[0][0] - outs[1][0]).abs().max().item() <= 2e-2 * outs[1][0].abs().max().item()
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-6) and torch.allclose(outs[0][2], outs[1][2], rtol=1e-4, atol=1e-6)
