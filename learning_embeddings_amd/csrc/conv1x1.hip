@@ -182,11 +182,160 @@ static int launch_conv1x1(const void* x, const void* w, int64_t M, int Ntot, voi
   return LEC_OK;
 }
 
+// Wide-K form (K = 512: the 512 -> 128 convolutions of layer2 and the data gradient of its 128 -> 512 ones).  A strip's
+// fragments no longer fit the register file next to their prefetch, so K streams through a ring of R 64-wide chunks:
+// chunk ch is consumed by the MFMAs of all N/32 accumulator tiles (kept in registers for the whole strip) and its slot
+// is refilled at once with chunk ch + R -- of this strip, or of the next one, so that the loads never drain.
+template <int K, int N, bool STATS>
+__global__ __launch_bounds__(kC1Threads) void conv1x1_bigk_kernel(const unsigned short* __restrict__ X,
+                                                                  const unsigned short* __restrict__ Wt, int64_t M, int Ntot,
+                                                                  unsigned short* __restrict__ Y, float* __restrict__ part) {
+  constexpr int NCH = K / 64, R = 4, NT = N / 32, NC = N / 64;
+  constexpr int WLD = K + 8, YLD = 64 + 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  unsigned short* Ws = smem;
+  unsigned short* Ys = Ws + N * WLD + (threadIdx.x >> 6) * 32 * YLD;
+  float* Ss = (float*)(smem + N * WLD + 4 * 32 * YLD);
+  Wt += (int64_t)blockIdx.y * N * K; Y += (int64_t)blockIdx.y * N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  for (int e = threadIdx.x; e < N * (K / 8); e += kC1Threads) {
+    const int n = e / (K / 8), c = e - n * (K / 8);
+    *(u32x4_t*)(Ws + n * WLD + c * 8) = *(const u32x4_t*)(Wt + (int64_t)n * K + c * 8);
+  }
+  __syncthreads();
+  float st_s[NC][8], st_q[NC][8];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { st_s[c][j] = 0.0f; st_q[c][j] = 0.0f; }
+
+  const int64_t nstrips = M / 32;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t s = (int64_t)blockIdx.x * 4 + wave;
+  bf16x8_t ring[R][4];
+  if (s < nstrips) {
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) ring[j][ks] = *(const bf16x8_t*)(X + (s * 32 + r) * K + j * 64 + ks * 16 + h * 8);
+  }
+  for (; s < nstrips; s += stride) {
+    const int64_t sn = s + stride;
+    f32x16_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[t][q] = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      constexpr int dummy = 0; (void)dummy;
+      const int slot = ch % R;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const unsigned short* wrow = Ws + (t * 32 + r) * WLD + ch * 64 + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(wrow + ks * 16), ring[slot][ks], acc[t], 0, 0, 0);
+      }
+      const int nch = ch + R;
+      if (nch < NCH) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ring[slot][ks] = *(const bf16x8_t*)(X + (s * 32 + r) * K + nch * 64 + ks * 16 + h * 8);
+      } else if (sn < nstrips) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ring[slot][ks] = *(const bf16x8_t*)(X + (sn * 32 + r) * K + (nch - NCH) * 64 + ks * 16 + h * 8);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u32x2_t pk;
+          pk.x = (unsigned int)c1_f2bf(acc[c * 2 + t][4 * g + 0]) | ((unsigned int)c1_f2bf(acc[c * 2 + t][4 * g + 1]) << 16);
+          pk.y = (unsigned int)c1_f2bf(acc[c * 2 + t][4 * g + 2]) | ((unsigned int)c1_f2bf(acc[c * 2 + t][4 * g + 3]) << 16);
+          *(u32x2_t*)(Ys + r * YLD + t * 32 + 8 * g + 4 * h) = pk;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int cc = lane & 7, r0 = lane >> 3;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = r0 + 8 * i;
+        const u32x4_t v = *(const u32x4_t*)(Ys + row * YLD + cc * 8);
+        const unsigned int w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = c1_bf2f((unsigned short)(w4[j >> 1] >> ((j & 1) * 16)));
+          if (STATS) { st_s[c][j] += f; st_q[c][j] += f * f; }
+        }
+        __builtin_nontemporal_store(v, (u32x4_t*)(Y + (s * 32 + row) * Ntot + c * 64 + cc * 8));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  if (!STATS) return;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a = st_s[c][j], b = st_q[c][j];
+      a += __shfl_xor(a, 8, 64); b += __shfl_xor(b, 8, 64);
+      a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+      a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+      st_s[c][j] = a; st_q[c][j] = b;
+    }
+  }
+  __syncthreads();
+  if (lane < 8) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        Ss[(wave * 2 + 0) * N + c * 64 + lane * 8 + j] = st_s[c][j];
+        Ss[(wave * 2 + 1) * N + c * 64 + lane * 8 + j] = st_q[c][j];
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * N; e += kC1Threads) {
+    const int which = e / N, n = e - which * N;
+    part[(int64_t)blockIdx.x * 2 * Ntot + which * Ntot + blockIdx.y * N + n] =
+        Ss[(0 * 2 + which) * N + n] + Ss[(1 * 2 + which) * N + n] + Ss[(2 * 2 + which) * N + n] + Ss[(3 * 2 + which) * N + n];
+  }
+}
+
+template <int K, int N, bool STATS>
+static int launch_conv1x1_bigk(const void* x, const void* w, int64_t M, int Ntot, void* y, float* part, int* nblk_out, hipStream_t st) {
+  const size_t smem = ((size_t)N * (K + 8) + 4 * 32 * (64 + 8)) * sizeof(unsigned short) + (size_t)4 * 2 * N * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv1x1_bigk_kernel<K, N, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv1x1_bigk)");
+    attr_set = true;
+  }
+  const int64_t nstrips = M / 32;
+  int64_t nb = (nstrips + 3) / 4;
+  const int cap = kC1MaxBlocks / (Ntot / N) > 0 ? kC1MaxBlocks / (Ntot / N) : 1;
+  const int nblk = (int)(nb > cap ? cap : nb);
+  hipLaunchKernelGGL((conv1x1_bigk_kernel<K, N, STATS>), dim3(nblk, Ntot / N), dim3(kC1Threads), smem, st, (const unsigned short*)x,
+                     (const unsigned short*)w, M, Ntot, (unsigned short*)y, part);
+  if (nblk_out) *nblk_out = nblk;
+  LEC_CHECK_LAUNCH("conv1x1_bigk_kernel");
+  return LEC_OK;
+}
+
 }  // namespace lec
 
 // (Cin, Cout) pairs with a kernel instance; M = N*H*W must be a multiple of 32
 extern "C" int lec_conv1x1_supported(int Cin, int Cout, int64_t M) {
-  const bool shape = (Cin == 64 && (Cout == 64 || Cout == 256)) || (Cin == 128 && (Cout == 256 || Cout == 512)) || (Cin == 256 && (Cout == 64 || Cout == 128));
+  const bool shape = (Cin == 64 && (Cout == 64 || Cout == 256)) || (Cin == 128 && (Cout == 256 || Cout == 512)) || (Cin == 256 && (Cout == 64 || Cout == 128)) || (Cin == 512 && Cout == 128);
   return shape && M > 0 && M % 32 == 0;
 }
 
@@ -203,6 +352,8 @@ extern "C" int lec_conv1x1_fwd(const void* x, const void* w, int64_t M, int Cin,
   if (Cin == 64 && Cout == 256) return LEC_C1(64, 256);
   if (Cin == 64 && Cout == 64) return LEC_C1(64, 64);
   if (Cin == 128) return LEC_C1(128, 256);                          // Cout = 512: two column blocks, X is read twice
+  if (Cin == 512) return partials ? launch_conv1x1_bigk<512, 128, true>(x, w, M, Cout, y, partials, n_partials, st)
+                                  : launch_conv1x1_bigk<512, 128, false>(x, w, M, Cout, y, nullptr, nullptr, st);
   if (Cin == 256 && Cout == 64) return LEC_C1(256, 64);
   return LEC_C1(256, 128);
 #undef LEC_C1

@@ -474,7 +474,7 @@ def test_level_topk_empty_and_argument_errors():
 
 # ---------------------------------------------------------------------------------------------- MFMA 1x1 convolution (+ BN statistics)
 @pytest.mark.parametrize('cin,cout,M', [(64, 256, 32 * 301), (64, 64, 32 * 40), (128, 512, 32 * 97), (128, 256, 32 * 64),
-                                        (256, 64, 32 * 129), (256, 128, 32 * 33), (64, 256, 512 * 56 * 56)])
+                                        (256, 64, 32 * 129), (256, 128, 32 * 33), (512, 128, 32 * 77), (64, 256, 512 * 56 * 56)])
 def test_conv1x1_mfma_vs_fp32_matmul_and_statistics(cin, cout, M):
     """lec_conv1x1_fwd: y = x w^T (bf16 in, fp32 accumulate, bf16 out) against an fp32 matmul, and the per-channel
     sum / sum-of-squares partials it leaves for BatchNorm against sums over the rounded output."""
