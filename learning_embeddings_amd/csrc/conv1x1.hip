@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kC1Threads) void conv1x1_fwd_stats_kernel(const uns
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   unsigned short* Ws = smem;                                     // [N][WLD]
   unsigned short* Ys = Ws + N * WLD + (threadIdx.x >> 6) * 32 * YLD;   // per wave [32][YLD]
-  float* Ss = (float*)(smem + N * WLD + 4 * 32 * YLD);           // [4 waves][2][N] (end of the launch only)
+  float* Ss = (float*)(smem + N * WLD);                         // [4 waves][2][N]: end of the launch only, reuses the Y tiles
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -164,7 +164,8 @@ __global__ __launch_bounds__(kC1Threads) void conv1x1_fwd_stats_kernel(const uns
 
 template <int K, int N, bool STATS>
 static int launch_conv1x1(const void* x, const void* w, int64_t M, int Ntot, void* y, float* part, int* nblk_out, hipStream_t st) {
-  const size_t smem = ((size_t)N * (K + 8) + 4 * 32 * (64 + 8)) * sizeof(unsigned short) + (size_t)4 * 2 * N * sizeof(float);
+  static_assert(4 * 2 * N * sizeof(float) <= 4 * 32 * (64 + 8) * sizeof(unsigned short), "statistics staging must fit the Y tiles");
+  const size_t smem = ((size_t)N * (K + 8) + 4 * 32 * (64 + 8)) * sizeof(unsigned short);
   static bool attr_set = false;
   if (smem > 64 * 1024 && !attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv1x1_fwd_stats_kernel<K, N, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(kC1Threads) void conv1x1_bigk_kernel(const unsigned
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   unsigned short* Ws = smem;
   unsigned short* Ys = Ws + N * WLD + (threadIdx.x >> 6) * 32 * YLD;
-  float* Ss = (float*)(smem + N * WLD + 4 * 32 * YLD);
+  float* Ss = (float*)(smem + N * WLD);                         // reuses the Y tiles at the end of the launch
   Wt += (int64_t)blockIdx.y * N * K; Y += (int64_t)blockIdx.y * N;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -313,7 +314,8 @@ __global__ __launch_bounds__(kC1Threads) void conv1x1_bigk_kernel(const unsigned
 
 template <int K, int N, bool STATS>
 static int launch_conv1x1_bigk(const void* x, const void* w, int64_t M, int Ntot, void* y, float* part, int* nblk_out, hipStream_t st) {
-  const size_t smem = ((size_t)N * (K + 8) + 4 * 32 * (64 + 8)) * sizeof(unsigned short) + (size_t)4 * 2 * N * sizeof(float);
+  static_assert(4 * 2 * N * sizeof(float) <= 4 * 32 * (64 + 8) * sizeof(unsigned short), "statistics staging must fit the Y tiles");
+  const size_t smem = ((size_t)N * (K + 8) + 4 * 32 * (64 + 8)) * sizeof(unsigned short);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv1x1_bigk_kernel<K, N, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
