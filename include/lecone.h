@@ -221,6 +221,12 @@ int lec_bn_bwd(const void* dy, const void* dy2, const void* y, const uint8_t* re
 int lec_conv1x1_supported(int Cin, int Cout, int64_t M);
 int lec_conv1x1_fwd(const void* x, const void* w, int64_t M, int Cin, int Cout, void* y, float* partials,
                     int64_t partials_bytes, int* n_partials, lec_stream_t stream);
+/* 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels on NHWC bf16 (ResNet-50 layer1's conv2, the
+ * one 3x3 layer near the HBM ridge), same MFMA wave-strip scheme and optional statistics epilogue as lec_conv1x1_fwd.
+ * x: [N, H, W, 64], w: [64 out][3][3][64 in] (a channels_last conv weight), y: [N, H, W, 64]; N*H*W % 32 == 0.
+ * The layer's data gradient is the same call on dy with w'[ci][r][s][co] = w[co][2-r][2-s][ci]. */
+int lec_conv3x3_c64_fwd(const void* x, const void* w, int N, int H, int W, void* y, float* partials,
+                        int64_t partials_bytes, int* n_partials, lec_stream_t stream);
 /* lec_bn_fwd in training mode with the statistics pass already done: the first n_partials rows of the workspace hold
  * per-channel [sum | sum of squares] partials (written by lec_conv1x1_fwd into the SAME workspace). */
 int lec_bn_fwd_prestat(const void* x, const void* residual, int64_t M, int C, const float* gamma, const float* beta,

@@ -333,6 +333,185 @@ static int launch_conv1x1_bigk(const void* x, const void* w, int64_t M, int Ntot
   return LEC_OK;
 }
 
+// 3x3 / stride 1 / pad 1 convolution, 64 -> 64 channels (layer1's conv2 at 56x56: 205 MB in, 205 MB out at the bench batch,
+// the one 3x3 layer of ResNet-50 that sits near the HBM ridge rather than deep in MFMA territory).  The same wave-strip
+// scheme as the 1x1 kernels with the nine taps as the K loop: tap (dr, ds) contributes X[pixel + (dr, ds)] * W_tap^T, its B
+// fragments are the shifted pixels' channel vectors straight from global memory / L2 (zero outside the image), its A
+// fragments W_tap from LDS (9 x 64 x 64 bf16 = 83 KB resident).  A strip's nine fragment sets live in registers; each is
+// refilled with the next strip's same tap as soon as its MFMAs have issued (prefetch distance = one whole strip).  With W := flipped, transposed weights it is the layer's data gradient.
+template <bool STATS>
+__global__ __launch_bounds__(kC1Threads) void conv3x3_c64_kernel(const unsigned short* __restrict__ X,
+                                                                 const unsigned short* __restrict__ Wt, int64_t M, int H, int W,
+                                                                 unsigned short* __restrict__ Y, float* __restrict__ part) {
+  constexpr int K = 64, N = 64, R = 9, WLD = K + 8, YLD = 64 + 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  unsigned short* Ws = smem;                                     // [9 taps][64 out][WLD]
+  unsigned short* Ys = Ws + 9 * N * WLD + (threadIdx.x >> 6) * 32 * YLD;
+  float* Ss = (float*)(smem + 9 * N * WLD);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  // weights arrive as [co][3][3][ci] (a channels_last conv weight): LDS wants [tap][co][ci]
+  for (int e = threadIdx.x; e < 9 * N * (K / 8); e += kC1Threads) {
+    const int c8 = e % (K / 8); int t = e / (K / 8);
+    const int co = t % N; const int tap = t / N;
+    *(u32x4_t*)(Ws + (tap * N + co) * WLD + c8 * 8) = *(const u32x4_t*)(Wt + ((int64_t)co * 9 + tap) * K + c8 * 8);
+  }
+  __syncthreads();
+  float st_s[8], st_q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { st_s[j] = 0.0f; st_q[j] = 0.0f; }
+
+  const int nstrips = (int)(M / 32);
+  const int stride = (int)gridDim.x * 4;
+  const int HW = H * W;
+  // XCD-aware order: workgroup ids go round-robin over the 8 XCDs, each with its own L2.  Give every XCD a CONTIGUOUS run of
+  // strips, so that the image rows above and below a strip -- read for the dr = -1 / +1 taps -- are rows its own L2 has
+  // just served to the neighbouring workgroups (otherwise every XCD fetches each input row about three times).
+  const int nx = 8, per = (int)gridDim.x / nx;
+  const int lb = (per > 0 && (int)gridDim.x % nx == 0) ? ((int)blockIdx.x % nx) * per + (int)blockIdx.x / nx : (int)blockIdx.x;
+  int s = lb * 4 + wave;
+  bf16x8_t ring[R][4];
+  // the lane's pixel of a strip, decoded once: (row, column) inside its image and the address of its channel vector
+  struct Pix { int hh, ww; const unsigned short* p; };
+  auto decode = [&](int strip) {
+    Pix q; const int m = strip * 32 + r; const int rem = m % HW;
+    q.hh = rem / W; q.ww = rem - q.hh * W; q.p = X + (int64_t)m * K + h * 8; return q;
+  };
+  // Loads are UNCONDITIONAL (a tap outside the image reads the pixel itself and is zeroed when it is consumed): a load
+  // under a lane-dependent branch makes the compiler wait for every outstanding load (vmcnt(0)) at each use, which
+  // throws away the one-strip prefetch distance and costs ~2 us of memory latency per strip.
+  auto tap_ok = [&](const Pix& q, int tap) {
+    const int dr = tap / 3 - 1, ds = tap % 3 - 1;
+    return (unsigned)(q.hh + dr) < (unsigned)H && (unsigned)(q.ww + ds) < (unsigned)W;
+  };
+  auto load_tap = [&](const Pix& q, int tap, bf16x8_t (&dst)[4]) {
+    const int dr = tap / 3 - 1, ds = tap % 3 - 1;
+    const unsigned short* src = q.p + (tap_ok(q, tap) ? (dr * W + ds) * K : 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) dst[ks] = *(const bf16x8_t*)(src + ks * 16);
+  };
+  // A fragments of one tap (2 n-tiles x 4 k-steps), read a tap ahead of the MFMAs that use them
+  auto load_w = [&](int tap, bf16x8_t (&dst)[8]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) dst[t * 4 + ks] = *(const bf16x8_t*)(Ws + (tap * N + t * 32 + r) * WLD + h * 8 + ks * 16);
+  };
+  Pix qc; qc.hh = 0; qc.ww = 0; qc.p = X + h * 8;
+  if (s < nstrips) qc = decode(s);
+#pragma unroll
+  for (int j = 0; j < R; ++j) load_tap(qc, j, ring[j]);
+  bf16x8_t wf[2][8];
+  load_w(0, wf[0]);
+  for (; s < nstrips; s += stride) {
+    const int sn = s + stride;
+    Pix qn = qc;                                                  // past the end: harmless re-reads of the current pixel
+    if (sn < nstrips) qn = decode(sn);
+    f32x16_t acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[t][q] = 0.0f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      load_w((tap + 1) % 9, wf[(tap + 1) & 1]);                   // next tap's weights (tap 0 of the next strip after tap 8)
+      const bool ok = tap_ok(qc, tap);
+      bf16x8_t xz[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        xz[ks] = ok ? ring[tap][ks] : zero;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)                               // the two accumulator chains alternate
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap & 1][t * 4 + ks], xz[ks], acc[t], 0, 0, 0);
+      load_tap(qn, tap, ring[tap]);                               // the slot just consumed takes the next strip's same tap
+    }
+    qc = qn;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2_t pk;
+        pk.x = (unsigned int)c1_f2bf(acc[t][4 * g + 0]) | ((unsigned int)c1_f2bf(acc[t][4 * g + 1]) << 16);
+        pk.y = (unsigned int)c1_f2bf(acc[t][4 * g + 2]) | ((unsigned int)c1_f2bf(acc[t][4 * g + 3]) << 16);
+        *(u32x2_t*)(Ys + r * YLD + t * 32 + 8 * g + 4 * h) = pk;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int cc = lane & 7, r0 = lane >> 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = r0 + 8 * i;
+      const u32x4_t v = *(const u32x4_t*)(Ys + row * YLD + cc * 8);
+      const unsigned int w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = c1_bf2f((unsigned short)(w4[j >> 1] >> ((j & 1) * 16)));
+        if (STATS) { st_s[j] += f; st_q[j] += f * f; }
+      }
+      __builtin_nontemporal_store(v, (u32x4_t*)(Y + ((int64_t)s * 32 + row) * N + cc * 8));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  if (!STATS) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float a = st_s[j], b = st_q[j];
+    a += __shfl_xor(a, 8, 64); b += __shfl_xor(b, 8, 64);
+    a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+    a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+    st_s[j] = a; st_q[j] = b;
+  }
+  __syncthreads();
+  if (lane < 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { Ss[(wave * 2 + 0) * N + lane * 8 + j] = st_s[j]; Ss[(wave * 2 + 1) * N + lane * 8 + j] = st_q[j]; }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * N; e += kC1Threads) {
+    const int which = e / N, n = e - which * N;
+    part[(int64_t)blockIdx.x * 2 * N + which * N + n] =
+        Ss[(0 * 2 + which) * N + n] + Ss[(1 * 2 + which) * N + n] + Ss[(2 * 2 + which) * N + n] + Ss[(3 * 2 + which) * N + n];
+  }
+}
+
+}  // namespace lec
+
+extern "C" int lec_conv3x3_c64_fwd(const void* x, const void* w, int Nimg, int H, int W, void* y, float* partials,
+                                   int64_t partials_bytes, int* n_partials, lec_stream_t stream) {
+  using namespace lec;
+  LEC_CHECK_ARG(x && w && y, "conv3x3_c64_fwd: null pointer");
+  const int64_t M = (int64_t)Nimg * H * W;
+  LEC_CHECK_ARG(Nimg > 0 && H > 0 && W > 0 && M % 32 == 0, "conv3x3_c64_fwd: N*H*W must be a positive multiple of 32");
+  LEC_CHECK_ARG((partials == nullptr) == (n_partials == nullptr), "conv3x3_c64_fwd: pass partials and n_partials together");
+  LEC_CHECK_ARG(!partials || partials_bytes >= (int64_t)kC1MaxBlocks * 2 * 64 * (int64_t)sizeof(float), "conv3x3_c64_fwd: partials buffer too small");
+  const size_t smem = ((size_t)9 * 64 * (64 + 8) + 4 * 32 * (64 + 8)) * sizeof(unsigned short);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3x3_c64)");
+    attr_set = true;
+  }
+  const int64_t nstrips = M / 32;
+  int64_t nb = (nstrips + 3) / 4;
+  const int nblk = (int)(nb > kC1MaxBlocks ? kC1MaxBlocks : nb);
+  hipStream_t st = (hipStream_t)stream;
+  if (partials) hipLaunchKernelGGL((conv3x3_c64_kernel<true>), dim3(nblk), dim3(kC1Threads), smem, st, (const unsigned short*)x, (const unsigned short*)w, M, H, W, (unsigned short*)y, partials);
+  else hipLaunchKernelGGL((conv3x3_c64_kernel<false>), dim3(nblk), dim3(kC1Threads), smem, st, (const unsigned short*)x, (const unsigned short*)w, M, H, W, (unsigned short*)y, (float*)nullptr);
+  if (n_partials) *n_partials = nblk;
+  LEC_CHECK_LAUNCH("conv3x3_c64_kernel");
+  return LEC_OK;
+}
+
+namespace lec {
 }  // namespace lec
 
 // (Cin, Cout) pairs with a kernel instance; M = N*H*W must be a multiple of 32

@@ -112,6 +112,10 @@ GEMM_1X1 = os.environ.get('LEC_CONV1X1_GEMM', '1') != '0'
 # same kernel on the transposed weights.  tools/bench_conv1x1_fused.py: 64->256 @56x56 169 us against MIOpen's 227 us,
 # and the BatchNorm that follows drops its statistics pass (447 -> 302 us).
 MFMA_1X1 = os.environ.get('LEC_CONV1X1_MFMA', '1') != '0'
+# layer1's 3x3 convolution (64 -> 64 @56x56) on the same wave-strip scheme (lec_conv3x3_c64_fwd): correct and on par with
+# MIOpen stand-alone (254 vs 273 us forward, 253 vs 346 us data gradient) but no gain inside the step (46.5 vs 46.3 ms:
+# its 101 KB of LDS per workgroup keep the second stream's weight-gradient kernels off the CU) -- off by default.
+MFMA_3X3 = os.environ.get('LEC_CONV3X3_MFMA', '0') != '0'
 GEMM_FWD_MIN_CIN = 1024
 GEMM_DGRAD_MIN_CIN = 256
 
@@ -145,7 +149,12 @@ class _OverlapConvFn(torch.autograd.Function):
             w16 = w16.contiguous(memory_format=torch.channels_last)
         ctx.pointwise = GEMM_1X1 and nhwc and _is_pointwise(conv)
         ctx.own = ctx.pointwise and MFMA_1X1 and x.dtype == torch.bfloat16
-        if ctx.own and _ops().conv1x1_supported(conv.in_channels, conv.out_channels, x.shape[0] * x.shape[2] * x.shape[3]):
+        ctx.own3 = (MFMA_3X3 and nhwc and x.dtype == torch.bfloat16 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+                    and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels == 64
+                    and conv.out_channels == 64 and (x.shape[0] * x.shape[2] * x.shape[3]) % 32 == 0)
+        if ctx.own3:                                            # layer1's conv2: liblecone's MFMA kernel, statistics in the epilogue
+            y = _ops().conv3x3_c64(x, w16, want_stats=True)
+        elif ctx.own and _ops().conv1x1_supported(conv.in_channels, conv.out_channels, x.shape[0] * x.shape[2] * x.shape[3]):
             n, _, h, wd = x.shape
             y = _from_rows(_ops().conv1x1_rows(_rows(x), w16.reshape(conv.out_channels, conv.in_channels), want_stats=True), n, h, wd)
         elif ctx.pointwise and conv.in_channels >= GEMM_FWD_MIN_CIN:
@@ -162,7 +171,10 @@ class _OverlapConvFn(torch.autograd.Function):
         gx = None
         if ctx.needs_input_grad[0]:
             nhwc_g = gy.is_contiguous(memory_format=torch.channels_last)
-            if (ctx.own and nhwc_g and _ops().conv1x1_supported(conv.out_channels, conv.in_channels, gy.shape[0] * gy.shape[2] * gy.shape[3])):
+            if ctx.own3 and nhwc_g:                             # dX = conv(dY, W flipped and transposed): the same kernel
+                wt = w16.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
+                gx = _ops().conv3x3_c64(gy, wt)
+            elif (ctx.own and nhwc_g and _ops().conv1x1_supported(conv.out_channels, conv.in_channels, gy.shape[0] * gy.shape[2] * gy.shape[3])):
                 n, _, h, wd = gy.shape                          # dX = dY * W: the same kernel on W^T [Cin, Cout]
                 wt = w16.reshape(conv.out_channels, conv.in_channels).t().contiguous()
                 gx = _from_rows(_ops().conv1x1_rows(_rows(gy), wt), n, h, wd)
