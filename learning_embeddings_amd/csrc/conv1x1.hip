@@ -415,6 +415,8 @@ __global__ __launch_bounds__(kC1Threads) void conv3x3_c64_kernel(const unsigned 
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       load_w((tap + 1) % 9, wf[(tap + 1) & 1]);                   // next tap's weights (tap 0 of the next strip after tap 8)
+      __builtin_amdgcn_sched_barrier(0);                          // keep these LDS reads HERE: the scheduler otherwise sinks each one
+                                                                  // to just before its MFMA and every MFMA pair eats the LDS latency
       const bool ok = tap_ok(qc, tap);
       bf16x8_t xz[4];
 #pragma unroll
