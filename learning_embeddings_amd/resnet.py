@@ -112,10 +112,10 @@ GEMM_1X1 = os.environ.get('LEC_CONV1X1_GEMM', '1') != '0'
 # same kernel on the transposed weights.  tools/bench_conv1x1_fused.py: 64->256 @56x56 169 us against MIOpen's 227 us,
 # and the BatchNorm that follows drops its statistics pass (447 -> 302 us).
 MFMA_1X1 = os.environ.get('LEC_CONV1X1_MFMA', '1') != '0'
-# layer1's 3x3 convolution (64 -> 64 @56x56) on the same wave-strip scheme (lec_conv3x3_c64_fwd): correct and on par with
-# MIOpen stand-alone (254 vs 273 us forward, 253 vs 346 us data gradient) but no gain inside the step (46.5 vs 46.3 ms:
-# its 101 KB of LDS per workgroup keep the second stream's weight-gradient kernels off the CU) -- off by default.
-MFMA_3X3 = os.environ.get('LEC_CONV3X3_MFMA', '0') != '0'
+# layer1's 3x3 convolution (64 -> 64 @56x56) runs liblecone's LDS-halo MFMA kernel (lec_conv3x3_c64_fwd: 4x8-pixel tiles, the
+# 6x10 input halo loaded once into LDS, nine taps as the K loop, BatchNorm statistics in the epilogue; the data gradient is
+# the same kernel on the flipped, transposed weights): 185 us forward / 168 us data gradient against MIOpen's 298 / 350 us.
+MFMA_3X3 = os.environ.get('LEC_CONV3X3_MFMA', '1') != '0'
 GEMM_FWD_MIN_CIN = 1024
 GEMM_DGRAD_MIN_CIN = 256
 
