@@ -227,6 +227,9 @@ int lec_conv1x1_fwd(const void* x, const void* w, int64_t M, int Cin, int Cout, 
  * The layer's data gradient is the same call on dy with w'[ci][r][s][co] = w[co][2-r][2-s][ci]. */
 int lec_conv3x3_c64_fwd(const void* x, const void* w, int N, int H, int W, void* y, float* partials,
                         int64_t partials_bytes, int* n_partials, lec_stream_t stream);
+/* The same for 128 -> 128 channels (layer2's conv2 at 28x28): weights streamed through LDS one tap at a time, any H, W. */
+int lec_conv3x3_c128_fwd(const void* x, const void* w, int N, int H, int W, void* y, float* partials,
+                         int64_t partials_bytes, int* n_partials, lec_stream_t stream);
 /* lec_bn_fwd in training mode with the statistics pass already done: the first n_partials rows of the workspace hold
  * per-channel [sum | sum of squares] partials (written by lec_conv1x1_fwd into the SAME workspace). */
 int lec_bn_fwd_prestat(const void* x, const void* residual, int64_t M, int C, const float* gamma, const float* beta,

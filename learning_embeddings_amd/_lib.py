@@ -68,6 +68,7 @@ def _load():
         'lec_conv1x1_supported': (i32, [i32, i32, i64]),
         'lec_conv1x1_fwd': (i32, [p, p, i64, i32, i32, p, p, i64, p, p]),
         'lec_conv3x3_c64_fwd': (i32, [p, p, i32, i32, i32, p, p, i64, p, p]),
+        'lec_conv3x3_c128_fwd': (i32, [p, p, i32, i32, i32, p, p, i64, p, p]),
         'lec_bn_fwd_prestat': (i32, [p, p, i64, i32, p, p, f32, f32, p, p, i32, p, p, p, i32, p, p, i64, p]),
         'lec_maxpool3x3s2_fwd': (i32, [p, i32, i32, i32, i32, p, p, p]),
         'lec_maxpool3x3s2_bwd': (i32, [p, p, i32, i32, i32, i32, p, p]),

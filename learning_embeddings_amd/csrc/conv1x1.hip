@@ -686,6 +686,206 @@ extern "C" int lec_conv3x3_c64_fwd(const void* x, const void* w, int Nimg, int H
 }
 
 namespace lec {
+// 3x3 / stride 1 / pad 1, 128 -> 128 (layer2's conv2 at 28x28; ResNet-18's layer2).  295 KB of weights do not fit LDS, so
+// they stream through it one tap at a time: the workgroup's 4 waves walk the nine taps in lockstep, each tap's 128 x 128
+// slice (32 KB) double-buffered in LDS -- fetched from L2 into registers two taps ahead, written one tap ahead, one
+// workgroup barrier per tap -- while every wave keeps its own 4 x 8-pixel tile's halo (60 pixels x 128 channels) in LDS
+// and all four 32-channel accumulator tiles in registers, so that a B fragment read serves four MFMAs.
+// Tiles may hang over the right / bottom edge (28 = 3.5 x 8): such pixels read zeros, store nothing and stay out of the
+// statistics.
+template <bool STATS>
+__global__ __launch_bounds__(kC1Threads) void conv3x3_c128_kernel(const unsigned short* __restrict__ X,
+                                                                  const unsigned short* __restrict__ Wt, int Nimg, int H, int W,
+                                                                  unsigned short* __restrict__ Y, float* __restrict__ part) {
+  constexpr int C = 128, LD = C + 8, NT = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  unsigned short* Wb = smem;                                                   // [2][128][LD]
+  unsigned short* Hs = Wb + 2 * C * LD + (threadIdx.x >> 6) * kHaloPix * LD;   // per wave [60][LD]; reused as the [32][LD] output tile
+  float* Ss = (float*)(Wb + 2 * C * LD);                                       // end of the launch only
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int py = r >> 3, px = r & 7;
+  float st_s[8], st_q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { st_s[j] = 0.0f; st_q[j] = 0.0f; }
+
+  const int tx_n = (W + 7) / 8, ty_n = (H + 3) / 4;
+  const int ntiles = Nimg * ty_n * tx_n;
+  const int nrounds = (ntiles + 3) / 4;                                         // a round = one tile per wave
+  const int nx = 8, per = (int)gridDim.x / nx;
+  const int lb = (per > 0 && (int)gridDim.x % nx == 0) ? ((int)blockIdx.x % nx) * per + (int)blockIdx.x / nx : (int)blockIdx.x;
+  struct Tile { int n, y0, x0; };
+  auto decode = [&](int tt) { Tile q; q.x0 = (tt % tx_n) * 8; const int u = tt / tx_n; q.y0 = (u % ty_n) * 4; q.n = u / ty_n; return q; };
+  // halo: 60 pixels x 16 chunks of 16 B = 960 elements = 15 per lane
+  u32x4_t hreg[15];
+  unsigned int hmask = 0;
+  auto load_halo = [&](const Tile& q, bool live) {
+    hmask = 0;
+#pragma unroll
+    for (int i = 0; i < 15; ++i) {
+      const int e = lane + 64 * i, pix = e >> 4, ch = e & 15;
+      const int hy = pix / 10, hx = pix - hy * 10;
+      const int yy = q.y0 + hy - 1, xx = q.x0 + hx - 1;
+      const bool ok = live && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      const int64_t row = ok ? ((int64_t)q.n * H + yy) * W + xx : 0;
+      hreg[i] = *(const u32x4_t*)(X + row * C + ch * 8);
+      hmask |= (ok ? 1u : 0u) << i;
+    }
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int i = 0; i < 15; ++i) {
+      const int e = lane + 64 * i, pix = e >> 4, ch = e & 15;
+      u32x4_t v = hreg[i];
+      if (!((hmask >> i) & 1u)) { v.x = 0; v.y = 0; v.z = 0; v.w = 0; }
+      *(u32x4_t*)(Hs + pix * LD + ch * 8) = v;
+    }
+  };
+  // one tap's weights: 128 rows x 16 chunks = 2048 elements of 16 B = 8 per thread
+  u32x4_t wreg[8];
+  auto load_wtap = [&](int tap) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = threadIdx.x + kC1Threads * i, co = e >> 4, c8 = e & 15;
+      wreg[i] = *(const u32x4_t*)(Wt + ((int64_t)co * 9 + tap) * C + c8 * 8);
+    }
+  };
+  auto store_wtap = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = threadIdx.x + kC1Threads * i, co = e >> 4, c8 = e & 15;
+      *(u32x4_t*)(Wb + (buf * C + co) * LD + c8 * 8) = wreg[i];
+    }
+  };
+
+  int rd = lb;                                                                  // this workgroup's round
+  const int rstride = (int)gridDim.x;
+  Tile qc; qc.n = 0; qc.y0 = 0; qc.x0 = 0;
+  bool live = rd < nrounds && rd * 4 + wave < ntiles;
+  if (live) qc = decode(rd * 4 + wave);
+  load_halo(qc, live);
+  load_wtap(0); store_wtap(0);                                                  // tap 0 -> buffer 0
+  load_wtap(1);                                                                 // tap 1 in registers
+  int cur = 0;                                                                  // buffer holding the tap being consumed (9 taps: the parity flips every round)
+  for (; rd < nrounds; rd += rstride) {
+    store_halo();
+    const int rn = rd + rstride;
+    Tile qn = qc; bool live_n = rn < nrounds && rn * 4 + wave < ntiles;
+    if (live_n) qn = decode(rn * 4 + wave);
+    load_halo(qn, live_n);
+    f32x16_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[t][q] = 0.0f;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {      // not unrolled: nine unrolled taps push the kernel past 512 VGPRs
+      __syncthreads();                       // every wave is past tap - 1: buffer (tap+1)&1 is free, buffer tap&1 is complete
+      store_wtap(cur ^ 1);                   // weights of tap + 1 (tap 0 of the next round after tap 8)
+      load_wtap(tap + 2 >= 9 ? tap + 2 - 9 : tap + 2);
+      const unsigned short* wbase = Wb + (cur * C + r) * LD + h * 8;
+      const int tr = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0);
+      const unsigned short* hp = Hs + ((py + tr) * 10 + px + tap - 3 * tr) * LD + h * 8;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const bf16x8_t b = *(const bf16x8_t*)(hp + ks * 16);
+        bf16x8_t a[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[t] = *(const bf16x8_t*)(wbase + t * 32 * LD + ks * 16);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], b, acc[t], 0, 0, 0);
+      }
+      cur ^= 1;
+    }
+    // ---- epilogue: D'[n][m] -> the wave's LDS tile (over its halo, which the taps are done with) -> rows out
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2_t pk;
+        pk.x = (unsigned int)c1_f2bf(acc[t][4 * g + 0]) | ((unsigned int)c1_f2bf(acc[t][4 * g + 1]) << 16);
+        pk.y = (unsigned int)c1_f2bf(acc[t][4 * g + 2]) | ((unsigned int)c1_f2bf(acc[t][4 * g + 3]) << 16);
+        *(u32x2_t*)(Hs + r * LD + t * 32 + 8 * g + 4 * h) = pk;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int cc = lane & 15, r0 = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = r0 + 4 * i;                                               // tile pixel (row >> 3, row & 7)
+      const int oy = qc.y0 + (row >> 3), ox = qc.x0 + (row & 7);
+      const bool ok = live && oy < H && ox < W;
+      const u32x4_t v = *(const u32x4_t*)(Hs + row * LD + cc * 8);
+      if (ok) {
+        const unsigned int w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = c1_bf2f((unsigned short)(w4[j >> 1] >> ((j & 1) * 16)));
+          if (STATS) { st_s[j] += f; st_q[j] += f * f; }
+        }
+        __builtin_nontemporal_store(v, (u32x4_t*)(Y + (((int64_t)qc.n * H + oy) * W + ox) * C + cc * 8));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    qc = qn; live = live_n;
+  }
+  if (!STATS) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float a = st_s[j], b = st_q[j];
+    a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+    a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+    st_s[j] = a; st_q[j] = b;
+  }
+  __syncthreads();
+  if (lane < 16) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { Ss[(wave * 2 + 0) * C + lane * 8 + j] = st_s[j]; Ss[(wave * 2 + 1) * C + lane * 8 + j] = st_q[j]; }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * C; e += kC1Threads) {
+    const int which = e / C, n = e - which * C;
+    part[(int64_t)blockIdx.x * 2 * C + which * C + n] =
+        Ss[(0 * 2 + which) * C + n] + Ss[(1 * 2 + which) * C + n] + Ss[(2 * 2 + which) * C + n] + Ss[(3 * 2 + which) * C + n];
+  }
+}
+
+}  // namespace lec
+
+extern "C" int lec_conv3x3_c128_fwd(const void* x, const void* w, int Nimg, int H, int W, void* y, float* partials,
+                                    int64_t partials_bytes, int* n_partials, lec_stream_t stream) {
+  using namespace lec;
+  LEC_CHECK_ARG(x && w && y, "conv3x3_c128_fwd: null pointer");
+  LEC_CHECK_ARG(Nimg > 0 && H > 0 && W > 0, "conv3x3_c128_fwd: bad sizes");
+  LEC_CHECK_ARG((partials == nullptr) == (n_partials == nullptr), "conv3x3_c128_fwd: pass partials and n_partials together");
+  LEC_CHECK_ARG(!partials || partials_bytes >= (int64_t)kC1MaxBlocks * 2 * 128 * (int64_t)sizeof(float), "conv3x3_c128_fwd: partials buffer too small");
+  const size_t smem = ((size_t)2 * 128 * 136 + 4 * kHaloPix * 136) * sizeof(unsigned short);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_c128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3x3_c128)");
+    attr_set = true;
+  }
+  const int64_t ntiles = (int64_t)Nimg * ((H + 3) / 4) * ((W + 7) / 8);
+  int64_t nb = (ntiles + 3) / 4;
+  const int nblk = (int)(nb > kC1MaxBlocks ? kC1MaxBlocks : nb);
+  hipStream_t st = (hipStream_t)stream;
+  if (partials) hipLaunchKernelGGL((conv3x3_c128_kernel<true>), dim3(nblk), dim3(kC1Threads), smem, st, (const unsigned short*)x, (const unsigned short*)w, Nimg, H, W, (unsigned short*)y, partials);
+  else hipLaunchKernelGGL((conv3x3_c128_kernel<false>), dim3(nblk), dim3(kC1Threads), smem, st, (const unsigned short*)x, (const unsigned short*)w, Nimg, H, W, (unsigned short*)y, (float*)nullptr);
+  if (n_partials) *n_partials = nblk;
+  LEC_CHECK_LAUNCH("conv3x3_c128_kernel");
+  return LEC_OK;
+}
+
+namespace lec {
 }  // namespace lec
 
 // (Cin, Cout) pairs with a kernel instance; M = N*H*W must be a multiple of 32

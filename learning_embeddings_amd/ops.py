@@ -388,14 +388,15 @@ def conv3x3_c64(x, w_clast, want_stats=False):
     """3x3 / stride 1 / pad 1, 64 -> 64 channels on NHWC bf16 through lec_conv3x3_c64_fwd.  x: [N, 64, H, W] channels_last,
     w_clast: [64, 64, 3, 3] channels_last (memory [co][r][s][ci]).  Returns y like x."""
     n, c, h, w = x.shape
+    fn = {64: lib.lec_conv3x3_c64_fwd, 128: lib.lec_conv3x3_c128_fwd}[c]          # 128: weights streamed tap by tap
     y = torch.empty_like(x)
     if want_stats:
         ws = _bn_workspace(x.device)
         k = C.c_int(0)
-        check(lib.lec_conv3x3_c64_fwd(dptr(x), dptr(w_clast), n, h, w, dptr(y), dptr(ws), ws.numel(), C.byref(k), stream_ptr()))
+        check(fn(dptr(x), dptr(w_clast), n, h, w, dptr(y), dptr(ws), ws.numel(), C.byref(k), stream_ptr()))
         _BN_WS_OWNER[0], _BN_WS_OWNER[1] = y.data_ptr(), k.value
     else:
-        check(lib.lec_conv3x3_c64_fwd(dptr(x), dptr(w_clast), n, h, w, dptr(y), None, 0, None, stream_ptr()))
+        check(fn(dptr(x), dptr(w_clast), n, h, w, dptr(y), None, 0, None, stream_ptr()))
     return y
 
 

@@ -116,6 +116,10 @@ MFMA_1X1 = os.environ.get('LEC_CONV1X1_MFMA', '1') != '0'
 # 6x10 input halo loaded once into LDS, nine taps as the K loop, BatchNorm statistics in the epilogue; the data gradient is
 # the same kernel on the flipped, transposed weights): 185 us forward / 168 us data gradient against MIOpen's 298 / 350 us.
 MFMA_3X3 = os.environ.get('LEC_CONV3X3_MFMA', '1') != '0'
+# the 128 -> 128 @28x28 instance (weights streamed through LDS tap by tap) trails MIOpen forward (214 vs 170 us) and only
+# leads it in the data gradient (207 vs 245 us); no measurable gain inside the step, so it stays opt-in:
+# '0' (default) nowhere, 'dgrad' data gradient only, '1' everywhere
+MFMA_3X3_C128 = os.environ.get('LEC_CONV3X3_C128', '0')
 GEMM_FWD_MIN_CIN = 1024
 GEMM_DGRAD_MIN_CIN = 256
 
@@ -150,9 +154,12 @@ class _OverlapConvFn(torch.autograd.Function):
         ctx.pointwise = GEMM_1X1 and nhwc and _is_pointwise(conv)
         ctx.own = ctx.pointwise and MFMA_1X1 and x.dtype == torch.bfloat16
         ctx.own3 = (MFMA_3X3 and nhwc and x.dtype == torch.bfloat16 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
-                    and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels == 64
-                    and conv.out_channels == 64 and (x.shape[0] * x.shape[2] * x.shape[3]) % 32 == 0)
-        if ctx.own3:                                            # layer1's conv2: liblecone's MFMA kernel, statistics in the epilogue
+                    and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+                    and conv.in_channels == conv.out_channels and conv.in_channels in (64, 128)
+                    and (x.shape[0] * x.shape[2] * x.shape[3]) % 32 == 0)
+        if ctx.own3 and conv.in_channels == 128 and MFMA_3X3_C128 == '0':
+            ctx.own3 = False
+        if ctx.own3 and (conv.in_channels == 64 or MFMA_3X3_C128 == '1'):                                            # layer1's conv2: liblecone's MFMA kernel, statistics in the epilogue
             y = _ops().conv3x3_c64(x, w16, want_stats=True)
         elif ctx.own and _ops().conv1x1_supported(conv.in_channels, conv.out_channels, x.shape[0] * x.shape[2] * x.shape[3]):
             n, _, h, wd = x.shape

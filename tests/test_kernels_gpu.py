@@ -520,23 +520,24 @@ def test_conv1x1_statistics_feed_batchnorm():
     assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-6) and torch.allclose(outs[0][2], outs[1][2], rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize('N,H,W', [(2, 8, 8), (3, 16, 16), (1, 56, 56), (4, 12, 20)])
-def test_conv3x3_c64_mfma_vs_torch(N, H, W):
+@pytest.mark.parametrize('N,H,W,Cc', [(2, 8, 8, 64), (3, 16, 16, 64), (1, 56, 56, 64), (4, 12, 20, 64),
+                                      (2, 8, 8, 128), (3, 28, 28, 128), (5, 7, 13, 128), (9, 4, 8, 128)])
+def test_conv3x3_mfma_vs_torch(N, H, W, Cc):
     """lec_conv3x3_c64_fwd (3x3 / stride 1 / pad 1, 64 -> 64, NHWC bf16): forward, statistics partials and the data gradient
     (same kernel on the flipped, transposed weights) against torch in fp32; strips cross image rows and images."""
     g = torch.Generator(device='cpu').manual_seed(N * H)
-    x = (torch.randn(N, 64, H, W, generator=g) * 0.7).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x = (torch.randn(N, Cc, H, W, generator=g) * 0.7).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cc, Cc, 3, 3, generator=g) * 0.05).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     y = ops.conv3x3_c64(x, w, want_stats=True)
     n = ops._BN_WS_OWNER[1]; assert ops._BN_WS_OWNER[0] == y.data_ptr(); ops._BN_WS_OWNER[0] = 0
     ref = torch.nn.functional.conv2d(x.float(), w.float(), padding=1)
     assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
     assert (y.float() - ref).abs().max().item() <= 6e-3 * ref.abs().max().item()
-    part = ops._bn_workspace(x.device)[:n * 2 * 64 * 4].view(torch.float32).view(n, 2, 64).double().sum(0)
+    part = ops._bn_workspace(x.device)[:n * 2 * Cc * 4].view(torch.float32).view(n, 2, Cc).double().sum(0)
     yd = y.float().double()
     assert ((part[0] - yd.sum((0, 2, 3))).abs().max() / (yd.abs().sum((0, 2, 3)).max())).item() < 1e-5
     assert ((part[1] - (yd * yd).sum((0, 2, 3))).abs().max() / (yd * yd).sum((0, 2, 3)).max()).item() < 1e-5
-    dy = torch.randn(N, 64, H, W, generator=g).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(N, Cc, H, W, generator=g).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
     gx = ops.conv3x3_c64(dy, wt)
     xr = x.float().requires_grad_(True)

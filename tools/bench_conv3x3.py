@@ -18,13 +18,18 @@ def timed(fn, reps=20):
 
 
 def main():
-    B, H = int(os.environ.get('LEC_B', 512)), 56
+    for Cc, H in ((64, 56), (128, 28)):
+        run(Cc, H)
+
+
+def run(Cc, H):
+    B = int(os.environ.get('LEC_B', 512))
     g = torch.Generator(device='cpu').manual_seed(0)
-    x = (torch.randn(B, 64, H, H, generator=g) * 0.7).to('cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to('cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x = (torch.randn(B, Cc, H, H, generator=g) * 0.7).to('cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cc, Cc, 3, 3, generator=g) * 0.05).to('cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     y = ops.conv3x3_c64(x, w, want_stats=True)
     n = ops._BN_WS_OWNER[1]; ops._BN_WS_OWNER[0] = 0
-    part = ops._bn_workspace(x.device)[:n * 2 * 64 * 4].view(torch.float32).view(n, 2, 64).double().sum(0)
+    part = ops._bn_workspace(x.device)[:n * 2 * Cc * 4].view(torch.float32).view(n, 2, Cc).double().sum(0)
     ref = torch.nn.functional.conv2d(x[:8].float(), w.float(), padding=1)
     err = (y[:8].float() - ref).abs().max().item() / ref.abs().max().item()
     yd = y.float().double()
@@ -39,9 +44,9 @@ def main():
     gref = cb(dy[:4].float(), x[:4].float(), w.float(), [0], [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
     derr = (gx[:4].float() - gref).abs().max().item() / gref.abs().max().item()
     t_own_d = timed(lambda: ops.conv3x3_c64(dy, wt))
-    print(json.dumps({'fwd_rel_err': err, 'stats_rel_err': s_err, 'dgrad_rel_err': derr, 'own_fwd_us': round(t_own, 1), 'miopen_fwd_us': round(t_mi, 1),
+    print(json.dumps({'C': Cc, 'H': H, 'fwd_rel_err': err, 'stats_rel_err': s_err, 'dgrad_rel_err': derr, 'own_fwd_us': round(t_own, 1), 'miopen_fwd_us': round(t_mi, 1),
                       'own_dgrad_us': round(t_own_d, 1), 'miopen_dgrad_us': round(t_mi_d, 1),
-                      'own_fwd_TFLOPs': round(2 * B * H * H * 64 * 64 * 9 / t_own / 1e6, 1), 'own_fwd_GBps': round(B * H * H * 128 * 2 / t_own / 1e3, 1)}))
+                      'own_fwd_TFLOPs': round(2 * B * H * H * Cc * Cc * 9 / t_own / 1e6, 1), 'own_fwd_GBps': round(B * H * H * Cc * 2 * 2 / t_own / 1e3, 1)}))
 
 
 if __name__ == '__main__':
