@@ -83,6 +83,13 @@ def main():
     ap.add_argument('--cudnn-benchmark', action='store_true', help='let MIOpen benchmark every solver per conv shape (slow start)')
     args = ap.parse_args()
 
+    # stdout carries ONE line, the JSON result.  Everything else this process or its libraries write to file descriptor 1
+    # (the reference-style banners of the host mirror, RCCL's version banner -- printed through C stdio, which would
+    # otherwise land AFTER the JSON line when stdout is a pipe) goes to stderr until the result is ready.
+    sys.stdout.flush()
+    saved_stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     t_start = time.time()
     def stamp(what):
         if int(os.environ.get('RANK', 0)) == 0:
@@ -260,11 +267,20 @@ def main():
                                   'avg_launch_us': round(rb['us_fwd_bwd'], 1)}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(eng)
-        print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)                           # C stdio buffers (RCCL / MIOpen banners) out through stderr
+    except Exception:
+        pass
+    os.dup2(saved_stdout_fd, 1)
+    os.close(saved_stdout_fd)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

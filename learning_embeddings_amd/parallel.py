@@ -129,7 +129,9 @@ def env_rank():
 def init_process_group(backend=None):
     """Idempotent.  Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torchrun contract)."""
     rank, local_rank, world = env_rank()
-    if world > 1 and not dist.is_initialized():
+    # LEC_FORCE_DIST=1: bring the process group (and the gradient reducer) up even for ONE rank -- exercises the RCCL
+    # all-reduce path, its streams and its interplay with the hipGraph replay on a single-GPU box
+    if (world > 1 or os.environ.get('LEC_FORCE_DIST')) and not dist.is_initialized():
         if backend is None:
             # LEC_DIST_BACKEND=gloo lets several ranks share ONE GPU (tests on a 1-GPU box): gloo reduces CUDA tensors
             backend = os.environ.get('LEC_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
@@ -159,7 +161,7 @@ class GradientReducer:
     def __init__(self, arena, bucket_mb=32.0, extra=()):
         self.arena = arena
         self.extra = list(extra)
-        self.enabled = world_size() > 1
+        self.enabled = world_size() > 1 or (dist.is_initialized() and bool(os.environ.get('LEC_FORCE_DIST')))
         self.live = True             # False: hooks are muted (gradients produced by a hipGraph replay; see reduce_now)
         self.handles = []
         self.buckets = []            # (start, end, [param indices])
