@@ -234,14 +234,15 @@ class StepEngine:
         """Capture `_core` into a hipGraph (after eager steps have sized every workspace and MIOpen has settled on its
         solvers).  Under capture the gradient reducer's per-parameter hooks are muted: the all-reduce runs after the
         replay.  On any capture error the engine stays in eager launch mode and says so."""
+        saved_timer = ops.BN_TIMER
         try:
             torch.cuda.synchronize()
             self.reducer.live = False
-            ops.BN_TIMER, saved_timer = None, ops.BN_TIMER
+            ops.BN_TIMER = None
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: RCCL's watchdog thread polls events while we capture; only THIS thread's calls may fail the capture
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
                 out = self._core(None)
-            ops.BN_TIMER = saved_timer
             torch.cuda.synchronize()
             self.hip_graph, self.graph_out = g, out
         except Exception as e:                                     # noqa: BLE001  (launch mode only; the kernels are the same)
@@ -251,6 +252,8 @@ class StepEngine:
             import sys
             print('[StepEngine] hipGraph capture failed, staying in eager launch mode: %s' % self.graph_error, file=sys.stderr)
             torch.cuda.synchronize()
+        finally:
+            ops.BN_TIMER = saved_timer
 
     def set_launch_mode(self, graph):
         """Switch between replaying the captured graph and eager launches (bench.py times per-kernel phases with HIP
