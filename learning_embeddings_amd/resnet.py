@@ -108,7 +108,7 @@ class WgradOverlap:
 # gradient (a transposed-A GEMM with K = N*H*W is 2-30x slower in hipBLASLt).
 GEMM_1X1 = os.environ.get('LEC_CONV1X1_GEMM', '1') != '0'
 # ... and the wide HBM-bound 1x1 layers (Cin 64 / 128 / 256 at 56x56 and 28x28) run liblecone's own MFMA kernel
-# (csrc/conv1x1.hip): forward with the BatchNorm statistics of the output in its epilogue, and the data gradient as the
+# (csrc/conv_mfma.hip): forward with the BatchNorm statistics of the output in its epilogue, and the data gradient as the
 # same kernel on the transposed weights.  tools/bench_conv1x1_fused.py: 64->256 @56x56 169 us against MIOpen's 227 us,
 # and the BatchNorm that follows drops its statistics pass (447 -> 302 us).
 MFMA_1X1 = os.environ.get('LEC_CONV1X1_MFMA', '1') != '0'
