@@ -520,7 +520,7 @@ def test_conv1x1_statistics_feed_batchnorm():
     assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-6) and torch.allclose(outs[0][2], outs[1][2], rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize('N,H,W,Cc', [(2, 8, 8, 64), (3, 16, 16, 64), (1, 56, 56, 64), (4, 12, 20, 64),
+@pytest.mark.parametrize('N,H,W,Cc', [(2, 8, 8, 64), (3, 16, 16, 64), (1, 56, 56, 64), (4, 12, 20, 64), (4, 12, 16, 64),
                                       (2, 8, 8, 128), (3, 28, 28, 128), (5, 7, 13, 128), (9, 4, 8, 128)])
 def test_conv3x3_mfma_vs_torch(N, H, W, Cc):
     """lec_conv3x3_c64_fwd (3x3 / stride 1 / pad 1, 64 -> 64, NHWC bf16): forward, statistics partials and the data gradient
