@@ -489,20 +489,23 @@ __global__ __launch_bounds__(kC1Threads) void conv3x3_c64_kernel(const unsigned 
 // the tile's 6 x 10 input halo ONCE -- 60 pixel lines as coalesced 16-byte-per-lane loads, 8 lanes per line, prefetched a
 // tile ahead into registers -- into a per-wave LDS image (zeros outside the image), and the nine taps read their B
 // fragments from it with ds_read_b128: 60 L1 line fetches per tile instead of the 1 152 of the strip kernel above.
+// A workgroup is EIGHT waves sharing the 83 KB of weights (two waves per SIMD: one wave's halo traffic and epilogue run
+// under the other's MFMAs; 182 -> 156 us against four waves; sharing each weight fragment between two sub-tiles of an
+// 8 x 8 tile instead, which needs the LDS of the second wave set, gave 169 us).
 constexpr int kHaloPix = 60, kHaloLd = 64 + 8;                   // bf16 elements per halo pixel (16-byte pad)
 template <bool STATS>
-__global__ __launch_bounds__(kC1Threads) void conv3x3_c64_halo_kernel(const unsigned short* __restrict__ X,
+__global__ __launch_bounds__(512) void conv3x3_c64_halo_kernel(const unsigned short* __restrict__ X,
                                                                       const unsigned short* __restrict__ Wt, int Nimg, int H, int W,
                                                                       unsigned short* __restrict__ Y, float* __restrict__ part) {
   constexpr int K = 64, N = 64, WLD = K + 8, YLD = 64 + 8;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   unsigned short* Ws = smem;                                                   // [9][64][WLD]
   unsigned short* Hs = Ws + 9 * N * WLD + (threadIdx.x >> 6) * kHaloPix * kHaloLd;   // per wave [60][kHaloLd]
-  unsigned short* Ys = Ws + 9 * N * WLD + 4 * kHaloPix * kHaloLd + (threadIdx.x >> 6) * 32 * YLD;
+  unsigned short* Ys = Hs;                                                     // output tile over the (consumed) halo image
   float* Ss = (float*)(Ws + 9 * N * WLD);                                      // end of the launch only
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  for (int e = threadIdx.x; e < 9 * N * (K / 8); e += kC1Threads) {
+  for (int e = threadIdx.x; e < 9 * N * (K / 8); e += 512) {
     const int c8 = e % (K / 8); int t = e / (K / 8);
     const int co = t % N; const int tap = t / N;
     *(u32x4_t*)(Ws + (tap * N + co) * WLD + c8 * 8) = *(const u32x4_t*)(Wt + ((int64_t)co * 9 + tap) * K + c8 * 8);
@@ -514,10 +517,10 @@ __global__ __launch_bounds__(kC1Threads) void conv3x3_c64_halo_kernel(const unsi
 
   const int tx_n = W / 8, ty_n = H / 4;
   const int ntiles = Nimg * ty_n * tx_n;
-  const int stride = (int)gridDim.x * 4;
+  const int stride = (int)gridDim.x * 8;
   const int nx = 8, per = (int)gridDim.x / nx;                                 // XCD-contiguous tile ranges (see above)
   const int lb = (per > 0 && (int)gridDim.x % nx == 0) ? ((int)blockIdx.x % nx) * per + (int)blockIdx.x / nx : (int)blockIdx.x;
-  int t = lb * 4 + wave;
+  int t = lb * 8 + wave;
   // halo element e = lane + 64 i (i < 8): pixel e >> 3 (0..59, row-major 6 x 10), 16-byte chunk e & 7
   struct Tile { int n, y0, x0; };
   auto decode = [&](int tt) { Tile q; q.x0 = (tt % tx_n) * 8; const int u = tt / tx_n; q.y0 = (u % ty_n) * 4; q.n = u / ty_n; return q; };
@@ -634,181 +637,15 @@ __global__ __launch_bounds__(kC1Threads) void conv3x3_c64_halo_kernel(const unsi
     for (int j = 0; j < 8; ++j) { Ss[(wave * 2 + 0) * N + lane * 8 + j] = st_s[j]; Ss[(wave * 2 + 1) * N + lane * 8 + j] = st_q[j]; }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < 2 * N; e += kC1Threads) {
+  for (int e = threadIdx.x; e < 2 * N; e += 512) {
     const int which = e / N, n = e - which * N;
-    part[(int64_t)blockIdx.x * 2 * N + which * N + n] =
-        Ss[(0 * 2 + which) * N + n] + Ss[(1 * 2 + which) * N + n] + Ss[(2 * 2 + which) * N + n] + Ss[(3 * 2 + which) * N + n];
+    float a = 0.0f;
+#pragma unroll
+    for (int wv = 0; wv < 8; ++wv) a += Ss[(wv * 2 + which) * N + n];
+    part[(int64_t)blockIdx.x * 2 * N + which * N + n] = a;
   }
 }
 
-
-// The same with 8 x 8-pixel tiles (H % 8 == 0, W % 8 == 0: ResNet's 56 x 56): two 4 x 8 sub-tiles share every weight fragment,
-// which halves the LDS traffic of the A operand -- the limiter of the form above (one 1-KB fragment read per MFMA).
-// -- original comment of the 4 x 8 form: A wave owns 4 x 8-pixel output tiles.  It loads
-// the tile's 6 x 10 input halo ONCE -- 60 pixel lines as coalesced 16-byte-per-lane loads, 8 lanes per line, prefetched a
-// tile ahead into registers -- into a per-wave LDS image (zeros outside the image), and the nine taps read their B
-// fragments from it with ds_read_b128: 60 L1 line fetches per tile instead of the 1 152 of the strip kernel above.
-constexpr int kHalo2Pix = 100;
-template <bool STATS>
-__global__ __launch_bounds__(kC1Threads) void conv3x3_c64_halo2_kernel(const unsigned short* __restrict__ X,
-                                                                      const unsigned short* __restrict__ Wt, int Nimg, int H, int W,
-                                                                      unsigned short* __restrict__ Y, float* __restrict__ part) {
-  constexpr int K = 64, N = 64, WLD = K + 8, YLD = 64 + 8;
-  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-  unsigned short* Ws = smem;                                                   // [9][64][WLD]
-  unsigned short* Hs = Ws + 9 * N * WLD + (threadIdx.x >> 6) * kHalo2Pix * kHaloLd;   // per wave [60][kHaloLd]
-  unsigned short* Ys = Hs;                                                     // the output tile reuses the halo image (wave-private)
-  float* Ss = (float*)(Ws + 9 * N * WLD);                                      // end of the launch only
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  for (int e = threadIdx.x; e < 9 * N * (K / 8); e += kC1Threads) {
-    const int c8 = e % (K / 8); int t = e / (K / 8);
-    const int co = t % N; const int tap = t / N;
-    *(u32x4_t*)(Ws + (tap * N + co) * WLD + c8 * 8) = *(const u32x4_t*)(Wt + ((int64_t)co * 9 + tap) * K + c8 * 8);
-  }
-  __syncthreads();
-  float st_s[8], st_q[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { st_s[j] = 0.0f; st_q[j] = 0.0f; }
-
-  const int tx_n = W / 8, ty_n = H / 8;
-  const int ntiles = Nimg * ty_n * tx_n;
-  const int stride = (int)gridDim.x * 4;
-  const int nx = 8, per = (int)gridDim.x / nx;                                 // XCD-contiguous tile ranges (see above)
-  const int lb = (per > 0 && (int)gridDim.x % nx == 0) ? ((int)blockIdx.x % nx) * per + (int)blockIdx.x / nx : (int)blockIdx.x;
-  int t = lb * 4 + wave;
-  // halo element e = lane + 64 i (i < 13): pixel e >> 3 (0..99, row-major 10 x 10), 16-byte chunk e & 7
-  struct Tile { int n, y0, x0; };
-  auto decode = [&](int tt) { Tile q; q.x0 = (tt % tx_n) * 8; const int u = tt / tx_n; q.y0 = (u % ty_n) * 8; q.n = u / ty_n; return q; };
-  u32x4_t hreg[13];
-  unsigned int hmask = 0;                                                       // bit i: element i of this lane lies inside the image
-  auto load_halo = [&](const Tile& q) {
-    hmask = 0;
-#pragma unroll
-    for (int i = 0; i < 13; ++i) {
-      const int e = lane + 64 * i, pix = e >> 3, ch = e & 7;
-      const int hy = pix / 10, hx = pix - hy * 10;
-      const int yy = q.y0 + hy - 1, xx = q.x0 + hx - 1;
-      const bool ok = pix < kHalo2Pix && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-      const int64_t row = ok ? ((int64_t)q.n * H + yy) * W + xx : ((int64_t)q.n * H + q.y0) * W + q.x0;   // always a valid address
-      hreg[i] = *(const u32x4_t*)(X + row * K + ch * 8);
-      hmask |= (ok ? 1u : 0u) << i;
-    }
-  };
-  auto store_halo = [&]() {
-#pragma unroll
-    for (int i = 0; i < 13; ++i) {
-      const int e = lane + 64 * i, pix = e >> 3, ch = e & 7;
-      if (pix < kHalo2Pix) {
-        u32x4_t v = hreg[i];
-        if (!((hmask >> i) & 1u)) { v.x = 0; v.y = 0; v.z = 0; v.w = 0; }
-        *(u32x4_t*)(Hs + pix * kHaloLd + ch * 8) = v;
-      }
-    }
-  };
-  auto load_w = [&](int tap, bf16x8_t (&dst)[8]) {
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) dst[tt * 4 + ks] = *(const bf16x8_t*)(Ws + (tap * N + tt * 32 + r) * WLD + h * 8 + ks * 16);
-  };
-  const int py = r >> 3, px = r & 7;                                            // this lane's output pixel inside the tile
-  Tile qc; qc.n = 0; qc.y0 = 0; qc.x0 = 0;
-  if (t < ntiles) qc = decode(t);
-  load_halo(qc);
-  bf16x8_t wf[2][8];
-  load_w(0, wf[0]);
-  for (; t < ntiles; t += stride) {
-    store_halo();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int tn = t + stride;
-    Tile qn = qc;
-    if (tn < ntiles) qn = decode(tn);
-    load_halo(qn);                                                              // next tile's halo, in flight during this tile's taps
-    f32x16_t acc[2][2];                                                         // [sub-tile][n-tile]
-#pragma unroll
-    for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[sb][tt][q] = 0.0f;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      load_w((tap + 1) % 9, wf[(tap + 1) & 1]);
-      bf16x8_t xb[2][4];
-#pragma unroll
-      for (int sb = 0; sb < 2; ++sb) {
-        const unsigned short* hp = Hs + ((py + 4 * sb + tap / 3) * 10 + px + tap % 3) * kHaloLd + h * 8;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) xb[sb][ks] = *(const bf16x8_t*)(hp + ks * 16);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-          for (int sb = 0; sb < 2; ++sb)                                        // one weight fragment, two pixel sub-tiles
-            acc[sb][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap & 1][tt * 4 + ks], xb[sb][ks], acc[sb][tt], 0, 0, 0);
-    }
-#pragma unroll
-    for (int sb = 0; sb < 2; ++sb) {
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u32x2_t pk;
-        pk.x = (unsigned int)c1_f2bf(acc[sb][tt][4 * g + 0]) | ((unsigned int)c1_f2bf(acc[sb][tt][4 * g + 1]) << 16);
-        pk.y = (unsigned int)c1_f2bf(acc[sb][tt][4 * g + 2]) | ((unsigned int)c1_f2bf(acc[sb][tt][4 * g + 3]) << 16);
-        *(u32x2_t*)(Ys + r * YLD + tt * 32 + 8 * g + 4 * h) = pk;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int cc = lane & 7, r0 = lane >> 3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = r0 + 8 * i;                                               // tile pixel (row >> 3, row & 7)
-      const u32x4_t v = *(const u32x4_t*)(Ys + row * YLD + cc * 8);
-      const unsigned int w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float f = c1_bf2f((unsigned short)(w4[j >> 1] >> ((j & 1) * 16)));
-        if (STATS) { st_s[j] += f; st_q[j] += f * f; }
-      }
-      const int64_t orow = ((int64_t)qc.n * H + qc.y0 + 4 * sb + (row >> 3)) * W + qc.x0 + (row & 7);
-      __builtin_nontemporal_store(v, (u32x4_t*)(Y + orow * N + cc * 8));
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    qc = qn;
-  }
-  if (!STATS) return;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float a = st_s[j], b = st_q[j];
-    a += __shfl_xor(a, 8, 64); b += __shfl_xor(b, 8, 64);
-    a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
-    a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
-    st_s[j] = a; st_q[j] = b;
-  }
-  __syncthreads();
-  if (lane < 8) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { Ss[(wave * 2 + 0) * N + lane * 8 + j] = st_s[j]; Ss[(wave * 2 + 1) * N + lane * 8 + j] = st_q[j]; }
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < 2 * N; e += kC1Threads) {
-    const int which = e / N, n = e - which * N;
-    part[(int64_t)blockIdx.x * 2 * N + which * N + n] =
-        Ss[(0 * 2 + which) * N + n] + Ss[(1 * 2 + which) * N + n] + Ss[(2 * 2 + which) * N + n] + Ss[(3 * 2 + which) * N + n];
-  }
-}
 
 }  // namespace lec
 
@@ -832,36 +669,21 @@ extern "C" int lec_conv3x3_c64_fwd(const void* x, const void* w, int Nimg, int H
   int64_t nb = (nstrips + 3) / 4;
   const int nblk = (int)(nb > kC1MaxBlocks ? kC1MaxBlocks : nb);
   hipStream_t st = (hipStream_t)stream;
-  if (H % 8 == 0 && W % 8 == 0 && !getenv("LEC_C3_STRIP") && !getenv("LEC_C3_HALO1")) {   // 8 x 8-pixel tiles: weight fragments shared by two sub-tiles
-    const size_t hsm = ((size_t)9 * 64 * (64 + 8) + 4 * kHalo2Pix * kHaloLd) * sizeof(unsigned short);
-    static bool hattr2 = false;
-    if (!hattr2) {
-      hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_halo2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hsm);
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_c64_halo2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hsm);
-      if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3x3_c64_halo2)");
-      hattr2 = true;
-    }
-    const int64_t nt2 = (int64_t)Nimg * (H / 8) * (W / 8);
-    int64_t nb2 = (nt2 + 3) / 4;
-    const int nblk2 = (int)(nb2 > kC1MaxBlocks ? kC1MaxBlocks : nb2);
-    if (partials) hipLaunchKernelGGL((conv3x3_c64_halo2_kernel<true>), dim3(nblk2), dim3(kC1Threads), hsm, st, (const unsigned short*)x, (const unsigned short*)w, Nimg, H, W, (unsigned short*)y, partials);
-    else hipLaunchKernelGGL((conv3x3_c64_halo2_kernel<false>), dim3(nblk2), dim3(kC1Threads), hsm, st, (const unsigned short*)x, (const unsigned short*)w, Nimg, H, W, (unsigned short*)y, (float*)nullptr);
-    if (n_partials) *n_partials = nblk2;
-    LEC_CHECK_LAUNCH("conv3x3_c64_halo2_kernel");
-    return LEC_OK;
-  }
   if (H % 4 == 0 && W % 8 == 0 && !getenv("LEC_C3_STRIP")) {             // 4 x 8-pixel tiles: the LDS-halo kernel
-    const size_t hsm = ((size_t)9 * 64 * (64 + 8) + 4 * kHaloPix * kHaloLd + 4 * 32 * (64 + 8)) * sizeof(unsigned short);
-    static bool hattr = false;
-    if (!hattr) {
+    const size_t hsm = ((size_t)9 * 64 * (64 + 8) + 8 * kHaloPix * kHaloLd) * sizeof(unsigned short);
+    static bool hattr8 = false;
+    if (!hattr8) {
       hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_halo_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hsm);
       if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_c64_halo_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hsm);
-      if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3x3_c64_halo)");
-      hattr = true;
+      if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3x3_c64_halo_w8)");
+      hattr8 = true;
     }
-    if (partials) hipLaunchKernelGGL((conv3x3_c64_halo_kernel<true>), dim3(nblk), dim3(kC1Threads), hsm, st, (const unsigned short*)x, (const unsigned short*)w, Nimg, H, W, (unsigned short*)y, partials);
-    else hipLaunchKernelGGL((conv3x3_c64_halo_kernel<false>), dim3(nblk), dim3(kC1Threads), hsm, st, (const unsigned short*)x, (const unsigned short*)w, Nimg, H, W, (unsigned short*)y, (float*)nullptr);
-    if (n_partials) *n_partials = nblk;
+    const int64_t nt8 = (int64_t)Nimg * (H / 4) * (W / 8);
+    int64_t nb8 = (nt8 + 7) / 8;
+    const int nblk8 = (int)(nb8 > 256 ? 256 : nb8);
+    if (partials) hipLaunchKernelGGL((conv3x3_c64_halo_kernel<true>), dim3(nblk8), dim3(512), hsm, st, (const unsigned short*)x, (const unsigned short*)w, Nimg, H, W, (unsigned short*)y, partials);
+    else hipLaunchKernelGGL((conv3x3_c64_halo_kernel<false>), dim3(nblk8), dim3(512), hsm, st, (const unsigned short*)x, (const unsigned short*)w, Nimg, H, W, (unsigned short*)y, (float*)nullptr);
+    if (n_partials) *n_partials = nblk8;
     LEC_CHECK_LAUNCH("conv3x3_c64_halo_kernel");
     return LEC_OK;
   }
