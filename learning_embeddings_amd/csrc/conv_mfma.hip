@@ -38,8 +38,8 @@ constexpr int kC1MaxBlocks = 512;          // = kBnMaxBlocks: the partials land 
 // K: reduction width (input channels); N: output channels handled by ONE workgroup (blockIdx.y selects the N-wide column
 // block of an Ntot-wide output: a layer wider than its weights' LDS budget re-reads X once per column block);
 // STATS: leave the per-channel partials (forward) or not (the same kernel serves the data gradient: X := dY, W := W^T).
-template <int K, int N, bool STATS>
-__global__ __launch_bounds__(kC1Threads) void conv1x1_fwd_stats_kernel(const unsigned short* __restrict__ X,
+template <int K, int N, bool STATS, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void conv1x1_fwd_stats_kernel(const unsigned short* __restrict__ X,
                                                                        const unsigned short* __restrict__ Wt, int64_t M, int Ntot,
                                                                        unsigned short* __restrict__ Y, float* __restrict__ part) {
   constexpr int KS = K / 16;                 // k-steps of one MFMA
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kC1Threads) void conv1x1_fwd_stats_kernel(const uns
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   // ---- weights -> LDS, once
-  for (int e = threadIdx.x; e < N * (K / 8); e += kC1Threads) {
+  for (int e = threadIdx.x; e < N * (K / 8); e += WAVES * 64) {
     const int n = e / (K / 8), c = e - n * (K / 8);
     *(u32x4_t*)(Ws + n * WLD + c * 8) = *(const u32x4_t*)(Wt + (int64_t)n * K + c * 8);
   }
@@ -68,8 +68,8 @@ __global__ __launch_bounds__(kC1Threads) void conv1x1_fwd_stats_kernel(const uns
     for (int j = 0; j < 8; ++j) { st_s[c][j] = 0.0f; st_q[c][j] = 0.0f; }
 
   const int64_t nstrips = M / 32;
-  const int64_t stride = (int64_t)gridDim.x * 4;
-  int64_t s = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t stride = (int64_t)gridDim.x * WAVES;
+  int64_t s = (int64_t)blockIdx.x * WAVES + wave;
   bf16x8_t xb[KS], xn[KS];
   if (s < nstrips) {
 #pragma unroll
@@ -156,28 +156,34 @@ __global__ __launch_bounds__(kC1Threads) void conv1x1_fwd_stats_kernel(const uns
     }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < 2 * N; e += kC1Threads) {
+  for (int e = threadIdx.x; e < 2 * N; e += WAVES * 64) {
     const int which = e / N, n = e - which * N;
-    part[(int64_t)blockIdx.x * 2 * Ntot + which * Ntot + blockIdx.y * N + n] =
-        Ss[(0 * 2 + which) * N + n] + Ss[(1 * 2 + which) * N + n] + Ss[(2 * 2 + which) * N + n] + Ss[(3 * 2 + which) * N + n];
+    float a = 0.0f;
+#pragma unroll
+    for (int wv = 0; wv < WAVES; ++wv) a += Ss[(wv * 2 + which) * N + n];
+    part[(int64_t)blockIdx.x * 2 * Ntot + which * Ntot + blockIdx.y * N + n] = a;
   }
 }
 
 template <int K, int N, bool STATS>
 static int launch_conv1x1(const void* x, const void* w, int64_t M, int Ntot, void* y, float* part, int* nblk_out, hipStream_t st) {
-  static_assert(4 * 2 * N * sizeof(float) <= 4 * 32 * (64 + 8) * sizeof(unsigned short), "statistics staging must fit the Y tiles");
-  const size_t smem = ((size_t)N * (K + 8) + 4 * 32 * (64 + 8)) * sizeof(unsigned short);
+  // eight waves per workgroup (two per SIMD) for K <= 128 (128 -> 512: 117 -> 105 us); the K = 256 instances, whose
+  // fragment sets already fill the registers, measured better with four (256 -> 128: 229 vs 241 us)
+  constexpr int WAVES = (K <= 128 && ((size_t)N * (K + 8) + 8 * 32 * (64 + 8)) * sizeof(unsigned short) <= 160 * 1024) ? 8 : 4;
+  static_assert(WAVES * 2 * N * sizeof(float) <= WAVES * 32 * (64 + 8) * sizeof(unsigned short), "statistics staging must fit the Y tiles");
+  const size_t smem = ((size_t)N * (K + 8) + WAVES * 32 * (64 + 8)) * sizeof(unsigned short);
   static bool attr_set = false;
   if (smem > 64 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv1x1_fwd_stats_kernel<K, N, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)conv1x1_fwd_stats_kernel<K, N, STATS, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv1x1)");
     attr_set = true;
   }
   const int64_t nstrips = M / 32;
-  int64_t nb = (nstrips + 3) / 4;
-  const int cap = kC1MaxBlocks / (Ntot / N) > 0 ? kC1MaxBlocks / (Ntot / N) : 1;
+  int64_t nb = (nstrips + WAVES - 1) / WAVES;
+  int cap = kC1MaxBlocks / (Ntot / N) > 0 ? kC1MaxBlocks / (Ntot / N) : 1;
+  if (WAVES == 8 && cap > 256) cap = 256;
   const int nblk = (int)(nb > cap ? cap : nb);
-  hipLaunchKernelGGL((conv1x1_fwd_stats_kernel<K, N, STATS>), dim3(nblk, Ntot / N), dim3(kC1Threads), smem, st, (const unsigned short*)x,
+  hipLaunchKernelGGL((conv1x1_fwd_stats_kernel<K, N, STATS, WAVES>), dim3(nblk, Ntot / N), dim3(WAVES * 64), smem, st, (const unsigned short*)x,
                      (const unsigned short*)w, M, Ntot, (unsigned short*)y, part);
   if (nblk_out) *nblk_out = nblk;
   LEC_CHECK_LAUNCH("conv1x1_fwd_stats_kernel");
