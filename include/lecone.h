@@ -217,15 +217,18 @@ int lec_bn_bwd(const void* dy, const void* dy2, const void* y, const uint8_t* re
  * layers' data gradient.  x: [M, Cin] bf16 (M = N*H*W), w: [Cout, Cin] bf16, y: [M, Cout] bf16.
  * partials (optional): >= 512*2*Cout floats, receives n_partials (HOST int, <= 512) rows of [sum | sum of squares] per
  * channel of the bf16-rounded y -- the layout lec_bn_fwd_prestat consumes; pass NULL, NULL for a plain product.
+ * w_transposed = 1: w is stored [Cin][Cout] -- i.e. it is the FORWARD weight of the layer whose data gradient this call
+ * computes (x := dy) -- and is transposed while it is loaded; no transpose kernel is needed.
  * Shapes with a kernel instance: lec_conv1x1_supported(Cin, Cout, M) != 0. */
 int lec_conv1x1_supported(int Cin, int Cout, int64_t M);
-int lec_conv1x1_fwd(const void* x, const void* w, int64_t M, int Cin, int Cout, void* y, float* partials,
+int lec_conv1x1_fwd(const void* x, const void* w, int w_transposed, int64_t M, int Cin, int Cout, void* y, float* partials,
                     int64_t partials_bytes, int* n_partials, lec_stream_t stream);
 /* 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels on NHWC bf16 (ResNet-50 layer1's conv2, the
  * one 3x3 layer near the HBM ridge), same MFMA wave-strip scheme and optional statistics epilogue as lec_conv1x1_fwd.
  * x: [N, H, W, 64], w: [64 out][3][3][64 in] (a channels_last conv weight), y: [N, H, W, 64]; N*H*W % 32 == 0.
- * The layer's data gradient is the same call on dy with w'[ci][r][s][co] = w[co][2-r][2-s][ci]. */
-int lec_conv3x3_c64_fwd(const void* x, const void* w, int N, int H, int W, void* y, float* partials,
+ * The layer's data gradient is the same call on dy with w'[ci][r][s][co] = w[co][2-r][2-s][ci]; w_transposed = 1 takes the
+ * forward weight itself and applies that flip + transpose while loading it. */
+int lec_conv3x3_c64_fwd(const void* x, const void* w, int w_transposed, int N, int H, int W, void* y, float* partials,
                         int64_t partials_bytes, int* n_partials, lec_stream_t stream);
 /* The same for 128 -> 128 channels (layer2's conv2 at 28x28): weights streamed through LDS one tap at a time, any H, W. */
 int lec_conv3x3_c128_fwd(const void* x, const void* w, int N, int H, int W, void* y, float* partials,

@@ -41,10 +41,10 @@ constexpr int kC1MaxBlocks = 512;          // = kBnMaxBlocks: the partials land 
 template <int K, int N, bool STATS, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void conv1x1_fwd_stats_kernel(const unsigned short* __restrict__ X,
                                                                        const unsigned short* __restrict__ Wt, int64_t M, int Ntot,
-                                                                       unsigned short* __restrict__ Y, float* __restrict__ part) {
+                                                                       unsigned short* __restrict__ Y, float* __restrict__ part, int wtrans) {
   constexpr int KS = K / 16;                 // k-steps of one MFMA
   constexpr int NC = N / 64;                 // 64-channel chunks of the epilogue
-  Wt += (int64_t)blockIdx.y * N * K; Y += (int64_t)blockIdx.y * N;
+  Y += (int64_t)blockIdx.y * N;
   constexpr int WLD = K + 8;                 // padded LDS row (bf16 elements): 16-byte reads of 32 rows hit distinct banks
   constexpr int YLD = 64 + 8;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -54,10 +54,23 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_fwd_stats_kernel(const uns
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  // ---- weights -> LDS, once
-  for (int e = threadIdx.x; e < N * (K / 8); e += WAVES * 64) {
-    const int n = e / (K / 8), c = e - n * (K / 8);
-    *(u32x4_t*)(Ws + n * WLD + c * 8) = *(const u32x4_t*)(Wt + (int64_t)n * K + c * 8);
+  // ---- weights -> LDS, once.  wtrans: the matrix arrives as [K][Ntot] (the FORWARD weight of the layer whose data gradient
+  // this launch is) and is transposed on the way in -- no transpose kernel per layer and step
+  if (!wtrans) {
+    const unsigned short* Wb = Wt + (int64_t)blockIdx.y * N * K;
+    for (int e = threadIdx.x; e < N * (K / 8); e += WAVES * 64) {
+      const int n = e / (K / 8), c = e - n * (K / 8);
+      *(u32x4_t*)(Ws + n * WLD + c * 8) = *(const u32x4_t*)(Wb + (int64_t)n * K + c * 8);
+    }
+  } else {
+    const unsigned short* Wb = Wt + (int64_t)blockIdx.y * N;
+    for (int e = threadIdx.x; e < K * (N / 8); e += WAVES * 64) {
+      const int k = e / (N / 8), c = e - k * (N / 8);
+      const u32x4_t v = *(const u32x4_t*)(Wb + (int64_t)k * Ntot + c * 8);
+      const unsigned int w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Ws[(c * 8 + j) * WLD + k] = (unsigned short)(w4[j >> 1] >> ((j & 1) * 16));
+    }
   }
   __syncthreads();
 
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_fwd_stats_kernel(const uns
 }
 
 template <int K, int N, bool STATS>
-static int launch_conv1x1(const void* x, const void* w, int64_t M, int Ntot, void* y, float* part, int* nblk_out, hipStream_t st) {
+static int launch_conv1x1(const void* x, const void* w, int64_t M, int Ntot, void* y, float* part, int* nblk_out, int wtrans, hipStream_t st) {
   // eight waves per workgroup (two per SIMD) for K <= 128 (128 -> 512: 117 -> 105 us); the K = 256 instances, whose
   // fragment sets already fill the registers, measured better with four (256 -> 128: 229 vs 241 us)
   constexpr int WAVES = (K <= 128 && ((size_t)N * (K + 8) + 8 * 32 * (64 + 8)) * sizeof(unsigned short) <= 160 * 1024) ? 8 : 4;
@@ -184,7 +197,7 @@ static int launch_conv1x1(const void* x, const void* w, int64_t M, int Ntot, voi
   if (WAVES == 8 && cap > 256) cap = 256;
   const int nblk = (int)(nb > cap ? cap : nb);
   hipLaunchKernelGGL((conv1x1_fwd_stats_kernel<K, N, STATS, WAVES>), dim3(nblk, Ntot / N), dim3(WAVES * 64), smem, st, (const unsigned short*)x,
-                     (const unsigned short*)w, M, Ntot, (unsigned short*)y, part);
+                     (const unsigned short*)w, M, Ntot, (unsigned short*)y, part, wtrans);
   if (nblk_out) *nblk_out = nblk;
   LEC_CHECK_LAUNCH("conv1x1_fwd_stats_kernel");
   return LEC_OK;
@@ -197,19 +210,31 @@ static int launch_conv1x1(const void* x, const void* w, int64_t M, int Ntot, voi
 template <int K, int N, bool STATS>
 __global__ __launch_bounds__(kC1Threads) void conv1x1_bigk_kernel(const unsigned short* __restrict__ X,
                                                                   const unsigned short* __restrict__ Wt, int64_t M, int Ntot,
-                                                                  unsigned short* __restrict__ Y, float* __restrict__ part) {
+                                                                  unsigned short* __restrict__ Y, float* __restrict__ part, int wtrans) {
   constexpr int NCH = K / 64, R = 4, NT = N / 32, NC = N / 64;
   constexpr int WLD = K + 8, YLD = 64 + 8;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   unsigned short* Ws = smem;
   unsigned short* Ys = Ws + N * WLD + (threadIdx.x >> 6) * 32 * YLD;
   float* Ss = (float*)(smem + N * WLD);                         // reuses the Y tiles at the end of the launch
-  Wt += (int64_t)blockIdx.y * N * K; Y += (int64_t)blockIdx.y * N;
+  Y += (int64_t)blockIdx.y * N;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  for (int e = threadIdx.x; e < N * (K / 8); e += kC1Threads) {
-    const int n = e / (K / 8), c = e - n * (K / 8);
-    *(u32x4_t*)(Ws + n * WLD + c * 8) = *(const u32x4_t*)(Wt + (int64_t)n * K + c * 8);
+  if (!wtrans) {
+    const unsigned short* Wb = Wt + (int64_t)blockIdx.y * N * K;
+    for (int e = threadIdx.x; e < N * (K / 8); e += kC1Threads) {
+      const int n = e / (K / 8), c = e - n * (K / 8);
+      *(u32x4_t*)(Ws + n * WLD + c * 8) = *(const u32x4_t*)(Wb + (int64_t)n * K + c * 8);
+    }
+  } else {                                                       // [K][Ntot] forward weight, transposed on the way in
+    const unsigned short* Wb = Wt + (int64_t)blockIdx.y * N;
+    for (int e = threadIdx.x; e < K * (N / 8); e += kC1Threads) {
+      const int k = e / (N / 8), c = e - k * (N / 8);
+      const u32x4_t v = *(const u32x4_t*)(Wb + (int64_t)k * Ntot + c * 8);
+      const unsigned int w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Ws[(c * 8 + j) * WLD + k] = (unsigned short)(w4[j >> 1] >> ((j & 1) * 16));
+    }
   }
   __syncthreads();
   float st_s[NC][8], st_q[NC][8];
@@ -320,7 +345,7 @@ __global__ __launch_bounds__(kC1Threads) void conv1x1_bigk_kernel(const unsigned
 }
 
 template <int K, int N, bool STATS>
-static int launch_conv1x1_bigk(const void* x, const void* w, int64_t M, int Ntot, void* y, float* part, int* nblk_out, hipStream_t st) {
+static int launch_conv1x1_bigk(const void* x, const void* w, int64_t M, int Ntot, void* y, float* part, int* nblk_out, int wtrans, hipStream_t st) {
   static_assert(4 * 2 * N * sizeof(float) <= 4 * 32 * (64 + 8) * sizeof(unsigned short), "statistics staging must fit the Y tiles");
   const size_t smem = ((size_t)N * (K + 8) + 4 * 32 * (64 + 8)) * sizeof(unsigned short);
   static bool attr_set = false;
@@ -334,7 +359,7 @@ static int launch_conv1x1_bigk(const void* x, const void* w, int64_t M, int Ntot
   const int cap = kC1MaxBlocks / (Ntot / N) > 0 ? kC1MaxBlocks / (Ntot / N) : 1;
   const int nblk = (int)(nb > cap ? cap : nb);
   hipLaunchKernelGGL((conv1x1_bigk_kernel<K, N, STATS>), dim3(nblk, Ntot / N), dim3(kC1Threads), smem, st, (const unsigned short*)x,
-                     (const unsigned short*)w, M, Ntot, (unsigned short*)y, part);
+                     (const unsigned short*)w, M, Ntot, (unsigned short*)y, part, wtrans);
   if (nblk_out) *nblk_out = nblk;
   LEC_CHECK_LAUNCH("conv1x1_bigk_kernel");
   return LEC_OK;
@@ -349,7 +374,7 @@ static int launch_conv1x1_bigk(const void* x, const void* w, int64_t M, int Ntot
 template <bool STATS>
 __global__ __launch_bounds__(kC1Threads) void conv3x3_c64_kernel(const unsigned short* __restrict__ X,
                                                                  const unsigned short* __restrict__ Wt, int64_t M, int H, int W,
-                                                                 unsigned short* __restrict__ Y, float* __restrict__ part) {
+                                                                 unsigned short* __restrict__ Y, float* __restrict__ part, int wtrans) {
   constexpr int K = 64, N = 64, R = 9, WLD = K + 8, YLD = 64 + 8;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   unsigned short* Ws = smem;                                     // [9 taps][64 out][WLD]
@@ -361,7 +386,13 @@ __global__ __launch_bounds__(kC1Threads) void conv3x3_c64_kernel(const unsigned 
   for (int e = threadIdx.x; e < 9 * N * (K / 8); e += kC1Threads) {
     const int c8 = e % (K / 8); int t = e / (K / 8);
     const int co = t % N; const int tap = t / N;
-    *(u32x4_t*)(Ws + (tap * N + co) * WLD + c8 * 8) = *(const u32x4_t*)(Wt + ((int64_t)co * 9 + tap) * K + c8 * 8);
+    const u32x4_t v = *(const u32x4_t*)(Wt + ((int64_t)co * 9 + tap) * K + c8 * 8);
+    if (!wtrans) *(u32x4_t*)(Ws + (tap * N + co) * WLD + c8 * 8) = v;
+    else {       // forward weight [co][r][s][ci] of the layer whose data gradient this is: W'[ci][2-r][2-s][co], flipped and transposed here
+      const unsigned int w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Ws[((8 - tap) * N + c8 * 8 + j) * WLD + co] = (unsigned short)(w4[j >> 1] >> ((j & 1) * 16));
+    }
   }
   __syncthreads();
   float st_s[8], st_q[8];
@@ -502,7 +533,7 @@ constexpr int kHaloPix = 60, kHaloLd = 64 + 8;                   // bf16 element
 template <bool STATS>
 __global__ __launch_bounds__(512) void conv3x3_c64_halo_kernel(const unsigned short* __restrict__ X,
                                                                       const unsigned short* __restrict__ Wt, int Nimg, int H, int W,
-                                                                      unsigned short* __restrict__ Y, float* __restrict__ part) {
+                                                                      unsigned short* __restrict__ Y, float* __restrict__ part, int wtrans) {
   constexpr int K = 64, N = 64, WLD = K + 8, YLD = 64 + 8;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   unsigned short* Ws = smem;                                                   // [9][64][WLD]
@@ -514,7 +545,13 @@ __global__ __launch_bounds__(512) void conv3x3_c64_halo_kernel(const unsigned sh
   for (int e = threadIdx.x; e < 9 * N * (K / 8); e += 512) {
     const int c8 = e % (K / 8); int t = e / (K / 8);
     const int co = t % N; const int tap = t / N;
-    *(u32x4_t*)(Ws + (tap * N + co) * WLD + c8 * 8) = *(const u32x4_t*)(Wt + ((int64_t)co * 9 + tap) * K + c8 * 8);
+    const u32x4_t v = *(const u32x4_t*)(Wt + ((int64_t)co * 9 + tap) * K + c8 * 8);
+    if (!wtrans) *(u32x4_t*)(Ws + (tap * N + co) * WLD + c8 * 8) = v;
+    else {       // forward weight [co][r][s][ci] of the layer whose data gradient this is: W'[ci][2-r][2-s][co], flipped and transposed here
+      const unsigned int w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Ws[((8 - tap) * N + c8 * 8 + j) * WLD + co] = (unsigned short)(w4[j >> 1] >> ((j & 1) * 16));
+    }
   }
   __syncthreads();
   float st_s[8], st_q[8];
@@ -655,7 +692,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_halo_kernel(const unsigned sh
 
 }  // namespace lec
 
-extern "C" int lec_conv3x3_c64_fwd(const void* x, const void* w, int Nimg, int H, int W, void* y, float* partials,
+extern "C" int lec_conv3x3_c64_fwd(const void* x, const void* w, int w_transposed, int Nimg, int H, int W, void* y, float* partials,
                                    int64_t partials_bytes, int* n_partials, lec_stream_t stream) {
   using namespace lec;
   LEC_CHECK_ARG(x && w && y, "conv3x3_c64_fwd: null pointer");
@@ -687,14 +724,14 @@ extern "C" int lec_conv3x3_c64_fwd(const void* x, const void* w, int Nimg, int H
     const int64_t nt8 = (int64_t)Nimg * (H / 4) * (W / 8);
     int64_t nb8 = (nt8 + 7) / 8;
     const int nblk8 = (int)(nb8 > 256 ? 256 : nb8);
-    if (partials) hipLaunchKernelGGL((conv3x3_c64_halo_kernel<true>), dim3(nblk8), dim3(512), hsm, st, (const unsigned short*)x, (const unsigned short*)w, Nimg, H, W, (unsigned short*)y, partials);
-    else hipLaunchKernelGGL((conv3x3_c64_halo_kernel<false>), dim3(nblk8), dim3(512), hsm, st, (const unsigned short*)x, (const unsigned short*)w, Nimg, H, W, (unsigned short*)y, (float*)nullptr);
+    if (partials) hipLaunchKernelGGL((conv3x3_c64_halo_kernel<true>), dim3(nblk8), dim3(512), hsm, st, (const unsigned short*)x, (const unsigned short*)w, Nimg, H, W, (unsigned short*)y, partials, w_transposed);
+    else hipLaunchKernelGGL((conv3x3_c64_halo_kernel<false>), dim3(nblk8), dim3(512), hsm, st, (const unsigned short*)x, (const unsigned short*)w, Nimg, H, W, (unsigned short*)y, (float*)nullptr, w_transposed);
     if (n_partials) *n_partials = nblk8;
     LEC_CHECK_LAUNCH("conv3x3_c64_halo_kernel");
     return LEC_OK;
   }
-  if (partials) hipLaunchKernelGGL((conv3x3_c64_kernel<true>), dim3(nblk), dim3(kC1Threads), smem, st, (const unsigned short*)x, (const unsigned short*)w, M, H, W, (unsigned short*)y, partials);
-  else hipLaunchKernelGGL((conv3x3_c64_kernel<false>), dim3(nblk), dim3(kC1Threads), smem, st, (const unsigned short*)x, (const unsigned short*)w, M, H, W, (unsigned short*)y, (float*)nullptr);
+  if (partials) hipLaunchKernelGGL((conv3x3_c64_kernel<true>), dim3(nblk), dim3(kC1Threads), smem, st, (const unsigned short*)x, (const unsigned short*)w, M, H, W, (unsigned short*)y, partials, w_transposed);
+  else hipLaunchKernelGGL((conv3x3_c64_kernel<false>), dim3(nblk), dim3(kC1Threads), smem, st, (const unsigned short*)x, (const unsigned short*)w, M, H, W, (unsigned short*)y, (float*)nullptr, w_transposed);
   if (n_partials) *n_partials = nblk;
   LEC_CHECK_LAUNCH("conv3x3_c64_kernel");
   return LEC_OK;
@@ -909,7 +946,7 @@ extern "C" int lec_conv1x1_supported(int Cin, int Cout, int64_t M) {
   return shape && M > 0 && M % 32 == 0;
 }
 
-extern "C" int lec_conv1x1_fwd(const void* x, const void* w, int64_t M, int Cin, int Cout, void* y, float* partials,
+extern "C" int lec_conv1x1_fwd(const void* x, const void* w, int w_transposed, int64_t M, int Cin, int Cout, void* y, float* partials,
                                int64_t partials_bytes, int* n_partials, lec_stream_t stream) {
   using namespace lec;
   LEC_CHECK_ARG(x && w && y, "conv1x1_fwd: null pointer");
@@ -917,13 +954,13 @@ extern "C" int lec_conv1x1_fwd(const void* x, const void* w, int64_t M, int Cin,
   LEC_CHECK_ARG((partials == nullptr) == (n_partials == nullptr), "conv1x1_fwd: pass partials and n_partials together");
   LEC_CHECK_ARG(!partials || partials_bytes >= (int64_t)kC1MaxBlocks * 2 * Cout * (int64_t)sizeof(float), "conv1x1_fwd: partials buffer too small");
   hipStream_t st = (hipStream_t)stream;
-#define LEC_C1(K_, NB_) (partials ? launch_conv1x1<K_, NB_, true>(x, w, M, Cout, y, partials, n_partials, st) \
-                                  : launch_conv1x1<K_, NB_, false>(x, w, M, Cout, y, nullptr, nullptr, st))
+#define LEC_C1(K_, NB_) (partials ? launch_conv1x1<K_, NB_, true>(x, w, M, Cout, y, partials, n_partials, w_transposed, st) \
+                                  : launch_conv1x1<K_, NB_, false>(x, w, M, Cout, y, nullptr, nullptr, w_transposed, st))
   if (Cin == 64 && Cout == 256) return LEC_C1(64, 256);
   if (Cin == 64 && Cout == 64) return LEC_C1(64, 64);
   if (Cin == 128) return LEC_C1(128, 256);                          // Cout = 512: two column blocks, X is read twice
-  if (Cin == 512) return partials ? launch_conv1x1_bigk<512, 128, true>(x, w, M, Cout, y, partials, n_partials, st)
-                                  : launch_conv1x1_bigk<512, 128, false>(x, w, M, Cout, y, nullptr, nullptr, st);
+  if (Cin == 512) return partials ? launch_conv1x1_bigk<512, 128, true>(x, w, M, Cout, y, partials, n_partials, w_transposed, st)
+                                  : launch_conv1x1_bigk<512, 128, false>(x, w, M, Cout, y, nullptr, nullptr, w_transposed, st);
   if (Cin == 256 && Cout == 64) return LEC_C1(256, 64);
   return LEC_C1(256, 128);
 #undef LEC_C1

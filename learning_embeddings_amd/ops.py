@@ -384,36 +384,43 @@ def conv1x1_supported(cin, cout, M):
     return bool(lib.lec_conv1x1_supported(int(cin), int(cout), int(M)))
 
 
-def conv3x3_c64(x, w_clast, want_stats=False):
-    """3x3 / stride 1 / pad 1, 64 -> 64 channels on NHWC bf16 through lec_conv3x3_c64_fwd.  x: [N, 64, H, W] channels_last,
-    w_clast: [64, 64, 3, 3] channels_last (memory [co][r][s][ci]).  Returns y like x."""
+def conv3x3_c64(x, w_clast, want_stats=False, w_transposed=False):
+    """3x3 / stride 1 / pad 1, C -> C channels (C = 64, or 128 through the tap-streaming kernel) on NHWC bf16.
+    x: [N, C, H, W] channels_last, w_clast: [C, C, 3, 3] channels_last (memory [co][r][s][ci]).  w_transposed (C = 64): x is
+    a gradient and w_clast the layer's FORWARD weight; the kernel flips and transposes it while loading (data gradient)."""
     n, c, h, w = x.shape
-    fn = {64: lib.lec_conv3x3_c64_fwd, 128: lib.lec_conv3x3_c128_fwd}[c]          # 128: weights streamed tap by tap
     y = torch.empty_like(x)
-    if want_stats:
-        ws = _bn_workspace(x.device)
-        k = C.c_int(0)
-        check(fn(dptr(x), dptr(w_clast), n, h, w, dptr(y), dptr(ws), ws.numel(), C.byref(k), stream_ptr()))
-        _BN_WS_OWNER[0], _BN_WS_OWNER[1] = y.data_ptr(), k.value
+    ws = _bn_workspace(x.device) if want_stats else None
+    k = C.c_int(0)
+    args = (dptr(ws), ws.numel(), C.byref(k)) if want_stats else (None, 0, None)
+    if c == 64:
+        check(lib.lec_conv3x3_c64_fwd(dptr(x), dptr(w_clast), int(bool(w_transposed)), n, h, w, dptr(y), *args, stream_ptr()))
     else:
-        check(fn(dptr(x), dptr(w_clast), n, h, w, dptr(y), None, 0, None, stream_ptr()))
+        if w_transposed:
+            w_clast = w_clast.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
+        check(lib.lec_conv3x3_c128_fwd(dptr(x), dptr(w_clast), n, h, w, dptr(y), *args, stream_ptr()))
+    if want_stats:
+        _BN_WS_OWNER[0], _BN_WS_OWNER[1] = y.data_ptr(), k.value
     return y
 
 
-def conv1x1_rows(x_rows, w2, want_stats=False):
+def conv1x1_rows(x_rows, w2, want_stats=False, w_transposed=False):
     """y[M, Cout] = x[M, Cin] @ w[Cout, Cin]^T on the hand-written MFMA kernel (lec_conv1x1_fwd); with want_stats the
     per-channel sum / sum-of-squares partials of y are left in the BatchNorm workspace for the BN that follows
-    (BNActFn checks the ownership tag before trusting them)."""
+    (BNActFn checks the ownership tag before trusting them).  w_transposed: w2 is [Cin, Cout] (a layer's forward weight
+    used for its data gradient) and the kernel transposes it while loading."""
     M, cin = x_rows.shape
-    cout = w2.shape[0]
+    cout = w2.shape[1] if w_transposed else w2.shape[0]
+    if (w2.shape[0] if w_transposed else w2.shape[1]) != cin:
+        raise ValueError('weight shape %s does not match %d input channels' % (tuple(w2.shape), cin))
     y = torch.empty((M, cout), dtype=torch.bfloat16, device=x_rows.device)
     if want_stats:
         ws = _bn_workspace(x_rows.device)
         n = C.c_int(0)
-        check(lib.lec_conv1x1_fwd(dptr(x_rows), dptr(w2), M, cin, cout, dptr(y), dptr(ws), ws.numel(), C.byref(n), stream_ptr()))
+        check(lib.lec_conv1x1_fwd(dptr(x_rows), dptr(w2), int(bool(w_transposed)), M, cin, cout, dptr(y), dptr(ws), ws.numel(), C.byref(n), stream_ptr()))
         _BN_WS_OWNER[0], _BN_WS_OWNER[1] = y.data_ptr(), n.value
     else:
-        check(lib.lec_conv1x1_fwd(dptr(x_rows), dptr(w2), M, cin, cout, dptr(y), None, 0, None, stream_ptr()))
+        check(lib.lec_conv1x1_fwd(dptr(x_rows), dptr(w2), int(bool(w_transposed)), M, cin, cout, dptr(y), None, 0, None, stream_ptr()))
     return y
 
 

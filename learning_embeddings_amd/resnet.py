@@ -178,13 +178,11 @@ class _OverlapConvFn(torch.autograd.Function):
         gx = None
         if ctx.needs_input_grad[0]:
             nhwc_g = gy.is_contiguous(memory_format=torch.channels_last)
-            if ctx.own3 and nhwc_g:                             # dX = conv(dY, W flipped and transposed): the same kernel
-                wt = w16.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
-                gx = _ops().conv3x3_c64(gy, wt)
+            if ctx.own3 and nhwc_g:                             # dX = conv(dY, W flipped and transposed): the same kernel,
+                gx = _ops().conv3x3_c64(gy, w16, w_transposed=True)   # which flips / transposes the weight as it loads it
             elif (ctx.own and nhwc_g and _ops().conv1x1_supported(conv.out_channels, conv.in_channels, gy.shape[0] * gy.shape[2] * gy.shape[3])):
-                n, _, h, wd = gy.shape                          # dX = dY * W: the same kernel on W^T [Cin, Cout]
-                wt = w16.reshape(conv.out_channels, conv.in_channels).t().contiguous()
-                gx = _from_rows(_ops().conv1x1_rows(_rows(gy), wt), n, h, wd)
+                n, _, h, wd = gy.shape                          # dX = dY * W: the same kernel, W transposed as it is loaded
+                gx = _from_rows(_ops().conv1x1_rows(_rows(gy), w16.reshape(conv.out_channels, conv.in_channels), w_transposed=True), n, h, wd)
             elif (ctx.pointwise and conv.in_channels >= GEMM_DGRAD_MIN_CIN and nhwc_g):
                 n, _, h, wd = gy.shape
                 gx = _from_rows(torch.mm(_rows(gy), w16.reshape(conv.out_channels, conv.in_channels)), n, h, wd)

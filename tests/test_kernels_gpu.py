@@ -497,6 +497,8 @@ def test_conv1x1_mfma_vs_fp32_matmul_and_statistics(cin, cout, M):
     assert ((part[1] - (yd * yd).sum(0)).abs().max() / (yd * yd).sum(0).abs().max()).item() < 1e-5
     y2 = ops.conv1x1_rows(x, w)                                                               # plain product (the dgrad form)
     assert torch.equal(y, y2)
+    y3 = ops.conv1x1_rows(x, w.t().contiguous(), w_transposed=True)                           # weight given as [Cin, Cout]
+    assert torch.equal(y, y3)
     ops._BN_WS_OWNER[0] = 0
 
 
@@ -538,8 +540,7 @@ def test_conv3x3_mfma_vs_torch(N, H, W, Cc):
     assert ((part[0] - yd.sum((0, 2, 3))).abs().max() / (yd.abs().sum((0, 2, 3)).max())).item() < 1e-5
     assert ((part[1] - (yd * yd).sum((0, 2, 3))).abs().max() / (yd * yd).sum((0, 2, 3)).max()).item() < 1e-5
     dy = torch.randn(N, Cc, H, W, generator=g).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
-    gx = ops.conv3x3_c64(dy, wt)
+    gx = ops.conv3x3_c64(dy, w, w_transposed=True)
     xr = x.float().requires_grad_(True)
     torch.nn.functional.conv2d(xr, w.float(), padding=1).backward(dy.float())
     assert (gx.float() - xr.grad).abs().max().item() <= 6e-3 * xr.grad.abs().max().item()

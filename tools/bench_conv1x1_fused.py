@@ -31,7 +31,7 @@ def main():
         npart = C.c_int(0)
 
         def fused():
-            check(lib.lec_conv1x1_fwd(dptr(x), dptr(w), M, ci, co, dptr(y), dptr(ws), ws.numel(), C.byref(npart), stream_ptr()))
+            check(lib.lec_conv1x1_fwd(dptr(x), dptr(w), 0, M, ci, co, dptr(y), dptr(ws), ws.numel(), C.byref(npart), stream_ptr()))
         fused(); torch.cuda.synchronize()
         part = ws[:npart.value * 2 * co * 4].view(torch.float32).view(npart.value, 2, co).double().sum(0).cpu()
         ref = (x.float() @ w.float().t())

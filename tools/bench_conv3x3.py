@@ -39,11 +39,10 @@ def run(Cc, H):
     cb = torch.ops.aten.convolution_backward
     dy = torch.randn_like(x)
     t_mi_d = timed(lambda: cb(dy, x, w, [0], [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False]))
-    wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
-    gx = ops.conv3x3_c64(dy, wt)
+    gx = ops.conv3x3_c64(dy, w, w_transposed=True)
     gref = cb(dy[:4].float(), x[:4].float(), w.float(), [0], [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
     derr = (gx[:4].float() - gref).abs().max().item() / gref.abs().max().item()
-    t_own_d = timed(lambda: ops.conv3x3_c64(dy, wt))
+    t_own_d = timed(lambda: ops.conv3x3_c64(dy, w, w_transposed=True))
     print(json.dumps({'C': Cc, 'H': H, 'fwd_rel_err': err, 'stats_rel_err': s_err, 'dgrad_rel_err': derr, 'own_fwd_us': round(t_own, 1), 'miopen_fwd_us': round(t_mi, 1),
                       'own_dgrad_us': round(t_own_d, 1), 'miopen_dgrad_us': round(t_mi_d, 1),
                       'own_fwd_TFLOPs': round(2 * B * H * H * Cc * Cc * 9 / t_own / 1e6, 1), 'own_fwd_GBps': round(B * H * H * Cc * 2 * 2 / t_own / 1e3, 1)}))
