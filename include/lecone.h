@@ -223,6 +223,12 @@ int lec_bn_bwd(const void* dy, const void* dy2, const void* y, const uint8_t* re
 int lec_conv1x1_supported(int Cin, int Cout, int64_t M);
 int lec_conv1x1_fwd(const void* x, const void* w, int w_transposed, int64_t M, int Cin, int Cout, void* y, float* partials,
                     int64_t partials_bytes, int* n_partials, lec_stream_t stream);
+/* Weight gradient of the same 1x1 layers: dw[Cout][Cin] (fp32) += dy[M, Cout]^T x[M, Cin], accumulated with float atomics
+ * straight into the caller's gradient buffer (which must hold the running sum, e.g. zero at the start of a step):
+ * replaces the library's weight-gradient kernel together with its zero-fill, its fp32 -> bf16 cast and the copy into the
+ * optimizer's gradient slot.  M % 64 == 0; shapes: lec_conv1x1_wgrad_supported. */
+int lec_conv1x1_wgrad_supported(int Cin, int Cout, int64_t M);
+int lec_conv1x1_wgrad(const void* dy, const void* x, int64_t M, int Cin, int Cout, float* dw, lec_stream_t stream);
 /* 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels on NHWC bf16 (ResNet-50 layer1's conv2, the
  * one 3x3 layer near the HBM ridge), same MFMA wave-strip scheme and optional statistics epilogue as lec_conv1x1_fwd.
  * x: [N, H, W, 64], w: [64 out][3][3][64 in] (a channels_last conv weight), y: [N, H, W, 64]; N*H*W % 32 == 0.

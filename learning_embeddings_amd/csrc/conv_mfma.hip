@@ -938,6 +938,156 @@ extern "C" int lec_conv3x3_c128_fwd(const void* x, const void* w, int Nimg, int 
 }
 
 namespace lec {
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of the wide 1x1 convolutions:  dW[co][ci] += sum_m dY[m][co] * X[m][ci]   (fp32, accumulated straight into
+// the parameter's gradient slot of the flat arena: no zero-fill, no fp32 -> bf16 cast, no copy kernel around it).
+// HBM-bound like the forward (dY and X are read once, the output is a few KB).  The reduction index m is the slow memory
+// index of BOTH operands, while an MFMA fragment wants 8 consecutive m per lane: the workgroup stages 64-row chunks of dY
+// and X through LDS TRANSPOSED -- coalesced 16-byte global loads, eight 2-byte LDS stores each into [channel][m] images
+// whose 16-byte groups are XOR-swizzled by the channel-octet index (4-way instead of 32-way bank conflicts on the stores)
+// -- double-buffered, one barrier per chunk.  A wave owns a TCO x TCI block of 32 x 32 accumulator tiles for the whole
+// launch and adds it into dW with float atomics at the end (rows of 32 consecutive floats per instruction).
+// KO / KI: output / input channels of this workgroup (blockIdx.y selects the KO- or KI-wide window of a wider layer).
+template <int KO, int KI, int WCO, int NW, bool SPLIT_CO>
+__global__ __launch_bounds__(NW * 64) void wgrad1x1_kernel(const unsigned short* __restrict__ dY, int CoutTot,
+                                                           const unsigned short* __restrict__ X, int CinTot, int64_t M,
+                                                           float* __restrict__ dW) {
+  constexpr int MC = 64, NT = NW * 64;                 // rows per chunk, threads
+  constexpr int WCI = NW / WCO, TCO = KO / 32 / WCO, TCI = KI / 32 / WCI;
+  constexpr int NC8 = (KO + KI) / 8;                   // 16-byte pieces per row
+  constexpr int PAIRS = NC8 * (MC / 2) / NT;           // (piece of row m, piece of row m + 1) pairs per thread and chunk
+  static_assert(NC8 % 8 == 0 && NC8 * (MC / 2) % NT == 0 && TCO >= 1 && TCI >= 1 && WCO * WCI == NW, "tile split");
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];   // [2][(KO + KI)][MC]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int co0 = SPLIT_CO ? (int)blockIdx.y * KO : 0, ci0 = SPLIT_CO ? 0 : (int)blockIdx.y * KI;
+  const int wco = wave / WCI, wci = wave % WCI;        // this wave's block of tiles
+  f32x16_t acc[TCO][TCI];
+#pragma unroll
+  for (int a = 0; a < TCO; ++a)
+#pragma unroll
+    for (int b = 0; b < TCI; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.0f;
+
+  // Pair q of a chunk: channel octet c8 = 8 * c8hi + (q & 7), rows m = 8 * mhi + 2 * ((q >> 3) & 3) + {0, 1}.  The 32 lanes
+  // of a half-wave hold 8 octets x 4 row pairs: four 128-byte row segments per global load, and in the LDS image
+  // (element (n, m) at n * MC + (((m >> 3) ^ ((n >> 3) & 7)) << 3) + (m & 7)) their 4-byte stores fall on 32 different banks.
+  const int64_t nchunks = M / MC;
+  u32x4_t regs[PAIRS][2];
+  auto load_chunk = [&](int64_t c) {
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) {
+      const int q = threadIdx.x + NT * i, rest = q >> 5;
+      const int c8 = (rest % (NC8 / 8)) * 8 + (q & 7), m = (rest / (NC8 / 8)) * 8 + ((q >> 3) & 3) * 2;
+      const int64_t row = c * MC + m;
+      const unsigned short* src = c8 < KO / 8 ? dY + row * CoutTot + co0 + c8 * 8 : X + row * CinTot + ci0 + (c8 - KO / 8) * 8;
+      const int ld = c8 < KO / 8 ? CoutTot : CinTot;
+      regs[i][0] = *(const u32x4_t*)src;
+      regs[i][1] = *(const u32x4_t*)(src + ld);
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    unsigned short* T = smem + buf * (KO + KI) * MC;
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) {
+      const int q = threadIdx.x + NT * i, rest = q >> 5;
+      const int c8 = (rest % (NC8 / 8)) * 8 + (q & 7), m = (rest / (NC8 / 8)) * 8 + ((q >> 3) & 3) * 2;
+      const unsigned int a4[4] = {regs[i][0].x, regs[i][0].y, regs[i][0].z, regs[i][0].w};
+      const unsigned int b4[4] = {regs[i][1].x, regs[i][1].y, regs[i][1].z, regs[i][1].w};
+      unsigned int* base = (unsigned int*)(T + (c8 * 8) * MC + (((m >> 3) ^ (c8 & 7)) << 3) + (m & 7));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {                    // channels 2j, 2j + 1 of the octet: (row m, row m + 1) in one dword
+        base[(2 * j) * (MC / 2)] = __builtin_amdgcn_perm(b4[j], a4[j], 0x05040100u);
+        base[(2 * j + 1) * (MC / 2)] = __builtin_amdgcn_perm(b4[j], a4[j], 0x07060302u);
+      }
+    }
+  };
+  int64_t c = blockIdx.x;
+  if (c < nchunks) { load_chunk(c); store_chunk(0); }
+  __syncthreads();
+  int buf = 0;
+  for (; c < nchunks; c += gridDim.x) {
+    const int64_t cn = c + gridDim.x;
+    if (cn < nchunks) load_chunk(cn);
+    const unsigned short* T = smem + buf * (KO + KI) * MC;
+#pragma unroll
+    for (int ks = 0; ks < MC / 16; ++ks) {
+      const int g = 2 * ks + h;                        // 16-byte group of this lane's 8 consecutive m
+      bf16x8_t af[TCO], bfr[TCI];
+#pragma unroll
+      for (int a = 0; a < TCO; ++a) {
+        const int n = (wco * TCO + a) * 32 + r;
+        af[a] = *(const bf16x8_t*)(T + n * MC + ((g ^ ((n >> 3) & 7)) << 3));
+      }
+#pragma unroll
+      for (int b = 0; b < TCI; ++b) {
+        const int n = KO + (wci * TCI + b) * 32 + r;
+        bfr[b] = *(const bf16x8_t*)(T + n * MC + ((g ^ ((n >> 3) & 7)) << 3));
+      }
+#pragma unroll
+      for (int a = 0; a < TCO; ++a)
+#pragma unroll
+        for (int b = 0; b < TCI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+    }
+    if (cn < nchunks) store_chunk(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // D[co][ci]: lane holds ci = col, co rows (reg & 3) + 8 (reg >> 2) + 4 h
+#pragma unroll
+  for (int a = 0; a < TCO; ++a)
+#pragma unroll
+    for (int b = 0; b < TCI; ++b) {
+      float* base = dW + (int64_t)(co0 + (wco * TCO + a) * 32) * CinTot + ci0 + (wci * TCI + b) * 32 + r;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) atomicAdd(base + (int64_t)((q & 3) + 8 * (q >> 2) + 4 * h) * CinTot, acc[a][b][q]);
+    }
+}
+
+template <int KO, int KI, int WCO, int NW, bool SPLIT_CO>
+static int launch_wgrad1x1(const void* dy, int CoutTot, const void* x, int CinTot, int64_t M, float* dW, hipStream_t st) {
+  const size_t smem = (size_t)2 * (KO + KI) * 64 * sizeof(unsigned short);
+  static bool attr_set = false;
+  if (smem > 64 * 1024 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad1x1_kernel<KO, KI, WCO, NW, SPLIT_CO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(wgrad1x1)");
+    attr_set = true;
+  }
+  const int ny = SPLIT_CO ? CoutTot / KO : CinTot / KI;
+  const int64_t nchunks = M / 64;
+  static const int per_cu = [] { const char* e = getenv("LEC_WGRAD_WG_PER_CU"); return e ? atoi(e) : 0; }();
+  static const int blocks = [] { const char* e = getenv("LEC_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();
+  const int want = (blocks > 0 ? blocks : 256 * (per_cu > 0 ? per_cu : (smem <= 80 * 1024 ? 2 : 1))) / ny;
+  const int nblk = (int)(nchunks < want ? nchunks : want);
+  hipLaunchKernelGGL((wgrad1x1_kernel<KO, KI, WCO, NW, SPLIT_CO>), dim3(nblk, ny), dim3(NW * 64), smem, st, (const unsigned short*)dy, CoutTot,
+                     (const unsigned short*)x, CinTot, M, dW);
+  LEC_CHECK_LAUNCH("wgrad1x1_kernel");
+  return LEC_OK;
+}
+
+}  // namespace lec
+
+extern "C" int lec_conv1x1_wgrad_supported(int Cin, int Cout, int64_t M) {
+  const bool shape = (Cin == 64 && (Cout == 64 || Cout == 256)) || (Cin == 128 && Cout == 512) || (Cin == 256 && (Cout == 64 || Cout == 128)) ||
+                     (Cin == 512 && Cout == 128);
+  return shape && M > 0 && M % 64 == 0;
+}
+
+extern "C" int lec_conv1x1_wgrad(const void* dy, const void* x, int64_t M, int Cin, int Cout, float* dw, lec_stream_t stream) {
+  using namespace lec;
+  LEC_CHECK_ARG(dy && x && dw, "conv1x1_wgrad: null pointer");
+  LEC_CHECK_ARG(lec_conv1x1_wgrad_supported(Cin, Cout, M), "conv1x1_wgrad: unsupported shape Cin=%d Cout=%d M=%lld", Cin, Cout, (long long)M);
+  hipStream_t st = (hipStream_t)stream;
+  if (Cin == 64 && Cout == 64) return launch_wgrad1x1<64, 64, 2, 4, true>(dy, Cout, x, Cin, M, dw, st);
+  if (Cin == 64 && Cout == 256) return launch_wgrad1x1<256, 64, 4, 4, true>(dy, Cout, x, Cin, M, dw, st);
+  if (Cin == 256 && Cout == 64) return launch_wgrad1x1<64, 256, 1, 4, true>(dy, Cout, x, Cin, M, dw, st);
+  if (Cin == 256 && Cout == 128) return launch_wgrad1x1<128, 256, 4, 8, true>(dy, Cout, x, Cin, M, dw, st);
+  if (Cin == 128 && Cout == 512) return launch_wgrad1x1<256, 128, 4, 8, true>(dy, Cout, x, Cin, M, dw, st);  // two 256-row halves of dW
+  return launch_wgrad1x1<128, 256, 2, 8, false>(dy, Cout, x, Cin, M, dw, st);                                // 512 -> 128: two 256-column halves
+}
+
+namespace lec {
 }  // namespace lec
 
 // (Cin, Cout) pairs with a kernel instance; M = N*H*W must be a multiple of 32

@@ -404,6 +404,20 @@ def conv3x3_c64(x, w_clast, want_stats=False, w_transposed=False):
     return y
 
 
+def conv1x1_wgrad_supported(cin, cout, M):
+    return bool(lib.lec_conv1x1_wgrad_supported(int(cin), int(cout), int(M)))
+
+
+def conv1x1_wgrad_rows(dy_rows, x_rows, dw):
+    """dw[Cout, Cin] (fp32, contiguous) += dy[M, Cout]^T @ x[M, Cin] on the MFMA weight-gradient kernel (float atomics)."""
+    M, cout = dy_rows.shape
+    cin = x_rows.shape[1]
+    if dw.dtype != torch.float32 or dw.numel() != cout * cin or not dw.is_contiguous():
+        raise ValueError('dw must be a contiguous float32 [Cout, Cin] buffer')
+    check(lib.lec_conv1x1_wgrad(dptr(dy_rows), dptr(x_rows), M, cin, cout, dptr(dw), stream_ptr()))
+    return dw
+
+
 def conv1x1_rows(x_rows, w2, want_stats=False, w_transposed=False):
     """y[M, Cout] = x[M, Cin] @ w[Cout, Cin]^T on the hand-written MFMA kernel (lec_conv1x1_fwd); with want_stats the
     per-channel sum / sum-of-squares partials of y are left in the BatchNorm workspace for the BN that follows

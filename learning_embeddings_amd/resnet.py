@@ -79,8 +79,28 @@ class WgradOverlap:
         if self.reducer is not None:
             self.reducer.mark_ready(w)
 
+    def _own_wgrad(self, gy, x, conv):
+        """The wide 1x1 layers: liblecone's MFMA weight-gradient kernel adds dY^T X straight into the arena's fp32 gradient
+        slot (zeroed at the start of the step) -- no library kernel, zero-fill, cast or copy.  False when not applicable."""
+        w = conv.weight
+        if not (MFMA_WGRAD and self.arena is not None and _is_pointwise(conv) and w.grad is not None and w.grad.dtype == torch.float32
+                and gy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
+                and gy.is_contiguous(memory_format=torch.channels_last) and x.is_contiguous(memory_format=torch.channels_last)):
+            return False
+        ops = _ops()
+        m = gy.shape[0] * gy.shape[2] * gy.shape[3]
+        if not ops.conv1x1_wgrad_supported(conv.in_channels, conv.out_channels, m):
+            return False
+        gw = w.grad.view(conv.out_channels, conv.in_channels)      # a 1x1 weight is [Cout][Cin] in memory in either layout
+        ops.conv1x1_wgrad_rows(_rows(gy), _rows(x), gw)
+        if self.reducer is not None:
+            self.reducer.mark_ready(w)
+        return True
+
     def submit(self, gy, x, w16, conv):
         if self.side is None:
+            if self._own_wgrad(gy, x, conv):
+                return
             gw = torch.ops.aten.convolution_backward(gy, x, w16, None, conv.stride, conv.padding, conv.dilation, False,
                                                      [0, 0], conv.groups, [False, True, False])[1]
             self._finish_wgrad(gw, conv)
@@ -89,12 +109,15 @@ class WgradOverlap:
         ev = torch.cuda.Event(); ev.record(main)
         with torch.cuda.stream(self.side):
             self.side.wait_event(ev)
-            gw = torch.ops.aten.convolution_backward(gy, x, w16, None, conv.stride, conv.padding, conv.dilation, False,
-                                                     [0, 0], conv.groups, [False, True, False])[1]
+            own = self._own_wgrad(gy, x, conv)
+            if not own:
+                gw = torch.ops.aten.convolution_backward(gy, x, w16, None, conv.stride, conv.padding, conv.dilation, False,
+                                                         [0, 0], conv.groups, [False, True, False])[1]
             for t in (gy, x, w16):
                 t.record_stream(self.side)                 # the caching allocator must not recycle them under the side stream
                                                            # (under hipGraph capture such blocks are held until the capture ends)
-            self._finish_wgrad(gw, conv)
+            if not own:
+                self._finish_wgrad(gw, conv)
 
     def join(self):
         if self.side is not None:
@@ -120,6 +143,12 @@ MFMA_3X3 = os.environ.get('LEC_CONV3X3_MFMA', '1') != '0'
 # leads it in the data gradient (207 vs 245 us); no measurable gain inside the step, so it stays opt-in:
 # '0' (default) nowhere, 'dgrad' data gradient only, '1' everywhere
 MFMA_3X3_C128 = os.environ.get('LEC_CONV3X3_C128', '0')
+# the weight gradient of the same wide 1x1 layers: liblecone's MFMA kernel (lec_conv1x1_wgrad) accumulates dY^T X into the
+# arena's fp32 gradient slot with float atomics -- alone 179 us against the library's 204 us (+ cast and copy kernels) at
+# 64 -> 256 @56x56 (tools/bench_conv1x1_wgrad.py), but inside the step, where it shares the GPU with the main stream's
+# HBM-bound kernels, the step time is unchanged (46.2 / 45.7 ms off, 45.8 / 45.9 ms on): opt-in, because float atomics
+# also make the summation order (not the value to fp32 tolerance) vary from run to run
+MFMA_WGRAD = os.environ.get('LEC_CONV1X1_WGRAD', '0') != '0'
 GEMM_FWD_MIN_CIN = 1024
 GEMM_DGRAD_MIN_CIN = 256
 

@@ -182,6 +182,43 @@ def test_wgrad_side_stream_overlap_matches_inline_and_fp32():
         assert (a - b).abs().max().item() < 0.02 * b.abs().max().item()
 
 
+@pytest.mark.parametrize('cin,cout,hw', [(64, 256, 16), (256, 64, 16), (128, 512, 8), (512, 128, 8)])
+def test_pointwise_conv_own_weight_gradient_into_arena(cin, cout, hw):
+    """LEC_CONV1X1_WGRAD path: liblecone's MFMA weight-gradient kernel adds dY^T X straight into the flat arena's fp32 gradient
+    slot on the side stream; equals the fp32 convolution's weight gradient (tighter than the library path, whose result is
+    rounded to bf16 first) and accumulates over two backward passes."""
+    from learning_embeddings_amd import resnet
+    from learning_embeddings_amd.parallel import FlatArena
+    from learning_embeddings_amd.resnet import WgradOverlap, Conv2d
+    torch.manual_seed(cin + cout)
+    conv = Conv2d(cin, cout, kernel_size=1, bias=False).to(DEV).to(memory_format=torch.channels_last)
+    conv.train()
+    arena = FlatArena(list(conv.parameters()))
+    x = torch.randn(16, cin, hw, hw, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(16, cout, hw, hw, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    xr = x.float(); wr = conv.weight.detach().float().requires_grad_(True)
+    F.conv2d(xr, wr).backward(g.float())
+    grads = {}
+    prev = resnet.MFMA_WGRAD
+    try:
+        for own in (True, False):
+            resnet.MFMA_WGRAD = own
+            arena.zero_grad()
+            WgradOverlap.instance = WgradOverlap(arena=arena)
+            for _ in range(2 if own else 1):
+                with torch.autocast('cuda', dtype=torch.bfloat16):
+                    y = conv(x.clone().requires_grad_(True))
+                y.backward(g)
+            WgradOverlap.instance.join(); torch.cuda.synchronize()
+            grads[own] = conv.weight.grad.detach().float().clone() / (2 if own else 1)
+    finally:
+        WgradOverlap.instance = None
+        resnet.MFMA_WGRAD = prev
+    scale = wr.grad.abs().max().item()
+    assert (grads[True] - wr.grad).abs().max().item() < 1e-4 * scale
+    assert (grads[False] - wr.grad).abs().max().item() < 1e-2 * scale
+
+
 @pytest.mark.parametrize('cin,cout,hw', [(256, 64, 14), (1024, 256, 7), (64, 256, 14), (2048, 512, 7)])
 def test_pointwise_conv_gemm_dispatch_matches_fp32(cin, cout, hw):
     """1x1 stride-1 convs: forward (Cin >= 1024) and data gradient (Cin >= 256) go out as hipBLASLt GEMMs on the NHWC

@@ -502,6 +502,35 @@ def test_conv1x1_mfma_vs_fp32_matmul_and_statistics(cin, cout, M):
     ops._BN_WS_OWNER[0] = 0
 
 
+@pytest.mark.parametrize('cin,cout,M', [(64, 64, 64), (64, 256, 64 * 5), (256, 64, 64 * 300), (256, 128, 64 * 257), (128, 512, 64 * 513),
+                                        (512, 128, 64 * 700)])
+def test_conv1x1_wgrad_mfma_vs_fp32_matmul(cin, cout, M):
+    """lec_conv1x1_wgrad: dw += dy^T x (bf16 in, fp32 accumulate, float atomics into the caller's buffer) against an fp32
+    matmul -- integer-valued data first (every product and sum exact: the result must be bit-equal), then random data; the
+    buffer's previous content is kept (accumulation across calls)."""
+    assert ops.conv1x1_wgrad_supported(cin, cout, M) and not ops.conv1x1_wgrad_supported(cin, cout, M + 32) and not ops.conv1x1_wgrad_supported(96, 256, M)
+    g = torch.Generator(device='cpu').manual_seed(cin * 3 + cout)
+    rows = min(M, 64 * 64)
+    xi = torch.randint(-3, 4, (rows, cin), generator=g).float(); dyi = torch.randint(-2, 3, (rows, cout), generator=g).float()
+    reps = M // rows; tail = M - reps * rows
+    def tile(t):
+        return torch.cat([t.repeat(reps, 1), t[:tail]], 0).to(DEV).to(torch.bfloat16)
+    x, dy = tile(xi), tile(dyi)
+    dw = torch.zeros(cout, cin, device=DEV)
+    ops.conv1x1_wgrad_rows(dy, x, dw)
+    ref = (dy.float().double().t() @ x.float().double())
+    assert torch.equal(dw.double(), ref)                                                       # |sums| < 2^24: exact in fp32
+    ops.conv1x1_wgrad_rows(dy, x, dw)
+    assert torch.equal(dw.double(), 2 * ref)
+    x = tile(torch.randn(rows, cin, generator=g) * 0.7); dy = tile(torch.randn(rows, cout, generator=g) * 0.1)
+    dw = torch.full((cout, cin), 0.5, device=DEV)
+    ops.conv1x1_wgrad_rows(dy, x, dw)
+    ref = dy.float().double().t() @ x.float().double() + 0.5
+    assert ((dw.double() - ref).abs().max() / ref.abs().max()).item() < 2e-5
+    with pytest.raises(ValueError):
+        ops.conv1x1_wgrad_rows(dy, x, dw.half())
+
+
 def test_conv1x1_statistics_feed_batchnorm():
     """conv (MFMA kernel, statistics in the epilogue) -> BatchNorm (no statistics pass) equals conv -> full BatchNorm."""
     g = torch.Generator(device='cpu').manual_seed(5)
