@@ -163,6 +163,8 @@ class GradientReducer:
         self.extra = list(extra)
         self.enabled = world_size() > 1 or (dist.is_initialized() and bool(os.environ.get('LEC_FORCE_DIST')))
         self.live = True             # False: hooks are muted (gradients produced by a hipGraph replay; see reduce_now)
+        self.side_streams = []       # streams other than the autograd one that write gradients (WgradOverlap registers its own)
+        self._launch = None          # stream the bucket all-reduces are issued from (waits for every producer stream)
         self.handles = []
         self.buckets = []            # (start, end, [param indices])
         cap = int(bucket_mb * 1024 * 1024 / 4)
@@ -208,8 +210,23 @@ class GradientReducer:
             self._pending[bi] -= 1
             if self._pending[bi] == 0:
                 lo, hi = self._spans[bi]
-                self.handles.append(dist.all_reduce(self.arena.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+                self.handles.append(self._launch_bucket(self.arena.grad[lo:hi]))
         return hook
+
+    def _launch_bucket(self, flat):
+        """Issue one bucket's all-reduce.  The bucket's gradients come from more than one stream (BatchNorm / fc gradients
+        from the autograd stream, convolution weight gradients from WgradOverlap's side stream) and the parameter that
+        completes the bucket may report from either: the collective is issued from a third stream that waits for all of
+        them, so neither producer stream stalls and the reduction never reads a gradient still being written."""
+        if not (flat.is_cuda and self.side_streams):
+            return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        if self._launch is None:
+            self._launch = torch.cuda.Stream()
+        self._launch.wait_stream(torch.cuda.current_stream())
+        for s in self.side_streams:
+            self._launch.wait_stream(s)
+        with torch.cuda.stream(self._launch):
+            return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def mark_ready(self, p):
         """Manual form of the post-accumulate hook, for gradients written outside autograd (e.g. weight gradients computed

@@ -63,6 +63,8 @@ class WgradOverlap:
         self.reducer = reducer
         self.arena = arena
         self.enabled = True
+        if reducer is not None and self.side is not None and hasattr(reducer, 'side_streams'):
+            reducer.side_streams.append(self.side)
 
     def weight_lp(self, conv, dtype):
         w16 = self.arena.lowp_view(conv.weight) if (self.arena is not None and dtype == torch.bfloat16) else None
