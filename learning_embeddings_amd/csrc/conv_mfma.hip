@@ -1056,9 +1056,8 @@ static int launch_wgrad1x1(const void* dy, int CoutTot, const void* x, int CinTo
   }
   const int ny = SPLIT_CO ? CoutTot / KO : CinTot / KI;
   const int64_t nchunks = M / 64;
-  static const int per_cu = [] { const char* e = getenv("LEC_WGRAD_WG_PER_CU"); return e ? atoi(e) : 0; }();
-  static const int blocks = [] { const char* e = getenv("LEC_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();
-  const int want = (blocks > 0 ? blocks : 256 * (per_cu > 0 ? per_cu : (smem <= 80 * 1024 ? 2 : 1))) / ny;
+  // two workgroups per CU where their LDS images fit (measured: 5.8 against 5.7 TB/s with one; three: 5.4), one otherwise
+  const int want = 256 * (smem <= 80 * 1024 ? 2 : 1) / ny;
   const int nblk = (int)(nchunks < want ? nchunks : want);
   hipLaunchKernelGGL((wgrad1x1_kernel<KO, KI, WCO, NW, SPLIT_CO>), dim3(nblk, ny), dim3(NW * 64), smem, st, (const unsigned short*)dy, CoutTot,
                      (const unsigned short*)x, CinTot, M, dW);
