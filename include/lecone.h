@@ -223,6 +223,23 @@ int lec_bn_bwd(const void* dy, const void* dy2, const void* y, const uint8_t* re
 int lec_conv1x1_supported(int Cin, int Cout, int64_t M);
 int lec_conv1x1_fwd(const void* x, const void* w, int w_transposed, int64_t M, int Cin, int Cout, void* y, float* partials,
                     int64_t partials_bytes, int* n_partials, lec_stream_t stream);
+/* Data gradient of a 1x1 layer whose INPUT is the forked output z = relu(bn(x_bn) + residual) of a bottleneck block
+ * (torchvision Bottleneck.forward as reached from oe_h.py:311,317: z feeds the next block's conv1 and its identity branch), with
+ * pass 1 of that BatchNorm's backward folded into the epilogue: g = relu_mask * (dy W + dy2) (bf16), where dy2 is the
+ * identity branch's gradient, written instead of the raw product, plus per-workgroup partials of (sum g, sum g * xhat) in the
+ * layout lec_bn_bwd_prereduced consumes.  Replaces lec_conv1x1_fwd(w_transposed) + the reduce pass of lec_bn_bwd: one write and
+ * one read of the [M, Cout] gradient less.  dy [M, Cin], w as for lec_conv1x1_fwd, dy2 / bn_x / g [M, Cout] bf16, relu_mask
+ * [M, Cout / 8].  Shapes: lec_conv1x1_dgrad_bnfold_supported ((64, 256), (128, 512); M % 32 == 0). */
+int lec_conv1x1_dgrad_bnfold_supported(int Cin, int Cout, int64_t M);
+int lec_conv1x1_dgrad_bnfold(const void* dy, const void* w, int w_transposed, int64_t M, int Cin, int Cout, const void* dy2,
+                             const void* bn_x, const uint8_t* relu_mask, const float* save_mean, const float* save_invstd, void* g,
+                             float* partials, int64_t partials_bytes, int* n_partials, lec_stream_t stream);
+/* The rest of that BatchNorm backward: finalize (d gamma, d beta, coefficients) from n_partials partial rows at the start
+ * of `workspace`, then dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)).  The gradient of the residual branch is
+ * g itself. */
+int lec_bn_bwd_prereduced(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean,
+                          const float* save_invstd, int n_partials, void* dx, float* dgamma, float* dbeta, void* workspace,
+                          int64_t workspace_bytes, lec_stream_t stream);
 /* Weight gradient of the same 1x1 layers: dw[Cout][Cin] (fp32) += dy[M, Cout]^T x[M, Cin], accumulated with float atomics
  * straight into the caller's gradient buffer (which must hold the running sum, e.g. zero at the start of a step):
  * replaces the library's weight-gradient kernel together with its zero-fill, its fp32 -> bf16 cast and the copy into the

@@ -442,6 +442,27 @@ extern "C" int lec_bn_bwd(const void* dy, const void* dy2, const void* y, const 
   return LEC_OK;
 }
 
+extern "C" int lec_bn_bwd_prereduced(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean,
+                                     const float* save_invstd, int n_partials, void* dx, float* dgamma, float* dbeta, void* workspace,
+                                     int64_t workspace_bytes, lec_stream_t stream) {
+  using namespace lec;
+  if (int rc = bn_check("bn_bwd_prereduced", M, C)) return rc;
+  LEC_CHECK_ARG(g && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && workspace, "bn_bwd_prereduced: null pointer");
+  LEC_CHECK_ARG(n_partials >= 1 && n_partials <= kBnMaxBlocks, "bn_bwd_prereduced: n_partials=%d outside 1..%d", n_partials, kBnMaxBlocks);
+  LEC_CHECK_ARG(workspace_bytes >= lec_bn_workspace_bytes(C), "bn_bwd_prereduced: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  BnGeom geo = bn_geom(M, C);
+  float* part = (float*)workspace;
+  float* c1 = part + (int64_t)kBnMaxBlocks * 2 * C; float* c2 = c1 + C;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, n_partials, C, M, dgamma, dbeta, c1, c2);
+  int64_t nb = (M + geo.RPI - 1) / geo.RPI; nb = (nb + 1) / 2;
+  const int nblk = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<false, 0>), dim3(nblk), dim3(kBnThreads), 0, st, (const bf16x8*)g, (const bf16x8*)nullptr,
+                     (const bf16x8*)nullptr, (const bf16x8*)x, M, geo.CV, geo.RPI, gamma, save_mean, save_invstd, c1, c2, (bf16x8*)dx, (bf16x8*)nullptr);
+  LEC_CHECK_LAUNCH("bn_bwd_prereduced kernels");
+  return LEC_OK;
+}
+
 extern "C" int lec_bn_fwd_prestat(const void* x, const void* residual, int64_t M, int C, const float* gamma, const float* beta,
                                   float eps, float momentum, float* running_mean, float* running_var, int n_partials,
                                   float* save_mean, float* save_invstd, void* y, int relu, uint8_t* relu_mask, void* workspace,

@@ -38,10 +38,24 @@ constexpr int kC1MaxBlocks = 512;          // = kBnMaxBlocks: the partials land 
 // K: reduction width (input channels); N: output channels handled by ONE workgroup (blockIdx.y selects the N-wide column
 // block of an Ntot-wide output: a layer wider than its weights' LDS budget re-reads X once per column block);
 // STATS: leave the per-channel partials (forward) or not (the same kernel serves the data gradient: X := dY, W := W^T).
-template <int K, int N, bool STATS, int WAVES>
+// FOLD (data gradient feeding a forked BatchNorm+residual+ReLU output, STATS set): the epilogue is pass 1 of that
+// BatchNorm's backward.  With the strip's rows in registers on their way out it reads the other branch's gradient dy2,
+// the ReLU bitmask and the BatchNorm's input x at the same addresses, forms g = mask * (dY W + dy2) rounded to bf16, writes
+// g instead of the raw product and leaves per-channel partials of (sum g, sum g * xhat) where the forward form leaves
+// (sum y, sum y^2) -- the standalone reduce pass (read dy, dy2, x, mask; write g) and this kernel's own write of dy go away.
+struct FoldArgs {
+  const unsigned short* dy2;      // [M][Ntot] bf16
+  const unsigned short* xbn;      // [M][Ntot] bf16: input of the BatchNorm whose output this gradient belongs to
+  const unsigned char* mask;      // [M][Ntot / 8] ReLU bitmask of that output
+  const float* mean;              // [Ntot]
+  const float* invstd;            // [Ntot]
+};
+
+template <int K, int N, bool STATS, int WAVES, bool FOLD>
 __global__ __launch_bounds__(WAVES * 64) void conv1x1_fwd_stats_kernel(const unsigned short* __restrict__ X,
                                                                        const unsigned short* __restrict__ Wt, int64_t M, int Ntot,
-                                                                       unsigned short* __restrict__ Y, float* __restrict__ part, int wtrans) {
+                                                                       unsigned short* __restrict__ Y, float* __restrict__ part, int wtrans,
+                                                                       FoldArgs fa) {
   constexpr int KS = K / 16;                 // k-steps of one MFMA
   constexpr int NC = N / 64;                 // 64-channel chunks of the epilogue
   Y += (int64_t)blockIdx.y * N;
@@ -51,9 +65,16 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_fwd_stats_kernel(const uns
   unsigned short* Ws = smem;                                     // [N][WLD]
   unsigned short* Ys = Ws + N * WLD + (threadIdx.x >> 6) * 32 * YLD;   // per wave [32][YLD]
   float* Ss = (float*)(smem + N * WLD);                         // [4 waves][2][N]: end of the launch only, reuses the Y tiles
+  float* Ms = (float*)(smem + N * WLD + WAVES * 32 * YLD);      // FOLD: [2][N] mean, invstd of this column block
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
+  if (FOLD) {
+    for (int e = threadIdx.x; e < N; e += WAVES * 64) {
+      Ms[e] = fa.mean[(int)blockIdx.y * N + e];
+      Ms[N + e] = fa.invstd[(int)blockIdx.y * N + e];
+    }
+  }
   // ---- weights -> LDS, once.  wtrans: the matrix arrives as [K][Ntot] (the FORWARD weight of the layer whose data gradient
   // this launch is) and is transposed on the way in -- no transpose kernel per layer and step
   if (!wtrans) {
@@ -96,6 +117,24 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_fwd_stats_kernel(const uns
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
+      // FOLD: this chunk's epilogue operands, requested before the MFMAs (lane -> rows (lane >> 3) + 8 i, 8 channels)
+      u32x4_t f_d2[4], f_x[4];
+      unsigned int f_m[4];
+      float f_mu[8], f_is[8];
+      if (FOLD) {
+        // addresses as (wave-uniform 64-bit base) + (one 32-bit lane offset): spelled out, the compiler otherwise keeps a
+        // 64-bit vector address per tensor, chunk and row alive across the strip loop (~100 registers)
+        const int su = __builtin_amdgcn_readfirstlane((int)s);
+        const int64_t ub = ((int64_t)su * 32) * Ntot + (int)blockIdx.y * N + c * 64;
+        const int loff = (lane >> 3) * Ntot + (lane & 7) * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t ue = ub + (int64_t)(8 * i) * Ntot;
+          f_x[i] = __builtin_nontemporal_load((const u32x4_t*)(fa.xbn + ue + loff));
+          f_d2[i] = __builtin_nontemporal_load((const u32x4_t*)(fa.dy2 + ue + loff));
+          f_m[i] = (unsigned int)(fa.mask + (ue >> 3))[loff >> 3];
+        }
+      }
       f32x16_t acc[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -124,15 +163,37 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_fwd_stats_kernel(const uns
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       // rows back out as 16-byte segments: lane -> rows (lane >> 3) + 8 i, channels c*64 + (lane & 7) * 8 .. + 8
       const int cc = lane & 7, r0 = lane >> 3;
+      if (FOLD) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { f_mu[j] = Ms[c * 64 + cc * 8 + j]; f_is[j] = Ms[N + c * 64 + cc * 8 + j]; }
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = r0 + 8 * i;
-        const u32x4_t v = *(const u32x4_t*)(Ys + row * YLD + cc * 8);
+        u32x4_t v = *(const u32x4_t*)(Ys + row * YLD + cc * 8);
         const unsigned int w4[4] = {v.x, v.y, v.z, v.w};
+        if (FOLD) {
+          const unsigned int d4[4] = {f_d2[i].x, f_d2[i].y, f_d2[i].z, f_d2[i].w};
+          const unsigned int x4[4] = {f_x[i].x, f_x[i].y, f_x[i].z, f_x[i].w};
+          unsigned int o4[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float f = c1_bf2f((unsigned short)(w4[j >> 1] >> ((j & 1) * 16)));
-          if (STATS) { st_s[c][j] += f; st_q[c][j] += f * f; }
+          for (int j = 0; j < 8; ++j) {
+            float a = c1_bf2f((unsigned short)(w4[j >> 1] >> ((j & 1) * 16)));
+            a += c1_bf2f((unsigned short)(d4[j >> 1] >> ((j & 1) * 16)));
+            a = (f_m[i] >> j) & 1u ? a : 0.0f;
+            const unsigned short gb = c1_f2bf(a);
+            a = c1_bf2f(gb);
+            st_s[c][j] += a;
+            st_q[c][j] += a * ((c1_bf2f((unsigned short)(x4[j >> 1] >> ((j & 1) * 16))) - f_mu[j]) * f_is[j]);
+            o4[j >> 1] |= (unsigned int)gb << ((j & 1) * 16);
+          }
+          v.x = o4[0]; v.y = o4[1]; v.z = o4[2]; v.w = o4[3];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float f = c1_bf2f((unsigned short)(w4[j >> 1] >> ((j & 1) * 16)));
+            if (STATS) { st_s[c][j] += f; st_q[c][j] += f * f; }
+          }
         }
         __builtin_nontemporal_store(v, (u32x4_t*)(Y + (s * 32 + row) * Ntot + c * 64 + cc * 8));
       }
@@ -178,16 +239,18 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_fwd_stats_kernel(const uns
   }
 }
 
-template <int K, int N, bool STATS>
-static int launch_conv1x1(const void* x, const void* w, int64_t M, int Ntot, void* y, float* part, int* nblk_out, int wtrans, hipStream_t st) {
+template <int K, int N, bool STATS, bool FOLD = false>
+static int launch_conv1x1(const void* x, const void* w, int64_t M, int Ntot, void* y, float* part, int* nblk_out, int wtrans, hipStream_t st,
+                          FoldArgs fa = FoldArgs{nullptr, nullptr, nullptr, nullptr, nullptr}) {
   // eight waves per workgroup (two per SIMD) for K <= 128 (128 -> 512: 117 -> 105 us); the K = 256 instances, whose
   // fragment sets already fill the registers, measured better with four (256 -> 128: 229 vs 241 us)
-  constexpr int WAVES = (K <= 128 && ((size_t)N * (K + 8) + 8 * 32 * (64 + 8)) * sizeof(unsigned short) <= 160 * 1024) ? 8 : 4;
+  // (the FOLD epilogue's operand sets need more than the 256 registers per lane of an eight-wave workgroup: four waves)
+  constexpr int WAVES = (!FOLD && K <= 128 && ((size_t)N * (K + 8) + 8 * 32 * (64 + 8)) * sizeof(unsigned short) <= 160 * 1024) ? 8 : 4;
   static_assert(WAVES * 2 * N * sizeof(float) <= WAVES * 32 * (64 + 8) * sizeof(unsigned short), "statistics staging must fit the Y tiles");
-  const size_t smem = ((size_t)N * (K + 8) + WAVES * 32 * (64 + 8)) * sizeof(unsigned short);
+  const size_t smem = ((size_t)N * (K + 8) + WAVES * 32 * (64 + 8)) * sizeof(unsigned short) + (FOLD ? 2 * N * sizeof(float) : 0);
   static bool attr_set = false;
   if (smem > 64 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv1x1_fwd_stats_kernel<K, N, STATS, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)conv1x1_fwd_stats_kernel<K, N, STATS, WAVES, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv1x1)");
     attr_set = true;
   }
@@ -196,8 +259,8 @@ static int launch_conv1x1(const void* x, const void* w, int64_t M, int Ntot, voi
   int cap = kC1MaxBlocks / (Ntot / N) > 0 ? kC1MaxBlocks / (Ntot / N) : 1;
   if (WAVES == 8 && cap > 256) cap = 256;
   const int nblk = (int)(nb > cap ? cap : nb);
-  hipLaunchKernelGGL((conv1x1_fwd_stats_kernel<K, N, STATS, WAVES>), dim3(nblk, Ntot / N), dim3(WAVES * 64), smem, st, (const unsigned short*)x,
-                     (const unsigned short*)w, M, Ntot, (unsigned short*)y, part, wtrans);
+  hipLaunchKernelGGL((conv1x1_fwd_stats_kernel<K, N, STATS, WAVES, FOLD>), dim3(nblk, Ntot / N), dim3(WAVES * 64), smem, st, (const unsigned short*)x,
+                     (const unsigned short*)w, M, Ntot, (unsigned short*)y, part, wtrans, fa);
   if (nblk_out) *nblk_out = nblk;
   LEC_CHECK_LAUNCH("conv1x1_fwd_stats_kernel");
   return LEC_OK;
@@ -1093,6 +1156,24 @@ namespace lec {
 extern "C" int lec_conv1x1_supported(int Cin, int Cout, int64_t M) {
   const bool shape = (Cin == 64 && (Cout == 64 || Cout == 256)) || (Cin == 128 && (Cout == 256 || Cout == 512)) || (Cin == 256 && (Cout == 64 || Cout == 128)) || (Cin == 512 && Cout == 128);
   return shape && M > 0 && M % 32 == 0;
+}
+
+extern "C" int lec_conv1x1_dgrad_bnfold_supported(int Cin, int Cout, int64_t M) {
+  return ((Cin == 64 && Cout == 256) || (Cin == 128 && Cout == 512)) && M > 0 && M % 32 == 0;
+}
+
+extern "C" int lec_conv1x1_dgrad_bnfold(const void* dy, const void* w, int w_transposed, int64_t M, int Cin, int Cout, const void* dy2,
+                                        const void* bn_x, const uint8_t* relu_mask, const float* save_mean, const float* save_invstd, void* g,
+                                        float* partials, int64_t partials_bytes, int* n_partials, lec_stream_t stream) {
+  using namespace lec;
+  LEC_CHECK_ARG(dy && w && dy2 && bn_x && relu_mask && save_mean && save_invstd && g && partials && n_partials, "conv1x1_dgrad_bnfold: null pointer");
+  LEC_CHECK_ARG(lec_conv1x1_dgrad_bnfold_supported(Cin, Cout, M), "conv1x1_dgrad_bnfold: unsupported shape Cin=%d Cout=%d M=%lld", Cin, Cout,
+                (long long)M);
+  LEC_CHECK_ARG(partials_bytes >= (int64_t)kC1MaxBlocks * 2 * Cout * (int64_t)sizeof(float), "conv1x1_dgrad_bnfold: partials buffer too small");
+  const FoldArgs fa{(const unsigned short*)dy2, (const unsigned short*)bn_x, (const unsigned char*)relu_mask, save_mean, save_invstd};
+  hipStream_t st = (hipStream_t)stream;
+  if (Cin == 64) return launch_conv1x1<64, 256, true, true>(dy, w, M, Cout, g, partials, n_partials, w_transposed, st, fa);
+  return launch_conv1x1<128, 256, true, true>(dy, w, M, Cout, g, partials, n_partials, w_transposed, st, fa);
 }
 
 extern "C" int lec_conv1x1_fwd(const void* x, const void* w, int w_transposed, int64_t M, int Cin, int Cout, void* y, float* partials,

@@ -335,6 +335,13 @@ class BNActFn(torch.autograd.Function):
             ctx.save_for_backward(x, mask, weight, save_mean, save_invstd)
             ctx.meta = (M, Cc, bool(relu), residual is not None)
             ctx.sink = sink                       # (weight Parameter, bias Parameter, reducer or None): write d gamma / d beta in place
+            ctx.res_ptr = residual.data_ptr() if residual is not None else 0
+            ctx.out_ptr = y.data_ptr()
+            if fork and FOLD_BN_BWD and residual is not None:
+                if len(_FORKS) > 64:              # forward passes that never ran backward
+                    _FORKS.clear()
+                # what the consumer convolution's data gradient needs to run pass 1 of THIS layer's backward in its epilogue
+                _FORKS[y.data_ptr()] = {'x': x, 'mask': mask, 'mean': save_mean, 'invstd': save_invstd, 'dres': None}
         if fork:
             return y, y.as_strided(y.size(), y.stride())
         return y
@@ -351,8 +358,16 @@ class BNActFn(torch.autograd.Function):
             dy = dy.contiguous(memory_format=torch.channels_last)
         if dy2 is not None and not dy2.is_contiguous(memory_format=torch.channels_last):
             dy2 = dy2.contiguous(memory_format=torch.channels_last)
+        _FORKS.pop(ctx.out_ptr, None)
+        pre = 0                                   # > 0: dy is already g = mask * (dy + dy2) and its partial sums sit in the workspace
+        if dy.data_ptr() in _FOLDED:
+            tag = _FOLDED.pop(dy.data_ptr())
+            if _BN_WS_OWNER[0] == dy.data_ptr() and _BN_WS_OWNER[1] == tag:
+                pre = tag
+            dy2 = None                            # already folded into dy, and so is the ReLU mask
+            relu = False; mask = None
         dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if has_res else None
+        dres = (dy if pre else torch.empty_like(x)) if has_res else None      # folded: the residual branch's gradient IS g
         sink = ctx.sink
         if sink is not None and sink[0].grad is not None and sink[1].grad is not None:
             dgamma, dbeta = sink[0].grad, sink[1].grad           # the flat arena's slots: no AccumulateGrad kernels
@@ -366,9 +381,16 @@ class BNActFn(torch.autograd.Function):
             nbytes = el * ((4 + (2 if dy2 is not None else 0) + 2) + (4 + 2)) + (el // 8 if relu else 0)
         else:            # both passes read dy [+ dy2], x, mask; pass 2 writes dx
             nbytes = el * (2 * (4 + (2 if dy2 is not None else 0)) + 2) + (2 * (el // 8) if relu else 0)
-        _bn_timed(lambda: check(lib.lec_bn_bwd(dptr(dy), dptr(dy2), None, dptr(mask), dptr(x), M, Cc, dptr(weight), dptr(save_mean),
-                                               dptr(save_invstd), dptr(dx), dptr(dres), dptr(dgamma), dptr(dbeta), int(relu),
-                                               dptr(ws), ws.numel(), stream_ptr())), nbytes)
+        if pre:
+            nbytes = el * 6                       # pass 2 only: read g, x; write dx (pass 1 ran in the convolution's epilogue)
+            _bn_timed(lambda: check(lib.lec_bn_bwd_prereduced(dptr(dy), dptr(x), M, Cc, dptr(weight), dptr(save_mean), dptr(save_invstd), pre,
+                                                              dptr(dx), dptr(dgamma), dptr(dbeta), dptr(ws), ws.numel(), stream_ptr())), nbytes)
+        else:
+            _bn_timed(lambda: check(lib.lec_bn_bwd(dptr(dy), dptr(dy2), None, dptr(mask), dptr(x), M, Cc, dptr(weight), dptr(save_mean),
+                                                   dptr(save_invstd), dptr(dx), dptr(dres), dptr(dgamma), dptr(dbeta), int(relu),
+                                                   dptr(ws), ws.numel(), stream_ptr())), nbytes)
+        if has_res and ctx.res_ptr in _FORKS:     # this layer's residual is a forked block output: its consumer convolution's data
+            _FORKS[ctx.res_ptr]['dres'] = dres    # gradient can fold this gradient into its epilogue (conv1x1_dgrad_bnfold_rows)
         if sink is not None:
             if sink[2] is not None:
                 sink[2].mark_ready(sink[0]); sink[2].mark_ready(sink[1])
@@ -376,6 +398,15 @@ class BNActFn(torch.autograd.Function):
         return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
+# Backward of a forked block output z = relu(bn(x) + residual) (two consumers: the next block's conv1 and its identity branch):
+# pass 1 of the BatchNorm backward can run in the epilogue of conv1's data gradient (lec_conv1x1_dgrad_bnfold), which needs this
+# layer's saved tensors and the identity branch's gradient.  _FORKS: data_ptr of z -> those tensors (filled by forward, 'dres' by
+# the backward of the layer that took z as its residual, dropped by this layer's backward).  _FOLDED: data_ptr of a gradient that
+# already is g = mask * (dy + dy2) -> number of partial rows its producer left in the BatchNorm workspace.
+import os as _os
+FOLD_BN_BWD = _os.environ.get('LEC_FOLD_BN_BWD', '1') != '0'
+_FORKS = {}
+_FOLDED = {}
 _bn_ws = {}
 _BN_WS_OWNER = [0, 0]        # (data_ptr of the tensor whose statistics partials sit in the BN workspace, number of partial rows)
 
@@ -416,6 +447,33 @@ def conv1x1_wgrad_rows(dy_rows, x_rows, dw):
         raise ValueError('dw must be a contiguous float32 [Cout, Cin] buffer')
     check(lib.lec_conv1x1_wgrad(dptr(dy_rows), dptr(x_rows), M, cin, cout, dptr(dw), stream_ptr()))
     return dw
+
+
+def conv1x1_dgrad_bnfold_supported(cin, cout, M):
+    return bool(lib.lec_conv1x1_dgrad_bnfold_supported(int(cin), int(cout), int(M)))
+
+
+def conv1x1_dgrad_bnfold_rows(gy_rows, w2_fwd, entry):
+    """Data gradient of a 1x1 layer whose input is a forked block output, with pass 1 of that output's BatchNorm backward in
+    the epilogue (lec_conv1x1_dgrad_bnfold).  gy_rows [M, Cconv_out], w2_fwd the layer's forward weight [Cconv_out, C],
+    entry: the _FORKS record of the block output.  Returns g [M, C] = mask * (gy w + d identity) and tags it for BNActFn."""
+    M, cin = gy_rows.shape
+    cout = w2_fwd.shape[1]
+    if w2_fwd.shape[0] != cin:
+        raise ValueError('weight shape %s does not match %d gradient channels' % (tuple(w2_fwd.shape), cin))
+    xb, dres, mask = entry['x'], entry['dres'], entry['mask']
+    for t in (xb, dres):
+        if t.dtype != torch.bfloat16 or t.numel() != M * cout or not t.is_contiguous(memory_format=torch.channels_last):
+            raise ValueError('fork record does not match the gradient: expected NHWC bf16 with %d x %d elements' % (M, cout))
+    g = torch.empty((M, cout), dtype=torch.bfloat16, device=gy_rows.device)
+    ws = _bn_workspace(gy_rows.device)
+    n = C.c_int(0)
+    check(lib.lec_conv1x1_dgrad_bnfold(dptr(gy_rows), dptr(w2_fwd), 1, M, cin, cout, dptr(dres), dptr(xb), dptr(mask), dptr(entry['mean']),
+                                       dptr(entry['invstd']), dptr(g), dptr(ws), ws.numel(), C.byref(n), stream_ptr()))
+    _BN_WS_OWNER[0], _BN_WS_OWNER[1] = g.data_ptr(), n.value
+    _FOLDED.clear()
+    _FOLDED[g.data_ptr()] = n.value
+    return g
 
 
 def conv1x1_rows(x_rows, w2, want_stats=False, w_transposed=False):

@@ -213,7 +213,15 @@ class _OverlapConvFn(torch.autograd.Function):
                 gx = _ops().conv3x3_c64(gy, w16, w_transposed=True)   # which flips / transposes the weight as it loads it
             elif (ctx.own and nhwc_g and _ops().conv1x1_supported(conv.out_channels, conv.in_channels, gy.shape[0] * gy.shape[2] * gy.shape[3])):
                 n, _, h, wd = gy.shape                          # dX = dY * W: the same kernel, W transposed as it is loaded
-                gx = _from_rows(_ops().conv1x1_rows(_rows(gy), w16.reshape(conv.out_channels, conv.in_channels), w_transposed=True), n, h, wd)
+                ops = _ops()
+                fork = ops._FORKS.get(x.data_ptr()) if ops.FOLD_BN_BWD else None
+                if (fork is not None and fork['dres'] is not None and fork['x'].shape == x.shape
+                        and ops.conv1x1_dgrad_bnfold_supported(conv.out_channels, conv.in_channels, n * h * wd)):
+                    # x is a forked block output and the identity branch's gradient is already there: pass 1 of that
+                    # block's BatchNorm backward runs in this kernel's epilogue (BNActFn.backward recognises the result)
+                    gx = _from_rows(ops.conv1x1_dgrad_bnfold_rows(_rows(gy), w16.reshape(conv.out_channels, conv.in_channels), fork), n, h, wd)
+                else:
+                    gx = _from_rows(ops.conv1x1_rows(_rows(gy), w16.reshape(conv.out_channels, conv.in_channels), w_transposed=True), n, h, wd)
             elif (ctx.pointwise and conv.in_channels >= GEMM_DGRAD_MIN_CIN and nhwc_g):
                 n, _, h, wd = gy.shape
                 gx = _from_rows(torch.mm(_rows(gy), w16.reshape(conv.out_channels, conv.in_channels)), n, h, wd)

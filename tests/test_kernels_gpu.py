@@ -531,6 +531,51 @@ def test_conv1x1_wgrad_mfma_vs_fp32_matmul(cin, cout, M):
         ops.conv1x1_wgrad_rows(dy, x, dw.half())
 
 
+@pytest.mark.parametrize('cin,cout,M', [(64, 256, 32 * 70), (128, 512, 32 * 33), (64, 256, 32 * 2100)])
+def test_conv1x1_dgrad_with_batchnorm_backward_pass1_in_the_epilogue(cin, cout, M):
+    """lec_conv1x1_dgrad_bnfold: g = relu_mask * (dy W + dy2) must be bit-equal to the two-kernel path (data gradient, then pass 1
+    of lec_bn_bwd), its partials must sum to (sum g, sum g * xhat), and lec_bn_bwd_prereduced must finish the backward like
+    lec_bn_bwd does from the unfused inputs."""
+    from learning_embeddings_amd._lib import lib, check, dptr, stream_ptr
+    assert ops.conv1x1_dgrad_bnfold_supported(cin, cout, M) and not ops.conv1x1_dgrad_bnfold_supported(256, 64, M)
+    g_ = torch.Generator(device='cpu').manual_seed(cin + M)
+    gy = (torch.randn(M, cin, generator=g_) * 0.5).to(DEV).to(torch.bfloat16)
+    w = (torch.randn(cin, cout, generator=g_) * 0.2).to(DEV).to(torch.bfloat16)          # the layer's forward weight [Cout_fwd = cin][Cin_fwd = cout]
+    hw = M // 32
+    nhwc = lambda t: t.view(32, hw, 1, cout).permute(0, 3, 1, 2)                         # [N, C, H, W] channels_last view of [M, C] rows
+    dy2 = nhwc((torch.randn(M, cout, generator=g_) * 0.5).to(DEV).to(torch.bfloat16))
+    xbn = nhwc((torch.randn(M, cout, generator=g_) * 1.3 + 0.4).to(DEV).to(torch.bfloat16))
+    mask = torch.randint(0, 256, (M * cout // 8,), generator=g_, dtype=torch.int32).to(torch.uint8).to(DEV)
+    mean = (torch.randn(cout, generator=g_) * 0.3).to(DEV); invstd = (torch.rand(cout, generator=g_) + 0.5).to(DEV)
+    gamma = (torch.rand(cout, generator=g_) + 0.5).to(DEV)
+    entry = {'x': xbn, 'dres': dy2, 'mask': mask, 'mean': mean, 'invstd': invstd}
+    g = ops.conv1x1_dgrad_bnfold_rows(gy, w, entry)
+    n = ops._BN_WS_OWNER[1]
+    assert ops._BN_WS_OWNER[0] == g.data_ptr() and ops._FOLDED == {g.data_ptr(): n}
+    ws = ops._bn_workspace(gy.device)
+    part = ws[:n * 2 * cout * 4].view(torch.float32).view(n, 2, cout).double().sum(0)
+    # the two-kernel path
+    dyc = ops.conv1x1_rows(gy, w, w_transposed=True)
+    bits = ((mask.view(M, cout // 8, 1).to(torch.int32) >> torch.arange(8, device=DEV, dtype=torch.int32)) & 1).view(M, cout).bool()
+    ref = torch.where(bits, dyc.float() + dy2.permute(0, 2, 3, 1).reshape(M, cout).float(), torch.zeros((), device=DEV)).to(torch.bfloat16)
+    assert torch.equal(g, ref)
+    gd = ref.float().double(); xh = (xbn.permute(0, 2, 3, 1).reshape(M, cout).float().double() - mean.double()) * invstd.double()
+    assert ((part[0] - gd.sum(0)).abs().max() / gd.abs().sum(0).max()).item() < 1e-5
+    assert ((part[1] - (gd * xh).sum(0)).abs().max() / (gd * xh).abs().sum(0).max()).item() < 1e-5
+    # finish the backward from the partials; against lec_bn_bwd on the unfused inputs
+    dx = torch.empty_like(xbn); dgam = torch.empty(cout, device=DEV); dbet = torch.empty(cout, device=DEV)
+    check(lib.lec_bn_bwd_prereduced(dptr(g), dptr(xbn), M, cout, dptr(gamma), dptr(mean), dptr(invstd), n, dptr(dx), dptr(dgam), dptr(dbet),
+                                    dptr(ws), ws.numel(), stream_ptr()))
+    dx2 = torch.empty_like(xbn); dres2 = torch.empty_like(xbn); dgam2 = torch.empty_like(dgam); dbet2 = torch.empty_like(dbet)
+    check(lib.lec_bn_bwd(dptr(nhwc(dyc)), dptr(dy2), None, dptr(mask), dptr(xbn), M, cout, dptr(gamma), dptr(mean), dptr(invstd), dptr(dx2),
+                         dptr(dres2), dptr(dgam2), dptr(dbet2), 1, dptr(ws), ws.numel(), stream_ptr()))
+    assert torch.equal(dres2.permute(0, 2, 3, 1).reshape(M, cout), g)
+    assert torch.allclose(dgam, dgam2, rtol=1e-4, atol=1e-3) and torch.allclose(dbet, dbet2, rtol=1e-4, atol=1e-3)
+    assert (dx.float() - dx2.float()).abs().max().item() <= 2e-2 * dx2.float().abs().max().item()
+    assert (dx != dx2).float().mean().item() < 1e-3
+    ops._BN_WS_OWNER[0] = 0; ops._FOLDED.clear()
+
+
 def test_conv1x1_statistics_feed_batchnorm():
     """conv (MFMA kernel, statistics in the epilogue) -> BatchNorm (no statistics pass) equals conv -> full BatchNorm."""
     g = torch.Generator(device='cpu').manual_seed(5)
