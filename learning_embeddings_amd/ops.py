@@ -337,7 +337,7 @@ class BNActFn(torch.autograd.Function):
             ctx.sink = sink                       # (weight Parameter, bias Parameter, reducer or None): write d gamma / d beta in place
             ctx.res_ptr = residual.data_ptr() if residual is not None else 0
             ctx.out_ptr = y.data_ptr()
-            if fork and FOLD_BN_BWD and residual is not None:
+            if fork and FOLD_BN_BWD and residual is not None and ctx.needs_input_grad[0]:
                 if len(_FORKS) > 64:              # forward passes that never ran backward
                     _FORKS.clear()
                 # what the consumer convolution's data gradient needs to run pass 1 of THIS layer's backward in its epilogue
