@@ -334,7 +334,7 @@ class ResNet(nn.Module):
     def forward(self, x):
         if x.is_cuda and torch.is_autocast_enabled() and x.dtype == torch.float32:
             x = x.to(torch.get_autocast_gpu_dtype())          # the stem conv sees low-precision input like every other layer
-        _ops()._FORKS.clear()                                   # fork records of a forward whose backward never ran
+        _ops()._FORKS.clear(); _ops()._FOLDED.clear()           # records of a forward whose backward never ran (or raised)
         x = self.maxpool(self.bn1(self.conv1(x)))
         blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
         for i, b in enumerate(blocks):
