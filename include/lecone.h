@@ -229,7 +229,7 @@ int lec_conv1x1_fwd(const void* x, const void* w, int w_transposed, int64_t M, i
  * identity branch's gradient, written instead of the raw product, plus per-workgroup partials of (sum g, sum g * xhat) in the
  * layout lec_bn_bwd_prereduced consumes.  Replaces lec_conv1x1_fwd(w_transposed) + the reduce pass of lec_bn_bwd: one write and
  * one read of the [M, Cout] gradient less.  dy [M, Cin], w as for lec_conv1x1_fwd, dy2 / bn_x / g [M, Cout] bf16, relu_mask
- * [M, Cout / 8].  Shapes: lec_conv1x1_dgrad_bnfold_supported ((64, 256), (128, 512); M % 32 == 0). */
+ * [M, Cout / 8].  Shapes: lec_conv1x1_dgrad_bnfold_supported ((64, 256), (128, 256), (128, 512); M % 32 == 0). */
 int lec_conv1x1_dgrad_bnfold_supported(int Cin, int Cout, int64_t M);
 int lec_conv1x1_dgrad_bnfold(const void* dy, const void* w, int w_transposed, int64_t M, int Cin, int Cout, const void* dy2,
                              const void* bn_x, const uint8_t* relu_mask, const float* save_mean, const float* save_invstd, void* g,

@@ -1159,7 +1159,7 @@ extern "C" int lec_conv1x1_supported(int Cin, int Cout, int64_t M) {
 }
 
 extern "C" int lec_conv1x1_dgrad_bnfold_supported(int Cin, int Cout, int64_t M) {
-  return ((Cin == 64 && Cout == 256) || (Cin == 128 && Cout == 512)) && M > 0 && M % 32 == 0;
+  return ((Cin == 64 && Cout == 256) || (Cin == 128 && (Cout == 512 || Cout == 256))) && M > 0 && M % 32 == 0;
 }
 
 extern "C" int lec_conv1x1_dgrad_bnfold(const void* dy, const void* w, int w_transposed, int64_t M, int Cin, int Cout, const void* dy2,

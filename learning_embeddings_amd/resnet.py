@@ -215,7 +215,8 @@ class _OverlapConvFn(torch.autograd.Function):
                 n, _, h, wd = gy.shape                          # dX = dY * W: the same kernel, W transposed as it is loaded
                 ops = _ops()
                 fork = ops._FORKS.get(x.data_ptr()) if ops.FOLD_BN_BWD else None
-                if (fork is not None and fork['dres'] is not None and fork['x'].shape == x.shape
+                if (fork is not None and fork['dres'] is not None and fork['x'].shape == x.shape and fork['dres'].shape == x.shape
+                        and fork['dres'].dtype == torch.bfloat16 and fork['dres'].is_contiguous(memory_format=torch.channels_last)
                         and ops.conv1x1_dgrad_bnfold_supported(conv.out_channels, conv.in_channels, n * h * wd)):
                     # x is a forked block output and the identity branch's gradient is already there: pass 1 of that
                     # block's BatchNorm backward runs in this kernel's epilogue (BNActFn.backward recognises the result)
@@ -228,6 +229,10 @@ class _OverlapConvFn(torch.autograd.Function):
             else:
                 gx = torch.ops.aten.convolution_backward(gy, x, w16, None, conv.stride, conv.padding, conv.dilation, False,
                                                          [0, 0], conv.groups, [True, False, False])[0]
+        if gx is not None and x.data_ptr() in _ops()._FORKS:   # x is a forked block output and this layer one of its two consumers
+            rec = _ops()._FORKS[x.data_ptr()]
+            if rec['dres'] is None and x.data_ptr() not in _ops()._FOLDED and gx.data_ptr() not in _ops()._FOLDED:
+                rec['dres'] = gx                                # (the other consumer's data gradient may fold it into its epilogue)
         WgradOverlap.instance.submit(gy, x, w16, conv)
         return gx, None, None
 
@@ -295,8 +300,10 @@ class Bottleneck(nn.Module):
 
     def forward(self, x, fork=False):
         xa, xb = x if isinstance(x, tuple) else (x, x)          # two handles on the block input: conv path / identity path
-        idt = xb if self.downsample is None else self.downsample(xb)
         out = self.bn1(self.conv1(xa))
+        # the downsample branch is built AFTER conv1 / bn1: autograd runs later-built nodes first, so in backward the branch's
+        # gradient into the block input exists before conv1's data gradient runs and can be folded into it (ops._FORKS)
+        idt = xb if self.downsample is None else self.downsample(xb)
         out = self.bn2(self.conv2(out))
         return self.bn3(self.conv3(out), idt, fork)
 

@@ -144,7 +144,7 @@ def test_bottleneck_stage_own_convolution_kernels_match_library_path():
     assert min(cs) > 0.8 and sum(cs) / len(cs) > 0.93, (min(cs), sum(cs) / len(cs))
 
 
-@pytest.mark.parametrize('stage', ['layer1', 'layer2'])
+@pytest.mark.parametrize('stage', ['layer1', 'layer2', 'transition'])
 def test_batchnorm_backward_pass1_folded_into_conv_dgrad_matches_unfolded(stage):
     """Identity-residual bottlenecks of ResNet-50's layer1 (256 channels) / layer2 (512) through the side-stream conv path with
     and without ops.FOLD_BN_BWD: the folded form (pass 1 of a forked block output's BatchNorm backward in the epilogue of the
@@ -154,8 +154,9 @@ def test_batchnorm_backward_pass1_folded_into_conv_dgrad_matches_unfolded(stage)
     from learning_embeddings_amd.resnet import WgradOverlap
     torch.manual_seed(0)
     net = R.ResNet(R.Bottleneck, [3, 4, 6, 3])
-    blocks = list(net.layer1) if stage == 'layer1' else list(net.layer2)[1:]
-    cin = 64 if stage == 'layer1' else 512
+    # 'transition': layer1's last block into layer2's first -- the second gradient of the fork comes from the downsample branch
+    blocks = {'layer1': list(net.layer1), 'layer2': list(net.layer2)[1:], 'transition': [net.layer1[2], net.layer2[0]]}[stage]
+    cin = {'layer1': 64, 'layer2': 512, 'transition': 256}[stage]
     for b in blocks:
         b.to(DEV).to(memory_format=torch.channels_last).train()
     x0 = (torch.randn(4, cin, 16, 16, device=DEV) * 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
@@ -189,7 +190,7 @@ def test_batchnorm_backward_pass1_folded_into_conv_dgrad_matches_unfolded(stage)
         WgradOverlap.instance = None
         ops.FOLD_BN_BWD = prev
         ops.conv1x1_dgrad_bnfold_rows = orig
-    assert calls.get('fold') == 2 and 'plain' not in calls and not ops._FORKS
+    assert calls.get('fold') == (1 if stage == 'transition' else 2) and 'plain' not in calls and not ops._FORKS
     cos = lambda a, b: torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0).item()
     assert cos(res['fold'][0], res['plain'][0]) > 0.99999
     # yardstick: the unfolded path against itself (the library's 3x3 data / weight gradients are not bit-reproducible)
