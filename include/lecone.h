@@ -240,6 +240,11 @@ int lec_conv1x1_dgrad_bnfold(const void* dy, const void* w, int w_transposed, in
 int lec_bn_bwd_prereduced(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean,
                           const float* save_invstd, int n_partials, void* dx, float* dgamma, float* dbeta, void* workspace,
                           int64_t workspace_bytes, lec_stream_t stream);
+/* Weight gradient of the 3x3 / stride 1 / pad 1 / 64 -> 64 convolution (torchvision Bottleneck.conv2 of layer1, reached from
+ * oe_h.py:311,317): dw[co][ky][kx][ci] (fp32, the channels_last weight layout) += sum over pixels of dy[.., co] * x[shifted by tap, ci],
+ * accumulated with float atomics into the caller's gradient buffer.  dy, x: [N, H, W, 64] bf16; H % 8 == 0 and W % 8 == 0. */
+int lec_conv3x3_c64_wgrad_supported(int N, int H, int W);
+int lec_conv3x3_c64_wgrad(const void* dy, const void* x, int N, int H, int W, float* dw, lec_stream_t stream);
 /* Weight gradient of the same 1x1 layers: dw[Cout][Cin] (fp32) += dy[M, Cout]^T x[M, Cin], accumulated with float atomics
  * straight into the caller's gradient buffer (which must hold the running sum, e.g. zero at the start of a step):
  * replaces the library's weight-gradient kernel together with its zero-fill, its fp32 -> bf16 cast and the copy into the

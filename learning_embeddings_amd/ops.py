@@ -435,6 +435,18 @@ def conv3x3_c64(x, w_clast, want_stats=False, w_transposed=False):
     return y
 
 
+def conv3x3_c64_wgrad(dy, x, dw):
+    """dw (fp32, [64, 64, 3, 3] channels_last, i.e. memory [co][ky][kx][ci]) += weight gradient of the 3x3 / stride 1 / pad 1
+    convolution from dy, x [N, 64, H, W] channels_last bf16 (MFMA kernel, float atomics)."""
+    n, c, h, w = x.shape
+    if c != 64 or dy.shape != x.shape or not (dy.is_contiguous(memory_format=torch.channels_last) and x.is_contiguous(memory_format=torch.channels_last)):
+        raise ValueError('conv3x3_c64_wgrad: need NHWC [N, 64, H, W] tensors of equal shape')
+    if dw.dtype != torch.float32 or tuple(dw.shape) != (64, 64, 3, 3) or not dw.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError('dw must be a float32 [64, 64, 3, 3] channels_last buffer')
+    check(lib.lec_conv3x3_c64_wgrad(dptr(dy), dptr(x), n, h, w, dptr(dw), stream_ptr()))
+    return dw
+
+
 def conv1x1_wgrad_supported(cin, cout, M):
     return bool(lib.lec_conv1x1_wgrad_supported(int(cin), int(cout), int(M)))
 

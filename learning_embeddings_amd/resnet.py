@@ -85,6 +85,16 @@ class WgradOverlap:
         """The wide 1x1 layers: liblecone's MFMA weight-gradient kernel adds dY^T X straight into the arena's fp32 gradient
         slot (zeroed at the start of the step) -- no library kernel, zero-fill, cast or copy.  False when not applicable."""
         w = conv.weight
+        if (MFMA_WGRAD_3X3 and self.arena is not None and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+                and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels == 64 and conv.out_channels == 64
+                and w.grad is not None and w.grad.dtype == torch.float32 and w.grad.is_contiguous(memory_format=torch.channels_last)
+                and gy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and gy.shape == x.shape
+                and gy.is_contiguous(memory_format=torch.channels_last) and x.is_contiguous(memory_format=torch.channels_last)
+                and x.shape[2] % 8 == 0 and x.shape[3] % 8 == 0):
+            _ops().conv3x3_c64_wgrad(gy, x, w.grad)                # layer1's 3x3: MFMA kernel, fp32 atomics into the arena slot
+            if self.reducer is not None:
+                self.reducer.mark_ready(w)
+            return True
         if not (MFMA_WGRAD and self.arena is not None and _is_pointwise(conv) and w.grad is not None and w.grad.dtype == torch.float32
                 and gy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
                 and gy.is_contiguous(memory_format=torch.channels_last) and x.is_contiguous(memory_format=torch.channels_last)):
@@ -151,6 +161,9 @@ MFMA_3X3_C128 = os.environ.get('LEC_CONV3X3_C128', '0')
 # HBM-bound kernels, the step time is unchanged (46.2 / 45.7 ms off, 45.8 / 45.9 ms on): opt-in, because float atomics
 # also make the summation order (not the value to fp32 tolerance) vary from run to run
 MFMA_WGRAD = os.environ.get('LEC_CONV1X1_WGRAD', '0') != '0'
+# the weight gradient of layer1's 3x3 convolution (64 -> 64 @56x56): liblecone's MFMA kernel (lec_conv3x3_c64_wgrad), alone 222 us
+# against the library's 385 us (577 us inside the step) -- and again no change of the step time (44.5 vs 44.3 ms): opt-in
+MFMA_WGRAD_3X3 = os.environ.get('LEC_CONV3X3_WGRAD', '0') != '0'
 GEMM_FWD_MIN_CIN = 1024
 GEMM_DGRAD_MIN_CIN = 256
 

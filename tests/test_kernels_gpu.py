@@ -502,6 +502,33 @@ def test_conv1x1_mfma_vs_fp32_matmul_and_statistics(cin, cout, M):
     ops._BN_WS_OWNER[0] = 0
 
 
+@pytest.mark.parametrize('N,H,W', [(1, 8, 8), (3, 16, 24), (2, 56, 56), (300, 8, 16)])
+def test_conv3x3_c64_wgrad_mfma_vs_torch(N, H, W):
+    """lec_conv3x3_c64_wgrad: dw[co][ky][kx][ci] += sum dy * shifted x (bf16 in, fp32 accumulate, float atomics) against autograd
+    of an fp32 convolution -- integer-valued data first (exact: bit-equal), then random data; accumulates across calls."""
+    g = torch.Generator(device='cpu').manual_seed(N * H + W)
+    def nhwc(t):
+        return t.to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    def reference(x, dy):
+        w = torch.zeros(64, 64, 3, 3, device=DEV, dtype=torch.float64, requires_grad=True)
+        torch.nn.functional.conv2d(x.double(), w, padding=1).backward(dy.double())
+        return w.grad
+    x = nhwc(torch.randint(-3, 4, (N, 64, H, W), generator=g).float()); dy = nhwc(torch.randint(-2, 3, (N, 64, H, W), generator=g).float())
+    dw = torch.zeros(64, 64, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last)
+    ops.conv3x3_c64_wgrad(dy, x, dw)
+    ref = reference(x, dy)
+    assert torch.equal(dw.double(), ref)
+    ops.conv3x3_c64_wgrad(dy, x, dw)
+    assert torch.equal(dw.double(), 2 * ref)
+    x = nhwc(torch.randn(N, 64, H, W, generator=g) * 0.7); dy = nhwc(torch.randn(N, 64, H, W, generator=g) * 0.1)
+    dw = torch.full((64, 64, 3, 3), 0.25, device=DEV).contiguous(memory_format=torch.channels_last)
+    ops.conv3x3_c64_wgrad(dy, x, dw)
+    ref = reference(x, dy) + 0.25
+    assert ((dw.double() - ref).abs().max() / ref.abs().max()).item() < 2e-5
+    with pytest.raises(ValueError):
+        ops.conv3x3_c64_wgrad(dy, x, torch.zeros(64, 64, 3, 3, device=DEV))            # not the channels_last layout
+
+
 @pytest.mark.parametrize('cin,cout,M', [(64, 64, 64), (64, 256, 64 * 5), (256, 64, 64 * 300), (256, 128, 64 * 257), (128, 512, 64 * 513),
                                         (512, 128, 64 * 700)])
 def test_conv1x1_wgrad_mfma_vs_fp32_matmul(cin, cout, M):
