@@ -223,6 +223,22 @@ int lec_bn_bwd(const void* dy, const void* dy2, const void* y, const uint8_t* re
 int lec_conv1x1_supported(int Cin, int Cout, int64_t M);
 int lec_conv1x1_fwd(const void* x, const void* w, int w_transposed, int64_t M, int Cin, int Cout, void* y, float* partials,
                     int64_t partials_bytes, int* n_partials, lec_stream_t stream);
+/* conv3 -> bn3 (+ identity, ReLU) of a bottleneck block (torchvision Bottleneck.forward, reached from oe_h.py:311,317) without the
+ * BatchNorm apply pass: the 1x1 convolution reads a quarter of what it writes, so it runs twice.  lec_conv1x1_stats forms the
+ * product and leaves only the statistics partials of its (bf16-rounded) output; lec_bn_fwd_finalize turns them into mean / invstd /
+ * running statistics and the scale / shift pair at lec_bn_workspace_coeff_offset(C) bytes into the workspace (scale[C], shift[C]);
+ * lec_conv1x1_fwd_bnapply forms the product again and writes y (the BatchNorm input, kept for backward), z = relu(y * scale + shift
+ * + residual) and the bitmask of z > 0 -- the same values lec_conv1x1_fwd + lec_bn_fwd_prestat produce, one read of y and of the
+ * residual less.  Shapes: lec_conv1x1_bnapply_supported ((64, 256), (128, 512); M % 32 == 0). */
+int lec_conv1x1_bnapply_supported(int Cin, int Cout, int64_t M);
+int lec_conv1x1_stats(const void* x, const void* w, int64_t M, int Cin, int Cout, float* partials, int64_t partials_bytes, int* n_partials,
+                      lec_stream_t stream);
+int64_t lec_bn_workspace_coeff_offset(int C);
+int lec_bn_fwd_finalize(int64_t M, int C, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                        float* running_var, int n_partials, float* save_mean, float* save_invstd, void* workspace, int64_t workspace_bytes,
+                        lec_stream_t stream);
+int lec_conv1x1_fwd_bnapply(const void* x, const void* w, int64_t M, int Cin, int Cout, const float* scale, const float* shift,
+                            const void* residual, void* y, void* z, uint8_t* relu_mask, lec_stream_t stream);
 /* Data gradient of a 1x1 layer whose INPUT is the forked output z = relu(bn(x_bn) + residual) of a bottleneck block
  * (torchvision Bottleneck.forward as reached from oe_h.py:311,317: z feeds the next block's conv1 and its identity branch), with
  * pass 1 of that BatchNorm's backward folded into the epilogue: g = relu_mask * (dy W + dy2) (bf16), where dy2 is the

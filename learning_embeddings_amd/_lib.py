@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblecone.so')
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 OK, E_ARG, E_HIP, E_EMPTY, E_STATE = 0, -1, -2, -3, -4
 ENERGY_HYP_CONE, ENERGY_ORDER, ENERGY_EUC_CONE = 0, 1, 2
@@ -67,6 +67,11 @@ def _load():
         'lec_bn_bwd': (i32, [p, p, p, p, p, i64, i32, p, p, p, p, p, p, p, i32, p, i64, p]),
         'lec_conv1x1_supported': (i32, [i32, i32, i64]),
         'lec_conv1x1_fwd': (i32, [p, p, i32, i64, i32, i32, p, p, i64, p, p]),
+        'lec_conv1x1_bnapply_supported': (i32, [i32, i32, i64]),
+        'lec_conv1x1_stats': (i32, [p, p, i64, i32, i32, p, i64, p, p]),
+        'lec_bn_workspace_coeff_offset': (i64, [i32]),
+        'lec_bn_fwd_finalize': (i32, [i64, i32, p, p, f32, f32, p, p, i32, p, p, p, i64, p]),
+        'lec_conv1x1_fwd_bnapply': (i32, [p, p, i64, i32, i32, p, p, p, p, p, p, p]),
         'lec_conv1x1_dgrad_bnfold_supported': (i32, [i32, i32, i64]),
         'lec_conv1x1_dgrad_bnfold': (i32, [p, p, i32, i64, i32, i32, p, p, p, p, p, p, p, i64, p, p]),
         'lec_bn_bwd_prereduced': (i32, [p, p, i64, i32, p, p, p, i32, p, p, p, p, i64, p]),

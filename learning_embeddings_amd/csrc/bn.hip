@@ -442,6 +442,27 @@ extern "C" int lec_bn_bwd(const void* dy, const void* dy2, const void* y, const 
   return LEC_OK;
 }
 
+extern "C" int64_t lec_bn_workspace_coeff_offset(int C) {                // byte offset of scale[C], shift[C] (forward) inside the workspace
+  if (C <= 0) return LEC_E_ARG;
+  return (int64_t)lec::kBnMaxBlocks * 2 * C * (int64_t)sizeof(float);
+}
+
+extern "C" int lec_bn_fwd_finalize(int64_t M, int C, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                   float* running_var, int n_partials, float* save_mean, float* save_invstd, void* workspace,
+                                   int64_t workspace_bytes, lec_stream_t stream) {
+  using namespace lec;
+  if (int rc = bn_check("bn_fwd_finalize", M, C)) return rc;
+  LEC_CHECK_ARG(gamma && beta && save_mean && save_invstd && workspace, "bn_fwd_finalize: null pointer");
+  LEC_CHECK_ARG(n_partials >= 1 && n_partials <= kBnMaxBlocks, "bn_fwd_finalize: n_partials=%d outside 1..%d", n_partials, kBnMaxBlocks);
+  LEC_CHECK_ARG(workspace_bytes >= lec_bn_workspace_bytes(C), "bn_fwd_finalize: workspace too small");
+  float* part = (float*)workspace;
+  float* scale = part + (int64_t)kBnMaxBlocks * 2 * C; float* shift = scale + C;
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, (hipStream_t)stream, part, n_partials, C, M, gamma, beta,
+                     eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
+  LEC_CHECK_LAUNCH("bn_stats_finalize_kernel");
+  return LEC_OK;
+}
+
 extern "C" int lec_bn_bwd_prereduced(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean,
                                      const float* save_invstd, int n_partials, void* dx, float* dgamma, float* dbeta, void* workspace,
                                      int64_t workspace_bytes, lec_stream_t stream) {

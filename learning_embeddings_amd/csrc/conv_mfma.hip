@@ -38,7 +38,12 @@ constexpr int kC1MaxBlocks = 512;          // = kBnMaxBlocks: the partials land 
 // K: reduction width (input channels); N: output channels handled by ONE workgroup (blockIdx.y selects the N-wide column
 // block of an Ntot-wide output: a layer wider than its weights' LDS budget re-reads X once per column block);
 // STATS: leave the per-channel partials (forward) or not (the same kernel serves the data gradient: X := dY, W := W^T).
-// FOLD (data gradient feeding a forked BatchNorm+residual+ReLU output, STATS set): the epilogue is pass 1 of that
+// FOLD = 2 / 3, the forward counterpart for conv3 -> bn3 (+ identity, ReLU): the convolution reads a quarter of what it writes, so
+// it is cheaper to run it twice than to let the BatchNorm re-read its output.  FOLD = 3 is the product with the statistics
+// epilogue and NO store; after the finalize kernel, FOLD = 2 forms the product again and its epilogue applies scale / shift, adds
+// the residual (fa.dy2), clamps, and writes y (kept for backward), z (fa.xbn, written) and z's bitmask (fa.mask, written);
+// fa.mean / fa.invstd carry scale / shift.  The BatchNorm apply pass (read y, residual; write z, mask) disappears.
+// FOLD = 1 (data gradient feeding a forked BatchNorm+residual+ReLU output, STATS set): the epilogue is pass 1 of that
 // BatchNorm's backward.  With the strip's rows in registers on their way out it reads the other branch's gradient dy2,
 // the ReLU bitmask and the BatchNorm's input x at the same addresses, forms g = mask * (dY W + dy2) rounded to bf16, writes
 // g instead of the raw product and leaves per-channel partials of (sum g, sum g * xhat) where the forward form leaves
@@ -51,7 +56,7 @@ struct FoldArgs {
   const float* invstd;            // [Ntot]
 };
 
-template <int K, int N, bool STATS, int WAVES, bool FOLD>
+template <int K, int N, bool STATS, int WAVES, int FOLD>
 __global__ __launch_bounds__(WAVES * 64) void conv1x1_fwd_stats_kernel(const unsigned short* __restrict__ X,
                                                                        const unsigned short* __restrict__ Wt, int64_t M, int Ntot,
                                                                        unsigned short* __restrict__ Y, float* __restrict__ part, int wtrans,
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_fwd_stats_kernel(const uns
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  if (FOLD) {
+  if (FOLD == 1 || FOLD == 2) {
     for (int e = threadIdx.x; e < N; e += WAVES * 64) {
       Ms[e] = fa.mean[(int)blockIdx.y * N + e];
       Ms[N + e] = fa.invstd[(int)blockIdx.y * N + e];
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_fwd_stats_kernel(const uns
       u32x4_t f_d2[4], f_x[4];
       unsigned int f_m[4];
       float f_mu[8], f_is[8];
-      if (FOLD) {
+      if (FOLD == 1 || FOLD == 2) {
         // addresses as (wave-uniform 64-bit base) + (one 32-bit lane offset): spelled out, the compiler otherwise keeps a
         // 64-bit vector address per tensor, chunk and row alive across the strip loop (~100 registers)
         const int su = __builtin_amdgcn_readfirstlane((int)s);
@@ -130,9 +135,11 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_fwd_stats_kernel(const uns
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int64_t ue = ub + (int64_t)(8 * i) * Ntot;
-          f_x[i] = __builtin_nontemporal_load((const u32x4_t*)(fa.xbn + ue + loff));
           f_d2[i] = __builtin_nontemporal_load((const u32x4_t*)(fa.dy2 + ue + loff));
-          f_m[i] = (unsigned int)(fa.mask + (ue >> 3))[loff >> 3];
+          if (FOLD == 1) {
+            f_x[i] = __builtin_nontemporal_load((const u32x4_t*)(fa.xbn + ue + loff));
+            f_m[i] = (unsigned int)(fa.mask + (ue >> 3))[loff >> 3];
+          }
         }
       }
       f32x16_t acc[2];
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_fwd_stats_kernel(const uns
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       // rows back out as 16-byte segments: lane -> rows (lane >> 3) + 8 i, channels c*64 + (lane & 7) * 8 .. + 8
       const int cc = lane & 7, r0 = lane >> 3;
-      if (FOLD) {
+      if (FOLD == 1 || FOLD == 2) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { f_mu[j] = Ms[c * 64 + cc * 8 + j]; f_is[j] = Ms[N + c * 64 + cc * 8 + j]; }
       }
@@ -172,7 +179,25 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_fwd_stats_kernel(const uns
         const int row = r0 + 8 * i;
         u32x4_t v = *(const u32x4_t*)(Ys + row * YLD + cc * 8);
         const unsigned int w4[4] = {v.x, v.y, v.z, v.w};
-        if (FOLD) {
+        if (FOLD == 2) {
+          // forward: z = relu(y * scale + shift + residual) from the ROUNDED y, exactly as bn_apply_kernel forms it; y is stored
+          // too (the BatchNorm backward needs it), the bitmask of z > 0 as well
+          const unsigned int d4[4] = {f_d2[i].x, f_d2[i].y, f_d2[i].z, f_d2[i].w};
+          unsigned int o4[4] = {0u, 0u, 0u, 0u}, bits = 0u;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float a = c1_bf2f((unsigned short)(w4[j >> 1] >> ((j & 1) * 16))) * f_mu[j] + f_is[j];
+            a += c1_bf2f((unsigned short)(d4[j >> 1] >> ((j & 1) * 16)));
+            a = a > 0.0f ? a : 0.0f;
+            const unsigned short zb = c1_f2bf(a);
+            bits |= (c1_bf2f(zb) > 0.0f ? 1u : 0u) << j;
+            o4[j >> 1] |= (unsigned int)zb << ((j & 1) * 16);
+          }
+          const int64_t e = (s * 32 + row) * Ntot + (int)blockIdx.y * N + c * 64 + cc * 8;
+          u32x4_t z; z.x = o4[0]; z.y = o4[1]; z.z = o4[2]; z.w = o4[3];
+          __builtin_nontemporal_store(z, (u32x4_t*)(const_cast<unsigned short*>(fa.xbn) + e));
+          const_cast<unsigned char*>(fa.mask)[e >> 3] = (unsigned char)bits;
+        } else if (FOLD == 1) {
           const unsigned int d4[4] = {f_d2[i].x, f_d2[i].y, f_d2[i].z, f_d2[i].w};
           const unsigned int x4[4] = {f_x[i].x, f_x[i].y, f_x[i].z, f_x[i].w};
           unsigned int o4[4] = {0u, 0u, 0u, 0u};
@@ -195,7 +220,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_fwd_stats_kernel(const uns
             if (STATS) { st_s[c][j] += f; st_q[c][j] += f * f; }
           }
         }
-        __builtin_nontemporal_store(v, (u32x4_t*)(Y + (s * 32 + row) * Ntot + c * 64 + cc * 8));
+        if (FOLD != 3) __builtin_nontemporal_store(v, (u32x4_t*)(Y + (s * 32 + row) * Ntot + c * 64 + cc * 8));
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -239,15 +264,15 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_fwd_stats_kernel(const uns
   }
 }
 
-template <int K, int N, bool STATS, bool FOLD = false>
+template <int K, int N, bool STATS, int FOLD = 0>
 static int launch_conv1x1(const void* x, const void* w, int64_t M, int Ntot, void* y, float* part, int* nblk_out, int wtrans, hipStream_t st,
                           FoldArgs fa = FoldArgs{nullptr, nullptr, nullptr, nullptr, nullptr}) {
   // eight waves per workgroup (two per SIMD) for K <= 128 (128 -> 512: 117 -> 105 us); the K = 256 instances, whose
   // fragment sets already fill the registers, measured better with four (256 -> 128: 229 vs 241 us)
-  // (the FOLD epilogue's operand sets need more than the 256 registers per lane of an eight-wave workgroup: four waves)
-  constexpr int WAVES = (!FOLD && K <= 128 && ((size_t)N * (K + 8) + 8 * 32 * (64 + 8)) * sizeof(unsigned short) <= 160 * 1024) ? 8 : 4;
+  // (the FOLD = 1 epilogue's operand sets need more than the 256 registers per lane of an eight-wave workgroup: four waves)
+  constexpr int WAVES = (FOLD != 1 && K <= 128 && ((size_t)N * (K + 8) + 8 * 32 * (64 + 8)) * sizeof(unsigned short) <= 160 * 1024) ? 8 : 4;
   static_assert(WAVES * 2 * N * sizeof(float) <= WAVES * 32 * (64 + 8) * sizeof(unsigned short), "statistics staging must fit the Y tiles");
-  const size_t smem = ((size_t)N * (K + 8) + WAVES * 32 * (64 + 8)) * sizeof(unsigned short) + (FOLD ? 2 * N * sizeof(float) : 0);
+  const size_t smem = ((size_t)N * (K + 8) + WAVES * 32 * (64 + 8)) * sizeof(unsigned short) + ((FOLD == 1 || FOLD == 2) ? 2 * N * sizeof(float) : 0);
   static bool attr_set = false;
   if (smem > 64 * 1024 && !attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv1x1_fwd_stats_kernel<K, N, STATS, WAVES, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1358,8 +1383,34 @@ extern "C" int lec_conv1x1_dgrad_bnfold(const void* dy, const void* w, int w_tra
   LEC_CHECK_ARG(partials_bytes >= (int64_t)kC1MaxBlocks * 2 * Cout * (int64_t)sizeof(float), "conv1x1_dgrad_bnfold: partials buffer too small");
   const FoldArgs fa{(const unsigned short*)dy2, (const unsigned short*)bn_x, (const unsigned char*)relu_mask, save_mean, save_invstd};
   hipStream_t st = (hipStream_t)stream;
-  if (Cin == 64) return launch_conv1x1<64, 256, true, true>(dy, w, M, Cout, g, partials, n_partials, w_transposed, st, fa);
-  return launch_conv1x1<128, 256, true, true>(dy, w, M, Cout, g, partials, n_partials, w_transposed, st, fa);
+  if (Cin == 64) return launch_conv1x1<64, 256, true, 1>(dy, w, M, Cout, g, partials, n_partials, w_transposed, st, fa);
+  return launch_conv1x1<128, 256, true, 1>(dy, w, M, Cout, g, partials, n_partials, w_transposed, st, fa);
+}
+
+extern "C" int lec_conv1x1_bnapply_supported(int Cin, int Cout, int64_t M) {
+  return ((Cin == 64 && Cout == 256) || (Cin == 128 && Cout == 512)) && M > 0 && M % 32 == 0;
+}
+
+extern "C" int lec_conv1x1_stats(const void* x, const void* w, int64_t M, int Cin, int Cout, float* partials, int64_t partials_bytes,
+                                 int* n_partials, lec_stream_t stream) {
+  using namespace lec;
+  LEC_CHECK_ARG(x && w && partials && n_partials, "conv1x1_stats: null pointer");
+  LEC_CHECK_ARG(lec_conv1x1_bnapply_supported(Cin, Cout, M), "conv1x1_stats: unsupported shape Cin=%d Cout=%d M=%lld", Cin, Cout, (long long)M);
+  LEC_CHECK_ARG(partials_bytes >= (int64_t)kC1MaxBlocks * 2 * Cout * (int64_t)sizeof(float), "conv1x1_stats: partials buffer too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (Cin == 64) return launch_conv1x1<64, 256, true, 3>(x, w, M, Cout, nullptr, partials, n_partials, 0, st);
+  return launch_conv1x1<128, 256, true, 3>(x, w, M, Cout, nullptr, partials, n_partials, 0, st);
+}
+
+extern "C" int lec_conv1x1_fwd_bnapply(const void* x, const void* w, int64_t M, int Cin, int Cout, const float* scale, const float* shift,
+                                       const void* residual, void* y, void* z, uint8_t* relu_mask, lec_stream_t stream) {
+  using namespace lec;
+  LEC_CHECK_ARG(x && w && scale && shift && residual && y && z && relu_mask, "conv1x1_fwd_bnapply: null pointer");
+  LEC_CHECK_ARG(lec_conv1x1_bnapply_supported(Cin, Cout, M), "conv1x1_fwd_bnapply: unsupported shape Cin=%d Cout=%d M=%lld", Cin, Cout, (long long)M);
+  const FoldArgs fa{(const unsigned short*)residual, (const unsigned short*)z, (const unsigned char*)relu_mask, scale, shift};
+  hipStream_t st = (hipStream_t)stream;
+  if (Cin == 64) return launch_conv1x1<64, 256, false, 2>(x, w, M, Cout, y, nullptr, nullptr, 0, st, fa);
+  return launch_conv1x1<128, 256, false, 2>(x, w, M, Cout, y, nullptr, nullptr, 0, st, fa);
 }
 
 extern "C" int lec_conv1x1_fwd(const void* x, const void* w, int w_transposed, int64_t M, int Cin, int Cout, void* y, float* partials,

@@ -320,8 +320,27 @@ class BNActFn(torch.autograd.Function):
         # the convolution that produced x may have left its statistics partials in the workspace (conv1x1_rows)
         prestat = _BN_WS_OWNER[1] if (training and _BN_WS_OWNER[0] == x.data_ptr()) else 0
         _BN_WS_OWNER[0] = 0
+        dfr = _DEFERRED.pop(x.data_ptr(), None)
+        if dfr is not None:
+            x_in, w2 = dfr
+            cin = x_in.shape[1]
+            fused = (prestat and residual is not None and mask is not None and x.dtype == torch.bfloat16 and residual.dtype == torch.bfloat16
+                     and residual.is_contiguous(memory_format=torch.channels_last))
+            if fused:
+                # statistics are in the workspace: finalize, then the convolution again with scale / shift / residual / ReLU in its
+                # epilogue -- it writes x (this layer's input, kept for backward), y and the bitmask; no apply pass
+                check(lib.lec_bn_fwd_finalize(M, Cc, dptr(weight), dptr(bias), float(eps), float(momentum), dptr(running_mean), dptr(running_var),
+                                              prestat, dptr(save_mean), dptr(save_invstd), dptr(ws), ws.numel(), stream_ptr()))
+                off = lib.lec_bn_workspace_coeff_offset(Cc)
+                check(lib.lec_conv1x1_fwd_bnapply(dptr(x_in), dptr(w2), M, cin, Cc, C.c_void_p(ws.data_ptr() + off), C.c_void_p(ws.data_ptr() + off + 4 * Cc),
+                                                  dptr(residual), dptr(x), dptr(y), dptr(mask), stream_ptr()))
+            else:                                 # not the layer the deferral was meant for: materialise the product first
+                check(lib.lec_conv1x1_fwd(dptr(x_in), dptr(w2), 0, M, cin, Cc, dptr(x), None, 0, None, stream_ptr()))
+                dfr = None
         nbytes = el * ((4 if (training and not prestat) else 2) + 2 + (2 if residual is not None else 0)) + (el // 8 if mask is not None else 0)
-        if prestat:
+        if dfr is not None:
+            pass                                  # done above, inside the convolution
+        elif prestat:
             _bn_timed(lambda: check(lib.lec_bn_fwd_prestat(dptr(x), dptr(residual), M, Cc, dptr(weight), dptr(bias), float(eps), float(momentum),
                                                            dptr(running_mean), dptr(running_var), prestat, dptr(save_mean),
                                                            dptr(save_invstd), dptr(y), int(bool(relu)), dptr(mask), dptr(ws), ws.numel(),
@@ -407,6 +426,11 @@ import os as _os
 FOLD_BN_BWD = _os.environ.get('LEC_FOLD_BN_BWD', '1') != '0'
 _FORKS = {}
 _FOLDED = {}
+# Forward of conv3 -> bn3 (+ identity, ReLU): the convolution first runs as a statistics-only pass (conv1x1_stats_rows) and hands
+# BNActFn an UNWRITTEN output tensor; _DEFERRED: data_ptr of that tensor -> (input rows, weight).  BNActFn.forward finalizes the
+# statistics and runs the convolution again with the BatchNorm apply in its epilogue, which writes both tensors.
+DEFER_BN_APPLY = _os.environ.get('LEC_DEFER_BN_APPLY', '1') != '0'
+_DEFERRED = {}
 _bn_ws = {}
 _BN_WS_OWNER = [0, 0]        # (data_ptr of the tensor whose statistics partials sit in the BN workspace, number of partial rows)
 
@@ -459,6 +483,26 @@ def conv1x1_wgrad_rows(dy_rows, x_rows, dw):
         raise ValueError('dw must be a contiguous float32 [Cout, Cin] buffer')
     check(lib.lec_conv1x1_wgrad(dptr(dy_rows), dptr(x_rows), M, cin, cout, dptr(dw), stream_ptr()))
     return dw
+
+
+def conv1x1_bnapply_supported(cin, cout, M):
+    return bool(lib.lec_conv1x1_bnapply_supported(int(cin), int(cout), int(M)))
+
+
+def conv1x1_stats_rows(x_rows, w2):
+    """Statistics-only pass of y = x w^T (lec_conv1x1_stats): returns an UNWRITTEN [M, Cout] tensor whose per-channel partials sit
+    in the BatchNorm workspace; BNActFn.forward, handed that tensor with a residual and ReLU, runs the convolution again with the
+    BatchNorm apply in its epilogue (and fills the tensor), or materialises the plain product if it is used differently."""
+    M, cin = x_rows.shape
+    cout = w2.shape[0]
+    y = torch.empty((M, cout), dtype=torch.bfloat16, device=x_rows.device)
+    ws = _bn_workspace(x_rows.device)
+    n = C.c_int(0)
+    check(lib.lec_conv1x1_stats(dptr(x_rows), dptr(w2), M, cin, cout, dptr(ws), ws.numel(), C.byref(n), stream_ptr()))
+    _BN_WS_OWNER[0], _BN_WS_OWNER[1] = y.data_ptr(), n.value
+    _DEFERRED.clear()
+    _DEFERRED[y.data_ptr()] = (x_rows, w2)
+    return y
 
 
 def conv1x1_dgrad_bnfold_supported(cin, cout, M):

@@ -207,7 +207,13 @@ class _OverlapConvFn(torch.autograd.Function):
             y = _ops().conv3x3_c64(x, w16, want_stats=True)
         elif ctx.own and _ops().conv1x1_supported(conv.in_channels, conv.out_channels, x.shape[0] * x.shape[2] * x.shape[3]):
             n, _, h, wd = x.shape
-            y = _from_rows(_ops().conv1x1_rows(_rows(x), w16.reshape(conv.out_channels, conv.in_channels), want_stats=True), n, h, wd)
+            ops = _ops()
+            if (getattr(conv, 'defer_bn', False) and ops.DEFER_BN_APPLY and x.dtype == torch.bfloat16
+                    and ops.conv1x1_bnapply_supported(conv.in_channels, conv.out_channels, n * h * wd)):
+                # conv3 -> bn3: statistics only for now; the BatchNorm runs the product again with its apply pass in the epilogue
+                y = _from_rows(ops.conv1x1_stats_rows(_rows(x), w16.reshape(conv.out_channels, conv.in_channels)), n, h, wd)
+            else:
+                y = _from_rows(ops.conv1x1_rows(_rows(x), w16.reshape(conv.out_channels, conv.in_channels), want_stats=True), n, h, wd)
         elif ctx.pointwise and conv.in_channels >= GEMM_FWD_MIN_CIN:
             n, _, h, wd = x.shape
             y = _from_rows(torch.mm(_rows(x), w16.reshape(conv.out_channels, conv.in_channels).t()), n, h, wd)
@@ -309,6 +315,7 @@ class Bottleneck(nn.Module):
         self.conv1 = conv1x1(cin, planes); self.bn1 = BatchNormAct2d(planes, relu=True)
         self.conv2 = conv3x3(planes, planes, stride); self.bn2 = BatchNormAct2d(planes, relu=True)   # stride on the 3x3 (v1.5)
         self.conv3 = conv1x1(planes, planes * 4); self.bn3 = BatchNormAct2d(planes * 4, relu=True)  # relu(bn3(.) + identity)
+        self.conv3.defer_bn = True                             # forward() hands conv3's output to bn3 and to nothing else (ops._DEFERRED)
         self.downsample = downsample
 
     def forward(self, x, fork=False):
@@ -354,7 +361,7 @@ class ResNet(nn.Module):
     def forward(self, x):
         if x.is_cuda and torch.is_autocast_enabled() and x.dtype == torch.float32:
             x = x.to(torch.get_autocast_gpu_dtype())          # the stem conv sees low-precision input like every other layer
-        _ops()._FORKS.clear(); _ops()._FOLDED.clear()           # records of a forward whose backward never ran (or raised)
+        _ops()._FORKS.clear(); _ops()._FOLDED.clear(); _ops()._DEFERRED.clear()   # records of a forward whose backward never ran (or raised)
         x = self.maxpool(self.bn1(self.conv1(x)))
         blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
         for i, b in enumerate(blocks):

@@ -205,6 +205,61 @@ def test_batchnorm_backward_pass1_folded_into_conv_dgrad_matches_unfolded(stage)
     assert dx < max(floor_x, 4 * noise_x) and dp < max(floor_p, 4 * noise_p), (dx, dp, noise_x, noise_p)
 
 
+def test_conv3_bn3_forward_with_apply_inside_the_convolution_is_bit_identical():
+    """ops.DEFER_BN_APPLY: conv3 runs as a statistics-only pass, bn3 runs it again with the apply pass in its epilogue.  Through
+    ResNet-50's layer1 (liblecone kernels only, bit-reproducible) outputs, input gradient and every parameter gradient must be
+    EQUAL to the path with a separate apply pass -- and the deferred path must actually run."""
+    from learning_embeddings_amd import resnet as R
+    from learning_embeddings_amd.resnet import WgradOverlap
+    torch.manual_seed(0)
+    net = R.ResNet(R.Bottleneck, [3, 4, 6, 3])
+    blocks = list(net.layer1)
+    for b in blocks:
+        b.to(DEV).to(memory_format=torch.channels_last).train()
+    x0 = (torch.randn(4, 64, 16, 16, device=DEV) * 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gsave = None
+    res = {}
+    calls = {}
+    orig = ops.conv1x1_stats_rows
+    prev = ops.DEFER_BN_APPLY
+    try:
+        for tag in ('warm', 'defer', 'plain'):
+            ops.DEFER_BN_APPLY = tag != 'plain'
+            def counted(*a, **k):
+                calls[tag] = calls.get(tag, 0) + 1
+                return orig(*a, **k)
+            ops.conv1x1_stats_rows = counted
+            for b in blocks:
+                for p_ in b.parameters():
+                    p_.grad = torch.zeros_like(p_)
+                for m_ in b.modules():
+                    if hasattr(m_, 'running_mean') and m_.running_mean is not None:
+                        m_.running_mean.zero_(); m_.running_var.fill_(1.0)
+            WgradOverlap.instance = WgradOverlap()
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                y = x
+                for i, b in enumerate(blocks):
+                    y = b(y, fork=i + 1 < len(blocks))
+            if gsave is None:
+                gsave = torch.randn_like(y)
+            y.backward(gsave)
+            WgradOverlap.instance.join(); torch.cuda.synchronize()
+            res[tag] = ([y.detach().clone(), x.grad.clone()] + [p_.grad.clone() for b in blocks for p_ in b.parameters()]
+                        + [m_.running_var.clone() for b in blocks for m_ in b.modules() if hasattr(m_, 'running_var') and m_.running_var is not None])
+    finally:
+        WgradOverlap.instance = None
+        ops.DEFER_BN_APPLY = prev
+        ops.conv1x1_stats_rows = orig
+    assert calls.get('defer') == 3 and 'plain' not in calls and not ops._DEFERRED
+    n_par = sum(1 for b in blocks for _ in b.parameters())
+    for i, (a, b) in enumerate(zip(res['defer'], res['plain'])):
+        if 2 <= i < 2 + n_par and a.dim() == 4:      # convolution weight gradients: the library's kernels (fp32 atomics, then rounded to
+            assert (a - b).abs().max().item() <= 1e-2 * b.abs().max().item()   # bf16) differ by an ulp of bf16 from run to run
+        else:                                        # output, input gradient, BatchNorm parameter gradients, running statistics
+            assert torch.equal(a, b), i
+
+
 def test_bottleneck_block_state_dict_keys_unchanged():
     blk = Bottleneck(64, 16)
     keys = set(blk.state_dict())

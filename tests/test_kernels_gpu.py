@@ -603,6 +603,44 @@ def test_conv1x1_dgrad_with_batchnorm_backward_pass1_in_the_epilogue(cin, cout, 
     ops._BN_WS_OWNER[0] = 0; ops._FOLDED.clear()
 
 
+@pytest.mark.parametrize('cin,cout,M', [(64, 256, 32 * 70), (128, 512, 32 * 33), (64, 256, 32 * 2100)])
+def test_conv1x1_twice_with_batchnorm_apply_in_the_epilogue(cin, cout, M):
+    """lec_conv1x1_stats + lec_bn_fwd_finalize + lec_conv1x1_fwd_bnapply (the convolution run twice, the BatchNorm apply pass inside
+    the second run) against lec_conv1x1_fwd + lec_bn_fwd_prestat: y, z = relu(bn(y) + residual), the bitmask, the saved statistics
+    and the running statistics must be bit-equal."""
+    from learning_embeddings_amd._lib import lib, check, dptr, stream_ptr
+    import ctypes as C
+    g_ = torch.Generator(device='cpu').manual_seed(cin + M)
+    x = (torch.randn(M, cin, generator=g_) * 0.7).to(DEV).to(torch.bfloat16)
+    w = (torch.randn(cout, cin, generator=g_) * 0.2).to(DEV).to(torch.bfloat16)
+    hw = M // 32
+    nhwc = lambda t: t.view(32, hw, 1, cout).permute(0, 3, 1, 2)
+    res = nhwc((torch.randn(M, cout, generator=g_) * 0.8).to(DEV).to(torch.bfloat16))
+    gam = (torch.rand(cout, generator=g_) + 0.5).to(DEV); bet = torch.randn(cout, generator=g_).to(DEV)
+    ws = ops._bn_workspace(x.device)
+    outs = []
+    for fused in (False, True):
+        rm = torch.zeros(cout, device=DEV); rv = torch.ones(cout, device=DEV)
+        sm = torch.empty(cout, device=DEV); si = torch.empty(cout, device=DEV)
+        z = nhwc(torch.empty(M, cout, device=DEV, dtype=torch.bfloat16)); mask = torch.zeros(M * cout // 8, dtype=torch.uint8, device=DEV)
+        if fused:
+            y = ops.conv1x1_stats_rows(x, w)
+            n = ops._BN_WS_OWNER[1]; ops._DEFERRED.clear(); ops._BN_WS_OWNER[0] = 0
+            check(lib.lec_bn_fwd_finalize(M, cout, dptr(gam), dptr(bet), 1e-5, 0.1, dptr(rm), dptr(rv), n, dptr(sm), dptr(si), dptr(ws), ws.numel(), stream_ptr()))
+            off = lib.lec_bn_workspace_coeff_offset(cout)
+            check(lib.lec_conv1x1_fwd_bnapply(dptr(x), dptr(w), M, cin, cout, C.c_void_p(ws.data_ptr() + off), C.c_void_p(ws.data_ptr() + off + 4 * cout),
+                                              dptr(res), dptr(y), dptr(z), dptr(mask), stream_ptr()))
+        else:
+            y = ops.conv1x1_rows(x, w, want_stats=True)
+            n = ops._BN_WS_OWNER[1]; ops._BN_WS_OWNER[0] = 0
+            check(lib.lec_bn_fwd_prestat(dptr(nhwc(y)), dptr(res), M, cout, dptr(gam), dptr(bet), 1e-5, 0.1, dptr(rm), dptr(rv), n, dptr(sm), dptr(si),
+                                         dptr(z), 1, dptr(mask), dptr(ws), ws.numel(), stream_ptr()))
+        outs.append((y.clone(), z.clone(), mask.clone(), sm, si, rm, rv))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert outs[0][2].any() and (outs[0][1] == 0).any()
+
+
 def test_conv1x1_statistics_feed_batchnorm():
     """conv (MFMA kernel, statistics in the epilogue) -> BatchNorm (no statistics pass) equals conv -> full BatchNorm."""
     g = torch.Generator(device='cpu').manual_seed(5)
