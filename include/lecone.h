@@ -261,6 +261,26 @@ int lec_bn_bwd_prereduced(const void* g, const void* x, int64_t M, int C, const 
  * accumulated with float atomics into the caller's gradient buffer.  dy, x: [N, H, W, 64] bf16; H % 8 == 0 and W % 8 == 0. */
 int lec_conv3x3_c64_wgrad_supported(int N, int H, int W);
 int lec_conv3x3_c64_wgrad(const void* dy, const void* x, int N, int H, int W, float* dw, lec_stream_t stream);
+/* lec_bn_bwd in stages, for callers that run pass 2 elsewhere (lec_conv1x1_wgrad_bnapply).  lec_bn_bwd_pass1: g = mask * (dy [+ dy2])
+ * written, sums reduced, d gamma / d beta and the coefficients c1, c2 finalized (c1[C], c2[C] at lec_bn_workspace_coeff_offset(C) bytes
+ * into the workspace).  lec_bn_bwd_finalize: the finalize alone, from n_partials partial rows a convolution epilogue left.
+ * lec_bn_bwd_apply: pass 2 alone (dx from g, x and the c1, c2 in the workspace). */
+int lec_bn_bwd_pass1(const void* dy, const void* dy2, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* save_mean,
+                     const float* save_invstd, void* g, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, lec_stream_t stream);
+int lec_bn_bwd_finalize(int64_t M, int C, int n_partials, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
+                        lec_stream_t stream);
+int lec_bn_bwd_apply(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd,
+                     void* dx, void* workspace, int64_t workspace_bytes, lec_stream_t stream);
+/* conv3 behind bn3, backward: the weight gradient of the 1x1 layer AND pass 2 of the BatchNorm backward in one kernel.  g [M, Cout] is
+ * the masked gradient (pass 1's output: lec_bn_bwd's d residual, or lec_conv1x1_dgrad_bnfold's g), bn_x [M, Cout] the BatchNorm's
+ * input, c1 / c2 [Cout] the per-channel means the finalize kernel leaves at lec_bn_workspace_coeff_offset(Cout) bytes into the
+ * workspace.  Writes dx = gamma invstd (g - c1 - xhat c2) [M, Cout] (bf16, what lec_bn_bwd's pass 2 writes, bit for bit) for the data
+ * gradient kernel and accumulates dw[Cout][Cin] (fp32) += dx^T x.  Replaces pass 2 + the weight-gradient kernel: dx is read once
+ * less.  Shapes: lec_conv1x1_wgrad_bnapply_supported ((64, 256), (128, 512); M % 64 == 0). */
+int lec_conv1x1_wgrad_bnapply_supported(int Cin, int Cout, int64_t M);
+int lec_conv1x1_wgrad_bnapply(const void* g, const void* bn_x, const void* x, int64_t M, int Cin, int Cout, const float* gamma,
+                              const float* save_mean, const float* save_invstd, const float* c1, const float* c2, void* dx, float* dw,
+                              lec_stream_t stream);
 /* Weight gradient of the same 1x1 layers: dw[Cout][Cin] (fp32) += dy[M, Cout]^T x[M, Cin], accumulated with float atomics
  * straight into the caller's gradient buffer (which must hold the running sum, e.g. zero at the start of a step):
  * replaces the library's weight-gradient kernel together with its zero-fill, its fp32 -> bf16 cast and the copy into the

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblecone.so')
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 OK, E_ARG, E_HIP, E_EMPTY, E_STATE = 0, -1, -2, -3, -4
 ENERGY_HYP_CONE, ENERGY_ORDER, ENERGY_EUC_CONE = 0, 1, 2
@@ -77,6 +77,11 @@ def _load():
         'lec_bn_bwd_prereduced': (i32, [p, p, i64, i32, p, p, p, i32, p, p, p, p, i64, p]),
         'lec_conv3x3_c64_wgrad_supported': (i32, [i32, i32, i32]),
         'lec_conv3x3_c64_wgrad': (i32, [p, p, i32, i32, i32, p, p]),
+        'lec_bn_bwd_pass1': (i32, [p, p, p, p, i64, i32, p, p, p, p, p, p, i64, p]),
+        'lec_bn_bwd_finalize': (i32, [i64, i32, i32, p, p, p, i64, p]),
+        'lec_bn_bwd_apply': (i32, [p, p, i64, i32, p, p, p, p, p, i64, p]),
+        'lec_conv1x1_wgrad_bnapply_supported': (i32, [i32, i32, i64]),
+        'lec_conv1x1_wgrad_bnapply': (i32, [p, p, p, i64, i32, i32, p, p, p, p, p, p, p, p]),
         'lec_conv1x1_wgrad_supported': (i32, [i32, i32, i64]),
         'lec_conv1x1_wgrad': (i32, [p, p, i64, i32, i32, p, p]),
         'lec_conv3x3_c64_fwd': (i32, [p, p, i32, i32, i32, i32, p, p, i64, p, p]),

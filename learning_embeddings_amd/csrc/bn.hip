@@ -463,6 +463,58 @@ extern "C" int lec_bn_fwd_finalize(int64_t M, int C, const float* gamma, const f
   return LEC_OK;
 }
 
+// The backward split into its stages, for callers that run pass 2 somewhere else (lec_conv1x1_wgrad_bnapply): pass 1 + finalize,
+// finalize alone (partials left by a convolution epilogue), and pass 2 alone from the c1 / c2 the finalize left in the workspace.
+extern "C" int lec_bn_bwd_pass1(const void* dy, const void* dy2, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* save_mean,
+                                const float* save_invstd, void* g, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
+                                lec_stream_t stream) {
+  using namespace lec;
+  if (int rc = bn_check("bn_bwd_pass1", M, C)) return rc;
+  LEC_CHECK_ARG(dy && x && save_mean && save_invstd && g && dgamma && dbeta && workspace, "bn_bwd_pass1: null pointer");
+  LEC_CHECK_ARG(workspace_bytes >= lec_bn_workspace_bytes(C), "bn_bwd_pass1: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  BnGeom geo = bn_geom(M, C);
+  float* part = (float*)workspace;
+  float* c1 = part + (int64_t)kBnMaxBlocks * 2 * C; float* c2 = c1 + C;
+#define R(M_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<M_>), dim3(geo.nrb, geo.NCH), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)dy2, (const bf16x8*)relu_mask, (const bf16x8*)x, M, C, geo.CV, geo.CVB, geo.RPIB, save_mean, save_invstd, part, (bf16x8*)g)
+  if (relu_mask) R(2); else R(0);
+#undef R
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, geo.nrb, C, M, dgamma, dbeta, c1, c2);
+  LEC_CHECK_LAUNCH("bn_bwd_pass1 kernels");
+  return LEC_OK;
+}
+
+extern "C" int lec_bn_bwd_finalize(int64_t M, int C, int n_partials, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
+                                   lec_stream_t stream) {
+  using namespace lec;
+  if (int rc = bn_check("bn_bwd_finalize", M, C)) return rc;
+  LEC_CHECK_ARG(dgamma && dbeta && workspace, "bn_bwd_finalize: null pointer");
+  LEC_CHECK_ARG(n_partials >= 1 && n_partials <= kBnMaxBlocks, "bn_bwd_finalize: n_partials=%d outside 1..%d", n_partials, kBnMaxBlocks);
+  LEC_CHECK_ARG(workspace_bytes >= lec_bn_workspace_bytes(C), "bn_bwd_finalize: workspace too small");
+  float* part = (float*)workspace;
+  float* c1 = part + (int64_t)kBnMaxBlocks * 2 * C; float* c2 = c1 + C;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, (hipStream_t)stream, part, n_partials, C, M, dgamma, dbeta,
+                     c1, c2);
+  LEC_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+  return LEC_OK;
+}
+
+extern "C" int lec_bn_bwd_apply(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd,
+                                void* dx, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+  using namespace lec;
+  if (int rc = bn_check("bn_bwd_apply", M, C)) return rc;
+  LEC_CHECK_ARG(g && x && gamma && save_mean && save_invstd && dx && workspace, "bn_bwd_apply: null pointer");
+  LEC_CHECK_ARG(workspace_bytes >= lec_bn_workspace_bytes(C), "bn_bwd_apply: workspace too small");
+  BnGeom geo = bn_geom(M, C);
+  float* c1 = (float*)workspace + (int64_t)kBnMaxBlocks * 2 * C; float* c2 = c1 + C;
+  int64_t nb = (M + geo.RPI - 1) / geo.RPI; nb = (nb + 1) / 2;
+  const int nblk = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<false, 0>), dim3(nblk), dim3(kBnThreads), 0, (hipStream_t)stream, (const bf16x8*)g, (const bf16x8*)nullptr,
+                     (const bf16x8*)nullptr, (const bf16x8*)x, M, geo.CV, geo.RPI, gamma, save_mean, save_invstd, c1, c2, (bf16x8*)dx, (bf16x8*)nullptr);
+  LEC_CHECK_LAUNCH("bn_bwd_apply_kernel");
+  return LEC_OK;
+}
+
 extern "C" int lec_bn_bwd_prereduced(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean,
                                      const float* save_invstd, int n_partials, void* dx, float* dgamma, float* dbeta, void* workspace,
                                      int64_t workspace_bytes, lec_stream_t stream) {

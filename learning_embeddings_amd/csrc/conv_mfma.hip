@@ -1036,10 +1036,21 @@ namespace lec {
 // -- double-buffered, one barrier per chunk.  A wave owns a TCO x TCI block of 32 x 32 accumulator tiles for the whole
 // launch and adds it into dW with float atomics at the end (rows of 32 consecutive floats per instruction).
 // KO / KI: output / input channels of this workgroup (blockIdx.y selects the KO- or KI-wide window of a wider layer).
-template <int KO, int KI, int WCO, int NW, bool SPLIT_CO>
+// XF (conv3 behind bn3): dY does not exist yet.  The kernel is handed g (the masked gradient, pass 1's output) and the
+// BatchNorm's input instead, forms pass 2 -- dx = gamma invstd (g - c1 - xhat c2), rounded to bf16, bn_bwd_apply_kernel's
+// arithmetic -- on the 16-byte pieces while they sit in registers between the coalesced load and the transposed LDS store,
+// writes dx out for the data-gradient kernel (coalesced, the same addresses) and uses it as its own dY operand.  The separate
+// pass 2 (read g, x; write dx) and this kernel's read of dx go away: one read of a block-output-sized tensor less per layer.
+struct XfArgs {
+  const unsigned short* xbn;      // [M][CoutTot] BatchNorm input
+  const float *gamma, *mean, *invstd, *c1, *c2;   // [CoutTot]
+  unsigned short* dx;             // [M][CoutTot] out
+};
+
+template <int KO, int KI, int WCO, int NW, bool SPLIT_CO, bool XF>
 __global__ __launch_bounds__(NW * 64) void wgrad1x1_kernel(const unsigned short* __restrict__ dY, int CoutTot,
                                                            const unsigned short* __restrict__ X, int CinTot, int64_t M,
-                                                           float* __restrict__ dW) {
+                                                           float* __restrict__ dW, XfArgs xf) {
   constexpr int MC = 64, NT = NW * 64;                 // rows per chunk, threads
   constexpr int WCI = NW / WCO, TCO = KO / 32 / WCO, TCI = KI / 32 / WCI;
   constexpr int NC8 = (KO + KI) / 8;                   // 16-byte pieces per row
@@ -1063,6 +1074,16 @@ __global__ __launch_bounds__(NW * 64) void wgrad1x1_kernel(const unsigned short*
   // (element (n, m) at n * MC + (((m >> 3) ^ ((n >> 3) & 7)) << 3) + (m & 7)) their 4-byte stores fall on 32 different banks.
   const int64_t nchunks = M / MC;
   u32x4_t regs[PAIRS][2];
+  u32x4_t regx[XF ? PAIRS : 1][2];                       // XF: the BatchNorm input at the dY pieces' addresses
+  float* Cs = (float*)(smem + 2 * (KO + KI) * MC);       // XF: [5][KO] gamma*invstd, mean, invstd, c1, c2 of this workgroup's channels
+  if (XF) {
+    for (int e = threadIdx.x; e < KO; e += NT) {
+      const float is = xf.invstd[co0 + e];
+      Cs[e] = xf.gamma[co0 + e] * is; Cs[KO + e] = xf.mean[co0 + e]; Cs[2 * KO + e] = is;
+      Cs[3 * KO + e] = xf.c1[co0 + e]; Cs[4 * KO + e] = xf.c2[co0 + e];
+    }
+    __syncthreads();
+  }
   auto load_chunk = [&](int64_t c) {
 #pragma unroll
     for (int i = 0; i < PAIRS; ++i) {
@@ -1073,16 +1094,42 @@ __global__ __launch_bounds__(NW * 64) void wgrad1x1_kernel(const unsigned short*
       const int ld = c8 < KO / 8 ? CoutTot : CinTot;
       regs[i][0] = *(const u32x4_t*)src;
       regs[i][1] = *(const u32x4_t*)(src + ld);
+      if (XF) {                                          // (the X pieces re-read their own address: every load stays unconditional)
+        const unsigned short* sx = c8 < KO / 8 ? xf.xbn + row * CoutTot + co0 + c8 * 8 : src;
+        regx[i][0] = *(const u32x4_t*)sx;
+        regx[i][1] = *(const u32x4_t*)(sx + ld);
+      }
     }
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, int64_t c) {
     unsigned short* T = smem + buf * (KO + KI) * MC;
 #pragma unroll
     for (int i = 0; i < PAIRS; ++i) {
       const int q = threadIdx.x + NT * i, rest = q >> 5;
       const int c8 = (rest % (NC8 / 8)) * 8 + (q & 7), m = (rest / (NC8 / 8)) * 8 + ((q >> 3) & 3) * 2;
-      const unsigned int a4[4] = {regs[i][0].x, regs[i][0].y, regs[i][0].z, regs[i][0].w};
-      const unsigned int b4[4] = {regs[i][1].x, regs[i][1].y, regs[i][1].z, regs[i][1].w};
+      unsigned int a4[4] = {regs[i][0].x, regs[i][0].y, regs[i][0].z, regs[i][0].w};
+      unsigned int b4[4] = {regs[i][1].x, regs[i][1].y, regs[i][1].z, regs[i][1].w};
+      if (XF && c8 < KO / 8) {
+        const unsigned int xa[4] = {regx[i][0].x, regx[i][0].y, regx[i][0].z, regx[i][0].w};
+        const unsigned int xb[4] = {regx[i][1].x, regx[i][1].y, regx[i][1].z, regx[i][1].w};
+        unsigned int oa[4] = {0u, 0u, 0u, 0u}, ob[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int ch = c8 * 8 + j, sh = (j & 1) * 16;
+          const float gs = Cs[ch], mu = Cs[KO + ch], is = Cs[2 * KO + ch], k1 = Cs[3 * KO + ch], k2 = Cs[4 * KO + ch];
+          const float ga = c1_bf2f((unsigned short)(a4[j >> 1] >> sh)), gb = c1_bf2f((unsigned short)(b4[j >> 1] >> sh));
+          const float ha = (c1_bf2f((unsigned short)(xa[j >> 1] >> sh)) - mu) * is, hb = (c1_bf2f((unsigned short)(xb[j >> 1] >> sh)) - mu) * is;
+          oa[j >> 1] |= (unsigned int)c1_f2bf(gs * (ga - k1 - ha * k2)) << sh;
+          ob[j >> 1] |= (unsigned int)c1_f2bf(gs * (gb - k1 - hb * k2)) << sh;
+        }
+        unsigned short* dst = xf.dx + (c * MC + m) * CoutTot + co0 + c8 * 8;
+        u32x4_t va, vb;
+        va.x = oa[0]; va.y = oa[1]; va.z = oa[2]; va.w = oa[3]; vb.x = ob[0]; vb.y = ob[1]; vb.z = ob[2]; vb.w = ob[3];
+        __builtin_nontemporal_store(va, (u32x4_t*)dst);
+        __builtin_nontemporal_store(vb, (u32x4_t*)(dst + CoutTot));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a4[j] = oa[j]; b4[j] = ob[j]; }
+      }
       unsigned int* base = (unsigned int*)(T + (c8 * 8) * MC + (((m >> 3) ^ (c8 & 7)) << 3) + (m & 7));
 #pragma unroll
       for (int j = 0; j < 4; ++j) {                    // channels 2j, 2j + 1 of the octet: (row m, row m + 1) in one dword
@@ -1092,7 +1139,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad1x1_kernel(const unsigned short*
     }
   };
   int64_t c = blockIdx.x;
-  if (c < nchunks) { load_chunk(c); store_chunk(0); }
+  if (c < nchunks) { load_chunk(c); store_chunk(0, c); }
   __syncthreads();
   int buf = 0;
   for (; c < nchunks; c += gridDim.x) {
@@ -1118,7 +1165,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad1x1_kernel(const unsigned short*
 #pragma unroll
         for (int b = 0; b < TCI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
     }
-    if (cn < nchunks) store_chunk(buf ^ 1);
+    if (cn < nchunks) store_chunk(buf ^ 1, cn);
     __syncthreads();
     buf ^= 1;
   }
@@ -1133,12 +1180,13 @@ __global__ __launch_bounds__(NW * 64) void wgrad1x1_kernel(const unsigned short*
     }
 }
 
-template <int KO, int KI, int WCO, int NW, bool SPLIT_CO>
-static int launch_wgrad1x1(const void* dy, int CoutTot, const void* x, int CinTot, int64_t M, float* dW, hipStream_t st) {
-  const size_t smem = (size_t)2 * (KO + KI) * 64 * sizeof(unsigned short);
+template <int KO, int KI, int WCO, int NW, bool SPLIT_CO, bool XF = false>
+static int launch_wgrad1x1(const void* dy, int CoutTot, const void* x, int CinTot, int64_t M, float* dW, hipStream_t st,
+                           XfArgs xf = XfArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}) {
+  const size_t smem = (size_t)2 * (KO + KI) * 64 * sizeof(unsigned short) + (XF ? 5 * KO * sizeof(float) : 0);
   static bool attr_set = false;
   if (smem > 64 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad1x1_kernel<KO, KI, WCO, NW, SPLIT_CO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad1x1_kernel<KO, KI, WCO, NW, SPLIT_CO, XF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(wgrad1x1)");
     attr_set = true;
   }
@@ -1147,13 +1195,33 @@ static int launch_wgrad1x1(const void* dy, int CoutTot, const void* x, int CinTo
   // two workgroups per CU where their LDS images fit (measured: 5.8 against 5.7 TB/s with one; three: 5.4), one otherwise
   const int want = 256 * (smem <= 80 * 1024 ? 2 : 1) / ny;
   const int nblk = (int)(nchunks < want ? nchunks : want);
-  hipLaunchKernelGGL((wgrad1x1_kernel<KO, KI, WCO, NW, SPLIT_CO>), dim3(nblk, ny), dim3(NW * 64), smem, st, (const unsigned short*)dy, CoutTot,
-                     (const unsigned short*)x, CinTot, M, dW);
+  hipLaunchKernelGGL((wgrad1x1_kernel<KO, KI, WCO, NW, SPLIT_CO, XF>), dim3(nblk, ny), dim3(NW * 64), smem, st, (const unsigned short*)dy, CoutTot,
+                     (const unsigned short*)x, CinTot, M, dW, xf);
   LEC_CHECK_LAUNCH("wgrad1x1_kernel");
   return LEC_OK;
 }
 
 }  // namespace lec
+
+extern "C" int lec_conv1x1_wgrad_bnapply_supported(int Cin, int Cout, int64_t M) {
+  return ((Cin == 64 && Cout == 256) || (Cin == 128 && Cout == 512)) && M > 0 && M % 64 == 0;
+}
+
+extern "C" int lec_conv1x1_wgrad_bnapply(const void* g, const void* bn_x, const void* x, int64_t M, int Cin, int Cout, const float* gamma,
+                                         const float* save_mean, const float* save_invstd, const float* c1, const float* c2, void* dx, float* dw,
+                                         lec_stream_t stream) {
+  using namespace lec;
+  LEC_CHECK_ARG(g && bn_x && x && gamma && save_mean && save_invstd && c1 && c2 && dx && dw, "conv1x1_wgrad_bnapply: null pointer");
+  LEC_CHECK_ARG(lec_conv1x1_wgrad_bnapply_supported(Cin, Cout, M), "conv1x1_wgrad_bnapply: unsupported shape Cin=%d Cout=%d M=%lld", Cin, Cout,
+                (long long)M);
+  const XfArgs xf{(const unsigned short*)bn_x, gamma, save_mean, save_invstd, c1, c2, (unsigned short*)dx};
+  hipStream_t st = (hipStream_t)stream;
+  // 64 -> 256: two 128-channel windows (x, a quarter of the traffic, is read twice): 51 KB of LDS and 204 registers instead of
+  // the one-window form's 85 KB and 300 -- two workgroups per CU instead of one (step: 44.1 against 44.6 ms).  128 -> 512: two
+  // 256-channel windows, eight waves (four 128-channel windows measured worse: 44.5 against 43.9 ms)
+  if (Cin == 64) return launch_wgrad1x1<128, 64, 2, 4, true, true>(g, Cout, x, Cin, M, dw, st, xf);
+  return launch_wgrad1x1<256, 128, 4, 8, true, true>(g, Cout, x, Cin, M, dw, st, xf);
+}
 
 extern "C" int lec_conv1x1_wgrad_supported(int Cin, int Cout, int64_t M) {
   const bool shape = (Cin == 64 && (Cout == 64 || Cout == 256)) || (Cin == 128 && Cout == 512) || (Cin == 256 && (Cout == 64 || Cout == 128)) ||

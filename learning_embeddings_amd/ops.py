@@ -400,7 +400,22 @@ class BNActFn(torch.autograd.Function):
             nbytes = el * ((4 + (2 if dy2 is not None else 0) + 2) + (4 + 2)) + (el // 8 if relu else 0)
         else:            # both passes read dy [+ dy2], x, mask; pass 2 writes dx
             nbytes = el * (2 * (4 + (2 if dy2 is not None else 0)) + 2) + (2 * (el // 8) if relu else 0)
-        if pre:
+        lazy = (LAZY_BN_PASS2 and has_res and x.data_ptr() in _LAZY_OK and x.dtype == torch.bfloat16
+                and lib.lec_conv1x1_wgrad_bnapply_supported(_LAZY_OK[x.data_ptr()], Cc, M))
+        _LAZY_OK.pop(x.data_ptr(), None)
+        if lazy:
+            # the convolution that produced x runs pass 2 inside its weight-gradient kernel (conv1x1_wgrad_bnapply_rows): here only
+            # pass 1 (unless a data-gradient epilogue already did it) and the finalize; dx is handed on UNWRITTEN with a record
+            if pre:
+                _bn_timed(lambda: check(lib.lec_bn_bwd_finalize(M, Cc, pre, dptr(dgamma), dptr(dbeta), dptr(ws), ws.numel(), stream_ptr())), 0)
+            else:
+                nb1 = el * (4 + (2 if dy2 is not None else 0) + 2) + (el // 8 if relu else 0)
+                _bn_timed(lambda: check(lib.lec_bn_bwd_pass1(dptr(dy), dptr(dy2), dptr(mask) if relu else None, dptr(x), M, Cc, dptr(save_mean),
+                                                             dptr(save_invstd), dptr(dres), dptr(dgamma), dptr(dbeta), dptr(ws), ws.numel(),
+                                                             stream_ptr())), nb1)
+            _LAZY_DX.clear()
+            _LAZY_DX[dx.data_ptr()] = {'g': dres, 'x': x, 'gamma': weight, 'mean': save_mean, 'invstd': save_invstd, 'M': M, 'C': Cc}
+        elif pre:
             nbytes = el * 6                       # pass 2 only: read g, x; write dx (pass 1 ran in the convolution's epilogue)
             _bn_timed(lambda: check(lib.lec_bn_bwd_prereduced(dptr(dy), dptr(x), M, Cc, dptr(weight), dptr(save_mean), dptr(save_invstd), pre,
                                                               dptr(dx), dptr(dgamma), dptr(dbeta), dptr(ws), ws.numel(), stream_ptr())), nbytes)
@@ -431,6 +446,12 @@ _FOLDED = {}
 # statistics and runs the convolution again with the BatchNorm apply in its epilogue, which writes both tensors.
 DEFER_BN_APPLY = _os.environ.get('LEC_DEFER_BN_APPLY', '1') != '0'
 _DEFERRED = {}
+# Backward of the same pair: pass 2 of bn3's backward runs inside conv3's weight-gradient kernel (lec_conv1x1_wgrad_bnapply).
+# _LAZY_OK: data_ptr of a BatchNorm input whose producer convolution can do that -> its input channels (filled by the
+# convolution's forward); _LAZY_DX: data_ptr of the UNWRITTEN dx BNActFn.backward returned -> what the kernel needs.
+LAZY_BN_PASS2 = _os.environ.get('LEC_LAZY_BN_PASS2', '1') != '0'
+_LAZY_OK = {}
+_LAZY_DX = {}
 _bn_ws = {}
 _BN_WS_OWNER = [0, 0]        # (data_ptr of the tensor whose statistics partials sit in the BN workspace, number of partial rows)
 
@@ -485,6 +506,27 @@ def conv1x1_wgrad_rows(dy_rows, x_rows, dw):
     return dw
 
 
+def bn_bwd_apply_lazy(rec, dx):
+    """Pass 2 of a BatchNorm backward whose dx was handed on unwritten (_LAZY_DX) and whose consumer cannot run it itself."""
+    ws = _bn_workspace(dx.device)
+    check(lib.lec_bn_bwd_apply(dptr(rec['g']), dptr(rec['x']), rec['M'], rec['C'], dptr(rec['gamma']), dptr(rec['mean']), dptr(rec['invstd']),
+                               dptr(dx), dptr(ws), ws.numel(), stream_ptr()))
+
+
+def conv1x1_wgrad_bnapply_rows(rec, x_rows, dx, dw):
+    """dx (the UNWRITTEN gradient of a 1x1 layer's output, [N, Cout, H, W] channels_last) := pass 2 of the BatchNorm backward
+    described by rec (_LAZY_DX), and dw [Cout, Cin] (fp32) += dx^T x_rows, in one kernel (lec_conv1x1_wgrad_bnapply)."""
+    M, cin = x_rows.shape
+    cout = rec['C']
+    if dw.dtype != torch.float32 or dw.numel() != cout * cin or not dw.is_contiguous():
+        raise ValueError('dw must be a contiguous float32 [Cout, Cin] buffer')
+    ws = _bn_workspace(dx.device)
+    off = lib.lec_bn_workspace_coeff_offset(cout)
+    check(lib.lec_conv1x1_wgrad_bnapply(dptr(rec['g']), dptr(rec['x']), dptr(x_rows), M, cin, cout, dptr(rec['gamma']), dptr(rec['mean']),
+                                        dptr(rec['invstd']), C.c_void_p(ws.data_ptr() + off), C.c_void_p(ws.data_ptr() + off + 4 * cout),
+                                        dptr(dx), dptr(dw), stream_ptr()))
+
+
 def conv1x1_bnapply_supported(cin, cout, M):
     return bool(lib.lec_conv1x1_bnapply_supported(int(cin), int(cout), int(M)))
 
@@ -502,6 +544,9 @@ def conv1x1_stats_rows(x_rows, w2):
     _BN_WS_OWNER[0], _BN_WS_OWNER[1] = y.data_ptr(), n.value
     _DEFERRED.clear()
     _DEFERRED[y.data_ptr()] = (x_rows, w2)
+    if len(_LAZY_OK) > 64:
+        _LAZY_OK.clear()
+    _LAZY_OK[y.data_ptr()] = cin              # this layer's backward can run the following BatchNorm's pass 2 in its weight gradient
     return y
 
 

@@ -226,6 +226,23 @@ class _OverlapConvFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, w16 = ctx.saved_tensors; conv = ctx.conv
         gx = None
+        wgrad_done = False
+        lz = _ops()._LAZY_DX.pop(gy.data_ptr(), None)
+        if lz is not None:
+            # gy is UNWRITTEN: the BatchNorm behind this layer left pass 2 of its backward to us.  With the flat arena's fp32 gradient
+            # slot at hand the weight-gradient kernel does it on the way (and writes gy for the data gradient below); otherwise
+            # pass 2 runs on its own first.
+            ov = WgradOverlap.instance
+            w = conv.weight
+            if (ov is not None and ov.arena is not None and w.grad is not None and w.grad.dtype == torch.float32 and _is_pointwise(conv)
+                    and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
+                    and gy.is_contiguous(memory_format=torch.channels_last)):
+                _ops().conv1x1_wgrad_bnapply_rows(lz, _rows(x), gy, w.grad.view(conv.out_channels, conv.in_channels))
+                if ov.reducer is not None:
+                    ov.reducer.mark_ready(w)
+                wgrad_done = True
+            else:
+                _ops().bn_bwd_apply_lazy(lz, gy)
         if ctx.needs_input_grad[0]:
             nhwc_g = gy.is_contiguous(memory_format=torch.channels_last)
             if ctx.own3 and nhwc_g:                             # dX = conv(dY, W flipped and transposed): the same kernel,
@@ -252,7 +269,8 @@ class _OverlapConvFn(torch.autograd.Function):
             rec = _ops()._FORKS[x.data_ptr()]
             if rec['dres'] is None and x.data_ptr() not in _ops()._FOLDED and gx.data_ptr() not in _ops()._FOLDED:
                 rec['dres'] = gx                                # (the other consumer's data gradient may fold it into its epilogue)
-        WgradOverlap.instance.submit(gy, x, w16, conv)
+        if not wgrad_done:
+            WgradOverlap.instance.submit(gy, x, w16, conv)
         return gx, None, None
 
 
@@ -361,7 +379,7 @@ class ResNet(nn.Module):
     def forward(self, x):
         if x.is_cuda and torch.is_autocast_enabled() and x.dtype == torch.float32:
             x = x.to(torch.get_autocast_gpu_dtype())          # the stem conv sees low-precision input like every other layer
-        _ops()._FORKS.clear(); _ops()._FOLDED.clear(); _ops()._DEFERRED.clear()   # records of a forward whose backward never ran (or raised)
+        _ops()._FORKS.clear(); _ops()._FOLDED.clear(); _ops()._DEFERRED.clear(); _ops()._LAZY_OK.clear(); _ops()._LAZY_DX.clear()   # records of a forward whose backward never ran (or raised)
         x = self.maxpool(self.bn1(self.conv1(x)))
         blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
         for i, b in enumerate(blocks):

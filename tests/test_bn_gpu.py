@@ -255,8 +255,72 @@ def test_conv3_bn3_forward_with_apply_inside_the_convolution_is_bit_identical():
     n_par = sum(1 for b in blocks for _ in b.parameters())
     for i, (a, b) in enumerate(zip(res['defer'], res['plain'])):
         if 2 <= i < 2 + n_par and a.dim() == 4:      # convolution weight gradients: the library's kernels (fp32 atomics, then rounded to
-            assert (a - b).abs().max().item() <= 1e-2 * b.abs().max().item()   # bf16) differ by an ulp of bf16 from run to run
+            assert (a - b).abs().max().item() <= 3e-2 * b.abs().max().item()   # bf16) differ by an ulp or two of bf16 from run to run
         else:                                        # output, input gradient, BatchNorm parameter gradients, running statistics
+            assert torch.equal(a, b), i
+
+
+@pytest.mark.parametrize('with_arena', [True, False])
+def test_bn3_backward_pass2_inside_conv3_weight_gradient(with_arena):
+    """ops.LAZY_BN_PASS2: bn3's backward hands its dx on unwritten and conv3's backward runs pass 2 inside its weight-gradient kernel
+    (flat arena at hand) or as a stand-alone apply pass (no arena: the fallback).  Through ResNet-50's layer1 the output, the input
+    gradient and the BatchNorm parameter gradients must EQUAL the path with pass 2 in lec_bn_bwd; convolution weight gradients agree
+    to the rounding of the library's bf16 result."""
+    from learning_embeddings_amd import resnet as R
+    from learning_embeddings_amd.parallel import FlatArena
+    from learning_embeddings_amd.resnet import WgradOverlap
+    torch.manual_seed(0)
+    net = R.ResNet(R.Bottleneck, [3, 4, 6, 3])
+    blocks = list(net.layer1)
+    for b in blocks:
+        b.to(DEV).to(memory_format=torch.channels_last).train()
+    params = [p_ for b in blocks for p_ in b.parameters()]
+    arena = FlatArena(params) if with_arena else None
+    x0 = (torch.randn(4, 64, 16, 16, device=DEV) * 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gsave = None
+    res = {}
+    calls = {}
+    orig = ops.conv1x1_wgrad_bnapply_rows; orig_fb = ops.bn_bwd_apply_lazy
+    prev = ops.LAZY_BN_PASS2
+    try:
+        for tag in ('warm', 'lazy', 'plain'):
+            ops.LAZY_BN_PASS2 = tag != 'plain'
+            def counted(*a, **k):
+                calls[tag] = calls.get(tag, 0) + 1
+                return orig(*a, **k)
+            def counted_fb(*a, **k):
+                calls[tag + '_fallback'] = calls.get(tag + '_fallback', 0) + 1
+                return orig_fb(*a, **k)
+            ops.conv1x1_wgrad_bnapply_rows = counted; ops.bn_bwd_apply_lazy = counted_fb
+            if arena is not None:
+                arena.zero_grad()
+            else:
+                for p_ in params:
+                    p_.grad = torch.zeros_like(p_)
+            WgradOverlap.instance = WgradOverlap(arena=arena)
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                y = x
+                for i, b in enumerate(blocks):
+                    y = b(y, fork=i + 1 < len(blocks))
+            if gsave is None:
+                gsave = torch.randn_like(y)
+            y.backward(gsave)
+            WgradOverlap.instance.join(); torch.cuda.synchronize()
+            res[tag] = [y.detach().clone(), x.grad.clone()] + [p_.grad.detach().clone() for p_ in params]
+    finally:
+        WgradOverlap.instance = None
+        ops.LAZY_BN_PASS2 = prev
+        ops.conv1x1_wgrad_bnapply_rows = orig; ops.bn_bwd_apply_lazy = orig_fb
+    if with_arena:
+        assert calls.get('lazy') == 3 and 'lazy_fallback' not in calls
+    else:
+        assert calls.get('lazy_fallback') == 3 and 'lazy' not in calls
+    assert 'plain' not in calls and 'plain_fallback' not in calls and not ops._LAZY_DX and not ops._LAZY_OK
+    for i, (a, b) in enumerate(zip(res['lazy'], res['plain'])):
+        if i >= 2 and a.dim() == 4:                  # convolution weight gradients (library: fp32 atomics then bf16; own: fp32)
+            assert (a.float() - b.float()).abs().max().item() <= 3e-2 * b.float().abs().max().item(), i
+        else:
             assert torch.equal(a, b), i
 
 

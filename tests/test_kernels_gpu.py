@@ -641,6 +641,36 @@ def test_conv1x1_twice_with_batchnorm_apply_in_the_epilogue(cin, cout, M):
     assert outs[0][2].any() and (outs[0][1] == 0).any()
 
 
+@pytest.mark.parametrize('cin,cout,M', [(64, 256, 64 * 37), (128, 512, 64 * 19), (64, 256, 64 * 1100)])
+def test_conv1x1_wgrad_with_batchnorm_backward_pass2_in_its_staging(cin, cout, M):
+    """lec_conv1x1_wgrad_bnapply: dx must be bit-equal to pass 2 of lec_bn_bwd (here through lec_bn_bwd_prereduced on the same
+    coefficients) and dw must be dx^T x accumulated in fp32."""
+    from learning_embeddings_amd._lib import lib, check, dptr, stream_ptr
+    import ctypes as C
+    assert lib.lec_conv1x1_wgrad_bnapply_supported(cin, cout, M) and not lib.lec_conv1x1_wgrad_bnapply_supported(256, 64, M)
+    g_ = torch.Generator(device='cpu').manual_seed(cout + M)
+    hw = M // 32
+    nhwc = lambda t: t.view(32, hw, 1, t.shape[1]).permute(0, 3, 1, 2)
+    g = nhwc((torch.randn(M, cout, generator=g_) * 0.5).to(DEV).to(torch.bfloat16))
+    xbn = nhwc((torch.randn(M, cout, generator=g_) * 1.3 + 0.4).to(DEV).to(torch.bfloat16))
+    x = (torch.randn(M, cin, generator=g_) * 0.7).to(DEV).to(torch.bfloat16)
+    gamma = (torch.rand(cout, generator=g_) + 0.5).to(DEV); mean = (torch.randn(cout, generator=g_) * 0.3).to(DEV)
+    invstd = (torch.rand(cout, generator=g_) + 0.5).to(DEV)
+    ws = ops._bn_workspace(g.device)
+    part = (torch.randn(2, cout, generator=g_) * 0.05 * M).to(DEV)                     # one row of "partials": c1, c2 = part / M
+    ws[:2 * cout * 4].view(torch.float32).copy_(part.flatten())
+    dx_ref = torch.empty_like(g); dgam = torch.empty(cout, device=DEV); dbet = torch.empty(cout, device=DEV)
+    check(lib.lec_bn_bwd_prereduced(dptr(g), dptr(xbn), M, cout, dptr(gamma), dptr(mean), dptr(invstd), 1, dptr(dx_ref), dptr(dgam), dptr(dbet),
+                                    dptr(ws), ws.numel(), stream_ptr()))
+    off = lib.lec_bn_workspace_coeff_offset(cout)
+    dx = torch.empty_like(g); dw = torch.full((cout, cin), 0.5, device=DEV)
+    check(lib.lec_conv1x1_wgrad_bnapply(dptr(g), dptr(xbn), dptr(x), M, cin, cout, dptr(gamma), dptr(mean), dptr(invstd),
+                                        C.c_void_p(ws.data_ptr() + off), C.c_void_p(ws.data_ptr() + off + 4 * cout), dptr(dx), dptr(dw), stream_ptr()))
+    assert torch.equal(dx, dx_ref)
+    ref = dx_ref.permute(0, 2, 3, 1).reshape(M, cout).float().double().t() @ x.float().double() + 0.5
+    assert ((dw.double() - ref).abs().max() / ref.abs().max()).item() < 2e-5
+
+
 def test_conv1x1_statistics_feed_batchnorm():
     """conv (MFMA kernel, statistics in the epilogue) -> BatchNorm (no statistics pass) equals conv -> full BatchNorm."""
     g = torch.Generator(device='cpu').manual_seed(5)
