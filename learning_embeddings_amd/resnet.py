@@ -155,15 +155,14 @@ MFMA_3X3 = os.environ.get('LEC_CONV3X3_MFMA', '1') != '0'
 # leads it in the data gradient (207 vs 245 us); no measurable gain inside the step, so it stays opt-in:
 # '0' (default) nowhere, 'dgrad' data gradient only, '1' everywhere
 MFMA_3X3_C128 = os.environ.get('LEC_CONV3X3_C128', '0')
-# the weight gradient of the same wide 1x1 layers: liblecone's MFMA kernel (lec_conv1x1_wgrad) accumulates dY^T X into the
-# arena's fp32 gradient slot with float atomics -- alone 179 us against the library's 204 us (+ cast and copy kernels) at
-# 64 -> 256 @56x56 (tools/bench_conv1x1_wgrad.py), but inside the step, where it shares the GPU with the main stream's
-# HBM-bound kernels, the step time is unchanged (46.2 / 45.7 ms off, 45.8 / 45.9 ms on): opt-in, because float atomics
-# also make the summation order (not the value to fp32 tolerance) vary from run to run
-MFMA_WGRAD = os.environ.get('LEC_CONV1X1_WGRAD', '0') != '0'
-# the weight gradient of layer1's 3x3 convolution (64 -> 64 @56x56): liblecone's MFMA kernel (lec_conv3x3_c64_wgrad), alone 222 us
-# against the library's 385 us (577 us inside the step) -- and again no change of the step time (44.5 vs 44.3 ms): opt-in
-MFMA_WGRAD_3X3 = os.environ.get('LEC_CONV3X3_WGRAD', '0') != '0'
+# the weight gradients of the same wide 1x1 layers and of layer1's 3x3 convolution: liblecone's MFMA kernels (lec_conv1x1_wgrad,
+# lec_conv3x3_c64_wgrad) accumulate straight into the arena's fp32 gradient slot with float atomics -- alone 179 us against the
+# library's 204 us (+ cast and copy kernels) at 64 -> 256 @56x56, 222 against 385 us for the 3x3.  While the second stream still
+# had slack they changed nothing in the step (46.4 ms either way); since the BatchNorm passes moved into the convolutions the step
+# is the sum of its kernels and they are worth 0.4 ms (44.5 -> 44.1 ms).  Float atomics make the summation ORDER (not the value to
+# fp32 tolerance) vary from run to run, as the library's own split-K weight gradients do.
+MFMA_WGRAD = os.environ.get('LEC_CONV1X1_WGRAD', '1') != '0'
+MFMA_WGRAD_3X3 = os.environ.get('LEC_CONV3X3_WGRAD', '1') != '0'
 GEMM_FWD_MIN_CIN = 1024
 GEMM_DGRAD_MIN_CIN = 256
 
