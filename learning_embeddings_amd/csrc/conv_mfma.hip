@@ -1225,7 +1225,7 @@ extern "C" int lec_conv1x1_wgrad_bnapply(const void* g, const void* bn_x, const 
 
 extern "C" int lec_conv1x1_wgrad_supported(int Cin, int Cout, int64_t M) {
   const bool shape = (Cin == 64 && (Cout == 64 || Cout == 256)) || (Cin == 128 && Cout == 512) || (Cin == 256 && (Cout == 64 || Cout == 128)) ||
-                     (Cin == 512 && Cout == 128);
+                     (Cin == 512 && Cout == 128) || (Cin == 256 && Cout == 1024) || (Cin == 1024 && Cout == 256);
   return shape && M > 0 && M % 64 == 0;
 }
 
@@ -1239,6 +1239,9 @@ extern "C" int lec_conv1x1_wgrad(const void* dy, const void* x, int64_t M, int C
   if (Cin == 256 && Cout == 64) return launch_wgrad1x1<64, 256, 1, 4, true>(dy, Cout, x, Cin, M, dw, st);
   if (Cin == 256 && Cout == 128) return launch_wgrad1x1<128, 256, 4, 8, true>(dy, Cout, x, Cin, M, dw, st);
   if (Cin == 128 && Cout == 512) return launch_wgrad1x1<256, 128, 4, 8, true>(dy, Cout, x, Cin, M, dw, st);  // two 256-row halves of dW
+  // layer3's 1x1 pairs (14 x 14): 256 x 256 windows of dW, four of them; the narrow operand is read once per window
+  if (Cin == 256 && Cout == 1024) return launch_wgrad1x1<256, 256, 4, 8, true>(dy, Cout, x, Cin, M, dw, st);
+  if (Cin == 1024 && Cout == 256) return launch_wgrad1x1<256, 256, 4, 8, false>(dy, Cout, x, Cin, M, dw, st);
   return launch_wgrad1x1<128, 256, 2, 8, false>(dy, Cout, x, Cin, M, dw, st);                                // 512 -> 128: two 256-column halves
 }
 

@@ -101,7 +101,7 @@ class WgradOverlap:
             return False
         ops = _ops()
         m = gy.shape[0] * gy.shape[2] * gy.shape[3]
-        if not ops.conv1x1_wgrad_supported(conv.in_channels, conv.out_channels, m):
+        if not ops.conv1x1_wgrad_supported(conv.in_channels, conv.out_channels, m) or (max(conv.in_channels, conv.out_channels) > 512 and not MFMA_WGRAD_L3):
             return False
         gw = w.grad.view(conv.out_channels, conv.in_channels)      # a 1x1 weight is [Cout][Cin] in memory in either layout
         ops.conv1x1_wgrad_rows(_rows(gy), _rows(x), gw)
@@ -163,6 +163,9 @@ MFMA_3X3_C128 = os.environ.get('LEC_CONV3X3_C128', '0')
 # fp32 tolerance) vary from run to run, as the library's own split-K weight gradients do.
 MFMA_WGRAD = os.environ.get('LEC_CONV1X1_WGRAD', '1') != '0'
 MFMA_WGRAD_3X3 = os.environ.get('LEC_CONV3X3_WGRAD', '1') != '0'
+# layer3's 256 <-> 1024 pairs (14 x 14): 104 against the library's 115 us alone, but 44.0 against 43.5 ms in the step (its 131 KB,
+# eight-wave workgroups sit on every CU beside layer3's short main-stream kernels): off
+MFMA_WGRAD_L3 = os.environ.get('LEC_CONV1X1_WGRAD_L3', '0') != '0'
 GEMM_FWD_MIN_CIN = 1024
 GEMM_DGRAD_MIN_CIN = 256
 

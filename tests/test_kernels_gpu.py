@@ -530,7 +530,7 @@ def test_conv3x3_c64_wgrad_mfma_vs_torch(N, H, W):
 
 
 @pytest.mark.parametrize('cin,cout,M', [(64, 64, 64), (64, 256, 64 * 5), (256, 64, 64 * 300), (256, 128, 64 * 257), (128, 512, 64 * 513),
-                                        (512, 128, 64 * 700)])
+                                        (512, 128, 64 * 700), (256, 1024, 64 * 130), (1024, 256, 64 * 70)])
 def test_conv1x1_wgrad_mfma_vs_fp32_matmul(cin, cout, M):
     """lec_conv1x1_wgrad: dw += dy^T x (bf16 in, fp32 accumulate, float atomics into the caller's buffer) against an fp32
     matmul -- integer-valued data first (every product and sum exact: the result must be bit-equal), then random data; the

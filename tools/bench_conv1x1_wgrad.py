@@ -20,7 +20,7 @@ def timed(fn, reps=20):
 
 def main():
     B = int(os.environ.get('LEC_B', 512))
-    for ci, co, hw in ((64, 256, 56), (64, 64, 56), (128, 512, 28), (256, 64, 56), (256, 128, 56), (512, 128, 28)):
+    for ci, co, hw in ((64, 256, 56), (64, 64, 56), (128, 512, 28), (256, 64, 56), (256, 128, 56), (512, 128, 28), (256, 1024, 14), (1024, 256, 14)):
         M = B * hw * hw
         g = torch.Generator(device='cpu').manual_seed(ci + co)
         x = (torch.randn(M // 8, ci, generator=g) * 0.7).to('cuda').to(torch.bfloat16).repeat(8, 1)
