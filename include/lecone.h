@@ -210,6 +210,17 @@ int lec_bn_fwd(const void* x, const void* residual, int64_t M, int C, const floa
 int lec_bn_bwd(const void* dy, const void* dy2, const void* y, const uint8_t* relu_mask, const void* x, int64_t M, int C,
                const float* gamma, const float* save_mean, const float* save_invstd, void* dx, void* dresidual,
                float* dgamma, float* dbeta, int relu, void* workspace, int64_t workspace_bytes, lec_stream_t stream);
+/* The same kernels on fp32 activations -- the reference's own precision (oe_h.py:281-328 runs torchvision's ResNet in fp32,
+ * no AMP anywhere): x, residual, y, dy, dy2, dx, dresidual are fp32 [M, C]; everything else as above.  The `_f32` twins of the
+ * staged entry points further down (lec_bn_fwd_prestat, lec_bn_bwd_pass1 / _apply / _prereduced) and of the max pooling follow
+ * the same rule: identical arguments, fp32 activations. */
+int lec_bn_fwd_f32(const void* x, const void* residual, int64_t M, int C, const float* gamma, const float* beta, float eps,
+                   float momentum, float* running_mean, float* running_var, int training, float* save_mean,
+                   float* save_invstd, void* y, int relu, uint8_t* relu_mask, void* workspace, int64_t workspace_bytes,
+                   lec_stream_t stream);
+int lec_bn_bwd_f32(const void* dy, const void* dy2, const void* y, const uint8_t* relu_mask, const void* x, int64_t M, int C,
+                   const float* gamma, const float* save_mean, const float* save_invstd, void* dx, void* dresidual,
+                   float* dgamma, float* dbeta, int relu, void* workspace, int64_t workspace_bytes, lec_stream_t stream);
 
 /* 1x1 stride-1 convolution on NHWC bf16 as an HBM-bound MFMA GEMM, y[M, Cout] = x[M, Cin] * w[Cout, Cin]^T, optionally with
  * the BatchNorm statistics of its output in the epilogue: replaces the library convolution AND the statistics pass of
@@ -256,6 +267,9 @@ int lec_conv1x1_dgrad_bnfold(const void* dy, const void* w, int w_transposed, in
 int lec_bn_bwd_prereduced(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean,
                           const float* save_invstd, int n_partials, void* dx, float* dgamma, float* dbeta, void* workspace,
                           int64_t workspace_bytes, lec_stream_t stream);
+int lec_bn_bwd_prereduced_f32(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean,
+                              const float* save_invstd, int n_partials, void* dx, float* dgamma, float* dbeta, void* workspace,
+                              int64_t workspace_bytes, lec_stream_t stream);
 /* Weight gradient of the 3x3 / stride 1 / pad 1 / 64 -> 64 convolution (torchvision Bottleneck.conv2 of layer1, reached from
  * oe_h.py:311,317): dw[co][ky][kx][ci] (fp32, the channels_last weight layout) += sum over pixels of dy[.., co] * x[shifted by tap, ci],
  * accumulated with float atomics into the caller's gradient buffer.  dy, x: [N, H, W, 64] bf16; H % 8 == 0 and W % 8 == 0. */
@@ -271,6 +285,10 @@ int lec_bn_bwd_finalize(int64_t M, int C, int n_partials, float* dgamma, float* 
                         lec_stream_t stream);
 int lec_bn_bwd_apply(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd,
                      void* dx, void* workspace, int64_t workspace_bytes, lec_stream_t stream);
+int lec_bn_bwd_pass1_f32(const void* dy, const void* dy2, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* save_mean,
+                         const float* save_invstd, void* g, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, lec_stream_t stream);
+int lec_bn_bwd_apply_f32(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd,
+                         void* dx, void* workspace, int64_t workspace_bytes, lec_stream_t stream);
 /* conv3 behind bn3, backward: the weight gradient of the 1x1 layer AND pass 2 of the BatchNorm backward in one kernel.  g [M, Cout] is
  * the masked gradient (pass 1's output: lec_bn_bwd's d residual, or lec_conv1x1_dgrad_bnfold's g), bn_x [M, Cout] the BatchNorm's
  * input, c1 / c2 [Cout] the per-channel means the finalize kernel leaves at lec_bn_workspace_coeff_offset(Cout) bytes into the
@@ -303,6 +321,29 @@ int lec_bn_fwd_prestat(const void* x, const void* residual, int64_t M, int C, co
                        float eps, float momentum, float* running_mean, float* running_var, int n_partials,
                        float* save_mean, float* save_invstd, void* y, int relu, uint8_t* relu_mask, void* workspace,
                        int64_t workspace_bytes, lec_stream_t stream);
+int lec_bn_fwd_prestat_f32(const void* x, const void* residual, int64_t M, int C, const float* gamma, const float* beta,
+                           float eps, float momentum, float* running_mean, float* running_var, int n_partials,
+                           float* save_mean, float* save_invstd, void* y, int relu, uint8_t* relu_mask, void* workspace,
+                           int64_t workspace_bytes, lec_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * (7b) Convolutions at the reference's precision: fp32 NHWC activations, fp32 weights, exact fp32 arithmetic on the f32-input
+ *     matrix instruction (v_mfma_f32_32x32x2_f32).  Replaces torchvision's conv2d inside FeatCNN18 / FeatCNN (oe_h.py:311,317,
+ *     :331-378; every 1x1 / 3x3 / 7x7, stride 1 / 2 layer of ResNet-18 / -50) and its autograd, as implicit GEMMs.
+ *     x: [N, H, W, Cin], w / dw: [Cout][R][S][Cin] (a channels_last conv weight), y / dy: [N, Ho, Wo, Cout] with
+ *     Ho = (H + 2 pad - R) / stride + 1.  Cin and Cout powers of two >= 4 (the stem's 3 input channels are padded to 4 by the
+ *     caller), stride 1 or 2.
+ *     lec_conv_f32_fwd: partials (optional, >= 512 * 2 * Cout floats) receives n_partials (HOST int, <= 512) rows of per-channel
+ *       [sum | sum of squares] of y -- the layout lec_bn_fwd_prestat_f32 consumes: the BatchNorm statistics pass over y disappears.
+ *     lec_conv_f32_dgrad: dx is overwritten (a strided layer runs one launch per parity class of the input pixels).
+ *     lec_conv_f32_wgrad: dw += (float atomics over the split reduction; zero it first for a plain gradient).
+ * ------------------------------------------------------------------------------------------------------------- */
+int lec_conv_f32_fwd(const float* x, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                     float* y, float* partials, int64_t partials_bytes, int* n_partials, lec_stream_t stream);
+int lec_conv_f32_dgrad(const float* dy, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                       float* dx, lec_stream_t stream);
+int lec_conv_f32_wgrad(const float* dy, const float* x, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                       float* dw, lec_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * (8) 3x3 / stride 2 / pad 1 max pooling on NHWC bf16 (the ResNet stem's `maxpool`, oe_h.py:311 -> torchvision).
@@ -312,6 +353,8 @@ int lec_bn_fwd_prestat(const void* x, const void* residual, int64_t M, int C, co
  * ------------------------------------------------------------------------------------------------------------- */
 int lec_maxpool3x3s2_fwd(const void* x, int N, int H, int W, int C, void* y, uint8_t* argmax, lec_stream_t stream);
 int lec_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, int N, int H, int W, int C, void* dx, lec_stream_t stream);
+int lec_maxpool3x3s2_fwd_f32(const void* x, int N, int H, int W, int C, void* y, uint8_t* argmax, lec_stream_t stream);   /* fp32 x, y */
+int lec_maxpool3x3s2_bwd_f32(const void* dy, const uint8_t* argmax, int N, int H, int W, int C, void* dx, lec_stream_t stream);
 
 #ifdef __cplusplus
 }

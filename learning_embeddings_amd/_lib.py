@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblecone.so')
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 OK, E_ARG, E_HIP, E_EMPTY, E_STATE = 0, -1, -2, -3, -4
 ENERGY_HYP_CONE, ENERGY_ORDER, ENERGY_EUC_CONE = 0, 1, 2
@@ -87,9 +87,15 @@ def _load():
         'lec_conv3x3_c64_fwd': (i32, [p, p, i32, i32, i32, i32, p, p, i64, p, p]),
         'lec_conv3x3_c128_fwd': (i32, [p, p, i32, i32, i32, p, p, i64, p, p]),
         'lec_bn_fwd_prestat': (i32, [p, p, i64, i32, p, p, f32, f32, p, p, i32, p, p, p, i32, p, p, i64, p]),
+        'lec_conv_f32_fwd': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p, i64, p, p]),
+        'lec_conv_f32_dgrad': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p]),
+        'lec_conv_f32_wgrad': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p]),
         'lec_maxpool3x3s2_fwd': (i32, [p, i32, i32, i32, i32, p, p, p]),
         'lec_maxpool3x3s2_bwd': (i32, [p, p, i32, i32, i32, i32, p, p]),
     }
+    for base in ('lec_bn_fwd', 'lec_bn_bwd', 'lec_bn_bwd_pass1', 'lec_bn_bwd_apply', 'lec_bn_bwd_prereduced', 'lec_bn_fwd_prestat',
+                 'lec_maxpool3x3s2_fwd', 'lec_maxpool3x3s2_bwd'):
+        sig[base + '_f32'] = sig[base]            # fp32-activation twins: identical arguments
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)           # AttributeError here = header and library disagree: fail loudly
         fn.restype = res; fn.argtypes = args

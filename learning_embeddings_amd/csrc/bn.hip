@@ -25,20 +25,18 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef LEC_BN_NT
 #define LEC_BN_NT 1
 #endif
-__device__ __forceinline__ bf16x8 ld8(const bf16x8* p, int64_t i) {
+__device__ __forceinline__ u32x4 ld16(const void* p) {
 #if LEC_BN_NT
-  u32x4 r = __builtin_nontemporal_load((const u32x4*)(p + i));
-  bf16x8 o; __builtin_memcpy(&o, &r, 16); return o;
+  return __builtin_nontemporal_load((const u32x4*)p);
 #else
-  return p[i];
+  return *(const u32x4*)p;
 #endif
 }
-__device__ __forceinline__ void st8(bf16x8* p, int64_t i, const bf16x8& v) {
+__device__ __forceinline__ void st16(void* p, u32x4 r) {
 #if LEC_BN_NT
-  u32x4 r; __builtin_memcpy(&r, &v, 16);
-  __builtin_nontemporal_store(r, (u32x4*)(p + i));
+  __builtin_nontemporal_store(r, (u32x4*)p);
 #else
-  p[i] = v;
+  *(u32x4*)p = r;
 #endif
 }
 
@@ -47,6 +45,41 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
   __hip_bfloat16 h = __float2bfloat16(f);                 // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
   return *reinterpret_cast<unsigned short*>(&h);
 }
+
+// Element types of the activations.  A "vector" is 8 consecutive channels of one row: 16 bytes of bf16 (the MI355X-native
+// storage) or 32 bytes of fp32 (the reference's precision, oe_h.py:281-328: no AMP anywhere).  Kernels hold a vector as
+// float[8]; `rnd` is the storage rounding (bf16: round-to-nearest-even and back; fp32: identity), applied wherever the
+// bf16 kernels reuse a value they have just stored so that both passes of a layer see the same numbers.
+struct EBf16 {
+  static constexpr int kBytes = 2;
+  static __device__ __forceinline__ void ld(const void* p, int64_t i, float (&f)[8]) {
+    u32x4 r = ld16((const char*)p + i * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { f[2 * q] = __uint_as_float(r[q] << 16); f[2 * q + 1] = __uint_as_float(r[q] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void st(void* p, int64_t i, const float (&f)[8]) {
+    u32x4 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = (unsigned int)f2bf(f[2 * q]) | ((unsigned int)f2bf(f[2 * q + 1]) << 16);
+    st16((char*)p + i * 16, r);
+  }
+  static __device__ __forceinline__ float rnd(float v) { return bf2f(f2bf(v)); }
+};
+struct EF32 {
+  static constexpr int kBytes = 4;
+  static __device__ __forceinline__ void ld(const void* p, int64_t i, float (&f)[8]) {
+    u32x4 a = ld16((const char*)p + i * 32), b = ld16((const char*)p + i * 32 + 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { f[q] = __uint_as_float(a[q]); f[4 + q] = __uint_as_float(b[q]); }
+  }
+  static __device__ __forceinline__ void st(void* p, int64_t i, const float (&f)[8]) {
+    u32x4 a, b;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { a[q] = __float_as_uint(f[q]); b[q] = __float_as_uint(f[4 + q]); }
+    st16((char*)p + i * 32, a); st16((char*)p + i * 32 + 16, b);
+  }
+  static __device__ __forceinline__ float rnd(float v) { return v; }
+};
 
 constexpr int kBnThreads = 256;
 constexpr int kBnMaxBlocks = 512;
@@ -90,7 +123,8 @@ __device__ __forceinline__ void block_reduce_rows(float (&acc)[NV][8], int CV, i
 
 // ---------------------------------------------------------------------------------------------------------------
 // forward, pass 1: per-block partial sum / sum of squares per channel -> part[rb][2][C]
-__global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const bf16x8* __restrict__ x, int64_t M, int C, int CV, int CVB,
+template <typename E>
+__global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const void* __restrict__ x, int64_t M, int C, int CV, int CVB,
                                                               int RPIB, float* __restrict__ part) {
   __shared__ float smem[kBnThreads * 8];
   const int tid = threadIdx.x;
@@ -101,22 +135,24 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const bf16x8* __re
 #pragma unroll
   for (int j = 0; j < 8; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; }
   const int64_t stride = (int64_t)gridDim.x * RPIB;
+  constexpr int U = E::kBytes == 2 ? 8 : 4;                                  // 8 independent 16-byte loads in flight either way
   if (live) {
     int64_t r = (int64_t)blockIdx.x * RPIB + rg;
-    for (; r + 7 * stride < M; r += 8 * stride) {                            // 8 independent 16-byte loads in flight
-      bf16x8 v[8];
+    for (; r + (U - 1) * stride < M; r += U * stride) {
+      float v[U][8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = ld8(x, (r + u * stride) * CV + cv);
+      for (int u = 0; u < U; ++u) E::ld(x, (r + u * stride) * CV + cv, v[u]);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < U; ++u) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { float f = bf2f(v[u].v[j]); acc[0][j] += f; acc[1][j] += f * f; }
+        for (int j = 0; j < 8; ++j) { float f = v[u][j]; acc[0][j] += f; acc[1][j] += f * f; }
       }
     }
     for (; r < M; r += stride) {
-      bf16x8 a = ld8(x, r * CV + cv);
+      float a[8];
+      E::ld(x, r * CV + cv, a);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { float fa = bf2f(a.v[j]); acc[0][j] += fa; acc[1][j] += fa * fa; }
+      for (int j = 0; j < 8; ++j) { acc[0][j] += a[j]; acc[1][j] += a[j] * a[j]; }
     }
   }
   block_reduce_rows<2>(acc, CVB, RPIB, smem);
@@ -197,10 +233,10 @@ __global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, con
 
 // forward, pass 2: y = [relu]( x * scale + shift [+ residual] )
 // `mask` (optional, RELU only): one byte per thread-vector, bit j = [y_j > 0] -- backward reads it instead of y (1/16 the bytes)
-template <bool RES, bool RELU>
-__global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const bf16x8* __restrict__ x, const bf16x8* __restrict__ res,
+template <typename E, bool RES, bool RELU>
+__global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const void* __restrict__ x, const void* __restrict__ res,
                                                               int64_t M, int CV, int RPI, const float* __restrict__ scale,
-                                                              const float* __restrict__ shift, bf16x8* __restrict__ y,
+                                                              const float* __restrict__ shift, void* __restrict__ y,
                                                               unsigned char* __restrict__ mask) {
   const int tid = threadIdx.x;
   const int cv = tid % CV, rg = tid / CV;
@@ -209,49 +245,54 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const bf16x8* __re
 #pragma unroll
   for (int j = 0; j < 8; ++j) { sc[j] = scale[cv * 8 + j]; sh[j] = shift[cv * 8 + j]; }
   const int64_t stride = (int64_t)gridDim.x * RPI;
-  auto one = [&](bf16x8 a, bf16x8 r, int64_t idx) {
-    bf16x8 o;
+  auto one = [&](float (&a)[8], const float (&r)[8], int64_t idx) {
     unsigned int bits = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float v = bf2f(a.v[j]) * sc[j] + sh[j];
-      if (RES) v += bf2f(r.v[j]);
+      float v = a[j] * sc[j] + sh[j];
+      if (RES) v += r[j];
       if (RELU) v = v > 0.0f ? v : 0.0f;
-      o.v[j] = f2bf(v);
-      if (RELU) bits |= (bf2f(o.v[j]) > 0.0f ? 1u : 0u) << j;       // decided on the ROUNDED output, like a y-based mask
+      a[j] = v;
+      if (RELU) bits |= (E::rnd(v) > 0.0f ? 1u : 0u) << j;           // decided on the ROUNDED output, like a y-based mask
     }
     if (RELU && mask) mask[idx] = (unsigned char)bits;
-    return o;
+    E::st(y, idx, a);
   };
+  constexpr int U = E::kBytes == 2 ? 4 : 2;
   int64_t r = (int64_t)blockIdx.x * RPI + rg;
-  for (; r + 3 * stride < M; r += 4 * stride) {
-    const int64_t i0 = r * CV + cv, i1 = (r + stride) * CV + cv, i2 = (r + 2 * stride) * CV + cv, i3 = (r + 3 * stride) * CV + cv;
-    bf16x8 a = ld8(x, i0), b = ld8(x, i1), c = ld8(x, i2), d = ld8(x, i3);
-    bf16x8 ra = a, rb = a, rc = a, rd = a;
-    if (RES) { ra = ld8(res, i0); rb = ld8(res, i1); rc = ld8(res, i2); rd = ld8(res, i3); }
-    st8(y, i0, one(a, ra, i0)); st8(y, i1, one(b, rb, i1)); st8(y, i2, one(c, rc, i2)); st8(y, i3, one(d, rd, i3));
+  for (; r + (U - 1) * stride < M; r += U * stride) {
+    float a[U][8], rr[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) E::ld(x, (r + u * stride) * CV + cv, a[u]);
+    if (RES) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) E::ld(res, (r + u * stride) * CV + cv, rr[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) one(a[u], rr[u], (r + u * stride) * CV + cv);
   }
   for (; r < M; r += stride) {
     const int64_t i0 = r * CV + cv;
-    bf16x8 a = ld8(x, i0), ra = a;
-    if (RES) ra = ld8(res, i0);
-    st8(y, i0, one(a, ra, i0));
+    float a[8], rr[8];
+    E::ld(x, i0, a);
+    if (RES) E::ld(res, i0, rr);
+    one(a, rr, i0);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // backward, pass 1: per-block partials of  dbeta = sum g,  dgamma = sum g * xhat,   g = dy * [y > 0]
 // RELU: 0 none, 1 mask from the saved output y, 2 mask from the saved bitmask (y is then a byte array [M, C/8])
-// gout (layers with a residual branch): the pass also WRITES g (bf16) -- it is the gradient of the identity branch, and
+// gout (layers with a residual branch): the pass also WRITES g -- it is the gradient of the identity branch, and
 // pass 2 then reads this one tensor instead of dy, dy2 and the mask again (8.1 -> 7.1 bytes-units per element on the
 // forked block outputs).  The sums are taken over the rounded g so that both passes see the same values.
-template <int RELU>
-__global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const bf16x8* __restrict__ dy, const bf16x8* __restrict__ dy2,
-                                                                   const bf16x8* __restrict__ y,
-                                                                   const bf16x8* __restrict__ x, int64_t M, int C, int CV,
+template <typename E, int RELU>
+__global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const void* __restrict__ dy, const void* __restrict__ dy2,
+                                                                   const void* __restrict__ y,
+                                                                   const void* __restrict__ x, int64_t M, int C, int CV,
                                                                    int CVB, int RPI, const float* __restrict__ mean,
                                                                    const float* __restrict__ invstd, float* __restrict__ part,
-                                                                   bf16x8* __restrict__ gout) {
+                                                                   void* __restrict__ gout) {
   __shared__ float smem[kBnThreads * 8];
   const int tid = threadIdx.x;
   const int cvl = tid % CVB, rg = tid / CVB;
@@ -261,46 +302,47 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const bf16x8*
 #pragma unroll
   for (int j = 0; j < 8; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; mu[j] = mean[cv * 8 + j]; is[j] = invstd[cv * 8 + j]; }
   const int64_t stride = (int64_t)gridDim.x * RPI;
+  auto one = [&](float (&g)[8], const float (&h)[8], const float (&yv)[8], unsigned int m, const float (&xv)[8], int64_t i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a = g[j];
+      if (dy2) a += h[j];
+      if (RELU == 1) a = yv[j] > 0.0f ? a : 0.0f;
+      if (RELU == 2) a = (m >> j) & 1u ? a : 0.0f;
+      if (gout) a = E::rnd(a);
+      g[j] = a;
+      acc[0][j] += a;
+      acc[1][j] += a * ((xv[j] - mu[j]) * is[j]);
+    }
+    if (gout) E::st(gout, i, g);
+  };
   if (live) {
     int64_t r = (int64_t)blockIdx.x * RPI + rg;
-    for (; r + stride < M; r += 2 * stride) {
-      const int64_t i0 = r * CV + cv, i1 = (r + stride) * CV + cv;
-      bf16x8 g0 = ld8(dy, i0), g1 = ld8(dy, i1), x0 = ld8(x, i0), x1 = ld8(x, i1);
-      bf16x8 h0 = g0, h1 = g1;
-      if (dy2) { h0 = ld8(dy2, i0); h1 = ld8(dy2, i1); }                      // second gradient stream of a forked activation
-      bf16x8 y0 = g0, y1 = g1;
-      unsigned int m0 = 0xff, m1 = 0xff;
-      if (RELU == 1) { y0 = ld8(y, i0); y1 = ld8(y, i1); }
-      if (RELU == 2) { m0 = ((const unsigned char*)y)[i0]; m1 = ((const unsigned char*)y)[i1]; }
+    constexpr int U = E::kBytes == 2 ? 2 : 1;
+    for (; r + (U - 1) * stride < M; r += U * stride) {
+      float g[U][8], xv[U][8], h[U][8], yv[U][8];
+      unsigned int m[U];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float a = bf2f(g0.v[j]), b = bf2f(g1.v[j]);
-        if (dy2) { a += bf2f(h0.v[j]); b += bf2f(h1.v[j]); }
-        if (RELU == 1) { a = bf2f(y0.v[j]) > 0.0f ? a : 0.0f; b = bf2f(y1.v[j]) > 0.0f ? b : 0.0f; }
-        if (RELU == 2) { a = (m0 >> j) & 1u ? a : 0.0f; b = (m1 >> j) & 1u ? b : 0.0f; }
-        if (gout) { g0.v[j] = f2bf(a); g1.v[j] = f2bf(b); a = bf2f(g0.v[j]); b = bf2f(g1.v[j]); }
-        acc[0][j] += a + b;
-        acc[1][j] += a * ((bf2f(x0.v[j]) - mu[j]) * is[j]) + b * ((bf2f(x1.v[j]) - mu[j]) * is[j]);
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = (r + u * stride) * CV + cv;
+        E::ld(dy, i, g[u]); E::ld(x, i, xv[u]);
+        if (dy2) E::ld(dy2, i, h[u]);                                        // second gradient stream of a forked activation
+        m[u] = 0xff;
+        if (RELU == 1) E::ld(y, i, yv[u]);
+        if (RELU == 2) m[u] = ((const unsigned char*)y)[i];
       }
-      if (gout) { st8(gout, i0, g0); st8(gout, i1, g1); }
+#pragma unroll
+      for (int u = 0; u < U; ++u) one(g[u], h[u], yv[u], m[u], xv[u], (r + u * stride) * CV + cv);
     }
     for (; r < M; r += stride) {
-      const int64_t i0 = r * CV + cv;
-      bf16x8 g0 = ld8(dy, i0), x0 = ld8(x, i0), y0 = g0, h0 = g0;
-      if (dy2) h0 = ld8(dy2, i0);
-      unsigned int m0 = 0xff;
-      if (RELU == 1) y0 = ld8(y, i0);
-      if (RELU == 2) m0 = ((const unsigned char*)y)[i0];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float a = bf2f(g0.v[j]);
-        if (dy2) a += bf2f(h0.v[j]);
-        if (RELU == 1) a = bf2f(y0.v[j]) > 0.0f ? a : 0.0f;
-        if (RELU == 2) a = (m0 >> j) & 1u ? a : 0.0f;
-        if (gout) { g0.v[j] = f2bf(a); a = bf2f(g0.v[j]); }
-        acc[0][j] += a; acc[1][j] += a * ((bf2f(x0.v[j]) - mu[j]) * is[j]);
-      }
-      if (gout) st8(gout, i0, g0);
+      const int64_t i = r * CV + cv;
+      float g[8], xv[8], h[8], yv[8];
+      unsigned int m = 0xff;
+      E::ld(dy, i, g); E::ld(x, i, xv);
+      if (dy2) E::ld(dy2, i, h);
+      if (RELU == 1) E::ld(y, i, yv);
+      if (RELU == 2) m = ((const unsigned char*)y)[i];
+      one(g, h, yv, m, xv, i);
     }
   }
   block_reduce_rows<2>(acc, CVB, RPI, smem);
@@ -323,14 +365,14 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk,
 }
 
 // backward, pass 2: dx = gamma*invstd * (g - mean(g) - xhat * mean(g*xhat));  d residual = g
-template <bool RES, int RELU>
-__global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(const bf16x8* __restrict__ dy, const bf16x8* __restrict__ dy2,
-                                                                  const bf16x8* __restrict__ y,
-                                                                  const bf16x8* __restrict__ x, int64_t M, int CV, int RPI,
+template <typename E, bool RES, int RELU>
+__global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(const void* __restrict__ dy, const void* __restrict__ dy2,
+                                                                  const void* __restrict__ y,
+                                                                  const void* __restrict__ x, int64_t M, int CV, int RPI,
                                                                   const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                   const float* __restrict__ invstd, const float* __restrict__ c1,
-                                                                  const float* __restrict__ c2, bf16x8* __restrict__ dx,
-                                                                  bf16x8* __restrict__ dres) {
+                                                                  const float* __restrict__ c2, void* __restrict__ dx,
+                                                                  void* __restrict__ dres) {
   const int tid = threadIdx.x;
   const int cv = tid % CV, rg = tid / CV;
   if (rg >= RPI) return;
@@ -342,23 +384,24 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(const bf16x8* 
   }
   const int64_t stride = (int64_t)gridDim.x * RPI;
   auto one = [&](int64_t i) {
-    bf16x8 g0 = ld8(dy, i), x0 = ld8(x, i), y0 = g0, h0 = g0, o, gr;
-    if (dy2) h0 = ld8(dy2, i);
+    float g[8], xv[8], h[8], yv[8], o[8];
+    E::ld(dy, i, g); E::ld(x, i, xv);
+    if (dy2) E::ld(dy2, i, h);
     unsigned int m0 = 0xff;
-    if (RELU == 1) y0 = ld8(y, i);
+    if (RELU == 1) E::ld(y, i, yv);
     if (RELU == 2) m0 = ((const unsigned char*)y)[i];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float a = bf2f(g0.v[j]);
-      if (dy2) a += bf2f(h0.v[j]);
-      if (RELU == 1) a = bf2f(y0.v[j]) > 0.0f ? a : 0.0f;
+      float a = g[j];
+      if (dy2) a += h[j];
+      if (RELU == 1) a = yv[j] > 0.0f ? a : 0.0f;
       if (RELU == 2) a = (m0 >> j) & 1u ? a : 0.0f;
-      const float xh = (bf2f(x0.v[j]) - mu[j]) * is[j];
-      o.v[j] = f2bf(gs[j] * (a - k1[j] - xh * k2[j]));
-      if (RES) gr.v[j] = f2bf(a);
+      const float xh = (xv[j] - mu[j]) * is[j];
+      o[j] = gs[j] * (a - k1[j] - xh * k2[j]);
+      g[j] = a;
     }
-    st8(dx, i, o);
-    if (RES) st8(dres, i, gr);
+    E::st(dx, i, o);
+    if (RES) E::st(dres, i, g);
   };
   int64_t r = (int64_t)blockIdx.x * RPI + rg;
   for (; r + stride < M; r += 2 * stride) { one(r * CV + cv); one((r + stride) * CV + cv); }
@@ -378,7 +421,7 @@ extern "C" int64_t lec_bn_workspace_bytes(int C) {
   return ((int64_t)lec::kBnMaxBlocks * 2 * C + 4 * (int64_t)C) * sizeof(float);
 }
 
-extern "C" int lec_bn_fwd(const void* x, const void* residual, int64_t M, int C, const float* gamma, const float* beta,
+template <typename E> static int bn_fwd_impl(const void* x, const void* residual, int64_t M, int C, const float* gamma, const float* beta,
                           float eps, float momentum, float* running_mean, float* running_var, int training,
                           float* save_mean, float* save_invstd, void* y, int relu, uint8_t* relu_mask,
                           void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
@@ -395,7 +438,7 @@ extern "C" int lec_bn_fwd(const void* x, const void* residual, int64_t M, int C,
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, training - 2, C, M, gamma, beta, eps,
                        momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
   } else if (training) {
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(g.nrb, g.NCH), dim3(kBnThreads), 0, st, (const bf16x8*)x, M, C, g.CV, g.CVB, g.RPIB, part);
+    hipLaunchKernelGGL((bn_stats_kernel<E>), dim3(g.nrb, g.NCH), dim3(kBnThreads), 0, st, x, M, C, g.CV, g.CVB, g.RPIB, part);
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, g.nrb, C, M, gamma, beta, eps,
                        momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
   } else {
@@ -403,14 +446,14 @@ extern "C" int lec_bn_fwd(const void* x, const void* residual, int64_t M, int C,
   }
   int64_t nb = (M + g.RPI - 1) / g.RPI; nb = (nb + 3) / 4;
   const int nblk = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
-#define A(RES_, RELU_) hipLaunchKernelGGL((bn_apply_kernel<RES_, RELU_>), dim3(nblk), dim3(kBnThreads), 0, st, (const bf16x8*)x, (const bf16x8*)residual, M, g.CV, g.RPI, scale, shift, (bf16x8*)y, (unsigned char*)relu_mask)
+#define A(RES_, RELU_) hipLaunchKernelGGL((bn_apply_kernel<E, RES_, RELU_>), dim3(nblk), dim3(kBnThreads), 0, st, x, residual, M, g.CV, g.RPI, scale, shift, y, relu_mask)
   if (residual) { if (relu) A(true, true); else A(true, false); } else { if (relu) A(false, true); else A(false, false); }
 #undef A
   LEC_CHECK_LAUNCH("bn_fwd kernels");
   return LEC_OK;
 }
 
-extern "C" int lec_bn_bwd(const void* dy, const void* dy2, const void* y, const uint8_t* relu_mask, const void* x, int64_t M, int C,
+template <typename E> static int bn_bwd_impl(const void* dy, const void* dy2, const void* y, const uint8_t* relu_mask, const void* x, int64_t M, int C,
                           const float* gamma, const float* save_mean, const float* save_invstd, void* dx,
                           void* dresidual, float* dgamma, float* dbeta, int relu, void* workspace,
                           int64_t workspace_bytes, lec_stream_t stream) {
@@ -425,17 +468,17 @@ extern "C" int lec_bn_bwd(const void* dy, const void* dy2, const void* y, const 
   BnGeom g = bn_geom(M, C);
   float* part = (float*)workspace;
   float* c1 = part + (int64_t)kBnMaxBlocks * 2 * C; float* c2 = c1 + C;
-#define R(M_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<M_>), dim3(g.nrb, g.NCH), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)dy2, (const bf16x8*)ym, (const bf16x8*)x, M, C, g.CV, g.CVB, g.RPIB, save_mean, save_invstd, part, (bf16x8*)dresidual)
+#define R(M_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<E, M_>), dim3(g.nrb, g.NCH), dim3(kBnThreads), 0, st, dy, dy2, ym, x, M, C, g.CV, g.CVB, g.RPIB, save_mean, save_invstd, part, dresidual)
   if (rm == 0) R(0); else if (rm == 1) R(1); else R(2);
 #undef R
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, g.nrb, C, M, dgamma, dbeta, c1, c2);
   int64_t nb = (M + g.RPI - 1) / g.RPI; nb = (nb + 1) / 2;
   const int nblk = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
-#define A(RES_, RELU_) hipLaunchKernelGGL((bn_bwd_apply_kernel<RES_, RELU_>), dim3(nblk), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)dy2, (const bf16x8*)ym, (const bf16x8*)x, M, g.CV, g.RPI, gamma, save_mean, save_invstd, c1, c2, (bf16x8*)dx, (bf16x8*)dresidual)
+#define A(RES_, RELU_) hipLaunchKernelGGL((bn_bwd_apply_kernel<E, RES_, RELU_>), dim3(nblk), dim3(kBnThreads), 0, st, dy, dy2, ym, x, M, g.CV, g.RPI, gamma, save_mean, save_invstd, c1, c2, dx, dresidual)
   if (dresidual) {
     // pass 1 has written g = masked(dy [+ dy2]) into dresidual: pass 2 reads that one tensor, no mask, no second stream
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<false, 0>), dim3(nblk), dim3(kBnThreads), 0, st, (const bf16x8*)dresidual, (const bf16x8*)nullptr,
-                       (const bf16x8*)nullptr, (const bf16x8*)x, M, g.CV, g.RPI, gamma, save_mean, save_invstd, c1, c2, (bf16x8*)dx, (bf16x8*)nullptr);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<E, false, 0>), dim3(nblk), dim3(kBnThreads), 0, st, dresidual, nullptr,
+                       nullptr, x, M, g.CV, g.RPI, gamma, save_mean, save_invstd, c1, c2, dx, nullptr);
   } else { if (rm == 0) A(false, 0); else if (rm == 1) A(false, 1); else A(false, 2); }
 #undef A
   LEC_CHECK_LAUNCH("bn_bwd kernels");
@@ -465,7 +508,7 @@ extern "C" int lec_bn_fwd_finalize(int64_t M, int C, const float* gamma, const f
 
 // The backward split into its stages, for callers that run pass 2 somewhere else (lec_conv1x1_wgrad_bnapply): pass 1 + finalize,
 // finalize alone (partials left by a convolution epilogue), and pass 2 alone from the c1 / c2 the finalize left in the workspace.
-extern "C" int lec_bn_bwd_pass1(const void* dy, const void* dy2, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* save_mean,
+template <typename E> static int bn_bwd_pass1_impl(const void* dy, const void* dy2, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* save_mean,
                                 const float* save_invstd, void* g, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
                                 lec_stream_t stream) {
   using namespace lec;
@@ -476,7 +519,7 @@ extern "C" int lec_bn_bwd_pass1(const void* dy, const void* dy2, const uint8_t* 
   BnGeom geo = bn_geom(M, C);
   float* part = (float*)workspace;
   float* c1 = part + (int64_t)kBnMaxBlocks * 2 * C; float* c2 = c1 + C;
-#define R(M_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<M_>), dim3(geo.nrb, geo.NCH), dim3(kBnThreads), 0, st, (const bf16x8*)dy, (const bf16x8*)dy2, (const bf16x8*)relu_mask, (const bf16x8*)x, M, C, geo.CV, geo.CVB, geo.RPIB, save_mean, save_invstd, part, (bf16x8*)g)
+#define R(M_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<E, M_>), dim3(geo.nrb, geo.NCH), dim3(kBnThreads), 0, st, dy, dy2, relu_mask, x, M, C, geo.CV, geo.CVB, geo.RPIB, save_mean, save_invstd, part, g)
   if (relu_mask) R(2); else R(0);
 #undef R
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, geo.nrb, C, M, dgamma, dbeta, c1, c2);
@@ -499,7 +542,7 @@ extern "C" int lec_bn_bwd_finalize(int64_t M, int C, int n_partials, float* dgam
   return LEC_OK;
 }
 
-extern "C" int lec_bn_bwd_apply(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd,
+template <typename E> static int bn_bwd_apply_impl(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd,
                                 void* dx, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
   using namespace lec;
   if (int rc = bn_check("bn_bwd_apply", M, C)) return rc;
@@ -509,13 +552,13 @@ extern "C" int lec_bn_bwd_apply(const void* g, const void* x, int64_t M, int C, 
   float* c1 = (float*)workspace + (int64_t)kBnMaxBlocks * 2 * C; float* c2 = c1 + C;
   int64_t nb = (M + geo.RPI - 1) / geo.RPI; nb = (nb + 1) / 2;
   const int nblk = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<false, 0>), dim3(nblk), dim3(kBnThreads), 0, (hipStream_t)stream, (const bf16x8*)g, (const bf16x8*)nullptr,
-                     (const bf16x8*)nullptr, (const bf16x8*)x, M, geo.CV, geo.RPI, gamma, save_mean, save_invstd, c1, c2, (bf16x8*)dx, (bf16x8*)nullptr);
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<E, false, 0>), dim3(nblk), dim3(kBnThreads), 0, (hipStream_t)stream, g, nullptr,
+                     nullptr, x, M, geo.CV, geo.RPI, gamma, save_mean, save_invstd, c1, c2, dx, nullptr);
   LEC_CHECK_LAUNCH("bn_bwd_apply_kernel");
   return LEC_OK;
 }
 
-extern "C" int lec_bn_bwd_prereduced(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean,
+template <typename E> static int bn_bwd_prereduced_impl(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean,
                                      const float* save_invstd, int n_partials, void* dx, float* dgamma, float* dbeta, void* workspace,
                                      int64_t workspace_bytes, lec_stream_t stream) {
   using namespace lec;
@@ -530,17 +573,55 @@ extern "C" int lec_bn_bwd_prereduced(const void* g, const void* x, int64_t M, in
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, n_partials, C, M, dgamma, dbeta, c1, c2);
   int64_t nb = (M + geo.RPI - 1) / geo.RPI; nb = (nb + 1) / 2;
   const int nblk = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<false, 0>), dim3(nblk), dim3(kBnThreads), 0, st, (const bf16x8*)g, (const bf16x8*)nullptr,
-                     (const bf16x8*)nullptr, (const bf16x8*)x, M, geo.CV, geo.RPI, gamma, save_mean, save_invstd, c1, c2, (bf16x8*)dx, (bf16x8*)nullptr);
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<E, false, 0>), dim3(nblk), dim3(kBnThreads), 0, st, g, nullptr,
+                     nullptr, x, M, geo.CV, geo.RPI, gamma, save_mean, save_invstd, c1, c2, dx, nullptr);
   LEC_CHECK_LAUNCH("bn_bwd_prereduced kernels");
   return LEC_OK;
 }
 
-extern "C" int lec_bn_fwd_prestat(const void* x, const void* residual, int64_t M, int C, const float* gamma, const float* beta,
+template <typename E> static int bn_fwd_prestat_impl(const void* x, const void* residual, int64_t M, int C, const float* gamma, const float* beta,
                                   float eps, float momentum, float* running_mean, float* running_var, int n_partials,
                                   float* save_mean, float* save_invstd, void* y, int relu, uint8_t* relu_mask, void* workspace,
                                   int64_t workspace_bytes, lec_stream_t stream) {
   LEC_CHECK_ARG(n_partials >= 1 && n_partials <= lec::kBnMaxBlocks, "bn_fwd_prestat: n_partials=%d outside 1..%d", n_partials, lec::kBnMaxBlocks);
-  return lec_bn_fwd(x, residual, M, C, gamma, beta, eps, momentum, running_mean, running_var, 2 + n_partials, save_mean, save_invstd,
+  return bn_fwd_impl<E>(x, residual, M, C, gamma, beta, eps, momentum, running_mean, running_var, 2 + n_partials, save_mean, save_invstd,
                     y, relu, relu_mask, workspace, workspace_bytes, stream);
+}
+
+// ---- C entry points: bf16 (the MI355X-native storage) and fp32 (the reference's precision) instances of the same kernels
+extern "C" int lec_bn_fwd(const void* x, const void* residual, int64_t M, int C, const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var, int training, float* save_mean, float* save_invstd, void* y, int relu, uint8_t* relu_mask, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+  return bn_fwd_impl<lec::EBf16>(x, residual, M, C, gamma, beta, eps, momentum, running_mean, running_var, training, save_mean, save_invstd, y, relu, relu_mask, workspace, workspace_bytes, stream);
+}
+extern "C" int lec_bn_fwd_f32(const void* x, const void* residual, int64_t M, int C, const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var, int training, float* save_mean, float* save_invstd, void* y, int relu, uint8_t* relu_mask, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+  return bn_fwd_impl<lec::EF32>(x, residual, M, C, gamma, beta, eps, momentum, running_mean, running_var, training, save_mean, save_invstd, y, relu, relu_mask, workspace, workspace_bytes, stream);
+}
+extern "C" int lec_bn_bwd(const void* dy, const void* dy2, const void* y, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta, int relu, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+  return bn_bwd_impl<lec::EBf16>(dy, dy2, y, relu_mask, x, M, C, gamma, save_mean, save_invstd, dx, dresidual, dgamma, dbeta, relu, workspace, workspace_bytes, stream);
+}
+extern "C" int lec_bn_bwd_f32(const void* dy, const void* dy2, const void* y, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta, int relu, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+  return bn_bwd_impl<lec::EF32>(dy, dy2, y, relu_mask, x, M, C, gamma, save_mean, save_invstd, dx, dresidual, dgamma, dbeta, relu, workspace, workspace_bytes, stream);
+}
+extern "C" int lec_bn_bwd_pass1(const void* dy, const void* dy2, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* save_mean, const float* save_invstd, void* g, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+  return bn_bwd_pass1_impl<lec::EBf16>(dy, dy2, relu_mask, x, M, C, save_mean, save_invstd, g, dgamma, dbeta, workspace, workspace_bytes, stream);
+}
+extern "C" int lec_bn_bwd_pass1_f32(const void* dy, const void* dy2, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* save_mean, const float* save_invstd, void* g, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+  return bn_bwd_pass1_impl<lec::EF32>(dy, dy2, relu_mask, x, M, C, save_mean, save_invstd, g, dgamma, dbeta, workspace, workspace_bytes, stream);
+}
+extern "C" int lec_bn_bwd_apply(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd, void* dx, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+  return bn_bwd_apply_impl<lec::EBf16>(g, x, M, C, gamma, save_mean, save_invstd, dx, workspace, workspace_bytes, stream);
+}
+extern "C" int lec_bn_bwd_apply_f32(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd, void* dx, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+  return bn_bwd_apply_impl<lec::EF32>(g, x, M, C, gamma, save_mean, save_invstd, dx, workspace, workspace_bytes, stream);
+}
+extern "C" int lec_bn_bwd_prereduced(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd, int n_partials, void* dx, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+  return bn_bwd_prereduced_impl<lec::EBf16>(g, x, M, C, gamma, save_mean, save_invstd, n_partials, dx, dgamma, dbeta, workspace, workspace_bytes, stream);
+}
+extern "C" int lec_bn_bwd_prereduced_f32(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd, int n_partials, void* dx, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+  return bn_bwd_prereduced_impl<lec::EF32>(g, x, M, C, gamma, save_mean, save_invstd, n_partials, dx, dgamma, dbeta, workspace, workspace_bytes, stream);
+}
+extern "C" int lec_bn_fwd_prestat(const void* x, const void* residual, int64_t M, int C, const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var, int n_partials, float* save_mean, float* save_invstd, void* y, int relu, uint8_t* relu_mask, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+  return bn_fwd_prestat_impl<lec::EBf16>(x, residual, M, C, gamma, beta, eps, momentum, running_mean, running_var, n_partials, save_mean, save_invstd, y, relu, relu_mask, workspace, workspace_bytes, stream);
+}
+extern "C" int lec_bn_fwd_prestat_f32(const void* x, const void* residual, int64_t M, int C, const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var, int n_partials, float* save_mean, float* save_invstd, void* y, int relu, uint8_t* relu_mask, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+  return bn_fwd_prestat_impl<lec::EF32>(x, residual, M, C, gamma, beta, eps, momentum, running_mean, running_var, n_partials, save_mean, save_invstd, y, relu, relu_mask, workspace, workspace_bytes, stream);
 }

@@ -106,8 +106,10 @@ class StepEngine:
         # low-precision shadow weights (no per-layer cast kernels) + gradients written straight into the arena; the
         # weight-gradient kernels optionally run on a second stream (overlap_wgrad)
         self.overlap = None
-        if self.compute_dtype == torch.bfloat16:
-            self.arena.enable_lowp_shadow()
+        if self.compute_dtype in (torch.bfloat16, torch.float32):
+            if self.compute_dtype == torch.bfloat16:
+                self.arena.enable_lowp_shadow()
+            # fp32 (the reference's precision): the convolutions read the arena's master weights directly
             self.overlap = WgradOverlap.instance = WgradOverlap(self.reducer, self.arena, side_stream=overlap_wgrad)
         else:
             WgradOverlap.instance = None
@@ -131,7 +133,7 @@ class StepEngine:
         # static device inputs of the step (the captured graph reads these addresses)
         self.codes_dev = torch.zeros((self.B, 2 + 2 * K), dtype=torch.int32, device=self.device)
         self.idx_dev = torch.zeros(self.n_rows, dtype=torch.int64, device=self.device)
-        self.use_graph = bool(use_graph) and self.compute_dtype != torch.float32
+        self.use_graph = bool(use_graph)
         self.graph_after = graph_after
         self.hip_graph = None
         self.graph_out = None

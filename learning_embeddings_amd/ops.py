@@ -281,13 +281,18 @@ class MultiLevelCEFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------------ fused BN (+add) (+ReLU)
 def _nhwc_rows(t, name):
-    """[N, C, H, W] channels_last bf16 tensor -> (M, C); raises unless the memory really is [M, C] with C innermost."""
-    if t.dtype != torch.bfloat16:
-        raise TypeError('%s must be bf16' % name)
+    """[N, C, H, W] channels_last bf16 / fp32 tensor -> (M, C); raises unless the memory really is [M, C] with C innermost."""
+    if t.dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError('%s must be bf16 or fp32' % name)
     if t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
         raise ValueError('%s must be a 4-D channels_last tensor' % name)
     N, Cc, H, W = t.shape
     return N * H * W, Cc
+
+
+def _dt(name, dtype):
+    """The entry point of `name` for activations of `dtype`: bf16 (MI355X-native storage) or fp32 (the reference's precision)."""
+    return getattr(lib, name + '_f32') if dtype == torch.float32 else getattr(lib, name)
 
 
 BN_TIMER = None     # set to a list to record (start_event, end_event, algorithmic_bytes) per fused-BN launch group (bench.py)
@@ -309,8 +314,9 @@ class BNActFn(torch.autograd.Function):
         """fork=True returns (y, y_alias): two handles on the SAME memory for an activation that feeds two branches, so
         that backward receives the two branch gradients separately and the kernels add them on the fly."""
         M, Cc = _nhwc_rows(x, 'x')
-        if residual is not None and (_nhwc_rows(residual, 'residual') != (M, Cc)):
-            raise ValueError('residual shape mismatch')
+        if residual is not None and (_nhwc_rows(residual, 'residual') != (M, Cc) or residual.dtype != x.dtype):
+            raise ValueError('residual shape / dtype mismatch')
+        es = x.element_size()                         # 2 (bf16) or 4 (fp32) bytes per activation element
         y = torch.empty_like(x)                       # preserves channels_last
         save_mean = torch.empty(Cc, dtype=torch.float32, device=x.device); save_invstd = torch.empty_like(save_mean)
         ws = _bn_workspace(x.device)
@@ -337,16 +343,16 @@ class BNActFn(torch.autograd.Function):
             else:                                 # not the layer the deferral was meant for: materialise the product first
                 check(lib.lec_conv1x1_fwd(dptr(x_in), dptr(w2), 0, M, cin, Cc, dptr(x), None, 0, None, stream_ptr()))
                 dfr = None
-        nbytes = el * ((4 if (training and not prestat) else 2) + 2 + (2 if residual is not None else 0)) + (el // 8 if mask is not None else 0)
+        nbytes = el * es * ((2 if (training and not prestat) else 1) + 1 + (1 if residual is not None else 0)) + (el // 8 if mask is not None else 0)
         if dfr is not None:
             pass                                  # done above, inside the convolution
         elif prestat:
-            _bn_timed(lambda: check(lib.lec_bn_fwd_prestat(dptr(x), dptr(residual), M, Cc, dptr(weight), dptr(bias), float(eps), float(momentum),
+            _bn_timed(lambda: check(_dt('lec_bn_fwd_prestat', x.dtype)(dptr(x), dptr(residual), M, Cc, dptr(weight), dptr(bias), float(eps), float(momentum),
                                                            dptr(running_mean), dptr(running_var), prestat, dptr(save_mean),
                                                            dptr(save_invstd), dptr(y), int(bool(relu)), dptr(mask), dptr(ws), ws.numel(),
                                                            stream_ptr())), nbytes)
         else:
-            _bn_timed(lambda: check(lib.lec_bn_fwd(dptr(x), dptr(residual), M, Cc, dptr(weight), dptr(bias), float(eps), float(momentum),
+            _bn_timed(lambda: check(_dt('lec_bn_fwd', x.dtype)(dptr(x), dptr(residual), M, Cc, dptr(weight), dptr(bias), float(eps), float(momentum),
                                                    dptr(running_mean), dptr(running_var), int(bool(training)), dptr(save_mean),
                                                    dptr(save_invstd), dptr(y), int(bool(relu)), dptr(mask), dptr(ws), ws.numel(),
                                                    stream_ptr())), nbytes)
@@ -396,10 +402,15 @@ class BNActFn(torch.autograd.Function):
         ws = _bn_workspace(x.device)
         _BN_WS_OWNER[0] = 0
         el = M * Cc                                   # 2 x (dy [+ dy2] + x [+ mask]) + dx [+ d residual]
+        es = x.element_size()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        if dy2 is not None and dy2.dtype != x.dtype:
+            dy2 = dy2.to(x.dtype)
         if has_res:      # pass 1 reads dy [+ dy2], x, mask and writes g (= d residual); pass 2 reads g, x and writes dx
-            nbytes = el * ((4 + (2 if dy2 is not None else 0) + 2) + (4 + 2)) + (el // 8 if relu else 0)
+            nbytes = el * es * ((2 + (1 if dy2 is not None else 0) + 1) + (2 + 1)) + (el // 8 if relu else 0)
         else:            # both passes read dy [+ dy2], x, mask; pass 2 writes dx
-            nbytes = el * (2 * (4 + (2 if dy2 is not None else 0)) + 2) + (2 * (el // 8) if relu else 0)
+            nbytes = el * es * (2 * (2 + (1 if dy2 is not None else 0)) + 1) + (2 * (el // 8) if relu else 0)
         lazy = (LAZY_BN_PASS2 and has_res and x.data_ptr() in _LAZY_OK and x.dtype == torch.bfloat16
                 and lib.lec_conv1x1_wgrad_bnapply_supported(_LAZY_OK[x.data_ptr()], Cc, M))
         _LAZY_OK.pop(x.data_ptr(), None)
@@ -409,18 +420,18 @@ class BNActFn(torch.autograd.Function):
             if pre:
                 _bn_timed(lambda: check(lib.lec_bn_bwd_finalize(M, Cc, pre, dptr(dgamma), dptr(dbeta), dptr(ws), ws.numel(), stream_ptr())), 0)
             else:
-                nb1 = el * (4 + (2 if dy2 is not None else 0) + 2) + (el // 8 if relu else 0)
-                _bn_timed(lambda: check(lib.lec_bn_bwd_pass1(dptr(dy), dptr(dy2), dptr(mask) if relu else None, dptr(x), M, Cc, dptr(save_mean),
+                nb1 = el * es * (2 + (1 if dy2 is not None else 0) + 1) + (el // 8 if relu else 0)
+                _bn_timed(lambda: check(_dt('lec_bn_bwd_pass1', x.dtype)(dptr(dy), dptr(dy2), dptr(mask) if relu else None, dptr(x), M, Cc, dptr(save_mean),
                                                              dptr(save_invstd), dptr(dres), dptr(dgamma), dptr(dbeta), dptr(ws), ws.numel(),
                                                              stream_ptr())), nb1)
             _LAZY_DX.clear()
             _LAZY_DX[dx.data_ptr()] = {'g': dres, 'x': x, 'gamma': weight, 'mean': save_mean, 'invstd': save_invstd, 'M': M, 'C': Cc}
         elif pre:
-            nbytes = el * 6                       # pass 2 only: read g, x; write dx (pass 1 ran in the convolution's epilogue)
-            _bn_timed(lambda: check(lib.lec_bn_bwd_prereduced(dptr(dy), dptr(x), M, Cc, dptr(weight), dptr(save_mean), dptr(save_invstd), pre,
+            nbytes = el * es * 3                  # pass 2 only: read g, x; write dx (pass 1 ran in the convolution's epilogue)
+            _bn_timed(lambda: check(_dt('lec_bn_bwd_prereduced', x.dtype)(dptr(dy), dptr(x), M, Cc, dptr(weight), dptr(save_mean), dptr(save_invstd), pre,
                                                               dptr(dx), dptr(dgamma), dptr(dbeta), dptr(ws), ws.numel(), stream_ptr())), nbytes)
         else:
-            _bn_timed(lambda: check(lib.lec_bn_bwd(dptr(dy), dptr(dy2), None, dptr(mask), dptr(x), M, Cc, dptr(weight), dptr(save_mean),
+            _bn_timed(lambda: check(_dt('lec_bn_bwd', x.dtype)(dptr(dy), dptr(dy2), None, dptr(mask), dptr(x), M, Cc, dptr(weight), dptr(save_mean),
                                                    dptr(save_invstd), dptr(dx), dptr(dres), dptr(dgamma), dptr(dbeta), int(relu),
                                                    dptr(ws), ws.numel(), stream_ptr())), nbytes)
         if has_res and ctx.res_ptr in _FORKS:     # this layer's residual is a forked block output: its consumer convolution's data
@@ -509,7 +520,7 @@ def conv1x1_wgrad_rows(dy_rows, x_rows, dw):
 def bn_bwd_apply_lazy(rec, dx):
     """Pass 2 of a BatchNorm backward whose dx was handed on unwritten (_LAZY_DX) and whose consumer cannot run it itself."""
     ws = _bn_workspace(dx.device)
-    check(lib.lec_bn_bwd_apply(dptr(rec['g']), dptr(rec['x']), rec['M'], rec['C'], dptr(rec['gamma']), dptr(rec['mean']), dptr(rec['invstd']),
+    check(_dt('lec_bn_bwd_apply', rec['x'].dtype)(dptr(rec['g']), dptr(rec['x']), rec['M'], rec['C'], dptr(rec['gamma']), dptr(rec['mean']), dptr(rec['invstd']),
                                dptr(dx), dptr(ws), ws.numel(), stream_ptr()))
 
 
@@ -597,6 +608,57 @@ def conv1x1_rows(x_rows, w2, want_stats=False, w_transposed=False):
     return y
 
 
+# ------------------------------------------------------------------------------------------------ fp32 convolutions
+def _nhwc_f32(t, name):
+    if t.dtype != torch.float32 or t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError('%s must be a 4-D channels_last float32 tensor' % name)
+    return t
+
+
+def conv_f32_supported(conv_or_cin, cout=None):
+    """Shapes lec_conv_f32_* serve: channel counts that are powers of two >= 4, stride 1 or 2, square dilation-1 group-1 filters."""
+    if cout is None:
+        c = conv_or_cin
+        return (c.groups == 1 and c.dilation == (1, 1) and c.stride[0] == c.stride[1] and c.stride[0] in (1, 2) and c.bias is None
+                and c.padding[0] == c.padding[1] and c.padding[0] < c.kernel_size[0] and c.kernel_size[0] == c.kernel_size[1]
+                and conv_f32_supported(c.in_channels, c.out_channels))
+    pw2 = lambda v: v >= 4 and (v & (v - 1)) == 0
+    return pw2(conv_or_cin) and pw2(cout)
+
+
+def conv_f32_fwd(x, w, stride, pad, want_stats=False):
+    """y = conv2d(x, w) in exact fp32 on the f32 MFMA (lec_conv_f32_fwd).  x [N, Cin, H, W], w [Cout, Cin, R, S], both
+    channels_last fp32.  want_stats: the BatchNorm statistics partials of y are left in the BatchNorm workspace."""
+    _nhwc_f32(x, 'x'); _nhwc_f32(w, 'w')
+    n, cin, h, wd = x.shape; cout, _, r, s_ = w.shape
+    ho, wo = (h + 2 * pad - r) // stride + 1, (wd + 2 * pad - s_) // stride + 1
+    y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if want_stats:
+        ws = _bn_workspace(x.device); k = C.c_int(0)
+        check(lib.lec_conv_f32_fwd(dptr(x), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), dptr(ws), ws.numel(), C.byref(k), stream_ptr()))
+        _BN_WS_OWNER[0], _BN_WS_OWNER[1] = y.data_ptr(), k.value
+    else:
+        check(lib.lec_conv_f32_fwd(dptr(x), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), None, 0, None, stream_ptr()))
+    return y
+
+
+def conv_f32_dgrad(dy, w, x_shape, stride, pad):
+    """dx of the same convolution (lec_conv_f32_dgrad): dy [N, Cout, Ho, Wo], w the FORWARD weight, x_shape = (N, Cin, H, W)."""
+    _nhwc_f32(dy, 'dy'); _nhwc_f32(w, 'w')
+    n, cin, h, wd = x_shape; cout, _, r, s_ = w.shape
+    dx = torch.empty((n, cin, h, wd), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last)
+    check(lib.lec_conv_f32_dgrad(dptr(dy), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(dx), stream_ptr()))
+    return dx
+
+
+def conv_f32_wgrad(dy, x, dw, stride, pad):
+    """dw += weight gradient (lec_conv_f32_wgrad, float atomics).  dw [Cout, Cin, R, S] channels_last fp32."""
+    _nhwc_f32(dy, 'dy'); _nhwc_f32(x, 'x'); _nhwc_f32(dw, 'dw')
+    n, cin, h, wd = x.shape; cout, _, r, s_ = dw.shape
+    check(lib.lec_conv_f32_wgrad(dptr(dy), dptr(x), n, h, wd, cin, cout, r, s_, stride, pad, dptr(dw), stream_ptr()))
+    return dw
+
+
 def _bn_workspace(device):
     key = (device.type, device.index)
     ws = _bn_ws.get(key)
@@ -615,7 +677,7 @@ class MaxPool3x3s2Fn(torch.autograd.Function):
         N, Cc, H, W = x.shape
         y = torch.empty((N, Cc, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         arg = torch.empty(N * (H // 2) * (W // 2) * Cc, dtype=torch.uint8, device=x.device)
-        check(lib.lec_maxpool3x3s2_fwd(dptr(x), N, H, W, Cc, dptr(y), dptr(arg), stream_ptr()))
+        check(_dt('lec_maxpool3x3s2_fwd', x.dtype)(dptr(x), N, H, W, Cc, dptr(y), dptr(arg), stream_ptr()))
         ctx.save_for_backward(arg); ctx.shape = (N, Cc, H, W)
         return y
 
@@ -626,5 +688,5 @@ class MaxPool3x3s2Fn(torch.autograd.Function):
         if not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.contiguous(memory_format=torch.channels_last)
         dx = torch.empty((N, Cc, H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
-        check(lib.lec_maxpool3x3s2_bwd(dptr(dy), dptr(arg), N, H, W, Cc, dptr(dx), stream_ptr()))
+        check(_dt('lec_maxpool3x3s2_bwd', dy.dtype)(dptr(dy), dptr(arg), N, H, W, Cc, dptr(dx), stream_ptr()))
         return dx

@@ -28,9 +28,9 @@ class BatchNormAct2d(nn.BatchNorm2d):
     def forward(self, x, residual=None, fork=False):
         """fork=True: return TWO handles (y, y_alias) on the output, one per consuming branch of the next block (its conv
         path and its identity / downsample path): the fused backward then adds the two branch gradients on the fly."""
-        if (BatchNormAct2d.fused_enabled and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and self.num_features % 8 == 0
+        if (BatchNormAct2d.fused_enabled and x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and x.dim() == 4 and self.num_features % 8 == 0
                 and self.num_features <= 2048 and x.is_contiguous(memory_format=torch.channels_last)
-                and (residual is None or (residual.dtype == torch.bfloat16 and residual.shape == x.shape
+                and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape
                                           and residual.is_contiguous(memory_format=torch.channels_last)))):
             from . import ops
             ov = WgradOverlap.instance
@@ -283,7 +283,7 @@ class Conv2d(nn.Conv2d):
     def forward(self, x):
         ov = WgradOverlap.instance
         if (ov is not None and ov.enabled and x.is_cuda and self.training and torch.is_grad_enabled() and self.bias is None
-                and x.dtype in (torch.bfloat16, torch.float16) and self.weight.requires_grad):
+                and x.dtype in (torch.bfloat16, torch.float16, torch.float32) and self.weight.requires_grad):
             return _OverlapConvFn.apply(x, self.weight, self)
         return super().forward(x)
 
@@ -296,7 +296,7 @@ class MaxPool3x3s2(nn.MaxPool2d):
         super().__init__(kernel_size=3, stride=2, padding=1)
 
     def forward(self, x):
-        if (BatchNormAct2d.fused_enabled and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0
+        if (BatchNormAct2d.fused_enabled and x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and x.dim() == 4 and x.shape[1] % 8 == 0
                 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.is_contiguous(memory_format=torch.channels_last)):
             from . import ops
             return ops.MaxPool3x3s2Fn.apply(x)

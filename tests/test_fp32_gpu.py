@@ -1,0 +1,198 @@
+"""The backbone's kernels at the REFERENCE's precision (fp32 activations: oe_h.py:281-328 runs torchvision's ResNet in fp32,
+no AMP): fused BatchNorm(+add)(+ReLU), max pooling and the whole ResNet through them, against plain PyTorch fp32 ops."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from learning_embeddings_amd import ops  # noqa: E402
+from learning_embeddings_amd.resnet import resnet18, resnet50, BatchNormAct2d, WgradOverlap  # noqa: E402
+
+DEV = 'cuda'
+
+
+def _cl(t):
+    return t.to(DEV).contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize('N,C,H,W', [(4, 64, 14, 14), (2, 2048, 7, 7), (8, 256, 9, 5), (3, 24, 5, 5), (16, 64, 56, 56), (5, 1024, 3, 3)])
+@pytest.mark.parametrize('res,relu', [(False, True), (True, True), (False, False), (True, False)])
+def test_bn_f32_fwd_bwd_vs_torch(N, C, H, W, res, relu):
+    g = torch.Generator(device='cpu').manual_seed(N * 1000 + C)
+    x = _cl(torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3)
+    r = _cl(torch.randn(N, C, H, W, generator=g)) if res else None
+    w = (torch.rand(C, generator=g) + 0.5).to(DEV); b = (torch.randn(C, generator=g) * 0.2).to(DEV)
+    dy = _cl(torch.randn(N, C, H, W, generator=g))
+    rm = torch.zeros(C, device=DEV); rv = torch.ones(C, device=DEV); rm2 = rm.clone(); rv2 = rv.clone()
+    xa = x.clone().requires_grad_(True); ra = r.clone().requires_grad_(True) if res else None
+    wa = w.clone().requires_grad_(True); ba = b.clone().requires_grad_(True)
+    y = ops.BNActFn.apply(xa, ra, wa, ba, rm, rv, True, 0.1, 1e-5, relu)
+    y.backward(dy)
+    # float64 reference of the same op
+    xb = x.double().requires_grad_(True); rb = r.double().requires_grad_(True) if res else None
+    wb = w.double().requires_grad_(True); bb = b.double().requires_grad_(True)
+    yr = F.batch_norm(xb, rm2.double(), rv2.double(), wb, bb, True, 0.1, 1e-5)
+    if res:
+        yr = yr + rb
+    if relu:
+        yr = F.relu(yr)
+    yr.backward(dy.double())
+    assert y.dtype == torch.float32 and y.is_contiguous(memory_format=torch.channels_last)
+    # tolerance: fp32 rounding of a normalised value (a few ulp at |y| ~ 10)
+    assert (y.double() - yr).abs().max().item() <= 2e-5 * (1 + yr.abs().max().item())
+    m64 = x.double().mean(dim=(0, 2, 3)); v64 = x.double().var(dim=(0, 2, 3), unbiased=True)
+    assert torch.allclose(rm.double(), 0.1 * m64, atol=1e-6, rtol=1e-5) and torch.allclose(rv.double(), 0.9 + 0.1 * v64, atol=1e-6, rtol=1e-5)
+    # elements whose |y| sits within fp32 rounding of the ReLU kink may flip mask: compare robustly
+    scale = xb.grad.abs().max().item() + 1e-12
+    bad = ((xa.grad.double() - xb.grad).abs() > 2e-4 * scale).float().mean().item()
+    assert bad < 1e-4, bad
+    # d gamma / d beta: a mask flip at the kink moves one channel's sum by one element's worth; allow a couple of such channels
+    for a_, b_ in ((wa.grad.double(), wb.grad), (ba.grad.double(), bb.grad)):
+        off = (a_ - b_).abs() > 1e-4 * b_.abs().max().item() + 1e-4 * b_.abs()
+        assert int(off.sum()) <= 2 and (a_ - b_).abs().max().item() < 30.0, (int(off.sum()), (a_ - b_).abs().max().item())
+    if res:
+        assert ((ra.grad.double() - rb.grad).abs() > 1e-5 * (rb.grad.abs().max().item() + 1e-12)).float().mean().item() < 1e-4
+
+
+def test_bn_f32_forked_output_two_gradient_streams():
+    g = torch.Generator(device='cpu').manual_seed(5)
+    N, C, H, W = 6, 128, 7, 9
+    x = _cl(torch.randn(N, C, H, W, generator=g)); r = _cl(torch.randn(N, C, H, W, generator=g))
+    w = (torch.rand(C, generator=g) + 0.5).to(DEV); b = torch.zeros(C, device=DEV)
+    d1 = _cl(torch.randn(N, C, H, W, generator=g)); d2 = _cl(torch.randn(N, C, H, W, generator=g))
+    rm = torch.zeros(C, device=DEV); rv = torch.ones(C, device=DEV)
+    xa = x.clone().requires_grad_(True); ra = r.clone().requires_grad_(True)
+    ya, yb = ops.BNActFn.apply(xa, ra, w, b, rm, rv, True, 0.1, 1e-5, True, True)
+    torch.autograd.backward([ya, yb], [d1, d2])
+    xb = x.clone().requires_grad_(True); rb = r.clone().requires_grad_(True)
+    yr = F.relu(F.batch_norm(xb, None, None, w, b, True, 0.1, 1e-5) + rb)
+    yr.backward(d1 + d2)
+    assert torch.allclose(xa.grad, xb.grad, rtol=1e-4, atol=1e-5 * xb.grad.abs().max().item())
+    assert torch.allclose(ra.grad, rb.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_bn_f32_eval_mode_uses_running_stats():
+    C = 64
+    x = _cl(torch.randn(4, C, 8, 8))
+    m = BatchNormAct2d(C, relu=True).to(DEV)
+    with torch.no_grad():
+        m.running_mean.normal_(); m.running_var.uniform_(0.5, 2); m.weight.uniform_(0.5, 1.5); m.bias.normal_()
+    m.eval()
+    y = m(x)
+    yr = F.relu(F.batch_norm(x, m.running_mean, m.running_var, m.weight, m.bias, False, 0.1, m.eps))
+    assert torch.allclose(y, yr, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('N,C,H,W', [(4, 64, 16, 16), (2, 8, 6, 10), (8, 64, 112, 112)])
+def test_maxpool3x3s2_f32_vs_torch(N, C, H, W):
+    x = _cl(torch.randn(N, C, H, W)).requires_grad_(True)
+    y = ops.MaxPool3x3s2Fn.apply(x)
+    dy = _cl(torch.randn_like(y))
+    y.backward(dy)
+    xr = x.detach().clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    yr.backward(dy)
+    assert y.dtype == torch.float32 and torch.equal(y, yr)                 # the max is one of the inputs: exact
+    assert torch.allclose(x.grad, xr.grad, rtol=1e-6, atol=1e-6)           # <= 4 window gradients summed per position
+
+
+def test_resnet_f32_fused_path_matches_stock_torch():
+    """Whole ResNet-18 in fp32: liblecone's BatchNorm / pooling kernels (and whichever convolution path is active) against
+    stock torch ops on the same weights and batch.  Same precision on both sides, so the match is tight -- this is the
+    precision the reference trains in."""
+    torch.manual_seed(0)
+    net = resnet18(num_classes=10).to(DEV).to(memory_format=torch.channels_last)
+    x = _cl(torch.rand(16, 3, 64, 64))
+    net.train()
+    res = {}
+    g = None
+    for tag in ('fused', 'stock'):
+        net.zero_grad()
+        BatchNormAct2d.fused_enabled = tag == 'fused'
+        try:
+            y = net(x)
+        finally:
+            BatchNormAct2d.fused_enabled = True
+        if g is None:
+            g = torch.randn_like(y)
+        y.backward(g)
+        res[tag] = (y.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters()})
+    ya, yb = res['fused'][0], res['stock'][0]
+    assert (ya - yb).abs().max().item() <= 1e-4 * (1 + yb.abs().max().item())
+    for n in res['stock'][1]:
+        a, b = res['fused'][1][n].double().flatten(), res['stock'][1][n].double().flatten()
+        cos = float(a @ b / (a.norm() * b.norm() + 1e-300))
+        assert cos > 0.9999, (n, cos)
+
+
+def test_bf16_step_drift_from_the_reference_precision_is_bounded():
+    """The bf16 conv stack (MI355X-native storage, licensed by BASELINE.json's config 5 only) against the fp32 one (the
+    reference's precision) on the same ResNet-50, same weights, same batch: drift of the raw CNN outputs and of the cone
+    energies computed from them.  The bound is what a random-init network shows (the measured values are printed)."""
+    from learning_embeddings_amd.oe_h import FeatCNN
+    torch.manual_seed(0)
+    D = 10
+    f32 = FeatCNN(image_dir='', output_dim=D, K=0.1, compute_dtype=torch.float32).to(DEV)
+    b16 = FeatCNN(image_dir='', output_dim=D, K=0.1, compute_dtype=torch.bfloat16).to(DEV)
+    b16.load_state_dict(f32.state_dict())
+    f32.train(); b16.train()
+    x = _cl(torch.rand(32, 3, 224, 224))
+    with torch.no_grad():
+        ra = f32.forward_raw(x); rb = b16.forward_raw(x)
+    rel = ((ra - rb).norm() / ra.norm()).item()
+    cos = F.cosine_similarity(ra.flatten().double(), rb.flatten().double(), dim=0).item()
+    # cone energies of (label, image) pairs from both sets of image points
+    lab = torch.randn(32, D, device=DEV); lab = lab / lab.norm(dim=1, keepdim=True) * 0.3
+    ea = ops.pair_energy(lab, f32.soft_clip(ra), 0.1); eb = ops.pair_energy(lab, b16.soft_clip(rb), 0.1)
+    de = (ea - eb).abs().max().item()
+    print('bf16 vs fp32 ResNet-50 (random init, batch 32): raw-output relative L2 drift %.4f, cosine %.5f, max |dE| %.4f' % (rel, cos, de))
+    assert np.isfinite(rel) and rel < 0.08 and cos > 0.995
+    assert de < 0.15
+
+
+# ---------------------------------------------------------------------------------------------------------------- fp32 convolutions
+CONV_CASES = [  # N, Cin, H, W, Cout, R, stride, pad
+    (2, 64, 12, 12, 64, 1, 1, 0), (2, 64, 12, 12, 256, 1, 1, 0), (3, 256, 9, 7, 64, 1, 1, 0), (2, 64, 10, 14, 64, 3, 1, 1),
+    (2, 128, 12, 12, 128, 3, 2, 1), (2, 128, 11, 9, 128, 3, 2, 1), (2, 256, 8, 8, 512, 1, 2, 0), (1, 512, 7, 7, 512, 3, 1, 1),
+    (2, 4, 32, 32, 64, 7, 2, 3), (1, 1024, 5, 5, 2048, 1, 2, 0), (5, 64, 3, 3, 128, 3, 1, 1), (2, 8, 6, 6, 16, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize('N,Cin,H,W,Cout,R,stride,pad', CONV_CASES)
+def test_conv_f32_fwd_dgrad_wgrad_exact_on_integers_and_vs_float64(N, Cin, H, W, Cout, R, stride, pad):
+    """lec_conv_f32_{fwd,dgrad,wgrad}: (a) small-integer operands -- every product and partial sum is exactly representable, so the
+    result must EQUAL the float64 convolution, whatever the summation order (a wrong operand layout, tap or parity class shows up
+    as a mismatch, not as noise); (b) random operands against float64 to fp32 accumulation noise."""
+    g = torch.Generator(device='cpu').manual_seed(Cin * 31 + Cout + R)
+    for kind in ('int', 'rand'):
+        if kind == 'int':
+            x = torch.randint(-3, 4, (N, Cin, H, W), generator=g).float(); w = torch.randint(-2, 3, (Cout, Cin, R, R), generator=g).float()
+        else:
+            x = torch.randn(N, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, R, R, generator=g) / (Cin * R * R) ** 0.5
+        x = _cl(x); w = _cl(w)
+        xr = x.double().requires_grad_(True); wr = w.double().requires_grad_(True)
+        yr = F.conv2d(xr, wr, None, stride, pad)
+        dy = (torch.randint(-2, 3, yr.shape, generator=g).float() if kind == 'int' else torch.randn(yr.shape, generator=g))
+        dy = _cl(dy)
+        yr.backward(dy.double())
+        y = ops.conv_f32_fwd(x, w, stride, pad, want_stats=True)
+        ws = ops._bn_workspace(x.device).view(torch.float32)
+        k = ops._BN_WS_OWNER[1]; ops._BN_WS_OWNER[0] = 0
+        part = ws[:k * 2 * Cout].view(k, 2, Cout).double().sum(0)
+        dx = ops.conv_f32_dgrad(dy, w, x.shape, stride, pad)
+        dw = torch.zeros_like(w)
+        ops.conv_f32_wgrad(dy, x, dw, stride, pad)
+        assert y.shape == yr.shape and y.is_contiguous(memory_format=torch.channels_last)
+        if kind == 'int':
+            assert torch.equal(y.double(), yr.detach()), 'forward'
+            assert torch.equal(dx.double(), xr.grad), 'data gradient'
+            assert torch.equal(dw.double(), wr.grad), 'weight gradient'
+            assert torch.equal(part[0], yr.detach().sum(dim=(0, 2, 3))) and torch.equal(part[1], (yr.detach() ** 2).sum(dim=(0, 2, 3)))
+        else:
+            tol = lambda ref: 2e-5 * ref.abs().max().item()
+            assert (y.double() - yr.detach()).abs().max().item() <= tol(yr.detach())
+            assert (dx.double() - xr.grad).abs().max().item() <= tol(xr.grad)
+            assert (dw.double() - wr.grad).abs().max().item() <= tol(wr.grad)
+            assert torch.allclose(part[0], yr.detach().sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3)
