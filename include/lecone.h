@@ -172,6 +172,9 @@ int  lec_sampler_draw(lec_sampler* s, int side, int32_t node, int32_t level_id, 
 int  lec_sampler_draw_batch(lec_sampler* s, const int32_t* pos_from, const int32_t* pos_to, int B, int K, int32_t* neg);
 int  lec_sampler_next_u32(lec_sampler* s, uint32_t* out);                /* raw MT19937 word (known-answer tests)   */
 int64_t lec_sampler_tc_edges(const lec_sampler* s);                      /* |TC| (label-label + label-image)        */
+/* The closure as CSR (replaces nx.transitive_closure at oe_h.py:539 for the host's G_train_tc): descendants of node u,
+ * ascending, are adj[ptr[u] .. ptr[u+1]).  ptr: n_nodes + 1 entries; adj: lec_sampler_tc_edges() entries or NULL. */
+int  lec_sampler_tc_export(const lec_sampler* s, int64_t* ptr, int32_t* adj);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * (6) Multi-level cross-entropy, forward + backward in one launch.  Replaces MultiLevelCELoss.forward

@@ -61,6 +61,7 @@ def _load():
         'lec_sampler_draw_batch': (i32, [p, p, p, i32, i32, p]),
         'lec_sampler_next_u32': (i32, [p, p]),
         'lec_sampler_tc_edges': (i64, [p]),
+        'lec_sampler_tc_export': (i32, [p, p, p]),
         'lec_multilevel_ce_fwd_bwd': (i32, [p, i64, p, i32, i32, p, p, i32, p, p, p, i64, p]),
         'lec_bn_workspace_bytes': (i64, [i32]),
         'lec_bn_fwd': (i32, [p, p, i64, i32, p, p, f32, f32, p, p, i32, p, p, p, i32, p, p, i64, p]),

@@ -67,6 +67,20 @@ struct ActGeo {
   FastDiv dWm, dHm, dnb;                   // divisions by Wm, Hm, nb
 };
 
+// A predicated 16-byte load WITHOUT a branch: the address is clamped to the tensor's base when the predicate is false and the
+// result replaced by zeros afterwards.  (`if (ok) v = *p;` makes hipcc branch around every load and wait for it before the next
+// one: eight serialized memory round trips per chunk instead of eight loads in flight.)
+// The zeroing happens when the piece is written to LDS (a chunk later), so that nothing uses a loaded register -- and the wave
+// waits for none -- until the current chunk's MFMAs have issued.
+__device__ __forceinline__ f32x4v ldg4(const float* __restrict__ base, int64_t off, bool ok, unsigned& mask, int bit) {
+  mask |= (ok ? 1u : 0u) << bit;
+  return *(const f32x4v*)(base + (ok ? off : 0));
+}
+__device__ __forceinline__ f32x4v keep4(f32x4v v, unsigned mask, int bit) {
+  const f32x4v z = {0.f, 0.f, 0.f, 0.f};
+  return (mask >> bit) & 1u ? v : z;
+}
+
 // MFMAs of one K chunk on the workgroup's LDS tiles.  sA: [BM][kCfLdk] (A_KC) or [32][LDA] (k slow); sB likewise.
 template <bool A_KC, bool B_KC, int LDA, int LDB, int TM, int TN>
 __device__ __forceinline__ void mma_chunk(const float* __restrict__ sA, const float* __restrict__ sB, int wm0, int wn0, int lane,
@@ -151,7 +165,9 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
         for (int r = 0; r < 16; ++r) acc[it][jt][r] = 0.f;
 
     f32x4v ra[NA], rb[NB];
+    unsigned okm = 0;                                           // predicates of the pieces in flight: bit u (A), bit 16 + u (B)
     auto load_chunk = [&](int ch) {
+      okm = 0;
       const int k0 = ch * kCfBK;
       // A: one tap / channel position per 16-byte piece (a chunk lies inside one tap whenever Cs >= 32; the stem has Cs = 4)
       const int kA = k0 + 4 * kqA;
@@ -163,9 +179,7 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
       for (int u = 0; u < NA; ++u) {
         const int hs = hb[u] + dh, ws = wb[u] + dw;
         const bool ok = tap_ok && pixn[u] >= 0 && (unsigned)hs < (unsigned)g.Hs && (unsigned)ws < (unsigned)g.Ws;
-        f32x4v v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) v = *(const f32x4v*)(src + (int64_t)(pixn[u] + hs * g.Ws + ws) * g.Cs + cA);
-        ra[u] = v;
+        ra[u] = ldg4(src, (int64_t)(pixn[u] + hs * g.Ws + ws) * g.Cs + cA, ok, okm, u);
       }
       if (B_KC) {
         // B tile [BN rows = output channel co][32 k]: W[co][tap][ci], k contiguous
@@ -173,9 +187,7 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
           const int co = n0 + (tid >> 3) + 32 * u;
-          f32x4v v = {0.f, 0.f, 0.f, 0.f};
-          if (tap_ok && co < g.Cd) v = *(const f32x4v*)(wgt + ((int64_t)co * g.RS + tw) * g.Cin + cA);
-          rb[u] = v;
+          rb[u] = ldg4(wgt, ((int64_t)co * g.RS + tw) * g.Cin + cA, tap_ok && co < g.Cd, okm, 16 + u);
         }
       } else {
         // B tile [32 k rows = channel co of the gradient][BN columns = ci]: W[co][tap][ci], ci contiguous
@@ -189,22 +201,20 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
           const int ta2 = fdiv(tapB, g.dnb), tb2 = tapB - ta2 * g.nb;
           const int tw2 = (g.r0 + g.rstep * ta2) * g.S + g.s0 + g.sstep * tb2;
           const int ci = n0 + 4 * jq;
-          f32x4v v = {0.f, 0.f, 0.f, 0.f};
-          if (tapB < g.na * g.nb && ci < g.Cd) v = *(const f32x4v*)(wgt + ((int64_t)cB * g.RS + tw2) * g.Cin + ci);
-          rb[u] = v;
+          rb[u] = ldg4(wgt, ((int64_t)cB * g.RS + tw2) * g.Cin + ci, tapB < g.na * g.nb && ci < g.Cd, okm, 16 + u);
         }
       }
     };
     auto store_chunk = [&](int buf) {
       float* sA = sAb(buf); float* sB = sBb(buf);
 #pragma unroll
-      for (int u = 0; u < NA; ++u) *(f32x4v*)(sA + ((tid >> 3) + 32 * u) * kCfLdk + 4 * kqA) = ra[u];
+      for (int u = 0; u < NA; ++u) *(f32x4v*)(sA + ((tid >> 3) + 32 * u) * kCfLdk + 4 * kqA) = keep4(ra[u], okm, u);
       if (B_KC) {
 #pragma unroll
-        for (int u = 0; u < NB; ++u) *(f32x4v*)(sB + ((tid >> 3) + 32 * u) * kCfLdk + 4 * kqA) = rb[u];
+        for (int u = 0; u < NB; ++u) *(f32x4v*)(sB + ((tid >> 3) + 32 * u) * kCfLdk + 4 * kqA) = keep4(rb[u], okm, 16 + u);
       } else {
 #pragma unroll
-        for (int u = 0; u < NB; ++u) *(f32x4v*)(sB + (tid + kCfThreads * u) * 4) = rb[u];      // [kr][jq] is linear in v
+        for (int u = 0; u < NB; ++u) *(f32x4v*)(sB + (tid + kCfThreads * u) * 4) = keep4(rb[u], okm, 16 + u);      // [kr][jq] is linear in v
       }
     };
 
@@ -329,37 +339,35 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const flo
   const bool dense = g.RS == 1 && g.stride == 1 && g.pad == 0;   // 1x1 stride 1: the source pixel of m is m
 
   f32x4v ra[NA], rb[NB];
+  unsigned okm = 0;
   auto load_chunk = [&](int ch) {
+    okm = 0;
     const int mbase = ch * kCfBK;
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
       const int m = mbase + krA[u]; const int co = co0 + 4 * cqA[u];
-      f32x4v v = {0.f, 0.f, 0.f, 0.f};
-      if (m < g.Mpix && co < g.Cout) v = *(const f32x4v*)(dy + (int64_t)m * g.Cout + co);
-      ra[u] = v;
+      ra[u] = ldg4(dy, (int64_t)m * g.Cout + co, m < g.Mpix && co < g.Cout, okm, u);
     }
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
       const int m = mbase + krB[u];
-      f32x4v v = {0.f, 0.f, 0.f, 0.f};
-      if (m < g.Mpix && okB[u]) {
-        if (dense) {
-          v = *(const f32x4v*)(x + (int64_t)m * g.Cin + ciB[u]);
-        } else {
-          const int t2 = fdiv(m, g.dWo); const int wo = m - t2 * g.Wo; const int n = fdiv(t2, g.dHo); const int ho = t2 - n * g.Ho;
-          const int hs = ho * g.stride + drB[u], ws = wo * g.stride + dsB[u];
-          if ((unsigned)hs < (unsigned)g.H && (unsigned)ws < (unsigned)g.W)
-            v = *(const f32x4v*)(x + ((int64_t)(n * g.H + hs) * g.W + ws) * g.Cin + ciB[u]);
-        }
+      bool ok = m < g.Mpix && okB[u];
+      int64_t pix = m;
+      if (!dense) {
+        const int mm = ok ? m : 0;
+        const int t2 = fdiv(mm, g.dWo); const int wo = mm - t2 * g.Wo; const int n = fdiv(t2, g.dHo); const int ho = t2 - n * g.Ho;
+        const int hs = ho * g.stride + drB[u], ws = wo * g.stride + dsB[u];
+        ok = ok && (unsigned)hs < (unsigned)g.H && (unsigned)ws < (unsigned)g.W;
+        pix = (int64_t)(n * g.H + hs) * g.W + ws;
       }
-      rb[u] = v;
+      rb[u] = ldg4(x, pix * g.Cin + ciB[u], ok, okm, 16 + u);
     }
   };
   auto store_chunk = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < NA; ++u) *(f32x4v*)(sAb(buf) + (tid + kCfThreads * u) * 4) = ra[u];
+    for (int u = 0; u < NA; ++u) *(f32x4v*)(sAb(buf) + (tid + kCfThreads * u) * 4) = keep4(ra[u], okm, u);
 #pragma unroll
-    for (int u = 0; u < NB; ++u) *(f32x4v*)(sBb(buf) + (tid + kCfThreads * u) * 4) = rb[u];
+    for (int u = 0; u < NB; ++u) *(f32x4v*)(sBb(buf) + (tid + kCfThreads * u) * 4) = keep4(rb[u], okm, 16 + u);
   };
   if (ch_lo < ch_hi) {
     load_chunk(ch_lo);

@@ -259,3 +259,21 @@ extern "C" int lec_sampler_next_u32(lec_sampler* s, uint32_t* out) {
 }
 
 extern "C" int64_t lec_sampler_tc_edges(const lec_sampler* s) { return s ? s->tc_edges : -1; }
+
+// The transitive closure itself, as CSR over all nodes: node u's descendants (ascending, u excluded) are
+// adj[ptr[u] .. ptr[u + 1]).  ptr: n_nodes + 1 entries, adj: lec_sampler_tc_edges() entries (pass adj = NULL to get ptr only).
+// Lets the host build G_train_tc (oe_h.py:539 nx.transitive_closure) from the closure the sampler already holds.
+extern "C" int lec_sampler_tc_export(const lec_sampler* s, int64_t* ptr, int32_t* adj) {
+  if (!s || !ptr) { lec::set_error("sampler_tc_export: bad arguments"); return LEC_E_ARG; }
+  int64_t k = 0;
+  for (int64_t u = 0; u < s->n_nodes; ++u) {
+    ptr[u] = k;
+    for (int64_t i = s->desc_ptr[u]; i < s->desc_ptr[u + 1]; ++i) {
+      if (s->desc[i] == (int32_t)u) continue;
+      if (adj) adj[k] = s->desc[i];
+      ++k;
+    }
+  }
+  ptr[s->n_nodes] = k;
+  return LEC_OK;
+}

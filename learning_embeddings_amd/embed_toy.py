@@ -9,33 +9,25 @@ from .order_embeddings import Embedder, OrderEmbeddingLoss
 
 
 class ToyGraph:
-    """embed_toy.py:29-62: levels = [b**i for i in 1..levels-1]; duck-typed labelmap with `edges`."""
+    """The synthetic b-ary tree labelmap of config 1 (the duck type network/embed_toy.py:29-62 builds: `levels, level_names,
+    level_start, level_stop, n_classes, classes, edges`).  Level l (1-based name) holds b**l nodes; node i of a level is the
+    parent of nodes b*i .. b*i + b - 1 of the next one; global ids are level offsets + the index inside the level.  Built from
+    that contract by integer arithmetic; fixture F7 pins `levels` and `edges` against the reference."""
 
     def __init__(self, levels=4, branching_factor=3):
-        self.n_levels = levels
-        self.branching_factor = branching_factor
-        self.levels = [self.branching_factor ** i for i in range(1, self.n_levels)]
-        self.level_names = [str(i) for i in range(1, self.n_levels)]
-        for level_id, level_name in enumerate(self.level_names):
-            setattr(self, level_name, {'{}_{}'.format(level_name, str(i)): i for i in range(self.levels[level_id])})
-        for level_id, level_name in enumerate(self.level_names[:-1]):
-            setattr(self, 'child_of_' + level_name,
-                    {'{}_{}'.format(level_name, str(i)): ['{}_{}'.format(self.level_names[level_id + 1], str(j + (self.branching_factor * i)))
-                                                          for j in range(self.branching_factor)] for i in range(self.levels[level_id])})
-        self.n_classes = sum(self.levels)
-        self.classes = [key for class_list in [getattr(self, n) for n in self.level_names] for key in class_list]
-        self.level_stop, self.level_start = [], []
-        for level_id, level_len in enumerate(self.levels):
-            self.level_start.append(0 if level_id == 0 else self.level_stop[level_id - 1])
-            self.level_stop.append(self.level_start[level_id] + level_len)
+        b = int(branching_factor)
+        self.n_levels, self.branching_factor = levels, b
+        depth = levels - 1                                        # the root is implicit: `levels` counts it, the labelmap does not
+        self.levels = [b ** (l + 1) for l in range(depth)]
+        self.level_names = [str(l + 1) for l in range(depth)]
+        offs = np.concatenate(([0], np.cumsum(self.levels))).astype(int)
+        self.level_start, self.level_stop = offs[:-1].tolist(), offs[1:].tolist()
+        self.n_classes = int(offs[-1])
+        self.classes = ['%s_%d' % (nm, i) for nm, n in zip(self.level_names, self.levels) for i in range(n)]
         self.edges = set()
-        for level_id, level_name in enumerate(self.level_names[:-1]):
-            child_of = getattr(self, 'child_of_' + level_name)
-            for parent in child_of:
-                for child in child_of[parent]:
-                    u = getattr(self, level_name)[parent] + self.level_start[level_id]
-                    v = getattr(self, self.level_names[level_id + 1])[child] + self.level_start[level_id + 1]
-                    self.edges.add((u, v))
+        for l in range(depth - 1):
+            child = np.arange(self.levels[l + 1])
+            self.edges.update(zip((self.level_start[l] + child // b).tolist(), (self.level_start[l + 1] + child).tolist()))
 
 
 class ToyOrderEmbedding:

@@ -37,11 +37,11 @@ class SyntheticLabelMap:
 
     @classmethod
     def ethec(cls, path=None):
-        """The real ETHEC label DAG (6/21/135/561 nodes, 717 edges) from the integer fixture exported from
-        data/db.py:1122-3468 (tests/golden/F9_ethec_hierarchy.json)."""
+        """The real ETHEC label DAG (6/21/135/561 nodes, 717 edges) as integer data exported from data/db.py:1122-3468.  The
+        package carries its own copy (learning_embeddings_amd/data/ethec_hierarchy.json); tests/golden/F9 is the fixture the
+        tests pin it against."""
         if path is None:
-            path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden',
-                                'F9_ethec_hierarchy.json')
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'ethec_hierarchy.json')
         with open(path) as f:
             d = json.load(f)
         return cls(d['levels'], edges=[tuple(e) for e in d['edges']], level_names=d['level_names'])
@@ -91,6 +91,8 @@ class NegativeGraph:
                                      int(bool(pick_per_level)), 1 if labels_only else 0, int(seed)))
         self._h = h
         self.pick_per_level = bool(pick_per_level)
+        self.labels_only = bool(labels_only)
+        self._spec = (edges, image_ptr, image_adj)          # what save() writes: the structure, never the dense matrix
 
     @classmethod
     def from_labelmap(cls, labelmap, n_images=0, image_leaf=None, **kw):
@@ -156,3 +158,36 @@ class NegativeGraph:
     @property
     def tc_edges(self):
         return int(lib.lec_sampler_tc_edges(self._h))
+
+    def closure_csr(self):
+        """The transitive closure the sampler holds, as CSR over node indices: descendants of u (ascending) are
+        adj[ptr[u]:ptr[u+1]]."""
+        ptr = np.empty(self.n_nodes + 1, dtype=np.int64); adj = np.empty(self.tc_edges, dtype=np.int32)
+        check(lib.lec_sampler_tc_export(self._h, ptr.ctypes.data, adj.ctypes.data))
+        return ptr, adj
+
+    # ---- on-disk form (replaces the reference's dense `neg_adjacency.npy`, oe_h.py:563: O((N+M)^2) bytes) ----------
+    def save(self, path):
+        """`neg_structure.npz`: levels, label edges [E, 2], image parents CSR -- O(N + M) bytes; the closure is rebuilt on load."""
+        edges, ptr, adj = self._spec
+        np.savez_compressed(path, levels=np.asarray(self.levels, dtype=np.int32), label_edges=edges, image_ptr=ptr, image_adj=adj,
+                            pick_per_level=np.asarray(int(self.pick_per_level)), labels_only=np.asarray(int(self.labels_only)))
+
+    @classmethod
+    def load(cls, path, seed=0, pick_per_level=None):
+        d = np.load(path)
+        ppl = bool(int(d['pick_per_level'])) if pick_per_level is None else bool(pick_per_level)
+        return cls(d['levels'].tolist(), [tuple(e) for e in d['label_edges'].tolist()], d['image_ptr'], d['image_adj'],
+                   pick_per_level=ppl, labels_only=bool(int(d['labels_only'])), seed=seed)
+
+    def to_dense(self):
+        """The reference's dense negative adjacency A = 1 - TC - I (oe_h.py:554-561), for interchange with its
+        `neg_adjacency.npy`; O((N+M)^2) bytes -- refuses above 30 000 nodes."""
+        if self.n_nodes > 30000:
+            raise ValueError('dense negative adjacency of %d nodes would take %.1f GB' % (self.n_nodes, self.n_nodes ** 2 / 1e9))
+        ptr, adj = self.closure_csr()
+        A = np.ones((self.n_nodes, self.n_nodes), dtype=bool)
+        rows = np.repeat(np.arange(self.n_nodes), np.diff(ptr))
+        A[rows, adj] = False
+        np.fill_diagonal(A, False)
+        return A

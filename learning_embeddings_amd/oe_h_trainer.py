@@ -94,6 +94,100 @@ def transitive_closure(G):
     return out
 
 
+def closure_graph(skeleton, neg, mapping_ix_to_node, mapping_node_to_ix):
+    """nx.transitive_closure(skeleton) (oe_h.py:539) from the closure liblecone's sampler already holds (CSR, built in C++):
+    nodes in the skeleton's order, each node's skeleton edges first (in their order), then its remaining descendants by
+    ascending node index.  (networkx leaves the order of the added edges unspecified: 2.2 adds them in DFS preorder, 3.x in
+    set order; only the edge SET is pinned by fixture F11.)  Seconds for 50 000 labels + 100 000 images, where a memoised
+    python recursion over dict-of-dict graphs takes minutes."""
+    ptr, adj = neg.closure_csr()
+    out = DiGraph()
+    for n in skeleton.nodes():
+        out.add_node(n)
+    for u in skeleton.nodes():
+        succ = out._succ[u]
+        for v in skeleton._succ[u] if isinstance(skeleton, DiGraph) else skeleton.successors(u):
+            succ[v] = True; out._pred[v][u] = True
+        iu = mapping_node_to_ix[u]
+        for iv in adj[ptr[iu]:ptr[iu + 1]].tolist():
+            v = mapping_ix_to_node[iv]
+            if v not in succ:
+                succ[v] = True; out._pred[v][u] = True
+    return out
+
+
+GRAPH_FILES = ('G', 'G_tc', 'G_train', 'G_val', 'G_test', 'G_train_skeleton_full', 'G_train_tc')
+_GRAPH_KEYS = ('graph', 'graph_tc', 'G_train', 'G_val', 'G_test', 'G_train_skeleton_full', 'G_train_tc')
+
+
+def save_combined_graphs(graph_dict, path_to_folder, dense=None):
+    """The writer half of oe_h.py:563-571.  Same file names as the reference: the seven graphs `G`, `G_tc`, `G_train`, `G_val`,
+    `G_test`, `G_train_skeleton_full`, `G_train_tc` -- each a pickle (the reference's nx.write_gpickle IS pickle.dump) of
+    {'nodes': [...], 'edges': [(u, v), ...]} in insertion order, version-independent where a pickled networkx object is not --
+    plus the negative structure as `neg_structure.npz` (NegativeGraph.save: O(N + M) bytes).  dense=True (default: only up to
+    4 000 nodes) also writes the reference's own `neg_adjacency.npy` so that the reference can read the folder back."""
+    import pickle
+    os.makedirs(path_to_folder, exist_ok=True)
+    for fname, key in zip(GRAPH_FILES, _GRAPH_KEYS):
+        g = graph_dict[key]
+        with open(os.path.join(path_to_folder, fname), 'wb') as f:
+            pickle.dump({'nodes': list(g.nodes()), 'edges': [tuple(e) for e in g.edges()]}, f, protocol=4)
+    neg = graph_dict['G_train_neg']
+    if not isinstance(neg, NegativeGraph):
+        neg = NegativeGraph.from_dense(np.asarray(neg), graph_dict['levels'])
+    neg.save(os.path.join(path_to_folder, 'neg_structure.npz'))
+    if dense or (dense is None and neg.n_nodes <= 4000):
+        np.save(os.path.join(path_to_folder, 'neg_adjacency.npy'), neg.to_dense())
+
+
+def _read_graph(path):
+    import pickle
+    with open(path, 'rb') as f:
+        obj = pickle.load(f)                  # a reference-written file unpickles to a networkx.DiGraph (needs networkx importable)
+    if isinstance(obj, dict) and 'edges' in obj:
+        g = DiGraph()
+        for n in obj['nodes']:
+            g.add_node(n)
+        g.add_edges_from(obj['edges'])
+        return g
+    g = DiGraph()                              # anything with nodes() / edges(): copy into the insertion-ordered type
+    for n in obj.nodes():
+        g.add_node(n)
+    g.add_edges_from(obj.edges())
+    return g
+
+
+def load_combined_graphs(debug_or_path, labelmap=None, pick_per_level=False):
+    """oe_h.py:2250-2297.  `debug_or_path`: the reference's bool (its two hard-wired relative folders) or a folder path.
+    Reads folders written by save_combined_graphs AND by the reference (gpickled networkx graphs + dense neg_adjacency.npy;
+    for those pass `labelmap`, whose level sizes the sampler needs).  Returns the reference's graph_dict keys."""
+    print('Reading graphs from disk!')
+    if isinstance(debug_or_path, (str, os.PathLike)):
+        folder = debug_or_path
+    else:
+        folder = '../database/ETHEC/ETHECSmall_embeddings/graphs' if debug_or_path else '../database/ETHEC/ETHEC_embeddings/graphs'
+    gd = {key: _read_graph(os.path.join(folder, fname)) for fname, key in zip(GRAPH_FILES, _GRAPH_KEYS)}
+    mapping_ix_to_node = {}
+    img_label = len(gd['graph'].nodes()) if labelmap is None else labelmap.n_classes
+    for node in gd['G_train_tc'].nodes():                       # oe_h.py:2276-2283
+        if isinstance(node, (int, np.integer)):
+            mapping_ix_to_node[int(node)] = int(node)
+        else:
+            mapping_ix_to_node[img_label] = node; img_label += 1
+    mapping_node_to_ix = {v: k for k, v in mapping_ix_to_node.items()}
+    st = os.path.join(folder, 'neg_structure.npz')
+    if os.path.exists(st):
+        neg = NegativeGraph.load(st, seed=0, pick_per_level=pick_per_level)
+    else:
+        if labelmap is None:
+            raise ValueError('a folder written by the reference holds only the dense neg_adjacency.npy: pass `labelmap` (its level sizes)')
+        neg = NegativeGraph.from_dense(np.load(os.path.join(folder, 'neg_adjacency.npy')), labelmap.levels, pick_per_level=pick_per_level, seed=0)
+    print('Graph with labels connected has {} edges, {} nodes'.format(gd['graph'].size(), len(gd['graph'].nodes())))
+    print('Transitive closure of graphs with labels & images: train {}'.format(gd['G_train_tc'].size()))
+    gd.update({'G_train_neg': neg, 'mapping_ix_to_node': mapping_ix_to_node, 'mapping_node_to_ix': mapping_node_to_ix})
+    return gd
+
+
 def create_combined_graphs(dataloaders, labelmap, pick_per_level=False):
     """oe_h.py:506-580 on the same inputs (dataloaders yielding {'level_labels': [b, L], 'image_filename': [b]}), but the
     negative structure is a CSR NegativeGraph instead of the dense (N+M)^2 matrix, nothing is pickled to disk, and
@@ -121,11 +215,10 @@ def create_combined_graphs(dataloaders, labelmap, pick_per_level=False):
                         G_train_tc_base.add_edge(lab, fname)
                         image_leaf_parents.setdefault(fname, []).append(lab)
     G_train_skeleton_full = copy.deepcopy(G_train_tc_base)
-    G_train_tc = transitive_closure(G_train_tc_base)
     n_labels = labelmap.n_classes
     mapping_ix_to_node = {i: i for i in range(n_labels)}
     img_label = n_labels
-    for node in G_train_tc.nodes():
+    for node in G_train_tc_base.nodes():                        # the closure has the skeleton's nodes in the skeleton's order
         if isinstance(node, str):
             mapping_ix_to_node[img_label] = node; img_label += 1
     mapping_node_to_ix = {v: k for k, v in mapping_ix_to_node.items()}
@@ -135,6 +228,7 @@ def create_combined_graphs(dataloaders, labelmap, pick_per_level=False):
         adj.extend(image_leaf_parents[nm]); ptr[j + 1] = len(adj)
     label_edges = [(u, v) for u, v in G.edges()]
     neg = NegativeGraph(labelmap.levels, label_edges, ptr, np.asarray(adj, dtype=np.int32), pick_per_level=pick_per_level, seed=0)
+    G_train_tc = closure_graph(G_train_tc_base, neg, mapping_ix_to_node, mapping_node_to_ix)    # oe_h.py:539, closure from the C++ sampler
     return {'graph': G, 'graph_tc': transitive_closure(G), 'G_train': graphs['train'], 'G_val': graphs['val'],
             'G_test': graphs['test'], 'G_train_skeleton_full': G_train_skeleton_full, 'G_train_neg': neg,
             'mapping_ix_to_node': mapping_ix_to_node, 'mapping_node_to_ix': mapping_node_to_ix,

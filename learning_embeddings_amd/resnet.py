@@ -85,6 +85,18 @@ class WgradOverlap:
         """The wide 1x1 layers: liblecone's MFMA weight-gradient kernel adds dY^T X straight into the arena's fp32 gradient
         slot (zeroed at the start of the step) -- no library kernel, zero-fill, cast or copy.  False when not applicable."""
         w = conv.weight
+        if (MFMA_F32 and gy.dtype == torch.float32 and x.dtype == torch.float32 and w.grad is not None and w.grad.dtype == torch.float32
+                and w.grad.shape == w.shape and _f32_conv_ok(conv) and w.grad.is_contiguous(memory_format=torch.channels_last)
+                and gy.is_contiguous(memory_format=torch.channels_last) and x.is_contiguous(memory_format=torch.channels_last)):
+            if conv.in_channels == 3:             # the stem: x carries the zero 4th channel (_pad_c4), its gradient column is dropped
+                dw4 = torch.empty((w.shape[0], 4, w.shape[2], w.shape[3]), dtype=torch.float32, device=w.device, memory_format=torch.channels_last).zero_()
+                _ops().conv_f32_wgrad(gy, x, dw4, conv.stride[0], conv.padding[0])
+                w.grad.add_(dw4[:, :3])
+            else:
+                _ops().conv_f32_wgrad(gy, x, w.grad, conv.stride[0], conv.padding[0])   # f32 MFMA, atomics straight into the gradient slot
+            if self.reducer is not None:
+                self.reducer.mark_ready(w)
+            return True
         if (MFMA_WGRAD_3X3 and self.arena is not None and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
                 and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels == 64 and conv.out_channels == 64
                 and w.grad is not None and w.grad.dtype == torch.float32 and w.grad.is_contiguous(memory_format=torch.channels_last)
@@ -166,6 +178,8 @@ MFMA_WGRAD_3X3 = os.environ.get('LEC_CONV3X3_WGRAD', '1') != '0'
 # layer3's 256 <-> 1024 pairs (14 x 14): 104 against the library's 115 us alone, but 44.0 against 43.5 ms in the step (its 131 KB,
 # eight-wave workgroups sit on every CU beside layer3's short main-stream kernels): off
 MFMA_WGRAD_L3 = os.environ.get('LEC_CONV1X1_WGRAD_L3', '0') != '0'
+# fp32 activations (the reference's precision): every convolution runs liblecone's f32-MFMA implicit-GEMM family (csrc/conv_f32.hip)
+MFMA_F32 = os.environ.get('LEC_CONV_F32', '1') != '0'
 GEMM_FWD_MIN_CIN = 1024
 GEMM_DGRAD_MIN_CIN = 256
 
@@ -173,6 +187,25 @@ GEMM_DGRAD_MIN_CIN = 256
 def _ops():
     from . import ops
     return ops
+
+
+def _f32_conv_ok(conv):
+    """Layers lec_conv_f32_* serve: everything in ResNet-18 / -50 (the 3-channel stem through a zero 4th channel)."""
+    ops = _ops()
+    if conv.in_channels == 3:
+        return (conv.groups == 1 and conv.dilation == (1, 1) and conv.bias is None and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2)
+                and conv.padding[0] == conv.padding[1] and conv.kernel_size[0] == conv.kernel_size[1] and conv.padding[0] < conv.kernel_size[0]
+                and ops.conv_f32_supported(4, conv.out_channels))
+    return ops.conv_f32_supported(conv)
+
+
+def _pad_c4(t):
+    """[N, 3, H, W] -> [N, 4, H, W] channels_last with a zero 4th channel (already 4 channels: returned as is)."""
+    if t.shape[1] == 4:
+        return t
+    out = torch.empty((t.shape[0], 4, t.shape[2], t.shape[3]), dtype=t.dtype, device=t.device, memory_format=torch.channels_last)
+    out[:, 3:].zero_(); out[:, :3] = t
+    return out
 
 
 def _is_pointwise(conv):
@@ -197,6 +230,18 @@ class _OverlapConvFn(torch.autograd.Function):
         nhwc = x.is_contiguous(memory_format=torch.channels_last)
         if nhwc and w16.dim() == 4 and not w16.is_contiguous(memory_format=torch.channels_last):
             w16 = w16.contiguous(memory_format=torch.channels_last)
+        ctx.f32 = (MFMA_F32 and nhwc and x.dtype == torch.float32 and w16.dtype == torch.float32 and _f32_conv_ok(conv)
+                   and w16.is_contiguous(memory_format=torch.channels_last))
+        if ctx.f32:
+            # the reference's precision: liblecone's f32-MFMA implicit GEMM (every layer shape, stride and direction), with the
+            # BatchNorm statistics of the output in its epilogue
+            ctx.stem = conv.in_channels == 3
+            if ctx.stem:                          # the kernels want >= 4 input channels: a zero 4th channel on both operands
+                x, w16 = _pad_c4(x), _pad_c4(w16)
+            y = _ops().conv_f32_fwd(x, w16, conv.stride[0], conv.padding[0], want_stats=True)
+            ctx.save_for_backward(x, w16); ctx.conv = conv
+            ctx.pointwise = ctx.own = ctx.own3 = False
+            return y
         ctx.pointwise = GEMM_1X1 and nhwc and _is_pointwise(conv)
         ctx.own = ctx.pointwise and MFMA_1X1 and x.dtype == torch.bfloat16
         ctx.own3 = (MFMA_3X3 and nhwc and x.dtype == torch.bfloat16 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
@@ -245,9 +290,15 @@ class _OverlapConvFn(torch.autograd.Function):
                 wgrad_done = True
             else:
                 _ops().bn_bwd_apply_lazy(lz, gy)
+        if ctx.f32 and not gy.is_contiguous(memory_format=torch.channels_last):
+            gy = gy.contiguous(memory_format=torch.channels_last)
         if ctx.needs_input_grad[0]:
             nhwc_g = gy.is_contiguous(memory_format=torch.channels_last)
-            if ctx.own3 and nhwc_g:                             # dX = conv(dY, W flipped and transposed): the same kernel,
+            if ctx.f32:
+                gx = _ops().conv_f32_dgrad(gy, w16, x.shape, conv.stride[0], conv.padding[0])
+                if ctx.stem:
+                    gx = gx[:, :3]
+            elif ctx.own3 and nhwc_g:                             # dX = conv(dY, W flipped and transposed): the same kernel,
                 gx = _ops().conv3x3_c64(gy, w16, w_transposed=True)   # which flips / transposes the weight as it loads it
             elif (ctx.own and nhwc_g and _ops().conv1x1_supported(conv.out_channels, conv.in_channels, gy.shape[0] * gy.shape[2] * gy.shape[3])):
                 n, _, h, wd = gy.shape                          # dX = dY * W: the same kernel, W transposed as it is loaded

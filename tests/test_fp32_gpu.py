@@ -196,3 +196,43 @@ def test_conv_f32_fwd_dgrad_wgrad_exact_on_integers_and_vs_float64(N, Cin, H, W,
             assert (dx.double() - xr.grad).abs().max().item() <= tol(xr.grad)
             assert (dw.double() - wr.grad).abs().max().item() <= tol(wr.grad)
             assert torch.allclose(part[0], yr.detach().sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('arch,hw,n', [('resnet18', 64, 8), ('resnet50', 96, 6)])
+def test_resnet_f32_own_convolutions_match_stock_torch(arch, hw, n):
+    """The whole backbone at the reference's precision through liblecone only -- f32-MFMA convolutions (statistics epilogue, parity-class
+    data gradients of the strided layers, the 3-channel stem through a zero 4th channel, weight gradients on the side stream),
+    BatchNorm(+add)(+ReLU) and max pooling -- against stock torch fp32 ops on the same weights and batch: outputs, input gradient,
+    every parameter gradient."""
+    from learning_embeddings_amd import resnet as R
+    torch.manual_seed(0)
+    net = (resnet18 if arch == 'resnet18' else resnet50)(num_classes=10).to(DEV).to(memory_format=torch.channels_last)
+    net.train()
+    x0 = _cl(torch.rand(n, 3, hw, hw))
+    res = {}
+    g = None
+    for tag in ('own', 'stock'):
+        for p_ in net.parameters():
+            p_.grad = torch.zeros_like(p_)                      # the weight-gradient kernels accumulate into existing slots
+        x = x0.clone().requires_grad_(True)
+        WgradOverlap.instance = WgradOverlap() if tag == 'own' else None
+        BatchNormAct2d.fused_enabled = tag == 'own'
+        try:
+            y = net(x)
+            if g is None:
+                g = torch.randn_like(y)
+            y.backward(g)
+            if WgradOverlap.instance is not None:
+                WgradOverlap.instance.join()
+            torch.cuda.synchronize()
+        finally:
+            WgradOverlap.instance = None
+            BatchNormAct2d.fused_enabled = True
+        res[tag] = (y.detach().clone(), x.grad.clone(), {k: p_.grad.clone() for k, p_ in net.named_parameters()})
+    ya, yb = res['own'][0], res['stock'][0]
+    assert (ya - yb).abs().max().item() <= 2e-4 * (1 + yb.abs().max().item())
+    cos = lambda a, b: float(a.double().flatten() @ b.double().flatten() / (a.double().norm() * b.double().norm() + 1e-300))
+    assert cos(res['own'][1], res['stock'][1]) > 0.9995
+    for k in res['stock'][2]:
+        c = cos(res['own'][2][k], res['stock'][2][k])
+        assert c > 0.999, (k, c)

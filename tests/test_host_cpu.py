@@ -29,6 +29,9 @@ def test_toygraph_matches_reference_fixture():
 
 
 def test_ethec_labelmap_fixture():
+    import json
+    pkg = os.path.join(os.path.dirname(GOLDEN), '..', 'learning_embeddings_amd', 'data', 'ethec_hierarchy.json')
+    assert json.load(open(pkg)) == json.load(open(os.path.join(GOLDEN, 'F9_ethec_hierarchy.json')))   # the package's copy IS the fixture
     lm = SyntheticLabelMap.ethec()
     assert lm.levels == [6, 21, 135, 561] and lm.n_classes == 723 and len(lm.edges) == 717
     assert lm.level_start == [0, 6, 27, 162] and lm.level_stop == [6, 27, 162, 723]
@@ -187,3 +190,74 @@ def test_pair_dataset_loads_image_files_and_collates(tmp_path):
     assert len(lab_edge) == 1 and ds[lab_edge[0]]['to'] == 2
     ds.set_levels_to_hide([1])                                           # hides every edge touching level 1 (labels 2..5)
     assert all(not (isinstance(u, int) and 2 <= u < 6) and not (isinstance(v, int) and 2 <= v < 6) for u, v in ds.edge_list)
+
+
+# ---------------------------------------------------------------------------------------------------- F11: pair dataset + graph build
+def _f11():
+    return json.load(open(os.path.join(GOLDEN, 'F11_pair_dataset.json')))
+
+
+def _graph_from(nodes, edges):
+    g = DiGraph()
+    for n in nodes:
+        g.add_node(n)
+    for u, v in edges:
+        g.add_edge(u, v)
+    return g
+
+
+def test_create_combined_graphs_matches_reference_fixture():
+    """oe_h.py:506-580 on the fixture's imageless loaders: node <-> index mapping (labels keep their id, images numbered in
+    first-appearance order), every graph's edge set, the insertion-ordered graphs' edge ORDER, and the negative structure
+    (dense A = 1 - TC - I in the reference, CSR here): draws from both are bit-identical."""
+    f = _f11()
+    lm = SyntheticLabelMap(f['levels'])
+    loaders = {s: [{'level_labels': np.asarray(b['level_labels']), 'image_filename': b['image_filename']} for b in bl] for s, bl in f['loaders'].items()}
+    gd = create_combined_graphs(loaders, lm, pick_per_level=True)
+    n_nodes = len(f['mapping_ix_to_node'])
+    assert [gd['mapping_ix_to_node'][i] for i in range(n_nodes)] == f['mapping_ix_to_node']
+    assert gd['mapping_node_to_ix'] == {n: i for i, n in enumerate(f['mapping_ix_to_node'])}
+    tup = lambda es: [tuple(e) for e in es]
+    for key, name in (('graph', 'graph_edges'), ('G_train', 'G_train_edges'), ('G_val', 'G_val_edges'), ('G_test', 'G_test_edges'),
+                      ('G_train_skeleton_full', 'G_train_skeleton_full_edges')):
+        assert gd[key].edges() == tup(f[name]), key                      # insertion-ordered in both code bases
+    assert sorted(gd['graph_tc'].edges()) == sorted(tup(f['graph_tc_edges']))
+    # the closure's edge ORDER is networkx-version dependent in the reference (descendants() is a set in networkx 3): pin the set
+    key = lambda e: (str(type(e[0])), str(e[0]), str(type(e[1])), str(e[1]))
+    assert sorted(gd['G_train_tc'].edges(), key=key) == sorted(tup(f['G_train_tc_edges']), key=key)
+    assert gd['G_train_tc'].size() == len(f['G_train_tc_edges'])
+    # negative structure: same candidates / same stream as the reference's dense matrix
+    A = np.asarray(f['neg_adjacency'], dtype=bool)
+    dense = NegativeGraph.from_dense(A, lm.levels, pick_per_level=True, seed=0)
+    csr = gd['G_train_neg']; csr.seed(0)
+    N = lm.n_classes
+    frm = np.array([0, 3, 9, 1, 5, 13, 2, 6], dtype=np.int32); to = np.array([N + 0, N + 3, N + 8, N + 4, N + 9, N + 5, 7, N + 11], dtype=np.int32)
+    assert np.array_equal(csr.draw_batch(frm, to, 5), dense.draw_batch(frm, to, 5))
+
+
+@pytest.mark.parametrize('half_half', [False, True])
+def test_pair_dataset_matches_reference_fixture(half_half):
+    """oe_h.py:583-736: edge lists, __len__, __getitem__ (half_half's map_ranges index mapping included) and
+    set_levels_to_hide filtering, item by item against the reference's own dataset on the same graph."""
+    from learning_embeddings_amd.oe_h_trainer import ETHECHierarchyWithImages
+    f = _f11()
+    lm = SyntheticLabelMap(f['levels'])
+    g = _graph_from(f['G_train_tc_nodes'], f['G_train_tc_edges'])
+    assert g.edges() == [tuple(e) for e in f['G_train_tc_edges']]
+    d = ETHECHierarchyWithImages(g, lm, imageless_dataloaders=None, half_half=half_half)
+    for hide in ([], [1], [0, 2], [0, 1, 2]):
+        rec = f['dataset']['half_half=%s hide=%s' % (half_half, hide)]
+        if hide or half_half:
+            d.set_levels_to_hide(hide)
+        assert len(d) == rec['len']
+        if half_half:
+            assert d.edge_list_ll == [tuple(e) for e in rec['edge_list_ll']] and d.edge_list_li == [tuple(e) for e in rec['edge_list_li']]
+        else:
+            assert d.edge_list == [tuple(e) for e in rec['edge_list']]
+        for i, want in enumerate(rec['items']):
+            if want == 'IndexError':
+                with pytest.raises(IndexError):
+                    d[i]
+            else:
+                it = d[i]
+                assert [it['original_from'], it['original_to'], it['status']] == want and it['from'] == want[0] and it['to'] == want[1]
