@@ -10,30 +10,50 @@
 //     data gradient  dX[m, ci] = sum_{tap, co} dY[src(m, tap), co]  * W[co, tap, ci]           M = N*H*W,   N = Cin,  K = taps*Cout
 //     weight grad.   dW[co, (tap, ci)] += sum_m dY[m, co] * X[pixel(m) + tap, ci]               M = Cout, N = R*S*Cin, K = N*Ho*Wo
 //
-// A workgroup is 4 waves, each owning a 64 x 64 block (2 x 2 MFMA tiles, 64 accumulator registers) of a 128 x 128, 256 x 64 or
-// 64 x 256 output tile; K advances in chunks of 32: the chunk's two operand tiles travel global -> registers (16-byte loads, a
-// chunk ahead) -> LDS (double-buffered, one barrier per chunk) in the orientation they have in memory -- no transposes on the
-// staging path: an operand whose k index is contiguous in memory is read back with ds_read_b128 (4 consecutive k per lane), one
-// whose k index is the slow one with 4 x ds_read_b32, and the k ORDER inside an 8-group (k = 8q + 4h + t for lane half h, MFMA
-// step t) is the same for both operands, which is all a sum over k needs.  Two workgroups per CU (72 KB of LDS each): one's staging
-// runs under the other's MFMAs.
+// A workgroup is 4 waves, each owning a 64 x 64 block (2 x 2 MFMA tiles, 64 accumulator registers); K advances in chunks of 32: the
+// chunk's two operand tiles travel global -> registers (16-byte buffer loads, a chunk ahead) -> LDS (double-buffered, one barrier
+// per chunk) in the orientation they have in memory -- no transposes on the staging path: an operand whose k index is contiguous in
+// memory is read back with ds_read_b128 (4 consecutive k per lane), one whose k index is the slow one with 4 x ds_read_b32, and the
+// k ORDER inside an 8-group (k = 8q + 4h + t for lane half h, MFMA step t) is the same for both operands, which is all a sum over k
+// needs.  Two workgroups per CU.
+//
+// THE rule this file is written by (measured, profiles/r02_conv_f32_pmc.md): the f32 MFMA runs ON the vector ALUs -- rocprofv3 reads
+// SQ_VALU_MFMA_COEXEC_CYCLES = 0 for these kernels, and a second wave per SIMD hides nothing -- so every VALU instruction of any
+// resident wave is matrix time lost (the first version spent 2.3 VALU instructions per MFMA on 64-bit address arithmetic, predicate
+// selects and branches and reached 62 % of the matrix peak where the same loop with trivial addresses reaches 92 %).  Hence:
+//   * operands are fetched with raw buffer loads: a 32-bit byte offset per piece, and the hardware's range check returns the zeros
+//     of padding, row tails and K tails (offset 0x80000000 = out of range), so no data is ever masked;
+//   * a chunk lies inside one filter tap: tap decode, channel offset and weight offset are wave-uniform (scalar ALU); a piece's
+//     offset is a per-row base computed once per m-tile plus that scalar; its validity is one bit of a per-row tap mask;
+//   * the weight gradient stages 256-wide rows so that one wave-instruction covers ONE pixel: the pixel decode is scalar too;
+//   * no 64-bit vector arithmetic, no branches inside the K loop.
 // A strided layer's data gradient runs as stride^2 launches, one per parity class of the input pixels: a class has a fixed subset
 // of the taps (3x3 / stride 2: 1, 2, 2 and 4 of the 9), so no MFMA is spent on structural zeros.
 // Forward optionally leaves the BatchNorm statistics partials of its output (lec_bn_fwd_prestat_f32's layout): the workgroups
 // loop over their m-tiles and keep per-channel sum / sum of squares in registers, so the statistics pass over Y disappears.
 //
 // Roofline: MFMA (f32).  Algorithmic flops 2*M*N*K per launch; bytes are noise except for layer1's 1x1 layers.
+#include <cstdlib>
 #include "lec_common.h"
 
 namespace lec {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4r __attribute__((__vector_size__(4 * sizeof(unsigned int))));
 
 constexpr int kCfBK = 32;                 // K chunk (floats)
 constexpr int kCfLdk = kCfBK + 4;         // row stride of a k-contiguous LDS tile: 144 B, conflict-free ds_read_b128
+constexpr int kCfKQ = kCfBK / 4;          // 16-byte pieces per k-contiguous row
+constexpr int kCfRP = 256 / kCfKQ;        // rows staged per pass of the 256 threads
 constexpr int kCfThreads = 256;
 constexpr int kCfMaxPart = 512;           // = kBnMaxBlocks: statistics partial rows
+#ifndef LEC_WG_BK
+#define LEC_WG_BK 16
+#endif
+constexpr int kWgBK = LEC_WG_BK;          // K chunk of the weight gradient (pixels): 16 -> 40 KB of LDS per workgroup
+constexpr unsigned kOob = 0x80000000u;    // a byte offset no tensor reaches (num_records < 2^31): the load returns zeros, the store is dropped
 
 // exact unsigned division by a launch-invariant divisor (Granlund-Montgomery round-up form: exact for every 32-bit dividend)
 struct FastDiv { uint32_t mul, sh1, sh2, d; };
@@ -44,12 +64,23 @@ static inline FastDiv make_fastdiv(int d_) {
   f.sh1 = l < 1 ? l : 1; f.sh2 = l > 0 ? l - 1 : 0;
   return f;
 }
-#if defined(__HIPCC__)
 __device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
   const uint32_t t = __umulhi(f.mul, (uint32_t)n);
   return (int)((t + (((uint32_t)n - t) >> f.sh1)) >> f.sh2);
 }
-#endif
+
+// raw buffer resource over [p, p + bytes): stride 0, hardware range check on the byte offset
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4v bload4(rsrc_t rsrc, unsigned voff) {
+  const u32x4r v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0);
+  return __builtin_bit_cast(f32x4v, v);
+}
+__device__ __forceinline__ void bstore1(float v, rsrc_t rsrc, unsigned voff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)voff, 0, 0);
+}
 
 // geometry of an "activation-gather" GEMM (forward, or one parity class of a data gradient)
 struct ActGeo {
@@ -64,30 +95,17 @@ struct ActGeo {
   int Cin;                                 // the layer's input channels (innermost weight dimension)
   int Hd, Wd, dst_st, dph, dpw;            // destination pixel of m: (n, mh * dst_st + dph, mw * dst_st + dpw) of [N, Hd, Wd, Cd]
   int Kg;                                  // na * nb * Cs
+  uint32_t src_bytes, wgt_bytes, dst_bytes;
   FastDiv dWm, dHm, dnb;                   // divisions by Wm, Hm, nb
 };
 
-// A predicated 16-byte load WITHOUT a branch: the address is clamped to the tensor's base when the predicate is false and the
-// result replaced by zeros afterwards.  (`if (ok) v = *p;` makes hipcc branch around every load and wait for it before the next
-// one: eight serialized memory round trips per chunk instead of eight loads in flight.)
-// The zeroing happens when the piece is written to LDS (a chunk later), so that nothing uses a loaded register -- and the wave
-// waits for none -- until the current chunk's MFMAs have issued.
-__device__ __forceinline__ f32x4v ldg4(const float* __restrict__ base, int64_t off, bool ok, unsigned& mask, int bit) {
-  mask |= (ok ? 1u : 0u) << bit;
-  return *(const f32x4v*)(base + (ok ? off : 0));
-}
-__device__ __forceinline__ f32x4v keep4(f32x4v v, unsigned mask, int bit) {
-  const f32x4v z = {0.f, 0.f, 0.f, 0.f};
-  return (mask >> bit) & 1u ? v : z;
-}
-
 // MFMAs of one K chunk on the workgroup's LDS tiles.  sA: [BM][kCfLdk] (A_KC) or [32][LDA] (k slow); sB likewise.
-template <bool A_KC, bool B_KC, int LDA, int LDB, int TM, int TN>
+template <bool A_KC, bool B_KC, int LDA, int LDB, int TM, int TN, int BKT = kCfBK>
 __device__ __forceinline__ void mma_chunk(const float* __restrict__ sA, const float* __restrict__ sB, int wm0, int wn0, int lane,
                                           f32x16 (&acc)[TM][TN]) {
   const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
-  for (int q = 0; q < kCfBK / 8; ++q) {
+  for (int q = 0; q < BKT / 8; ++q) {
     float a[TM][4], b[TN][4];
 #pragma unroll
     for (int it = 0; it < TM; ++it) {
@@ -121,40 +139,67 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ sA, const fl
 
 // ---------------------------------------------------------------------------------------------------------------
 // forward / data gradient: A = gathered activations (k contiguous), B = weights (k contiguous: forward; k slow: data gradient)
-template <bool B_KC, int WM, int WN, int TM, int TN, bool STATS>
+// TAPV: the tap of a 16-byte piece varies inside a chunk (source channels < chunk width: the stem's 4 channels, 8 taps per
+// chunk); otherwise a chunk lies inside ONE tap and everything but the per-row validity bit and one add per piece is scalar.
+template <bool B_KC, int WM, int WN, int TM, int TN, bool STATS, bool TAPV>
 __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
                                                                      float* __restrict__ dst, ActGeo g, float* __restrict__ part) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   static_assert(WM * WN == 4, "four waves per workgroup");
-  constexpr int NA = BM * 8 / kCfThreads;                     // 16-byte pieces of the A tile per thread
-  constexpr int NB = BN * 8 / kCfThreads;                     // ... of the B tile (same count in either orientation)
+  constexpr int NA = BM * kCfKQ / kCfThreads;                 // 16-byte pieces of the A tile per thread
+  constexpr int NB = BN * kCfKQ / kCfThreads;                 // ... of the B tile (same count in either orientation)
   constexpr int SA = BM * kCfLdk;
   constexpr int SB = B_KC ? BN * kCfLdk : kCfBK * BN;
+  constexpr int PR = BN / 4;                                  // 16-byte pieces per k row of a k-slow B tile
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  auto sAb = [&](int b) -> float* { return smem + b * (SA + SB); };
-  auto sBb = [&](int b) -> float* { return smem + b * (SA + SB) + SA; };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WN) * 32 * TM, wn0 = (wave % WN) * 32 * TN;
   const int n0 = blockIdx.y * BN;
   const int nchunks = (g.Kg + kCfBK - 1) / kCfBK;
   const int mtiles = (g.Mg + BM - 1) / BM;
-  const int kqA = tid & 7;                                    // this thread's 16-byte column of the k-contiguous A tile
+  const int kqA = tid & (kCfKQ - 1);                          // this thread's 16-byte column of a k-contiguous tile
+  const int rowA = tid / kCfKQ;                               // ... and its first row (further rows: + kCfRP u)
+  const rsrc_t rs_src = make_rsrc(src, g.src_bytes), rs_wgt = make_rsrc(wgt, g.wgt_bytes), rs_dst = make_rsrc(dst, g.dst_bytes);
   float st_s[TN], st_q[TN];
 #pragma unroll
   for (int jt = 0; jt < TN; ++jt) { st_s[jt] = 0.f; st_q[jt] = 0.f; }
+  // per-piece constants of the B tile (they do not depend on the m-tile): byte offset inside the weights, kOob past the channels
+  const int rsc = g.RS * g.Cin;
+  unsigned wB[NB];
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    if (B_KC) { const int co = n0 + rowA + kCfRP * u; wB[u] = co < g.Cd ? (unsigned)(co * rsc + 4 * kqA) * 4u : kOob; }
+    else { const int v_ = tid + kCfThreads * u; const int kr = v_ / PR, jq = v_ - kr * PR; const int ci = n0 + 4 * jq;
+           wB[u] = ci < g.Cd ? (unsigned)(kr * rsc + ci) * 4u : kOob; }
+  }
+  // LDS byte offsets of this thread's pieces inside a buffer
+  const unsigned ldsA = (unsigned)((rowA * kCfLdk + 4 * kqA) * 4);
+  const unsigned ldsB = (unsigned)((SA + (B_KC ? rowA * kCfLdk + 4 * kqA : tid * 4)) * 4);
   const bool dense_dst = g.dst_st == 1;                        // destination pixel index == m (forward, stride-1 data gradient)
+  const int ntaps = g.na * g.nb;
 
   for (int mt = blockIdx.x; mt < mtiles; mt += gridDim.x) {
     const int m0 = mt * BM;
-    // rows of the A tile this thread stages: row = tid / 8 + 32 u
-    int pixn[NA], hb[NA], wb[NA];
+    // rows of the A tile this thread stages (rowA + kCfRP u): byte offset of the row's source pixel at tap offset (0, 0) and
+    // a bit per tap: the row exists and the tap's source pixel lies inside the image
+    int rowoff[NA]; unsigned tapmask[NA]; int hb[NA], wb[NA], pixn[NA];
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
-      const int m = m0 + (tid >> 3) + 32 * u;
-      if (m < g.Mg) {
-        const int t2 = fdiv(m, g.dWm); const int mw = m - t2 * g.Wm; const int n = fdiv(t2, g.dHm); const int mh = t2 - n * g.Hm;
-        pixn[u] = n * g.Hs * g.Ws; hb[u] = mh * g.sst + g.oh0; wb[u] = mw * g.sst + g.ow0;
-      } else { pixn[u] = -1; hb[u] = 0; wb[u] = 0; }
+      const int m = m0 + rowA + kCfRP * u;
+      const bool live = m < g.Mg;
+      const int mm = live ? m : 0;
+      const int t2 = fdiv(mm, g.dWm); const int mw = mm - t2 * g.Wm; const int n = fdiv(t2, g.dHm); const int mh = t2 - n * g.Hm;
+      hb[u] = mh * g.sst + g.oh0; wb[u] = mw * g.sst + g.ow0; pixn[u] = live ? n * g.Hs * g.Ws : -1;
+      rowoff[u] = (((n * g.Hs + hb[u]) * g.Ws + wb[u]) << g.lgCs) * 4 + 16 * kqA;
+      unsigned msk = 0;
+      if (!TAPV) {
+        for (int t = 0; t < ntaps; ++t) {
+          const int ta = fdiv(t, g.dnb), tb = t - ta * g.nb;
+          const int hs = hb[u] + g.sg * ta, ws = wb[u] + g.sg * tb;
+          msk |= ((unsigned)hs < (unsigned)g.Hs && (unsigned)ws < (unsigned)g.Ws ? 1u : 0u) << t;
+        }
+      }
+      tapmask[u] = live ? msk : 0u;
     }
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -165,33 +210,42 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
         for (int r = 0; r < 16; ++r) acc[it][jt][r] = 0.f;
 
     f32x4v ra[NA], rb[NB];
-    unsigned okm = 0;                                           // predicates of the pieces in flight: bit u (A), bit 16 + u (B)
     auto load_chunk = [&](int ch) {
-      okm = 0;
       const int k0 = ch * kCfBK;
-      // A: one tap / channel position per 16-byte piece (a chunk lies inside one tap whenever Cs >= 32; the stem has Cs = 4)
+      if (!TAPV) {
+        // the whole chunk lies in one tap: wave-uniform (scalar) decode
+        const int tap = k0 >> g.lgCs, c0 = k0 & (g.Cs - 1);
+        const int ta = fdiv(tap, g.dnb), tb = tap - ta * g.nb;
+        const int coff = ((((g.sg * ta) * g.Ws + g.sg * tb) << g.lgCs) + c0) * 4;
+        const unsigned tapbit = 1u << tap;
+        const int tw = (g.r0 + g.rstep * ta) * g.S + g.s0 + g.sstep * tb;
+        const unsigned wsc = (unsigned)(B_KC ? tw * g.Cin + c0 : c0 * rsc + tw * g.Cin) * 4u;
+#pragma unroll
+        for (int u = 0; u < NA; ++u) ra[u] = bload4(rs_src, (tapmask[u] & tapbit) ? (unsigned)(rowoff[u] + coff) : kOob);
+#pragma unroll
+        for (int u = 0; u < NB; ++u) rb[u] = bload4(rs_wgt, wB[u] + wsc);          // (a poisoned base stays out of range: wsc < 2^30)
+        return;
+      }
+      // one tap / channel position per 16-byte piece (the stem: 4 source channels, 8 taps per chunk)
       const int kA = k0 + 4 * kqA;
       const int tapA = kA >> g.lgCs, cA = kA & (g.Cs - 1);
       const int ta = fdiv(tapA, g.dnb), tb = tapA - ta * g.nb;
       const int dh = g.sg * ta, dw = g.sg * tb;
-      const bool tap_ok = tapA < g.na * g.nb;
+      const bool tap_ok = tapA < ntaps;
 #pragma unroll
       for (int u = 0; u < NA; ++u) {
         const int hs = hb[u] + dh, ws = wb[u] + dw;
         const bool ok = tap_ok && pixn[u] >= 0 && (unsigned)hs < (unsigned)g.Hs && (unsigned)ws < (unsigned)g.Ws;
-        ra[u] = ldg4(src, (int64_t)(pixn[u] + hs * g.Ws + ws) * g.Cs + cA, ok, okm, u);
+        ra[u] = bload4(rs_src, ok ? (unsigned)(((pixn[u] + hs * g.Ws + ws) << g.lgCs) + cA) * 4u : kOob);
       }
       if (B_KC) {
-        // B tile [BN rows = output channel co][32 k]: W[co][tap][ci], k contiguous
         const int tw = (g.r0 + g.rstep * ta) * g.S + g.s0 + g.sstep * tb;
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-          const int co = n0 + (tid >> 3) + 32 * u;
-          rb[u] = ldg4(wgt, ((int64_t)co * g.RS + tw) * g.Cin + cA, tap_ok && co < g.Cd, okm, 16 + u);
+          const int co = n0 + rowA + kCfRP * u;
+          rb[u] = bload4(rs_wgt, (tap_ok && co < g.Cd) ? (unsigned)((co * g.RS + tw) * g.Cin + cA) * 4u : kOob);
         }
       } else {
-        // B tile [32 k rows = channel co of the gradient][BN columns = ci]: W[co][tap][ci], ci contiguous
-        constexpr int PR = BN / 4;                              // 16-byte pieces per k row
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
           const int v_ = tid + kCfThreads * u;
@@ -201,21 +255,16 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
           const int ta2 = fdiv(tapB, g.dnb), tb2 = tapB - ta2 * g.nb;
           const int tw2 = (g.r0 + g.rstep * ta2) * g.S + g.s0 + g.sstep * tb2;
           const int ci = n0 + 4 * jq;
-          rb[u] = ldg4(wgt, ((int64_t)cB * g.RS + tw2) * g.Cin + ci, tapB < g.na * g.nb && ci < g.Cd, okm, 16 + u);
+          rb[u] = bload4(rs_wgt, (tapB < ntaps && ci < g.Cd) ? (unsigned)((cB * g.RS + tw2) * g.Cin + ci) * 4u : kOob);
         }
       }
     };
     auto store_chunk = [&](int buf) {
-      float* sA = sAb(buf); float* sB = sBb(buf);
+      char* base = (char*)smem + buf * (SA + SB) * 4;
 #pragma unroll
-      for (int u = 0; u < NA; ++u) *(f32x4v*)(sA + ((tid >> 3) + 32 * u) * kCfLdk + 4 * kqA) = keep4(ra[u], okm, u);
-      if (B_KC) {
+      for (int u = 0; u < NA; ++u) *(f32x4v*)(base + ldsA + u * kCfRP * kCfLdk * 4) = ra[u];
 #pragma unroll
-        for (int u = 0; u < NB; ++u) *(f32x4v*)(sB + ((tid >> 3) + 32 * u) * kCfLdk + 4 * kqA) = keep4(rb[u], okm, 16 + u);
-      } else {
-#pragma unroll
-        for (int u = 0; u < NB; ++u) *(f32x4v*)(sB + (tid + kCfThreads * u) * 4) = keep4(rb[u], okm, 16 + u);      // [kr][jq] is linear in v
-      }
+      for (int u = 0; u < NB; ++u) *(f32x4v*)(base + ldsB + u * (B_KC ? kCfRP * kCfLdk * 4 : kCfThreads * 16)) = rb[u];
     };
 
     if (nchunks > 0) {
@@ -225,32 +274,37 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
       __syncthreads();
       for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
+        const float* sA = smem + buf * (SA + SB);
         if (ch + 1 < nchunks) load_chunk(ch + 1);               // global -> registers, under this chunk's MFMAs
-        mma_chunk<true, B_KC, 0, BN, TM, TN>(sAb(buf), sBb(buf), wm0, wn0, lane, acc);
+        mma_chunk<true, B_KC, 0, BN, TM, TN>(sA, sA + SA, wm0, wn0, lane, acc);
         if (ch + 1 < nchunks) store_chunk(buf ^ 1);             // (its last readers passed the barrier one chunk ago)
         __syncthreads();
       }
     }
 
-    // epilogue: rows on the registers, 32 consecutive channels on the lanes
+    // epilogue: rows on the registers, 32 consecutive channels on the lanes; out-of-range rows / channels carry the kOob bit and
+    // are dropped by the buffer's range check
     const int l31 = lane & 31, h = lane >> 5;
+    unsigned coff[TN];
+#pragma unroll
+    for (int jt = 0; jt < TN; ++jt) { const int c = n0 + wn0 + jt * 32 + l31; coff[jt] = c < g.Cd ? (unsigned)c * 4u : kOob; }
 #pragma unroll
     for (int it = 0; it < TM; ++it) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm0 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < g.Mg) {
-          int64_t pix = m;
-          if (!dense_dst) {
-            const int t2 = fdiv(m, g.dWm); const int mw = m - t2 * g.Wm; const int n = fdiv(t2, g.dHm); const int mh = t2 - n * g.Hm;
-            pix = ((int64_t)n * g.Hd + mh * g.dst_st + g.dph) * g.Wd + mw * g.dst_st + g.dpw;
-          }
-#pragma unroll
-          for (int jt = 0; jt < TN; ++jt) {
-            const int c = n0 + wn0 + jt * 32 + l31;
-            if (c < g.Cd) dst[pix * g.Cd + c] = acc[it][jt][r];
-          }
+        unsigned poff;
+        if (dense_dst) {
+          poff = m < g.Mg ? (unsigned)(m * g.Cd) * 4u : kOob;
+        } else {
+          const int mm = m < g.Mg ? m : 0;
+          const int t2 = fdiv(mm, g.dWm); const int mw = mm - t2 * g.Wm; const int n = fdiv(t2, g.dHm); const int mh = t2 - n * g.Hm;
+          const int pix = (n * g.Hd + mh * g.dst_st + g.dph) * g.Wd + mw * g.dst_st + g.dpw;
+          poff = m < g.Mg ? (unsigned)(pix * g.Cd) * 4u : kOob;
         }
+        // valid offsets are < 2^31 and coff < 2^14: the sum of two valid parts cannot reach the kOob bit, and a poisoned part keeps it
+#pragma unroll
+        for (int jt = 0; jt < TN; ++jt) bstore1(acc[it][jt][r], rs_dst, (poff + coff[jt]) | ((poff | coff[jt]) & kOob));
       }
     }
     if (STATS) {
@@ -288,47 +342,63 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// weight gradient: A[co][k = pixel] = dY (k slow), B[k = pixel][(tap, ci)] = X gathered (k slow); split over K, float atomics
+// weight gradient: A[co][k = pixel] = dY (k slow), B[k = pixel][(tap, ci)] = X gathered (k slow); split over K, float atomics.
+// The tile is 64 (co) x 256 (tap, ci): a 256-wide B row is ONE wave-instruction (64 lanes x 16 bytes), so the pixel a piece
+// belongs to is wave-uniform and its decode runs on the scalar ALU; per lane only the (static) tap of its four columns matters.
 struct WgGeo {
   int Mpix;                                // N * Ho * Wo
   int Ho, Wo, H, W, Cin, lgCin, Cout;
   int S, RS, stride, pad;
   int Ng;                                  // RS * Cin
   int chunks_per_split;
+  uint32_t dy_bytes, x_bytes;
   FastDiv dWo, dHo, dS;
 };
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int WBK, bool DENSE>
 __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                        float* __restrict__ dw, WgGeo g) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   static_assert(WM * WN == 4, "four waves per workgroup");
-  constexpr int NA = BM / 32, NB = BN / 32;                   // 16-byte pieces per thread (32 k rows x BM/4 or BN/4 pieces)
-  constexpr int SA = kCfBK * BM, SB = kCfBK * BN;
+  static_assert(DENSE || BN == 256, "a gathered B row must be one wave-instruction (256 columns) for the scalar pixel decode");
+  constexpr int PA = BM / 4, PB = BN / 4;                     // 16-byte pieces per k row
+  constexpr int NA = WBK * PA / kCfThreads, NB = WBK * PB / kCfThreads;
+  static_assert(NA >= 1 && NB >= 1, "tile too small for 256 threads");
+  constexpr int SA = WBK * BM, SB = WBK * BN;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  auto sAb = [&](int b) -> float* { return smem + b * (SA + SB); };
-  auto sBb = [&](int b) -> float* { return smem + b * (SA + SB) + SA; };
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave / WN) * 32 * TM, wn0 = (wave % WN) * 32 * TN;
   const int ntn = (g.Ng + BN - 1) / BN;
   const int tm = blockIdx.x / ntn, tn = blockIdx.x - tm * ntn;
   const int co0 = tm * BM, j0 = tn * BN;
-  const int nchunks_all = (g.Mpix + kCfBK - 1) / kCfBK;
+  const int nchunks_all = (g.Mpix + WBK - 1) / WBK;
   const int ch_lo = blockIdx.y * g.chunks_per_split;
   const int ch_hi = min(nchunks_all, ch_lo + g.chunks_per_split);
+  const rsrc_t rs_dy = make_rsrc(dy, g.dy_bytes), rs_x = make_rsrc(x, g.x_bytes);
 
-  // this thread's pieces: A: v = tid + 256 u -> (k row, co piece); B: (k row, j piece)
-  constexpr int PA = BM / 4, PB = BN / 4;
-  int krA[NA], cqA[NA], krB[NB], ciB[NB], drB[NB], dsB[NB]; bool okB[NB];
+  // A pieces: v = tid + 256 u -> k row v / PA, co piece v % PA: byte offset inside dY of chunk 0, + mbase * Cout * 4 per chunk;
+  // rows past Mpix fall out of the buffer's range
+  unsigned aoff[NA];
 #pragma unroll
-  for (int u = 0; u < NA; ++u) { const int v = tid + kCfThreads * u; krA[u] = v / PA; cqA[u] = v - krA[u] * PA; }
+  for (int u = 0; u < NA; ++u) {
+    const int v = tid + kCfThreads * u; const int kr = v / PA, cq = v - kr * PA; const int co = co0 + 4 * cq;
+    aoff[u] = co < g.Cout ? (unsigned)(kr * g.Cout + co) * 4u : kOob;
+  }
+  // B pieces.  DENSE (1x1 / stride 1: the source pixel of m is m): like A, on x.  Otherwise k row = wave + 4 u (wave-uniform),
+  // columns j0 + 4 lane .. + 3 (inside one tap: Cin % 4 == 0), whose tap is a per-lane constant.
+  unsigned boff[NB];
 #pragma unroll
   for (int u = 0; u < NB; ++u) {
-    const int v = tid + kCfThreads * u; krB[u] = v / PB; const int jq = v - krB[u] * PB;
-    const int j = j0 + 4 * jq;
-    const int tap = j >> g.lgCin; ciB[u] = j & (g.Cin - 1);
-    const int r = fdiv(tap, g.dS); drB[u] = r - g.pad; dsB[u] = tap - r * g.S - g.pad; okB[u] = j < g.Ng;
+    const int v = tid + kCfThreads * u; const int kr = v / PB, jq = v - kr * PB; const int jj = j0 + 4 * jq;
+    boff[u] = jj < g.Ng ? (unsigned)(kr * g.Cin + jj) * 4u : kOob;
   }
+  const int j = j0 + 4 * lane;
+  const int tapL = j >> g.lgCin, ciL = j & (g.Cin - 1);
+  const int rL = fdiv(tapL, g.dS);
+  const int drL = rL - g.pad, dsL = tapL - rL * g.S - g.pad;
+  const bool okL = j < g.Ng;
+  const int laneoff = ((drL * g.W + dsL) * g.Cin + ciL) * 4;   // this lane's tap / channel relative to the pixel's (0, 0) tap, bytes
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int it = 0; it < TM; ++it)
@@ -336,38 +406,37 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const flo
     for (int jt = 0; jt < TN; ++jt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[it][jt][r] = 0.f;
-  const bool dense = g.RS == 1 && g.stride == 1 && g.pad == 0;   // 1x1 stride 1: the source pixel of m is m
 
   f32x4v ra[NA], rb[NB];
-  unsigned okm = 0;
   auto load_chunk = [&](int ch) {
-    okm = 0;
-    const int mbase = ch * kCfBK;
+    const int mbase = ch * WBK;
+    const unsigned abase = (unsigned)(mbase * g.Cout) * 4u;
 #pragma unroll
-    for (int u = 0; u < NA; ++u) {
-      const int m = mbase + krA[u]; const int co = co0 + 4 * cqA[u];
-      ra[u] = ldg4(dy, (int64_t)m * g.Cout + co, m < g.Mpix && co < g.Cout, okm, u);
-    }
+    for (int u = 0; u < NA; ++u) ra[u] = bload4(rs_dy, aoff[u] + abase);
+    if (DENSE) {
+      const unsigned bbase = (unsigned)(mbase * g.Cin) * 4u;
 #pragma unroll
-    for (int u = 0; u < NB; ++u) {
-      const int m = mbase + krB[u];
-      bool ok = m < g.Mpix && okB[u];
-      int64_t pix = m;
-      if (!dense) {
-        const int mm = ok ? m : 0;
+      for (int u = 0; u < NB; ++u) rb[u] = bload4(rs_x, boff[u] + bbase);
+    } else {
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int m = mbase + wave + 4 * u;                     // scalar
+        const bool live = m < g.Mpix;
+        const int mm = live ? m : 0;
         const int t2 = fdiv(mm, g.dWo); const int wo = mm - t2 * g.Wo; const int n = fdiv(t2, g.dHo); const int ho = t2 - n * g.Ho;
-        const int hs = ho * g.stride + drB[u], ws = wo * g.stride + dsB[u];
-        ok = ok && (unsigned)hs < (unsigned)g.H && (unsigned)ws < (unsigned)g.W;
-        pix = (int64_t)(n * g.H + hs) * g.W + ws;
+        const int h0 = ho * g.stride, w0 = wo * g.stride;       // all scalar up to here
+        const int pixoff = ((n * g.H + h0) * g.W + w0) * g.Cin * 4;
+        const bool ok = live && okL && (unsigned)(h0 + drL) < (unsigned)g.H && (unsigned)(w0 + dsL) < (unsigned)g.W;
+        rb[u] = bload4(rs_x, ok ? (unsigned)(pixoff + laneoff) : kOob);
       }
-      rb[u] = ldg4(x, pix * g.Cin + ciB[u], ok, okm, 16 + u);
     }
   };
   auto store_chunk = [&](int buf) {
+    char* base = (char*)smem + buf * (SA + SB) * 4;
 #pragma unroll
-    for (int u = 0; u < NA; ++u) *(f32x4v*)(sAb(buf) + (tid + kCfThreads * u) * 4) = keep4(ra[u], okm, u);
+    for (int u = 0; u < NA; ++u) *(f32x4v*)(base + (tid + kCfThreads * u) * 16) = ra[u];
 #pragma unroll
-    for (int u = 0; u < NB; ++u) *(f32x4v*)(sBb(buf) + (tid + kCfThreads * u) * 4) = keep4(rb[u], okm, 16 + u);
+    for (int u = 0; u < NB; ++u) *(f32x4v*)(base + SA * 4 + (tid + kCfThreads * u) * 16) = rb[u];
   };
   if (ch_lo < ch_hi) {
     load_chunk(ch_lo);
@@ -375,8 +444,9 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const flo
     __syncthreads();
     for (int ch = ch_lo; ch < ch_hi; ++ch) {
       const int buf = (ch - ch_lo) & 1;
+      const float* sA = smem + buf * (SA + SB);
       if (ch + 1 < ch_hi) load_chunk(ch + 1);
-      mma_chunk<false, false, BM, BN, TM, TN>(sAb(buf), sBb(buf), wm0, wn0, lane, acc);
+      mma_chunk<false, false, BM, BN, TM, TN, WBK>(sA, sA + SA, wm0, wn0, lane, acc);
       if (ch + 1 < ch_hi) store_chunk(buf ^ 1);
       __syncthreads();
     }
@@ -389,8 +459,8 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const flo
         if (co < g.Cout) {
 #pragma unroll
           for (int jt = 0; jt < TN; ++jt) {
-            const int j = j0 + wn0 + jt * 32 + l31;
-            if (j < g.Ng) atomicAdd(dw + (int64_t)co * g.Ng + j, acc[it][jt][r]);
+            const int jj = j0 + wn0 + jt * 32 + l31;
+            if (jj < g.Ng) atomicAdd(dw + (int64_t)co * g.Ng + jj, acc[it][jt][r]);
           }
         }
       }
@@ -411,9 +481,17 @@ static int launch_act(const float* src, const float* wgt, float* dst, const ActG
   if (STATS) { const int cap = kCfMaxPart; if (gx > cap) gx = cap; }
   else { const int cap = 2048 / (ntiles > 8 ? 8 : ntiles); if (gx > cap) gx = cap; }
   if (gx < 1) gx = 1;
-  const size_t lds = (size_t)2 * (BM * kCfLdk + (B_KC ? BN * kCfLdk : kCfBK * BN)) * 4;      // 74 / 55 KB: two workgroups per CU
-  if (narrow) hipLaunchKernelGGL((conv_f32_act_kernel<B_KC, 2, 2, 2, 1, STATS>), dim3(gx, ntiles), dim3(kCfThreads), lds, st, src, wgt, dst, g, part);
-  else hipLaunchKernelGGL((conv_f32_act_kernel<B_KC, 2, 2, 2, 2, STATS>), dim3(gx, ntiles), dim3(kCfThreads), lds, st, src, wgt, dst, g, part);
+  size_t lds = (size_t)2 * (BM * kCfLdk + (B_KC ? BN * kCfLdk : kCfBK * BN)) * 4;      // 74 / 55 KB: two workgroups per CU
+  if (const char* e = getenv("LEC_CF_LDS_PAD")) lds += (size_t)atoi(e);                // experiments: force one workgroup per CU
+  const bool tapv = g.Cs % kCfBK != 0;                          // source channels narrower than a chunk (the stem)
+  LEC_CHECK_ARG(tapv || g.na * g.nb <= 32, "conv_f32: more than 32 taps per launch need the per-piece tap path");
+  if (tapv) {
+    if (narrow) hipLaunchKernelGGL((conv_f32_act_kernel<B_KC, 2, 2, 2, 1, STATS, true>), dim3(gx, ntiles), dim3(kCfThreads), lds, st, src, wgt, dst, g, part);
+    else hipLaunchKernelGGL((conv_f32_act_kernel<B_KC, 2, 2, 2, 2, STATS, true>), dim3(gx, ntiles), dim3(kCfThreads), lds, st, src, wgt, dst, g, part);
+  } else {
+    if (narrow) hipLaunchKernelGGL((conv_f32_act_kernel<B_KC, 2, 2, 2, 1, STATS, false>), dim3(gx, ntiles), dim3(kCfThreads), lds, st, src, wgt, dst, g, part);
+    else hipLaunchKernelGGL((conv_f32_act_kernel<B_KC, 2, 2, 2, 2, STATS, false>), dim3(gx, ntiles), dim3(kCfThreads), lds, st, src, wgt, dst, g, part);
+  }
   if (nparts) *nparts = gx;
   LEC_CHECK_LAUNCH("conv_f32_act_kernel");
   return LEC_OK;
@@ -424,8 +502,11 @@ static int conv_check(const char* who, int N, int H, int W, int Cin, int Cout, i
                 "%s: bad geometry N=%d H=%d W=%d Cin=%d Cout=%d R=%d S=%d stride=%d pad=%d", who, N, H, W, Cin, Cout, R, S, stride, pad);
   LEC_CHECK_ARG(Cin % 4 == 0 && ilog2_exact(Cin) >= 2, "%s: Cin must be a power of two >= 4 (pad the stem's 3 channels to 4), got %d", who, Cin);
   LEC_CHECK_ARG(Cout % 4 == 0 && ilog2_exact(Cout) >= 2, "%s: Cout must be a power of two >= 4, got %d", who, Cout);
-  LEC_CHECK_ARG((H + 2 * pad - R) / stride + 1 > 0 && (W + 2 * pad - S) / stride + 1 > 0, "%s: empty output", who);
-  LEC_CHECK_ARG((int64_t)N * H * W < (1ll << 31) / 4, "%s: too many pixels for 32-bit pixel indices", who);
+  const int64_t Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+  LEC_CHECK_ARG(Ho > 0 && Wo > 0, "%s: empty output", who);
+  // 32-bit byte offsets with the top bit reserved for "out of range"
+  LEC_CHECK_ARG((int64_t)N * H * W * Cin * 4 < (1ll << 31) && (int64_t)N * Ho * Wo * Cout * 4 < (1ll << 31) && (int64_t)Cout * R * S * Cin * 4 < (1ll << 30),
+                "%s: a tensor of this layer reaches 2 GiB (N=%d H=%d W=%d Cin=%d Cout=%d): split the batch", who, N, H, W, Cin, Cout);
   return LEC_OK;
 }
 
@@ -441,6 +522,8 @@ extern "C" int lec_conv_f32_fwd(const float* x, const float* w, int N, int H, in
   g.Mg = N * Ho * Wo; g.Hm = Ho; g.Wm = Wo; g.Hs = H; g.Ws = W; g.Cs = Cin; g.lgCs = ilog2_exact(Cin); g.sst = stride;
   g.oh0 = -pad; g.ow0 = -pad; g.sg = 1; g.na = R; g.nb = S; g.r0 = 0; g.rstep = 1; g.s0 = 0; g.sstep = 1; g.S = S; g.RS = R * S;
   g.Cd = Cout; g.Cin = Cin; g.Hd = Ho; g.Wd = Wo; g.dst_st = 1; g.dph = 0; g.dpw = 0; g.Kg = R * S * Cin;
+  g.src_bytes = (uint32_t)((int64_t)N * H * W * Cin * 4); g.wgt_bytes = (uint32_t)((int64_t)Cout * R * S * Cin * 4);
+  g.dst_bytes = (uint32_t)((int64_t)g.Mg * Cout * 4);
   g.dWm = make_fastdiv(g.Wm); g.dHm = make_fastdiv(g.Hm); g.dnb = make_fastdiv(g.nb);
   if (partials) {
     LEC_CHECK_ARG(n_partials && partials_bytes >= (int64_t)kCfMaxPart * 2 * Cout * (int64_t)sizeof(float), "conv_f32_fwd: partials buffer too small");
@@ -466,6 +549,8 @@ extern "C" int lec_conv_f32_dgrad(const float* dy, const float* w, int N, int H,
       g.oh0 = (ph + pad - g.r0) / stride; g.ow0 = (pw + pad - g.s0) / stride; g.sg = -1;
       g.S = S; g.RS = R * S; g.Cd = Cin; g.Cin = Cin; g.Hd = H; g.Wd = W; g.dst_st = stride; g.dph = ph; g.dpw = pw;
       g.Kg = g.na * g.nb * Cout;
+      g.src_bytes = (uint32_t)((int64_t)N * Ho * Wo * Cout * 4); g.wgt_bytes = (uint32_t)((int64_t)Cout * R * S * Cin * 4);
+      g.dst_bytes = (uint32_t)((int64_t)N * H * W * Cin * 4);
       g.dWm = make_fastdiv(g.Wm); g.dHm = make_fastdiv(g.Hm); g.dnb = make_fastdiv(g.nb);   // (Kg = 0: the loop is empty, zeros are stored)
       if (int rc = launch_act<false, false>(dy, w, dx, g, nullptr, nullptr, (hipStream_t)stream)) return rc;
     }
@@ -482,19 +567,32 @@ extern "C" int lec_conv_f32_wgrad(const float* dy, const float* x, int N, int H,
   g.Ho = (H + 2 * pad - R) / stride + 1; g.Wo = (W + 2 * pad - S) / stride + 1; g.Mpix = N * g.Ho * g.Wo;
   g.H = H; g.W = W; g.Cin = Cin; g.lgCin = ilog2_exact(Cin); g.Cout = Cout; g.S = S; g.RS = R * S; g.stride = stride; g.pad = pad;
   g.Ng = R * S * Cin;
+  g.dy_bytes = (uint32_t)((int64_t)g.Mpix * Cout * 4); g.x_bytes = (uint32_t)((int64_t)N * H * W * Cin * 4);
   g.dWo = make_fastdiv(g.Wo); g.dHo = make_fastdiv(g.Ho); g.dS = make_fastdiv(S);
-  const bool narrow = Cout <= 64;
-  const int BM = narrow ? 64 : 128, BN = 128;
+  const bool dense = R == 1 && S == 1 && stride == 1 && pad == 0;
+  // tile (BM over Cout) x (BN over R*S*Cin), chunk width WBK: gathered layers 64 x 256; dense 1x1 layers whatever fits their shape
+  int BM = 64, BN = 256, WBK = kWgBK;
+  if (dense) {
+    if (g.Ng >= 256) { BM = 64; BN = 256; }
+    else if (g.Ng >= 128) { BM = 128; BN = 128; }
+    else if (Cout >= 256) { BM = 256; BN = 64; }
+    else { BM = 64; BN = 64; WBK = 32; }
+  }
   const int tiles = ((Cout + BM - 1) / BM) * ((g.Ng + BN - 1) / BN);
-  const int nchunks = (g.Mpix + kCfBK - 1) / kCfBK;
+  const int nchunks = (g.Mpix + WBK - 1) / WBK;
   int split = (1024 + tiles - 1) / tiles;                      // ~4 workgroups per CU in total
   if (split > nchunks) split = nchunks;
   if (split < 1) split = 1;
   g.chunks_per_split = (nchunks + split - 1) / split;
   split = (nchunks + g.chunks_per_split - 1) / g.chunks_per_split;
-  const size_t lds = (size_t)2 * kCfBK * (BM + BN) * 4;
-  if (narrow) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 1, 2>), dim3(tiles, split), dim3(kCfThreads), lds, (hipStream_t)stream, dy, x, dw, g);
-  else hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 2>), dim3(tiles, split), dim3(kCfThreads), lds, (hipStream_t)stream, dy, x, dw, g);
+  const size_t lds = (size_t)2 * WBK * (BM + BN) * 4;
+  const dim3 grid(tiles, split), blk(kCfThreads);
+  hipStream_t st = (hipStream_t)stream;
+  if (!dense) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, false>), grid, blk, lds, st, dy, x, dw, g);
+  else if (BM == 64 && BN == 256) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, true>), grid, blk, lds, st, dy, x, dw, g);
+  else if (BM == 128) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 2, kWgBK, true>), grid, blk, lds, st, dy, x, dw, g);
+  else if (BM == 256) hipLaunchKernelGGL((conv_f32_wgrad_kernel<4, 1, 2, 2, kWgBK, true>), grid, blk, lds, st, dy, x, dw, g);
+  else hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 1, 1, 32, true>), grid, blk, lds, st, dy, x, dw, g);
   LEC_CHECK_LAUNCH("conv_f32_wgrad_kernel");
   return LEC_OK;
 }

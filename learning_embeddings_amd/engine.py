@@ -154,6 +154,7 @@ class StepEngine:
         mk = lambda: torch.cuda.Event(enable_timing=True)
         self.timers = {'records': [], 'mk': mk}
         ops.BN_TIMER = []
+        ops.CONV_TIMER = []
 
     def step(self):
         B, K = self.B, self.K
@@ -237,10 +238,12 @@ class StepEngine:
         solvers).  Under capture the gradient reducer's per-parameter hooks are muted: the all-reduce runs after the
         replay.  On any capture error the engine stays in eager launch mode and says so."""
         saved_timer = ops.BN_TIMER
+        saved_ctimer = ops.CONV_TIMER
         try:
             torch.cuda.synchronize()
             self.reducer.live = False
             ops.BN_TIMER = None
+            ops.CONV_TIMER = None
             g = torch.cuda.CUDAGraph()
             # thread_local: RCCL's watchdog thread polls events while we capture; only THIS thread's calls may fail the capture
             with torch.cuda.graph(g, capture_error_mode='thread_local'):
@@ -256,6 +259,7 @@ class StepEngine:
             torch.cuda.synchronize()
         finally:
             ops.BN_TIMER = saved_timer
+            ops.CONV_TIMER = saved_ctimer
 
     def set_launch_mode(self, graph):
         """Switch between replaying the captured graph and eager launches (bench.py times per-kernel phases with HIP
@@ -282,6 +286,10 @@ class StepEngine:
             res['fused_bn'] = sum(a.elapsed_time(b) for a, b, _ in ops.BN_TIMER) / max(len(recs), 1)
             self.bn_bytes_per_step = sum(n for _, _, n in ops.BN_TIMER) / max(len(recs), 1)
             self.bn_launch_groups_per_step = len(ops.BN_TIMER) / max(len(recs), 1)
+        if ops.CONV_TIMER:
+            res['conv_f32'] = sum(a.elapsed_time(b) for a, b, _ in ops.CONV_TIMER) / max(len(recs), 1)
+            self.conv_flops_per_step = sum(n for _, _, n in ops.CONV_TIMER) / max(len(recs), 1)
+            self.conv_launches_per_step = len(ops.CONV_TIMER) / max(len(recs), 1)
         return res
 
     def close(self):

@@ -650,12 +650,39 @@ class JointEmbeddings:
         torch.save({'epoch': self.epoch, 'model_state_dict': self._state(self.model), 'optimizer_state_dict': opt,
                     'loss': loss, 'optimal_threshold': self.optimal_threshold, 'reconstruction_scores': rec},
                    os.path.join(self.path_to_save_model, '{}_model.pth'.format(tag)))
-        torch.save({'epoch': self.epoch, 'model_state_dict': self.img_feat_net.state_dict(), 'optimizer_state_dict': {},
+        torch.save({'epoch': self.epoch, 'model_state_dict': self._img_state(), 'optimizer_state_dict': self._optimizer_images_state_dict(),
                     'loss': loss, 'optimal_threshold': self.optimal_threshold, 'reconstruction_scores': rec},
                    os.path.join(self.path_to_save_model, '{}_img_feat_net.pth'.format(tag)))
 
+    def _img_state(self):
+        """The image network's state dict with the reference's key names: FeatCNN18 keeps its ResNet inside nn.DataParallel
+        (oe_h.py:301: `model.module.conv1.weight`, ...), and the feature-input FeatNet is itself wrapped (oe_h.py:1439:
+        `module.fc1.weight`)."""
+        sd = self.img_feat_net.state_dict()
+        if self.use_CNN:
+            return {('model.module.' + k[len('model.'):] if k.startswith('model.') else k): v for k, v in sd.items()}
+        return {'module.' + k: v for k, v in sd.items()}
+
+    def _optimizer_images_state_dict(self):
+        """torch.optim.Adam state-dict layout of the reference's `optimizer_images` (oe_h.py:1521: Adam over the image network's
+        parameters at lr_images; it is stepped only under use_rsgd, so its state is empty otherwise).  The reference's load_model
+        calls optimizer_images.load_state_dict on this entry (oe_h.py:1956): it must be a valid Adam state dict."""
+        n = len(self.arena.params)
+        state = self.arena.export_adam_state(first_index=0) if (self.use_rsgd and self.arena.exp_avg is not None) else {}
+        group = {'lr': self.lr_images, 'betas': (0.9, 0.999), 'eps': 1e-8, 'weight_decay': 0, 'amsgrad': False,
+                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                 'params': list(range(n))}
+        return {'state': state, 'param_groups': [group]}
+
+    @staticmethod
+    def _plain_key(k):
+        """Key without the nn.DataParallel segments the reference's wrappers insert (leading `module.` and inner `.module.`)."""
+        if k.startswith('module.'):
+            k = k[len('module.'):]
+        return k.replace('.module.', '.')
+
     def _load_sd(self, module, sd):
-        sd = {k[len('module.'):] if k.startswith('module.') else k: v for k, v in sd.items()}
+        sd = {self._plain_key(k): v for k, v in sd.items()}
         with torch.no_grad():
             own = module.state_dict()
             for k, v in sd.items():

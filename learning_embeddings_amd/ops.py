@@ -626,6 +626,18 @@ def conv_f32_supported(conv_or_cin, cout=None):
     return pw2(conv_or_cin) and pw2(cout)
 
 
+CONV_TIMER = None    # set to a list to record (start_event, end_event, flops) per lec_conv_f32_* launch (bench.py); events are recorded on
+                     # the stream the kernel is launched on (the weight gradients run on WgradOverlap's side stream)
+
+
+def _conv_timed(call, flops):
+    if CONV_TIMER is None:
+        return call()
+    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+    a.record(); call(); b.record()
+    CONV_TIMER.append((a, b, flops))
+
+
 def conv_f32_fwd(x, w, stride, pad, want_stats=False):
     """y = conv2d(x, w) in exact fp32 on the f32 MFMA (lec_conv_f32_fwd).  x [N, Cin, H, W], w [Cout, Cin, R, S], both
     channels_last fp32.  want_stats: the BatchNorm statistics partials of y are left in the BatchNorm workspace."""
@@ -633,12 +645,14 @@ def conv_f32_fwd(x, w, stride, pad, want_stats=False):
     n, cin, h, wd = x.shape; cout, _, r, s_ = w.shape
     ho, wo = (h + 2 * pad - r) // stride + 1, (wd + 2 * pad - s_) // stride + 1
     y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    flops = 2.0 * n * ho * wo * cout * cin * r * s_
     if want_stats:
         ws = _bn_workspace(x.device); k = C.c_int(0)
-        check(lib.lec_conv_f32_fwd(dptr(x), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), dptr(ws), ws.numel(), C.byref(k), stream_ptr()))
+        _conv_timed(lambda: check(lib.lec_conv_f32_fwd(dptr(x), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), dptr(ws), ws.numel(),
+                                                       C.byref(k), stream_ptr())), flops)
         _BN_WS_OWNER[0], _BN_WS_OWNER[1] = y.data_ptr(), k.value
     else:
-        check(lib.lec_conv_f32_fwd(dptr(x), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), None, 0, None, stream_ptr()))
+        _conv_timed(lambda: check(lib.lec_conv_f32_fwd(dptr(x), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), None, 0, None, stream_ptr())), flops)
     return y
 
 
@@ -647,7 +661,8 @@ def conv_f32_dgrad(dy, w, x_shape, stride, pad):
     _nhwc_f32(dy, 'dy'); _nhwc_f32(w, 'w')
     n, cin, h, wd = x_shape; cout, _, r, s_ = w.shape
     dx = torch.empty((n, cin, h, wd), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last)
-    check(lib.lec_conv_f32_dgrad(dptr(dy), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(dx), stream_ptr()))
+    _conv_timed(lambda: check(lib.lec_conv_f32_dgrad(dptr(dy), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(dx), stream_ptr())),
+                2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * cout * cin * r * s_)
     return dx
 
 
@@ -655,7 +670,8 @@ def conv_f32_wgrad(dy, x, dw, stride, pad):
     """dw += weight gradient (lec_conv_f32_wgrad, float atomics).  dw [Cout, Cin, R, S] channels_last fp32."""
     _nhwc_f32(dy, 'dy'); _nhwc_f32(x, 'x'); _nhwc_f32(dw, 'dw')
     n, cin, h, wd = x.shape; cout, _, r, s_ = dw.shape
-    check(lib.lec_conv_f32_wgrad(dptr(dy), dptr(x), n, h, wd, cin, cout, r, s_, stride, pad, dptr(dw), stream_ptr()))
+    _conv_timed(lambda: check(lib.lec_conv_f32_wgrad(dptr(dy), dptr(x), n, h, wd, cin, cout, r, s_, stride, pad, dptr(dw), stream_ptr())),
+                2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * cout * cin * r * s_)
     return dw
 
 

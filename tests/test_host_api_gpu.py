@@ -356,7 +356,11 @@ def test_checkpoint_interchange_with_torch_adam(tmp_path):
     sd = {k: v for k, v in tr.img_feat_net.state_dict().items()}
     names = [n for n, _ in tr.img_feat_net.named_parameters()]
     for n, p in zip(names, ref[1:]): sd[n] = p.detach()
-    torch.save({'epoch': 0, 'model_state_dict': sd, 'optimizer_state_dict': {}, 'loss': 0.0, 'optimal_threshold': 0.0,
+    # the reference's key names: its FeatCNN18 keeps the ResNet inside nn.DataParallel (oe_h.py:301) -> `model.module.*`
+    sd = {k.replace('model.', 'model.module.', 1): v for k, v in sd.items()}
+    assert 'model.module.conv1.weight' in sd
+    opt_img = torch.optim.Adam([p.detach().clone().requires_grad_(True) for p in tr.img_feat_net.parameters()], lr=1e-3)
+    torch.save({'epoch': 0, 'model_state_dict': sd, 'optimizer_state_dict': opt_img.state_dict(), 'loss': 0.0, 'optimal_threshold': 0.0,
                 'reconstruction_scores': {}}, os.path.join(tr.path_to_save_model, '7_img_feat_net.pth'))
     tr.load_model(7)
     assert tr.table_step == 2 and tr.arena.step == 2
@@ -377,6 +381,20 @@ def test_checkpoint_interchange_with_torch_adam(tmp_path):
     opt2 = torch.optim.Adam([{'params': [p.detach().clone().requires_grad_(True) for p in params]}], lr=1e-3)
     opt2.load_state_dict(ck['optimizer_state_dict'])
     assert int(opt2.state_dict()['state'][0]['step']) == 3
+    # the image network's file: the reference's key names, and an optimizer entry its load_model can hand to
+    # optimizer_images.load_state_dict (oe_h.py:1955-1956)
+    ck2 = torch.load(os.path.join(tr.path_to_save_model, 'out_img_feat_net.pth'))
+    assert all(k.startswith('model.module.') for k in ck2['model_state_dict'])
+    import torch.nn as nn
+    from learning_embeddings_amd.resnet import resnet18
+    class RefShape(nn.Module):                     # the reference's module nesting: FeatCNN18.model = nn.DataParallel(resnet18) with fc -> D
+        def __init__(self):
+            super().__init__()
+            m = resnet18(); m.fc = nn.Linear(512, 10); self.model = nn.DataParallel(m)
+    ref_net = RefShape()
+    ref_net.load_state_dict(ck2['model_state_dict'])                       # strict: every key present, none unexpected
+    opt3 = torch.optim.Adam(ref_net.parameters(), lr=1e-3)
+    opt3.load_state_dict(ck2['optimizer_state_dict'])
 
 
 def test_order_embeddings_images_legacy_trainer_step_vs_oracle():
@@ -393,17 +411,40 @@ def test_order_embeddings_images_legacy_trainer_step_vs_oracle():
     edges = [(u, v) for u, v in gd['G_train_tc'].edges() if type(v) == str][:8]
     frm = [torch.tensor([u for u, _ in edges])]; to = [[v for _, v in edges]]
     W0 = tr.model.embeddings.weight.detach().cpu().numpy().copy()
+    seen = {}
+    orig = tr.img_feat_net
+    def capturing(names):                                                     # FeatNet output of THIS step (order_embeddings_images.py:143-178)
+        out = orig(names); out.retain_grad(); seen['names'] = list(names); seen['out'] = out
+        return out
+    tr.img_feat_net = capturing
     loss, e_pos, e_neg = tr.train_step(frm, to)
     neg = crit.last_negatives
-    N = lm.n_classes
-    assert (neg[:, :3] >= N).all() and (neg[:, 3:] < N).all()                 # corrupt image / corrupt label
-    names = sorted(set(crit.mapping_from_node_to_ix[v] for _, v in edges) | set(neg[neg >= N].tolist()))
-    with torch.no_grad():
-        tr.feat_net.eval()
-    # oracle on the same points: image points = FeatNet output BEFORE the update is not recoverable after the step, so
-    # recompute the loss from the returned energies and check their internal consistency + the label-side energies
-    h = np.maximum(1.0 - e_neg.cpu().numpy(), 0).sum() + e_pos.cpu().numpy().sum()
-    assert abs(loss.item() - h) < 1e-3 * max(1.0, abs(h))
+    N, K, B = lm.n_classes, 3, len(edges)
+    assert (neg[:, :K] >= N).all() and (neg[:, K:] < N).all()                 # corrupt image / corrupt label
+    # the pinned oracle on the same points (order_embeddings.py:818-824 energy, order_embeddings_images.py:371-470 loss): label
+    # rows of the table BEFORE the update, image points = the captured FeatNet outputs, the same negatives
+    R = seen['out'].detach().cpu().numpy(); slot = {crit.mapping_from_node_to_ix[n]: j for j, n in enumerate(seen['names'])}
+    point = lambda ix: W0[ix] if ix < N else R[slot[ix]]
+    fa = [u for u, _ in edges]; ta = [crit.mapping_from_node_to_ix[v] for _, v in edges]
+    pf = [fa[b] for b in range(B)] + [fa[b] for b in range(B) for p in range(K)] + [int(neg[b, K + p]) for b in range(B) for p in range(K)]
+    pt = [ta[b] for b in range(B)] + [int(neg[b, p]) for b in range(B) for p in range(K)] + [ta[b] for b in range(B) for p in range(K)]
+    x = np.stack([point(i) for i in pf]).astype(np.float32); y = np.stack([point(i) for i in pt]).astype(np.float32)
+    E = O.order_energy(x, y)
+    o_pos = E[:B]; o_neg_v = E[B:B + B * K].reshape(B, K); o_neg_u = E[B + B * K:].reshape(B, K)
+    o_neg = np.concatenate([o_neg_v, o_neg_u], axis=1)
+    o_loss = float(o_pos.sum() + np.maximum(1.0 - o_neg, 0).sum())
+    assert np.abs(e_pos.cpu().numpy() - o_pos).max() <= 1e-4 * max(1.0, np.abs(o_pos).max())
+    assert np.abs(e_neg.cpu().numpy().reshape(B, 2 * K) - o_neg).max() <= 1e-4 * max(1.0, np.abs(o_neg).max())
+    assert abs(loss.item() - o_loss) <= 1e-4 * max(1.0, abs(o_loss))
+    gE = np.concatenate([np.ones(B), -((1.0 - o_neg_v) >= 0).reshape(-1).astype(np.float64), -((1.0 - o_neg_u) >= 0).reshape(-1).astype(np.float64)])
+    gx, gy = O.order_energy_grad(x, y, gE)
+    gW = np.zeros_like(W0, dtype=np.float64); gR = np.zeros_like(R, dtype=np.float64)
+    for ids, gg in ((pf, gx), (pt, gy)):
+        for i, row in zip(ids, gg):
+            if i < N: gW[i] += row
+            else: gR[slot[i]] += row
+    assert np.abs(tr.model.embeddings.weight.grad.cpu().numpy() - gW).max() <= 1e-4 * max(1.0, np.abs(gW).max())
+    assert np.abs(seen['out'].grad.cpu().numpy() - gR).max() <= 1e-4 * max(1.0, np.abs(gR).max())
     assert (tr.model.embeddings.weight.detach().cpu().numpy() != W0).any()      # the table moved
     l2, _, _ = tr.train_step(frm, to)
     assert torch.isfinite(l2)
