@@ -207,6 +207,109 @@ def measure(args, dtype, rank, world, stamp, primary):
     return res, eng
 
 
+def measure_classifier(args, dtype, rank, world, stamp):
+    """Config 4 (ResNet-50 + MultiLevelCELoss over the 723 ETHEC labels, B = 512 per GPU): engine.ClassifierEngine."""
+    import torch
+    import torch.distributed as dist
+    from learning_embeddings_amd.engine import ClassifierEngine
+    from learning_embeddings_amd.resnet import conv_macs
+    eng = ClassifierEngine(args.workload, dtype=dtype, batch=args.batch, use_graph=not args.no_graph, overlap_wgrad=not args.no_overlap_wgrad)
+    stamp('%s: classifier engine built' % dtype)
+    for _ in range(max(args.warmup, 4)):
+        eng.step()
+    while eng.use_graph and eng.hip_graph is None and eng.graph_error is None:
+        eng.step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=eng.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    if rank != 0:
+        return None
+    f32 = dtype == 'fp32'
+    macs = conv_macs(eng.exp.model, eng.hw)
+    flops = 3 * 2 * macs * eng.B
+    peak_tf = 157.3 if f32 else 2500.0
+    step_s = dt / args.steps
+    return {'value': round(world * eng.B * args.steps / dt, 2), 'ms_per_step': round(step_s * 1e3, 3), 'dtype': 'f32' if f32 else dtype,
+            'launch_mode': 'hipgraph' if eng.hip_graph is not None else 'eager', 'mean_loss': round(float(eng.loss_acc.item()) / max(eng.step_no, 1), 4),
+            'B': eng.B, 'arch': eng.arch, 'hw': eng.hw, 'n_classes': eng.labelmap.n_classes,
+            'hbm_peak_allocated_gb': round(torch.cuda.max_memory_allocated() / 1e9, 1),
+            'roofline': {'kernel': '%s fwd+bwd + MultiLevelCELoss + Adam (whole step; analytic conv/fc flops / step time)' % eng.arch, 'bound': 'mfma',
+                         'achieved': round(flops / step_s / 1e12, 3), 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': round(flops / step_s / 1e12 / peak_tf, 5), 'traffic': None}}
+
+
+def measure_trainer(args, dtype, stamp, n_steps, n_warm):
+    """The same cfg3 step driven through the reference's trainer API instead of the synthetic-input engine: JointEmbeddings
+    (oe_h.py:1318-1774 mirror) built from create_combined_graphs, its DataLoader / my_collate / criterion call / train_step,
+    on in-memory images that are resident in HBM.  Eager launches (the batch composition varies from step to step)."""
+    import tempfile
+    import numpy as np, torch
+    from learning_embeddings_amd import oe_h
+    from learning_embeddings_amd.engine import WORKLOADS, make_labelmap
+    from learning_embeddings_amd.oe_h_trainer import DiGraph
+    hier, arch, B, K, D, hw = WORKLOADS[args.workload]
+    B = args.batch or B
+    lm = make_labelmap(hier)
+    M, P = 4096, 2 * B
+    dev = torch.device('cuda', torch.cuda.current_device())
+    g = torch.Generator(device='cpu').manual_seed(1234)
+    pool = torch.rand(P, 3, hw, hw, generator=g).to(dev)
+    L = len(lm.levels)
+    par = lm.parents()
+    def chain(j):
+        v = lm.level_start[-1] + j % lm.levels[-1]; c = [v]
+        while c[-1] in par:
+            c.append(par[c[-1]][0])
+        c = c[::-1]
+        return [c[l] - lm.level_start[l] for l in range(L)]
+    def loader(lo, hi, bs=256):
+        out = []
+        for i in range(lo, hi, bs):
+            js = list(range(i, min(i + bs, hi)))
+            out.append({'level_labels': np.asarray([chain(j) for j in js]), 'image_filename': ['img_%06d' % j for j in js],
+                        'path_to_image': [pool[j % P] for j in js]})
+        return out
+    dl = {'train': loader(0, M), 'val': loader(M, M + 8), 'test': loader(M + 8, M + 16)}
+    gd = oe_h.create_combined_graphs(dl, lm, pick_per_level=True)
+    li = DiGraph()                                               # the (label, image) positives only: every batch entry brings an image
+    for u, v in gd['G_train_tc'].edges():
+        if type(v) == str:
+            li.add_edge(u, v)
+    gd = dict(gd, G_train_tc=li)
+    crit = oe_h.EuclideanConesWithImagesHypernymLoss(lm, K, {}, 0.01, pick_per_level=True, K=0.1, use_CNN=True)
+    tmp = tempfile.mkdtemp(prefix='lec_bench_')
+    tr = oe_h.JointEmbeddings(gd, dl, image_dir='', use_CNN=True, labelmap=lm, criterion=crit, lr=1e-4, n_workers=0, batch_size=B,
+                               experiment_name='bench', embedding_dim=D, neg_to_pos_ratio=K, image_fc7=None, normalize=None, alpha=0.01,
+                               experiment_dir=tmp, n_epochs=1, eval_interval=10, model_name=arch,
+                               compute_dtype=torch.float32 if dtype == 'fp32' else torch.bfloat16)
+    crit.set_dataloader(tr.datasets['train'])
+    tr.model.train(); tr.img_feat_net.train()
+    it = iter(tr.dataloaders['train'])
+    stamp('through-trainer %s: trainer built (%d positives in the dataset)' % (dtype, len(tr.train_set)))
+    rows = 0
+    for _ in range(n_warm):
+        tr.train_step(next(it))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        tr.train_step(next(it))
+        rows += len(np.unique(crit.last_negatives[crit.last_negatives >= lm.n_classes])) + B
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {'value': round(B * n_steps / dt, 2), 'unit': 'images/sec', 'ms_per_step': round(dt / n_steps * 1e3, 3), 'steps': n_steps, 'dtype': 'f32' if dtype == 'fp32' else dtype,
+            'cnn_rows_per_step': round(rows / n_steps, 1), 'launch_mode': 'eager',
+            'api': 'JointEmbeddings.train_step over its own DataLoader / my_collate / criterion(...) (oe_h.py:1734-1774 mirror), images resident in HBM'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -223,6 +326,7 @@ def main():
     ap.add_argument('--check-replicas', action='store_true', help='after the run, assert that every rank holds identical parameters')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying the captured hipGraph of forward+loss+backward')
     ap.add_argument('--cudnn-benchmark', action='store_true', help='let MIOpen benchmark every solver per conv shape (slow start)')
+    ap.add_argument('--through-trainer', type=int, default=6, help='also time N steps of the same workload driven through JointEmbeddings.train_step (0: skip)')
     args = ap.parse_args()
 
     # stdout carries ONE line, the JSON result.  Everything else this process or its libraries write to file descriptor 1
@@ -251,6 +355,27 @@ def main():
         raise SystemExit('bench.py --gpus %d but WORLD_SIZE=%d: launch N > 1 as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`'
                          % (args.gpus, world))
 
+    if args.workload in ('cfg4', 'tiny4'):
+        # config 4 of BASELINE.json: the classification head (a parity-test case of the same backbone; not the headline config)
+        res = measure_classifier(args, args.dtype, rank, world, stamp)
+        sec = measure_classifier(args, args.secondary, rank, world, stamp) if args.secondary not in ('none', args.dtype) else None
+        if dist.is_initialized():
+            dist.barrier(); dist.destroy_process_group()
+        os.dup2(saved_stdout_fd, 1); os.close(saved_stdout_fd)
+        if rank == 0:
+            out = {'metric': 'images/sec (CNN + multi-level cross-entropy step)', 'value': res['value'], 'unit': 'images/sec', 'n_gpus': world,
+                   'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': res['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak',
+                   'vs_baseline': None, 'dtype': res['dtype'], 'data': 'synthetic',
+                   'config': {'workload': '%s: ETHEC hierarchy (%d labels), %s, multi_level cross-entropy (loss.py:29-38), B=%d/GPU, %dx%d'
+                                          % (args.workload, res['n_classes'], res['arch'], res['B'], res['hw'], res['hw']),
+                              'global_batch': res['B'] * world, 'parallelism': 'dp%d' % world, 'launch_mode': res['launch_mode'],
+                              'mean_loss': res['mean_loss'], 'hbm_peak_allocated_gb': res['hbm_peak_allocated_gb']},
+                   'roofline': res['roofline']}
+            if sec is not None:
+                out['secondary_bf16'] = {'note': 'NARROWER than the reference (bf16 conv stack); not the headline', 'value': sec['value'],
+                                         'ms_per_step': sec['ms_per_step'], 'dtype': sec['dtype'], 'roofline': sec['roofline']}
+            print(json.dumps(out), flush=True)
+        return
     res, eng = measure(args, args.dtype, rank, world, stamp, primary=True)
     out = None
     if rank == 0:
@@ -301,6 +426,11 @@ def main():
     eng.close()
     del eng
     torch.cuda.empty_cache()
+    if args.through_trainer > 0 and world == 1 and args.workload in ('cfg2', 'cfg3'):
+        tt = measure_trainer(args, args.dtype, stamp, args.through_trainer, 3)
+        tt['vs_engine'] = round(tt['value'] / out['value'], 4)
+        out['through_trainer'] = tt
+        torch.cuda.empty_cache()
 
     if args.secondary != 'none' and args.secondary != args.dtype:
         torch.cuda.reset_peak_memory_stats()

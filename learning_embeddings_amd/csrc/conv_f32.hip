@@ -350,7 +350,7 @@ struct WgGeo {
   int Ho, Wo, H, W, Cin, lgCin, Cout;
   int S, RS, stride, pad;
   int Ng;                                  // RS * Cin
-  int chunks_per_split;
+  int chunks_per_split, tiles, split;
   uint32_t dy_bytes, x_bytes;
   FastDiv dWo, dHo, dS;
 };
@@ -370,12 +370,17 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const flo
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave / WN) * 32 * TM, wn0 = (wave % WN) * 32 * TN;
   const int ntn = (g.Ng + BN - 1) / BN;
-  const int tm = blockIdx.x / ntn, tn = blockIdx.x - tm * ntn;
-  const int co0 = tm * BM, j0 = tn * BN;
   const int nchunks_all = (g.Mpix + WBK - 1) / WBK;
-  const int ch_lo = blockIdx.y * g.chunks_per_split;
-  const int ch_hi = min(nchunks_all, ch_lo + g.chunks_per_split);
   const rsrc_t rs_dy = make_rsrc(dy, g.dy_bytes), rs_x = make_rsrc(x, g.x_bytes);
+  // work items = (output tile, K split); a workgroup walks its share when LEC_WGRAD_WGS caps the grid.  (Measured on the fp32 step:
+  // one workgroup per CU leaves the main stream's HBM-bound BatchNorm kernels room -- their time drops 63.8 -> 50.9 ms -- but the
+  // convolutions beside it stretch more than that: 164.7 ms per step against 157.0 uncapped, so the default is no cap.)
+  for (int wi = blockIdx.x; wi < g.tiles * g.split; wi += gridDim.x) {
+  const int tile = wi % g.tiles, sp = wi / g.tiles;
+  const int tm = tile / ntn, tn = tile - tm * ntn;
+  const int co0 = tm * BM, j0 = tn * BN;
+  const int ch_lo = sp * g.chunks_per_split;
+  const int ch_hi = min(nchunks_all, ch_lo + g.chunks_per_split);
 
   // A pieces: v = tid + 256 u -> k row v / PA, co piece v % PA: byte offset inside dY of chunk 0, + mbase * Cout * 4 per chunk;
   // rows past Mpix fall out of the buffer's range
@@ -440,6 +445,7 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const flo
   };
   if (ch_lo < ch_hi) {
     load_chunk(ch_lo);
+    __syncthreads();                                            // the previous work item's last reads of buffer 0 are done
     store_chunk(0);
     __syncthreads();
     for (int ch = ch_lo; ch < ch_hi; ++ch) {
@@ -465,6 +471,7 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const flo
         }
       }
   }
+  }   // work items
 }
 
 static int ilog2_exact(int v) {
@@ -585,8 +592,11 @@ extern "C" int lec_conv_f32_wgrad(const float* dy, const float* x, int N, int H,
   if (split < 1) split = 1;
   g.chunks_per_split = (nchunks + split - 1) / split;
   split = (nchunks + g.chunks_per_split - 1) / g.chunks_per_split;
+  g.tiles = tiles; g.split = split;
   const size_t lds = (size_t)2 * WBK * (BM + BN) * 4;
-  const dim3 grid(tiles, split), blk(kCfThreads);
+  static const int wg_cap = [] { const char* e = getenv("LEC_WGRAD_WGS"); const int v = e ? atoi(e) : (1 << 30); return v > 0 ? v : (1 << 30); }();
+  const int total = tiles * split;
+  const dim3 grid(total < wg_cap ? total : wg_cap), blk(kCfThreads);
   hipStream_t st = (hipStream_t)stream;
   if (!dense) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, false>), grid, blk, lds, st, dy, x, dw, g);
   else if (BM == 64 && BN == 256) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, true>), grid, blk, lds, st, dy, x, dw, g);

@@ -26,6 +26,9 @@ from .hierarchy import NegativeGraph, SyntheticLabelMap, SYNTHETIC
 from .oe_h import Embedder, FeatCNN18, FeatCNN, EuclideanConesWithImagesHypernymLoss
 from .resnet import WgradOverlap
 
+# BASELINE.json configs[3]: ETHEC, resnet50, multi-level cross-entropy head over the 723 labels, batch 512 per GPU
+CLASSIFIER_WORKLOADS = {'cfg4': ('ETHEC', 'resnet50', 512, 224), 'tiny4': ('ETHEC', 'resnet18', 8, 32)}
+
 WORKLOADS = {
     # name: (hierarchy, arch, per-GPU batch, K negatives ratio, D, image hw)
     'cfg2': ('ETHEC', 'resnet18', 128, 5, 10, 224),     # BASELINE.json configs[1]
@@ -296,3 +299,94 @@ class StepEngine:
         self.prefetch.close()
         if WgradOverlap.instance is self.overlap:
             WgradOverlap.instance = None
+
+
+class ClassifierEngine:
+    """Config 4 (ethec_experiments.py:243-383 + finetuner.py:199-246) on synthetic inputs: experiment.ETHECExperiment's step --
+    ResNet forward, MultiLevelCELoss (one fused launch), backward, gradient all-reduce, flat Adam -- on an image pool resident in
+    HBM, forward + loss + backward replayed as ONE hipGraph after a few eager steps.  Image j carries the label chain of leaf
+    j mod n_leaf."""
+
+    def __init__(self, workload='cfg4', dtype='fp32', batch=None, lr=1e-4, use_graph=True, graph_after=3, overlap_wgrad=True):
+        import tempfile
+        from .experiment import ETHECExperiment
+        from .loss import MultiLevelCELoss
+        hier, arch, B, hw = CLASSIFIER_WORKLOADS[workload]
+        self.workload, self.arch, self.B, self.hw = workload, arch, batch or B, hw
+        self.rank, self.local_rank, self.world = parallel.init_process_group()
+        self.device = torch.device('cuda', self.local_rank % max(torch.cuda.device_count(), 1))
+        torch.cuda.set_device(self.device)
+        self.labelmap = lm = make_labelmap(hier)
+        self.compute_dtype = {'bf16': torch.bfloat16, 'fp32': torch.float32}[dtype]
+        torch.manual_seed(0)
+        self.exp = ETHECExperiment({}, lm, MultiLevelCELoss(lm), lr=lr, batch_size=self.B, model_name=arch, experiment_dir=tempfile.mkdtemp(prefix='lec_cfg4_'),
+                                   compute_dtype=self.compute_dtype)
+        if not overlap_wgrad and self.exp.overlap is not None:
+            self.exp.overlap.side = None
+        self.exp.model.train()
+        L = len(lm.levels)
+        par = lm.parents()
+        nleaf = lm.levels[-1]
+        chains = np.zeros((nleaf, L), dtype=np.int64)
+        for i in range(nleaf):
+            v = lm.level_start[-1] + i; c = [v]
+            while c[-1] in par:
+                c.append(par[c[-1]][0])
+            c = c[::-1]
+            chains[i] = [c[l] - lm.level_start[l] for l in range(L)]
+        self.P = P = self.B
+        g = torch.Generator(device='cpu').manual_seed(4321 + self.rank)
+        pool = torch.rand(P, 3, hw, hw, generator=g).to(self.device).contiguous(memory_format=torch.channels_last)
+        self.pool = pool if self.compute_dtype == torch.float32 else pool.to(self.compute_dtype)
+        self.pool_levels = torch.from_numpy(chains[np.arange(P) % nleaf]).to(self.device)
+        self.idx_dev = torch.zeros(self.B, dtype=torch.int64, device=self.device)
+        self.pin = [torch.empty(self.B, dtype=torch.int64).pin_memory() for _ in range(2)]
+        self.pin_ev = [None, None]
+        self.use_graph, self.graph_after = bool(use_graph), graph_after
+        self.hip_graph = self.graph_out = self.graph_error = None
+        self.step_no = 0
+        self.loss_acc = torch.zeros((), device=self.device)
+
+    def _core(self):
+        images = self.pool.index_select(0, self.idx_dev)
+        lvl = self.pool_levels.index_select(0, self.idx_dev)
+        return self.exp.fwd_bwd(images, lvl)
+
+    def step(self):
+        slot = self.step_no & 1
+        if self.pin_ev[slot] is not None:
+            self.pin_ev[slot].synchronize()
+        rs = np.random.RandomState(self.step_no * 7919 + self.rank)
+        self.pin[slot].numpy()[:] = rs.permutation(self.P)[:self.B] if self.P > self.B else rs.permutation(self.P)
+        self.idx_dev.copy_(self.pin[slot], non_blocking=True)
+        self.pin_ev[slot] = torch.cuda.Event(); self.pin_ev[slot].record()
+        if self.use_graph and self.hip_graph is None and self.graph_error is None and self.step_no >= self.graph_after:
+            try:
+                torch.cuda.synchronize()
+                self.exp.reducer.live = False
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                    out = self._core()
+                torch.cuda.synchronize()
+                self.hip_graph, self.graph_out = g, out
+            except Exception as e:                                  # noqa: BLE001 (launch mode only)
+                self.graph_error = '%s: %s' % (type(e).__name__, e)
+                self.exp.reducer.live = True
+                import sys
+                print('[ClassifierEngine] hipGraph capture failed, staying in eager launch mode: %s' % self.graph_error, file=sys.stderr)
+                torch.cuda.synchronize()
+        if self.hip_graph is not None:
+            self.hip_graph.replay()
+            loss, outputs = self.graph_out
+            self.exp.reducer.reduce_now()
+        else:
+            loss, outputs = self._core()
+            self.exp.reducer.finish()
+        self.exp.arena.adam_step(self.exp.lr, grad_scale=1.0 / self.world)
+        self.loss_acc += loss
+        self.step_no += 1
+        self.last = (loss, outputs)
+        return loss
+
+    def close(self):
+        pass

@@ -106,7 +106,7 @@ class ETHECExperiment(Experiment):
 
     def __init__(self, data_loaders, labelmap, criterion, lr, batch_size=8, evaluator=None, experiment_name='exp',
                  experiment_dir='../exp/', n_epochs=10, eval_interval=2, feature_extracting=False, use_pretrained=False,
-                 load_wt=False, model_name='resnet50', optimizer_method='adam', compute_dtype=torch.bfloat16, weights=None):
+                 load_wt=False, model_name='resnet50', optimizer_method='adam', compute_dtype=torch.float32, weights=None, fast_path=True):
         self.labelmap = labelmap; self.lr = lr; self.model_name = model_name
         self.n_classes = labelmap.n_classes; self.levels = labelmap.levels; self.n_levels = len(labelmap.levels)
         self.rank, self.local_rank, self.world = parallel.init_process_group()
@@ -124,16 +124,38 @@ class ETHECExperiment(Experiment):
         self.reducer = parallel.GradientReducer(self.arena)
         if self.world > 1:
             torch.distributed.broadcast(self.arena.data, 0)
+        # liblecone's convolutions / fused BatchNorm / arena gradients / side-stream weight gradients, as in engine.StepEngine
+        from .resnet import WgradOverlap
+        self.overlap = None
+        if fast_path and compute_dtype in (torch.float32, torch.bfloat16):
+            if compute_dtype == torch.bfloat16:
+                self.arena.enable_lowp_shadow()
+            self.overlap = WgradOverlap(self.reducer, self.arena, side_stream=True)
+
+    def fwd_bwd(self, inputs, level_labels, labels=None):
+        """Forward, criterion, backward of one batch already on the device (NHWC): the region a hipGraph can capture."""
+        from .resnet import WgradOverlap
+        prev = WgradOverlap.instance
+        WgradOverlap.instance = self.overlap
+        try:
+            self.arena.zero_grad()
+            with torch.autocast('cuda', dtype=self.compute_dtype, enabled=self.compute_dtype != torch.float32):
+                outputs = self.model(inputs)
+            loss = self.criterion(outputs.float(), labels, level_labels)
+            loss.backward()
+            if self.overlap is not None:
+                self.overlap.join()
+        finally:
+            WgradOverlap.instance = prev
+        # detached: a live `outputs` would keep this step's autograd graph (and its AccumulateGrad nodes, bound to this step's
+        # stream) alive into the next one -- under hipGraph capture that ends in a crash inside capture_end
+        return loss.detach(), outputs.detach()
 
     def train_step(self, inputs, labels, level_labels):
         """finetuner.py:213-246 for one batch: forward, criterion, backward, (SUM all-reduce), Adam.  The criterion's
         mean is over the LOCAL batch, so under DP the summed gradient is divided by the world size."""
-        self.arena.zero_grad()
         inputs = inputs.to(self.device, non_blocking=True).contiguous(memory_format=torch.channels_last)
-        with torch.autocast('cuda', dtype=self.compute_dtype, enabled=self.compute_dtype != torch.float32):
-            outputs = self.model(inputs)
-        loss = self.criterion(outputs.float(), labels, level_labels.to(self.device))
-        loss.backward()
+        loss, outputs = self.fwd_bwd(inputs, level_labels.to(self.device), labels)
         self.reducer.finish()
         self.arena.adam_step(self.lr, grad_scale=1.0 / self.world)
-        return loss.detach(), outputs
+        return loss, outputs

@@ -416,10 +416,10 @@ class JointEmbeddings:
                  lr_step=[], experiment_dir='../exp/', n_epochs=10, eval_interval=2, feature_extracting=True,
                  use_pretrained=True, load_wt=False, model_name=None, optimizer_method='adam', use_grayscale=False,
                  load_emb_from=None, load_cosine_emb=None, hide_levels=None, half_half=False,
-                 compute_dtype=torch.float32, cnn_weights=None, writer=None):
+                 compute_dtype=torch.float32, cnn_weights=None, writer=None, fast_path=True):
         Embedder, FeatCNN18, FeatCNN, FeatNet = self._model_classes()
         from .resnet import WgradOverlap
-        WgradOverlap.instance = None            # this trainer drives gradients through plain autograd
+        WgradOverlap.instance = None            # set to this trainer's own instance around every train step (see train_step)
         torch.manual_seed(0)                                               # oe_h.py:1338
         self.classes = labelmap.classes; self.n_classes = labelmap.n_classes
         self.levels = labelmap.levels; self.n_levels = len(self.levels); self.level_names = labelmap.level_names
@@ -471,6 +471,14 @@ class JointEmbeddings:
         self.reducer = parallel.GradientReducer(self.arena, extra=[self.table_grad])
         if self.world > 1:                                                  # replicas start identical
             torch.distributed.broadcast(self.arena.data, 0); torch.distributed.broadcast(w.data, 0)
+        # The measured path of engine.StepEngine, behind this trainer too: liblecone's convolutions (fp32: the f32-MFMA implicit
+        # GEMMs; bf16: the MFMA kernels + low-precision shadow weights written by the Adam kernel), BatchNorm statistics / apply /
+        # backward fusions, weight gradients accumulated straight into the flat arena on a second HIP stream.
+        self.overlap = None
+        if self.use_CNN and fast_path and compute_dtype in (torch.float32, torch.bfloat16):
+            if compute_dtype == torch.bfloat16:
+                self.arena.enable_lowp_shadow()
+            self.overlap = WgradOverlap(self.reducer, self.arena, side_stream=True)
         self.check_graph_embedding_neg_graph = None
         self.check_reconstr_every = 1; self.save_model_every = 1
         self.reconstruction_f1 = self.reconstruction_threshold = self.reconstruction_accuracy = 0.0
@@ -568,11 +576,22 @@ class JointEmbeddings:
         self.load_best_model()
 
     def train_step(self, data_item):
-        """oe_h.py:1734-1774 for one batch.  Returns the (device) loss; nothing here synchronises with the host."""
-        self.arena.zero_grad(); self.table_grad.zero_()
-        loss, e_pos, e_neg = self.criterion(self.model, self.img_feat_net, data_item['from'], data_item['to'],
-                                            data_item['original_from'], data_item['original_to'], data_item['status'], 'train')
-        loss.backward()                                                     # oe_h.py:1766
+        """oe_h.py:1734-1774 for one batch.  Returns the (device) loss; nothing here synchronises with the host.
+        Exactly one forward / backward of the image network per step: the weight-gradient kernels ADD into the arena's gradient
+        slots (zeroed here), BatchNorm gradients are written in place."""
+        from .resnet import WgradOverlap
+        ov = self.overlap
+        prev = WgradOverlap.instance
+        WgradOverlap.instance = ov
+        try:
+            self.arena.zero_grad(); self.table_grad.zero_()
+            loss, e_pos, e_neg = self.criterion(self.model, self.img_feat_net, data_item['from'], data_item['to'],
+                                                data_item['original_from'], data_item['original_to'], data_item['status'], 'train')
+            loss.backward()                                                 # oe_h.py:1766
+            if ov is not None:
+                ov.join()                                                   # weight gradients from the side stream
+        finally:
+            WgradOverlap.instance = prev
         self.reducer.finish()
         self.apply_updates()
         return loss.detach(), e_pos, e_neg
@@ -687,6 +706,8 @@ class JointEmbeddings:
             own = module.state_dict()
             for k, v in sd.items():
                 own[k].copy_(v)                                            # in place: parameters stay inside the arena
+        if getattr(self, 'arena', None) is not None:
+            self.arena.refresh_lowp()                                      # the bf16 shadow (if any) follows the loaded weights
 
     def load_model(self, epoch_to_load):
         ck = torch.load(os.path.join(self.path_to_save_model, '{}_model.pth'.format(epoch_to_load)), map_location=self.device)

@@ -100,7 +100,7 @@ def test_config4_multilevel_ce_trainer_step():
     lm = SyntheticLabelMap.ethec()
     crit = loss_mod.MultiLevelCELoss(lm)
     exp = experiment.ETHECExperiment({}, lm, crit, lr=1e-3, batch_size=8, model_name='resnet18', experiment_dir='/tmp/lec_exp',
-                                     compute_dtype=torch.bfloat16)
+                                     compute_dtype=torch.float32)
     g = torch.Generator().manual_seed(0)
     x = torch.rand(8, 3, 32, 32, generator=g)
     lvl = torch.stack([torch.randint(0, n, (8,), generator=g) for n in lm.levels], 1)
@@ -112,6 +112,26 @@ def test_config4_multilevel_ce_trainer_step():
     assert (exp.arena.data - w0).abs().max().item() > 0                     # parameters moved
     l2, _ = exp.train_step(x, None, lvl)
     assert l2.item() < l1.item()                                            # same batch again: the loss goes down
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_config4_full_size_step_resnet50_b512(dtype):
+    """BASELINE.json configs[3] at its stated size: ResNet-50, 723 ETHEC logits, batch 512, 224 x 224, through
+    engine.ClassifierEngine (the `bench.py --workload cfg4` path): the loss of every step equals the oracle's multi-level CE of
+    the logits the step produced, the hipGraph replay continues the eager steps, and training on a fixed pool reduces the loss."""
+    from learning_embeddings_amd.engine import ClassifierEngine
+    eng = ClassifierEngine('cfg4', dtype=dtype, use_graph=True, graph_after=2)
+    losses = []
+    for s in range(5):
+        l = eng.step()
+        loss, out = eng.last
+        assert out.shape == (512, 723)
+        lvl = eng.pool_levels.index_select(0, eng.idx_dev).cpu().numpy()
+        ol, _ = O.multilevel_ce(out.detach().float().cpu().numpy(), lvl, eng.labelmap.levels)
+        assert abs(float(loss) - ol) <= 2e-4 * ol, (s, float(loss), ol)
+        losses.append(float(l))
+    assert eng.hip_graph is not None, eng.graph_error
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
 
 
 def test_step_engine_matches_oracle_stream_and_loss():
@@ -205,6 +225,44 @@ def test_joint_embeddings_trainer_runs_and_learns(tmp_path):
     tr.load_model('best_model')
     sd = torch.load(os.path.join(tr.path_to_save_model, '0_model.pth'))['model_state_dict']
     assert list(sd) == ['module.embeddings.weight']                          # the reference's DataParallel key prefix
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_joint_embeddings_fast_path_matches_plain_autograd(tmp_path, dtype):
+    """JointEmbeddings.train_step through liblecone's convolutions / fused BatchNorm / arena gradients / side stream (the path
+    bench.py measures) against the same trainer on plain autograd + library convolutions: same seed, same batches -> same loss,
+    same label-table update, same image-network update (to the noise of the precision in use)."""
+    from test_host_cpu import _fake_loaders
+    lm = SyntheticLabelMap([2, 4, 8])
+    dl = _fake_loaders(lm, 32, 8)
+    for split in dl.values():
+        for b in split:
+            b['path_to_image'] = [torch.rand(3, 64, 64, generator=torch.Generator().manual_seed(int(n[4:]))).to(DEV) for n in b['image_filename']]
+    gd = oe_h.create_combined_graphs(dl, lm, pick_per_level=True)
+    out = {}
+    for fast in (True, False):
+        crit = oe_h.EuclideanConesWithImagesHypernymLoss(lm, 5, {}, 0.05, True, K=0.1, use_CNN=True)
+        tr = oe_h.JointEmbeddings(gd, dl, image_dir='', use_CNN=True, labelmap=lm, criterion=crit, lr=1e-3, n_workers=0,
+                                  batch_size=16, experiment_name='f%d' % fast, embedding_dim=10, neg_to_pos_ratio=5, image_fc7=None,
+                                  normalize=None, alpha=0.05, experiment_dir=str(tmp_path), n_epochs=1, eval_interval=5,
+                                  compute_dtype=dtype, fast_path=fast)
+        assert (tr.overlap is not None) == fast
+        crit.set_dataloader(tr.datasets['train'])
+        tr.train_set.transform = None                                        # no random flip: identical batches on both sides
+        tr.model.train(); tr.img_feat_net.train()
+        torch.manual_seed(1)
+        it = iter(tr.dataloaders['train'])
+        losses = [float(tr.train_step(next(it))[0])]
+        torch.cuda.synchronize()
+        # the image network is compared through its GRADIENT (what the two paths compute); Adam's first update is lr * sign(g),
+        # which turns rounding noise on near-zero gradients into +-lr on the parameter
+        out[fast] = (losses, tr.model.embeddings.weight.detach().clone(), tr.arena.grad.clone())
+    tol = 2e-4 if dtype == torch.float32 else 5e-2
+    for a, b in zip(out[True][0], out[False][0]):
+        assert abs(a - b) <= tol * max(1.0, abs(b)), (out[True][0], out[False][0])
+    assert (out[True][1] - out[False][1]).abs().max().item() <= (1e-5 if dtype == torch.float32 else 3e-3)
+    d = (out[True][2] - out[False][2]).double().norm().item() / out[False][2].double().norm().item()
+    assert d < (1e-4 if dtype == torch.float32 else 5e-2), d
 
 
 # ------------------------------------------------------------------------------------------------ DP on one GPU (gloo)
