@@ -225,6 +225,7 @@ class StepEngine:
         self.arena.zero_grad(); self.table_grad.zero_(); self.gfeat.zero_()
         if ev: ev[0].record()
         feats = self.img_feat_net.forward_raw(images)
+        self.last_feats = feats.detach()              # raw CNN outputs the loss kernel consumes (a static buffer under graph replay)
         if ev: ev[1].record()
         loss, e_pos, e_neg = ops.joint_loss_raw(self.table, feats.detach(), pos_from, pos_to, negc, None, self.K_cone,
                                                 self.alpha, _lib.ENERGY_HYP_CONE, _lib.LABEL_HYP, _lib.IMAGE_SOFTCLIP,

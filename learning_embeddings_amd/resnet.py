@@ -431,7 +431,7 @@ class ResNet(nn.Module):
 
     def forward(self, x):
         if x.is_cuda and torch.is_autocast_enabled() and x.dtype == torch.float32:
-            x = x.to(torch.get_autocast_gpu_dtype())          # the stem conv sees low-precision input like every other layer
+            x = x.to(torch.get_autocast_dtype('cuda'))          # the stem conv sees low-precision input like every other layer
         _ops()._FORKS.clear(); _ops()._FOLDED.clear(); _ops()._DEFERRED.clear(); _ops()._LAZY_OK.clear(); _ops()._LAZY_DX.clear()   # records of a forward whose backward never ran (or raised)
         x = self.maxpool(self.bn1(self.conv1(x)))
         blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
