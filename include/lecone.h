@@ -177,6 +177,20 @@ int64_t lec_sampler_tc_edges(const lec_sampler* s);                      /* |TC|
 int  lec_sampler_tc_export(const lec_sampler* s, int64_t* ptr, int32_t* adj);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * (5b) Data-parallel gradient exchange: a thin layer over RCCL (xGMI inside a node).  Replaces the reference's single-process
+ *     nn.DataParallel (oe_h.py:301,1434,1439; ethec_experiments.py:240: parameter broadcast every forward + gather + reduce-add on
+ *     device 0) by one process per GPU and a SUM all-reduce of the flat gradient arena (the loss is a plain sum over pairs,
+ *     oe_h.py:843-846).  lec_dp_unique_id: rank 0 draws the 128-byte id and hands it to the other ranks (any side channel: a file,
+ *     a TCP store); lec_dp_init: every rank joins, bound to GPU `device`; lec_dp_allreduce_sum: in place over `count` elements of
+ *     buf (dtype 0 = fp32, 1 = bf16), asynchronous on `stream`; call it per bucket of the arena as backward produces it.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct lec_dp lec_dp;
+int  lec_dp_unique_id(void* id128);
+int  lec_dp_init(lec_dp** out, int rank, int world, const void* unique_id, int device);
+int  lec_dp_allreduce_sum(lec_dp* comm, void* buf, int64_t count, int dtype, lec_stream_t stream);
+void lec_dp_destroy(lec_dp* comm);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * (6) Multi-level cross-entropy, forward + backward in one launch.  Replaces MultiLevelCELoss.forward
  *     (network/loss.py:29-38) and its autograd:  loss = mean_b sum_l w_l CE(logits[b, s_l:e_l], labels[b, l]).
  *     logits [B, C] (ld), level_labels [B, L] int64, level_sizes [L] (sum = C), level_weights [L] or NULL.

@@ -142,6 +142,11 @@ class StepEngine:
         self.graph_out = None
         self.graph_error = None
         self._graph_saved = None
+        # With liblecone's own RCCL layer (LEC_DP_BACKEND=lecone) the bucket all-reduces are plain stream-ordered RCCL calls and are
+        # captured INTO the step graph on the reducer's launch stream, where they overlap the rest of backward; torch.distributed's
+        # collectives cannot be (this PyTorch build refuses the external events that would order them against a replay), so with
+        # that backend the buckets are reduced after the replay.
+        self.graph_reduces = self.reducer.comm is not None
 
     # global positives of step s: image (s*Bg + b) mod M with its ancestor at level b mod L   
     def positives(self, s):
@@ -199,7 +204,8 @@ class StepEngine:
             self.hip_graph.replay()
             if ev: ev[1].record()
             loss, e_pos, e_neg = self.graph_out
-            self.reducer.reduce_now()
+            if not self.graph_reduces:
+                self.reducer.reduce_now()
             if ev: ev[2].record()
         else:
             ev = [T['mk']() for _ in range(6)] if T is not None else None
@@ -234,6 +240,8 @@ class StepEngine:
         feats.backward(self.gfeat)
         if self.overlap is not None:
             self.overlap.join()                       # weight gradients from the side stream
+        if self.graph_reduces and torch.cuda.is_current_stream_capturing():
+            self.reducer.finish()                     # in-graph: the buckets launched by the hooks during backward join here
         if ev: ev[3].record()
         return loss, e_pos, e_neg
 
@@ -245,7 +253,8 @@ class StepEngine:
         saved_ctimer = ops.CONV_TIMER
         try:
             torch.cuda.synchronize()
-            self.reducer.live = False
+            self.reducer.live = self.graph_reduces    # hooks muted unless the collectives are captured with the step
+            self.reducer.reset()
             ops.BN_TIMER = None
             ops.CONV_TIMER = None
             g = torch.cuda.CUDAGraph()
@@ -254,6 +263,7 @@ class StepEngine:
                 out = self._core(None)
             torch.cuda.synchronize()
             self.hip_graph, self.graph_out = g, out
+            self.reducer.live = False                 # after the capture every gradient of a step comes out of a replay
         except Exception as e:                                     # noqa: BLE001  (launch mode only; the kernels are the same)
             self.graph_error = '%s: %s' % (type(e).__name__, e)
             self.hip_graph = None

@@ -153,6 +153,59 @@ def rank():
     return dist.get_rank() if dist.is_initialized() else 0
 
 
+class DpComm:
+    """The C ABI's RCCL layer (include/lecone.h 5b: lec_dp_unique_id / lec_dp_init / lec_dp_allreduce_sum / lec_dp_destroy) as the
+    gradient exchange: what a maintainer of the reference binds in place of nn.DataParallel.  Rank 0 draws the 128-byte unique id;
+    it travels to the other ranks through the already-initialised torch.distributed group (any side channel would do).
+    `LEC_DP_BACKEND=lecone` makes GradientReducer use it instead of torch.distributed's own all-reduce."""
+
+    def __init__(self, device=None):
+        import ctypes as C
+        from ._lib import lib, check
+        self._lib, self._check, self._C = lib, check, C
+        self.rank, self.world = rank(), world_size()
+        dev = torch.cuda.current_device() if device is None else (device.index if isinstance(device, torch.device) else int(device))
+        buf = (C.c_char * 128)()
+        if self.rank == 0:
+            check(lib.lec_dp_unique_id(C.cast(buf, C.c_void_p)))
+        if self.world > 1:
+            box = [bytes(buf)]
+            dist.broadcast_object_list(box, src=0)
+            buf = (C.c_char * 128).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        check(lib.lec_dp_init(C.byref(h), self.rank, self.world, C.cast(buf, C.c_void_p), dev))
+        self._h = h
+
+    def allreduce_sum_(self, t, stream=None):
+        """In-place SUM all-reduce of a contiguous fp32 / bf16 device tensor, asynchronous on `stream` (default: the current one)."""
+        if not (t.is_cuda and t.is_contiguous()) or t.dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError('DpComm.allreduce_sum_: contiguous fp32 / bf16 device tensor required')
+        st = (stream or torch.cuda.current_stream()).cuda_stream
+        self._check(self._lib.lec_dp_allreduce_sum(self._h, self._C.c_void_p(t.data_ptr()), t.numel(), 0 if t.dtype == torch.float32 else 1,
+                                                   self._C.c_void_p(st)))
+        return t
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.lec_dp_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _StreamHandle:
+    """What dist.all_reduce(async_op=True) returns, for a collective enqueued on a HIP stream through the C ABI."""
+
+    def __init__(self, stream):
+        self.ev = torch.cuda.Event(); self.ev.record(stream)
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
 class GradientReducer:
     """Bucketed, backward-overlapped SUM all-reduce of a FlatArena's gradient (plus any extra flat tensors, e.g. the
     label table's dense gradient).  Buckets are contiguous slices of the arena in REVERSE parameter order, so the first
@@ -162,6 +215,9 @@ class GradientReducer:
         self.arena = arena
         self.extra = list(extra)
         self.enabled = world_size() > 1 or (dist.is_initialized() and bool(os.environ.get('LEC_FORCE_DIST')))
+        # LEC_DP_BACKEND=lecone: the collective goes through liblecone's own RCCL layer (lec_dp_allreduce_sum) instead of
+        # torch.distributed's -- same RCCL underneath, reached through the C ABI a reference maintainer would bind
+        self.comm = DpComm() if (self.enabled and os.environ.get('LEC_DP_BACKEND') == 'lecone' and arena.grad.is_cuda) else None
         self.live = True             # False: hooks are muted (gradients produced by a hipGraph replay; see reduce_now)
         self.side_streams = []       # streams other than the autograd one that write gradients (WgradOverlap registers its own)
         self._launch = None          # stream the bucket all-reduces are issued from (waits for every producer stream)
@@ -218,7 +274,7 @@ class GradientReducer:
         from the autograd stream, convolution weight gradients from WgradOverlap's side stream) and the parameter that
         completes the bucket may report from either: the collective is issued from a third stream that waits for all of
         them, so neither producer stream stalls and the reduction never reads a gradient still being written."""
-        if not (flat.is_cuda and self.side_streams):
+        if not (flat.is_cuda and (self.side_streams or self.comm is not None)):
             return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
         if self._launch is None:
             self._launch = torch.cuda.Stream()
@@ -226,7 +282,14 @@ class GradientReducer:
         for s in self.side_streams:
             self._launch.wait_stream(s)
         with torch.cuda.stream(self._launch):
-            return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+            return self._allreduce(flat)
+
+    def _allreduce(self, t):
+        """One SUM all-reduce on the current stream; returns a handle with .wait()."""
+        if self.comm is not None:
+            self.comm.allreduce_sum_(t)
+            return _StreamHandle(torch.cuda.current_stream())
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
 
     def mark_ready(self, p):
         """Manual form of the post-accumulate hook, for gradients written outside autograd (e.g. weight gradients computed
@@ -249,9 +312,9 @@ class GradientReducer:
         for bi, left in enumerate(self._pending):
             if left > 0:
                 lo, hi = self._spans[bi]
-                self.handles.append(dist.all_reduce(self.arena.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+                self.handles.append(self._allreduce(self.arena.grad[lo:hi]))
         for t in self.extra:
-            self.handles.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+            self.handles.append(self._allreduce(t))
         for h in self.handles:
             h.wait()
         self.reset()
@@ -259,9 +322,9 @@ class GradientReducer:
 
     def _reduce_now(self):
         for lo, hi in self._spans:
-            self.handles.append(dist.all_reduce(self.arena.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            self.handles.append(self._allreduce(self.arena.grad[lo:hi]))
         for t in self.extra:
-            self.handles.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+            self.handles.append(self._allreduce(t))
         for h in self.handles:
             h.wait()
         self.reset()

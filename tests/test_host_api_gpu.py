@@ -735,3 +735,52 @@ def test_euclidean_cones_trainer_runs(tmp_path):
     assert (w1 - w0).abs().max().item() > 0                                  # plain Adam moved the table ...
     assert w1.norm(dim=1).max().item() > 1.0                                 # ... and nothing clipped it into the unit ball
     assert set(['m-f1', 'hit@1']).issubset(tr.last_metrics)
+
+
+def test_dp_c_abi_rccl_layer_world_size_one():
+    """include/lecone.h (5b): lec_dp_unique_id / lec_dp_init / lec_dp_allreduce_sum / lec_dp_destroy over RCCL, one rank: the sum over
+    one rank is the identity, in fp32 and bf16, on a side stream, and a destroyed communicator refuses further calls."""
+    import ctypes as C
+    from learning_embeddings_amd import _lib
+    from learning_embeddings_amd.parallel import DpComm
+    comm = DpComm()
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.randn(1 << 20, device=DEV).to(dt); ref = x.clone()
+        side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+        comm.allreduce_sum_(x, stream=side)
+        torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+        assert torch.equal(x, ref)
+    with pytest.raises(ValueError):
+        comm.allreduce_sum_(torch.zeros(4, dtype=torch.int32, device=DEV))
+    rc = _lib.lib.lec_dp_allreduce_sum(None, None, 4, 0, None)
+    assert rc == _lib.E_STATE and b'not initialised' in _lib.lib.lec_last_error()
+    comm.close()
+
+
+def _dp_lecone_worker(q):
+    import os
+    os.environ.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29631', LEC_FORCE_DIST='1', LEC_DP_BACKEND='lecone')
+    import torch as t
+    from learning_embeddings_amd.engine import StepEngine
+    eng = StepEngine('tiny', n_images=64, dtype='fp32', use_graph=True, graph_after=2)
+    assert eng.reducer.enabled and eng.reducer.comm is not None
+    ls = [float(eng.step()) for _ in range(4)]
+    t.cuda.synchronize()
+    q.put((ls, eng.table.cpu().numpy(), eng.hip_graph is not None))
+    eng.close()
+    t.distributed.destroy_process_group()
+
+
+def test_step_engine_gradient_exchange_through_the_c_abi_rccl_layer():
+    """LEC_DP_BACKEND=lecone: the engine's bucketed gradient all-reduce (eager buckets and the after-replay reduction) goes through
+    lec_dp_allreduce_sum; with one forced rank the step must equal the plain single-process step."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn'); q = ctx.Queue()
+    p = ctx.Process(target=_dp_lecone_worker, args=(q,)); p.start()
+    ls, table, graphed = q.get(timeout=300); p.join(60)
+    ref = StepEngine('tiny', n_images=64, dtype='fp32', use_graph=True, graph_after=2)
+    ls_ref = [float(ref.step()) for _ in range(4)]
+    torch.cuda.synchronize()
+    assert graphed and np.allclose(ls, ls_ref, rtol=1e-5)
+    assert np.abs(table - ref.table.cpu().numpy()).max() < 1e-6
+    ref.close()
