@@ -105,6 +105,19 @@ int lec_joint_loss_fwd_bwd(int energy, int label_proj, int image_proj,
                            float* grad_table, float* grad_feat,
                            void* workspace, int64_t workspace_bytes, lec_stream_t stream);
 
+/* The same launch with the label table READ from a 2-byte fp16 shadow [n_labels, D] (ld_table in elements): BASELINE.json config 5
+ * ("fp16+fp32-master": 50 000 labels, 256 negatives per positive -- the gather of 2(1+K) table rows per positive is the kernel's
+ * traffic, SURVEY.md 8(d) s = 2).  Gradients still go to the fp32 grad_table; the fp32 master is updated by lec_table_step_adam_f16,
+ * which refreshes the shadow in the same pass. */
+int lec_joint_loss_fwd_bwd_f16(int energy, int label_proj, int image_proj,
+                               const void* table_f16, int64_t ld_table, int n_labels,
+                               const float* feat, int64_t ld_feat, int n_feat,
+                               const int32_t* pos_from, const int32_t* pos_to, const int32_t* neg, const float* weights,
+                               int B, int K, int D, float K_cone, float alpha,
+                               float* e_pos, float* e_neg, float* loss,
+                               float* grad_table, float* grad_feat,
+                               void* workspace, int64_t workspace_bytes, lec_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * (3) Stand-alone projections (used outside the fused loss: evaluation, metrics, FeatCNN18.forward itself).
  *     lec_label_project_fwd  = Embedder.forward (oe_h.py:77-104): out[i] = project(table[idx[i]]).
@@ -134,6 +147,9 @@ int lec_image_softclip_bwd(int image_proj, const float* raw, int64_t ld_raw, con
 int lec_table_step_adam(float* table, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t ld, int n_labels,
                         int D, float lr, float beta1, float beta2, float eps, int step, float K_cone, int riemannian,
                         int clip, lec_stream_t stream);
+int lec_table_step_adam_f16(float* table, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t ld, int n_labels,
+                            int D, float lr, float beta1, float beta2, float eps, int step, float K_cone, int riemannian,
+                            int clip, void* table_f16, lec_stream_t stream);   /* + fp16 shadow of the updated rows (config 5) */
 int lec_table_step_rsgd(float* table, const float* grad, int64_t ld, int n_labels, int D, float lr, float K_cone,
                         lec_stream_t stream);
 /* Adam over a flat fp32 parameter arena (the CNN's parameters live in one buffer so that the data-parallel gradient

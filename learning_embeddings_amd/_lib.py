@@ -46,6 +46,9 @@ def _load():
         'lec_level_topk': (i32, [i32, p, i64, i64, p, i64, i64, i32, p, i32, i32, f32, p, p, p]),
         'lec_joint_loss_fwd_bwd': (i32, [i32, i32, i32, p, i64, i32, p, i64, i32, p, p, p, p, i32, i32, i32, f32, f32,
                                          p, p, p, p, p, p, i64, p]),
+        'lec_joint_loss_fwd_bwd_f16': (i32, [i32, i32, i32, p, i64, i32, p, i64, i32, p, p, p, p, i32, i32, i32, f32, f32,
+                                             p, p, p, p, p, p, i64, p]),
+        'lec_table_step_adam_f16': (i32, [p, p, p, p, i64, i32, i32, f32, f32, f32, f32, i32, f32, i32, i32, p, p]),
         'lec_label_project_fwd': (i32, [i32, p, i64, i32, p, i64, i32, f32, p, i64, p]),
         'lec_label_project_bwd': (i32, [i32, p, i64, i32, p, i64, i32, f32, p, i64, p, p]),
         'lec_image_softclip_fwd': (i32, [i32, p, i64, i64, i32, f32, p, i64, p]),

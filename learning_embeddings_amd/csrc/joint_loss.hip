@@ -26,6 +26,7 @@ namespace lec {
 
 struct JointParams {
   const float* table; int64_t ld_table; int n_labels;
+  const _Float16* table_h;   // optional 2-byte shadow of the label table (config 5: fp16 rows + fp32 master): the loss READS this one
   const float* feat; int64_t ld_feat; int n_feat;
   const int32_t* pos_from; const int32_t* pos_to; const int32_t* neg; const float* weights;
   int B, K, D;
@@ -55,6 +56,19 @@ struct Row {
 // lane then reads its own row from LDS at an odd stride (conflict-free).
 constexpr int kNoRow = INT_MIN;
 
+// A row of the label table (fp32 master, or its fp16 shadow when one is given) or of the image features; reads element d.
+struct RowSrc { const float* f; const _Float16* h; };
+__device__ __forceinline__ bool code_in_range(const JointParams& P, int code) {      // a stale / corrupt node code must not become an
+  return code >= 0 ? code < P.n_labels : (-1 - code) < P.n_feat;                      // out-of-bounds read or atomic: it is skipped
+}
+__device__ __forceinline__ RowSrc row_src(const JointParams& P, int code) {
+  RowSrc r; r.f = nullptr; r.h = nullptr;
+  if (code >= 0) { if (P.table_h) r.h = P.table_h + (int64_t)code * P.ld_table; else r.f = P.table + (int64_t)code * P.ld_table; }
+  else r.f = P.feat + (int64_t)(-1 - code) * P.ld_feat;
+  return r;
+}
+__device__ __forceinline__ float row_ld(const RowSrc& r, int d) { return r.h ? (float)r.h[d] : r.f[d]; }
+
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -71,10 +85,7 @@ __device__ __forceinline__ void wave_gather_rows(const JointParams& P, int code_
     const int r = eidx / EPL, d = eidx - r * EPL;
     const int rc = __shfl(code_or_norow, r, kWave);
     float v = 0.0f;
-    if (rc != kNoRow && d < P.D) {
-      const float* src = rc >= 0 ? P.table + (int64_t)rc * P.ld_table : P.feat + (int64_t)(-1 - rc) * P.ld_feat;
-      v = src[d];
-    }
+    if (rc != kNoRow && d < P.D && code_in_range(P, rc)) v = row_ld(row_src(P, rc), d);
     stage[r * LDW + d] = v;
   }
   wave_sync();
@@ -95,7 +106,7 @@ __device__ __forceinline__ void wave_scatter_rows(const JointParams& P, int code
     const int eidx = k * 64 + lane;
     const int r = eidx / EPL, d = eidx - r * EPL;
     const int rc = __shfl(code_or_norow, r, kWave);
-    if (rc != kNoRow && d < P.D) {
+    if (rc != kNoRow && d < P.D && code_in_range(P, rc)) {
       float* dst = rc >= 0 ? P.grad_table + (int64_t)rc * P.ld_table : P.grad_feat + (int64_t)(-1 - rc) * P.ld_feat;
       atomicAdd(dst + d, stage[r * LDW + d]);
     }
@@ -106,12 +117,13 @@ __device__ __forceinline__ void wave_scatter_rows(const JointParams& P, int code
 // raw row elements of node `code` owned by this lane (d = t, t+T, ...); kNoRow -> zeros, no memory access
 template <int T, int EPL>
 __device__ __forceinline__ void fetch_row(const JointParams& P, int code, int t, float (&raw)[EPL]) {
-  const float* src = P.table;
-  if (code != kNoRow) src = code >= 0 ? P.table + (int64_t)code * P.ld_table : P.feat + (int64_t)(-1 - code) * P.ld_feat;
+  const bool ok = code != kNoRow && code_in_range(P, code);
+  RowSrc src; src.f = P.table; src.h = nullptr;
+  if (ok) src = row_src(P, code);
 #pragma unroll
   for (int i = 0; i < EPL; ++i) {
     const int d = t + i * T;
-    raw[i] = (code != kNoRow && d < P.D) ? src[d] : 0.0f;
+    raw[i] = (ok && d < P.D) ? row_ld(src, d) : 0.0f;
   }
 }
 
@@ -119,8 +131,9 @@ template <int T, int EPL>
 __device__ __forceinline__ void load_project(const JointParams& P, int code, bool valid, int t, Row<EPL>& r, float* stage,
                                              const float* prefetched = nullptr) {
   const bool is_label = code >= 0;
-  const float* src = nullptr;
-  if (valid) src = is_label ? P.table + (int64_t)code * P.ld_table : P.feat + (int64_t)(-1 - code) * P.ld_feat;
+  valid = valid && code_in_range(P, code);
+  RowSrc src; src.f = nullptr; src.h = nullptr;
+  if (valid) src = row_src(P, code);
   const bool hyp = valid && is_label && P.label_proj == LEC_LABEL_HYP;
   const bool img = valid && (is_label ? P.label_proj == LEC_LABEL_SOFTCLIP_K : P.image_proj != LEC_IMAGE_RAW);   // soft_clip forms
   float nn = 0.0f;
@@ -144,7 +157,7 @@ __device__ __forceinline__ void load_project(const JointParams& P, int code, boo
     for (int i = 0; i < EPL; ++i) {
       int d = t + i * T;
       float v = 0.0f;
-      if (valid && d < P.D) { v = src[d]; if (hyp) v += 1e-15f; }                  // oe_h.py:79
+      if (valid && d < P.D) { v = row_ld(src, d); if (hyp) v += 1e-15f; }          // oe_h.py:79
       r.e[i] = v; nn += v * v;
     }
   }
@@ -439,8 +452,8 @@ extern "C" int64_t lec_loss_workspace_bytes(int B, int K, int D) {
   return 256 + (int64_t)g.nblocks * sizeof(float);
 }
 
-extern "C" int lec_joint_loss_fwd_bwd(int energy, int label_proj, int image_proj,
-                                      const float* table, int64_t ld_table, int n_labels,
+static int joint_loss_impl(int energy, int label_proj, int image_proj,
+                                      const float* table, const void* table_f16, int64_t ld_table, int n_labels,
                                       const float* feat, int64_t ld_feat, int n_feat,
                                       const int32_t* pos_from, const int32_t* pos_to, const int32_t* neg,
                                       const float* weights, int B, int K, int D, float K_cone, float alpha,
@@ -451,7 +464,7 @@ extern "C" int lec_joint_loss_fwd_bwd(int energy, int label_proj, int image_proj
   LEC_CHECK_ARG(label_proj >= LEC_LABEL_RAW && label_proj <= LEC_LABEL_SOFTCLIP_K, "joint_loss: unknown label_proj %d", label_proj);
   LEC_CHECK_ARG(image_proj >= LEC_IMAGE_RAW && image_proj <= LEC_IMAGE_SOFTCLIP_K, "joint_loss: unknown image_proj %d", image_proj);
   LEC_CHECK_ARG(B > 0 && K >= 0 && D > 0, "joint_loss: B=%d K=%d D=%d must be positive (K >= 0)", B, K, D);
-  LEC_CHECK_ARG(table && n_labels > 0 && ld_table >= D, "joint_loss: table null or ld_table < D");
+  LEC_CHECK_ARG((table || table_f16) && n_labels > 0 && ld_table >= D, "joint_loss: table null or ld_table < D");
   LEC_CHECK_ARG(n_feat == 0 || (feat && ld_feat >= D), "joint_loss: feat null or ld_feat < D");
   LEC_CHECK_ARG(pos_from && pos_to && (K == 0 || neg), "joint_loss: null index arrays");
   LEC_CHECK_ARG(e_pos && (K == 0 || e_neg) && loss, "joint_loss: null outputs");
@@ -464,7 +477,7 @@ extern "C" int lec_joint_loss_fwd_bwd(int energy, int label_proj, int image_proj
                 (long long)workspace_bytes, (long long)need);
   hipStream_t st = (hipStream_t)stream;
   JointParams P;
-  P.table = table; P.ld_table = ld_table; P.n_labels = n_labels;
+  P.table = table; P.table_h = (const _Float16*)table_f16; P.ld_table = ld_table; P.n_labels = n_labels;
   P.feat = feat; P.ld_feat = ld_feat; P.n_feat = n_feat;
   P.pos_from = pos_from; P.pos_to = pos_to; P.neg = neg; P.weights = weights;
   P.B = B; P.K = K; P.D = D; P.K_cone = K_cone; P.alpha = alpha;
@@ -474,7 +487,35 @@ extern "C" int lec_joint_loss_fwd_bwd(int energy, int label_proj, int image_proj
   P.e_pos = e_pos; P.e_neg = e_neg; P.loss = loss; P.grad_table = grad_table; P.grad_feat = grad_feat;
   P.counter = (unsigned int*)workspace; P.partials = (float*)((char*)workspace + 256);
   P.iters = g.iters; P.tasks_per_group = g.tasks_per_group;
-  { const char* e = getenv("LEC_JOINT_STAGE"); P.lds_stage = e ? atoi(e) : 0; }
+  static const int stage_env = [] { const char* e = getenv("LEC_JOINT_STAGE"); return e ? atoi(e) : 0; }();   // read once, not per launch
+  P.lds_stage = stage_env;
   const bool grad = grad_table != nullptr;
   return dispatch(g, P, grad, energy, st);
+}
+
+extern "C" int lec_joint_loss_fwd_bwd(int energy, int label_proj, int image_proj,
+                                      const float* table, int64_t ld_table, int n_labels,
+                                      const float* feat, int64_t ld_feat, int n_feat,
+                                      const int32_t* pos_from, const int32_t* pos_to, const int32_t* neg,
+                                      const float* weights, int B, int K, int D, float K_cone, float alpha,
+                                      float* e_pos, float* e_neg, float* loss, float* grad_table, float* grad_feat,
+                                      void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+  LEC_CHECK_ARG(table, "joint_loss: table null");
+  return joint_loss_impl(energy, label_proj, image_proj, table, nullptr, ld_table, n_labels, feat, ld_feat, n_feat, pos_from, pos_to, neg, weights,
+                         B, K, D, K_cone, alpha, e_pos, e_neg, loss, grad_table, grad_feat, workspace, workspace_bytes, stream);
+}
+
+// Config 5 of BASELINE.json ("fp16+fp32-master"): the label table is READ from a 2-byte fp16 shadow [n_labels, D] (ld_table in
+// elements) -- half the gather traffic of the 2(1+K) rows per positive -- while gradients still go to the fp32 grad_table and
+// the fp32 master is what lec_table_step_adam_f16 updates (refreshing the shadow in the same pass).
+extern "C" int lec_joint_loss_fwd_bwd_f16(int energy, int label_proj, int image_proj,
+                                          const void* table_f16, int64_t ld_table, int n_labels,
+                                          const float* feat, int64_t ld_feat, int n_feat,
+                                          const int32_t* pos_from, const int32_t* pos_to, const int32_t* neg,
+                                          const float* weights, int B, int K, int D, float K_cone, float alpha,
+                                          float* e_pos, float* e_neg, float* loss, float* grad_table, float* grad_feat,
+                                          void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+  LEC_CHECK_ARG(table_f16, "joint_loss_f16: table null");
+  return joint_loss_impl(energy, label_proj, image_proj, nullptr, table_f16, ld_table, n_labels, feat, ld_feat, n_feat, pos_from, pos_to, neg, weights,
+                         B, K, D, K_cone, alpha, e_pos, e_neg, loss, grad_table, grad_feat, workspace, workspace_bytes, stream);
 }

@@ -35,7 +35,7 @@ template <int T>
 __global__ __launch_bounds__(256) void table_adam_kernel(float* __restrict__ W, const float* __restrict__ G,
                                                          float* __restrict__ Mo, float* __restrict__ Vo, int64_t ld,
                                                          int N, int D, AdamConsts c, float r_in, int riemannian,
-                                                         int clip) {
+                                                         int clip, _Float16* __restrict__ Wh) {
   constexpr int RPW = kWave / T;
   const int lane = threadIdx.x & 63, t = lane % T, slot = lane / T;
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -67,6 +67,9 @@ __global__ __launch_bounds__(256) void table_adam_kernel(float* __restrict__ W, 
       float no = sqrtf(n2);
       if (no <= r_in) { for (int d = t; d < D; d += T) W[off + d] = W[off + d] / no * r_in; }
       else if (no >= 1.0f) { for (int d = t; d < D; d += T) W[off + d] = W[off + d] / no * (float)(1.0 - 1e-5); }
+    }
+    if (Wh && valid) {                                               // config 5: refresh the fp16 shadow the loss kernel reads
+      for (int d = t; d < D; d += T) Wh[off + d] = (_Float16)W[off + d];
     }
   }
 }
@@ -236,9 +239,9 @@ static int launch_project(const float* src, int64_t ld_src, const int64_t* idx, 
 
 }  // namespace lec
 
-extern "C" int lec_table_step_adam(float* table, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t ld,
+static int table_step_adam_impl(float* table, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t ld,
                                    int n_labels, int D, float lr, float beta1, float beta2, float eps, int step,
-                                   float K_cone, int riemannian, int clip, lec_stream_t stream) {
+                                   float K_cone, int riemannian, int clip, void* table_f16, lec_stream_t stream) {
   using namespace lec;
   LEC_CHECK_ARG(table && grad && exp_avg && exp_avg_sq, "table_step_adam: null pointer");
   LEC_CHECK_ARG(n_labels > 0 && D > 0 && ld >= D && step >= 1, "table_step_adam: bad sizes N=%d D=%d step=%d", n_labels, D, step);
@@ -248,11 +251,22 @@ extern "C" int lec_table_step_adam(float* table, const float* grad, float* exp_a
   AdamConsts c = adam_consts(lr, beta1, beta2, eps, step);
   const float r_in = inner_radius_f(K_cone);
   hipStream_t st = (hipStream_t)stream;
-#define L(T_) hipLaunchKernelGGL((table_adam_kernel<T_>), dim3(nblocks), dim3(256), 0, st, table, grad, exp_avg, exp_avg_sq, ld, n_labels, D, c, r_in, riemannian, clip)
+#define L(T_) hipLaunchKernelGGL((table_adam_kernel<T_>), dim3(nblocks), dim3(256), 0, st, table, grad, exp_avg, exp_avg_sq, ld, n_labels, D, c, r_in, riemannian, clip, (_Float16*)table_f16)
   if (T == 1) L(1); else if (T == 4) L(4); else if (T == 16) L(16); else L(64);
 #undef L
   LEC_CHECK_LAUNCH("table_adam_kernel");
   return LEC_OK;
+}
+
+extern "C" int lec_table_step_adam(float* table, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t ld, int n_labels, int D, float lr, float beta1, float beta2, float eps, int step, float K_cone, int riemannian, int clip, lec_stream_t stream) {
+  return table_step_adam_impl(table, grad, exp_avg, exp_avg_sq, ld, n_labels, D, lr, beta1, beta2, eps, step, K_cone, riemannian, clip, nullptr, stream);
+}
+
+// The same step with the fp16 shadow of the table (BASELINE.json config 5, "fp16+fp32-master") refreshed in the same pass:
+// table_f16 [n_labels, D] (same ld, in elements) receives the updated, clipped rows rounded to fp16.
+extern "C" int lec_table_step_adam_f16(float* table, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t ld, int n_labels, int D, float lr, float beta1, float beta2, float eps, int step, float K_cone, int riemannian, int clip, void* table_f16, lec_stream_t stream) {
+  LEC_CHECK_ARG(table_f16, "table_step_adam_f16: null shadow");
+  return table_step_adam_impl(table, grad, exp_avg, exp_avg_sq, ld, n_labels, D, lr, beta1, beta2, eps, step, K_cone, riemannian, clip, table_f16, stream);
 }
 
 extern "C" int lec_table_step_rsgd(float* table, const float* grad, int64_t ld, int n_labels, int D, float lr,

@@ -49,7 +49,7 @@ def make_labelmap(name):
 class StepEngine:
     def __init__(self, workload='cfg3', n_images=4096, pool_images=None, dtype='bf16', lr=1e-4, alpha=0.01, K_cone=0.1,
                  sampler_mode='replicated', seed=0, batch=None, device=None, overlap_wgrad=True, use_graph=False,
-                 graph_after=3):
+                 graph_after=3, table_dtype='fp32', cnn_chunk=None):
         hier, arch, B, K, D, hw = WORKLOADS[workload]
         self.workload, self.arch, self.B, self.K, self.D, self.hw = workload, arch, batch or B, K, D, hw
         self.rank, self.local_rank, self.world = parallel.init_process_group()
@@ -88,7 +88,19 @@ class StepEngine:
         # measured for ResNet-50 at 224x224 in bf16 (22.9 GB at 512 rows, 80.3 GB at 1 856).  Config 5 (K = 256 over 8 levels draws 28
         # image negatives per positive: 7 424 rows at B = 256) does not fit 288 GB; say so instead of dying in hipMalloc.
         per_row_gb = (0.05 if arch == 'resnet50' else 0.015) * (hw / 224.0) ** 2 * (2 if dtype == 'fp32' else 1)
-        if self.n_rows * per_row_gb > 240:
+        # cnn_chunk: push the step's CNN rows through the backbone `cnn_chunk` rows at a time -- a forward of every chunk without
+        # saved activations, the loss on all raw outputs, then per chunk a second forward + backward (activations of ONE chunk alive at a
+        # time; BatchNorm statistics per chunk, as the reference's own separate forwards of positives and negatives have them,
+        # oe_h.py:980-985,1003-1009).  Picked automatically when the whole batch would not fit.
+        self.cnn_chunk = cnn_chunk
+        if self.cnn_chunk is None and self.n_rows * per_row_gb > 240:
+            self.cnn_chunk = 512                       # the bench batch: every library convolution shape is in the shipped find-db
+        if self.cnn_chunk is not None and self.cnn_chunk >= self.n_rows:
+            self.cnn_chunk = None
+        # chunks are all the same size (one set of kernel shapes): the row list is padded with repeats of row 0, whose outputs no
+        # pair references (zero gradient)
+        self.n_rows_pad = self.n_rows if self.cnn_chunk is None else -(-self.n_rows // self.cnn_chunk) * self.cnn_chunk
+        if self.cnn_chunk is None and self.n_rows * per_row_gb > 240:
             raise ValueError('workload %s at B=%d pushes %d images through %s per step (%d image negatives per positive): about %.0f GB of '
                              'activations, more than one MI355X holds; pass a smaller `batch` (e.g. %d)'
                              % (workload, self.B, self.n_rows, arch, self.cnt, self.n_rows * per_row_gb, max(1, int(200 / per_row_gb / (1 + self.cnt)))))
@@ -103,6 +115,9 @@ class StepEngine:
         self.table = w.data
         self.table_grad = torch.zeros_like(self.table)
         self.table_m = torch.zeros_like(self.table); self.table_v = torch.zeros_like(self.table); self.table_step = 0
+        # BASELINE.json config 5 ("fp16+fp32-master"): the loss kernel reads the label rows from a 2-byte shadow; gradients, Adam
+        # moments and the master stay fp32, the table-step kernel refreshes the shadow
+        self.table_h = self.table.to(torch.float16) if table_dtype == 'fp16' else None
         self.reducer = parallel.GradientReducer(self.arena, extra=[self.table_grad])
         if self.world > 1:
             torch.distributed.broadcast(self.arena.data, 0); torch.distributed.broadcast(self.table, 0)
@@ -124,7 +139,7 @@ class StepEngine:
         if self.compute_dtype != torch.float32:
             self.pool = self.pool.to(self.compute_dtype)      # the backbone's first op would cast it anyway; same values
         self.P = P
-        self.gfeat = torch.zeros(self.n_rows, D, device=self.device)
+        self.gfeat = torch.zeros(self.n_rows_pad, D, device=self.device)
         self.pin = [torch.empty((self.B, 2 + 2 * K), dtype=torch.int32).pin_memory() for _ in range(2)]
         self.pin_img = [torch.empty(self.n_rows, dtype=torch.int64).pin_memory() for _ in range(2)]
         self.pin_ev = [None, None]
@@ -135,8 +150,10 @@ class StepEngine:
         self.timers = None
         # static device inputs of the step (the captured graph reads these addresses)
         self.codes_dev = torch.zeros((self.B, 2 + 2 * K), dtype=torch.int32, device=self.device)
-        self.idx_dev = torch.zeros(self.n_rows, dtype=torch.int64, device=self.device)
-        self.use_graph = bool(use_graph)
+        self.idx_dev = torch.zeros(self.n_rows_pad, dtype=torch.int64, device=self.device)
+        self.use_graph = bool(use_graph) and self.cnn_chunk is None      # the chunked step launches eagerly
+        if self.cnn_chunk is not None and self.overlap is not None:
+            self.overlap.accumulate = True
         self.graph_after = graph_after
         self.hip_graph = None
         self.graph_out = None
@@ -191,7 +208,7 @@ class StepEngine:
         elif is_img.any():
             raise RuntimeError('unexpected image negative')
         self.codes_dev.copy_(pin, non_blocking=True)
-        self.idx_dev.copy_(self.pin_img[self.step_no & 1], non_blocking=True)
+        self.idx_dev[:self.n_rows].copy_(self.pin_img[self.step_no & 1], non_blocking=True)
         self.pin_ev[slot] = torch.cuda.Event(); self.pin_ev[slot].record()
 
         T = self.timers
@@ -213,7 +230,8 @@ class StepEngine:
             self.reducer.finish()
             if ev: ev[4].record()
         self.table_step += 1
-        ops.table_step_adam(self.table, self.table_grad, self.table_m, self.table_v, self.table_step, self.lr, self.K_cone)
+        ops.table_step_adam(self.table, self.table_grad, self.table_m, self.table_v, self.table_step, self.lr, self.K_cone,
+                            table_f16=self.table_h)
         self.arena.adam_step(self.lr)
         if ev:
             ev[-1].record(); T['records'].append(ev)
@@ -222,9 +240,45 @@ class StepEngine:
         self.last = (loss, e_pos, e_neg, frm, to, neg)
         return loss
 
+    def _core_chunked(self, ev=None):
+        """The same step with the CNN rows in chunks (see `cnn_chunk`): forward of every chunk without saved activations, ONE fused
+        loss launch over all raw outputs, then a second forward + backward per chunk."""
+        import torch.nn as nn
+        codes = self.codes_dev
+        pos_from = codes[:, 0].contiguous(); pos_to = codes[:, 1].contiguous(); negc = codes[:, 2:].contiguous()
+        self.arena.zero_grad(); self.table_grad.zero_(); self.gfeat.zero_()
+        if ev: ev[0].record()
+        R, C = self.n_rows_pad, self.cnn_chunk
+        feats = torch.empty(R, self.D, device=self.device)
+        bns = [m for m in self.img_feat_net.modules() if isinstance(m, nn.BatchNorm2d)]
+        saved = [m.momentum for m in bns]
+        for m in bns:
+            m.momentum = 0.0                           # the running statistics move once per chunk: in the second pass
+        try:
+            with torch.no_grad():
+                for lo in range(0, R, C):
+                    feats[lo:lo + C] = self.img_feat_net.forward_raw(self.pool.index_select(0, self.idx_dev[lo:lo + C]))
+        finally:
+            for m, mom in zip(bns, saved):
+                m.momentum = mom
+        self.last_feats = feats
+        if ev: ev[1].record()
+        loss, e_pos, e_neg = ops.joint_loss_raw(self.table, feats, pos_from, pos_to, negc, None, self.K_cone, self.alpha, _lib.ENERGY_HYP_CONE,
+                                                _lib.LABEL_HYP, _lib.IMAGE_SOFTCLIP, self.table_grad, self.gfeat, table_f16=self.table_h)
+        if ev: ev[2].record()
+        for lo in range(0, R, C):
+            f = self.img_feat_net.forward_raw(self.pool.index_select(0, self.idx_dev[lo:lo + C]))
+            f.backward(self.gfeat[lo:lo + C])
+            if self.overlap is not None:
+                self.overlap.join()
+        if ev: ev[3].record()
+        return loss, e_pos, e_neg
+
     def _core(self, ev=None):
         """Forward + fused loss + backward of one step on the static device inputs (codes_dev, idx_dev).  This is the
         region the hipGraph captures."""
+        if self.cnn_chunk is not None:
+            return self._core_chunked(ev)
         codes = self.codes_dev
         pos_from = codes[:, 0].contiguous(); pos_to = codes[:, 1].contiguous(); negc = codes[:, 2:].contiguous()
         images = self.pool.index_select(0, self.idx_dev)
@@ -235,7 +289,7 @@ class StepEngine:
         if ev: ev[1].record()
         loss, e_pos, e_neg = ops.joint_loss_raw(self.table, feats.detach(), pos_from, pos_to, negc, None, self.K_cone,
                                                 self.alpha, _lib.ENERGY_HYP_CONE, _lib.LABEL_HYP, _lib.IMAGE_SOFTCLIP,
-                                                self.table_grad, self.gfeat)
+                                                self.table_grad, self.gfeat, table_f16=self.table_h)
         if ev: ev[2].record()
         feats.backward(self.gfeat)
         if self.overlap is not None:

@@ -141,7 +141,7 @@ class ImageSoftClipFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------------ fused joint loss
 def joint_loss_raw(table, feat, pos_from, pos_to, neg, weights, K_cone, alpha, energy, label_proj, image_proj,
-                   grad_table=None, grad_feat=None):
+                   grad_table=None, grad_feat=None, table_f16=None):
     """One launch of lec_joint_loss_fwd_bwd.  table [N,D], feat [n_feat,D] (or None): contiguous float32; index tensors:
     contiguous int32 device tensors of node codes (>= 0 label row, < 0 feature row -1-code).  Gradients are ADDED into
     grad_table / grad_feat when given (same shapes, contiguous).  Returns (loss[1], e_pos[B], e_neg[B,2K])."""
@@ -179,7 +179,12 @@ def joint_loss_raw(table, feat, pos_from, pos_to, neg, weights, K_cone, alpha, e
     if need < 0:
         check(int(need))
     ws = _workspace(dev, need)
-    check(lib.lec_joint_loss_fwd_bwd(energy, label_proj, image_proj, dptr(table), D, N,
+    fn, tbl = lib.lec_joint_loss_fwd_bwd, table
+    if table_f16 is not None:
+        if table_f16.dtype != torch.float16 or table_f16.shape != table.shape or not table_f16.is_contiguous():
+            raise ValueError('table_f16 must be a contiguous float16 tensor of the table\'s shape')
+        fn, tbl = lib.lec_joint_loss_fwd_bwd_f16, table_f16
+    check(fn(energy, label_proj, image_proj, dptr(tbl), D, N,
                                      dptr(feat), D, n_feat, dptr(pos_from), dptr(pos_to), dptr(neg) if K else None,
                                      dptr(weights), B, K, D, float(K_cone), float(alpha),
                                      dptr(e_pos), dptr(e_neg) if K else None, dptr(loss),
@@ -221,12 +226,20 @@ class JointLossFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------------ table / optimiser steps
 def table_step_adam(table, grad, exp_avg, exp_avg_sq, step, lr, K_cone=0.1, betas=(0.9, 0.999), eps=1e-8,
-                    riemannian=True, clip=True):
-    """oe_h.py:1768-1771 in one pass: grad *= (1/lambda_x)^2 -> Adam -> clip into [r_in, 1-1e-5].  In place."""
+                    riemannian=True, clip=True, table_f16=None):
+    """oe_h.py:1768-1771 in one pass: grad *= (1/lambda_x)^2 -> Adam -> clip into [r_in, 1-1e-5].  In place.
+    table_f16: optional fp16 shadow of the table, refreshed with the updated rows in the same pass (config 5)."""
     for t in (table, grad, exp_avg, exp_avg_sq):
         if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != table.shape:
             raise ValueError('table_step_adam: all buffers must be contiguous float32 of the table\'s shape')
     N, D = table.shape
+    if table_f16 is not None:
+        if table_f16.dtype != torch.float16 or table_f16.shape != table.shape or not table_f16.is_contiguous():
+            raise ValueError('table_f16 must be a contiguous float16 tensor of the table\'s shape')
+        check(lib.lec_table_step_adam_f16(dptr(table), dptr(grad), dptr(exp_avg), dptr(exp_avg_sq), D, N, D, float(lr),
+                                          float(betas[0]), float(betas[1]), float(eps), int(step), float(K_cone or 0.0),
+                                          int(bool(riemannian)), int(bool(clip)), dptr(table_f16), stream_ptr()))
+        return
     check(lib.lec_table_step_adam(dptr(table), dptr(grad), dptr(exp_avg), dptr(exp_avg_sq), D, N, D, float(lr),
                                   float(betas[0]), float(betas[1]), float(eps), int(step), float(K_cone or 0.0),
                                   int(bool(riemannian)), int(bool(clip)), stream_ptr()))
@@ -411,7 +424,9 @@ class BNActFn(torch.autograd.Function):
             nbytes = el * es * ((2 + (1 if dy2 is not None else 0) + 1) + (2 + 1)) + (el // 8 if relu else 0)
         else:            # both passes read dy [+ dy2], x, mask; pass 2 writes dx
             nbytes = el * es * (2 * (2 + (1 if dy2 is not None else 0)) + 1) + (2 * (el // 8) if relu else 0)
+        from .resnet import WgradOverlap as _WO
         lazy = (LAZY_BN_PASS2 and has_res and x.data_ptr() in _LAZY_OK and x.dtype == torch.bfloat16
+                and _WO.instance is not None and _WO.instance.enabled       # the consumer that materialises dx is _OverlapConvFn.backward
                 and lib.lec_conv1x1_wgrad_bnapply_supported(_LAZY_OK[x.data_ptr()], Cc, M))
         _LAZY_OK.pop(x.data_ptr(), None)
         if lazy:

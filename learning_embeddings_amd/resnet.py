@@ -34,7 +34,7 @@ class BatchNormAct2d(nn.BatchNorm2d):
                                           and residual.is_contiguous(memory_format=torch.channels_last)))):
             from . import ops
             ov = WgradOverlap.instance
-            sink = (self.weight, self.bias, ov.reducer) if (ov is not None and ov.enabled and ov.arena is not None and self.training) else None
+            sink = (self.weight, self.bias, ov.reducer) if (ov is not None and ov.enabled and ov.arena is not None and self.training and not ov.accumulate) else None
             return ops.BNActFn.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var,
                                      self.training, self.momentum, self.eps, self.fuse_relu, fork and self.training, sink)
         y = F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, self.training, self.momentum, self.eps)
@@ -63,6 +63,8 @@ class WgradOverlap:
         self.reducer = reducer
         self.arena = arena
         self.enabled = True
+        self.accumulate = False         # True: several backward passes per step (chunked CNN rows): BatchNorm parameter gradients go
+                                        # through autograd's AccumulateGrad (which adds) instead of being written in place
         if reducer is not None and self.side is not None and hasattr(reducer, 'side_streams'):
             reducer.side_streams.append(self.side)
 
@@ -74,10 +76,10 @@ class WgradOverlap:
         w = conv.weight
         if w.grad is None:
             w.grad = gw.to(w.dtype)
-        elif self.arena is not None:
-            w.grad.copy_(gw)                                # each parameter gets exactly one gradient per step: overwrite
         else:
-            w.grad.add_(gw)
+            w.grad.add_(gw)                                 # ADD, like liblecone's own weight-gradient kernels and autograd's AccumulateGrad:
+                                                            # the arena is zeroed at the start of a step, and a step may run several backward
+                                                            # passes (CNN rows processed in chunks)
         if self.reducer is not None:
             self.reducer.mark_ready(w)
 
@@ -255,7 +257,9 @@ class _OverlapConvFn(torch.autograd.Function):
         elif ctx.own and _ops().conv1x1_supported(conv.in_channels, conv.out_channels, x.shape[0] * x.shape[2] * x.shape[3]):
             n, _, h, wd = x.shape
             ops = _ops()
-            if (getattr(conv, 'defer_bn', False) and ops.DEFER_BN_APPLY and x.dtype == torch.bfloat16
+            # (only when the fused BatchNorm op is the one that will consume the unwritten tensor: its stock-torch fallback would read
+            # uninitialised memory)
+            if (getattr(conv, 'defer_bn', False) and ops.DEFER_BN_APPLY and BatchNormAct2d.fused_enabled and x.dtype == torch.bfloat16
                     and ops.conv1x1_bnapply_supported(conv.in_channels, conv.out_channels, n * h * wd)):
                 # conv3 -> bn3: statistics only for now; the BatchNorm runs the product again with its apply pass in the epilogue
                 y = _from_rows(ops.conv1x1_stats_rows(_rows(x), w16.reshape(conv.out_channels, conv.in_channels)), n, h, wd)

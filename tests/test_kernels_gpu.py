@@ -713,3 +713,50 @@ def test_conv3x3_mfma_vs_torch(N, H, W, Cc):
     xr = x.float().requires_grad_(True)
     torch.nn.functional.conv2d(xr, w.float(), padding=1).backward(dy.float())
     assert (gx.float() - xr.grad).abs().max().item() <= 6e-3 * xr.grad.abs().max().item()
+
+
+@pytest.mark.parametrize('B,K,D,N', [(64, 5, 10, 2000), (256, 256, 10, 50000), (32, 16, 128, 5000)])
+def test_joint_loss_fp16_label_table_with_fp32_master(B, K, D, N):
+    """BASELINE.json config 5 ("fp16+fp32-master", SURVEY.md 8(d) s = 2): the fused loss reads the label rows from a 2-byte fp16
+    shadow of the table.  (a) Against the oracle evaluated ON THE fp16-ROUNDED TABLE the kernel is as exact as the fp32 path
+    (energies <= 1e-4 abs): the arithmetic is unchanged, only the stored rows are rounded.  (b) Against the oracle on the fp32
+    master the drift is the fp16 rounding of the rows: tolerance 5e-3 abs on the energies (rows have norm ~0.1: half-ulp 3e-5
+    per element, amplified by the cone angle's conditioning near the apex)."""
+    rs = np.random.RandomState(B + K + D)
+    W = rs.randn(N, D).astype(np.float32); W = W / np.linalg.norm(W, axis=1, keepdims=True) * (0.1 + 0.3 * rs.rand(N, 1)).astype(np.float32)
+    M = 64
+    R = (rs.randn(M, D) * 0.3).astype(np.float32)
+    frm = rs.randint(0, N, B); to = N + rs.randint(0, M, B)
+    neg = np.concatenate([N + rs.randint(0, M, (B, K)), rs.randint(0, N, (B, K))], axis=1)
+    dev = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(DEV) if dt is None else torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to(DEV)
+    code = lambda a: dev(np.where(a >= N, -1 - (a - N), a), np.int32)
+    Wd = dev(W); Wh = Wd.to(torch.float16)
+    gt = torch.zeros_like(Wd); gf = torch.zeros(M, D, device=DEV)
+    loss, e_pos, e_neg = ops.joint_loss_raw(Wd, dev(R), code(frm), code(to), code(neg), None, 0.1, 0.01, _lib.ENERGY_HYP_CONE, _lib.LABEL_HYP,
+                                            _lib.IMAGE_SOFTCLIP, gt, gf, table_f16=Wh)
+    W16 = Wh.float().cpu().numpy()
+    o16 = O.joint_loss_fwd_bwd(W16, R, frm, to, neg, 0.01, 0.1)
+    o32 = O.joint_loss_fwd_bwd(W, R, frm, to, neg, 0.01, 0.1)
+    assert np.abs(e_pos.cpu().numpy() - o16[1]).max() <= 1e-4 and np.abs(e_neg.cpu().numpy() - o16[2]).max() <= 1e-4
+    assert abs(loss.item() - o16[0]) <= 1e-4 * max(1.0, abs(o16[0]))
+    gs = np.abs(o16[3]).max() + 1e-12
+    assert np.abs(gt.cpu().numpy() - o16[3]).max() <= 5e-3 * gs
+    assert np.abs(e_pos.cpu().numpy() - o32[1]).max() <= 5e-3 and np.abs(e_neg.cpu().numpy() - o32[2]).max() <= 5e-3
+
+
+def test_table_step_refreshes_the_fp16_shadow():
+    """lec_table_step_adam_f16: the fp32 master, the Adam moments are bit-identical to the plain table step, and the shadow
+    is the updated, clipped master rounded to fp16."""
+    rs = np.random.RandomState(3)
+    N, D = 5000, 10
+    W = rs.randn(N, D).astype(np.float32); W = W / np.linalg.norm(W, axis=1, keepdims=True) * (0.05 + 0.9 * rs.rand(N, 1)).astype(np.float32)
+    G = rs.randn(N, D).astype(np.float32)
+    a = [torch.from_numpy(W.copy()).to(DEV), torch.from_numpy(G).to(DEV), torch.zeros(N, D, device=DEV), torch.zeros(N, D, device=DEV)]
+    b = [t.clone() for t in a]
+    sh = torch.zeros(N, D, dtype=torch.float16, device=DEV)
+    for step in (1, 2):
+        ops.table_step_adam(a[0], a[1], a[2], a[3], step, 1e-2, 0.1)
+        ops.table_step_adam(b[0], b[1], b[2], b[3], step, 1e-2, 0.1, table_f16=sh)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.equal(sh, b[0].to(torch.float16))
