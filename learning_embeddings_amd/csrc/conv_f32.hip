@@ -593,7 +593,9 @@ extern "C" int lec_conv_f32_wgrad(const float* dy, const float* x, int N, int H,
   g.chunks_per_split = (nchunks + split - 1) / split;
   split = (nchunks + g.chunks_per_split - 1) / g.chunks_per_split;
   g.tiles = tiles; g.split = split;
-  const size_t lds = (size_t)2 * WBK * (BM + BN) * 4;
+  size_t lds = (size_t)2 * WBK * (BM + BN) * 4;
+  static const int wg_lds_pad = [] { const char* e = getenv("LEC_WGRAD_LDS_PAD"); return e ? atoi(e) : 0; }();   // experiments: residency of this kernel
+  lds += (size_t)wg_lds_pad;
   static const int wg_cap = [] { const char* e = getenv("LEC_WGRAD_WGS"); const int v = e ? atoi(e) : (1 << 30); return v > 0 ? v : (1 << 30); }();
   const int total = tiles * split;
   const dim3 grid(total < wg_cap ? total : wg_cap), blk(kCfThreads);

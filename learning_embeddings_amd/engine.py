@@ -313,6 +313,8 @@ class StepEngine:
             ops.CONV_TIMER = None
             g = torch.cuda.CUDAGraph()
             # thread_local: RCCL's watchdog thread polls events while we capture; only THIS thread's calls may fail the capture
+            # (capturing the main chain on a HIGH-priority stream, so that its nodes outrank the side stream's weight gradients, was
+            # measured on the fp32 step: 171 ms against 157 ms -- dropped)
             with torch.cuda.graph(g, capture_error_mode='thread_local'):
                 out = self._core(None)
             torch.cuda.synchronize()
