@@ -418,8 +418,21 @@ def main():
             for tag, (b_, k_, d_, n_) in {'cfg5_B256_K256_D10': (256, 256, 10, 50000), 'B256_K256_D128': (256, 256, 128, 50000),
                                           'B4096_K256_D10': (4096, 256, 10, 50000)}.items():
                 r = bench_cone.time_joint(b_, k_, d_, n_, b_, iters=30)
+                t_s = r['us'] * 1e-6
+                # the bounds the launch actually sits under: the table (2 MB at D = 10, 25.6 MB at D = 128) lives in L2 / Infinity Cache,
+                # so its rows are GATHERED from cache (MI355X_MICROARCH.md "Indexed rows": 16.8 TB/s from L2, 8.6 TB/s from the Infinity
+                # Cache), and the gradient rows leave as scattered float atomics (chip-wide 1.3 TB/s for whole-row segments)
+                gather_b = b_ * (2 + 2 * k_) * d_ * 4 * 2                  # rows read by the forward and again by the backward half
+                atomic_b = b_ * (2 + 2 * k_) * d_ * 4
+                tbl_mb = n_ * d_ * 4 / 1e6
+                g_peak = 16800.0 if tbl_mb <= 4.0 else 8600.0
                 st[tag] = {'bound': 'hbm', 'achieved': round(r['GBps'], 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(r['GBps'] / 8000.0, 4),
-                           'traffic': None, 'avg_launch_us': round(r['us'], 1), 'pairs': r['pairs'], 'alg_bytes_per_launch': int(r['alg_MB'] * 1e6)}
+                           'traffic': None, 'avg_launch_us': round(r['us'], 1), 'pairs': r['pairs'], 'alg_bytes_per_launch': int(r['alg_MB'] * 1e6),
+                           'second_bounds': {
+                               'cache_gather': {'achieved': round(gather_b / t_s / 1e9, 1), 'peak': g_peak, 'unit': 'GB/s', 'frac': round(gather_b / t_s / 1e9 / g_peak, 4),
+                                                'note': 'table of %.1f MB resident in %s' % (tbl_mb, 'L2' if tbl_mb <= 4.0 else 'the Infinity Cache')},
+                               'float_atomics': {'achieved': round(atomic_b / t_s / 1e9, 1), 'peak': 1300.0, 'unit': 'GB/s', 'frac': round(atomic_b / t_s / 1e9 / 1300.0, 4)},
+                               'launch_floor_us': 16.5, 'note': 'forward-only launch of the cfg5 shape: 16.5 us (tools/sweep_cone.py) -- three dependent cache round trips + the deterministic loss reduction; the launch is latency-bound, none of the throughput bounds is near'}}
             out['roofline_stress'] = st
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(eng)

@@ -99,6 +99,14 @@ struct ActGeo {
   FastDiv dWm, dHm, dnb;                   // divisions by Wm, Hm, nb
 };
 
+// One dword of a k-slow LDS tile: per-lane base + a compile-time row offset.  Volatile on purpose: it keeps the access a single
+// ds_read_b32 with a 16-bit immediate offset; left to itself the compiler pairs two rows into ds_read2_b32, whose 8-bit offsets cannot
+// span a row, and spends a VALU add per pair on a new base -- vector instructions the f32 MFMA loop cannot hide.
+typedef __attribute__((address_space(3))) const volatile float lds_cvfloat;
+__device__ __forceinline__ float lds_ld1(const float* base, int elem_off) {
+  return *((lds_cvfloat*)base + elem_off);                    // explicit LDS address space: a volatile GENERIC access would become flat_load
+}
+
 // MFMAs of one K chunk on the workgroup's LDS tiles.  sA: [BM][kCfLdk] (A_KC) or [32][LDA] (k slow); sB likewise.
 template <bool A_KC, bool B_KC, int LDA, int LDB, int TM, int TN, int BKT = kCfBK>
 __device__ __forceinline__ void mma_chunk(const float* __restrict__ sA, const float* __restrict__ sB, int wm0, int wn0, int lane,
@@ -114,7 +122,7 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ sA, const fl
         a[it][0] = v[0]; a[it][1] = v[1]; a[it][2] = v[2]; a[it][3] = v[3];
       } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) a[it][t] = sA[(8 * q + 4 * h + t) * LDA + wm0 + it * 32 + l31];
+        for (int t = 0; t < 4; ++t) a[it][t] = lds_ld1(sA + 4 * h * LDA + wm0 + it * 32 + l31, (8 * q + t) * LDA);
       }
     }
 #pragma unroll
@@ -124,7 +132,7 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ sA, const fl
         b[it][0] = v[0]; b[it][1] = v[1]; b[it][2] = v[2]; b[it][3] = v[3];
       } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) b[it][t] = sB[(8 * q + 4 * h + t) * LDB + wn0 + it * 32 + l31];
+        for (int t = 0; t < 4; ++t) b[it][t] = lds_ld1(sB + 4 * h * LDB + wn0 + it * 32 + l31, (8 * q + t) * LDB);
       }
     }
 #pragma unroll
@@ -210,20 +218,28 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
         for (int r = 0; r < 16; ++r) acc[it][jt][r] = 0.f;
 
     f32x4v ra[NA], rb[NB];
+    unsigned cur[NA];                                           // byte offset of this thread's A pieces at channel 0 of the CURRENT tap (kOob: no such pixel)
+    int cur_tap = -1;
     auto load_chunk = [&](int ch) {
       const int k0 = ch * kCfBK;
       if (!TAPV) {
-        // the whole chunk lies in one tap: wave-uniform (scalar) decode
+        // the whole chunk lies in one tap: wave-uniform (scalar) decode; the per-row select runs once per TAP, a chunk adds a scalar
         const int tap = k0 >> g.lgCs, c0 = k0 & (g.Cs - 1);
         const int ta = fdiv(tap, g.dnb), tb = tap - ta * g.nb;
-        const int coff = ((((g.sg * ta) * g.Ws + g.sg * tb) << g.lgCs) + c0) * 4;
-        const unsigned tapbit = 1u << tap;
+        if (tap != cur_tap) {
+          cur_tap = tap;
+          const int toff = (((g.sg * ta) * g.Ws + g.sg * tb) << g.lgCs) * 4;
+          const unsigned tapbit = 1u << tap;
+#pragma unroll
+          for (int u = 0; u < NA; ++u) cur[u] = (tapmask[u] & tapbit) ? (unsigned)(rowoff[u] + toff) : kOob;
+        }
         const int tw = (g.r0 + g.rstep * ta) * g.S + g.s0 + g.sstep * tb;
         const unsigned wsc = (unsigned)(B_KC ? tw * g.Cin + c0 : c0 * rsc + tw * g.Cin) * 4u;
+        const unsigned c0b = (unsigned)c0 * 4u;
 #pragma unroll
-        for (int u = 0; u < NA; ++u) ra[u] = bload4(rs_src, (tapmask[u] & tapbit) ? (unsigned)(rowoff[u] + coff) : kOob);
+        for (int u = 0; u < NA; ++u) ra[u] = bload4(rs_src, cur[u] + c0b);         // (a poisoned offset stays out of range: c0b < 2^14)
 #pragma unroll
-        for (int u = 0; u < NB; ++u) rb[u] = bload4(rs_wgt, wB[u] + wsc);          // (a poisoned base stays out of range: wsc < 2^30)
+        for (int u = 0; u < NB; ++u) rb[u] = bload4(rs_wgt, wB[u] + wsc);          // (likewise: wsc < 2^30)
         return;
       }
       // one tap / channel position per 16-byte piece (the stem: 4 source channels, 8 taps per chunk)

@@ -422,9 +422,12 @@ static bool joint_geometry(int B, int K, int D, JointGeom& g) {
   }
   const int ppw = 64 / g.T, NP = 1 + 2 * K;
   const int64_t group_iters = (NP + ppw - 1) / ppw;                      // wave iterations one group needs
-  // aim for ~6k waves (a few residency rounds of 256 CUs x 4 SIMDs) but never more than 8 iterations per task
-  int64_t iters = ((int64_t)B * group_iters + 6143) / 6144;
-  if (iters > 8) iters = 8;
+  // aim for ~1.5k waves, never more than 6 iterations per task.  (Round 1 aimed for 6k waves / at most 8 iterations; a sweep on the
+  // MI355X -- B x K x D = 256 x 256 x 10: 34.0 us at 2 304 waves, 20.1 at 1 152; 1 024 x 256 x 10: 57.5 -> 33.8 us; 4 096 x 256 x 10:
+  // 131.8 us at 8 iterations, 119.5 at 6 -- shows the per-wave fixed work (u_b / v_b projection, the block's loss partial and ticket)
+  // outweighing the extra residency rounds.)
+  int64_t iters = ((int64_t)B * group_iters + 1535) / 1536;
+  if (iters > 6) iters = 6;
   if (iters > group_iters) iters = group_iters;
   if (iters < 1) iters = 1;
   if (iters_override > 0) iters = iters_override;
