@@ -379,6 +379,26 @@ int lec_conv_f32_wgrad(const float* dy, const float* x, int N, int H, int W, int
                        float* dw, lec_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * (7c) The same fp32 convolutions on the bf16 matrix cores (csrc/conv_f32x3.hip): every fp32 operand is cut into three bf16
+ *     pieces (x = h + m + l exactly) and every product into the six bf16 products above 2^-24 of it, each exact in the MFMA's
+ *     fp32 accumulation: fp32-grade results (an fp32 dot product's error; tests measure it against fp64 next to (7b)) at 2.67x
+ *     the matrix rate of the f32-input instruction.  Same tensors, shapes and semantics as (7b); replaces the same reference
+ *     lines (oe_h.py:311,317,:331-378).  The weights arrive pre-split:
+ *     lec_conv_f32x3_split_weights: w [Cout][R*S][Cin] fp32 -> planes_fwd (the forward GEMM's operand) and / or planes_t (the data
+ *       gradient's), bf16 bit patterns in the kernels' tile-major order [column tile][k chunk][h | m | l][rows][16 k];
+ *       lec_conv_f32x3_planes_elems(Cout, RS, Cin, transposed) elements each; either pointer may be NULL.  Run it after every
+ *       optimizer step.
+ *     lec_conv_f32x3_fwd takes planes_fwd, lec_conv_f32x3_dgrad takes planes_t (Cout % 32 == 0), lec_conv_f32x3_wgrad takes the
+ *       fp32 tensors themselves (dw +=, float atomics, as in (7b)).
+ * ------------------------------------------------------------------------------------------------------------- */
+int64_t lec_conv_f32x3_planes_elems(int Cout, int RS, int Cin, int transposed);
+int lec_conv_f32x3_split_weights(const float* w, int Cout, int RS, int Cin, uint16_t* planes_fwd, uint16_t* planes_t, lec_stream_t stream);
+int lec_conv_f32x3_fwd(const float* x, const uint16_t* w_planes, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                       float* y, float* partials, int64_t partials_bytes, int* n_partials, lec_stream_t stream);
+int lec_conv_f32x3_dgrad(const float* dy, const uint16_t* w_planes_t, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                         float* dx, lec_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * (8) 3x3 / stride 2 / pad 1 max pooling on NHWC bf16 (the ResNet stem's `maxpool`, oe_h.py:311 -> torchvision).
  *     x: [N, H, W, C] bf16 (H, W even, C % 8 == 0); y: [N, H/2, W/2, C]; argmax: one byte per pooled element (window
  *     position kh*3+kw; first maximum wins, NaN propagates, like the framework op).  Backward is a gather over the <= 4

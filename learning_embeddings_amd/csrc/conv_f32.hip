@@ -33,71 +33,10 @@
 // loop over their m-tiles and keep per-channel sum / sum of squares in registers, so the statistics pass over Y disappears.
 //
 // Roofline: MFMA (f32).  Algorithmic flops 2*M*N*K per launch; bytes are noise except for layer1's 1x1 layers.
-#include <cstdlib>
-#include "lec_common.h"
+#include "conv_geo.h"
 
 namespace lec {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-typedef int i32x4v __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4r __attribute__((__vector_size__(4 * sizeof(unsigned int))));
-
-constexpr int kCfBK = 32;                 // K chunk (floats)
-constexpr int kCfLdk = kCfBK + 4;         // row stride of a k-contiguous LDS tile: 144 B, conflict-free ds_read_b128
-constexpr int kCfKQ = kCfBK / 4;          // 16-byte pieces per k-contiguous row
-constexpr int kCfRP = 256 / kCfKQ;        // rows staged per pass of the 256 threads
-constexpr int kCfThreads = 256;
-constexpr int kCfMaxPart = 512;           // = kBnMaxBlocks: statistics partial rows
-#ifndef LEC_WG_BK
-#define LEC_WG_BK 16
-#endif
-constexpr int kWgBK = LEC_WG_BK;          // K chunk of the weight gradient (pixels): 16 -> 40 KB of LDS per workgroup
-constexpr unsigned kOob = 0x80000000u;    // a byte offset no tensor reaches (num_records < 2^31): the load returns zeros, the store is dropped
-
-// exact unsigned division by a launch-invariant divisor (Granlund-Montgomery round-up form: exact for every 32-bit dividend)
-struct FastDiv { uint32_t mul, sh1, sh2, d; };
-static inline FastDiv make_fastdiv(int d_) {
-  FastDiv f; const uint32_t d = (uint32_t)(d_ < 1 ? 1 : d_); f.d = d;
-  uint32_t l = 0; while ((1ull << l) < d) ++l;
-  f.mul = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - d)) / d + 1);
-  f.sh1 = l < 1 ? l : 1; f.sh2 = l > 0 ? l - 1 : 0;
-  return f;
-}
-__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
-  const uint32_t t = __umulhi(f.mul, (uint32_t)n);
-  return (int)((t + (((uint32_t)n - t) >> f.sh1)) >> f.sh2);
-}
-
-// raw buffer resource over [p, p + bytes): stride 0, hardware range check on the byte offset
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-__device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ f32x4v bload4(rsrc_t rsrc, unsigned voff) {
-  const u32x4r v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0);
-  return __builtin_bit_cast(f32x4v, v);
-}
-__device__ __forceinline__ void bstore1(float v, rsrc_t rsrc, unsigned voff) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)voff, 0, 0);
-}
-
-// geometry of an "activation-gather" GEMM (forward, or one parity class of a data gradient)
-struct ActGeo {
-  int Mg;                                  // GEMM rows = pixels of the m-space
-  int Hm, Wm;                              // m-space grid per image: m = (n * Hm + mh) * Wm + mw
-  int Hs, Ws, Cs, lgCs;                    // gathered source tensor [N, Hs, Ws, Cs]; Cs a power of two
-  int sst;                                 // source position of tap (a, b): (mh * sst + oh0 + sg * a, mw * sst + ow0 + sg * b)
-  int oh0, ow0, sg;
-  int na, nb;                              // taps per dimension of this launch (K = na * nb * Cs)
-  int r0, rstep, s0, sstep, S, RS;         // weight tap of (a, b): (r0 + rstep * a) * S + s0 + sstep * b
-  int Cd;                                  // GEMM columns = channels of the destination
-  int Cin;                                 // the layer's input channels (innermost weight dimension)
-  int Hd, Wd, dst_st, dph, dpw;            // destination pixel of m: (n, mh * dst_st + dph, mw * dst_st + dpw) of [N, Hd, Wd, Cd]
-  int Kg;                                  // na * nb * Cs
-  uint32_t src_bytes, wgt_bytes, dst_bytes;
-  FastDiv dWm, dHm, dnb;                   // divisions by Wm, Hm, nb
-};
 
 // One dword of a k-slow LDS tile: per-lane base + a compile-time row offset.  Volatile on purpose: it keeps the access a single
 // ds_read_b32 with a 16-bit immediate offset; left to itself the compiler pairs two rows into ds_read2_b32, whose 8-bit offsets cannot
@@ -361,15 +300,6 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
 // weight gradient: A[co][k = pixel] = dY (k slow), B[k = pixel][(tap, ci)] = X gathered (k slow); split over K, float atomics.
 // The tile is 64 (co) x 256 (tap, ci): a 256-wide B row is ONE wave-instruction (64 lanes x 16 bytes), so the pixel a piece
 // belongs to is wave-uniform and its decode runs on the scalar ALU; per lane only the (static) tap of its four columns matters.
-struct WgGeo {
-  int Mpix;                                // N * Ho * Wo
-  int Ho, Wo, H, W, Cin, lgCin, Cout;
-  int S, RS, stride, pad;
-  int Ng;                                  // RS * Cin
-  int chunks_per_split, tiles, split;
-  uint32_t dy_bytes, x_bytes;
-  FastDiv dWo, dHo, dS;
-};
 
 template <int WM, int WN, int TM, int TN, int WBK, bool DENSE>
 __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -490,9 +420,6 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const flo
   }   // work items
 }
 
-static int ilog2_exact(int v) {
-  int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1;
-}
 
 template <bool B_KC, bool STATS>
 static int launch_act(const float* src, const float* wgt, float* dst, const ActGeo& g, float* part, int* nparts, hipStream_t st) {
@@ -520,18 +447,6 @@ static int launch_act(const float* src, const float* wgt, float* dst, const ActG
   return LEC_OK;
 }
 
-static int conv_check(const char* who, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad) {
-  LEC_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && (stride == 1 || stride == 2) && pad >= 0 && pad < R && pad < S,
-                "%s: bad geometry N=%d H=%d W=%d Cin=%d Cout=%d R=%d S=%d stride=%d pad=%d", who, N, H, W, Cin, Cout, R, S, stride, pad);
-  LEC_CHECK_ARG(Cin % 4 == 0 && ilog2_exact(Cin) >= 2, "%s: Cin must be a power of two >= 4 (pad the stem's 3 channels to 4), got %d", who, Cin);
-  LEC_CHECK_ARG(Cout % 4 == 0 && ilog2_exact(Cout) >= 2, "%s: Cout must be a power of two >= 4, got %d", who, Cout);
-  const int64_t Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
-  LEC_CHECK_ARG(Ho > 0 && Wo > 0, "%s: empty output", who);
-  // 32-bit byte offsets with the top bit reserved for "out of range"
-  LEC_CHECK_ARG((int64_t)N * H * W * Cin * 4 < (1ll << 31) && (int64_t)N * Ho * Wo * Cout * 4 < (1ll << 31) && (int64_t)Cout * R * S * Cin * 4 < (1ll << 30),
-                "%s: a tensor of this layer reaches 2 GiB (N=%d H=%d W=%d Cin=%d Cout=%d): split the batch", who, N, H, W, Cin, Cout);
-  return LEC_OK;
-}
 
 }  // namespace lec
 

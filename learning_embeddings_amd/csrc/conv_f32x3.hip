@@ -1,0 +1,560 @@
+// fp32 convolutions on the bf16 matrix pipe: every fp32 operand is cut into three bf16 pieces and every fp32 product into six
+// bf16 products that the matrix cores compute EXACTLY, accumulated in fp32.
+//
+// Why.  The reference computes its ResNet in plain fp32 (oe_h.py:281-328 / :331-378).  On gfx950 the f32-input MFMA
+// (conv_f32.hip) runs on the vector ALUs at the fp32 vector rate, 157 TFLOP/s; the matrix cores proper take 16-bit inputs at
+// 2.5 PFLOP/s.  An fp32 number has 24 significand bits = three bf16 significands (8 bits each, same exponent range):
+//     x = h + m + l,   h = trunc_bf16(x),  m = trunc_bf16(x - h),  l = x - h - m      (exact: every step is exact in fp32)
+// and  a * b = ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh) + O(2^-24 |a b|).
+// A bf16 x bf16 product has 16 significant bits, so each of the six products is exact in the MFMA's fp32 accumulation; the three
+// dropped products (am*bl, al*bm, al*bl) are below 2^-23 of the product, the size of ONE fp32 rounding of it.  The result carries
+// the error of an fp32 dot product (tests/test_fp32_gpu.py measures it against fp64 next to the native-fp32 kernel's), at 6 bf16
+// MFMAs per 16 k instead of 8 f32 MFMAs of twice the duration: 2.67x the matrix throughput at equal clocks.
+//
+// Layout.  The same implicit GEMMs, geometry structs and launch decomposition as conv_f32.hip.  Differences:
+//   * weights arrive PRE-SPLIT (lec_conv_f32x3_split_weights, once per optimizer step and layer): three bf16 planes in the forward
+//     layout [Cout][R*S][Cin] and three in the data-gradient layout [R*S][Cin][Cout], so that the B operand is k-contiguous in
+//     both directions and travels global -> LDS untouched (16-byte pieces of 8 bf16);
+//   * activations / output gradients are loaded as fp32 (16-byte buffer loads, hardware range check = padding zeros), split in
+//     registers -- 4 vector instructions per element + 3 v_perm per pair, which the bf16 MFMA (unlike the f32 one) executes
+//     beside -- and stored as three bf16 planes;
+//   * LDS: planes of [rows][16 k] bf16, 48-byte rows (32 data + 16 pad: conflict-free ds_read_b128 for 16 consecutive rows),
+//     K advances 16 per chunk = one MFMA step, double-buffered, one barrier per chunk; 128 x 128 tile: 2 x 36 KB, two
+//     workgroups per CU;
+//   * the weight gradient transposes while it splits: a thread loads the SAME four channels of consecutive pixels and packs
+//     pixel pairs into dwords, so the LDS image is [channel][16 pixels] and both operands are read with ds_read_b128.
+// Roofline: MFMA (bf16 dense, 2.5 PFLOP/s) on 6x the algorithmic flops.
+#include <type_traits>
+#include "conv_geo.h"
+
+namespace lec {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int kX3BK = 16;                 // K chunk = one v_mfma_f32_32x32x16_bf16 step
+constexpr int kX3Row = 32;                // bytes of an LDS row of one plane (16 bf16, no padding: see x3_half)
+constexpr int kX3Threads = 512;           // 4 consumer + 4 producer waves
+#ifndef LEC_X3_PRIO
+#define LEC_X3_PRIO 1
+#endif
+#ifndef LEC_X3_DBG
+#define LEC_X3_DBG 0                      // experiments (wrong results): 1 no split arithmetic, 2 producers idle, 4 no MFMAs, 8 no fragment reads
+#endif
+constexpr int kX3KQ = kX3BK / 4;          // 16-byte fp32 pieces per row of an activation tile
+constexpr int kX3RP = kCfThreads / kX3KQ; // rows staged per pass
+
+// Pre-split weights are stored TILE-MAJOR: [n tile][k chunk][plane h|m|l][BN rows][16 k] bf16, so that the B operand of one step is one
+// contiguous block of 3 * BN * 32 bytes (full cache lines, read once) in exactly the order of its LDS image.  BN = x3_bn(columns).
+struct X3Wgt { int KC; };                 // k chunks per n tile
+static inline int x3_bn(int cols) { return cols <= 64 ? 64 : 128; }
+
+// high halves of two fp32 words -> one dword of two bf16 (truncation): lo -> bits 0..15, hi -> bits 16..31
+__device__ __forceinline__ unsigned pack_hi16(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+
+// x[0..3] -> three planes of 4 bf16 (2 dwords each); x = h + m + l exactly
+__device__ __forceinline__ void split4(const f32x4v x, u32x2v& h, u32x2v& m, u32x2v& l) {
+  unsigned xb[4], rb[4], lb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float xt = x[t];                                     // (a scalar copy: __builtin_bit_cast applied to the vector ELEMENT reads element 0)
+    xb[t] = __float_as_uint(xt);
+    const float r = xt - __uint_as_float(xb[t] & 0xffff0000u);
+    rb[t] = __float_as_uint(r);
+    const float lo = r - __uint_as_float(rb[t] & 0xffff0000u);
+    lb[t] = __float_as_uint(lo);
+  }
+  h[0] = pack_hi16(xb[0], xb[1]); h[1] = pack_hi16(xb[2], xb[3]);
+  m[0] = pack_hi16(rb[0], rb[1]); m[1] = pack_hi16(rb[2], rb[3]);
+  l[0] = pack_hi16(lb[0], lb[1]); l[1] = pack_hi16(lb[2], lb[3]);
+}
+
+// the six products of one 32 x 32 x 16 step, small terms first
+__device__ __forceinline__ f32x16 mma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+  return c;
+}
+
+// LDS image of one operand plane: [rows][16 k] bf16 = 32-byte rows, NO padding; the two 16-byte halves of a row are swapped on
+// rows with bit 3 set.  Reads (ds_read_b128, 16 consecutive rows per quarter-wave at the same half) then touch every bank once,
+// and so do the writes (8 consecutive rows per 256 bytes).
+__device__ __forceinline__ int x3_half(int row, int half) { return (half ^ ((row >> 3) & 1)) << 4; }
+
+// Workgroup barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) (vmcnt / expcnt left alone: the producers' global loads stay in
+// flight), through the builtins so that the compiler's own wait-count bookkeeping sees the counter drained.
+__device__ __forceinline__ void x3_barrier() {
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_s_barrier();
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+
+template <int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void x3_read_frags(const char* __restrict__ sA, const char* __restrict__ sB, int wm0, int wn0, int lane,
+                                              bf16x8 (&a)[TM][3], bf16x8 (&b)[TN][3]) {
+  const int l31 = lane & 31, hs = x3_half(l31, lane >> 5);
+#pragma unroll
+  for (int it = 0; it < TM; ++it)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) a[it][p] = *(const bf16x8*)(sA + (p * BM + wm0 + it * 32 + l31) * kX3Row + hs);
+#pragma unroll
+  for (int jt = 0; jt < TN; ++jt)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) b[jt][p] = *(const bf16x8*)(sB + (p * BN + wn0 + jt * 32 + l31) * kX3Row + hs);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward / data gradient.  A = gathered fp32 activations (split on the way to LDS), B = pre-split bf16 weights, k contiguous.
+// A workgroup is 8 waves, one per role and SIMD: waves 0-3 (consumers) own the accumulators -- per step 12 ds_read_b128 of the NEXT
+// chunk's fragments and the 24 MFMAs of the current one, nothing else; waves 4-7 (producers) fetch (two chunks ahead), split and
+// store.  The producers' vector instructions execute beside the consumers' MFMAs on the same SIMD, which is what the bf16 matrix
+// pipe (unlike the f32 one) allows; one barrier per step couples the two.
+//   step t:   producers: split chunk t -> LDS stage t & 1, issue the loads of chunk t + 2
+//             consumers: fragments of chunk t - 1 <- LDS stage (t - 1) & 1;  MFMAs of chunk t - 2 (fragments read one step ago)
+// Chunks number through the workgroup's m-tiles without a break, so the producers run ahead into the next tile while the
+// consumers store the finished one.
+template <int WM, int WN, int TM, int TN, bool STATS, bool TAPV>
+__global__ __launch_bounds__(kX3Threads) void conv_f32x3_act_kernel(const float* __restrict__ src, const uint16_t* __restrict__ wpl,
+                                                                    float* __restrict__ dst, ActGeo g, X3Wgt wg, float* __restrict__ part) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  static_assert(WM * WN == 4, "four consumer waves per workgroup");
+  constexpr int NA = BM / kX3RP;                               // fp32 pieces of the A tile per producer thread
+  constexpr int NBP = 6 * BN;                                  // 16-byte bf16 pieces of the B tile: 3 planes x BN rows x 2 halves
+  constexpr int NB = (NBP + kCfThreads - 1) / kCfThreads;
+  constexpr int SA = 3 * BM * kX3Row, SBUF = 3 * (BM + BN) * kX3Row;   // bytes
+  extern __shared__ __attribute__((aligned(16))) char smem_x3[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= 4;
+  const int n0 = blockIdx.y * BN;
+  const int nchunks = (g.Kg + kX3BK - 1) / kX3BK;
+  const int mtiles = (g.Mg + BM - 1) / BM;
+  const int ntl = (int)blockIdx.x < mtiles ? (mtiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;   // m-tiles of this workgroup
+  const int Q = ntl * nchunks;                                 // chunks of this workgroup
+  const int T = (Q + 2 + 3) & ~3;                              // steps, a multiple of the unroll factors of both roles (4 and 2)
+
+  if (producer) {
+    if (Q == 0) return;
+    if (LEC_X3_PRIO) __builtin_amdgcn_s_setprio(LEC_X3_PRIO);  // the second-dispatched half of a workgroup loses the VALU arbitration otherwise
+    const int ptid = tid & (kCfThreads - 1);
+    const int kqA = ptid & (kX3KQ - 1), rowA = ptid / kX3KQ;
+    const rsrc_t rs_src = make_rsrc(src, g.src_bytes), rs_wgt = make_rsrc(wpl, g.wgt_bytes);
+    // B pieces of this thread: 16-byte piece v of a chunk's contiguous block [plane][row][half] -> the same place of the LDS image
+    unsigned vB[NB], ldsB[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int v = ptid + kCfThreads * u;
+      const int pl = v / (2 * BN), rem = v - pl * 2 * BN, row = rem >> 1, half = rem & 1;
+      vB[u] = v < NBP ? (unsigned)v * 16u : kOob;
+      ldsB[u] = (unsigned)(SA + (pl * BN + row) * kX3Row + x3_half(row, half));
+    }
+    const unsigned wtile = (unsigned)blockIdx.y * (unsigned)wg.KC;        // first chunk block of this column tile
+    const unsigned ldsA = (unsigned)(rowA * kX3Row + x3_half(rowA, kqA >> 1) + 8 * (kqA & 1));   // (rows rowA + 64 u share bit 3)
+    const int ntaps = g.na * g.nb;
+    // A stream: the chunk pair to fetch next and its tile's row geometry.  Activations are fetched 32 channels (one 128-byte line per
+    // pixel) at a time -- the two 16-channel chunks of a pair -- so that no line is requested from L2 twice.
+    int a_ch = 0, a_mt = blockIdx.x, cur_tap = -1;
+    int b_ch = 0;                                               // B stream (does not depend on the m-tile)
+    int rowoff[NA]; unsigned tapmask[NA]; int hb[NA], wb[NA], pixn[NA];
+    unsigned cur[NA];
+    f32x4v ra[2][NA][2]; u32x4v rb[4][NB];
+    auto tile_setup = [&](int mt) __attribute__((always_inline)) {
+      const int m0 = mt * BM;
+#pragma unroll
+      for (int u = 0; u < NA; ++u) {
+        const int m = m0 + rowA + kX3RP * u;
+        const bool live = m < g.Mg;
+        const int mm = live ? m : 0;
+        const int t2 = fdiv(mm, g.dWm); const int mw = mm - t2 * g.Wm; const int n = fdiv(t2, g.dHm); const int mh = t2 - n * g.Hm;
+        hb[u] = mh * g.sst + g.oh0; wb[u] = mw * g.sst + g.ow0; pixn[u] = live ? n * g.Hs * g.Ws : -1;
+        rowoff[u] = (((n * g.Hs + hb[u]) * g.Ws + wb[u]) << g.lgCs) * 4 + 16 * kqA;
+        unsigned msk = 0;
+        if (!TAPV) {
+          for (int t = 0; t < ntaps; ++t) {
+            const int ta = fdiv(t, g.dnb), tb = t - ta * g.nb;
+            const int hs = hb[u] + g.sg * ta, ws = wb[u] + g.sg * tb;
+            msk |= ((unsigned)hs < (unsigned)g.Hs && (unsigned)ws < (unsigned)g.Ws ? 1u : 0u) << t;
+          }
+        }
+        tapmask[u] = live ? msk : 0u;
+      }
+      cur_tap = -1;
+    };
+    // chunks a_c, a_c + 1 (the same tap: source channels are a multiple of 32) -> ra[DSET][u][0 | 1]
+    auto issueA = [&](auto dset_c) __attribute__((always_inline)) {
+      constexpr int DSET = decltype(dset_c)::value;
+      if (a_ch == 0) tile_setup(a_mt);                          // (past the last tile every row is dead: the loads fall out of range)
+      const int k0 = a_ch * kX3BK;
+      const int tap = k0 >> g.lgCs, c0 = k0 & (g.Cs - 1);
+      if (tap != cur_tap) {
+        cur_tap = tap;
+        const int ta = fdiv(tap, g.dnb), tb = tap - ta * g.nb;
+        const int toff = (((g.sg * ta) * g.Ws + g.sg * tb) << g.lgCs) * 4;
+        const unsigned tapbit = 1u << tap;
+#pragma unroll
+        for (int u = 0; u < NA; ++u) cur[u] = (tapmask[u] & tapbit) ? (unsigned)(rowoff[u] + toff) : kOob;
+      }
+      const unsigned c0b = (unsigned)c0 * 4u;
+#pragma unroll
+      for (int u = 0; u < NA; ++u) {
+        ra[DSET][u][0] = bload4(rs_src, cur[u] + c0b);          // (a poisoned offset stays out of range: c0b < 2^14)
+        ra[DSET][u][1] = bload4(rs_src, cur[u] + c0b + 64u);
+      }
+      a_ch += 2;
+      if (a_ch >= nchunks) { a_ch = 0; a_mt += gridDim.x; }
+    };
+    // the stem (4 source channels, 4 taps per chunk): one chunk, one tap per 16-byte piece -> ra[DSET][u][HALF]
+    auto issueA_tapv = [&](auto dset_c, auto half_c) __attribute__((always_inline)) {
+      constexpr int DSET = decltype(dset_c)::value, HALF = decltype(half_c)::value;
+      if (a_ch == 0) tile_setup(a_mt);
+      const int kA = a_ch * kX3BK + 4 * kqA;
+      const int tapA = kA >> g.lgCs, cA = kA & (g.Cs - 1);
+      const int ta2 = fdiv(tapA, g.dnb), tb2 = tapA - ta2 * g.nb;
+      const int dh = g.sg * ta2, dw = g.sg * tb2;
+      const bool tap_ok = tapA < ntaps;
+#pragma unroll
+      for (int u = 0; u < NA; ++u) {
+        const int hs = hb[u] + dh, ws = wb[u] + dw;
+        const bool ok = tap_ok && pixn[u] >= 0 && (unsigned)hs < (unsigned)g.Hs && (unsigned)ws < (unsigned)g.Ws;
+        ra[DSET][u][HALF] = bload4(rs_src, ok ? (unsigned)(((pixn[u] + hs * g.Ws + ws) << g.lgCs) + cA) * 4u : kOob);
+      }
+      if (++a_ch == nchunks) { a_ch = 0; a_mt += gridDim.x; }
+    };
+    auto issueB = [&](auto set_c) __attribute__((always_inline)) {
+      constexpr int SET = decltype(set_c)::value;
+      const int k0 = b_ch * kX3BK;
+      const int tap = k0 >> g.lgCs, c0 = k0 & (g.Cs - 1);       // (the stem: forward only, where tw == tap and the chunk index is b_ch itself)
+      const int ta = fdiv(tap, g.dnb), tb = tap - ta * g.nb;
+      const int tw = (g.r0 + g.rstep * ta) * g.S + g.s0 + g.sstep * tb;
+      const unsigned kc = (unsigned)(tw * g.Cs + c0) >> 4;
+      const unsigned wsc = (wtile + kc) * (unsigned)(3 * BN * kX3BK * 2);
+#pragma unroll
+      for (int u = 0; u < NB; ++u) rb[SET][u] = __builtin_bit_cast(u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_wgt, (int)(vB[u] + wsc), 0, 0));
+      if (++b_ch == nchunks) b_ch = 0;                          // (past the last chunk: harmless re-reads)
+    };
+    // chunk t (= i mod 4): registers -> LDS stage t & 1, then refill.  No branch around a load or a store: the steps past the last
+    // chunk run too (dead loads, a stage nobody reads), so that the compiler's vmcnt bookkeeping stays exact and the loads really
+    // stay four chunks ahead -- with a guard it falls back to vmcnt(0) at every step.
+    auto step = [&](auto i_c) __attribute__((always_inline)) {
+      constexpr int I = decltype(i_c)::value;
+      if (!(LEC_X3_DBG & 2)) {
+        char* base = smem_x3 + (I & 1) * SBUF;
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+          u32x2v h, m, l;
+          if (LEC_X3_DBG & 1) { h[0] = m[0] = l[0] = __float_as_uint(ra[I >> 1][u][I & 1][0]); h[1] = m[1] = l[1] = __float_as_uint(ra[I >> 1][u][I & 1][2]); }
+          else split4(ra[I >> 1][u][I & 1], h, m, l);
+          char* p = base + ldsA + u * kX3RP * kX3Row;
+          *(u32x2v*)(p) = h; *(u32x2v*)(p + BM * kX3Row) = m; *(u32x2v*)(p + 2 * BM * kX3Row) = l;
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u)
+          if (NBP % kCfThreads == 0 || ptid + kCfThreads * u < NBP) *(u32x4v*)(base + ldsB[u]) = rb[I][u];
+        issueB(i_c);
+        if (TAPV) issueA_tapv(std::integral_constant<int, (I >> 1)>{}, std::integral_constant<int, (I & 1)>{});
+        else if (I & 1) issueA(std::integral_constant<int, (I >> 1)>{});
+      }
+      x3_barrier();
+    };
+    if (!(LEC_X3_DBG & 2)) {                                    // the first four chunks, in the order the loop issues them
+      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+      issueB(I0{}); if (TAPV) issueA_tapv(I0{}, I0{});
+      issueB(I1{}); if (TAPV) issueA_tapv(I0{}, I1{}); else issueA(I0{});
+      issueB(I2{}); if (TAPV) issueA_tapv(I1{}, I0{});
+      issueB(I3{}); if (TAPV) issueA_tapv(I1{}, I1{}); else issueA(I1{});
+    }
+    for (int t = 0; t < T; t += 4) {
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{});
+    }
+  } else {
+    // ---- consumers
+    const int wm0 = (wave / WN) * 32 * TM, wn0 = (wave % WN) * 32 * TN;
+    const rsrc_t rs_dst = make_rsrc(dst, g.dst_bytes);
+    const bool dense_dst = g.dst_st == 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    float st_s[TN], st_q[TN];
+#pragma unroll
+    for (int jt = 0; jt < TN; ++jt) { st_s[jt] = 0.f; st_q[jt] = 0.f; }
+    unsigned coff[TN];
+#pragma unroll
+    for (int jt = 0; jt < TN; ++jt) { const int c = n0 + wn0 + jt * 32 + l31; coff[jt] = c < g.Cd ? (unsigned)c * 4u : kOob; }
+    f32x16 acc[TM][TN];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int it = 0; it < TM; ++it)
+#pragma unroll
+        for (int jt = 0; jt < TN; ++jt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[it][jt][r] = 0.f;
+    };
+    auto epilogue = [&](int mt) __attribute__((always_inline)) {
+      const int m0 = mt * BM;
+#pragma unroll
+      for (int it = 0; it < TM; ++it) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm0 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          unsigned poff;
+          if (dense_dst) {
+            poff = m < g.Mg ? (unsigned)(m * g.Cd) * 4u : kOob;
+          } else {
+            const int mm = m < g.Mg ? m : 0;
+            const int t2 = fdiv(mm, g.dWm); const int mw = mm - t2 * g.Wm; const int n = fdiv(t2, g.dHm); const int mh = t2 - n * g.Hm;
+            const int pix = (n * g.Hd + mh * g.dst_st + g.dph) * g.Wd + mw * g.dst_st + g.dpw;
+            poff = m < g.Mg ? (unsigned)(pix * g.Cd) * 4u : kOob;
+          }
+#pragma unroll
+          for (int jt = 0; jt < TN; ++jt) bstore1(acc[it][jt][r], rs_dst, (poff + coff[jt]) | ((poff | coff[jt]) & kOob));
+        }
+      }
+      if (STATS) {
+#pragma unroll
+        for (int jt = 0; jt < TN; ++jt)
+#pragma unroll
+          for (int it = 0; it < TM; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float v = acc[it][jt][r]; st_s[jt] += v; st_q[jt] += v * v; }
+      }
+    };
+    zero_acc();
+    if (nchunks == 0) {                                         // a parity class without taps: its pixels of dx are zeros
+      for (int mt = blockIdx.x; mt < mtiles; mt += gridDim.x) epilogue(mt);
+      return;
+    }
+    if (Q > 0) {
+      bf16x8 fa[2][TM][3], fb[2][TN][3];
+      int mm_ch = 0, mm_mt = blockIdx.x;                        // the chunk the next MFMA step consumes
+      auto tile_end = [&]() __attribute__((always_inline)) {
+        if (++mm_ch == nchunks) { epilogue(mm_mt); zero_acc(); mm_ch = 0; mm_mt += gridDim.x; }
+      };
+      // prologue / tail steps: every part conditional, barrier at the end
+      auto slow_step = [&](int t, auto set_c) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_c)::value;             // = t & 1: fragments of chunk t - 1 go to set SET ^ 1, chunk t - 2's are in SET
+        if (t >= 1 && t <= Q && !(LEC_X3_DBG & 8)) {
+          const char* sA = smem_x3 + (SET ^ 1) * SBUF;
+          x3_read_frags<BM, BN, TM, TN>(sA, sA + SA, wm0, wn0, lane, fa[SET ^ 1], fb[SET ^ 1]);
+        }
+        if (t >= 2 && t <= Q + 1) {
+#pragma unroll
+          for (int it = 0; it < TM; ++it)
+#pragma unroll
+            for (int jt = 0; jt < TN; ++jt)
+              if (!(LEC_X3_DBG & 4)) acc[it][jt] = mma6(fa[SET][it], fb[SET][jt], acc[it][jt]);
+          tile_end();
+        }
+        x3_barrier();
+      };
+      // steady-state step (2 <= t <= Q): the 12 fragment reads of the next chunk are spread between the first MFMAs, and the barrier
+      // sits before the last TM * TN MFMAs, which keep the matrix pipe busy while the workgroup synchronises
+      auto fast_step = [&](auto set_c) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_c)::value;
+        const char* sA = smem_x3 + (SET ^ 1) * SBUF;
+        if (!(LEC_X3_DBG & 8)) x3_read_frags<BM, BN, TM, TN>(sA, sA + SA, wm0, wn0, lane, fa[SET ^ 1], fb[SET ^ 1]);
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // small terms first (as mma6)
+#pragma unroll
+        for (int p = 0; p < 5; ++p)
+#pragma unroll
+          for (int it = 0; it < TM; ++it)
+#pragma unroll
+            for (int jt = 0; jt < TN; ++jt)
+              if (!(LEC_X3_DBG & 4)) acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][it][PA[p]], fb[SET][jt][PB[p]], acc[it][jt], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 3 * (TM + TN); ++i) {                // one LDS read, one MFMA, ...
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 5 * TM * TN - 3 * (TM + TN), 0);
+        __builtin_amdgcn_sched_barrier(0);
+        x3_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < TM; ++it)
+#pragma unroll
+          for (int jt = 0; jt < TN; ++jt)
+            if (!(LEC_X3_DBG & 4)) acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][it][PA[5]], fb[SET][jt][PB[5]], acc[it][jt], 0, 0, 0);
+        tile_end();
+      };
+      slow_step(0, std::integral_constant<int, 0>{});
+      slow_step(1, std::integral_constant<int, 1>{});
+      int t = 2;
+      for (; t + 1 <= Q; t += 2) {
+        fast_step(std::integral_constant<int, 0>{});
+        fast_step(std::integral_constant<int, 1>{});
+      }
+      for (; t < T; t += 2) {
+        slow_step(t, std::integral_constant<int, 0>{});
+        slow_step(t + 1, std::integral_constant<int, 1>{});
+      }
+    }
+    if (STATS) {
+      // lane halves -> waves of the same column block -> one partial row per workgroup: part[blockIdx.x][2][Cd]
+      float* red = (float*)smem_x3;                             // [WM][2 stats][BN]; the ring is drained (last barrier passed)
+#pragma unroll
+      for (int jt = 0; jt < TN; ++jt) {
+        st_s[jt] += __shfl_xor(st_s[jt], 32, kWave); st_q[jt] += __shfl_xor(st_q[jt], 32, kWave);
+        if (h == 0) {
+          red[((wave / WN) * 2 + 0) * BN + wn0 + jt * 32 + l31] = st_s[jt];
+          red[((wave / WN) * 2 + 1) * BN + wn0 + jt * 32 + l31] = st_q[jt];
+        }
+      }
+    }
+  }
+  if (STATS) {
+    __syncthreads();
+    const float* red = (const float*)smem_x3;
+    for (int i = tid; i < 2 * BN; i += kX3Threads) {
+      const int s = i / BN, c = i - s * BN;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) v += red[(w * 2 + s) * BN + c];
+      if (n0 + c < g.Cd) part[((int64_t)blockIdx.x * 2 + s) * g.Cd + n0 + c] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight split: w[Cout][RS][Cin] fp32 -> tile-major bf16 planes (X3Wgt).  One thread per (n, k) of the padded GEMM operand B[n][k]:
+//   forward (T = false):       n = co, k = tap * Cin + ci
+//   data gradient (T = true):  n = ci, k = tap * Cout + co
+template <bool T>
+__global__ __launch_bounds__(256) void x3_split_weights_kernel(const float* __restrict__ w, int Cout, int RS, int Cin, int BN, int NT, int KC,
+                                                               uint16_t* __restrict__ out) {
+  const int64_t total = (int64_t)NT * KC * BN * kX3BK;
+  const int ncols = T ? Cin : Cout, kdim = T ? RS * Cout : RS * Cin;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int kk = (int)(e % kX3BK); int64_t q = e / kX3BK;
+    const int r = (int)(q % BN); q /= BN;
+    const int kc = (int)(q % KC); const int nt = (int)(q / KC);
+    const int n = nt * BN + r, k = kc * kX3BK + kk;
+    float x = 0.f;
+    if (n < ncols && k < kdim) {
+      if (T) { const int tap = k / Cout, co = k - tap * Cout; x = w[((int64_t)co * RS + tap) * Cin + n]; }
+      else x = w[(int64_t)n * kdim + k];
+    }
+    const unsigned xb = __float_as_uint(x);
+    const float rr = x - __uint_as_float(xb & 0xffff0000u);
+    const unsigned rb = __float_as_uint(rr);
+    const float lo = rr - __uint_as_float(rb & 0xffff0000u);
+    const unsigned lb = __float_as_uint(lo);
+    const int64_t o = ((int64_t)(nt * KC + kc) * 3 * BN + r) * kX3BK + kk;      // plane 0; planes are BN * 16 elements apart
+    out[o] = (uint16_t)(xb >> 16); out[o + (int64_t)BN * kX3BK] = (uint16_t)(rb >> 16); out[o + 2 * (int64_t)BN * kX3BK] = (uint16_t)(lb >> 16);
+  }
+}
+
+static inline void x3_plane_geo(int Cout, int RS, int Cin, bool transposed, int* BN, int* NT, int* KC) {
+  const int ncols = transposed ? Cin : Cout, kdim = transposed ? RS * Cout : RS * Cin;
+  *BN = x3_bn(ncols); *NT = (ncols + *BN - 1) / *BN; *KC = (kdim + kX3BK - 1) / kX3BK;
+}
+
+template <bool STATS>
+static int launch_act_x3(const float* src, const uint16_t* wpl, float* dst, const ActGeo& g, const X3Wgt& wg, float* part, int* nparts, hipStream_t st) {
+  // tile: 128 x 128, or 256 x 64 for layers of 64 output channels; one workgroup (8 waves) per CU, which walks its m-tiles
+  const bool narrow = g.Cd <= 64;
+  const int BM = narrow ? 256 : 128, BN = narrow ? 64 : 128;
+  const int mtiles = (g.Mg + BM - 1) / BM, ntiles = (g.Cd + BN - 1) / BN;
+  static const int wgs = [] { const char* e = getenv("LEC_X3_WGS"); const int v = e ? atoi(e) : 256; return v > 0 ? v : 256; }();
+  int gx = (wgs + ntiles - 1) / ntiles;
+  if (gx > mtiles) gx = mtiles;
+  if (STATS && gx > kCfMaxPart) gx = kCfMaxPart;
+  if (gx < 1) gx = 1;
+  const size_t lds = (size_t)2 * 3 * (BM + BN) * kX3Row;        // 48 / 60 KB
+  const bool tapv = g.Cs < 2 * kX3BK;                           // source channels narrower than a chunk pair (the stem)
+  LEC_CHECK_ARG(tapv || g.na * g.nb <= 32, "conv_f32x3: more than 32 taps per launch need the per-piece tap path");
+  LEC_CHECK_ARG(!tapv || (g.rstep == 1 && g.sstep == 1 && g.r0 == 0 && g.s0 == 0),
+                "conv_f32x3: layers with fewer than 32 source channels are supported in the forward direction only");
+  LEC_CHECK_ARG(BN == x3_bn(g.Cd), "conv_f32x3: tile width and weight layout disagree");
+  const dim3 grid(gx, ntiles), blk(kX3Threads);
+  if (tapv) {
+    if (narrow) hipLaunchKernelGGL((conv_f32x3_act_kernel<4, 1, 2, 2, STATS, true>), grid, blk, lds, st, src, wpl, dst, g, wg, part);
+    else hipLaunchKernelGGL((conv_f32x3_act_kernel<2, 2, 2, 2, STATS, true>), grid, blk, lds, st, src, wpl, dst, g, wg, part);
+  } else {
+    if (narrow) hipLaunchKernelGGL((conv_f32x3_act_kernel<4, 1, 2, 2, STATS, false>), grid, blk, lds, st, src, wpl, dst, g, wg, part);
+    else hipLaunchKernelGGL((conv_f32x3_act_kernel<2, 2, 2, 2, STATS, false>), grid, blk, lds, st, src, wpl, dst, g, wg, part);
+  }
+  if (nparts) *nparts = gx;
+  LEC_CHECK_LAUNCH("conv_f32x3_act_kernel");
+  return LEC_OK;
+}
+
+}  // namespace lec
+
+extern "C" int64_t lec_conv_f32x3_planes_elems(int Cout, int RS, int Cin, int transposed) {
+  int BN, NT, KC; lec::x3_plane_geo(Cout, RS, Cin, transposed != 0, &BN, &NT, &KC);
+  return (int64_t)NT * KC * 3 * BN * lec::kX3BK;
+}
+
+extern "C" int lec_conv_f32x3_split_weights(const float* w, int Cout, int RS, int Cin, uint16_t* planes_fwd, uint16_t* planes_t, lec_stream_t stream) {
+  using namespace lec;
+  LEC_CHECK_ARG(w && (planes_fwd || planes_t) && Cout > 0 && RS > 0 && Cin > 0, "conv_f32x3_split_weights: bad arguments");
+  for (int t = 0; t < 2; ++t) {
+    uint16_t* out = t ? planes_t : planes_fwd;
+    if (!out) continue;
+    int BN, NT, KC; x3_plane_geo(Cout, RS, Cin, t != 0, &BN, &NT, &KC);
+    const int64_t total = (int64_t)NT * KC * BN * kX3BK;
+    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    if (t) hipLaunchKernelGGL(x3_split_weights_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Cout, RS, Cin, BN, NT, KC, out);
+    else hipLaunchKernelGGL(x3_split_weights_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Cout, RS, Cin, BN, NT, KC, out);
+  }
+  LEC_CHECK_LAUNCH("x3_split_weights_kernel");
+  return LEC_OK;
+}
+
+extern "C" int lec_conv_f32x3_fwd(const float* x, const uint16_t* w_planes, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                                  float* y, float* partials, int64_t partials_bytes, int* n_partials, lec_stream_t stream) {
+  using namespace lec;
+  if (int rc = conv_check("conv_f32x3_fwd", N, H, W, Cin, Cout, R, S, stride, pad)) return rc;
+  LEC_CHECK_ARG(x && w_planes && y, "conv_f32x3_fwd: null pointer");
+  const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+  ActGeo g;
+  g.Mg = N * Ho * Wo; g.Hm = Ho; g.Wm = Wo; g.Hs = H; g.Ws = W; g.Cs = Cin; g.lgCs = ilog2_exact(Cin); g.sst = stride;
+  g.oh0 = -pad; g.ow0 = -pad; g.sg = 1; g.na = R; g.nb = S; g.r0 = 0; g.rstep = 1; g.s0 = 0; g.sstep = 1; g.S = S; g.RS = R * S;
+  g.Cd = Cout; g.Cin = Cin; g.Hd = Ho; g.Wd = Wo; g.dst_st = 1; g.dph = 0; g.dpw = 0; g.Kg = R * S * Cin;
+  g.src_bytes = (uint32_t)((int64_t)N * H * W * Cin * 4); g.dst_bytes = (uint32_t)((int64_t)g.Mg * Cout * 4);
+  X3Wgt wg; int bn_, nt_; x3_plane_geo(Cout, R * S, Cin, false, &bn_, &nt_, &wg.KC);
+  g.wgt_bytes = (uint32_t)(lec_conv_f32x3_planes_elems(Cout, R * S, Cin, 0) * 2);
+  g.dWm = make_fastdiv(g.Wm); g.dHm = make_fastdiv(g.Hm); g.dnb = make_fastdiv(g.nb);
+  if (partials) {
+    LEC_CHECK_ARG(n_partials && partials_bytes >= (int64_t)kCfMaxPart * 2 * Cout * (int64_t)sizeof(float), "conv_f32x3_fwd: partials buffer too small");
+    return launch_act_x3<true>(x, w_planes, y, g, wg, partials, n_partials, (hipStream_t)stream);
+  }
+  return launch_act_x3<false>(x, w_planes, y, g, wg, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int lec_conv_f32x3_dgrad(const float* dy, const uint16_t* w_planes_t, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                                    float* dx, lec_stream_t stream) {
+  using namespace lec;
+  if (int rc = conv_check("conv_f32x3_dgrad", N, H, W, Cin, Cout, R, S, stride, pad)) return rc;
+  LEC_CHECK_ARG(dy && w_planes_t && dx, "conv_f32x3_dgrad: null pointer");
+  LEC_CHECK_ARG(Cout % (2 * kX3BK) == 0, "conv_f32x3_dgrad: Cout must be a multiple of 32, got %d", Cout);
+  const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+  X3Wgt wg; int bn_, nt_; x3_plane_geo(Cout, R * S, Cin, true, &bn_, &nt_, &wg.KC);
+  const uint32_t wbytes = (uint32_t)(lec_conv_f32x3_planes_elems(Cout, R * S, Cin, 1) * 2);
+  for (int ph = 0; ph < stride; ++ph) {
+    for (int pw = 0; pw < stride; ++pw) {
+      ActGeo g;
+      g.Hm = (H - ph + stride - 1) / stride; g.Wm = (W - pw + stride - 1) / stride;
+      if (g.Hm <= 0 || g.Wm <= 0) continue;
+      g.Mg = N * g.Hm * g.Wm; g.Hs = Ho; g.Ws = Wo; g.Cs = Cout; g.lgCs = ilog2_exact(Cout); g.sst = 1;
+      g.r0 = (ph + pad) % stride; g.s0 = (pw + pad) % stride; g.rstep = stride; g.sstep = stride;
+      g.na = g.r0 < R ? (R - g.r0 + stride - 1) / stride : 0; g.nb = g.s0 < S ? (S - g.s0 + stride - 1) / stride : 0;
+      g.oh0 = (ph + pad - g.r0) / stride; g.ow0 = (pw + pad - g.s0) / stride; g.sg = -1;
+      g.S = S; g.RS = R * S; g.Cd = Cin; g.Cin = Cin; g.Hd = H; g.Wd = W; g.dst_st = stride; g.dph = ph; g.dpw = pw;
+      g.Kg = g.na * g.nb * Cout;
+      g.src_bytes = (uint32_t)((int64_t)N * Ho * Wo * Cout * 4); g.wgt_bytes = wbytes;
+      g.dst_bytes = (uint32_t)((int64_t)N * H * W * Cin * 4);
+      g.dWm = make_fastdiv(g.Wm); g.dHm = make_fastdiv(g.Hm); g.dnb = make_fastdiv(g.nb);
+      if (int rc = launch_act_x3<false>(dy, w_planes_t, dx, g, wg, nullptr, nullptr, (hipStream_t)stream)) return rc;
+    }
+  }
+  return LEC_OK;
+}

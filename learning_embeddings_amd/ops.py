@@ -690,6 +690,61 @@ def conv_f32_wgrad(dy, x, dw, stride, pad):
     return dw
 
 
+class X3Planes:
+    """Pre-split bf16 planes of one conv weight (lec_conv_f32x3_split_weights): `fwd` feeds conv_f32x3_fwd, `t` conv_f32x3_dgrad."""
+    __slots__ = ('shape', 'fwd', 't')
+
+    def __init__(self, shape, device, want_t=True):
+        cout, cin, r, s_ = shape
+        self.shape = tuple(shape)
+        self.fwd = torch.empty(int(lib.lec_conv_f32x3_planes_elems(cout, r * s_, cin, 0)), dtype=torch.int16, device=device)
+        self.t = torch.empty(int(lib.lec_conv_f32x3_planes_elems(cout, r * s_, cin, 1)), dtype=torch.int16, device=device) if want_t else None
+
+    def update(self, w):
+        _nhwc_f32(w, 'w')
+        cout, cin, r, s_ = self.shape
+        if tuple(w.shape) != self.shape:
+            raise ValueError('weight shape %s does not match the planes %s' % (tuple(w.shape), self.shape))
+        check(lib.lec_conv_f32x3_split_weights(dptr(w), cout, r * s_, cin, dptr(self.fwd), dptr(self.t) if self.t is not None else None, stream_ptr()))
+        return self
+
+
+def conv_f32x3_split_weights(w, want_t=True):
+    """The bf16 planes of a channels_last fp32 conv weight [Cout, Cin, R, S] (run again after every change of w)."""
+    return X3Planes(w.shape, w.device, want_t).update(w)
+
+
+def conv_f32x3_fwd(x, planes, stride, pad, want_stats=False):
+    """y = conv2d(x, w) with fp32 products on the bf16 matrix cores (lec_conv_f32x3_fwd); planes = conv_f32x3_split_weights(w)."""
+    _nhwc_f32(x, 'x')
+    n, cin, h, wd = x.shape; cout, cin_w, r, s_ = planes.shape
+    if cin_w != cin:
+        raise ValueError('weight planes have %d input channels, x has %d' % (cin_w, cin))
+    ho, wo = (h + 2 * pad - r) // stride + 1, (wd + 2 * pad - s_) // stride + 1
+    y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    flops = 2.0 * n * ho * wo * cout * cin * r * s_
+    if want_stats:
+        ws = _bn_workspace(x.device); k = C.c_int(0)
+        _conv_timed(lambda: check(lib.lec_conv_f32x3_fwd(dptr(x), dptr(planes.fwd), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), dptr(ws), ws.numel(),
+                                                         C.byref(k), stream_ptr())), flops)
+        _BN_WS_OWNER[0], _BN_WS_OWNER[1] = y.data_ptr(), k.value
+    else:
+        _conv_timed(lambda: check(lib.lec_conv_f32x3_fwd(dptr(x), dptr(planes.fwd), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), None, 0, None, stream_ptr())), flops)
+    return y
+
+
+def conv_f32x3_dgrad(dy, planes, x_shape, stride, pad):
+    """dx of the same convolution (lec_conv_f32x3_dgrad)."""
+    _nhwc_f32(dy, 'dy')
+    n, cin, h, wd = x_shape; cout, _, r, s_ = planes.shape
+    if planes.t is None:
+        raise ValueError('these planes were split without the data-gradient layout')
+    dx = torch.empty((n, cin, h, wd), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last)
+    _conv_timed(lambda: check(lib.lec_conv_f32x3_dgrad(dptr(dy), dptr(planes.t), n, h, wd, cin, cout, r, s_, stride, pad, dptr(dx), stream_ptr())),
+                2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * cout * cin * r * s_)
+    return dx
+
+
 def _bn_workspace(device):
     key = (device.type, device.index)
     ws = _bn_ws.get(key)
