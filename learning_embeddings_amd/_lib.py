@@ -102,6 +102,8 @@ def _load():
         'lec_conv_f32x3_split_weights': (i32, [p, i32, i32, i32, p, p, p]),
         'lec_conv_f32x3_fwd': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p, i64, p, p]),
         'lec_conv_f32x3_dgrad': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p]),
+        'lec_conv_f32x3_wgrad_supported': (i32, [i32, i32, i32, i32]),
+        'lec_conv_f32x3_wgrad': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p]),
         'lec_maxpool3x3s2_fwd': (i32, [p, i32, i32, i32, i32, p, p, p]),
         'lec_maxpool3x3s2_bwd': (i32, [p, p, i32, i32, i32, i32, p, p]),
     }

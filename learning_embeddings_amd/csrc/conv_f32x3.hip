@@ -16,7 +16,7 @@
 //     layout [Cout][R*S][Cin] and three in the data-gradient layout [R*S][Cin][Cout], so that the B operand is k-contiguous in
 //     both directions and travels global -> LDS untouched (16-byte pieces of 8 bf16);
 //   * activations / output gradients are loaded as fp32 (16-byte buffer loads, hardware range check = padding zeros), split in
-//     registers -- 4 vector instructions per element + 3 v_perm per pair, which the bf16 MFMA (unlike the f32 one) executes
+//     registers -- 11 vector instructions per pair of elements (4 v_and, 4 v_sub, 3 v_perm), which the bf16 MFMA (unlike the f32 one) executes
 //     beside -- and stored as three bf16 planes;
 //   * LDS: planes of [rows][16 k] bf16, 48-byte rows (32 data + 16 pad: conflict-free ds_read_b128 for 16 consecutive rows),
 //     K advances 16 per chunk = one MFMA step, double-buffered, one barrier per chunk; 128 x 128 tile: 2 x 36 KB, two
@@ -39,6 +39,9 @@ constexpr int kX3Threads = 512;           // 4 consumer + 4 producer waves
 #ifndef LEC_X3_PRIO
 #define LEC_X3_PRIO 1
 #endif
+#ifndef LEC_X3_TRUNC
+#define LEC_X3_TRUNC 1                    // pieces by truncation (default) or by round-to-nearest (0): see split_pair
+#endif
 #ifndef LEC_X3_DBG
 #define LEC_X3_DBG 0                      // experiments (wrong results): 1 no split arithmetic, 2 producers idle, 4 no MFMAs, 8 no fragment reads
 #endif
@@ -50,24 +53,42 @@ constexpr int kX3RP = kCfThreads / kX3KQ; // rows staged per pass
 struct X3Wgt { int KC; };                 // k chunks per n tile
 static inline int x3_bn(int cols) { return cols <= 64 ? 64 : 128; }
 
-// high halves of two fp32 words -> one dword of two bf16 (truncation): lo -> bits 0..15, hi -> bits 16..31
-__device__ __forceinline__ unsigned pack_hi16(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+// Round-to-nearest-even bf16 of two floats, packed (v_cvt_pk_bf16_f32): lo -> bits 0..15, hi -> bits 16..31
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  f32x2v v; v[0] = lo; v[1] = hi;
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
+}
 
-// x[0..3] -> three planes of 4 bf16 (2 dwords each); x = h + m + l exactly
+// (x0, x1) -> the packed h | m | l pieces of both: x = h + m + l exactly (every subtraction is exact in fp32).  11 vector instructions
+// per pair.  Default: TRUNCATED pieces (v_and_b32 to cut, v_perm_b32 to pack): the products the kernels drop (m*l, l*m, l*l) are below
+// 2^-23 of the product.  LEC_X3_TRUNC=0 rounds each piece to nearest (v_cvt_pk_bf16_f32 + shifts): dropped products below 2^-25 and of
+// either sign, but 12-20 % slower kernels (measured: the convert and the unpack shifts cost more issue time than and / perm) for no
+// measurable change of the error against fp64 (tests/test_fp32_gpu.py): truncation is the default.
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+#if LEC_X3_TRUNC
+  const unsigned a0 = __float_as_uint(x0), a1 = __float_as_uint(x1);
+  const float q0 = x0 - __uint_as_float(a0 & 0xffff0000u), q1 = x1 - __uint_as_float(a1 & 0xffff0000u);
+  const unsigned b0 = __float_as_uint(q0), b1 = __float_as_uint(q1);
+  const float s0 = q0 - __uint_as_float(b0 & 0xffff0000u), s1 = q1 - __uint_as_float(b1 & 0xffff0000u);
+  h = __builtin_amdgcn_perm(a1, a0, 0x07060302u); m = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+  l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+  return;
+#endif
+  h = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = cvt_pk_bf16(r0, r1);
+  const float l0 = r0 - __uint_as_float(m << 16), l1 = r1 - __uint_as_float(m & 0xffff0000u);
+  l = cvt_pk_bf16(l0, l1);
+}
+
+// x[0..3] -> three planes of 4 bf16 (2 dwords each)
 __device__ __forceinline__ void split4(const f32x4v x, u32x2v& h, u32x2v& m, u32x2v& l) {
-  unsigned xb[4], rb[4], lb[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const float xt = x[t];                                     // (a scalar copy: __builtin_bit_cast applied to the vector ELEMENT reads element 0)
-    xb[t] = __float_as_uint(xt);
-    const float r = xt - __uint_as_float(xb[t] & 0xffff0000u);
-    rb[t] = __float_as_uint(r);
-    const float lo = r - __uint_as_float(rb[t] & 0xffff0000u);
-    lb[t] = __float_as_uint(lo);
-  }
-  h[0] = pack_hi16(xb[0], xb[1]); h[1] = pack_hi16(xb[2], xb[3]);
-  m[0] = pack_hi16(rb[0], rb[1]); m[1] = pack_hi16(rb[2], rb[3]);
-  l[0] = pack_hi16(lb[0], lb[1]); l[1] = pack_hi16(lb[2], lb[3]);
+  const float x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];     // (scalar copies: a bit cast applied to a vector ELEMENT reads element 0)
+  unsigned a, b, c;
+  split_pair(x0, x1, a, b, c); h[0] = a; m[0] = b; l[0] = c;
+  split_pair(x2, x3, a, b, c); h[1] = a; m[1] = b; l[1] = c;
 }
 
 // the six products of one 32 x 32 x 16 step, small terms first
@@ -107,6 +128,77 @@ __device__ __forceinline__ void x3_read_frags(const char* __restrict__ sA, const
   for (int jt = 0; jt < TN; ++jt)
 #pragma unroll
     for (int p = 0; p < 3; ++p) b[jt][p] = *(const bf16x8*)(sB + (p * BN + wn0 + jt * 32 + l31) * kX3Row + hs);
+}
+
+// The consumers' loop (shared by the activation-gather kernel and the weight gradient).  Step t: fragments of chunk t - 1 <- LDS stage
+// (t - 1) & 1, MFMAs of chunk t - 2; after the last chunk of a tile (every `nchunks` chunks) tile_done() stores / resets `acc`.
+template <int BM, int BN, int TM, int TN, class TileDone>
+__device__ __forceinline__ void x3_consumer_loop(const char* __restrict__ smem, int Q, int T, int nchunks, int wm0, int wn0, int lane,
+                                                 f32x16 (&acc)[TM][TN], TileDone&& tile_done) {
+  constexpr int SA = 3 * BM * kX3Row, SBUF = 3 * (BM + BN) * kX3Row;
+  bf16x8 fa[2][TM][3], fb[2][TN][3];
+  int mm_ch = 0;                                                // chunks of the current tile already accumulated
+  auto tile_end = [&]() __attribute__((always_inline)) {
+    if (++mm_ch == nchunks) { tile_done(); mm_ch = 0; }
+  };
+  // prologue / tail steps: every part conditional, barrier at the end
+  auto slow_step = [&](int t, auto set_c) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_c)::value;                 // = t & 1: fragments of chunk t - 1 go to set SET ^ 1, chunk t - 2's are in SET
+    if (t >= 1 && t <= Q && !(LEC_X3_DBG & 8)) {
+      const char* sA = smem + (SET ^ 1) * SBUF;
+      x3_read_frags<BM, BN, TM, TN>(sA, sA + SA, wm0, wn0, lane, fa[SET ^ 1], fb[SET ^ 1]);
+    }
+    if (t >= 2 && t <= Q + 1) {
+#pragma unroll
+      for (int it = 0; it < TM; ++it)
+#pragma unroll
+        for (int jt = 0; jt < TN; ++jt)
+          if (!(LEC_X3_DBG & 4)) acc[it][jt] = mma6(fa[SET][it], fb[SET][jt], acc[it][jt]);
+      tile_end();
+    }
+    x3_barrier();
+  };
+  // steady-state step (2 <= t <= Q): the fragment reads of the next chunk are spread between the first MFMAs, and the barrier sits
+  // before the last TM * TN MFMAs, which keep the matrix pipe busy while the workgroup synchronises
+  auto fast_step = [&](auto set_c) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_c)::value;
+    const char* sA = smem + (SET ^ 1) * SBUF;
+    if (!(LEC_X3_DBG & 8)) x3_read_frags<BM, BN, TM, TN>(sA, sA + SA, wm0, wn0, lane, fa[SET ^ 1], fb[SET ^ 1]);
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};         // small terms first (as mma6)
+#pragma unroll
+    for (int p = 0; p < 5; ++p)
+#pragma unroll
+      for (int it = 0; it < TM; ++it)
+#pragma unroll
+        for (int jt = 0; jt < TN; ++jt)
+          if (!(LEC_X3_DBG & 4)) acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][it][PA[p]], fb[SET][jt][PB[p]], acc[it][jt], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 3 * (TM + TN); ++i) {                    // one LDS read, one MFMA, ...
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 5 * TM * TN - 3 * (TM + TN), 0);
+    __builtin_amdgcn_sched_barrier(0);
+    x3_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < TM; ++it)
+#pragma unroll
+      for (int jt = 0; jt < TN; ++jt)
+        if (!(LEC_X3_DBG & 4)) acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][it][PA[5]], fb[SET][jt][PB[5]], acc[it][jt], 0, 0, 0);
+    tile_end();
+  };
+  slow_step(0, std::integral_constant<int, 0>{});
+  slow_step(1, std::integral_constant<int, 1>{});
+  int t = 2;
+  for (; t + 1 <= Q; t += 2) {
+    fast_step(std::integral_constant<int, 0>{});
+    fast_step(std::integral_constant<int, 1>{});
+  }
+  for (; t < T; t += 2) {
+    slow_step(t, std::integral_constant<int, 0>{});
+    slow_step(t + 1, std::integral_constant<int, 1>{});
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -248,8 +340,7 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_act_kernel(const float*
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
           u32x2v h, m, l;
-          if (LEC_X3_DBG & 1) { h[0] = m[0] = l[0] = __float_as_uint(ra[I >> 1][u][I & 1][0]); h[1] = m[1] = l[1] = __float_as_uint(ra[I >> 1][u][I & 1][2]); }
-          else split4(ra[I >> 1][u][I & 1], h, m, l);
+          split4(ra[I >> 1][u][I & 1], h, m, l);
           char* p = base + ldsA + u * kX3RP * kX3Row;
           *(u32x2v*)(p) = h; *(u32x2v*)(p + BM * kX3Row) = m; *(u32x2v*)(p + 2 * BM * kX3Row) = l;
         }
@@ -332,69 +423,10 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_act_kernel(const float*
       return;
     }
     if (Q > 0) {
-      bf16x8 fa[2][TM][3], fb[2][TN][3];
-      int mm_ch = 0, mm_mt = blockIdx.x;                        // the chunk the next MFMA step consumes
-      auto tile_end = [&]() __attribute__((always_inline)) {
-        if (++mm_ch == nchunks) { epilogue(mm_mt); zero_acc(); mm_ch = 0; mm_mt += gridDim.x; }
-      };
-      // prologue / tail steps: every part conditional, barrier at the end
-      auto slow_step = [&](int t, auto set_c) __attribute__((always_inline)) {
-        constexpr int SET = decltype(set_c)::value;             // = t & 1: fragments of chunk t - 1 go to set SET ^ 1, chunk t - 2's are in SET
-        if (t >= 1 && t <= Q && !(LEC_X3_DBG & 8)) {
-          const char* sA = smem_x3 + (SET ^ 1) * SBUF;
-          x3_read_frags<BM, BN, TM, TN>(sA, sA + SA, wm0, wn0, lane, fa[SET ^ 1], fb[SET ^ 1]);
-        }
-        if (t >= 2 && t <= Q + 1) {
-#pragma unroll
-          for (int it = 0; it < TM; ++it)
-#pragma unroll
-            for (int jt = 0; jt < TN; ++jt)
-              if (!(LEC_X3_DBG & 4)) acc[it][jt] = mma6(fa[SET][it], fb[SET][jt], acc[it][jt]);
-          tile_end();
-        }
-        x3_barrier();
-      };
-      // steady-state step (2 <= t <= Q): the 12 fragment reads of the next chunk are spread between the first MFMAs, and the barrier
-      // sits before the last TM * TN MFMAs, which keep the matrix pipe busy while the workgroup synchronises
-      auto fast_step = [&](auto set_c) __attribute__((always_inline)) {
-        constexpr int SET = decltype(set_c)::value;
-        const char* sA = smem_x3 + (SET ^ 1) * SBUF;
-        if (!(LEC_X3_DBG & 8)) x3_read_frags<BM, BN, TM, TN>(sA, sA + SA, wm0, wn0, lane, fa[SET ^ 1], fb[SET ^ 1]);
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // small terms first (as mma6)
-#pragma unroll
-        for (int p = 0; p < 5; ++p)
-#pragma unroll
-          for (int it = 0; it < TM; ++it)
-#pragma unroll
-            for (int jt = 0; jt < TN; ++jt)
-              if (!(LEC_X3_DBG & 4)) acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][it][PA[p]], fb[SET][jt][PB[p]], acc[it][jt], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 3 * (TM + TN); ++i) {                // one LDS read, one MFMA, ...
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 5 * TM * TN - 3 * (TM + TN), 0);
-        __builtin_amdgcn_sched_barrier(0);
-        x3_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int it = 0; it < TM; ++it)
-#pragma unroll
-          for (int jt = 0; jt < TN; ++jt)
-            if (!(LEC_X3_DBG & 4)) acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][it][PA[5]], fb[SET][jt][PB[5]], acc[it][jt], 0, 0, 0);
-        tile_end();
-      };
-      slow_step(0, std::integral_constant<int, 0>{});
-      slow_step(1, std::integral_constant<int, 1>{});
-      int t = 2;
-      for (; t + 1 <= Q; t += 2) {
-        fast_step(std::integral_constant<int, 0>{});
-        fast_step(std::integral_constant<int, 1>{});
-      }
-      for (; t < T; t += 2) {
-        slow_step(t, std::integral_constant<int, 0>{});
-        slow_step(t + 1, std::integral_constant<int, 1>{});
-      }
+      int mm_mt = blockIdx.x;                                   // the m-tile the accumulators belong to
+      x3_consumer_loop<BM, BN, TM, TN>(smem_x3, Q, T, nchunks, wm0, wn0, lane, acc, [&]() __attribute__((always_inline)) {
+        epilogue(mm_mt); zero_acc(); mm_mt += gridDim.x;
+      });
     }
     if (STATS) {
       // lane halves -> waves of the same column block -> one partial row per workgroup: part[blockIdx.x][2][Cd]
@@ -423,6 +455,151 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_act_kernel(const float*
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradient: dW[co][(tap, ci)] += sum over pixels m of dY[m][co] * X[pixel(m) + tap][ci].   M = Cout, N = R*S*Cin, K = pixels.
+// Both operands are fp32 activations whose k index (the pixel) is the SLOW one in memory, and the bf16 MFMA wants 8 consecutive k per
+// lane: the producers transpose while they split.  A chunk is 16 pixels; a producer wave owns ONE octet of them and one operand
+// (waves 4, 5: dY octets 0, 1; waves 6, 7: X octets 0, 1); its lane L owns the tile's channels L and L + 64 and loads them for
+// the octet's 8 pixels (16 dword loads, each a contiguous 256 bytes across the wave), splits the 16 values and packs PIXEL pairs:
+// 8 k of one channel = 16 bytes per plane = the LDS image [channel][16 k] the consumers read with ds_read_b128.
+// The source pixel of an X row is wave-uniform: lane l of the wave decodes pixel (group base + l) once per four chunks (64 pixels,
+// vector ALU, ~20 instructions) and the row offsets are read back with v_readlane; the tile's tap is uniform because a 128-column
+// tile lies inside one tap (Cin >= 128).  Work item = (128 x 128 tile of dW, K split); float atomics into dW, as in conv_f32.hip.
+struct WgX3Geo {
+  int Mpix, Ho, Wo, H, W, Cin, lgCin, Cout, S, stride, pad, Ng;
+  int cps;                                 // chunks per work item (a multiple of 4; rows past Mpix are zeros)
+  int tiles_n, tiles, items;
+  uint32_t dy_bytes, x_bytes;
+  FastDiv dWo, dHo, dS;
+};
+
+__device__ __forceinline__ float bload1(rsrc_t rsrc, unsigned voff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, 0, 0));
+}
+
+template <bool DENSE>
+__global__ __launch_bounds__(kX3Threads) void conv_f32x3_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                      float* __restrict__ dw, WgX3Geo g) {
+  constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WN = 2;
+  constexpr int SA = 3 * BM * kX3Row, SBUF = 3 * (BM + BN) * kX3Row;
+  extern __shared__ __attribute__((aligned(16))) char smem_x3[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nit = (int)blockIdx.x < g.items ? (g.items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int Q = nit * g.cps;
+  const int T = (Q + 2 + 3) & ~3;
+  if (Q == 0) return;
+
+  if (wave >= 4) {
+    if (LEC_X3_PRIO) __builtin_amdgcn_s_setprio(LEC_X3_PRIO);
+    const int pw = wave - 4;
+    const bool isB = pw >= 2;                                   // (wave-uniform)
+    const int oct = pw & 1;
+    const rsrc_t rs = isB ? make_rsrc(x, g.x_bytes) : make_rsrc(dy, g.dy_bytes);
+    const int C = isB ? g.Cin : g.Cout;                         // channels per pixel of this wave's source tensor
+    const unsigned ldsW = (unsigned)((isB ? SA : 0) + lane * kX3Row + x3_half(lane, oct));   // channel row `lane`; row lane + 64: + 64 rows (same bit 3)
+    // load stream: item, chunk inside the item
+    int ld_it = blockIdx.x, ld_ch = 0;
+    unsigned vcol = 0;                                          // byte offset of this lane's first channel inside a pixel
+    int dr = 0, ds = 0;                                         // the tile's tap, relative to the output pixel (B)
+    int ch0 = 0;                                                // first chunk of the item
+    unsigned pixo = 0;                                          // B: byte offset of the source pixel of (group base + lane), kOob if there is none
+    float rr[4][16];
+    auto item_setup = [&]() __attribute__((always_inline)) {
+      const int wi = ld_it;
+      const int tile = wi % g.tiles, sp = wi / g.tiles;
+      const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+      ch0 = sp * g.cps;
+      if (isB) {
+        const int j0 = tn * BN;
+        const int tap = j0 >> g.lgCin, ci0 = j0 & (g.Cin - 1);
+        const int r_ = fdiv(tap, g.dS);
+        dr = r_ - g.pad; ds = tap - r_ * g.S - g.pad;
+        vcol = (unsigned)(ci0 + lane) * 4u;
+      } else {
+        vcol = (unsigned)(tm * BM + lane) * 4u;
+      }
+    };
+    auto issue = [&](auto i_c) __attribute__((always_inline)) {   // chunk ld_ch of item ld_it -> rr[I]; I == chunk & 3
+      constexpr int I = decltype(i_c)::value;
+      if (ld_ch == 0) item_setup();
+      const int mb = (ch0 + ld_ch) * kX3BK;                      // first pixel of the chunk
+      if (isB && !DENSE && I == 0) {                              // decode the 64 pixels of chunks ld_ch .. ld_ch + 3
+        const int m = mb + lane;
+        const bool live = m < g.Mpix;
+        const int mm = live ? m : 0;
+        const int t2 = fdiv(mm, g.dWo); const int wo = mm - t2 * g.Wo; const int n = fdiv(t2, g.dHo); const int ho = t2 - n * g.Ho;
+        const int hs = ho * g.stride + dr, ws = wo * g.stride + ds;
+        const bool ok = live && (unsigned)hs < (unsigned)g.H && (unsigned)ws < (unsigned)g.W;
+        pixo = ok ? (unsigned)(((n * g.H + hs) * g.W + ws) << g.lgCin) * 4u : kOob;
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        unsigned srow;
+        if (isB && !DENSE) srow = (unsigned)__builtin_amdgcn_readlane((int)pixo, 16 * I + 8 * oct + r);
+        else srow = (unsigned)((mb + 8 * oct + r) * C) * 4u;      // (past the tensor: out of range, zeros)
+        const unsigned o = vcol + srow;
+        rr[I][2 * r] = bload1(rs, o);
+        rr[I][2 * r + 1] = bload1(rs, o + 256u);
+      }
+      if (++ld_ch == g.cps) { ld_ch = 0; ld_it += gridDim.x; }
+    };
+    auto step = [&](auto i_c) __attribute__((always_inline)) {
+      constexpr int I = decltype(i_c)::value;
+      char* base = smem_x3 + (I & 1) * SBUF + ldsW;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        u32x4v ph, pm, pl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          unsigned a_, b_, c_;
+          split_pair(rr[I][2 * (2 * q) + j], rr[I][2 * (2 * q + 1) + j], a_, b_, c_);
+          ph[q] = a_; pm[q] = b_; pl[q] = c_;
+        }
+        char* p = base + j * 64 * kX3Row;
+        *(u32x4v*)(p) = ph; *(u32x4v*)(p + BM * kX3Row) = pm; *(u32x4v*)(p + 2 * BM * kX3Row) = pl;     // (BM == BN)
+      }
+      issue(i_c);
+      x3_barrier();
+    };
+    issue(std::integral_constant<int, 0>{}); issue(std::integral_constant<int, 1>{});
+    issue(std::integral_constant<int, 2>{}); issue(std::integral_constant<int, 3>{});
+    for (int t = 0; t < T; t += 4) {
+      step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+    }
+  } else {
+    const int wm0 = (wave / WN) * 32 * TM, wn0 = (wave % WN) * 32 * TN;
+    const int l31 = lane & 31, h = lane >> 5;
+    f32x16 acc[TM][TN];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int it = 0; it < TM; ++it)
+#pragma unroll
+        for (int jt = 0; jt < TN; ++jt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[it][jt][r] = 0.f;
+    };
+    zero_acc();
+    int cur_it = blockIdx.x;
+    x3_consumer_loop<BM, BN, TM, TN>(smem_x3, Q, T, g.cps, wm0, wn0, lane, acc, [&]() __attribute__((always_inline)) {
+      const int tile = cur_it % g.tiles;
+      const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+      float* out = dw + (int64_t)(tm * BM + wm0) * g.Ng + tn * BN + wn0 + l31;
+#pragma unroll
+      for (int it = 0; it < TM; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+          for (int jt = 0; jt < TN; ++jt) atomicAdd(out + (int64_t)row * g.Ng + jt * 32, acc[it][jt][r]);
+        }
+      zero_acc();
+      cur_it += gridDim.x;
+    });
+  }
+}
+
 // weight split: w[Cout][RS][Cin] fp32 -> tile-major bf16 planes (X3Wgt).  One thread per (n, k) of the padded GEMM operand B[n][k]:
 //   forward (T = false):       n = co, k = tap * Cin + ci
 //   data gradient (T = true):  n = ci, k = tap * Cout + co
@@ -441,13 +618,10 @@ __global__ __launch_bounds__(256) void x3_split_weights_kernel(const float* __re
       if (T) { const int tap = k / Cout, co = k - tap * Cout; x = w[((int64_t)co * RS + tap) * Cin + n]; }
       else x = w[(int64_t)n * kdim + k];
     }
-    const unsigned xb = __float_as_uint(x);
-    const float rr = x - __uint_as_float(xb & 0xffff0000u);
-    const unsigned rb = __float_as_uint(rr);
-    const float lo = rr - __uint_as_float(rb & 0xffff0000u);
-    const unsigned lb = __float_as_uint(lo);
+    unsigned hb, mb, lb;
+    split_pair(x, 0.f, hb, mb, lb);
     const int64_t o = ((int64_t)(nt * KC + kc) * 3 * BN + r) * kX3BK + kk;      // plane 0; planes are BN * 16 elements apart
-    out[o] = (uint16_t)(xb >> 16); out[o + (int64_t)BN * kX3BK] = (uint16_t)(rb >> 16); out[o + 2 * (int64_t)BN * kX3BK] = (uint16_t)(lb >> 16);
+    out[o] = (uint16_t)hb; out[o + (int64_t)BN * kX3BK] = (uint16_t)mb; out[o + 2 * (int64_t)BN * kX3BK] = (uint16_t)lb;
   }
 }
 
@@ -556,5 +730,46 @@ extern "C" int lec_conv_f32x3_dgrad(const float* dy, const uint16_t* w_planes_t,
       if (int rc = launch_act_x3<false>(dy, w_planes_t, dx, g, wg, nullptr, nullptr, (hipStream_t)stream)) return rc;
     }
   }
+  return LEC_OK;
+}
+
+extern "C" int lec_conv_f32x3_wgrad_supported(int Cin, int Cout, int R, int S) {
+  return Cin >= 128 && Cout >= 128 && Cin % 128 == 0 && Cout % 128 == 0 && (Cin & (Cin - 1)) == 0 && (Cout & (Cout - 1)) == 0 && R > 0 && S > 0;
+}
+
+extern "C" int lec_conv_f32x3_wgrad(const float* dy, const float* x, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                                    float* dw, lec_stream_t stream) {
+  using namespace lec;
+  if (int rc = conv_check("conv_f32x3_wgrad", N, H, W, Cin, Cout, R, S, stride, pad)) return rc;
+  LEC_CHECK_ARG(dy && x && dw, "conv_f32x3_wgrad: null pointer");
+  LEC_CHECK_ARG(lec_conv_f32x3_wgrad_supported(Cin, Cout, R, S), "conv_f32x3_wgrad: needs Cin and Cout to be powers of two >= 128 (got %d, %d): use lec_conv_f32_wgrad", Cin, Cout);
+  WgX3Geo g;
+  g.Ho = (H + 2 * pad - R) / stride + 1; g.Wo = (W + 2 * pad - S) / stride + 1; g.Mpix = N * g.Ho * g.Wo;
+  g.H = H; g.W = W; g.Cin = Cin; g.lgCin = ilog2_exact(Cin); g.Cout = Cout; g.S = S; g.stride = stride; g.pad = pad; g.Ng = R * S * Cin;
+  g.dy_bytes = (uint32_t)((int64_t)g.Mpix * Cout * 4); g.x_bytes = (uint32_t)((int64_t)N * H * W * Cin * 4);
+  g.dWo = make_fastdiv(g.Wo); g.dHo = make_fastdiv(g.Ho); g.dS = make_fastdiv(S);
+  const bool dense = R == 1 && S == 1 && stride == 1 && pad == 0;
+  g.tiles_n = g.Ng / 128; g.tiles = (Cout / 128) * g.tiles_n;
+  const int nchunks = (g.Mpix + kX3BK - 1) / kX3BK;
+  static const int wgs = [] { const char* e = getenv("LEC_X3_WGS"); const int v = e ? atoi(e) : 256; return v > 0 ? v : 256; }();
+  // K split: accumulation chains of at most 512 chunks (8192 pixels: the rounding error of a longer fp32 chain shows against fp64),
+  // and among the splits up to ~2048 work items the one that fills the last round of workgroups best (fewest atomics on a tie)
+  int best = 1; double best_eff = -1.0;
+  static const int chain = [] { const char* e = getenv("LEC_X3_CHAIN"); const int v = e ? atoi(e) : 512; return v > 0 ? v : 512; }();
+  const int smin = (nchunks + chain - 1) / chain;
+  for (int sp = smin < 1 ? 1 : smin; sp <= nchunks && (sp == smin || (int64_t)g.tiles * sp <= 2048); ++sp) {
+    const int items = g.tiles * sp;
+    const double eff = (double)items / (double)(((items + wgs - 1) / wgs) * wgs);
+    if (eff > best_eff + 0.02) { best_eff = eff; best = sp; }
+  }
+  int cps = (nchunks + best - 1) / best; cps = (cps + 3) & ~3; if (cps < 4) cps = 4;
+  const int split = (nchunks + cps - 1) / cps;
+  g.cps = cps; g.items = g.tiles * split;
+  const int grid = g.items < wgs ? g.items : wgs;
+  const size_t lds = (size_t)2 * 3 * (128 + 128) * kX3Row;
+  hipStream_t st = (hipStream_t)stream;
+  if (dense) hipLaunchKernelGGL(conv_f32x3_wgrad_kernel<true>, dim3(grid), dim3(kX3Threads), lds, st, dy, x, dw, g);
+  else hipLaunchKernelGGL(conv_f32x3_wgrad_kernel<false>, dim3(grid), dim3(kX3Threads), lds, st, dy, x, dw, g);
+  LEC_CHECK_LAUNCH("conv_f32x3_wgrad_kernel");
   return LEC_OK;
 }

@@ -745,6 +745,19 @@ def conv_f32x3_dgrad(dy, planes, x_shape, stride, pad):
     return dx
 
 
+def conv_f32x3_wgrad_supported(cin, cout, r=1, s_=1):
+    return bool(lib.lec_conv_f32x3_wgrad_supported(cin, cout, r, s_))
+
+
+def conv_f32x3_wgrad(dy, x, dw, stride, pad):
+    """dw += weight gradient with fp32 products on the bf16 matrix cores (lec_conv_f32x3_wgrad, float atomics)."""
+    _nhwc_f32(dy, 'dy'); _nhwc_f32(x, 'x'); _nhwc_f32(dw, 'dw')
+    n, cin, h, wd = x.shape; cout, _, r, s_ = dw.shape
+    _conv_timed(lambda: check(lib.lec_conv_f32x3_wgrad(dptr(dy), dptr(x), n, h, wd, cin, cout, r, s_, stride, pad, dptr(dw), stream_ptr())),
+                2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * cout * cin * r * s_)
+    return dw
+
+
 def _bn_workspace(device):
     key = (device.type, device.index)
     ws = _bn_ws.get(key)

@@ -182,6 +182,10 @@ MFMA_WGRAD_3X3 = os.environ.get('LEC_CONV3X3_WGRAD', '1') != '0'
 MFMA_WGRAD_L3 = os.environ.get('LEC_CONV1X1_WGRAD_L3', '0') != '0'
 # fp32 activations (the reference's precision): every convolution runs liblecone's f32-MFMA implicit-GEMM family (csrc/conv_f32.hip)
 MFMA_F32 = os.environ.get('LEC_CONV_F32', '1') != '0'
+# 'native': the f32-input MFMA (exact fp32 fmaf chains, 157 TFLOP/s peak).  'x3': the same fp32 products on the bf16 matrix cores
+# (csrc/conv_f32x3.hip: three bf16 pieces per operand, six exact products per fp32 product, fp32 accumulation -- an fp32 dot product's
+# error, measured against fp64 in tests/test_fp32_gpu.py) for the forward and the data gradient; the weight gradient stays native.
+F32_MODE = os.environ.get('LEC_CONV_F32_MODE', 'native')
 GEMM_FWD_MIN_CIN = 1024
 GEMM_DGRAD_MIN_CIN = 256
 
@@ -240,7 +244,15 @@ class _OverlapConvFn(torch.autograd.Function):
             ctx.stem = conv.in_channels == 3
             if ctx.stem:                          # the kernels want >= 4 input channels: a zero 4th channel on both operands
                 x, w16 = _pad_c4(x), _pad_c4(w16)
-            y = _ops().conv_f32_fwd(x, w16, conv.stride[0], conv.padding[0], want_stats=True)
+            ctx.planes = None
+            if F32_MODE == 'x3':
+                planes = getattr(conv, '_x3_planes', None)
+                if planes is None or planes.shape != tuple(w16.shape) or planes.fwd.device != w16.device:
+                    planes = conv._x3_planes = _ops().X3Planes(w16.shape, w16.device)
+                ctx.planes = planes.update(w16)                 # the weights move every optimizer step: split again (tens of KB to a few MB)
+                y = _ops().conv_f32x3_fwd(x, planes, conv.stride[0], conv.padding[0], want_stats=True)
+            else:
+                y = _ops().conv_f32_fwd(x, w16, conv.stride[0], conv.padding[0], want_stats=True)
             ctx.save_for_backward(x, w16); ctx.conv = conv
             ctx.pointwise = ctx.own = ctx.own3 = False
             return y
@@ -299,7 +311,10 @@ class _OverlapConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             nhwc_g = gy.is_contiguous(memory_format=torch.channels_last)
             if ctx.f32:
-                gx = _ops().conv_f32_dgrad(gy, w16, x.shape, conv.stride[0], conv.padding[0])
+                if ctx.planes is not None and not ctx.stem:
+                    gx = _ops().conv_f32x3_dgrad(gy, ctx.planes, x.shape, conv.stride[0], conv.padding[0])
+                else:
+                    gx = _ops().conv_f32_dgrad(gy, w16, x.shape, conv.stride[0], conv.padding[0])
                 if ctx.stem:
                     gx = gx[:, :3]
             elif ctx.own3 and nhwc_g:                             # dX = conv(dY, W flipped and transposed): the same kernel,

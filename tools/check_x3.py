@@ -42,15 +42,19 @@ for name, cin, hw, cout, r, st, pad in SHAPES:
     row = {'layer': name}
     y3 = ops.conv_f32x3_fwd(x, pf, st, pad); y1 = ops.conv_f32_fwd(x, w, st, pad)
     row['fwd_err_x3'] = '%.2e' % relerr(y3, y64); row['fwd_err_f32'] = '%.2e' % relerr(y1, y64)
+    row['fwd_err_lib'] = '%.2e' % relerr(F.conv2d(x, w, None, st, pad), y64)
     if name != 'stem':
         dx64 = torch.ops.aten.convolution_backward(dy.double(), x.double(), w.double(), None, [st, st], [pad, pad], [1, 1], False, [0, 0], 1, [True, False, False])[0]
         dx3 = ops.conv_f32x3_dgrad(dy, pt, x.shape, st, pad); dx1 = ops.conv_f32_dgrad(dy, w, x.shape, st, pad)
         row['dgrad_err_x3'] = '%.2e' % relerr(dx3, dx64); row['dgrad_err_f32'] = '%.2e' % relerr(dx1, dx64)
-    if a.wgrad:
+    wg_ok = a.wgrad and ops.conv_f32x3_wgrad_supported(cin, cout, r, r)
+    if wg_ok:
         dw64 = torch.ops.aten.convolution_backward(dy.double(), x.double(), w.double(), None, [st, st], [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         dw3 = torch.zeros_like(w); ops.conv_f32x3_wgrad(dy, x, dw3, st, pad)
         dw1 = torch.zeros_like(w); ops.conv_f32_wgrad(dy, x, dw1, st, pad)
         row['wgrad_err_x3'] = '%.2e' % relerr(dw3, dw64); row['wgrad_err_f32'] = '%.2e' % relerr(dw1, dw64)
+        dwl = torch.ops.aten.convolution_backward(dy, x, w, None, [st, st], [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        row['wgrad_err_lib'] = '%.2e' % relerr(dwl, dw64)
     del x, dy, y64
     if a.time_rows:
         N = a.time_rows
@@ -61,7 +65,7 @@ for name, cin, hw, cout, r, st, pad in SHAPES:
         if name != 'stem':
             t3 = timeit(lambda: ops.conv_f32x3_dgrad(dy, pt, x.shape, st, pad), a.iters); t1 = timeit(lambda: ops.conv_f32_dgrad(dy, w, x.shape, st, pad), a.iters)
             row['dgrad_us_x3'] = round(t3, 1); row['dgrad_us_f32'] = round(t1, 1)
-        if a.wgrad:
+        if wg_ok:
             dw = torch.zeros_like(w)
             t3 = timeit(lambda: ops.conv_f32x3_wgrad(dy, x, dw, st, pad), a.iters); t1 = timeit(lambda: ops.conv_f32_wgrad(dy, x, dw, st, pad), a.iters)
             row['wgrad_us_x3'] = round(t3, 1); row['wgrad_us_f32'] = round(t1, 1)
