@@ -199,6 +199,138 @@ def test_conv_f32_fwd_dgrad_wgrad_exact_on_integers_and_vs_float64(N, Cin, H, W,
             assert torch.allclose(part[0], yr.detach().sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3)
 
 
+X3_CASES = CONV_CASES[:11] + [(2, 32, 6, 6, 32, 3, 1, 1), (3, 256, 10, 10, 128, 3, 1, 1), (2, 128, 16, 16, 256, 1, 1, 0)]
+
+
+@pytest.mark.parametrize('N,Cin,H,W,Cout,R,stride,pad', X3_CASES)
+def test_conv_f32x3_exact_on_integers_and_fp32_grade_vs_float64(N, Cin, H, W, Cout, R, stride, pad):
+    """lec_conv_f32x3_{fwd,dgrad,wgrad} (fp32 products as six bf16 products on the matrix cores).
+    (a) 'int': operands that fit the leading bf16 piece -- the result must EQUAL the float64 convolution;
+    (b) 'wide': 10-bit integers (two pieces per operand: the h*m, m*h and m*m products carry the answer) sized so that every partial
+        sum stays below 2^24 -- again EQUAL, so a lost or misplaced piece is a mismatch, not noise;
+    (c) 'rand': against float64, next to the exact-fp32 kernels of this library (f32-input MFMA) and of MIOpen on the same
+        operands: the split kernels' error must lie within twice the larger of the two (measured: at or below the f32-MFMA
+        kernel's for the forward and the data gradient, within 2x of it for the weight gradient), and under 5e-6 of the
+        tensor's maximum in any case."""
+    g = torch.Generator(device='cpu').manual_seed(Cin * 37 + Cout + R)
+    stem = Cin < 32
+    K = Cin * R * R
+    for kind in ('int', 'wide', 'rand'):
+        if kind == 'int':
+            x = torch.randint(-3, 4, (N, Cin, H, W), generator=g).float(); w = torch.randint(-2, 3, (Cout, Cin, R, R), generator=g).float()
+        elif kind == 'wide':
+            bx = 511; bw = max(2, min(300, (1 << 24) // (bx * K) - 1))          # |sum| <= K * bx * bw < 2^24
+            x = torch.randint(-bx, bx + 1, (N, Cin, H, W), generator=g).float(); w = torch.randint(-bw, bw + 1, (Cout, Cin, R, R), generator=g).float()
+        else:
+            x = torch.randn(N, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, R, R, generator=g) / K ** 0.5
+        x = _cl(x); w = _cl(w)
+        xr = x.double().requires_grad_(True); wr = w.double().requires_grad_(True)
+        yr = F.conv2d(xr, wr, None, stride, pad)
+        npix = yr.shape[0] * yr.shape[2] * yr.shape[3]
+        if kind == 'int':
+            dy = torch.randint(-2, 3, yr.shape, generator=g).float()
+        elif kind == 'wide':
+            bd = max(1, min(300, (1 << 24) // (511 * max(npix, Cout * R * R)) - 1))     # weight gradient: sums over pixels; data gradient: over Cout * taps
+            dy = torch.randint(-bd, bd + 1, yr.shape, generator=g).float()
+            if bd * 300 * Cout * R * R >= (1 << 24):                            # (the data gradient multiplies dy by w)
+                dy = dy.clamp(-((1 << 24) // (300 * Cout * R * R)), (1 << 24) // (300 * Cout * R * R))
+        else:
+            dy = torch.randn(yr.shape, generator=g)
+        dy = _cl(dy)
+        yr.backward(dy.double())
+        planes = ops.conv_f32x3_split_weights(w)
+        y = ops.conv_f32x3_fwd(x, planes, stride, pad, want_stats=True)
+        ws = ops._bn_workspace(x.device).view(torch.float32)
+        k = ops._BN_WS_OWNER[1]; ops._BN_WS_OWNER[0] = 0
+        part = ws[:k * 2 * Cout].view(k, 2, Cout).double().sum(0)
+        dx = None if stem else ops.conv_f32x3_dgrad(dy, planes, x.shape, stride, pad)
+        dw = None
+        if ops.conv_f32x3_wgrad_supported(Cin, Cout, R, R):
+            dw = torch.zeros_like(w); ops.conv_f32x3_wgrad(dy, x, dw, stride, pad)
+        assert y.shape == yr.shape and y.is_contiguous(memory_format=torch.channels_last)
+        if kind != 'rand':
+            assert torch.equal(y.double(), yr.detach()), 'forward (%s)' % kind
+            assert dx is None or torch.equal(dx.double(), xr.grad), 'data gradient (%s)' % kind
+            assert dw is None or torch.equal(dw.double(), wr.grad), 'weight gradient (%s)' % kind
+            if kind == 'int':
+                assert torch.equal(part[0], yr.detach().sum(dim=(0, 2, 3))) and torch.equal(part[1], (yr.detach() ** 2).sum(dim=(0, 2, 3)))
+        else:
+            err = lambda t, ref: (t.double() - ref).abs().max().item() / ref.abs().max().item()
+            cb = torch.ops.aten.convolution_backward
+            y1 = ops.conv_f32_fwd(x, w, stride, pad); yl = F.conv2d(x, w, None, stride, pad)
+            e3, e1, el = err(y, yr.detach()), err(y1, yr.detach()), err(yl, yr.detach())
+            assert e3 <= 2.0 * max(e1, el) + 1e-7 and e3 < 5e-6, ('forward', e3, e1, el)
+            if dx is not None:
+                d1 = ops.conv_f32_dgrad(dy, w, x.shape, stride, pad)
+                dl = cb(dy, x, w, None, [stride] * 2, [pad] * 2, [1, 1], False, [0, 0], 1, [True, False, False])[0]
+                e3, e1, el = err(dx, xr.grad), err(d1, xr.grad), err(dl, xr.grad)
+                assert e3 <= 2.0 * max(e1, el) + 1e-7 and e3 < 5e-6, ('data gradient', e3, e1, el)
+            if dw is not None:
+                w1 = torch.zeros_like(w); ops.conv_f32_wgrad(dy, x, w1, stride, pad)
+                wl = cb(dy, x, w, None, [stride] * 2, [pad] * 2, [1, 1], False, [0, 0], 1, [False, True, False])[1]
+                e3, e1, el = err(dw, wr.grad), err(w1, wr.grad), err(wl, wr.grad)
+                assert e3 <= 2.5 * max(e1, el) + 1e-7 and e3 < 5e-6, ('weight gradient', e3, e1, el)
+            assert torch.allclose(part[0], yr.detach().sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3)
+
+
+def test_conv_f32x3_weight_pieces_add_up_to_the_weight_exactly():
+    """lec_conv_f32x3_split_weights: in the tile-major planes, h + m + l of every element IS the fp32 weight (bit for bit), every
+    piece a bf16, padding rows / k are zeros -- for both layouts."""
+    g = torch.Generator(device='cpu').manual_seed(5)
+    for (cout, cin, r) in [(64, 4, 7), (192 // 3 * 2, 32, 3), (256, 128, 1), (64, 64, 3)]:
+        w = _cl(torch.randn(cout, cin, r, r, generator=g) * torch.logspace(-6, 3, cout).view(-1, 1, 1, 1))
+        pl = ops.conv_f32x3_split_weights(w)
+        wk = w.permute(0, 2, 3, 1).reshape(cout, r * r * cin)                                   # [co][tap * Cin + ci]
+        wt = w.permute(1, 2, 3, 0).reshape(cin, r * r * cout)                                   # [ci][tap * Cout + co]
+        for planes, mat in ((pl.fwd, wk), (pl.t, wt)):
+            ncol, kdim = mat.shape
+            bn = 64 if ncol <= 64 else 128
+            nt, kc = (ncol + bn - 1) // bn, (kdim + 15) // 16
+            p = (planes.view(nt, kc, 3, bn, 16).int() & 0xffff) << 16                           # bf16 bit patterns -> fp32 bit patterns
+            f = p.view(torch.float32) if p.dtype == torch.float32 else p.to(torch.int32).view(torch.float32)
+            tot = (f[:, :, 0] + f[:, :, 1]) + f[:, :, 2]                                         # [nt, kc, bn, 16]
+            full = tot.permute(0, 2, 1, 3).reshape(nt * bn, kc * 16)
+            assert torch.equal(full[:ncol, :kdim], mat), (cout, cin, r)
+            assert not full[ncol:].any() and not full[:, kdim:].any()
+
+
+def test_resnet_f32_split_mode_matches_exact_mode(monkeypatch):
+    """A ResNet-50 forward + backward with LEC_CONV_F32_MODE=x3 (forward, data and weight gradients on the bf16 matrix cores) against
+    the same pass on the f32-input MFMA: outputs, input gradient and every parameter gradient agree as closely as the f32-MFMA path agrees
+    with stock torch."""
+    from learning_embeddings_amd import resnet as R
+    torch.manual_seed(0)
+    net = resnet50(num_classes=10).to(DEV).to(memory_format=torch.channels_last)
+    net.train()
+    x0 = _cl(torch.rand(6, 3, 96, 96))
+    res = {}
+    g = None
+    for mode in ('native', 'x3'):
+        monkeypatch.setattr(R, 'F32_MODE', mode)
+        for p_ in net.parameters():
+            p_.grad = torch.zeros_like(p_)
+        x = x0.clone().requires_grad_(True)
+        WgradOverlap.instance = WgradOverlap()
+        try:
+            y = net(x)
+            if g is None:
+                g = torch.randn_like(y)
+            y.backward(g)
+            WgradOverlap.instance.join()
+            torch.cuda.synchronize()
+        finally:
+            WgradOverlap.instance = None
+        res[mode] = (y.detach().clone(), x.grad.clone(), [p_.grad.clone() for p_ in net.parameters()])
+    (y0, dx0, g0), (y1, dx1, g1) = res['native'], res['x3']
+    # the same bounds as the f32-MFMA path against stock torch below: through 50 layers of batch statistics over a handful of pixels
+    # and ReLU kinks, two fp32-grade convolution families differ by a few per cent in the deepest gradients
+    assert (y0 - y1).abs().max().item() <= 2e-4 * (1 + y0.abs().max().item())
+    cos = lambda a, b: float(a.double().flatten() @ b.double().flatten() / (a.double().norm() * b.double().norm() + 1e-300))
+    assert cos(dx0, dx1) > 0.9995
+    for a, b in zip(g0, g1):
+        assert cos(a, b) > 0.999, (tuple(a.shape), cos(a, b))
+
+
 @pytest.mark.parametrize('arch,hw,n', [('resnet18', 64, 8), ('resnet50', 96, 6)])
 def test_resnet_f32_own_convolutions_match_stock_torch(arch, hw, n):
     """The whole backbone at the reference's precision through liblecone only -- f32-MFMA convolutions (statistics epilogue, parity-class
