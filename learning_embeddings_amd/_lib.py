@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LEC_LIB_PATH') or os.path.join(_HERE, 'liblecone.so')     # LEC_LIB_PATH: A/B builds of the same ABI
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 OK, E_ARG, E_HIP, E_EMPTY, E_STATE = 0, -1, -2, -3, -4
 ENERGY_HYP_CONE, ENERGY_ORDER, ENERGY_EUC_CONE = 0, 1, 2

@@ -469,12 +469,23 @@ struct WgX3Geo {
   int Mpix, Ho, Wo, H, W, Cin, lgCin, Cout, S, stride, pad, Ng;
   int cps;                                 // chunks per work item (a multiple of 4; rows past Mpix are zeros)
   int tiles_n, tiles, items;
+  int per;                                 // ceil(items / 8): work items per XCD
   uint32_t dy_bytes, x_bytes;
   FastDiv dWo, dHo, dS;
 };
 
 __device__ __forceinline__ float bload1(rsrc_t rsrc, unsigned voff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, 0, 0));
+}
+
+// Work item of slot i (i = workgroup id + k * grid).  Workgroup ids go round-robin over the 8 XCDs, each with its own L2, and the
+// items are numbered K-split major (split * tiles + tile): XCD x takes the CONTIGUOUS items [x * per, (x + 1) * per), so the tiles
+// that share a K range -- the same dY rows for every tap / column tile, the same X rows for every Cout tile -- run side by side
+// on one XCD and the second to ninth reader of a chunk hits that XCD's L2 instead of HBM.  -1: no such item.
+__device__ __forceinline__ int x3_wg_item(int i, int items, int per) {
+  if (i >= 8 * per) return -1;
+  const int it = (i & 7) * per + (i >> 3);
+  return ((i >> 3) < per && it < items) ? it : -1;
 }
 
 template <bool DENSE>
@@ -485,7 +496,8 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_wgrad_kernel(const floa
   extern __shared__ __attribute__((aligned(16))) char smem_x3[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nit = (int)blockIdx.x < g.items ? (g.items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  int nit = 0;                                                  // items of this workgroup (slots blockIdx.x, + grid, ...)
+  for (int i = blockIdx.x; i < 8 * g.per; i += gridDim.x) nit += x3_wg_item(i, g.items, g.per) >= 0 ? 1 : 0;
   const int Q = nit * g.cps;
   const int T = (Q + 2 + 3) & ~3;
   if (Q == 0) return;
@@ -499,14 +511,16 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_wgrad_kernel(const floa
     const int C = isB ? g.Cin : g.Cout;                         // channels per pixel of this wave's source tensor
     const unsigned ldsW = (unsigned)((isB ? SA : 0) + lane * kX3Row + x3_half(lane, oct));   // channel row `lane`; row lane + 64: + 64 rows (same bit 3)
     // load stream: item, chunk inside the item
-    int ld_it = blockIdx.x, ld_ch = 0;
+    int ld_slot = blockIdx.x, ld_ch = 0;
     unsigned vcol = 0;                                          // byte offset of this lane's first channel inside a pixel
     int dr = 0, ds = 0;                                         // the tile's tap, relative to the output pixel (B)
     int ch0 = 0;                                                // first chunk of the item
     unsigned pixo = 0;                                          // B: byte offset of the source pixel of (group base + lane), kOob if there is none
     float rr[4][16];
     auto item_setup = [&]() __attribute__((always_inline)) {
-      const int wi = ld_it;
+      int wi = x3_wg_item(ld_slot, g.items, g.per);
+      while (wi < 0 && ld_slot < 8 * g.per) { ld_slot += gridDim.x; wi = x3_wg_item(ld_slot, g.items, g.per); }
+      if (wi < 0) wi = 0;                                         // (past the last item: dead loads of the steps that drain the ring)
       const int tile = wi % g.tiles, sp = wi / g.tiles;
       const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
       ch0 = sp * g.cps;
@@ -542,7 +556,7 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_wgrad_kernel(const floa
         rr[I][2 * r] = bload1(rs, o);
         rr[I][2 * r + 1] = bload1(rs, o + 256u);
       }
-      if (++ld_ch == g.cps) { ld_ch = 0; ld_it += gridDim.x; }
+      if (++ld_ch == g.cps) { ld_ch = 0; ld_slot += gridDim.x; }
     };
     auto step = [&](auto i_c) __attribute__((always_inline)) {
       constexpr int I = decltype(i_c)::value;
@@ -581,9 +595,11 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_wgrad_kernel(const floa
           for (int r = 0; r < 16; ++r) acc[it][jt][r] = 0.f;
     };
     zero_acc();
-    int cur_it = blockIdx.x;
+    int cur_slot = blockIdx.x;
     x3_consumer_loop<BM, BN, TM, TN>(smem_x3, Q, T, g.cps, wm0, wn0, lane, acc, [&]() __attribute__((always_inline)) {
-      const int tile = cur_it % g.tiles;
+      int wi = x3_wg_item(cur_slot, g.items, g.per);
+      while (wi < 0) { cur_slot += gridDim.x; wi = x3_wg_item(cur_slot, g.items, g.per); }   // (terminates: this is one of the nit items)
+      const int tile = wi % g.tiles;
       const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
       float* out = dw + (int64_t)(tm * BM + wm0) * g.Ng + tn * BN + wn0 + l31;
 #pragma unroll
@@ -595,7 +611,7 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_wgrad_kernel(const floa
           for (int jt = 0; jt < TN; ++jt) atomicAdd(out + (int64_t)row * g.Ng + jt * 32, acc[it][jt][r]);
         }
       zero_acc();
-      cur_it += gridDim.x;
+      cur_slot += gridDim.x;
     });
   }
 }
@@ -764,8 +780,8 @@ extern "C" int lec_conv_f32x3_wgrad(const float* dy, const float* x, int N, int 
   }
   int cps = (nchunks + best - 1) / best; cps = (cps + 3) & ~3; if (cps < 4) cps = 4;
   const int split = (nchunks + cps - 1) / cps;
-  g.cps = cps; g.items = g.tiles * split;
-  const int grid = g.items < wgs ? g.items : wgs;
+  g.cps = cps; g.items = g.tiles * split; g.per = (g.items + 7) / 8;
+  const int grid = 8 * g.per < wgs ? 8 * g.per : wgs;
   const size_t lds = (size_t)2 * 3 * (128 + 128) * kX3Row;
   hipStream_t st = (hipStream_t)stream;
   if (dense) hipLaunchKernelGGL(conv_f32x3_wgrad_kernel<true>, dim3(grid), dim3(kX3Threads), lds, st, dy, x, dw, g);
