@@ -153,6 +153,38 @@ def test_bf16_step_drift_from_the_reference_precision_is_bounded():
     assert de < 0.2
 
 
+def test_split_mode_cone_energies_within_the_north_star_tolerance(monkeypatch):
+    """north_star: cone energies within 1e-4 of the reference's fp32 path.  ResNet-50 (random init, batch 32, 224 x 224, training-mode
+    BatchNorm) -> raw features -> cone energies, three times on the same weights and batch: liblecone's f32-MFMA convolutions (exact
+    fp32), the split mode (fp32 products as six bf16 products), stock torch / MIOpen fp32.  The split mode must sit as close to the
+    exact kernels as the two exact implementations sit to each other, and within 1e-4 on the energies."""
+    from learning_embeddings_amd.oe_h import FeatCNN
+    from learning_embeddings_amd import resnet as R
+    torch.manual_seed(0)
+    D = 10
+    net = FeatCNN(image_dir='', output_dim=D, K=0.1, compute_dtype=torch.float32).to(DEV)
+    net.train()
+    x = _cl(torch.rand(32, 3, 224, 224))
+    lab = torch.randn(32, D, device=DEV); lab = lab / lab.norm(dim=1, keepdim=True) * 0.3
+    out = {}
+    for tag in ('native', 'x3', 'stock'):
+        monkeypatch.setattr(R, 'F32_MODE', 'x3' if tag == 'x3' else 'native')
+        WgradOverlap.instance = WgradOverlap() if tag != 'stock' else None
+        try:
+            with torch.no_grad():
+                raw = net.forward_raw(x)
+            torch.cuda.synchronize()
+        finally:
+            WgradOverlap.instance = None
+        out[tag] = (raw.clone(), ops.pair_energy(lab, net.soft_clip(raw), 0.1).clone())
+    rel = lambda a, b: ((a - b).norm() / a.norm()).item()
+    d_x3 = (out['native'][1] - out['x3'][1]).abs().max().item(); d_lib = (out['native'][1] - out['stock'][1]).abs().max().item()
+    r_x3 = rel(out['native'][0], out['x3'][0]); r_lib = rel(out['native'][0], out['stock'][0])
+    print('ResNet-50 raw outputs, relative L2 to the f32-MFMA path: split %.2e, MIOpen fp32 %.2e; max |dE|: split %.2e, MIOpen %.2e' % (r_x3, r_lib, d_x3, d_lib))
+    assert d_x3 <= 1e-4
+    assert r_x3 <= 3.0 * r_lib + 1e-6
+
+
 # ---------------------------------------------------------------------------------------------------------------- fp32 convolutions
 CONV_CASES = [  # N, Cin, H, W, Cout, R, stride, pad
     (2, 64, 12, 12, 64, 1, 1, 0), (2, 64, 12, 12, 256, 1, 1, 0), (3, 256, 9, 7, 64, 1, 1, 0), (2, 64, 10, 14, 64, 3, 1, 1),

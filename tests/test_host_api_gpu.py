@@ -372,11 +372,15 @@ def test_config2_full_batch_128_matches_oracle():
     eng.close()
 
 
-@pytest.mark.parametrize('dtype,graph', [('fp32', False), ('fp32', True), ('bf16', True)])
-def test_config3_benchmarked_workload_full_batch_256_matches_oracle(dtype, graph):
+@pytest.mark.parametrize('dtype,graph', [('fp32', False), ('fp32', True), ('bf16', True), ('fp32-x3', True)])
+def test_config3_benchmarked_workload_full_batch_256_matches_oracle(dtype, graph, monkeypatch):
     """The workload bench.py measures (configs[2]: S3 hierarchy of 2 000 labels, ResNet-50, B = 256, K = 5, D = 10, 512 CNN rows per
     step), at full size, in the launch modes it is measured in: negatives bit-equal to the reference's stream, loss / energies /
-    table update against the oracle at the embedding boundary.  (fp32 eager, fp32 hipGraph replay, bf16 hipGraph replay.)"""
+    table update against the oracle at the embedding boundary.  (fp32 eager, fp32 hipGraph replay, bf16 hipGraph replay, fp32 with the
+    split convolutions under hipGraph replay.)"""
+    if dtype == 'fp32-x3':
+        from learning_embeddings_amd import resnet as R
+        monkeypatch.setattr(R, 'F32_MODE', 'x3'); dtype = 'fp32'
     eng = StepEngine('cfg3', n_images=4096, dtype=dtype, use_graph=graph, graph_after=1)
     assert eng.B == 256 and eng.n_rows == 512 and eng.N == 2000
     _engine_vs_oracle(eng, 4096, steps=3)
