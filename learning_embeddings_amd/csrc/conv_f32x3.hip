@@ -36,6 +36,11 @@ typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 constexpr int kX3BK = 16;                 // K chunk = one v_mfma_f32_32x32x16_bf16 step
 constexpr int kX3Row = 32;                // bytes of an LDS row of one plane (16 bf16, no padding: see x3_half)
 constexpr int kX3Threads = 512;           // 4 consumer + 4 producer waves
+#ifndef LEC_X3_ACT_PROD
+#define LEC_X3_ACT_PROD 256
+#endif
+constexpr int kX3ActProd = LEC_X3_ACT_PROD;          // producer threads of the activation-gather kernel (256, or 512: two producer waves per SIMD)
+constexpr int kX3ActThreads = 256 + kX3ActProd;
 #ifndef LEC_X3_PRIO
 #define LEC_X3_PRIO 1
 #endif
@@ -46,7 +51,6 @@ constexpr int kX3Threads = 512;           // 4 consumer + 4 producer waves
 #define LEC_X3_DBG 0                      // experiments (wrong results): 1 no split arithmetic, 2 producers idle, 4 no MFMAs, 8 no fragment reads
 #endif
 constexpr int kX3KQ = kX3BK / 4;          // 16-byte fp32 pieces per row of an activation tile
-constexpr int kX3RP = kCfThreads / kX3KQ; // rows staged per pass
 
 // Pre-split weights are stored TILE-MAJOR: [n tile][k chunk][plane h|m|l][BN rows][16 k] bf16, so that the B operand of one step is one
 // contiguous block of 3 * BN * 32 bytes (full cache lines, read once) in exactly the order of its LDS image.  BN = x3_bn(columns).
@@ -212,13 +216,14 @@ __device__ __forceinline__ void x3_consumer_loop(const char* __restrict__ smem, 
 // Chunks number through the workgroup's m-tiles without a break, so the producers run ahead into the next tile while the
 // consumers store the finished one.
 template <int WM, int WN, int TM, int TN, bool STATS, bool TAPV>
-__global__ __launch_bounds__(kX3Threads) void conv_f32x3_act_kernel(const float* __restrict__ src, const uint16_t* __restrict__ wpl,
+__global__ __launch_bounds__(kX3ActThreads) void conv_f32x3_act_kernel(const float* __restrict__ src, const uint16_t* __restrict__ wpl,
                                                                     float* __restrict__ dst, ActGeo g, X3Wgt wg, float* __restrict__ part) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   static_assert(WM * WN == 4, "four consumer waves per workgroup");
-  constexpr int NA = BM / kX3RP;                               // fp32 pieces of the A tile per producer thread
+  constexpr int RPP = kX3ActProd / kX3KQ;                      // rows staged per pass of the producers
+  constexpr int NA = BM / RPP;                               // fp32 pieces of the A tile per producer thread
   constexpr int NBP = 6 * BN;                                  // 16-byte bf16 pieces of the B tile: 3 planes x BN rows x 2 halves
-  constexpr int NB = (NBP + kCfThreads - 1) / kCfThreads;
+  constexpr int NB = (NBP + kX3ActProd - 1) / kX3ActProd;
   constexpr int SA = 3 * BM * kX3Row, SBUF = 3 * (BM + BN) * kX3Row;   // bytes
   extern __shared__ __attribute__((aligned(16))) char smem_x3[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -234,14 +239,14 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_act_kernel(const float*
   if (producer) {
     if (Q == 0) return;
     if (LEC_X3_PRIO) __builtin_amdgcn_s_setprio(LEC_X3_PRIO);  // the second-dispatched half of a workgroup loses the VALU arbitration otherwise
-    const int ptid = tid & (kCfThreads - 1);
+    const int ptid = tid - kCfThreads;
     const int kqA = ptid & (kX3KQ - 1), rowA = ptid / kX3KQ;
     const rsrc_t rs_src = make_rsrc(src, g.src_bytes), rs_wgt = make_rsrc(wpl, g.wgt_bytes);
     // B pieces of this thread: 16-byte piece v of a chunk's contiguous block [plane][row][half] -> the same place of the LDS image
     unsigned vB[NB], ldsB[NB];
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
-      const int v = ptid + kCfThreads * u;
+      const int v = ptid + kX3ActProd * u;
       const int pl = v / (2 * BN), rem = v - pl * 2 * BN, row = rem >> 1, half = rem & 1;
       vB[u] = v < NBP ? (unsigned)v * 16u : kOob;
       ldsB[u] = (unsigned)(SA + (pl * BN + row) * kX3Row + x3_half(row, half));
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_act_kernel(const float*
       const int m0 = mt * BM;
 #pragma unroll
       for (int u = 0; u < NA; ++u) {
-        const int m = m0 + rowA + kX3RP * u;
+        const int m = m0 + rowA + RPP * u;
         const bool live = m < g.Mg;
         const int mm = live ? m : 0;
         const int t2 = fdiv(mm, g.dWm); const int mw = mm - t2 * g.Wm; const int n = fdiv(t2, g.dHm); const int mh = t2 - n * g.Hm;
@@ -279,25 +284,29 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_act_kernel(const float*
       cur_tap = -1;
     };
     // chunks a_c, a_c + 1 (the same tap: source channels are a multiple of 32) -> ra[DSET][u][0 | 1]
+    // The stream's position is kept INCREMENTALLY (tap, byte offset of the channel block inside the pixel): a producer wave's
+    // instruction stream is the critical path of the kernel (one wave per SIMD issues ~1 instruction per 9 cycles next to the
+    // MFMAs), and the from-scratch decode (shifts, masks, an exact division per chunk) was a third of it.
+    int a_tap = 0; unsigned a_c0b = 0;
+    const unsigned a_row_bytes = (unsigned)g.Cs * 4u;
     auto issueA = [&](auto dset_c) __attribute__((always_inline)) {
       constexpr int DSET = decltype(dset_c)::value;
-      if (a_ch == 0) tile_setup(a_mt);                          // (past the last tile every row is dead: the loads fall out of range)
-      const int k0 = a_ch * kX3BK;
-      const int tap = k0 >> g.lgCs, c0 = k0 & (g.Cs - 1);
-      if (tap != cur_tap) {
-        cur_tap = tap;
-        const int ta = fdiv(tap, g.dnb), tb = tap - ta * g.nb;
+      if (a_ch == 0) { tile_setup(a_mt); a_tap = 0; a_c0b = 0; } // (past the last tile every row is dead: the loads fall out of range)
+      if (a_tap != cur_tap) {
+        cur_tap = a_tap;
+        const int ta = fdiv(a_tap, g.dnb), tb = a_tap - ta * g.nb;
         const int toff = (((g.sg * ta) * g.Ws + g.sg * tb) << g.lgCs) * 4;
-        const unsigned tapbit = 1u << tap;
+        const unsigned tapbit = 1u << a_tap;
 #pragma unroll
         for (int u = 0; u < NA; ++u) cur[u] = (tapmask[u] & tapbit) ? (unsigned)(rowoff[u] + toff) : kOob;
       }
-      const unsigned c0b = (unsigned)c0 * 4u;
 #pragma unroll
       for (int u = 0; u < NA; ++u) {
-        ra[DSET][u][0] = bload4(rs_src, cur[u] + c0b);          // (a poisoned offset stays out of range: c0b < 2^14)
-        ra[DSET][u][1] = bload4(rs_src, cur[u] + c0b + 64u);
+        ra[DSET][u][0] = bload4(rs_src, cur[u] + a_c0b);        // (a poisoned offset stays out of range: a_c0b < 2^14)
+        ra[DSET][u][1] = bload4(rs_src, cur[u] + a_c0b + 64u);
       }
+      a_c0b += 128u;
+      if (a_c0b == a_row_bytes) { a_c0b = 0; ++a_tap; }
       a_ch += 2;
       if (a_ch >= nchunks) { a_ch = 0; a_mt += gridDim.x; }
     };
@@ -318,17 +327,23 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_act_kernel(const float*
       }
       if (++a_ch == nchunks) { a_ch = 0; a_mt += gridDim.x; }
     };
+    constexpr unsigned kBlk = (unsigned)(3 * BN * kX3BK * 2);    // bytes of one chunk's B block
+    const bool b_linear = g.rstep == 1 && g.sstep == 1;          // the launch walks every tap in order (forward, stride-1 data gradient): block index = chunk index
+    unsigned b_wsc = wtile * kBlk;
     auto issueB = [&](auto set_c) __attribute__((always_inline)) {
       constexpr int SET = decltype(set_c)::value;
-      const int k0 = b_ch * kX3BK;
-      const int tap = k0 >> g.lgCs, c0 = k0 & (g.Cs - 1);       // (the stem: forward only, where tw == tap and the chunk index is b_ch itself)
-      const int ta = fdiv(tap, g.dnb), tb = tap - ta * g.nb;
-      const int tw = (g.r0 + g.rstep * ta) * g.S + g.s0 + g.sstep * tb;
-      const unsigned kc = (unsigned)(tw * g.Cs + c0) >> 4;
-      const unsigned wsc = (wtile + kc) * (unsigned)(3 * BN * kX3BK * 2);
+      unsigned wsc = b_wsc;
+      if (!b_linear) {                                          // a parity class of a strided data gradient: its taps are a subset, decode
+        const int k0 = b_ch * kX3BK;
+        const int tap = k0 >> g.lgCs, c0 = k0 & (g.Cs - 1);
+        const int ta = fdiv(tap, g.dnb), tb = tap - ta * g.nb;
+        const int tw = (g.r0 + g.rstep * ta) * g.S + g.s0 + g.sstep * tb;
+        wsc = (wtile + ((unsigned)(tw * g.Cs + c0) >> 4)) * kBlk;
+      }
 #pragma unroll
       for (int u = 0; u < NB; ++u) rb[SET][u] = __builtin_bit_cast(u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_wgt, (int)(vB[u] + wsc), 0, 0));
-      if (++b_ch == nchunks) b_ch = 0;                          // (past the last chunk: harmless re-reads)
+      b_wsc += kBlk;
+      if (++b_ch == nchunks) { b_ch = 0; b_wsc = wtile * kBlk; }  // (past the last chunk: harmless re-reads)
     };
     // chunk t (= i mod 4): registers -> LDS stage t & 1, then refill.  No branch around a load or a store: the steps past the last
     // chunk run too (dead loads, a stage nobody reads), so that the compiler's vmcnt bookkeeping stays exact and the loads really
@@ -341,12 +356,12 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_act_kernel(const float*
         for (int u = 0; u < NA; ++u) {
           u32x2v h, m, l;
           split4(ra[I >> 1][u][I & 1], h, m, l);
-          char* p = base + ldsA + u * kX3RP * kX3Row;
+          char* p = base + ldsA + u * RPP * kX3Row;
           *(u32x2v*)(p) = h; *(u32x2v*)(p + BM * kX3Row) = m; *(u32x2v*)(p + 2 * BM * kX3Row) = l;
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u)
-          if (NBP % kCfThreads == 0 || ptid + kCfThreads * u < NBP) *(u32x4v*)(base + ldsB[u]) = rb[I][u];
+          if (NBP % kX3ActProd == 0 || ptid + kX3ActProd * u < NBP) *(u32x4v*)(base + ldsB[u]) = rb[I][u];
         issueB(i_c);
         if (TAPV) issueA_tapv(std::integral_constant<int, (I >> 1)>{}, std::integral_constant<int, (I & 1)>{});
         else if (I & 1) issueA(std::integral_constant<int, (I >> 1)>{});
@@ -444,7 +459,7 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_act_kernel(const float*
   if (STATS) {
     __syncthreads();
     const float* red = (const float*)smem_x3;
-    for (int i = tid; i < 2 * BN; i += kX3Threads) {
+    for (int i = tid; i < 2 * BN; i += kX3ActThreads) {
       const int s = i / BN, c = i - s * BN;
       float v = 0.f;
 #pragma unroll
@@ -663,7 +678,7 @@ static int launch_act_x3(const float* src, const uint16_t* wpl, float* dst, cons
   LEC_CHECK_ARG(!tapv || (g.rstep == 1 && g.sstep == 1 && g.r0 == 0 && g.s0 == 0),
                 "conv_f32x3: layers with fewer than 32 source channels are supported in the forward direction only");
   LEC_CHECK_ARG(BN == x3_bn(g.Cd), "conv_f32x3: tile width and weight layout disagree");
-  const dim3 grid(gx, ntiles), blk(kX3Threads);
+  const dim3 grid(gx, ntiles), blk(kX3ActThreads);
   if (tapv) {
     if (narrow) hipLaunchKernelGGL((conv_f32x3_act_kernel<4, 1, 2, 2, STATS, true>), grid, blk, lds, st, src, wpl, dst, g, wg, part);
     else hipLaunchKernelGGL((conv_f32x3_act_kernel<2, 2, 2, 2, STATS, true>), grid, blk, lds, st, src, wpl, dst, g, wg, part);
