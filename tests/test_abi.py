@@ -38,3 +38,19 @@ def test_cpu_tensor_is_refused():
     from learning_embeddings_amd import ops
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         ops.pair_energy(torch.rand(4, 10), torch.rand(4, 10))
+
+
+def test_conv_f32x3_host_geometry_queries():
+    """Host-only entry points of the split convolutions: plane sizes follow the tile-major layout [column tile][k chunk][3][BN][16]
+    (BN = 64 up to 64 columns, else 128; k padded to 16), and the weight gradient serves powers of two from 128 channels."""
+    from learning_embeddings_amd import _lib
+    lib = _lib.lib
+    def elems(ncols, kdim):
+        bn = 64 if ncols <= 64 else 128
+        return ((ncols + bn - 1) // bn) * ((kdim + 15) // 16) * 3 * bn * 16
+    for cout, rs, cin in [(64, 49, 4), (64, 9, 64), (256, 1, 64), (128, 9, 128), (2048, 1, 512), (512, 9, 512), (1000, 1, 40)]:
+        assert lib.lec_conv_f32x3_planes_elems(cout, rs, cin, 0) == elems(cout, rs * cin)
+        assert lib.lec_conv_f32x3_planes_elems(cout, rs, cin, 1) == elems(cin, rs * cout)
+    assert lib.lec_conv_f32x3_wgrad_supported(128, 128, 3, 3) == 1 and lib.lec_conv_f32x3_wgrad_supported(2048, 512, 1, 1) == 1
+    assert lib.lec_conv_f32x3_wgrad_supported(64, 256, 1, 1) == 0 and lib.lec_conv_f32x3_wgrad_supported(256, 64, 1, 1) == 0
+    assert lib.lec_conv_f32x3_wgrad_supported(192, 128, 1, 1) == 0
