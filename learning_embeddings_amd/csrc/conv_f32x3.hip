@@ -205,6 +205,70 @@ __device__ __forceinline__ void x3_consumer_loop(const char* __restrict__ smem, 
   }
 }
 
+// The same loop with ROLLING fragment registers, for workgroups with two producer waves per SIMD (12 waves: 168 registers per wave).
+// A plane of the current chunk is dead after its last product (a_l after product 0, b_l after 1, a_m after 3, b_m after 4), so the next
+// chunk's plane is read into the same registers right there; only the h planes, which product 5 uses last and product 0 / 1 of the next
+// chunk use first, are double-buffered: 64 fragment registers instead of 96.
+template <int BM, int BN, int TM, int TN, class TileDone>
+__device__ __forceinline__ void x3_consumer_loop_rolling(const char* __restrict__ smem, int Q, int T, int nchunks, int wm0, int wn0, int lane,
+                                                         f32x16 (&acc)[TM][TN], TileDone&& tile_done) {
+  constexpr int SA = 3 * BM * kX3Row, SBUF = 3 * (BM + BN) * kX3Row;
+  bf16x8 ah[2][TM], bh[2][TN], am[TM], al[TM], bm[TN], bl[TN];
+  const int l31 = lane & 31, hs = x3_half(l31, lane >> 5);
+  const char* pa = smem + (wm0 + l31) * kX3Row + hs;            // plane 0, tile 0 of A in stage 0
+  const char* pb = smem + SA + (wn0 + l31) * kX3Row + hs;
+  auto rdA = [&](int stage, int plane, bf16x8 (&d)[TM]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < TM; ++it) d[it] = *(const bf16x8*)(pa + stage * SBUF + (plane * BM + it * 32) * kX3Row);
+  };
+  auto rdB = [&](int stage, int plane, bf16x8 (&d)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int jt = 0; jt < TN; ++jt) d[jt] = *(const bf16x8*)(pb + stage * SBUF + (plane * BN + jt * 32) * kX3Row);
+  };
+  auto mm = [&](const bf16x8 (&a)[TM], const bf16x8 (&b)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < TM; ++it)
+#pragma unroll
+      for (int jt = 0; jt < TN; ++jt)
+        if (!(LEC_X3_DBG & 4)) acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[it], b[jt], acc[it][jt], 0, 0, 0);
+  };
+  int mm_ch = 0;
+  // step t >= 2: MFMAs of chunk c = t - 2 (stage parity S = c & 1), reads of chunk c + 1 from stage S ^ 1 as the registers free up
+  auto fast_step = [&](auto s_c) __attribute__((always_inline)) {
+    constexpr int S = decltype(s_c)::value;
+    rdA(S ^ 1, 0, ah[S ^ 1]); rdB(S ^ 1, 0, bh[S ^ 1]);
+    mm(al, bh[S]);                                              // product 0: a_l b_h
+    __builtin_amdgcn_sched_barrier(0);
+    rdA(S ^ 1, 2, al);
+    mm(ah[S], bl);                                              // product 1: a_h b_l
+    __builtin_amdgcn_sched_barrier(0);
+    rdB(S ^ 1, 2, bl);
+    mm(am, bm);                                                 // product 2: a_m b_m
+    mm(am, bh[S]);                                              // product 3: a_m b_h
+    __builtin_amdgcn_sched_barrier(0);
+    rdA(S ^ 1, 1, am);
+    mm(ah[S], bm);                                              // product 4: a_h b_m
+    __builtin_amdgcn_sched_barrier(0);
+    rdB(S ^ 1, 1, bm);
+    __builtin_amdgcn_sched_barrier(0);
+    x3_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    mm(ah[S], bh[S]);                                           // product 5: a_h b_h
+    if (++mm_ch == nchunks) { tile_done(); mm_ch = 0; }
+  };
+  // t = 0: nothing to read yet; t = 1: every plane of chunk 0 (stage 0)
+  x3_barrier();
+  rdA(0, 0, ah[0]); rdB(0, 0, bh[0]); rdA(0, 1, am); rdB(0, 1, bm); rdA(0, 2, al); rdB(0, 2, bl);
+  x3_barrier();
+  int t = 2;
+  for (; t + 1 <= Q + 1; t += 2) {                               // chunks t - 2 (even) and t - 1 (odd); the last chunk's look-ahead reads are dead
+    fast_step(std::integral_constant<int, 0>{});
+    fast_step(std::integral_constant<int, 1>{});
+  }
+  if (t <= Q + 1) { fast_step(std::integral_constant<int, 0>{}); ++t; }
+  for (; t < T; ++t) x3_barrier();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // forward / data gradient.  A = gathered fp32 activations (split on the way to LDS), B = pre-split bf16 weights, k contiguous.
 // A workgroup is 8 waves, one per role and SIMD: waves 0-3 (consumers) own the accumulators -- per step 12 ds_read_b128 of the NEXT
@@ -439,9 +503,9 @@ __global__ __launch_bounds__(kX3ActThreads) void conv_f32x3_act_kernel(const flo
     }
     if (Q > 0) {
       int mm_mt = blockIdx.x;                                   // the m-tile the accumulators belong to
-      x3_consumer_loop<BM, BN, TM, TN>(smem_x3, Q, T, nchunks, wm0, wn0, lane, acc, [&]() __attribute__((always_inline)) {
-        epilogue(mm_mt); zero_acc(); mm_mt += gridDim.x;
-      });
+      auto done = [&]() __attribute__((always_inline)) { epilogue(mm_mt); zero_acc(); mm_mt += gridDim.x; };
+      if (kX3ActProd > 256) x3_consumer_loop_rolling<BM, BN, TM, TN>(smem_x3, Q, T, nchunks, wm0, wn0, lane, acc, done);
+      else x3_consumer_loop<BM, BN, TM, TN>(smem_x3, Q, T, nchunks, wm0, wn0, lane, acc, done);
     }
     if (STATS) {
       // lane halves -> waves of the same column block -> one partial row per workgroup: part[blockIdx.x][2][Cd]
