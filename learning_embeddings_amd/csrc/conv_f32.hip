@@ -51,36 +51,42 @@ template <bool A_KC, bool B_KC, int LDA, int LDB, int TM, int TN, int BKT = kCfB
 __device__ __forceinline__ void mma_chunk(const float* __restrict__ sA, const float* __restrict__ sB, int wm0, int wn0, int lane,
                                           f32x16 (&acc)[TM][TN]) {
   const int l31 = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int q = 0; q < BKT / 8; ++q) {
-    float a[TM][4], b[TN][4];
+  // the fragments of 8-group q + 1 are read while the MFMAs of group q run (two register sets): left to itself the compiler reads a
+  // group right before its MFMAs and the LDS latency is exposed four times per chunk
+  float a[2][TM][4], b[2][TN][4];
+  auto rd = [&](int q, int s_) __attribute__((always_inline)) {
 #pragma unroll
     for (int it = 0; it < TM; ++it) {
       if (A_KC) {
         const f32x4v v = *(const f32x4v*)(sA + (wm0 + it * 32 + l31) * kCfLdk + 8 * q + 4 * h);
-        a[it][0] = v[0]; a[it][1] = v[1]; a[it][2] = v[2]; a[it][3] = v[3];
+        a[s_][it][0] = v[0]; a[s_][it][1] = v[1]; a[s_][it][2] = v[2]; a[s_][it][3] = v[3];
       } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) a[it][t] = lds_ld1(sA + 4 * h * LDA + wm0 + it * 32 + l31, (8 * q + t) * LDA);
+        for (int t = 0; t < 4; ++t) a[s_][it][t] = lds_ld1(sA + 4 * h * LDA + wm0 + it * 32 + l31, (8 * q + t) * LDA);
       }
     }
 #pragma unroll
     for (int it = 0; it < TN; ++it) {
       if (B_KC) {
         const f32x4v v = *(const f32x4v*)(sB + (wn0 + it * 32 + l31) * kCfLdk + 8 * q + 4 * h);
-        b[it][0] = v[0]; b[it][1] = v[1]; b[it][2] = v[2]; b[it][3] = v[3];
+        b[s_][it][0] = v[0]; b[s_][it][1] = v[1]; b[s_][it][2] = v[2]; b[s_][it][3] = v[3];
       } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) b[it][t] = lds_ld1(sB + 4 * h * LDB + wn0 + it * 32 + l31, (8 * q + t) * LDB);
+        for (int t = 0; t < 4; ++t) b[s_][it][t] = lds_ld1(sB + 4 * h * LDB + wn0 + it * 32 + l31, (8 * q + t) * LDB);
       }
     }
+  };
+  rd(0, 0);
+#pragma unroll
+  for (int q = 0; q < BKT / 8; ++q) {
+    if (q + 1 < BKT / 8) { rd(q + 1, (q + 1) & 1); __builtin_amdgcn_sched_barrier(0); }   // (pinned: the scheduler sinks the reads back to their use otherwise)
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int it = 0; it < TM; ++it)
 #pragma unroll
         for (int jt = 0; jt < TN; ++jt)
-          acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[it][t], b[jt][t], acc[it][jt], 0, 0, 0);
+          acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][it][t], b[q & 1][jt][t], acc[it][jt], 0, 0, 0);
   }
 }
 
