@@ -13,6 +13,7 @@
 // one fp32 partial per block and channel -> finalize kernel (double accumulation over <= 1024 partials).
 // Roofline: HBM. Algorithmic bytes per element (bf16): fwd 2+2+2 (+2 residual); bwd 6 (reduce) + 6+2 (+2 d residual).
 #include <hip/hip_bf16.h>
+#include <cstdlib>
 #include "lec_common.h"
 
 namespace lec {
@@ -88,6 +89,10 @@ constexpr int kBnMaxBlocks = 512;
 // strided set of rows; grid = (nrb row blocks, NCH channel chunks), nrb * NCH <= 512 blocks (2 per CU, 8 loads in flight
 // per thread).  Per channel there are nrb partials, reduced by a 1024-thread finalize kernel (32 channels x 32 splits).
 // Apply passes: a block covers whole rows (CV vectors), up to 2048 blocks.
+static inline int bn_apply_cap() {                         // blocks of an apply pass (experiments: LEC_BN_BLOCKS)
+  static const int v = [] { const char* e = getenv("LEC_BN_BLOCKS"); const int x = e ? atoi(e) : 2048; return x > 0 ? x : 2048; }();
+  return v;
+}
 struct BnGeom { int CV, RPI, CVB, NCH, RPIB, nrb; };
 static inline BnGeom bn_geom(int64_t M, int C) {
   BnGeom g; g.CV = C / 8; g.RPI = kBnThreads / g.CV;
@@ -445,7 +450,7 @@ template <typename E> static int bn_fwd_impl(const void* x, const void* residual
     hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3((C + 255) / 256), dim3(256), 0, st, C, gamma, beta, eps, running_mean, running_var, scale, shift);
   }
   int64_t nb = (M + g.RPI - 1) / g.RPI; nb = (nb + 3) / 4;
-  const int nblk = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
+  const int nblk = (int)(nb < 1 ? 1 : (nb > bn_apply_cap() ? bn_apply_cap() : nb));
 #define A(RES_, RELU_) hipLaunchKernelGGL((bn_apply_kernel<E, RES_, RELU_>), dim3(nblk), dim3(kBnThreads), 0, st, x, residual, M, g.CV, g.RPI, scale, shift, y, relu_mask)
   if (residual) { if (relu) A(true, true); else A(true, false); } else { if (relu) A(false, true); else A(false, false); }
 #undef A
@@ -473,7 +478,7 @@ template <typename E> static int bn_bwd_impl(const void* dy, const void* dy2, co
 #undef R
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, g.nrb, C, M, dgamma, dbeta, c1, c2);
   int64_t nb = (M + g.RPI - 1) / g.RPI; nb = (nb + 1) / 2;
-  const int nblk = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
+  const int nblk = (int)(nb < 1 ? 1 : (nb > bn_apply_cap() ? bn_apply_cap() : nb));
 #define A(RES_, RELU_) hipLaunchKernelGGL((bn_bwd_apply_kernel<E, RES_, RELU_>), dim3(nblk), dim3(kBnThreads), 0, st, dy, dy2, ym, x, M, g.CV, g.RPI, gamma, save_mean, save_invstd, c1, c2, dx, dresidual)
   if (dresidual) {
     // pass 1 has written g = masked(dy [+ dy2]) into dresidual: pass 2 reads that one tensor, no mask, no second stream
@@ -551,7 +556,7 @@ template <typename E> static int bn_bwd_apply_impl(const void* g, const void* x,
   BnGeom geo = bn_geom(M, C);
   float* c1 = (float*)workspace + (int64_t)kBnMaxBlocks * 2 * C; float* c2 = c1 + C;
   int64_t nb = (M + geo.RPI - 1) / geo.RPI; nb = (nb + 1) / 2;
-  const int nblk = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
+  const int nblk = (int)(nb < 1 ? 1 : (nb > bn_apply_cap() ? bn_apply_cap() : nb));
   hipLaunchKernelGGL((bn_bwd_apply_kernel<E, false, 0>), dim3(nblk), dim3(kBnThreads), 0, (hipStream_t)stream, g, nullptr,
                      nullptr, x, M, geo.CV, geo.RPI, gamma, save_mean, save_invstd, c1, c2, dx, nullptr);
   LEC_CHECK_LAUNCH("bn_bwd_apply_kernel");
@@ -572,7 +577,7 @@ template <typename E> static int bn_bwd_prereduced_impl(const void* g, const voi
   float* c1 = part + (int64_t)kBnMaxBlocks * 2 * C; float* c2 = c1 + C;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, n_partials, C, M, dgamma, dbeta, c1, c2);
   int64_t nb = (M + geo.RPI - 1) / geo.RPI; nb = (nb + 1) / 2;
-  const int nblk = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
+  const int nblk = (int)(nb < 1 ? 1 : (nb > bn_apply_cap() ? bn_apply_cap() : nb));
   hipLaunchKernelGGL((bn_bwd_apply_kernel<E, false, 0>), dim3(nblk), dim3(kBnThreads), 0, st, g, nullptr,
                      nullptr, x, M, geo.CV, geo.RPI, gamma, save_mean, save_invstd, c1, c2, dx, nullptr);
   LEC_CHECK_LAUNCH("bn_bwd_prereduced kernels");

@@ -36,10 +36,7 @@ typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 constexpr int kX3BK = 16;                 // K chunk = one v_mfma_f32_32x32x16_bf16 step
 constexpr int kX3Row = 32;                // bytes of an LDS row of one plane (16 bf16, no padding: see x3_half)
 constexpr int kX3Threads = 512;           // 4 consumer + 4 producer waves
-#ifndef LEC_X3_ACT_PROD
-#define LEC_X3_ACT_PROD 256
-#endif
-constexpr int kX3ActProd = LEC_X3_ACT_PROD;          // producer threads of the activation-gather kernel (256, or 512: two producer waves per SIMD)
+constexpr int kX3ActProd = 256;            // producer threads of the activation-gather kernel (two producer waves per SIMD were tried: no gain)
 constexpr int kX3ActThreads = 256 + kX3ActProd;
 #ifndef LEC_X3_PRIO
 #define LEC_X3_PRIO 1
@@ -134,8 +131,11 @@ __device__ __forceinline__ void x3_read_frags(const char* __restrict__ sA, const
     for (int p = 0; p < 3; ++p) b[jt][p] = *(const bf16x8*)(sB + (p * BN + wn0 + jt * 32 + l31) * kX3Row + hs);
 }
 
-// The consumers' loop (shared by the activation-gather kernel and the weight gradient).  Step t: fragments of chunk t - 1 <- LDS stage
-// (t - 1) & 1, MFMAs of chunk t - 2; after the last chunk of a tile (every `nchunks` chunks) tile_done() stores / resets `acc`.
+// The consumers' loop (shared by the activation-gather kernel and the weight gradient).  An LDS stage holds TWO chunks and the workgroup
+// synchronises once per stage (every second step): chunks 2k and 2k + 1 are published by the barrier that ends step 2k + 1.
+//   step t:   producers: split chunk t -> stage (t >> 1) & 1, half t & 1; barrier after odd t
+//             consumers: fragments of chunk t - 2 <- LDS (published one barrier ago), MFMAs of chunk t - 3 (fragments read one step ago)
+// After the last chunk of a tile (every `nchunks` chunks) tile_done() stores / resets `acc`.
 template <int BM, int BN, int TM, int TN, class TileDone>
 __device__ __forceinline__ void x3_consumer_loop(const char* __restrict__ smem, int Q, int T, int nchunks, int wm0, int wn0, int lane,
                                                  f32x16 (&acc)[TM][TN], TileDone&& tile_done) {
@@ -145,29 +145,35 @@ __device__ __forceinline__ void x3_consumer_loop(const char* __restrict__ smem, 
   auto tile_end = [&]() __attribute__((always_inline)) {
     if (++mm_ch == nchunks) { tile_done(); mm_ch = 0; }
   };
-  // prologue / tail steps: every part conditional, barrier at the end
-  auto slow_step = [&](int t, auto set_c) __attribute__((always_inline)) {
-    constexpr int SET = decltype(set_c)::value;                 // = t & 1: fragments of chunk t - 1 go to set SET ^ 1, chunk t - 2's are in SET
-    if (t >= 1 && t <= Q && !(LEC_X3_DBG & 8)) {
-      const char* sA = smem + (SET ^ 1) * SBUF;
-      x3_read_frags<BM, BN, TM, TN>(sA, sA + SA, wm0, wn0, lane, fa[SET ^ 1], fb[SET ^ 1]);
+  // LDS image of the chunk read at a step with t & 3 == J: chunk t - 2 -> stage ((t - 2) >> 1) & 1, half (t - 2) & 1
+  auto chunk_base = [&](auto j_c) __attribute__((always_inline)) {
+    constexpr int J = decltype(j_c)::value;
+    return smem + ((((J + 2) >> 1) & 1) * 2 + (J & 1)) * SBUF;
+  };
+  // prologue / tail steps: every part conditional, barrier at the end of odd steps
+  auto slow_step = [&](int t, auto j_c) __attribute__((always_inline)) {
+    constexpr int J = decltype(j_c)::value;                     // = t & 3; fragments of chunk t - 2 go to set J & 1, chunk t - 3's are in set (J & 1) ^ 1
+    if (t >= 2 && t <= Q + 1 && !(LEC_X3_DBG & 8)) {
+      const char* sA = chunk_base(j_c);
+      x3_read_frags<BM, BN, TM, TN>(sA, sA + SA, wm0, wn0, lane, fa[J & 1], fb[J & 1]);
     }
-    if (t >= 2 && t <= Q + 1) {
+    if (t >= 3 && t <= Q + 2) {
 #pragma unroll
       for (int it = 0; it < TM; ++it)
 #pragma unroll
         for (int jt = 0; jt < TN; ++jt)
-          if (!(LEC_X3_DBG & 4)) acc[it][jt] = mma6(fa[SET][it], fb[SET][jt], acc[it][jt]);
+          if (!(LEC_X3_DBG & 4)) acc[it][jt] = mma6(fa[(J & 1) ^ 1][it], fb[(J & 1) ^ 1][jt], acc[it][jt]);
       tile_end();
     }
-    x3_barrier();
+    if (J & 1) x3_barrier();
   };
-  // steady-state step (2 <= t <= Q): the fragment reads of the next chunk are spread between the first MFMAs, and the barrier sits
-  // before the last TM * TN MFMAs, which keep the matrix pipe busy while the workgroup synchronises
-  auto fast_step = [&](auto set_c) __attribute__((always_inline)) {
-    constexpr int SET = decltype(set_c)::value;
-    const char* sA = smem + (SET ^ 1) * SBUF;
-    if (!(LEC_X3_DBG & 8)) x3_read_frags<BM, BN, TM, TN>(sA, sA + SA, wm0, wn0, lane, fa[SET ^ 1], fb[SET ^ 1]);
+  // steady-state step (3 <= t <= Q + 1): the fragment reads of the next chunk are spread between the first MFMAs; on odd steps the
+  // barrier sits before the last TM * TN MFMAs, which keep the matrix pipe busy while the workgroup synchronises
+  auto fast_step = [&](auto j_c) __attribute__((always_inline)) {
+    constexpr int J = decltype(j_c)::value;
+    constexpr int RS = J & 1, MS = RS ^ 1;                      // register sets: read into RS, multiply from MS
+    const char* sA = chunk_base(j_c);
+    if (!(LEC_X3_DBG & 8)) x3_read_frags<BM, BN, TM, TN>(sA, sA + SA, wm0, wn0, lane, fa[RS], fb[RS]);
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};         // small terms first (as mma6)
 #pragma unroll
     for (int p = 0; p < 5; ++p)
@@ -175,98 +181,31 @@ __device__ __forceinline__ void x3_consumer_loop(const char* __restrict__ smem, 
       for (int it = 0; it < TM; ++it)
 #pragma unroll
         for (int jt = 0; jt < TN; ++jt)
-          if (!(LEC_X3_DBG & 4)) acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][it][PA[p]], fb[SET][jt][PB[p]], acc[it][jt], 0, 0, 0);
+          if (!(LEC_X3_DBG & 4)) acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[MS][it][PA[p]], fb[MS][jt][PB[p]], acc[it][jt], 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 3 * (TM + TN); ++i) {                    // one LDS read, one MFMA, ...
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
     __builtin_amdgcn_sched_group_barrier(0x008, 5 * TM * TN - 3 * (TM + TN), 0);
-    __builtin_amdgcn_sched_barrier(0);
-    x3_barrier();
-    __builtin_amdgcn_sched_barrier(0);
+    if (J & 1) {
+      __builtin_amdgcn_sched_barrier(0);
+      x3_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int it = 0; it < TM; ++it)
 #pragma unroll
       for (int jt = 0; jt < TN; ++jt)
-        if (!(LEC_X3_DBG & 4)) acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][it][PA[5]], fb[SET][jt][PB[5]], acc[it][jt], 0, 0, 0);
+        if (!(LEC_X3_DBG & 4)) acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[MS][it][PA[5]], fb[MS][jt][PB[5]], acc[it][jt], 0, 0, 0);
     tile_end();
   };
-  slow_step(0, std::integral_constant<int, 0>{});
-  slow_step(1, std::integral_constant<int, 1>{});
-  int t = 2;
-  for (; t + 1 <= Q; t += 2) {
-    fast_step(std::integral_constant<int, 0>{});
-    fast_step(std::integral_constant<int, 1>{});
-  }
-  for (; t < T; t += 2) {
-    slow_step(t, std::integral_constant<int, 0>{});
-    slow_step(t + 1, std::integral_constant<int, 1>{});
-  }
-}
-
-// The same loop with ROLLING fragment registers, for workgroups with two producer waves per SIMD (12 waves: 168 registers per wave).
-// A plane of the current chunk is dead after its last product (a_l after product 0, b_l after 1, a_m after 3, b_m after 4), so the next
-// chunk's plane is read into the same registers right there; only the h planes, which product 5 uses last and product 0 / 1 of the next
-// chunk use first, are double-buffered: 64 fragment registers instead of 96.
-template <int BM, int BN, int TM, int TN, class TileDone>
-__device__ __forceinline__ void x3_consumer_loop_rolling(const char* __restrict__ smem, int Q, int T, int nchunks, int wm0, int wn0, int lane,
-                                                         f32x16 (&acc)[TM][TN], TileDone&& tile_done) {
-  constexpr int SA = 3 * BM * kX3Row, SBUF = 3 * (BM + BN) * kX3Row;
-  bf16x8 ah[2][TM], bh[2][TN], am[TM], al[TM], bm[TN], bl[TN];
-  const int l31 = lane & 31, hs = x3_half(l31, lane >> 5);
-  const char* pa = smem + (wm0 + l31) * kX3Row + hs;            // plane 0, tile 0 of A in stage 0
-  const char* pb = smem + SA + (wn0 + l31) * kX3Row + hs;
-  auto rdA = [&](int stage, int plane, bf16x8 (&d)[TM]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int it = 0; it < TM; ++it) d[it] = *(const bf16x8*)(pa + stage * SBUF + (plane * BM + it * 32) * kX3Row);
-  };
-  auto rdB = [&](int stage, int plane, bf16x8 (&d)[TN]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int jt = 0; jt < TN; ++jt) d[jt] = *(const bf16x8*)(pb + stage * SBUF + (plane * BN + jt * 32) * kX3Row);
-  };
-  auto mm = [&](const bf16x8 (&a)[TM], const bf16x8 (&b)[TN]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int it = 0; it < TM; ++it)
-#pragma unroll
-      for (int jt = 0; jt < TN; ++jt)
-        if (!(LEC_X3_DBG & 4)) acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[it], b[jt], acc[it][jt], 0, 0, 0);
-  };
-  int mm_ch = 0;
-  // step t >= 2: MFMAs of chunk c = t - 2 (stage parity S = c & 1), reads of chunk c + 1 from stage S ^ 1 as the registers free up
-  auto fast_step = [&](auto s_c) __attribute__((always_inline)) {
-    constexpr int S = decltype(s_c)::value;
-    rdA(S ^ 1, 0, ah[S ^ 1]); rdB(S ^ 1, 0, bh[S ^ 1]);
-    mm(al, bh[S]);                                              // product 0: a_l b_h
-    __builtin_amdgcn_sched_barrier(0);
-    rdA(S ^ 1, 2, al);
-    mm(ah[S], bl);                                              // product 1: a_h b_l
-    __builtin_amdgcn_sched_barrier(0);
-    rdB(S ^ 1, 2, bl);
-    mm(am, bm);                                                 // product 2: a_m b_m
-    mm(am, bh[S]);                                              // product 3: a_m b_h
-    __builtin_amdgcn_sched_barrier(0);
-    rdA(S ^ 1, 1, am);
-    mm(ah[S], bm);                                              // product 4: a_h b_m
-    __builtin_amdgcn_sched_barrier(0);
-    rdB(S ^ 1, 1, bm);
-    __builtin_amdgcn_sched_barrier(0);
-    x3_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    mm(ah[S], bh[S]);                                           // product 5: a_h b_h
-    if (++mm_ch == nchunks) { tile_done(); mm_ch = 0; }
-  };
-  // t = 0: nothing to read yet; t = 1: every plane of chunk 0 (stage 0)
-  x3_barrier();
-  rdA(0, 0, ah[0]); rdB(0, 0, bh[0]); rdA(0, 1, am); rdB(0, 1, bm); rdA(0, 2, al); rdB(0, 2, bl);
-  x3_barrier();
-  int t = 2;
-  for (; t + 1 <= Q + 1; t += 2) {                               // chunks t - 2 (even) and t - 1 (odd); the last chunk's look-ahead reads are dead
-    fast_step(std::integral_constant<int, 0>{});
-    fast_step(std::integral_constant<int, 1>{});
-  }
-  if (t <= Q + 1) { fast_step(std::integral_constant<int, 0>{}); ++t; }
-  for (; t < T; ++t) x3_barrier();
+  using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
+  using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
+  slow_step(0, J0{}); slow_step(1, J1{}); slow_step(2, J2{}); slow_step(3, J3{});
+  int t = 4;
+  for (; t + 3 <= Q + 1; t += 4) { fast_step(J0{}); fast_step(J1{}); fast_step(J2{}); fast_step(J3{}); }
+  for (; t < T; t += 4) { slow_step(t, J0{}); slow_step(t + 1, J1{}); slow_step(t + 2, J2{}); slow_step(t + 3, J3{}); }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -298,7 +237,7 @@ __global__ __launch_bounds__(kX3ActThreads) void conv_f32x3_act_kernel(const flo
   const int mtiles = (g.Mg + BM - 1) / BM;
   const int ntl = (int)blockIdx.x < mtiles ? (mtiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;   // m-tiles of this workgroup
   const int Q = ntl * nchunks;                                 // chunks of this workgroup
-  const int T = (Q + 2 + 3) & ~3;                              // steps, a multiple of the unroll factors of both roles (4 and 2)
+  const int T = (Q + 3 + 3) & ~3;                              // steps (the consumers trail the producers by three), a multiple of the unroll factor 4
 
   if (producer) {
     if (Q == 0) return;
@@ -415,7 +354,7 @@ __global__ __launch_bounds__(kX3ActThreads) void conv_f32x3_act_kernel(const flo
     auto step = [&](auto i_c) __attribute__((always_inline)) {
       constexpr int I = decltype(i_c)::value;
       if (!(LEC_X3_DBG & 2)) {
-        char* base = smem_x3 + (I & 1) * SBUF;
+        char* base = smem_x3 + I * SBUF;                         // stage I >> 1, half I & 1 (a stage = two chunks)
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
           u32x2v h, m, l;
@@ -430,7 +369,7 @@ __global__ __launch_bounds__(kX3ActThreads) void conv_f32x3_act_kernel(const flo
         if (TAPV) issueA_tapv(std::integral_constant<int, (I >> 1)>{}, std::integral_constant<int, (I & 1)>{});
         else if (I & 1) issueA(std::integral_constant<int, (I >> 1)>{});
       }
-      x3_barrier();
+      if (I & 1) x3_barrier();                                  // a stage is complete
     };
     if (!(LEC_X3_DBG & 2)) {                                    // the first four chunks, in the order the loop issues them
       using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -504,8 +443,7 @@ __global__ __launch_bounds__(kX3ActThreads) void conv_f32x3_act_kernel(const flo
     if (Q > 0) {
       int mm_mt = blockIdx.x;                                   // the m-tile the accumulators belong to
       auto done = [&]() __attribute__((always_inline)) { epilogue(mm_mt); zero_acc(); mm_mt += gridDim.x; };
-      if (kX3ActProd > 256) x3_consumer_loop_rolling<BM, BN, TM, TN>(smem_x3, Q, T, nchunks, wm0, wn0, lane, acc, done);
-      else x3_consumer_loop<BM, BN, TM, TN>(smem_x3, Q, T, nchunks, wm0, wn0, lane, acc, done);
+      x3_consumer_loop<BM, BN, TM, TN>(smem_x3, Q, T, nchunks, wm0, wn0, lane, acc, done);
     }
     if (STATS) {
       // lane halves -> waves of the same column block -> one partial row per workgroup: part[blockIdx.x][2][Cd]
@@ -578,7 +516,7 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_wgrad_kernel(const floa
   int nit = 0;                                                  // items of this workgroup (slots blockIdx.x, + grid, ...)
   for (int i = blockIdx.x; i < 8 * g.per; i += gridDim.x) nit += x3_wg_item(i, g.items, g.per) >= 0 ? 1 : 0;
   const int Q = nit * g.cps;
-  const int T = (Q + 2 + 3) & ~3;
+  const int T = (Q + 3 + 3) & ~3;
   if (Q == 0) return;
 
   if (wave >= 4) {
@@ -639,7 +577,7 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_wgrad_kernel(const floa
     };
     auto step = [&](auto i_c) __attribute__((always_inline)) {
       constexpr int I = decltype(i_c)::value;
-      char* base = smem_x3 + (I & 1) * SBUF + ldsW;
+      char* base = smem_x3 + I * SBUF + ldsW;                    // stage I >> 1, half I & 1
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         u32x4v ph, pm, pl;
@@ -653,7 +591,7 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_wgrad_kernel(const floa
         *(u32x4v*)(p) = ph; *(u32x4v*)(p + BM * kX3Row) = pm; *(u32x4v*)(p + 2 * BM * kX3Row) = pl;     // (BM == BN)
       }
       issue(i_c);
-      x3_barrier();
+      if (I & 1) x3_barrier();
     };
     issue(std::integral_constant<int, 0>{}); issue(std::integral_constant<int, 1>{});
     issue(std::integral_constant<int, 2>{}); issue(std::integral_constant<int, 3>{});
@@ -736,7 +674,7 @@ static int launch_act_x3(const float* src, const uint16_t* wpl, float* dst, cons
   if (gx > mtiles) gx = mtiles;
   if (STATS && gx > kCfMaxPart) gx = kCfMaxPart;
   if (gx < 1) gx = 1;
-  const size_t lds = (size_t)2 * 3 * (BM + BN) * kX3Row;        // 48 / 60 KB
+  const size_t lds = (size_t)4 * 3 * (BM + BN) * kX3Row;        // 2 stages x 2 chunks: 96 / 120 KB
   const bool tapv = g.Cs < 2 * kX3BK;                           // source channels narrower than a chunk pair (the stem)
   LEC_CHECK_ARG(tapv || g.na * g.nb <= 32, "conv_f32x3: more than 32 taps per launch need the per-piece tap path");
   LEC_CHECK_ARG(!tapv || (g.rstep == 1 && g.sstep == 1 && g.r0 == 0 && g.s0 == 0),
@@ -861,7 +799,7 @@ extern "C" int lec_conv_f32x3_wgrad(const float* dy, const float* x, int N, int 
   const int split = (nchunks + cps - 1) / cps;
   g.cps = cps; g.items = g.tiles * split; g.per = (g.items + 7) / 8;
   const int grid = 8 * g.per < wgs ? 8 * g.per : wgs;
-  const size_t lds = (size_t)2 * 3 * (128 + 128) * kX3Row;
+  const size_t lds = (size_t)4 * 3 * (128 + 128) * kX3Row;
   hipStream_t st = (hipStream_t)stream;
   if (dense) hipLaunchKernelGGL(conv_f32x3_wgrad_kernel<true>, dim3(grid), dim3(kX3Threads), lds, st, dy, x, dw, g);
   else hipLaunchKernelGGL(conv_f32x3_wgrad_kernel<false>, dim3(grid), dim3(kX3Threads), lds, st, dy, x, dw, g);
