@@ -537,8 +537,12 @@ extern "C" int lec_conv_f32_wgrad(const float* dy, const float* x, int N, int H,
   split = (nchunks + g.chunks_per_split - 1) / g.chunks_per_split;
   g.tiles = tiles; g.split = split;
   size_t lds = (size_t)2 * WBK * (BM + BN) * 4;
-  static const int wg_lds_pad = [] { const char* e = getenv("LEC_WGRAD_LDS_PAD"); return e ? atoi(e) : 0; }();   // experiments: residency of this kernel
-  lds += (size_t)wg_lds_pad;
+  // Residency: the tiles need 32 - 40 KB, which would let four workgroups share a CU and leave the main stream's HBM-bound BatchNorm kernels
+  // (this kernel runs on the side stream) no registers to land on.  Asking for 54 KB keeps it at TWO workgroups per CU -- the matrix pipe is
+  // as busy with two as with four -- and the step gains 1.6 % (A/B on one box: 164.4 -> 161.9 ms, three runs each).  LEC_WGRAD_LDS_PAD: experiments.
+  static const int wg_lds_pad = [] { const char* e = getenv("LEC_WGRAD_LDS_PAD"); return e ? atoi(e) : -1; }();
+  if (wg_lds_pad >= 0) lds += (size_t)wg_lds_pad;
+  else if (lds < 54 * 1024) lds = 54 * 1024;
   static const int wg_cap = [] { const char* e = getenv("LEC_WGRAD_WGS"); const int v = e ? atoi(e) : (1 << 30); return v > 0 ? v : (1 << 30); }();
   const int total = 8 * ((tiles * split + 7) / 8);              // slots (see the kernel's slot -> item map)
   const dim3 grid(total < wg_cap ? total : wg_cap), blk(kCfThreads);
