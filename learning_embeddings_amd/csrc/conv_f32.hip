@@ -530,7 +530,8 @@ extern "C" int lec_conv_f32_wgrad(const float* dy, const float* x, int N, int H,
   }
   const int tiles = ((Cout + BM - 1) / BM) * ((g.Ng + BN - 1) / BN);
   const int nchunks = (g.Mpix + WBK - 1) / WBK;
-  int split = (1024 + tiles - 1) / tiles;                      // ~4 workgroups per CU in total
+  static const int wg_target = [] { const char* e = getenv("LEC_WGRAD_ITEMS"); const int v = e ? atoi(e) : 1024; return v > 0 ? v : 1024; }();
+  int split = (wg_target + tiles - 1) / tiles;                 // ~4 workgroups per CU in total (LEC_WGRAD_ITEMS: experiments)
   if (split > nchunks) split = nchunks;
   if (split < 1) split = 1;
   g.chunks_per_split = (nchunks + split - 1) / split;
