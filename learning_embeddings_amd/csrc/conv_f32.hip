@@ -51,42 +51,38 @@ template <bool A_KC, bool B_KC, int LDA, int LDB, int TM, int TN, int BKT = kCfB
 __device__ __forceinline__ void mma_chunk(const float* __restrict__ sA, const float* __restrict__ sB, int wm0, int wn0, int lane,
                                           f32x16 (&acc)[TM][TN]) {
   const int l31 = lane & 31, h = lane >> 5;
-  // the fragments of 8-group q + 1 are read while the MFMAs of group q run (two register sets): left to itself the compiler reads a
-  // group right before its MFMAs and the LDS latency is exposed four times per chunk
-  float a[2][TM][4], b[2][TN][4];
-  auto rd = [&](int q, int s_) __attribute__((always_inline)) {
+  // (Reading the fragments of group q + 1 under the MFMAs of group q -- two register sets, pinned with a scheduling barrier -- was tried:
+  // the convolutions of a step take 123.8 instead of 118.7 ms; the second workgroup per CU already hides the LDS latency.)
+#pragma unroll
+  for (int q = 0; q < BKT / 8; ++q) {
+    float a[TM][4], b[TN][4];
 #pragma unroll
     for (int it = 0; it < TM; ++it) {
       if (A_KC) {
         const f32x4v v = *(const f32x4v*)(sA + (wm0 + it * 32 + l31) * kCfLdk + 8 * q + 4 * h);
-        a[s_][it][0] = v[0]; a[s_][it][1] = v[1]; a[s_][it][2] = v[2]; a[s_][it][3] = v[3];
+        a[it][0] = v[0]; a[it][1] = v[1]; a[it][2] = v[2]; a[it][3] = v[3];
       } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) a[s_][it][t] = lds_ld1(sA + 4 * h * LDA + wm0 + it * 32 + l31, (8 * q + t) * LDA);
+        for (int t = 0; t < 4; ++t) a[it][t] = lds_ld1(sA + 4 * h * LDA + wm0 + it * 32 + l31, (8 * q + t) * LDA);
       }
     }
 #pragma unroll
     for (int it = 0; it < TN; ++it) {
       if (B_KC) {
         const f32x4v v = *(const f32x4v*)(sB + (wn0 + it * 32 + l31) * kCfLdk + 8 * q + 4 * h);
-        b[s_][it][0] = v[0]; b[s_][it][1] = v[1]; b[s_][it][2] = v[2]; b[s_][it][3] = v[3];
+        b[it][0] = v[0]; b[it][1] = v[1]; b[it][2] = v[2]; b[it][3] = v[3];
       } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) b[s_][it][t] = lds_ld1(sB + 4 * h * LDB + wn0 + it * 32 + l31, (8 * q + t) * LDB);
+        for (int t = 0; t < 4; ++t) b[it][t] = lds_ld1(sB + 4 * h * LDB + wn0 + it * 32 + l31, (8 * q + t) * LDB);
       }
     }
-  };
-  rd(0, 0);
-#pragma unroll
-  for (int q = 0; q < BKT / 8; ++q) {
-    if (q + 1 < BKT / 8) { rd(q + 1, (q + 1) & 1); __builtin_amdgcn_sched_barrier(0); }   // (pinned: the scheduler sinks the reads back to their use otherwise)
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int it = 0; it < TM; ++it)
 #pragma unroll
         for (int jt = 0; jt < TN; ++jt)
-          acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][it][t], b[q & 1][jt][t], acc[it][jt], 0, 0, 0);
+          acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[it][t], b[jt][t], acc[it][jt], 0, 0, 0);
   }
 }
 
@@ -538,12 +534,12 @@ extern "C" int lec_conv_f32_wgrad(const float* dy, const float* x, int N, int H,
   split = (nchunks + g.chunks_per_split - 1) / g.chunks_per_split;
   g.tiles = tiles; g.split = split;
   size_t lds = (size_t)2 * WBK * (BM + BN) * 4;
-  // Residency: the tiles need 32 - 40 KB, which would let four workgroups share a CU and leave the main stream's HBM-bound BatchNorm kernels
-  // (this kernel runs on the side stream) no registers to land on.  Asking for 54 KB keeps it at TWO workgroups per CU -- the matrix pipe is
-  // as busy with two as with four -- and the step gains 1.6 % (A/B on one box: 164.4 -> 161.9 ms, three runs each).  LEC_WGRAD_LDS_PAD: experiments.
-  static const int wg_lds_pad = [] { const char* e = getenv("LEC_WGRAD_LDS_PAD"); return e ? atoi(e) : -1; }();
-  if (wg_lds_pad >= 0) lds += (size_t)wg_lds_pad;
-  else if (lds < 54 * 1024) lds = 54 * 1024;
+  // Residency knob (LEC_WGRAD_LDS_PAD = extra LDS bytes): the tiles need 32 - 40 KB, so four workgroups share a CU and the main stream's
+  // HBM-bound BatchNorm kernels (this kernel runs on the side stream) find no registers to land on.  14336 extra bytes keep it at two workgroups
+  // per CU: BatchNorm 61.6 -> 52.2 ms inside the step, these kernels 44 -> 47.5 ms, the step 157.5 -> 155.8 ms (same-box A/B, 1 %); left off by
+  // default: within the box-to-box spread, and it stretches every convolution's in-step duration.
+  static const int wg_lds_pad = [] { const char* e = getenv("LEC_WGRAD_LDS_PAD"); return e ? atoi(e) : 0; }();
+  if (wg_lds_pad > 0) lds += (size_t)wg_lds_pad;
   static const int wg_cap = [] { const char* e = getenv("LEC_WGRAD_WGS"); const int v = e ? atoi(e) : (1 << 30); return v > 0 ? v : (1 << 30); }();
   const int total = 8 * ((tiles * split + 7) / 8);              // slots (see the kernel's slot -> item map)
   const dim3 grid(total < wg_cap ? total : wg_cap), blk(kCfThreads);
