@@ -12,17 +12,23 @@
 // MFMAs per 16 k instead of 8 f32 MFMAs of twice the duration: 2.67x the matrix throughput at equal clocks.
 //
 // Layout.  The same implicit GEMMs, geometry structs and launch decomposition as conv_f32.hip.  Differences:
-//   * weights arrive PRE-SPLIT (lec_conv_f32x3_split_weights, once per optimizer step and layer): three bf16 planes in the forward
-//     layout [Cout][R*S][Cin] and three in the data-gradient layout [R*S][Cin][Cout], so that the B operand is k-contiguous in
-//     both directions and travels global -> LDS untouched (16-byte pieces of 8 bf16);
-//   * activations / output gradients are loaded as fp32 (16-byte buffer loads, hardware range check = padding zeros), split in
-//     registers -- 11 vector instructions per pair of elements (4 v_and, 4 v_sub, 3 v_perm), which the bf16 MFMA (unlike the f32 one) executes
-//     beside -- and stored as three bf16 planes;
-//   * LDS: planes of [rows][16 k] bf16, 48-byte rows (32 data + 16 pad: conflict-free ds_read_b128 for 16 consecutive rows),
-//     K advances 16 per chunk = one MFMA step, double-buffered, one barrier per chunk; 128 x 128 tile: 2 x 36 KB, two
-//     workgroups per CU;
-//   * the weight gradient transposes while it splits: a thread loads the SAME four channels of consecutive pixels and packs
-//     pixel pairs into dwords, so the LDS image is [channel][16 pixels] and both operands are read with ds_read_b128.
+//   * a workgroup is 4 CONSUMER waves (accumulators; per 16-k step 12 ds_read_b128 of the next chunk's fragments and 24 MFMAs, nothing
+//     else) and 4 PRODUCER waves (fetch four chunks ahead, split, store), one of each per SIMD: the bf16 MFMA, unlike the f32 one, executes
+//     beside the producers' vector instructions.  One workgroup per CU walks its tiles; chunks number through them without a break;
+//   * weights arrive PRE-SPLIT and TILE-MAJOR (lec_conv_f32x3_split_weights, once per optimizer step and layer):
+//     [column tile][k chunk][h | m | l][rows][16 k] bf16 in the forward and in the data-gradient order, so the B operand of a step is one
+//     contiguous 6 / 12 KB block read as full cache lines and copied to LDS untouched;
+//   * activations / output gradients are loaded as fp32 (16-byte buffer loads of whole 128-byte lines, hardware range check = padding
+//     zeros), split in registers -- 11 vector instructions per pair of elements (4 v_and, 4 v_sub, 3 v_perm) -- and stored as three planes;
+//   * LDS: planes of [rows][16 k] bf16, 32-byte rows without padding, the two 16-byte halves of a row swapped on rows with bit 3 set
+//     (conflict-free for the consumers' reads and the producers' writes: x3_half); a stage = two chunks, two stages (98 KB for
+//     128 x 128), ONE workgroup barrier per stage, placed before the last four MFMAs of the consumers' step; the barrier waits for LDS
+//     traffic only, so the producers' global loads stay in flight across it;
+//   * no branch around a load: the producers' stream runs past the last chunk (dead loads fall out of range), which keeps the compiler's
+//     vmcnt bookkeeping exact -- with a guard it waits for vmcnt(0) at every step;
+//   * the weight gradient transposes while it splits: a producer wave owns one octet of a chunk's 16 pixels and one operand, lane L the
+//     tile's channels L and L + 64; pixel pairs are packed per channel, so the LDS image is [channel][16 pixels] for both operands;
+//     work items (tile, K split) are dealt to the 8 XCDs in contiguous runs so that tiles sharing a K range share an L2.
 // Roofline: MFMA (bf16 dense, 2.5 PFLOP/s) on 6x the algorithmic flops.
 #include <type_traits>
 #include "conv_geo.h"
