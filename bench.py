@@ -214,6 +214,18 @@ def measure(args, dtype, rank, world, stamp, primary):
         if conv_isolated is not None:
             roof_conv['isolated'] = {'ms_per_step': round(conv_isolated, 3), 'achieved': round(eng.conv_flops_per_step / conv_isolated / 1e9, 2),
                                      'frac': round(eng.conv_flops_per_step / conv_isolated / 1e9 / 157.3, 4)}
+    if f32:
+        # HBM bytes per launch from the committed PMC passes (profiles/r02_step_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, whole family per step / launches)
+        try:
+            tr = json.load(open(os.path.join(ROOT, 'profiles', 'r02_step_traffic.json')))['x3' if x3 else 'native']
+            fam = lambda *keys: sum(sum(tr[k]) for k in keys if k in tr) * 1e9
+            if roof_conv is not None:
+                roof_conv['traffic'] = int(fam('convolution forward / data gradient', 'convolution weight gradients') / max(eng.conv_launches_per_step, 1))
+                roof_conv['traffic_note'] = 'HBM bytes per launch, family average: rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE over a profiled run of this command (profiles/r02_step_traffic.md); the bound is the matrix pipe'
+            if roof_bn is not None:
+                roof_bn['traffic'] = int(fam('BatchNorm family (bn.hip)') / max(eng.bn_launch_groups_per_step, 1))
+        except Exception:
+            pass
     res = {'value': round(ips, 2), 'ms_per_step': round(dt / args.steps * 1e3, 3), 'dtype': 'f32' if f32 else dtype,
            'launch_mode': 'hipgraph (forward + loss + backward of a step replayed as one graph)' if graph_mode else 'eager',
            'mean_loss': round(loss_mean, 4), 'hbm_peak_allocated_gb': round(torch.cuda.max_memory_allocated() / 1e9, 1),
