@@ -372,7 +372,9 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const flo
   const int rL = fdiv(tapL, g.dS);
   const int drL = rL - g.pad, dsL = tapL - rL * g.S - g.pad;
   const bool okL = j < g.Ng;
-  const int laneoff = ((drL * g.W + dsL) * g.Cin + ciL) * 4;   // this lane's tap / channel relative to the pixel's (0, 0) tap, bytes
+  int laneoff = ((drL * g.W + dsL) * g.Cin + ciL) * 4;         // this lane's tap / channel relative to the pixel's (0, 0) tap, bytes
+  asm volatile("" : "+v"(laneoff));                          // opaque: the compiler otherwise re-derives pixoff + laneoff from (h0 + drL, w0 + dsL)
+                                                              // with a 64-bit multiply-add and a v_mul_lo per piece -- vector time the f32 MFMA pays for
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int it = 0; it < TM; ++it)
