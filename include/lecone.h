@@ -397,7 +397,8 @@ int lec_conv_f32x3_fwd(const float* x, const uint16_t* w_planes, int N, int H, i
                        float* y, float* partials, int64_t partials_bytes, int* n_partials, lec_stream_t stream);
 int lec_conv_f32x3_dgrad(const float* dy, const uint16_t* w_planes_t, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                          float* dx, lec_stream_t stream);
-/*     lec_conv_f32x3_wgrad: layers with Cin and Cout powers of two >= 128 (lec_conv_f32x3_wgrad_supported; others: lec_conv_f32_wgrad). */
+/*     lec_conv_f32x3_wgrad: layers with Cin and Cout powers of two >= 64 and at most 32 taps (lec_conv_f32x3_wgrad_supported; others, i.e. the
+ *       stem: lec_conv_f32_wgrad). */
 int lec_conv_f32x3_wgrad_supported(int Cin, int Cout, int R, int S);
 int lec_conv_f32x3_wgrad(const float* dy, const float* x, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                          float* dw, lec_stream_t stream);

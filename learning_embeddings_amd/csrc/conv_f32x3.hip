@@ -527,7 +527,7 @@ __device__ __forceinline__ int x3_wg_item(int i, int items, int per) {
   return ((i >> 3) < per && it < items) ? it : -1;
 }
 
-template <bool DENSE>
+template <bool DENSE, bool NARROW>
 __global__ __launch_bounds__(kX3Threads) void conv_f32x3_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                       float* __restrict__ dw, WgX3Geo g) {
   constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WN = 2;
@@ -551,11 +551,13 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_wgrad_kernel(const floa
     const unsigned ldsW = (unsigned)((isB ? SA : 0) + lane * kX3Row + x3_half(lane, oct));   // channel row `lane`; row lane + 64: + 64 rows (same bit 3)
     // load stream: item, chunk inside the item
     int ld_slot = blockIdx.x, ld_ch = 0;
-    unsigned vcol = 0;                                          // byte offset of this lane's first channel inside a pixel
-    int dr = 0, ds = 0;                                         // the tile's tap, relative to the output pixel (B)
+    unsigned vcol = 0, vcol1 = 0;                               // byte offsets of this lane's two channels inside a pixel (NARROW: the second may not exist: kOob)
+    int dr = 0, ds = 0, dr1 = 0, ds1 = 0;                       // the taps of the lane's two columns, relative to the output pixel (B; NARROW: they may differ)
+    bool tap_ok = true, tap1_ok = true;
     int ch0 = 0;                                                // first chunk of the item
-    unsigned pixo = 0;                                          // B: byte offset of the source pixel of (group base + lane), kOob if there is none
-    float rr[4][16];
+    unsigned pixo = 0, pixo1 = 0;                               // B: byte offset of the source pixel of (group base + lane) per tap, kOob if there is none
+    constexpr int D = 4;                                        // chunks in flight (register sets)
+    float rr[D][16];
     auto item_setup = [&]() __attribute__((always_inline)) {
       int wi = x3_wg_item(ld_slot, g.items, g.per);
       while (wi < 0 && ld_slot < 8 * g.per) { ld_slot += gridDim.x; wi = x3_wg_item(ld_slot, g.items, g.per); }
@@ -568,13 +570,22 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_wgrad_kernel(const floa
         const int tap = j0 >> g.lgCin, ci0 = j0 & (g.Cin - 1);
         const int r_ = fdiv(tap, g.dS);
         dr = r_ - g.pad; ds = tap - r_ * g.S - g.pad;
-        vcol = (unsigned)(ci0 + lane) * 4u;
+        vcol = (unsigned)(ci0 + lane) * 4u; vcol1 = vcol + 256u;
+        if (NARROW) {                                           // layers of 64 channels / ragged column tiles: the second column has its own tap and may not exist
+          const int j1 = j0 + 64;
+          const int tap1 = j1 >> g.lgCin, ci1 = j1 & (g.Cin - 1);
+          const int r1 = fdiv(tap1, g.dS);
+          dr1 = r1 - g.pad; ds1 = tap1 - r1 * g.S - g.pad;
+          tap_ok = j0 < g.Ng; tap1_ok = j1 < g.Ng;              // (Ng = taps * Cin and 64 | Cin: a 64-column half lies inside one tap or past the last)
+          vcol1 = tap1_ok ? (unsigned)(ci1 + lane) * 4u : kOob;
+        }
       } else {
-        vcol = (unsigned)(tm * BM + lane) * 4u;
+        vcol = (unsigned)(tm * BM + lane) * 4u; vcol1 = vcol + 256u;
+        if (NARROW && tm * BM + 64 >= g.Cout) vcol1 = kOob;      // Cout = 64: rows 64 .. 127 of the tile do not exist
       }
     };
-    auto issue = [&](auto i_c) __attribute__((always_inline)) {   // chunk ld_ch of item ld_it -> rr[I]; I == chunk & 3
-      constexpr int I = decltype(i_c)::value;
+    auto issue = [&](auto i_c) __attribute__((always_inline)) {   // chunk ld_ch of the current item -> rr[I % D]; I == chunk & 3
+      constexpr int I = decltype(i_c)::value, SET = I % D;
       if (ld_ch == 0) item_setup();
       const int mb = (ch0 + ld_ch) * kX3BK;                      // first pixel of the chunk
       if (isB && !DENSE && I == 0) {                              // decode the 64 pixels of chunks ld_ch .. ld_ch + 3
@@ -583,8 +594,13 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_wgrad_kernel(const floa
         const int mm = live ? m : 0;
         const int t2 = fdiv(mm, g.dWo); const int wo = mm - t2 * g.Wo; const int n = fdiv(t2, g.dHo); const int ho = t2 - n * g.Ho;
         const int hs = ho * g.stride + dr, ws = wo * g.stride + ds;
-        const bool ok = live && (unsigned)hs < (unsigned)g.H && (unsigned)ws < (unsigned)g.W;
+        const bool ok = live && tap_ok && (unsigned)hs < (unsigned)g.H && (unsigned)ws < (unsigned)g.W;
         pixo = ok ? (unsigned)(((n * g.H + hs) * g.W + ws) << g.lgCin) * 4u : kOob;
+        if (NARROW) {
+          const int hs1 = ho * g.stride + dr1, ws1 = wo * g.stride + ds1;
+          const bool ok1 = live && tap1_ok && (unsigned)hs1 < (unsigned)g.H && (unsigned)ws1 < (unsigned)g.W;
+          pixo1 = ok1 ? (unsigned)(((n * g.H + hs1) * g.W + ws1) << g.lgCin) * 4u : kOob;
+        }
       }
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
@@ -592,8 +608,13 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_wgrad_kernel(const floa
         if (isB && !DENSE) srow = (unsigned)__builtin_amdgcn_readlane((int)pixo, 16 * I + 8 * oct + r);
         else srow = (unsigned)((mb + 8 * oct + r) * C) * 4u;      // (past the tensor: out of range, zeros)
         const unsigned o = vcol + srow;
-        rr[I][2 * r] = bload1(rs, o);
-        rr[I][2 * r + 1] = bload1(rs, o + 256u);
+        rr[SET][2 * r] = bload1(rs, o);
+        if (!NARROW) rr[SET][2 * r + 1] = bload1(rs, o + 256u);
+        else {
+          // (a missing column AND a missing pixel wrap to a small valid offset: finite garbage in a tile row / column the epilogue skips)
+          const unsigned srow1 = (isB && !DENSE) ? (unsigned)__builtin_amdgcn_readlane((int)pixo1, 16 * I + 8 * oct + r) : srow;
+          rr[SET][2 * r + 1] = bload1(rs, vcol1 + srow1);
+        }
       }
       if (++ld_ch == g.cps) { ld_ch = 0; ld_slot += gridDim.x; }
     };
@@ -606,17 +627,17 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_wgrad_kernel(const floa
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           unsigned a_, b_, c_;
-          split_pair(rr[I][2 * (2 * q) + j], rr[I][2 * (2 * q + 1) + j], a_, b_, c_);
+          split_pair(rr[I % D][2 * (2 * q) + j], rr[I % D][2 * (2 * q + 1) + j], a_, b_, c_);
           ph[q] = a_; pm[q] = b_; pl[q] = c_;
         }
         char* p = base + j * 64 * kX3Row;
         *(u32x4v*)(p) = ph; *(u32x4v*)(p + BM * kX3Row) = pm; *(u32x4v*)(p + 2 * BM * kX3Row) = pl;     // (BM == BN)
       }
-      issue(i_c);
+      issue(std::integral_constant<int, (I + D) & 3>{});           // refill the set with the chunk D steps ahead
       if (I & 1) x3_barrier();
     };
     issue(std::integral_constant<int, 0>{}); issue(std::integral_constant<int, 1>{});
-    issue(std::integral_constant<int, 2>{}); issue(std::integral_constant<int, 3>{});
+    if (D == 4) { issue(std::integral_constant<int, 2>{}); issue(std::integral_constant<int, 3>{}); }
     for (int t = 0; t < T; t += 4) {
       step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
       step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
@@ -641,14 +662,17 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_wgrad_kernel(const floa
       const int tile = wi % g.tiles;
       const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
       float* out = dw + (int64_t)(tm * BM + wm0) * g.Ng + tn * BN + wn0 + l31;
+      // (NARROW: Cout and Ng are multiples of 64, so a wave's 64 x 64 block is inside dW or outside it as a whole)
+      if (!NARROW || (tm * BM + wm0 < g.Cout && tn * BN + wn0 < g.Ng)) {
 #pragma unroll
-      for (int it = 0; it < TM; ++it)
+        for (int it = 0; it < TM; ++it)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          for (int r = 0; r < 16; ++r) {
+            const int row = it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
 #pragma unroll
-          for (int jt = 0; jt < TN; ++jt) atomicAdd(out + (int64_t)row * g.Ng + jt * 32, acc[it][jt][r]);
-        }
+            for (int jt = 0; jt < TN; ++jt) atomicAdd(out + (int64_t)row * g.Ng + jt * 32, acc[it][jt][r]);
+          }
+      }
       zero_acc();
       cur_slot += gridDim.x;
     });
@@ -789,7 +813,7 @@ extern "C" int lec_conv_f32x3_dgrad(const float* dy, const uint16_t* w_planes_t,
 }
 
 extern "C" int lec_conv_f32x3_wgrad_supported(int Cin, int Cout, int R, int S) {
-  return Cin >= 128 && Cout >= 128 && Cin % 128 == 0 && Cout % 128 == 0 && (Cin & (Cin - 1)) == 0 && (Cout & (Cout - 1)) == 0 && R > 0 && S > 0;
+  return Cin >= 64 && Cout >= 64 && (Cin & (Cin - 1)) == 0 && (Cout & (Cout - 1)) == 0 && R > 0 && S > 0 && R * S <= 32;
 }
 
 extern "C" int lec_conv_f32x3_wgrad(const float* dy, const float* x, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
@@ -797,14 +821,16 @@ extern "C" int lec_conv_f32x3_wgrad(const float* dy, const float* x, int N, int 
   using namespace lec;
   if (int rc = conv_check("conv_f32x3_wgrad", N, H, W, Cin, Cout, R, S, stride, pad)) return rc;
   LEC_CHECK_ARG(dy && x && dw, "conv_f32x3_wgrad: null pointer");
-  LEC_CHECK_ARG(lec_conv_f32x3_wgrad_supported(Cin, Cout, R, S), "conv_f32x3_wgrad: needs Cin and Cout to be powers of two >= 128 (got %d, %d): use lec_conv_f32_wgrad", Cin, Cout);
+  LEC_CHECK_ARG(lec_conv_f32x3_wgrad_supported(Cin, Cout, R, S), "conv_f32x3_wgrad: needs Cin and Cout to be powers of two >= 64 and at most 32 taps (got %d, %d): use lec_conv_f32_wgrad", Cin, Cout);
   WgX3Geo g;
   g.Ho = (H + 2 * pad - R) / stride + 1; g.Wo = (W + 2 * pad - S) / stride + 1; g.Mpix = N * g.Ho * g.Wo;
   g.H = H; g.W = W; g.Cin = Cin; g.lgCin = ilog2_exact(Cin); g.Cout = Cout; g.S = S; g.stride = stride; g.pad = pad; g.Ng = R * S * Cin;
   g.dy_bytes = (uint32_t)((int64_t)g.Mpix * Cout * 4); g.x_bytes = (uint32_t)((int64_t)N * H * W * Cin * 4);
   g.dWo = make_fastdiv(g.Wo); g.dHo = make_fastdiv(g.Ho); g.dS = make_fastdiv(S);
   const bool dense = R == 1 && S == 1 && stride == 1 && pad == 0;
-  g.tiles_n = g.Ng / 128; g.tiles = (Cout / 128) * g.tiles_n;
+  g.tiles_n = (g.Ng + 127) / 128; g.tiles = ((Cout + 127) / 128) * g.tiles_n;
+  static const bool force_narrow = getenv("LEC_X3_FORCE_NARROW") != nullptr;   // experiments
+  const bool narrow = Cin < 128 || Cout < 128 || force_narrow;   // 64-channel layers: half-empty tiles, two taps per column tile
   const int nchunks = (g.Mpix + kX3BK - 1) / kX3BK;
   static const int wgs = [] { const char* e = getenv("LEC_X3_WGS"); const int v = e ? atoi(e) : 256; return v > 0 ? v : 256; }();
   // K split: accumulation chains of at most 512 chunks (8192 pixels: the rounding error of a longer fp32 chain shows against fp64),
@@ -823,8 +849,10 @@ extern "C" int lec_conv_f32x3_wgrad(const float* dy, const float* x, int N, int 
   const int grid = 8 * g.per < wgs ? 8 * g.per : wgs;
   const size_t lds = (size_t)4 * 3 * (128 + 128) * kX3Row;
   hipStream_t st = (hipStream_t)stream;
-  if (dense) hipLaunchKernelGGL(conv_f32x3_wgrad_kernel<true>, dim3(grid), dim3(kX3Threads), lds, st, dy, x, dw, g);
-  else hipLaunchKernelGGL(conv_f32x3_wgrad_kernel<false>, dim3(grid), dim3(kX3Threads), lds, st, dy, x, dw, g);
+  if (dense && narrow) hipLaunchKernelGGL((conv_f32x3_wgrad_kernel<true, true>), dim3(grid), dim3(kX3Threads), lds, st, dy, x, dw, g);
+  else if (dense) hipLaunchKernelGGL((conv_f32x3_wgrad_kernel<true, false>), dim3(grid), dim3(kX3Threads), lds, st, dy, x, dw, g);
+  else if (narrow) hipLaunchKernelGGL((conv_f32x3_wgrad_kernel<false, true>), dim3(grid), dim3(kX3Threads), lds, st, dy, x, dw, g);
+  else hipLaunchKernelGGL((conv_f32x3_wgrad_kernel<false, false>), dim3(grid), dim3(kX3Threads), lds, st, dy, x, dw, g);
   LEC_CHECK_LAUNCH("conv_f32x3_wgrad_kernel");
   return LEC_OK;
 }

@@ -749,6 +749,12 @@ def conv_f32x3_wgrad_supported(cin, cout, r=1, s_=1):
     return bool(lib.lec_conv_f32x3_wgrad_supported(cin, cout, r, s_))
 
 
+def conv_f32x3_wgrad_preferred(cin, cout, r=1, s_=1):
+    """Where the split weight gradient beats the f32-MFMA one: from 128 channels on both sides (1.5 - 1.9x).  64-channel layers run
+    half-empty 128 x 128 tiles and only reach parity (measured: 64 -> 64 3x3 @56: 1634 vs 1684 us; 128 -> 64: 2920 vs 2809)."""
+    return cin >= 128 and cout >= 128 and conv_f32x3_wgrad_supported(cin, cout, r, s_)
+
+
 def conv_f32x3_wgrad(dy, x, dw, stride, pad):
     """dw += weight gradient with fp32 products on the bf16 matrix cores (lec_conv_f32x3_wgrad, float atomics)."""
     _nhwc_f32(dy, 'dy'); _nhwc_f32(x, 'x'); _nhwc_f32(dw, 'dw')

@@ -94,7 +94,7 @@ class WgradOverlap:
                 dw4 = torch.empty((w.shape[0], 4, w.shape[2], w.shape[3]), dtype=torch.float32, device=w.device, memory_format=torch.channels_last).zero_()
                 _ops().conv_f32_wgrad(gy, x, dw4, conv.stride[0], conv.padding[0])
                 w.grad.add_(dw4[:, :3])
-            elif F32_MODE == 'x3' and _ops().conv_f32x3_wgrad_supported(conv.in_channels, conv.out_channels, *conv.kernel_size):
+            elif F32_MODE == 'x3' and _ops().conv_f32x3_wgrad_preferred(conv.in_channels, conv.out_channels, *conv.kernel_size):
                 _ops().conv_f32x3_wgrad(gy, x, w.grad, conv.stride[0], conv.padding[0])  # bf16 matrix cores (layers of >= 128 channels)
             else:
                 _ops().conv_f32_wgrad(gy, x, w.grad, conv.stride[0], conv.padding[0])   # f32 MFMA, atomics straight into the gradient slot

@@ -42,7 +42,7 @@ def test_cpu_tensor_is_refused():
 
 def test_conv_f32x3_host_geometry_queries():
     """Host-only entry points of the split convolutions: plane sizes follow the tile-major layout [column tile][k chunk][3][BN][16]
-    (BN = 64 up to 64 columns, else 128; k padded to 16), and the weight gradient serves powers of two from 128 channels."""
+    (BN = 64 up to 64 columns, else 128; k padded to 16), and the weight gradient serves powers of two from 64 channels with at most 32 taps."""
     from learning_embeddings_amd import _lib
     lib = _lib.lib
     def elems(ncols, kdim):
@@ -52,5 +52,5 @@ def test_conv_f32x3_host_geometry_queries():
         assert lib.lec_conv_f32x3_planes_elems(cout, rs, cin, 0) == elems(cout, rs * cin)
         assert lib.lec_conv_f32x3_planes_elems(cout, rs, cin, 1) == elems(cin, rs * cout)
     assert lib.lec_conv_f32x3_wgrad_supported(128, 128, 3, 3) == 1 and lib.lec_conv_f32x3_wgrad_supported(2048, 512, 1, 1) == 1
-    assert lib.lec_conv_f32x3_wgrad_supported(64, 256, 1, 1) == 0 and lib.lec_conv_f32x3_wgrad_supported(256, 64, 1, 1) == 0
-    assert lib.lec_conv_f32x3_wgrad_supported(192, 128, 1, 1) == 0
+    assert lib.lec_conv_f32x3_wgrad_supported(64, 256, 1, 1) == 1 and lib.lec_conv_f32x3_wgrad_supported(256, 64, 3, 3) == 1
+    assert lib.lec_conv_f32x3_wgrad_supported(192, 128, 1, 1) == 0 and lib.lec_conv_f32x3_wgrad_supported(4, 64, 7, 7) == 0 and lib.lec_conv_f32x3_wgrad_supported(32, 64, 1, 1) == 0

@@ -62,7 +62,7 @@ for name, cin, hw, cout, r, st, pad, count in SHAPES:
         dx3 = ops.conv_f32x3_dgrad(dy, pt, x.shape, st, pad); dx1 = ops.conv_f32_dgrad(dy, w, x.shape, st, pad)
         row['dgrad_err_x3'] = '%.2e' % relerr(dx3, dx64); row['dgrad_err_f32'] = '%.2e' % relerr(dx1, dx64)
         row['dgrad_err_lib'] = '%.2e' % relerr(torch.ops.aten.convolution_backward(dy, x, w, None, [st, st], [pad, pad], [1, 1], False, [0, 0], 1, [True, False, False])[0], dx64)
-    wg_ok = a.wgrad and ops.conv_f32x3_wgrad_supported(cin, cout, r, r)
+    wg_ok = a.wgrad and ops.conv_f32x3_wgrad_preferred(cin, cout, r, r)
     if a.wgrad and not wg_ok:
         dw64_ = torch.ops.aten.convolution_backward(dy.double(), x.double(), w.double(), None, [st, st], [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         dw1_ = torch.zeros_like(w); ops.conv_f32_wgrad(dy, x, dw1_, st, pad); row['wgrad_err_f32'] = '%.2e' % relerr(dw1_, dw64_)
