@@ -53,12 +53,13 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 // bf16 kernels reuse a value they have just stored so that both passes of a layer see the same numbers.
 struct EBf16 {
   static constexpr int kBytes = 2;
-  static __device__ __forceinline__ void ld(const void* p, int64_t i, float (&f)[8]) {
+  static __device__ __forceinline__ int chan(int cv, int j, int) { return cv * 8 + j; }      // channel of a thread's j-th value
+  static __device__ __forceinline__ void ld(const void* p, int64_t i, float (&f)[8], int = 0, int = 0) {
     u32x4 r = ld16((const char*)p + i * 16);
 #pragma unroll
     for (int q = 0; q < 4; ++q) { f[2 * q] = __uint_as_float(r[q] << 16); f[2 * q + 1] = __uint_as_float(r[q] & 0xffff0000u); }
   }
-  static __device__ __forceinline__ void st(void* p, int64_t i, const float (&f)[8]) {
+  static __device__ __forceinline__ void st(void* p, int64_t i, const float (&f)[8], int = 0, int = 0) {
     u32x4 r;
 #pragma unroll
     for (int q = 0; q < 4; ++q) r[q] = (unsigned int)f2bf(f[2 * q]) | ((unsigned int)f2bf(f[2 * q + 1]) << 16);
@@ -66,18 +67,25 @@ struct EBf16 {
   }
   static __device__ __forceinline__ float rnd(float v) { return bf2f(f2bf(v)); }
 };
+// fp32: a thread's 8 channels are TWO runs of 4 -- channels 4 cv .. 4 cv + 3 and C / 2 + 4 cv .. + 3 -- so that each of its two 16-byte
+// accesses is, across the wave, one contiguous kilobyte.  (With 8 consecutive channels per thread both accesses stride 32 bytes from
+// lane to lane and touch every cache line of a 2 KB span half: 4.8 against 5.3 TB/s on a 2-read / 1-write pass,
+// tools/microbench/bn_access.hip.)  i = row * CV + cv as for bf16; the byte address of the first run is 32 i - 16 cv.
 struct EF32 {
   static constexpr int kBytes = 4;
-  static __device__ __forceinline__ void ld(const void* p, int64_t i, float (&f)[8]) {
-    u32x4 a = ld16((const char*)p + i * 32), b = ld16((const char*)p + i * 32 + 16);
+  static __device__ __forceinline__ int chan(int cv, int j, int CV) { return j < 4 ? cv * 4 + j : CV * 4 + cv * 4 + (j - 4); }
+  static __device__ __forceinline__ void ld(const void* p, int64_t i, float (&f)[8], int cv, int CV) {
+    const char* q0 = (const char*)p + i * 32 - cv * 16;
+    u32x4 a = ld16(q0), b = ld16(q0 + CV * 16);
 #pragma unroll
     for (int q = 0; q < 4; ++q) { f[q] = __uint_as_float(a[q]); f[4 + q] = __uint_as_float(b[q]); }
   }
-  static __device__ __forceinline__ void st(void* p, int64_t i, const float (&f)[8]) {
+  static __device__ __forceinline__ void st(void* p, int64_t i, const float (&f)[8], int cv, int CV) {
     u32x4 a, b;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { a[q] = __float_as_uint(f[q]); b[q] = __float_as_uint(f[4 + q]); }
-    st16((char*)p + i * 32, a); st16((char*)p + i * 32 + 16, b);
+    char* q0 = (char*)p + i * 32 - cv * 16;
+    st16(q0, a); st16(q0 + CV * 16, b);
   }
   static __device__ __forceinline__ float rnd(float v) { return v; }
 };
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const void* __rest
     for (; r + (U - 1) * stride < M; r += U * stride) {
       float v[U][8];
 #pragma unroll
-      for (int u = 0; u < U; ++u) E::ld(x, (r + u * stride) * CV + cv, v[u]);
+      for (int u = 0; u < U; ++u) E::ld(x, (r + u * stride) * CV + cv, v[u], cv, CV);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const void* __rest
     }
     for (; r < M; r += stride) {
       float a[8];
-      E::ld(x, r * CV + cv, a);
+      E::ld(x, r * CV + cv, a, cv, CV);
 #pragma unroll
       for (int j = 0; j < 8; ++j) { acc[0][j] += a[j]; acc[1][j] += a[j] * a[j]; }
     }
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const void* __rest
   if (tid < CVB) {
     float* p = part + (int64_t)blockIdx.x * 2 * C;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { p[cv * 8 + j] = acc[0][j]; p[C + cv * 8 + j] = acc[1][j]; }
+    for (int j = 0; j < 8; ++j) { p[E::chan(cv, j, CV)] = acc[0][j]; p[C + E::chan(cv, j, CV)] = acc[1][j]; }
   }
 }
 
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const void* __rest
   if (rg >= RPI) return;
   float sc[8], sh[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { sc[j] = scale[cv * 8 + j]; sh[j] = shift[cv * 8 + j]; }
+  for (int j = 0; j < 8; ++j) { sc[j] = scale[E::chan(cv, j, CV)]; sh[j] = shift[E::chan(cv, j, CV)]; }
   const int64_t stride = (int64_t)gridDim.x * RPI;
   auto one = [&](float (&a)[8], const float (&r)[8], int64_t idx) {
     unsigned int bits = 0;
@@ -261,17 +269,17 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const void* __rest
       if (RELU) bits |= (E::rnd(v) > 0.0f ? 1u : 0u) << j;           // decided on the ROUNDED output, like a y-based mask
     }
     if (RELU && mask) mask[idx] = (unsigned char)bits;
-    E::st(y, idx, a);
+    E::st(y, idx, a, cv, CV);
   };
   constexpr int U = E::kBytes == 2 ? 4 : 2;
   int64_t r = (int64_t)blockIdx.x * RPI + rg;
   for (; r + (U - 1) * stride < M; r += U * stride) {
     float a[U][8], rr[U][8];
 #pragma unroll
-    for (int u = 0; u < U; ++u) E::ld(x, (r + u * stride) * CV + cv, a[u]);
+    for (int u = 0; u < U; ++u) E::ld(x, (r + u * stride) * CV + cv, a[u], cv, CV);
     if (RES) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) E::ld(res, (r + u * stride) * CV + cv, rr[u]);
+      for (int u = 0; u < U; ++u) E::ld(res, (r + u * stride) * CV + cv, rr[u], cv, CV);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) one(a[u], rr[u], (r + u * stride) * CV + cv);
@@ -279,8 +287,8 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const void* __rest
   for (; r < M; r += stride) {
     const int64_t i0 = r * CV + cv;
     float a[8], rr[8];
-    E::ld(x, i0, a);
-    if (RES) E::ld(res, i0, rr);
+    E::ld(x, i0, a, cv, CV);
+    if (RES) E::ld(res, i0, rr, cv, CV);
     one(a, rr, i0);
   }
 }
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const void* _
   const bool live = rg < RPI;
   float acc[2][8], mu[8], is[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; mu[j] = mean[cv * 8 + j]; is[j] = invstd[cv * 8 + j]; }
+  for (int j = 0; j < 8; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; mu[j] = mean[E::chan(cv, j, CV)]; is[j] = invstd[E::chan(cv, j, CV)]; }
   const int64_t stride = (int64_t)gridDim.x * RPI;
   auto one = [&](float (&g)[8], const float (&h)[8], const float (&yv)[8], unsigned int m, const float (&xv)[8], int64_t i) {
 #pragma unroll
@@ -319,7 +327,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const void* _
       acc[0][j] += a;
       acc[1][j] += a * ((xv[j] - mu[j]) * is[j]);
     }
-    if (gout) E::st(gout, i, g);
+    if (gout) E::st(gout, i, g, cv, CV);
   };
   if (live) {
     int64_t r = (int64_t)blockIdx.x * RPI + rg;
@@ -330,10 +338,10 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const void* _
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int64_t i = (r + u * stride) * CV + cv;
-        E::ld(dy, i, g[u]); E::ld(x, i, xv[u]);
-        if (dy2) E::ld(dy2, i, h[u]);                                        // second gradient stream of a forked activation
+        E::ld(dy, i, g[u], cv, CV); E::ld(x, i, xv[u], cv, CV);
+        if (dy2) E::ld(dy2, i, h[u], cv, CV);                                        // second gradient stream of a forked activation
         m[u] = 0xff;
-        if (RELU == 1) E::ld(y, i, yv[u]);
+        if (RELU == 1) E::ld(y, i, yv[u], cv, CV);
         if (RELU == 2) m[u] = ((const unsigned char*)y)[i];
       }
 #pragma unroll
@@ -343,9 +351,9 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const void* _
       const int64_t i = r * CV + cv;
       float g[8], xv[8], h[8], yv[8];
       unsigned int m = 0xff;
-      E::ld(dy, i, g); E::ld(x, i, xv);
-      if (dy2) E::ld(dy2, i, h);
-      if (RELU == 1) E::ld(y, i, yv);
+      E::ld(dy, i, g, cv, CV); E::ld(x, i, xv, cv, CV);
+      if (dy2) E::ld(dy2, i, h, cv, CV);
+      if (RELU == 1) E::ld(y, i, yv, cv, CV);
       if (RELU == 2) m = ((const unsigned char*)y)[i];
       one(g, h, yv, m, xv, i);
     }
@@ -354,7 +362,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const void* _
   if (tid < CVB) {
     float* p = part + (int64_t)blockIdx.x * 2 * C;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { p[cv * 8 + j] = acc[0][j]; p[C + cv * 8 + j] = acc[1][j]; }
+    for (int j = 0; j < 8; ++j) { p[E::chan(cv, j, CV)] = acc[0][j]; p[C + E::chan(cv, j, CV)] = acc[1][j]; }
   }
 }
 
@@ -384,16 +392,16 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(const void* __
   float gs[8], mu[8], is[8], k1[8], k2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int c = cv * 8 + j;
+    const int c = E::chan(cv, j, CV);
     is[j] = invstd[c]; mu[j] = mean[c]; gs[j] = gamma[c] * is[j]; k1[j] = c1[c]; k2[j] = c2[c];
   }
   const int64_t stride = (int64_t)gridDim.x * RPI;
   auto one = [&](int64_t i) {
     float g[8], xv[8], h[8], yv[8], o[8];
-    E::ld(dy, i, g); E::ld(x, i, xv);
-    if (dy2) E::ld(dy2, i, h);
+    E::ld(dy, i, g, cv, CV); E::ld(x, i, xv, cv, CV);
+    if (dy2) E::ld(dy2, i, h, cv, CV);
     unsigned int m0 = 0xff;
-    if (RELU == 1) E::ld(y, i, yv);
+    if (RELU == 1) E::ld(y, i, yv, cv, CV);
     if (RELU == 2) m0 = ((const unsigned char*)y)[i];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -405,8 +413,8 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(const void* __
       o[j] = gs[j] * (a - k1[j] - xh * k2[j]);
       g[j] = a;
     }
-    E::st(dx, i, o);
-    if (RES) E::st(dres, i, g);
+    E::st(dx, i, o, cv, CV);
+    if (RES) E::st(dres, i, g, cv, CV);
   };
   int64_t r = (int64_t)blockIdx.x * RPI + rg;
   for (; r + stride < M; r += 2 * stride) { one(r * CV + cv); one((r + stride) * CV + cv); }
