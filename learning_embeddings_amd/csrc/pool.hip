@@ -17,29 +17,33 @@ __device__ __forceinline__ float pbf2f(unsigned short u) { return __uint_as_floa
 
 // element types: a "vector" is 8 consecutive channels, bf16 (16 bytes) or fp32 (32 bytes: the reference's precision)
 struct PBf16 {
-  static __device__ __forceinline__ void ld(const void* p, int64_t i, float (&f)[8]) {
+  static __device__ __forceinline__ void ld(const void* p, int64_t i, float (&f)[8], int = 0, int = 0) {
     const pbf16x8 v = ((const pbf16x8*)p)[i];
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = pbf2f(v.v[j]);
   }
-  static __device__ __forceinline__ void st(void* p, int64_t i, const float (&f)[8]) {
+  static __device__ __forceinline__ void st(void* p, int64_t i, const float (&f)[8], int = 0, int = 0) {
     pbf16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { __hip_bfloat16 hb = __float2bfloat16(f[j]); o.v[j] = *reinterpret_cast<unsigned short*>(&hb); }
     ((pbf16x8*)p)[i] = o;
   }
 };
+// fp32: a thread's 8 channels are two runs of 4 (channels 4 cv .. + 3 and C / 2 + 4 cv .. + 3), as in bn.hip's EF32: each 16-byte access of
+// the CV lanes of a pixel is then one contiguous half row instead of every other 16 bytes of the whole row.  i = pixel * CV + cv.
 struct PF32 {
-  static __device__ __forceinline__ void ld(const void* p, int64_t i, float (&f)[8]) {
-    const pf32x4 a = ((const pf32x4*)p)[2 * i], b = ((const pf32x4*)p)[2 * i + 1];
+  static __device__ __forceinline__ void ld(const void* p, int64_t i, float (&f)[8], int cv, int CV) {
+    const char* q0 = (const char*)p + i * 32 - cv * 16;
+    const pf32x4 a = *(const pf32x4*)q0, b = *(const pf32x4*)(q0 + CV * 16);
 #pragma unroll
     for (int j = 0; j < 4; ++j) { f[j] = a.v[j]; f[4 + j] = b.v[j]; }
   }
-  static __device__ __forceinline__ void st(void* p, int64_t i, const float (&f)[8]) {
+  static __device__ __forceinline__ void st(void* p, int64_t i, const float (&f)[8], int cv, int CV) {
     pf32x4 a, b;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { a.v[j] = f[j]; b.v[j] = f[4 + j]; }
-    ((pf32x4*)p)[2 * i] = a; ((pf32x4*)p)[2 * i + 1] = b;
+    char* q0 = (char*)p + i * 32 - cv * 16;
+    *(pf32x4*)q0 = a; *(pf32x4*)(q0 + CV * 16) = b;
   }
 };
 
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const void* __restrict
         const int w = 2 * wo - 1 + kw;
         if (w < 0 || w >= W) continue;
         float v[8];
-        E::ld(x, (((int64_t)n * H + h) * W + w) * CV + cv, v);
+        E::ld(x, (((int64_t)n * H + h) * W + w) * CV + cv, v, cv, CV);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float f = v[j];
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const void* __restrict
     pu8x8 a;
 #pragma unroll
     for (int j = 0; j < 8; ++j) a.v[j] = arg[j];
-    E::st(y, i, best);                                                   // exact: the max is one of the inputs
+    E::st(y, i, best, cv, CV);                                                   // exact: the max is one of the inputs
     idx[i] = a;
   }
 }
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const void* __restrict
         const int64_t o = (((int64_t)n * Ho + ho) * Wo + wo) * CV + cv;
         const pu8x8 am = idx[o];
         float g[8];
-        E::ld(dy, o, g);
+        E::ld(dy, o, g, cv, CV);
         // window (ho, wo) covers rows 2ho-1..2ho+1: patch row p (h = 2i+p) sits at kh = 2i + p - (2ho - 1) = p + 1 - 2a
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const void* __restrict
     for (int p = 0; p < 2; ++p) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        E::st(dx, (((int64_t)n * H + 2 * i + p) * W + 2 * j + q) * CV + cv, acc[p * 2 + q]);
+        E::st(dx, (((int64_t)n * H + 2 * i + p) * W + 2 * j + q) * CV + cv, acc[p * 2 + q], cv, CV);
       }
     }
   }
