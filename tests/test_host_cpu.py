@@ -261,3 +261,66 @@ def test_pair_dataset_matches_reference_fixture(half_half):
             else:
                 it = d[i]
                 assert [it['original_from'], it['original_to'], it['status']] == want and it['from'] == want[0] and it['to'] == want[1]
+
+
+# ---------------------------------------------------------------------------------------------------- graph interchange (oe_h.py:563-571, 2250-2297)
+class _PickledGraph:
+    """Stands in for a gpickled networkx.DiGraph of a reference-written folder: anything with nodes() / edges()."""
+    def __init__(self, g):
+        self._n = list(g.nodes()); self._e = [tuple(e) for e in g.edges()]
+    def nodes(self): return self._n
+    def edges(self): return self._e
+
+
+def _same_graph_dict(a, b, lm, n_img):
+    from learning_embeddings_amd.oe_h_trainer import _GRAPH_KEYS
+    for key in _GRAPH_KEYS:
+        assert list(a[key].nodes()) == list(b[key].nodes()), key
+        assert a[key].edges() == b[key].edges(), key
+    assert a['mapping_ix_to_node'] == b['mapping_ix_to_node'] and a['mapping_node_to_ix'] == b['mapping_node_to_ix']
+    N = lm.n_classes
+    ga, gb = a['G_train_neg'], b['G_train_neg']; ga.seed(3); gb.seed(3)
+    frm = np.array([0, 1, 3, 5, 2, 4, 6, 1], dtype=np.int32); to = np.array([N + 0, N + 5, N + 2, N + 7, 9, N + 11, N + 3, N + 1], dtype=np.int32)
+    assert np.array_equal(ga.draw_batch(frm, to, 6), gb.draw_batch(frm, to, 6))
+
+
+def test_save_and_load_combined_graphs_round_trip_and_reference_written_folder(tmp_path):
+    """save_combined_graphs -> load_combined_graphs gives back the same graph_dict (node and edge ORDER, index mappings, negative sampler
+    stream); a folder as the reference writes it (gpickled graph objects + the dense neg_adjacency.npy, no neg_structure.npz) loads to
+    the same thing."""
+    import pickle
+    from learning_embeddings_amd.oe_h_trainer import save_combined_graphs, load_combined_graphs, GRAPH_FILES, _GRAPH_KEYS
+    lm = SyntheticLabelMap([2, 4, 8])
+    gd = create_combined_graphs(_fake_loaders(lm, 24, 6), lm, pick_per_level=True)
+    own = tmp_path / 'own'
+    save_combined_graphs(gd, str(own))
+    assert sorted(os.listdir(own)) == sorted(list(GRAPH_FILES) + ['neg_structure.npz', 'neg_adjacency.npy'])
+    back = load_combined_graphs(str(own), pick_per_level=True)
+    _same_graph_dict(gd, back, lm, 24)
+    # the reference's own format
+    ref = tmp_path / 'ref'; os.makedirs(ref)
+    for fname, key in zip(GRAPH_FILES, _GRAPH_KEYS):
+        with open(ref / fname, 'wb') as f:
+            pickle.dump(_PickledGraph(gd[key]), f)
+    np.save(ref / 'neg_adjacency.npy', gd['G_train_neg'].to_dense())
+    with pytest.raises(ValueError):
+        load_combined_graphs(str(ref))                            # the dense matrix alone does not carry the level sizes
+    back2 = load_combined_graphs(str(ref), labelmap=lm, pick_per_level=True)
+    _same_graph_dict(gd, back2, lm, 24)
+
+
+def test_closure_graph_from_the_samplers_csr_equals_transitive_closure():
+    """closure_graph (transitive closure read back from the C++ sampler's CSR through lec_sampler_tc_export) against the python
+    transitive closure of the same skeleton: same edge set, skeleton edges first in their order."""
+    from learning_embeddings_amd.oe_h_trainer import closure_graph
+    lm = SyntheticLabelMap([3, 6, 12])
+    gd = create_combined_graphs(_fake_loaders(lm, 30, 6), lm, pick_per_level=False)
+    sk = gd['G_train_skeleton_full']
+    got = closure_graph(sk, gd['G_train_neg'], gd['mapping_ix_to_node'], gd['mapping_node_to_ix'])
+    want = transitive_closure(sk)
+    key = lambda e: (str(type(e[0])), str(e[0]), str(type(e[1])), str(e[1]))
+    assert sorted(got.edges(), key=key) == sorted(want.edges(), key=key)
+    assert list(got.nodes()) == list(sk.nodes())
+    for u in sk.nodes():
+        n_sk = len(list(sk.successors(u)))
+        assert list(got.successors(u))[:n_sk] == list(sk.successors(u))

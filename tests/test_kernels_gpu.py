@@ -760,3 +760,38 @@ def test_table_step_refreshes_the_fp16_shadow():
     for x, y in zip(a, b):
         assert torch.equal(x, y)
     assert torch.equal(sh, b[0].to(torch.float16))
+
+
+@pytest.mark.gpu
+def test_joint_loss_skips_node_codes_outside_the_tables():
+    """A stale or corrupt node code (label row >= n_labels, image row >= n_feat) reaching lec_joint_loss_fwd_bwd through the C ABI must not
+    become an out-of-bounds read or atomic: the tables sit inside larger buffers whose guard rows hold a sentinel, and a launch with bad
+    codes leaves every guard row -- values and gradients -- untouched and the energies of the pairs it did not corrupt are those of the
+    clean launch.  (The bad code is treated as a zero row: its own energy -- and so the loss -- may come out NaN, which is the loud
+    outcome a corrupt batch should have; the reference raises IndexError in nn.Embedding for the same input.)"""
+    torch.manual_seed(0)
+    N, M, D, B, K = 40, 12, 10, 8, 3
+    bigW = torch.full((N + 16, D), 7.0, device=DEV); bigG = torch.full((N + 16, D), 7.0, device=DEV)
+    bigF = torch.full((M + 16, D), 7.0, device=DEV); bigGF = torch.full((M + 16, D), 7.0, device=DEV)
+    W = bigW[:N]; F_ = bigF[:M]
+    W.copy_(torch.randn(N, D, device=DEV) * 0.1); F_.copy_(torch.randn(M, D, device=DEV))
+    frm = torch.randint(0, N, (B,), device=DEV, dtype=torch.int32)
+    to = (-1 - torch.randint(0, M, (B,), device=DEV)).to(torch.int32)
+    neg = torch.randint(0, N, (B, 2 * K), device=DEV, dtype=torch.int32)
+    def run(neg_):
+        gW = bigG[:N]; gF = bigGF[:M]; gW.zero_(); gF.zero_()
+        out = ops.joint_loss_raw(W, F_, frm, to, neg_.contiguous(), None, 0.1, 0.01, 0, 1, 1, grad_table=gW, grad_feat=gF)
+        torch.cuda.synchronize()
+        return [o.clone() for o in out], gW.clone(), gF.clone()
+    (loss0, ep0, en0), gW0, gF0 = run(neg)
+    bad = neg.clone()
+    bad[1, 0] = N + 5                                   # label row past the table
+    bad[2, 4] = -1 - (M + 3)                            # image row past the features
+    bad[5, 2] = 2 ** 30                                 # far out
+    (loss1, ep1, en1), gW1, gF1 = run(bad)
+    for big in (bigW, bigG, bigF, bigGF):
+        n = N if big.shape[0] == N + 16 else M
+        assert (big[n:] == 7.0).all(), 'a guard row was written'
+    assert torch.equal(ep0, ep1)                         # positives untouched
+    clean = [b for b in range(B) if b not in (1, 2, 5)]
+    assert torch.equal(en0[clean], en1[clean])
