@@ -576,6 +576,18 @@ def conv1x1_stats_rows(x_rows, w2):
     return y
 
 
+def materialise_deferred(y):
+    """A consumer other than the fused BatchNorm got hold of a tensor conv1x1_stats_rows left unwritten (stock-torch fallback of
+    BatchNormAct2d, a hook, a debugger): run the plain convolution into it now.  No-op for every other tensor."""
+    dfr = _DEFERRED.pop(y.data_ptr(), None)
+    if dfr is not None:
+        x_in, w2 = dfr
+        if _BN_WS_OWNER[0] == y.data_ptr():
+            _BN_WS_OWNER[0] = 0
+        check(lib.lec_conv1x1_fwd(dptr(x_in), dptr(w2), 0, x_in.shape[0], x_in.shape[1], w2.shape[0], dptr(y), None, 0, None, stream_ptr()))
+    return y
+
+
 def conv1x1_dgrad_bnfold_supported(cin, cout, M):
     return bool(lib.lec_conv1x1_dgrad_bnfold_supported(int(cin), int(cout), int(M)))
 

@@ -37,6 +37,8 @@ class BatchNormAct2d(nn.BatchNorm2d):
             sink = (self.weight, self.bias, ov.reducer) if (ov is not None and ov.enabled and ov.arena is not None and self.training and not ov.accumulate) else None
             return ops.BNActFn.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var,
                                      self.training, self.momentum, self.eps, self.fuse_relu, fork and self.training, sink)
+        if x.is_cuda:
+            _ops().materialise_deferred(x)          # conv3 may have handed its output on unwritten, expecting the fused layer above
         y = F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, self.training, self.momentum, self.eps)
         if residual is not None:
             y = y + residual

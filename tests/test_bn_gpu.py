@@ -468,3 +468,64 @@ def test_bn_forked_output_two_gradient_streams():
         outs.append((xa.grad.float(), ra.grad.float(), wa.grad, ba.grad))
     for a, b_ in zip(*outs):
         assert (a - b_).abs().max().item() <= 0.02 * (b_.abs().max().item() + 1e-6)      # bf16 rounding of the pre-summed gradient
+
+
+def test_deferred_conv3_output_is_materialised_for_the_stock_batchnorm_fallback():
+    """conv3 hands its output on UNWRITTEN when the fused bn3 is expected to finish it.  If the stock fallback of BatchNormAct2d gets
+    that tensor after all (a predicate mismatch between the two layers -- forced here by switching the fused layer off between conv3
+    and bn3) it must first be filled with the real product: outputs of ResNet-50's layer1 equal those of a run without deferral whose
+    bn3 layers take the same stock fallback, and no record is left behind."""
+    from learning_embeddings_amd import resnet as R
+    from learning_embeddings_amd.resnet import WgradOverlap, BatchNormAct2d
+    torch.manual_seed(0)
+    net = R.ResNet(R.Bottleneck, [3, 4, 6, 3])
+    blocks = list(net.layer1)
+    for b in blocks:
+        b.to(DEV).to(memory_format=torch.channels_last).train()
+    x0 = (torch.randn(4, 64, 16, 16, device=DEV) * 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res, calls = {}, {'defer': 0, 'filled': 0}
+    orig_stats, orig_mat, prev = ops.conv1x1_stats_rows, ops.materialise_deferred, ops.DEFER_BN_APPLY
+    def stats_then_switch_off(*a, **k):
+        calls['defer'] += 1
+        y = orig_stats(*a, **k)
+        y.fill_(float('nan'))                       # whatever the allocator left there must not survive
+        BatchNormAct2d.fused_enabled = False
+        return y
+    def fill_then_switch_on(t):
+        pending = t.data_ptr() in ops._DEFERRED
+        out = orig_mat(t)
+        calls['filled'] += int(pending)
+        return out
+    try:
+        for tag in ('defer', 'plain'):
+            ops.DEFER_BN_APPLY = tag == 'defer'
+            ops.conv1x1_stats_rows = stats_then_switch_off
+            ops.materialise_deferred = fill_then_switch_on
+            WgradOverlap.instance = WgradOverlap()
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                y = x0.clone().requires_grad_(True)
+                for b in blocks:
+                    BatchNormAct2d.fused_enabled = True
+                    if tag == 'plain':              # same layers on the stock path, product written by the ordinary convolution
+                        bn3_fwd = b.bn3.forward
+                        def stock(*a, _f=bn3_fwd, **k):
+                            BatchNormAct2d.fused_enabled = False
+                            try:
+                                return _f(*a, **k)
+                            finally:
+                                BatchNormAct2d.fused_enabled = True
+                        b.bn3.forward = stock
+                    y = b(y)
+                    if tag == 'plain':
+                        del b.bn3.forward
+            WgradOverlap.instance.join(); torch.cuda.synchronize()
+            res[tag] = y.detach().float().clone()
+    finally:
+        BatchNormAct2d.fused_enabled = True
+        WgradOverlap.instance = None
+        ops.DEFER_BN_APPLY = prev
+        ops.conv1x1_stats_rows = orig_stats
+        ops.materialise_deferred = orig_mat
+    assert calls['defer'] == 3 and calls['filled'] == 3 and not ops._DEFERRED
+    assert torch.isfinite(res['defer']).all()
+    assert torch.equal(res['defer'], res['plain'])
