@@ -84,7 +84,7 @@ def measure(args, dtype, rank, world, stamp, primary):
     from learning_embeddings_amd.engine import StepEngine, WORKLOADS
     from learning_embeddings_amd.resnet import conv_macs
     eng = StepEngine(args.workload, dtype=dtype, sampler_mode=args.sampler, batch=args.batch, overlap_wgrad=not args.no_overlap_wgrad,
-                     use_graph=not args.no_graph)
+                     use_graph=args.launch != 'eager')
     dev = eng.device
     stamp('%s: engine built' % dtype)
     for i in range(args.warmup):
@@ -93,8 +93,36 @@ def measure(args, dtype, rank, world, stamp, primary):
             torch.cuda.synchronize(); stamp('%s: warm-up step %d done' % (dtype, i))
     while eng.use_graph and eng.hip_graph is None and eng.graph_error is None:
         eng.step()                                              # fewer warm-up steps than the capture needs: finish them untimed
+    launch_probe = None
+    if args.launch == 'auto' and eng.hip_graph is not None:
+        # Same kernels either way; what differs is who feeds the two HIP streams.  The replayed graph is immune to a slow host but
+        # ROCm's graph executor overlaps the side stream's weight gradients with the main chain less than eager launches do (fp32
+        # step: 150 against 144 ms); eager launches need a host that enqueues a step faster than the GPU runs
+        # it (true for the fp32 step on a quiet host, false for the bf16 one).  Measure both on THIS box, untimed, and keep the
+        # faster for the timed region; every rank takes the same decision.
+        def block(graph, n=6):
+            eng.set_launch_mode(graph)
+            for _ in range(2):
+                eng.step()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(); t_ = time.perf_counter()
+            for _ in range(n):
+                eng.step()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t_) / n * 1e3
+        g_ms = block(True); e_ms = block(False)
+        eager_wins = torch.tensor([1.0 if e_ms < 0.985 * g_ms else 0.0], device=dev)
+        if world > 1:
+            dist.all_reduce(eager_wins, op=dist.ReduceOp.MIN)
+        eng.set_launch_mode(not bool(eager_wins.item()))
+        launch_probe = {'hipgraph_ms_per_step': round(g_ms, 2), 'eager_ms_per_step': round(e_ms, 2), 'chosen': 'eager' if eager_wins.item() else 'hipgraph'}
+        stamp('%s: launch-mode probe: hipGraph %.2f ms/step, eager %.2f ms/step -> %s' % (dtype, g_ms, e_ms, launch_probe['chosen']))
     stamp('%s: launch mode: %s' % (dtype, 'hipGraph replay' if eng.hip_graph is not None else 'eager'))
     eng.enable_timers()
+    auto_eager = launch_probe is not None and launch_probe['chosen'] == 'eager'
+    if auto_eager:
+        ops.BN_TIMER = None; ops.CONV_TIMER = None              # per-kernel events only in the probe steps after the timed region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -138,6 +166,13 @@ def measure(args, dtype, rank, world, stamp, primary):
         for _ in range(3 if primary else 2):
             probe_step()
         torch.cuda.synchronize()
+    elif auto_eager:
+        ops.BN_TIMER = []; ops.CONV_TIMER = []
+        n_rec = len(eng.timers['records'])
+        for _ in range(3 if primary else 2):
+            eng.step()
+        torch.cuda.synchronize()
+        del eng.timers['records'][:n_rec]                       # phases_ms: these steps (same launch mode, plus the per-kernel events)
     phases = eng.timer_summary()
     # The weight-gradient kernels run on a second stream next to the BatchNorm kernels, so per-kernel durations inside the
     # timed region include that sharing.  Three more steps with everything on ONE stream give the families' own durations.
@@ -227,7 +262,10 @@ def measure(args, dtype, rank, world, stamp, primary):
         except Exception:
             pass
     res = {'value': round(ips, 2), 'ms_per_step': round(dt / args.steps * 1e3, 3), 'dtype': 'f32' if f32 else dtype,
-           'launch_mode': 'hipgraph (forward + loss + backward of a step replayed as one graph)' if graph_mode else 'eager',
+           'launch_mode': ('hipgraph (forward + loss + backward of a step replayed as one graph)' if graph_mode else 'eager')
+                          + (' -- the faster of the two on this box in the warm-up probe: hipGraph %.2f, eager %.2f ms/step' % (launch_probe['hipgraph_ms_per_step'], launch_probe['eager_ms_per_step'])
+                             if launch_probe else ''),
+           'launch_probe': launch_probe,
            'mean_loss': round(loss_mean, 4), 'hbm_peak_allocated_gb': round(torch.cuda.max_memory_allocated() / 1e9, 1),
            'phases_ms': dict({('eager_probe_' + k if graph_mode and k in ('cnn_fwd', 'cone_loss', 'cnn_bwd', 'allreduce_wait', 'fused_bn', 'conv_f32') else k): round(v, 3)
                               for k, v in phases.items()}, host_enqueue=round(host_busy_s / args.steps * 1e3, 3)),
@@ -356,10 +394,15 @@ def main():
     ap.add_argument('--no-stress', action='store_true')
     ap.add_argument('--no-overlap-wgrad', action='store_true', help='keep the conv weight-gradient kernels on the main stream (default: second HIP stream)')
     ap.add_argument('--check-replicas', action='store_true', help='after the run, assert that every rank holds identical parameters')
-    ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying the captured hipGraph of forward+loss+backward')
+    ap.add_argument('--launch', default='auto', choices=['auto', 'graph', 'eager'],
+                    help='how the kernels of forward+loss+backward reach the GPU: graph = replay the captured hipGraph; eager = launch each one; '
+                         'auto (default) = probe both on this box during warm-up and keep the faster for the timed steps')
+    ap.add_argument('--no-graph', action='store_true', help='same as --launch eager')
     ap.add_argument('--cudnn-benchmark', action='store_true', help='let MIOpen benchmark every solver per conv shape (slow start)')
     ap.add_argument('--through-trainer', type=int, default=6, help='also time N steps of the same workload driven through JointEmbeddings.train_step (0: skip)')
     args = ap.parse_args()
+    if args.no_graph:
+        args.launch = 'eager'
     from learning_embeddings_amd import resnet as _resnet
     _resnet.F32_MODE = args.conv_f32
 
