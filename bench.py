@@ -369,7 +369,7 @@ def measure_trainer(args, dtype, stamp, n_steps, n_warm):
     t0 = time.perf_counter()
     for _ in range(n_steps):
         tr.train_step(next(it))
-        rows += len(np.unique(crit.last_negatives[crit.last_negatives >= lm.n_classes])) + B
+        rows += crit.last_cnn_rows                                # distinct images of the batch: positives' images + image negatives not among them
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {'value': round(B * n_steps / dt, 2), 'unit': 'images/sec', 'ms_per_step': round(dt / n_steps * 1e3, 3), 'steps': n_steps, 'dtype': 'f32' if dtype == 'fp32' else dtype,
@@ -399,7 +399,7 @@ def main():
                          'auto (default) = probe both on this box during warm-up and keep the faster for the timed steps')
     ap.add_argument('--no-graph', action='store_true', help='same as --launch eager')
     ap.add_argument('--cudnn-benchmark', action='store_true', help='let MIOpen benchmark every solver per conv shape (slow start)')
-    ap.add_argument('--through-trainer', type=int, default=6, help='also time N steps of the same workload driven through JointEmbeddings.train_step (0: skip)')
+    ap.add_argument('--through-trainer', type=int, default=8, help='also time N steps of the same workload driven through JointEmbeddings.train_step (0: skip)')
     args = ap.parse_args()
     if args.no_graph:
         args.launch = 'eager'
@@ -517,8 +517,11 @@ def main():
     del eng
     torch.cuda.empty_cache()
     if args.through_trainer > 0 and world == 1 and args.workload in ('cfg2', 'cfg3'):
-        tt = measure_trainer(args, args.dtype, stamp, args.through_trainer, 3)
+        tt = measure_trainer(args, args.dtype, stamp, args.through_trainer, 6)      # six warm-up steps: the batch's row count varies, the allocator settles
         tt['vs_engine'] = round(tt['value'] / out['value'], 4)
+        # the trainer's CNN batch holds the DISTINCT images of a step (an image drawn as a negative that is also a positive's image goes
+        # through the CNN once), the engine's a fixed 2B rows: compare the CNN rows per second as well
+        tt['vs_engine_per_cnn_row'] = round((tt['cnn_rows_per_step'] / tt['ms_per_step']) / (out['config']['cnn_rows_per_step_per_gpu'] / out['ms_per_step']), 4)
         out['through_trainer'] = tt
         torch.cuda.empty_cache()
 

@@ -154,8 +154,13 @@ class ETHECExperiment(Experiment):
     def train_step(self, inputs, labels, level_labels):
         """finetuner.py:213-246 for one batch: forward, criterion, backward, (SUM all-reduce), Adam.  The criterion's
         mean is over the LOCAL batch, so under DP the summed gradient is divided by the world size."""
+        pend = self.__dict__.setdefault('_steps_in_flight', [])     # host at most two steps ahead (see JointEmbeddings.train_step)
+        if len(pend) >= 2:
+            pend.pop(0).synchronize()
         inputs = inputs.to(self.device, non_blocking=True).contiguous(memory_format=torch.channels_last)
         loss, outputs = self.fwd_bwd(inputs, level_labels.to(self.device), labels)
         self.reducer.finish()
         self.arena.adam_step(self.lr, grad_scale=1.0 / self.world)
+        if loss.is_cuda:
+            done = torch.cuda.Event(); done.record(); pend.append(done)
         return loss, outputs

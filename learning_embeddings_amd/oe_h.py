@@ -310,6 +310,7 @@ class _JointCriterionBase(torch.nn.Module):
                 slot[ix] = len(stack); stack.append(self.dataloader.get_image(self.mapping_from_ix_to_node[ix]))
         dev = _unwrap(model).embeddings.weight.device
         feats, image_proj = None, _lib.IMAGE_RAW
+        self.last_cnn_rows = len(stack)                                 # distinct images of the step = rows of the one CNN batch
         if stack:
             batch = torch.stack([s.to(dev, non_blocking=True) for s in stack])
             if self.use_CNN and hasattr(img_feat_net, 'forward_raw') and getattr(img_feat_net, 'K', None):

@@ -12,12 +12,14 @@ def main():
     ap.add_argument('--steps', type=int, default=12)
     ap.add_argument('--dtype', default='fp32')
     ap.add_argument('--trainer', action='store_true')
+    ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--side-priority', type=int, default=None)
     a = ap.parse_args()
     from learning_embeddings_amd import miopen_tuning
     miopen_tuning.setup()
     from learning_embeddings_amd.engine import StepEngine
-    eng = StepEngine('cfg3', dtype=a.dtype, use_graph=True)
+    eng = StepEngine('cfg3', dtype=a.dtype, use_graph=True, batch=a.batch)
+    print('rows per step', eng.n_rows, flush=True)
     if a.side_priority is not None and eng.overlap is not None:
         eng.overlap.side = torch.cuda.Stream(priority=a.side_priority)
     for _ in range(8):
