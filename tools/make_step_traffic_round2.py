@@ -22,7 +22,12 @@ for m in ('native', 'x3'):
     for k, v in F['bytes_per_step'].items(): f[fam(k)] += v
     for k, v in W['bytes_per_step'].items(): w[fam(k)] += v
     out[m] = {k: (2 * f[k] / 1e9, w[k] / 1e9) for k in set(f) | set(w)}
+# the kernel sources these counters belong to: bench.py quotes `traffic` from this file only while they are unchanged
+import hashlib
+CS = os.path.join(ROOT, 'learning_embeddings_amd', 'csrc')
+out['kernel_sources_sha256'] = {f: hashlib.sha256(open(os.path.join(CS, f), 'rb').read()).hexdigest() for f in ('conv_f32.hip', 'conv_f32x3.hip', 'conv_geo.h', 'bn.hip')}
 json.dump(out, open(os.path.join(ROOT, 'profiles', 'r02_step_traffic.json'), 'w'), indent=1)
+del out['kernel_sources_sha256']
 md = ['# HBM traffic of the whole fp32 bench step, all kernels (rocprofv3 PMC, round 2, MI355X)', '',
       '`bash tools/step_traffic_round2.sh` then `python tools/make_step_traffic_round2.py`: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes) over',
       '`python3 bench.py --steps 2 --warmup 1 --no-graph --secondary none --no-cpu-baseline --no-stress --through-trainer 0 --conv-f32 <mode>`, every kernel of the run summed per step',
