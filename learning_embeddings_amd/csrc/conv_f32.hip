@@ -541,6 +541,15 @@ extern "C" int lec_conv_f32_wgrad(const float* dy, const float* x, int N, int H,
     else if (Cout >= 256) { BM = 256; BN = 64; }
     else { BM = 64; BN = 64; WBK = 32; }
   }
+  // Gathered layers whose output channels are a multiple of 128: a 128 x 256 tile where it pays -- the gathered operand's decode, bounds
+  // tests, loads and LDS traffic are per B tile, so twice the rows halve them per MFMA (and with 128 output channels x is gathered once
+  // instead of twice).  Same box, 512 images: 3x3 128 -> 128 @28 1391 -> 1075 us, stride-2 @56 1398 -> 1078; 3x3 256 -> 256 @14 1240 -> 1216;
+  // strided 1x1 (downsample) 920 -> 870 / 898 -> 869; 3x3 512 -> 512 @7 1126 -> 1154 (worse: left on the 64-row tile).  223 VGPRs instead
+  // of 128: beside this variant no BatchNorm wave fits a SIMD, so the step gains less than the kernels (144.4 -> 144.0 ms).
+  // LEC_WGRAD_BM128 = 0: off, 2: every eligible layer.
+  static const int wg_bm128 = [] { const char* e = getenv("LEC_WGRAD_BM128"); return e ? atoi(e) : 1; }();
+  const bool big = !dense && Cout % 128 == 0 && (wg_bm128 == 2 || (wg_bm128 == 1 && (R * S == 1 || Cout <= 256)));
+  if (big) BM = 128;
   const int tiles = ((Cout + BM - 1) / BM) * ((g.Ng + BN - 1) / BN);
   const int nchunks = (g.Mpix + WBK - 1) / WBK;
   static const int wg_target = [] { const char* e = getenv("LEC_WGRAD_ITEMS"); const int v = e ? atoi(e) : 1024; return v > 0 ? v : 1024; }();
@@ -561,7 +570,8 @@ extern "C" int lec_conv_f32_wgrad(const float* dy, const float* x, int N, int H,
   const int total = 8 * ((tiles * split + 7) / 8);              // slots (see the kernel's slot -> item map)
   const dim3 grid(total < wg_cap ? total : wg_cap), blk(kCfThreads);
   hipStream_t st = (hipStream_t)stream;
-  if (!dense) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, false>), grid, blk, lds, st, dy, x, dw, g);
+  if (big) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 4, kWgBK, false>), grid, blk, lds, st, dy, x, dw, g);
+  else if (!dense) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, false>), grid, blk, lds, st, dy, x, dw, g);
   else if (BM == 64 && BN == 256) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, true>), grid, blk, lds, st, dy, x, dw, g);
   else if (BM == 128) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 2, kWgBK, true>), grid, blk, lds, st, dy, x, dw, g);
   else if (BM == 256) hipLaunchKernelGGL((conv_f32_wgrad_kernel<4, 1, 2, 2, kWgBK, true>), grid, blk, lds, st, dy, x, dw, g);

@@ -366,6 +366,21 @@ class StepEngine:
         self.prefetch.close()
         if WgradOverlap.instance is self.overlap:
             WgradOverlap.instance = None
+        _release_graphs(self)
+
+
+def _release_graphs(eng):
+    """Destroy an engine's captured graphs NOW (hipGraphExecDestroy, the graph's private memory pool), not whenever Python's cycle
+    collector gets to the engine: the next engine of the process (bench.py builds three in a row, the tests dozens) starts from a
+    clean runtime state and from freed HBM."""
+    import gc
+    if getattr(eng, 'hip_graph', None) is not None or getattr(eng, '_graph_saved', None) is not None:
+        torch.cuda.synchronize()
+    eng.hip_graph = None
+    if hasattr(eng, '_graph_saved'):
+        eng._graph_saved = None
+    eng.graph_out = None
+    gc.collect()
 
 
 class ClassifierEngine:
@@ -456,4 +471,4 @@ class ClassifierEngine:
         return loss
 
     def close(self):
-        pass
+        _release_graphs(self)

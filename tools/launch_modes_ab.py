@@ -14,6 +14,7 @@ def main():
     ap.add_argument('--trainer', action='store_true')
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--side-priority', type=int, default=None)
+    ap.add_argument('--main-high', action='store_true', help='run every step on a high-priority stream')
     a = ap.parse_args()
     from learning_embeddings_amd import miopen_tuning
     miopen_tuning.setup()
@@ -22,6 +23,10 @@ def main():
     print('rows per step', eng.n_rows, flush=True)
     if a.side_priority is not None and eng.overlap is not None:
         eng.overlap.side = torch.cuda.Stream(priority=a.side_priority)
+    if a.main_high:
+        hs = torch.cuda.Stream(priority=-1)
+        hs.wait_stream(torch.cuda.current_stream())
+        ctx = torch.cuda.stream(hs); ctx.__enter__()
     for _ in range(8):
         eng.step()
     torch.cuda.synchronize()
