@@ -196,6 +196,7 @@ def test_step_engine_hipgraph_replay_matches_eager_launches():
         eng.set_launch_mode(True); eng.step(); torch.cuda.synchronize()
         assert (eng.hip_graph is not None) == mode
         eng.close()
+        assert eng.hip_graph is None and eng._graph_saved is None and eng.graph_out is None      # close() destroys the graphs, not the GC later
     le, lg = runs[False][0], runs[True][0]
     assert all(np.array_equal(a, b) for a, b in zip(runs[False][1], runs[True][1]))
     assert np.abs(le - lg).max() <= 0.15 * np.abs(le).max()                 # two eager runs drift by ~5 % here on their own
@@ -216,6 +217,15 @@ def test_joint_embeddings_trainer_runs_and_learns(tmp_path):
                               batch_size=16, experiment_name='t', embedding_dim=10, neg_to_pos_ratio=5, image_fc7=None,
                               normalize=None, alpha=0.05, experiment_dir=str(tmp_path), n_epochs=2, eval_interval=1)
     assert len(tr.datasets['train']) == gd['G_train_tc'].size()
+    # train_step never synchronises by itself, but it lets the host run at most two steps ahead of the GPU (the allocator holds
+    # what the side stream touched until its events pass: unbounded run-ahead piled up one step of activations per step)
+    crit.set_dataloader(tr.datasets['train']); tr.model.train(); tr.img_feat_net.train()
+    it = iter(tr.dataloaders['train'])
+    for _ in range(5):
+        tr.train_step(next(it))
+        assert len(tr._steps_in_flight) <= 2
+    torch.cuda.synchronize()
+    assert all(e.query() for e in tr._steps_in_flight)
     tr.run_model()
     assert np.isfinite(tr.last_epoch_loss)
     n = tr.model.embeddings.weight.detach().norm(dim=1)
