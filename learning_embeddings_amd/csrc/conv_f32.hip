@@ -127,6 +127,9 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
   const bool dense_dst = g.dst_st == 1;                        // destination pixel index == m (forward, stride-1 data gradient)
   const int ntaps = g.na * g.nb;
 
+  // (Loading the next tile's first chunk before this tile's epilogue -- so that its latency and the acknowledgement of the epilogue's stores
+  // overlap -- was built and measured: forward 38.8 -> 38.9 ms, data gradient 37.4 -> 37.4 ms over the step's layers, same box.  The second
+  // workgroup of the CU already fills a tile's prologue.)
   for (int mt = blockIdx.x; mt < mtiles; mt += gridDim.x) {
     const int m0 = mt * BM;
     // rows of the A tile this thread stages (rowA + kCfRP u): byte offset of the row's source pixel at tap offset (0, 0) and
