@@ -4,7 +4,6 @@ OrderEmbedding.pass_samples :606-645."""
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _lib, ops
 from .hierarchy import NegativeGraph
@@ -28,9 +27,8 @@ class Embedder(nn.Module):
         return embeds
 
     def soft_clip(self, x):
-        shp = x.shape
-        x = x.view(-1, shp[-1])
-        return (F.normalize(x, dim=1) * (torch.norm(x, dim=1, keepdim=True) + self.K)).view(shp)
+        # order_embeddings.py:194-199: direction * (norm + K) -- the oe.py form of the soft clip, lec_image_softclip_fwd / _bwd
+        return ops.ImageSoftClipFn.apply(x, float(self.K), _lib.IMAGE_SOFTCLIP_K)
 
 
 class OrderEmbeddingLoss(torch.nn.Module):

@@ -795,3 +795,26 @@ def test_joint_loss_skips_node_codes_outside_the_tables():
     assert torch.equal(ep0, ep1)                         # positives untouched
     clean = [b for b in range(B) if b not in (1, 2, 5)]
     assert torch.equal(en0[clean], en1[clean])
+
+
+@pytest.mark.gpu
+def test_order_embeddings_embedder_soft_clip_runs_the_kernel_and_matches_the_oracle():
+    """order_embeddings.Embedder with K (order_embeddings.py:179-199; off in config 1): forward = direction * (norm + K) through
+    lec_image_softclip_fwd, its gradient through lec_image_softclip_bwd, against the oracle's restatement and autograd of the formula."""
+    from learning_embeddings_amd import order_embeddings as oe1
+    from learning_embeddings_amd.hierarchy import SyntheticLabelMap
+    torch.manual_seed(0)
+    lm = SyntheticLabelMap([2, 4, 8])
+    emb = oe1.Embedder(10, lm, K=3.0).to(DEV)
+    idx = torch.randint(0, lm.n_classes, (4, 7), device=DEV)
+    out = emb(idx)
+    W = emb.embeddings.weight.detach()
+    ref = O.soft_clip_add(W.cpu().numpy()[idx.cpu().numpy().reshape(-1)], 3.0).reshape(4, 7, 10)
+    assert np.abs(out.detach().cpu().numpy() - ref).max() < 5e-6
+    g = torch.randn_like(out)
+    out.backward(g)
+    x = W[idx].clone().requires_grad_(True)
+    y = torch.nn.functional.normalize(x, dim=-1) * (x.norm(dim=-1, keepdim=True) + 3.0)
+    y.backward(g)
+    gW = torch.zeros_like(W).index_add_(0, idx.reshape(-1), x.grad.reshape(-1, 10))
+    assert (emb.embeddings.weight.grad - gW).abs().max().item() < 5e-6
