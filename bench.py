@@ -289,12 +289,32 @@ def measure_classifier(args, dtype, rank, world, stamp):
     import torch.distributed as dist
     from learning_embeddings_amd.engine import ClassifierEngine
     from learning_embeddings_amd.resnet import conv_macs
-    eng = ClassifierEngine(args.workload, dtype=dtype, batch=args.batch, use_graph=not args.no_graph, overlap_wgrad=not args.no_overlap_wgrad)
+    eng = ClassifierEngine(args.workload, dtype=dtype, batch=args.batch, use_graph=args.launch != 'eager', overlap_wgrad=not args.no_overlap_wgrad)
     stamp('%s: classifier engine built' % dtype)
     for _ in range(max(args.warmup, 4)):
         eng.step()
     while eng.use_graph and eng.hip_graph is None and eng.graph_error is None:
         eng.step()
+    launch_probe = None
+    if args.launch == 'auto' and eng.hip_graph is not None:      # as in measure(): replay against eager launches on this box, keep the faster
+        def block(graph, n=6):
+            eng.set_launch_mode(graph)
+            for _ in range(2):
+                eng.step()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(); t_ = time.perf_counter()
+            for _ in range(n):
+                eng.step()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t_) / n * 1e3
+        g_ms = block(True); e_ms = block(False)
+        eager_wins = torch.tensor([1.0 if e_ms < 0.985 * g_ms else 0.0], device=eng.device)
+        if world > 1:
+            dist.all_reduce(eager_wins, op=dist.ReduceOp.MIN)
+        eng.set_launch_mode(not bool(eager_wins.item()))
+        launch_probe = {'hipgraph_ms_per_step': round(g_ms, 2), 'eager_ms_per_step': round(e_ms, 2), 'chosen': 'eager' if eager_wins.item() else 'hipgraph'}
+        stamp('%s: launch-mode probe: hipGraph %.2f ms/step, eager %.2f ms/step -> %s' % (dtype, g_ms, e_ms, launch_probe['chosen']))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -316,7 +336,9 @@ def measure_classifier(args, dtype, rank, world, stamp):
     peak_tf = 157.3 if f32 else 2500.0
     step_s = dt / args.steps
     return {'value': round(world * eng.B * args.steps / dt, 2), 'ms_per_step': round(step_s * 1e3, 3), 'dtype': 'f32' if f32 else dtype,
-            'launch_mode': 'hipgraph' if eng.hip_graph is not None else 'eager', 'mean_loss': round(float(eng.loss_acc.item()) / max(eng.step_no, 1), 4),
+            'launch_mode': ('hipgraph' if eng.hip_graph is not None else 'eager')
+                           + (' -- the faster of the two in the warm-up probe: hipGraph %.2f, eager %.2f ms/step' % (launch_probe['hipgraph_ms_per_step'], launch_probe['eager_ms_per_step']) if launch_probe else ''),
+            'mean_loss': round(float(eng.loss_acc.item()) / max(eng.step_no, 1), 4),
             'B': eng.B, 'arch': eng.arch, 'hw': eng.hw, 'n_classes': eng.labelmap.n_classes,
             'hbm_peak_allocated_gb': round(torch.cuda.max_memory_allocated() / 1e9, 1),
             'roofline': {'kernel': '%s fwd+bwd + MultiLevelCELoss + Adam (whole step; analytic conv/fc flops / step time)' % eng.arch, 'bound': 'mfma',

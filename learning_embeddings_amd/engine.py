@@ -442,7 +442,8 @@ class ClassifierEngine:
         self.pin[slot].numpy()[:] = rs.permutation(self.P)[:self.B] if self.P > self.B else rs.permutation(self.P)
         self.idx_dev.copy_(self.pin[slot], non_blocking=True)
         self.pin_ev[slot] = torch.cuda.Event(); self.pin_ev[slot].record()
-        if self.use_graph and self.hip_graph is None and self.graph_error is None and self.step_no >= self.graph_after:
+        if (self.use_graph and self.hip_graph is None and getattr(self, '_graph_saved', None) is None and self.graph_error is None
+                and self.step_no >= self.graph_after):
             try:
                 torch.cuda.synchronize()
                 self.exp.reducer.live = False
@@ -469,6 +470,16 @@ class ClassifierEngine:
         self.step_no += 1
         self.last = (loss, outputs)
         return loss
+
+    def set_launch_mode(self, graph):
+        """Replay the captured graph (True) or launch eagerly (False); same contract as StepEngine.set_launch_mode."""
+        saved = getattr(self, '_graph_saved', None)
+        if graph and saved is not None:
+            self.hip_graph, self._graph_saved = saved, None
+            self.exp.reducer.live = False
+        elif not graph and self.hip_graph is not None:
+            self._graph_saved, self.hip_graph = self.hip_graph, None
+            self.exp.reducer.live = True
 
     def close(self):
         _release_graphs(self)
