@@ -469,6 +469,7 @@ def main():
         sec = measure_classifier(args, args.secondary, rank, world, stamp) if args.secondary not in ('none', args.dtype) else None
         if dist.is_initialized():
             dist.barrier(); dist.destroy_process_group()
+        sys.stdout.flush()                                      # python-level banners buffered while fd 1 pointed at stderr: out with them first
         os.dup2(saved_stdout_fd, 1); os.close(saved_stdout_fd)
         if rank == 0:
             out = {'metric': 'images/sec (CNN + multi-level cross-entropy step)', 'value': res['value'], 'unit': 'images/sec', 'n_gpus': world,
