@@ -548,7 +548,7 @@ def main():
     eng.close()
     del eng
     torch.cuda.empty_cache()
-    if args.through_trainer > 0 and world == 1 and args.workload in ('cfg2', 'cfg3'):
+    if args.through_trainer > 0 and world == 1 and args.workload in ('cfg2', 'cfg3', 'cfg3_ethec'):
         tt = measure_trainer(args, args.dtype, stamp, args.through_trainer, 6)      # six warm-up steps: the batch's row count varies, the allocator settles
         tt['vs_engine'] = round(tt['value'] / out['value'], 4)
         # the trainer's CNN batch holds the DISTINCT images of a step (an image drawn as a negative that is also a positive's image goes
@@ -557,7 +557,7 @@ def main():
         out['through_trainer'] = tt
         torch.cuda.empty_cache()
 
-    if args.dtype == 'fp32' and args.conv_f32 == 'native' and args.secondary != 'none' and args.workload in ('cfg2', 'cfg3'):
+    if args.dtype == 'fp32' and args.conv_f32 == 'native' and args.secondary != 'none' and args.workload in ('cfg2', 'cfg3', 'cfg3_ethec'):
         # the same fp32 step with the convolutions' fp32 products computed on the bf16 matrix cores (csrc/conv_f32x3.hip)
         torch.cuda.reset_peak_memory_stats()
         _resnet.F32_MODE = 'x3'

@@ -406,6 +406,16 @@ def test_config3_benchmarked_workload_full_batch_256_matches_oracle(dtype, graph
     eng.close()
 
 
+def test_config3_over_the_ethec_label_dag_full_batch_256_matches_oracle():
+    """BASELINE.json's configs[2] names ETHEC; SURVEY.md 8(d) gives the config its own 2 000-node hierarchy S3 (the bench line).  The same
+    ResNet-50 / B = 256 / K = 5 step over the real ETHEC DAG (723 labels, fixture F9), fp32, eager launches (the mode the bench times):
+    negatives bit-equal to the reference's stream, loss / energies / table update against the oracle."""
+    eng = StepEngine('cfg3_ethec', n_images=4096, dtype='fp32', use_graph=False)
+    assert eng.B == 256 and eng.n_rows == 512 and eng.N == 723 and eng.arch == 'resnet50'
+    _engine_vs_oracle(eng, 4096, steps=2)
+    eng.close()
+
+
 def test_chunked_cnn_rows_step_equals_unchunked_step_up_to_batchnorm_batches():
     """engine cnn_chunk: the step's CNN rows pushed through the backbone a chunk at a time (forward without saved activations, the
     loss on all outputs, re-forward + backward per chunk).  With ONE chunk covering every row the result must equal the plain step
