@@ -98,8 +98,19 @@ __device__ __forceinline__ void split4(const f32x4v x, u32x2v& h, u32x2v& m, u32
   split_pair(x2, x3, a, b, c); h[1] = a; m[1] = b; l[1] = c;
 }
 
-// the six products of one 32 x 32 x 16 step, small terms first
+// LEC_X3_NPROD: 6 (default) drops m l, l m (<= 2^-24 of the product each, truncated pieces) and l l (2^-32); 8 keeps the first two, so that
+// every dropped term is below 2^-32 -- far under one fp32 rounding (A/B builds: make EXTRA=-DLEC_X3_NPROD=8).
+#ifndef LEC_X3_NPROD
+#define LEC_X3_NPROD 6
+#endif
+constexpr int kX3NP = LEC_X3_NPROD;
+static_assert(kX3NP == 6 || kX3NP == 8, "six or eight products");
+// the products of one 32 x 32 x 16 step, small terms first
 __device__ __forceinline__ f32x16 mma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
+  if (kX3NP == 8) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[1], c, 0, 0, 0);
+  }
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
@@ -180,9 +191,10 @@ __device__ __forceinline__ void x3_consumer_loop(const char* __restrict__ smem, 
     constexpr int RS = J & 1, MS = RS ^ 1;                      // register sets: read into RS, multiply from MS
     const char* sA = chunk_base(j_c);
     if (!(LEC_X3_DBG & 8)) x3_read_frags<BM, BN, TM, TN>(sA, sA + SA, wm0, wn0, lane, fa[RS], fb[RS]);
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};         // small terms first (as mma6)
+    constexpr int PA[8] = {1, 2, 2, 0, 1, 1, 0, 0}, PB[8] = {2, 1, 0, 2, 1, 0, 1, 0};   // small terms first (as mma6); six products: from index 2
+    constexpr int P0 = 8 - kX3NP;
 #pragma unroll
-    for (int p = 0; p < 5; ++p)
+    for (int p = P0; p < 7; ++p)
 #pragma unroll
       for (int it = 0; it < TM; ++it)
 #pragma unroll
@@ -193,7 +205,7 @@ __device__ __forceinline__ void x3_consumer_loop(const char* __restrict__ smem, 
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 5 * TM * TN - 3 * (TM + TN), 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, (kX3NP - 1) * TM * TN - 3 * (TM + TN), 0);
     if (J & 1) {
       __builtin_amdgcn_sched_barrier(0);
       x3_barrier();
@@ -203,7 +215,7 @@ __device__ __forceinline__ void x3_consumer_loop(const char* __restrict__ smem, 
     for (int it = 0; it < TM; ++it)
 #pragma unroll
       for (int jt = 0; jt < TN; ++jt)
-        if (!(LEC_X3_DBG & 4)) acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[MS][it][PA[5]], fb[MS][jt][PB[5]], acc[it][jt], 0, 0, 0);
+        if (!(LEC_X3_DBG & 4)) acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[MS][it][PA[7]], fb[MS][jt][PB[7]], acc[it][jt], 0, 0, 0);
     tile_end();
   };
   using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
