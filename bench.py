@@ -570,7 +570,8 @@ def main():
                 'note': 'Same workload, same fp32 tensors; each fp32 product of the convolutions (forward, data gradient, weight gradient of layers 2-4) is computed as '
                         'six exact bf16 x bf16 products on the matrix cores (operands cut into three bf16 pieces, x = h + m + l exactly), fp32 accumulation: '
                         'error against float64 at the level of the exact-fp32 kernels (tests/test_fp32_gpu.py: equal on integer operands up to 10 bits; '
-                        'on random operands within 2x of the f32-MFMA / MIOpen fp32 kernels, forward and data gradient at or below). Not IEEE fp32 '
+                        'on random operands within 2x of the f32-MFMA / MIOpen fp32 kernels, forward and data gradient at or below; a build that keeps eight of the nine partial '
+                        'products -- every dropped term below 2^-32 of the product -- has the same error in every digit: the error is the fp32 accumulation\'s). Not IEEE fp32 '
                         'instruction by instruction, so it is NOT the headline; enable with --conv-f32 x3 or LEC_CONV_F32_MODE=x3.',
                 'value': res3['value'], 'unit': 'images/sec', 'ms_per_step': res3['ms_per_step'], 'dtype': 'f32 (3 x bf16 split products, fp32 accumulate)',
                 'vs_headline': round(res3['value'] / out['value'], 4), 'mean_loss': res3['mean_loss'],
