@@ -227,7 +227,7 @@ def measure(args, dtype, rank, world, stamp, primary):
         # (The stem and layer1's weight gradients still run the f32-input kernels; their launches are in the same sum.)
         cs = phases['conv_f32'] * 1e-3
         roof_conv = {'kernel': 'lec::conv_f32x3_act_kernel / conv_f32x3_wgrad_kernel (csrc/conv_f32x3.hip: fp32 products as six exact bf16 products on the matrix cores) '
-                               '+ the f32-input kernels of the layers it does not serve: all %d launches of the step' % int(eng.conv_launches_per_step),
+                               '+ the f32-input kernels of the layers it does not serve: all %d launch groups of the step (one per convolution call: a strided data gradient is up to four kernels, so rocprof counts more kernels for the same total time)' % int(eng.conv_launches_per_step),
                      'bound': 'mfma', 'achieved': round(6 * eng.conv_flops_per_step / cs / 1e12, 2), 'peak': 2500.0, 'unit': 'TFLOP/s',
                      'frac': round(6 * eng.conv_flops_per_step / cs / 1e12 / 2500.0, 4), 'traffic': None,
                      'executed_flops_per_step': int(6 * eng.conv_flops_per_step), 'alg_flops_per_step': int(eng.conv_flops_per_step),
@@ -239,7 +239,7 @@ def measure(args, dtype, rank, world, stamp, primary):
                                      'frac': round(6 * eng.conv_flops_per_step / conv_isolated / 1e9 / 2500.0, 4), 'alg_tflops': round(eng.conv_flops_per_step / conv_isolated / 1e9, 2)}
     elif 'conv_f32' in phases and getattr(eng, 'conv_flops_per_step', 0):
         cs = phases['conv_f32'] * 1e-3
-        roof_conv = {'kernel': 'lec::conv_f32_act_kernel / conv_f32_wgrad_kernel (csrc/conv_f32.hip: f32-MFMA implicit-GEMM forward, data gradient, weight gradient): all %d launches of the step'
+        roof_conv = {'kernel': 'lec::conv_f32_act_kernel / conv_f32_wgrad_kernel (csrc/conv_f32.hip: f32-MFMA implicit-GEMM forward, data gradient, weight gradient): all %d launch groups of the step (one per convolution call: a strided data gradient is up to four kernels, so rocprof counts more kernels for the same total time)'
                                % int(eng.conv_launches_per_step),
                      'bound': 'mfma', 'achieved': round(eng.conv_flops_per_step / cs / 1e12, 2), 'peak': 157.3, 'unit': 'TFLOP/s',
                      'frac': round(eng.conv_flops_per_step / cs / 1e12 / 157.3, 4), 'traffic': None,
