@@ -102,22 +102,25 @@ def measure(args, dtype, rank, world, stamp, primary):
         # faster for the timed region; every rank takes the same decision.
         def block(graph, n=6):
             eng.set_launch_mode(graph)
-            for _ in range(2):
+            for _ in range(2 if graph else 6):                  # eager: until the allocator holds the activations of the steps in flight
                 eng.step()
             if world > 1:
                 dist.barrier()
             torch.cuda.synchronize(); t_ = time.perf_counter()
+            eng.host_wait_s = 0.0; busy = 0.0
             for _ in range(n):
-                eng.step()
+                th_ = time.perf_counter(); eng.step(); busy += time.perf_counter() - th_
             torch.cuda.synchronize()
-            return (time.perf_counter() - t_) / n * 1e3
-        g_ms = block(True); e_ms = block(False)
-        eager_wins = torch.tensor([1.0 if e_ms < 0.985 * g_ms else 0.0], device=dev)
+            return (time.perf_counter() - t_) / n * 1e3, (busy - eng.host_wait_s) / n * 1e3
+        (g_ms, _), (e_ms, e_host_ms) = block(True), block(False)
+        # eager only with headroom: the host must enqueue a step in well under the time the GPU takes to run it, or the first hiccup shows
+        eager_wins = torch.tensor([1.0 if (e_ms < 0.985 * g_ms and e_host_ms < 0.6 * e_ms) else 0.0], device=dev)
         if world > 1:
             dist.all_reduce(eager_wins, op=dist.ReduceOp.MIN)
         eng.set_launch_mode(not bool(eager_wins.item()))
-        launch_probe = {'hipgraph_ms_per_step': round(g_ms, 2), 'eager_ms_per_step': round(e_ms, 2), 'chosen': 'eager' if eager_wins.item() else 'hipgraph'}
-        stamp('%s: launch-mode probe: hipGraph %.2f ms/step, eager %.2f ms/step -> %s' % (dtype, g_ms, e_ms, launch_probe['chosen']))
+        launch_probe = {'hipgraph_ms_per_step': round(g_ms, 2), 'eager_ms_per_step': round(e_ms, 2), 'eager_host_enqueue_ms_per_step': round(e_host_ms, 2),
+                        'chosen': 'eager' if eager_wins.item() else 'hipgraph'}
+        stamp('%s: launch-mode probe: hipGraph %.2f ms/step, eager %.2f ms/step (host enqueue %.1f ms/step) -> %s' % (dtype, g_ms, e_ms, e_host_ms, launch_probe['chosen']))
     stamp('%s: launch mode: %s' % (dtype, 'hipGraph replay' if eng.hip_graph is not None else 'eager'))
     eng.enable_timers()
     auto_eager = launch_probe is not None and launch_probe['chosen'] == 'eager'
