@@ -113,14 +113,16 @@ def measure(args, dtype, rank, world, stamp, primary):
             torch.cuda.synchronize()
             return (time.perf_counter() - t_) / n * 1e3, (busy - eng.host_wait_s) / n * 1e3
         (g_ms, _), (e_ms, e_host_ms) = block(True), block(False)
-        # eager only with headroom: the host must enqueue a step in well under the time the GPU takes to run it, or the first hiccup shows
-        eager_wins = torch.tensor([1.0 if (e_ms < 0.985 * g_ms and e_host_ms < 0.6 * e_ms) else 0.0], device=dev)
+        # (e_host_ms -- wall time inside step() minus the counted run-ahead waits -- is reported, not used: it also holds the caching
+        # allocator's stalls on blocks the side stream still owns, 18 ms in one run and 127 in the next on the same kind of box,
+        # while the step times of both modes repeat to 1 %.  A host too slow for eager launches shows in e_ms itself.)
+        eager_wins = torch.tensor([1.0 if e_ms < 0.985 * g_ms else 0.0], device=dev)
         if world > 1:
             dist.all_reduce(eager_wins, op=dist.ReduceOp.MIN)
         eng.set_launch_mode(not bool(eager_wins.item()))
-        launch_probe = {'hipgraph_ms_per_step': round(g_ms, 2), 'eager_ms_per_step': round(e_ms, 2), 'eager_host_enqueue_ms_per_step': round(e_host_ms, 2),
+        launch_probe = {'hipgraph_ms_per_step': round(g_ms, 2), 'eager_ms_per_step': round(e_ms, 2), 'eager_host_wall_in_step_ms': round(e_host_ms, 2),
                         'chosen': 'eager' if eager_wins.item() else 'hipgraph'}
-        stamp('%s: launch-mode probe: hipGraph %.2f ms/step, eager %.2f ms/step (host enqueue %.1f ms/step) -> %s' % (dtype, g_ms, e_ms, e_host_ms, launch_probe['chosen']))
+        stamp('%s: launch-mode probe: hipGraph %.2f ms/step, eager %.2f ms/step (host wall time inside step(), waits excluded: %.1f ms) -> %s' % (dtype, g_ms, e_ms, e_host_ms, launch_probe['chosen']))
     stamp('%s: launch mode: %s' % (dtype, 'hipGraph replay' if eng.hip_graph is not None else 'eager'))
     eng.enable_timers()
     auto_eager = launch_probe is not None and launch_probe['chosen'] == 'eager'
