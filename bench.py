@@ -102,7 +102,8 @@ def measure(args, dtype, rank, world, stamp, primary):
         # faster for the timed region; every rank takes the same decision.
         def block(graph, n=6):
             eng.set_launch_mode(graph)
-            for _ in range(2 if graph else 6):                  # eager: until the allocator holds the activations of the steps in flight
+            for _ in range(2 if graph else 12):                 # eager: until the allocator holds the activations of the steps in flight (the first
+                                                                # eager steps after the capture run 2 - 3 % slower: hipMalloc under a busy GPU)
                 eng.step()
             if world > 1:
                 dist.barrier()

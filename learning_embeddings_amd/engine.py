@@ -146,6 +146,7 @@ class StepEngine:
         self.pin_ev = [None, None]
         self.step_no = 0
         self.host_wait_s = 0.0                       # host time spent waiting for the GPU (run-ahead bound), for bench.py
+        self._in_flight = []                         # completion events of the steps the host has enqueued and the GPU has not finished
         self.loss_acc = torch.zeros((), device=self.device)
         self.prefetch = parallel.NegativePrefetcher(self.graph, self.positives, K, mode=sampler_mode)
         self.timers = None
@@ -189,6 +190,10 @@ class StepEngine:
         if self.pin_ev[slot] is not None:
             t_w = time.perf_counter()
             self.pin_ev[slot].synchronize()          # the H2D copies of step s-2 have left this pinned buffer (also bounds run-ahead)
+            self.host_wait_s += time.perf_counter() - t_w
+        if len(self._in_flight) >= 2:
+            t_w = time.perf_counter()
+            self._in_flight.pop(0).synchronize()
             self.host_wait_s += time.perf_counter() - t_w
         pin = self.pin[slot]
         # CNN batch rows: [0, B) the positives' images; row B + b*cnt + i the image drawn as negative in pass img_passes[i]
@@ -239,6 +244,9 @@ class StepEngine:
         self.loss_acc += loss[0]
         self.step_no += 1
         self.last = (loss, e_pos, e_neg, frm, to, neg)
+        # at most two whole steps in flight (the pinned-buffer wait above bounds the run-ahead by the START of step s - 2 only): what the side
+        # stream has touched returns to the allocator when its events pass, so every extra step of run-ahead holds one more step of activations
+        done = torch.cuda.Event(); done.record(); self._in_flight.append(done)
         return loss
 
     def _core_chunked(self, ev=None):
