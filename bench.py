@@ -20,6 +20,35 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def self_launch(n, script=None, argv=None, extra_env=None):
+    """`python bench.py --gpus N` with no torchrun environment: start the N ranks ourselves, the way the reference goes multi-GPU
+    from one plain command (oe_h.py:301,1434: nn.DataParallel inside `python oe_h.py ...`).  The caller has made NO GPU call yet (this
+    runs before torch / the HIP library are even imported): the ranks are CHILD processes of `python -m torch.distributed.run`, never
+    an exec of a process that touched the GPU.  Rank 0's single JSON line reaches stdout through the inherited descriptor; the exit
+    code is the launcher's (non-zero if any rank failed)."""
+    import socket, subprocess
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0)); port = s_.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.update(extra_env or {})
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    if 'LEC_DIST_BACKEND' not in env and not env.get('LEC_BENCH_NO_GPU_PROBE'):
+        # fewer GPUs on the box than ranks asked for (a 1-GPU test box): RCCL refuses two ranks on one device, gloo reduces device tensors
+        try:
+            import torch
+            n_dev = torch.cuda.device_count()                   # counting devices does not initialise the GPU
+        except Exception:                                       # noqa: BLE001
+            n_dev = n
+        if 0 < n_dev < n:
+            env['LEC_DIST_BACKEND'] = 'gloo'
+            print('[bench] %d ranks on %d GPU(s): ranks share devices, gradient exchange over gloo (LEC_DIST_BACKEND=gloo)' % (n, n_dev), file=sys.stderr, flush=True)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), script or os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    print('[bench] starting %d ranks: %s' % (n, ' '.join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def cone_alg_bytes(B, K, D):
     """fwd+bwd algorithmic bytes per positive, rows de-duplicated inside a group, fp32."""
     return B * ((2 + 2 * K) * (2 * D * 4 + 4 * D + 4) + (1 + 2 * K) * 8)
@@ -148,13 +177,23 @@ def measure(args, dtype, rank, world, stamp, primary):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
     stamp('%s: timed steps done' % dtype)
-    if args.check_replicas and world > 1:
+    replicas_identical = None
+    if world > 1 and not args.no_check_replicas:
+        replicas_identical = True
         for name, t in (('label table', eng.table), ('cnn arena', eng.arena.data)):
             ref = t.clone(); dist.broadcast(ref, 0)
             same = torch.tensor([float(torch.equal(ref, t))], device=dev); dist.all_reduce(same, op=dist.ReduceOp.MIN)
             if rank == 0:
                 print('[bench] replicas identical (%s): %s' % (name, bool(same.item())), file=sys.stderr)
             assert same.item() == 1.0, 'replicas diverged: ' + name
+    # the gradient exchange as it ran: the group's size proven by a collective (every rank adds 1), and each bucket's all-reduce alone
+    dp_info = None
+    if eng.reducer.enabled:
+        one = torch.ones(1, device=dev); dist.all_reduce(one)
+        dp_info = {'rccl_ranks': int(one.item()), 'world_size': dist.get_world_size(), 'backend': dist.get_backend(),
+                   'exchange': ('liblecone RCCL layer (lec_dp_allreduce_sum), captured into the step graph' if eng.reducer.comm is not None
+                                else 'torch.distributed all-reduce: per-bucket from backward hooks (eager launches) / after the replay (hipGraph)'),
+                   'buckets': eng.reducer.time_buckets(), 'replicas_identical_after_run': replicas_identical}
     graph_mode = eng.hip_graph is not None
     if graph_mode:
         # A replayed graph cannot carry timing events, so the per-kernel durations behind `roofline` come from eager
@@ -285,7 +324,7 @@ def measure(args, dtype, rank, world, stamp, primary):
            'phases_ms': dict({('eager_probe_' + k if graph_mode and k in ('cnn_fwd', 'cone_loss', 'cnn_bwd', 'allreduce_wait', 'fused_bn', 'conv_f32') else k): round(v, 3)
                               for k, v in phases.items()}, host_enqueue=round(host_busy_s / args.steps * 1e3, 3)),
            'roofline_cnn': roof_cnn, 'roofline_bn': roof_bn, 'roofline_conv': roof_conv,
-           'allreduce_ms': round(phases.get('allreduce', phases.get('allreduce_wait', 0.0)), 3)}
+           'allreduce_ms': round(phases.get('allreduce', phases.get('allreduce_wait', 0.0)), 3), 'data_parallel': dp_info}
     return res, eng
 
 
@@ -430,7 +469,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stress', action='store_true')
     ap.add_argument('--no-overlap-wgrad', action='store_true', help='keep the conv weight-gradient kernels on the main stream (default: second HIP stream)')
-    ap.add_argument('--check-replicas', action='store_true', help='after the run, assert that every rank holds identical parameters')
+    ap.add_argument('--check-replicas', action='store_true', help='(default at N > 1) after the run, assert that every rank holds identical parameters')
+    ap.add_argument('--no-check-replicas', action='store_true', help='skip the replica comparison at N > 1')
     ap.add_argument('--launch', default='auto', choices=['auto', 'graph', 'eager'],
                     help='how the kernels of forward+loss+backward reach the GPU: graph = replay the captured hipGraph; eager = launch each one; '
                          'auto (default) = probe both on this box during warm-up and keep the faster for the timed steps')
@@ -440,6 +480,8 @@ def main():
     args = ap.parse_args()
     if args.no_graph:
         args.launch = 'eager'
+    if args.gpus > 1 and 'LOCAL_RANK' not in os.environ and int(os.environ.get('WORLD_SIZE', '1')) == 1:
+        sys.exit(self_launch(args.gpus))                        # nothing has touched the GPU yet
     from learning_embeddings_amd import resnet as _resnet
     _resnet.F32_MODE = args.conv_f32
 
@@ -524,7 +566,8 @@ def main():
                # `roofline`: the kernel family that dominates the step's time at this precision; the others ride along
                'roofline': dominant, 'roofline_conv': res['roofline_conv'], 'roofline_bn': res['roofline_bn'], 'roofline_cone': roof_cone,
                'roofline_cnn': res['roofline_cnn'],
-               'sampler_us_per_negative': round(sampler_us, 4), 'allreduce_ms': res['allreduce_ms']}
+               'sampler_us_per_negative': round(sampler_us, 4), 'allreduce_ms': res['allreduce_ms'], 'data_parallel': res['data_parallel'],
+               'rccl_ranks': (res['data_parallel'] or {}).get('rccl_ranks', 1)}
         if not args.no_stress:
             # the loss kernel where it IS bandwidth-bound: config 5's label-embedding stress shape (K=256) and a D=128 table
             sys.path.insert(0, os.path.join(ROOT, 'tools'))

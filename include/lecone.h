@@ -197,7 +197,8 @@ int  lec_sampler_tc_export(const lec_sampler* s, int64_t* ptr, int32_t* adj);
  *     nn.DataParallel (oe_h.py:301,1434,1439; ethec_experiments.py:240: parameter broadcast every forward + gather + reduce-add on
  *     device 0) by one process per GPU and a SUM all-reduce of the flat gradient arena (the loss is a plain sum over pairs,
  *     oe_h.py:843-846).  lec_dp_unique_id: rank 0 draws the 128-byte id and hands it to the other ranks (any side channel: a file,
- *     a TCP store); lec_dp_init: every rank joins, bound to GPU `device`; lec_dp_allreduce_sum: in place over `count` elements of
+ *     a TCP store); lec_dp_init: every rank joins, bound to GPU `device` (the caller's current HIP device is left as it was);
+ *     lec_dp_allreduce_sum: in place over `count` elements of
  *     buf (dtype 0 = fp32, 1 = bf16), asynchronous on `stream`; call it per bucket of the arena as backward produces it.
  * ------------------------------------------------------------------------------------------------------------- */
 typedef struct lec_dp lec_dp;
@@ -211,10 +212,11 @@ void lec_dp_destroy(lec_dp* comm);
  *     (network/loss.py:29-38) and its autograd:  loss = mean_b sum_l w_l CE(logits[b, s_l:e_l], labels[b, l]).
  *     logits [B, C] (ld), level_labels [B, L] int64, level_sizes [L] (sum = C), level_weights [L] or NULL.
  *     glogits [B, C] (ld) is overwritten with d loss / d logits (pass NULL for forward only).
- *     level_sizes / level_weights are HOST arrays (L <= 16); workspace: >= 256 + 4*2048 bytes, zeroed once (as above).
+ *     level_sizes / level_weights are HOST arrays (L <= 16); class_weights: DEVICE array [C] of per-class weights (loss.py:16-25:
+ *     the sample's term is scaled by its target class's weight) or NULL; workspace: >= 256 + 4*2048 bytes, zeroed once (as above).
  * ------------------------------------------------------------------------------------------------------------- */
 int lec_multilevel_ce_fwd_bwd(const float* logits, int64_t ld, const int64_t* level_labels, int B, int C,
-                              const int32_t* level_sizes, const float* level_weights, int L,
+                              const int32_t* level_sizes, const float* level_weights, const float* class_weights, int L,
                               float* loss, float* glogits, void* workspace, int64_t workspace_bytes,
                               lec_stream_t stream);
 

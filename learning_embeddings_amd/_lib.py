@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LEC_LIB_PATH') or os.path.join(_HERE, 'liblecone.so')     # LEC_LIB_PATH: A/B builds of the same ABI
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 OK, E_ARG, E_HIP, E_EMPTY, E_STATE = 0, -1, -2, -3, -4
 ENERGY_HYP_CONE, ENERGY_ORDER, ENERGY_EUC_CONE = 0, 1, 2
@@ -69,7 +69,7 @@ def _load():
         'lec_dp_init': (i32, [C.POINTER(p), i32, i32, p, i32]),
         'lec_dp_allreduce_sum': (i32, [p, p, i64, i32, p]),
         'lec_dp_destroy': (None, [p]),
-        'lec_multilevel_ce_fwd_bwd': (i32, [p, i64, p, i32, i32, p, p, i32, p, p, p, i64, p]),
+        'lec_multilevel_ce_fwd_bwd': (i32, [p, i64, p, i32, i32, p, p, p, i32, p, p, p, i64, p]),
         'lec_bn_workspace_bytes': (i64, [i32]),
         'lec_bn_fwd': (i32, [p, p, i64, i32, p, p, f32, f32, p, p, i32, p, p, p, i32, p, p, i64, p]),
         'lec_bn_bwd': (i32, [p, p, p, p, p, i64, i32, p, p, p, p, p, p, p, i32, p, i64, p]),

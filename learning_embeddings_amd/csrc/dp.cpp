@@ -32,11 +32,8 @@ struct Rccl {
   const char* (*GetErrorString)(int) = nullptr;
   bool ok = false;
 };
-static Rccl& rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (tried) return r;
-  tried = true;
+static Rccl load_rccl() {
+  Rccl r;
   void* h = nullptr;
   const char* names[] = {"librccl.so", "librccl.so.1"};
   for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // the copy torch mapped
@@ -48,6 +45,10 @@ static Rccl& rccl() {
   r.AllReduce = (int (*)(const void*, void*, size_t, int, int, NcclComm, hipStream_t))dlsym(h, "ncclAllReduce");
   r.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
   r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce;
+  return r;
+}
+static Rccl& rccl() {
+  static Rccl r = load_rccl();            // function-local static: initialised exactly once, thread-safe (C++11)
   return r;
 }
 static int rccl_fail(int rc, const char* what) {
@@ -75,11 +76,16 @@ extern "C" int lec_dp_init(lec_dp** out, int rank, int world, const void* unique
   if (!out || !unique_id || world < 1 || rank < 0 || rank >= world || device < 0) { set_error("dp_init: bad arguments (rank %d of %d, device %d)", rank, world, device); return LEC_E_ARG; }
   Rccl& r = rccl();
   if (!r.ok) { set_error("dp_init: librccl.so not found"); return LEC_E_STATE; }
+  // ncclCommInitRank binds the communicator to the CURRENT device: switch to `device` for the call and put the caller's device back
+  int prev = -1;
+  if (hipError_t e = hipGetDevice(&prev)) return hip_fail(e, "dp_init: hipGetDevice");
   if (hipError_t e = hipSetDevice(device)) return hip_fail(e, "dp_init: hipSetDevice");
   lec_dp* d = new (std::nothrow) lec_dp();
-  if (!d) { set_error("dp_init: out of memory"); return LEC_E_STATE; }
+  if (!d) { (void)hipSetDevice(prev); set_error("dp_init: out of memory"); return LEC_E_STATE; }
   NcclUniqueId id; std::memcpy(&id, unique_id, sizeof(id));
-  if (int rc = r.CommInitRank(&d->comm, world, id, rank)) { delete d; return rccl_fail(rc, "ncclCommInitRank"); }
+  const int rc = r.CommInitRank(&d->comm, world, id, rank);
+  (void)hipSetDevice(prev);
+  if (rc) { delete d; return rccl_fail(rc, "ncclCommInitRank"); }
   d->rank = rank; d->world = world; d->device = device;
   *out = d;
   return LEC_OK;

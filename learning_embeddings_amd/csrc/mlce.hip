@@ -1,5 +1,7 @@
 // Multi-level cross-entropy, forward + backward fused (network/loss.py:29-38 MultiLevelCELoss + autograd):
-//   loss = mean_b sum_l w_l * CE(logits[b, s_l:e_l], level_labels[b, l]).
+//   loss = mean_b sum_l w_l * c[s_l + y_bl] * CE(logits[b, s_l:e_l], y_bl = level_labels[b, l]),
+// c = the optional per-class weights (loss.py:16-25: nn.CrossEntropyLoss(weight=weight[s_l:e_l], reduction='none'), i.e. the sample's
+// term is scaled by its target class's weight and nothing is renormalised); c = NULL: all ones.
 // One wave per (sample b, level l): max -> sum-exp -> loss term -> gradient slice, butterflies for the reductions.
 // HBM-bound: reads B*C*4 (twice, second pass from L1/L2), writes B*C*4.
 #include "lec_common.h"
@@ -10,7 +12,7 @@ struct LevelTable { int start[16]; int size[16]; float weight[16]; int L; };
 
 __global__ __launch_bounds__(256) void mlce_kernel(const float* __restrict__ logits, int64_t ld,
                                                    const int64_t* __restrict__ labels, int B, LevelTable lt,
-                                                   float* __restrict__ glogits, float* partials,
+                                                   const float* __restrict__ cw, float* __restrict__ glogits, float* partials,
                                                    unsigned int* counter, float* loss) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -29,7 +31,7 @@ __global__ __launch_bounds__(256) void mlce_kernel(const float* __restrict__ log
     for (int i = lane; i < n; i += 64) se += expf(z[i] - mx);
     se = group_sum<64>(se);
     const float lse = logf(se);
-    const float w = lt.weight[l];
+    const float w = cw ? lt.weight[l] * cw[lt.start[l] + lab] : lt.weight[l];
     if (lane == 0) lsum += w * (lse - (z[lab] - mx));
     if (glogits) {
       float* g = glogits + (int64_t)b * ld + lt.start[l];
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256) void mlce_kernel(const float* __restrict__ log
 }  // namespace lec
 
 extern "C" int lec_multilevel_ce_fwd_bwd(const float* logits, int64_t ld, const int64_t* level_labels, int B, int C,
-                                         const int32_t* level_sizes, const float* level_weights, int L, float* loss,
+                                         const int32_t* level_sizes, const float* level_weights, const float* class_weights, int L, float* loss,
                                          float* glogits, void* workspace, int64_t workspace_bytes,
                                          lec_stream_t stream) {
   using namespace lec;
@@ -64,7 +66,7 @@ extern "C" int lec_multilevel_ce_fwd_bwd(const float* logits, int64_t ld, const 
   const int64_t need = 256 + (int64_t)nblocks * sizeof(float);
   LEC_CHECK_ARG(workspace && workspace_bytes >= need, "multilevel_ce: workspace needs %lld bytes", (long long)need);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(mlce_kernel, dim3(nblocks), dim3(256), 0, st, logits, ld, level_labels, B, lt, glogits,
+  hipLaunchKernelGGL(mlce_kernel, dim3(nblocks), dim3(256), 0, st, logits, ld, level_labels, B, lt, class_weights, glogits,
                      (float*)((char*)workspace + 256), (unsigned int*)workspace, loss);
   LEC_CHECK_LAUNCH("mlce_kernel");
   return LEC_OK;

@@ -39,6 +39,11 @@ WORKLOADS = {
 }
 
 
+def max_rows_f32(hw):
+    """Rows per CNN pass the fp32 convolutions take (32-bit byte offsets: every activation below 2 GiB; the stem's output is the largest)."""
+    return ((1 << 31) - 1) // (max(hw // 2, 1) ** 2 * 64 * 4)
+
+
 def make_labelmap(name):
     if name == 'ETHEC':
         return SyntheticLabelMap.ethec()
@@ -96,10 +101,16 @@ class StepEngine:
         self.cnn_chunk = cnn_chunk
         if self.cnn_chunk is None and self.n_rows * per_row_gb > 240:
             self.cnn_chunk = 512                       # the bench batch: every library convolution shape is in the shipped find-db
+        # liblecone's fp32 convolutions address a tensor with 32-bit byte offsets (conv_geo.h conv_check): the largest activation of the
+        # backbone (the stem's output, (hw/2)^2 x 64 floats per row) must stay below 2 GiB -- 668 rows of ResNet at 224 x 224
+        rows_2g = max_rows_f32(hw)
+        if dtype == 'fp32' and self.cnn_chunk is None and self.n_rows > rows_2g:
+            self.cnn_chunk = min(512, rows_2g)
         if self.cnn_chunk is not None and self.cnn_chunk >= self.n_rows:
             self.cnn_chunk = None
-        # chunks are all the same size (one set of kernel shapes): the row list is padded with repeats of row 0, whose outputs no
-        # pair references (zero gradient)
+        # chunks are all the same size (one set of kernel shapes): the row list is padded with repeats of POOL IMAGE 0 (idx_dev is
+        # zero-initialised), whose outputs no pair references (zero gradient).  They do enter the last chunk's BatchNorm batch
+        # statistics and running statistics, as any image of that chunk does.
         self.n_rows_pad = self.n_rows if self.cnn_chunk is None else -(-self.n_rows // self.cnn_chunk) * self.cnn_chunk
         if self.cnn_chunk is None and self.n_rows * per_row_gb > 240:
             raise ValueError('workload %s at B=%d pushes %d images through %s per step (%d image negatives per positive): about %.0f GB of '
@@ -275,11 +286,20 @@ class StepEngine:
         loss, e_pos, e_neg = ops.joint_loss_raw(self.table, feats, pos_from, pos_to, negc, None, self.K_cone, self.alpha, _lib.ENERGY_HYP_CONE,
                                                 _lib.LABEL_HYP, _lib.IMAGE_SOFTCLIP, self.table_grad, self.gfeat, table_f16=self.table_h)
         if ev: ev[2].record()
-        for lo in range(0, R, C):
-            f = self.img_feat_net.forward_raw(self.pool.index_select(0, self.idx_dev[lo:lo + C]))
-            f.backward(self.gfeat[lo:lo + C])
-            if self.overlap is not None:
-                self.overlap.join()
+        # Several backward passes add into the same gradient slots: the reducer's per-parameter hooks stay muted for all of them (a
+        # parameter reports in EVERY chunk; a bucket launched after chunk 0 would reduce a partial sum and race with the later chunks'
+        # atomics) and the buckets are reduced once, by step()'s reducer.finish(), after the last chunk's weight gradients have joined.
+        live = self.reducer.live
+        self.reducer.live = False
+        try:
+            for lo in range(0, R, C):
+                f = self.img_feat_net.forward_raw(self.pool.index_select(0, self.idx_dev[lo:lo + C]))
+                f.backward(self.gfeat[lo:lo + C])
+                if self.overlap is not None:
+                    self.overlap.join()
+        finally:
+            self.reducer.live = live
+            self.reducer.reset()                       # nothing launched: finish() reduces every bucket and the table gradient
         if ev: ev[3].record()
         return loss, e_pos, e_neg
 

@@ -120,18 +120,30 @@ GRAPH_FILES = ('G', 'G_tc', 'G_train', 'G_val', 'G_test', 'G_train_skeleton_full
 _GRAPH_KEYS = ('graph', 'graph_tc', 'G_train', 'G_val', 'G_test', 'G_train_skeleton_full', 'G_train_tc')
 
 
-def save_combined_graphs(graph_dict, path_to_folder, dense=None):
+def save_combined_graphs(graph_dict, path_to_folder, dense=None, reference_compatible=False):
     """The writer half of oe_h.py:563-571.  Same file names as the reference: the seven graphs `G`, `G_tc`, `G_train`, `G_val`,
-    `G_test`, `G_train_skeleton_full`, `G_train_tc` -- each a pickle (the reference's nx.write_gpickle IS pickle.dump) of
-    {'nodes': [...], 'edges': [(u, v), ...]} in insertion order, version-independent where a pickled networkx object is not --
-    plus the negative structure as `neg_structure.npz` (NegativeGraph.save: O(N + M) bytes).  dense=True (default: only up to
-    4 000 nodes) also writes the reference's own `neg_adjacency.npy` so that the reference can read the folder back."""
+    `G_test`, `G_train_skeleton_full`, `G_train_tc` -- by default each a pickle of {'nodes': [...], 'edges': [(u, v), ...]} in
+    insertion order (version-independent where a pickled networkx object is not; load_combined_graphs reads it back, the reference
+    does NOT: its nx.read_gpickle would hand `G.size()` a dict) -- plus the negative structure as `neg_structure.npz`
+    (NegativeGraph.save: O(N + M) bytes).  dense=True (default: only up to 4 000 nodes) also writes the reference's own
+    `neg_adjacency.npy`, the one file of the folder both sides read as is.
+    reference_compatible=True: the seven files hold pickled `networkx.DiGraph` objects instead -- what the reference's
+    nx.write_gpickle writes (it IS pickle.dump of the graph object, oe_h.py:565-571) and its nx.read_gpickle (:2257-2263) reads
+    back, under the networkx version that wrote them; needs networkx importable and implies dense=True."""
     import pickle
     os.makedirs(path_to_folder, exist_ok=True)
+    if reference_compatible:
+        import networkx as nx
+        dense = True
     for fname, key in zip(GRAPH_FILES, _GRAPH_KEYS):
         g = graph_dict[key]
+        if reference_compatible:
+            obj = nx.DiGraph()
+            obj.add_nodes_from(g.nodes()); obj.add_edges_from(tuple(e) for e in g.edges())
+        else:
+            obj = {'nodes': list(g.nodes()), 'edges': [tuple(e) for e in g.edges()]}
         with open(os.path.join(path_to_folder, fname), 'wb') as f:
-            pickle.dump({'nodes': list(g.nodes()), 'edges': [tuple(e) for e in g.edges()]}, f, protocol=4)
+            pickle.dump(obj, f, protocol=4)
     neg = graph_dict['G_train_neg']
     if not isinstance(neg, NegativeGraph):
         neg = NegativeGraph.from_dense(np.asarray(neg), graph_dict['levels'])
@@ -290,9 +302,12 @@ class ETHECHierarchyWithImages(torch.utils.data.Dataset):
         elif callable(loc):
             img = loc()
         else:
+            # The reference decodes with cv2.imread (B, G, R channel order, 8-bit, no alpha) and hands the array to ToPILImage without a
+            # channel swap (oe_h.py:668-677, 700-712, 1463-1471): tensor channel 0 is BLUE.  Same layout here, so that a backbone trained
+            # by the reference sees the channels it was trained on (resize is per channel: swapping before or after it is the same).
             from PIL import Image
             pil = Image.open(loc).convert('RGB').resize((self.input_size, self.input_size), Image.BILINEAR)
-            img = torch.from_numpy(np.asarray(pil).copy()).permute(2, 0, 1).float().div_(255.0)
+            img = torch.from_numpy(np.asarray(pil)[:, :, ::-1].copy()).permute(2, 0, 1).float().div_(255.0)
         if train_transform and self.transform:
             img = self.transform(img)
         return img
@@ -352,10 +367,14 @@ class EmbeddingMetrics:
         p = self.e_for_u_v_positive.detach().double().cpu().numpy(); n = self.e_for_u_v_negative.detach().double().cpu().numpy()
         if self.phase != 'val':
             return self.calculate_best(self.threshold)
+        # candidate thresholds: the distinct energies, NaN (an energy whose apex row is zero) last as np.unique puts it; a NaN energy is
+        # neither "<= t" nor "> t" for any t, and a NaN threshold classifies nothing as anything (torch comparisons, oe_h.py:456-457)
         th = np.unique(np.concatenate((p, n)))
-        ps, ns = np.sort(p), np.sort(n)
-        cp = np.searchsorted(ps, th, side='right')                      # positives <= t
-        cn = len(ns) - np.searchsorted(ns, th, side='right')            # negatives  > t
+        ps, ns = np.sort(p[~np.isnan(p)]), np.sort(n[~np.isnan(n)])
+        live = ~np.isnan(th)
+        cp = np.where(live, np.searchsorted(ps, th, side='right'), 0)                       # positives <= t
+        cn = np.where(live, len(ns) - np.searchsorted(ns, th, side='right'), 0)             # negatives  > t
+        ps, ns = p, n                                                   # totals count every pair, NaN or not
         fp = len(ns) - cn
         with np.errstate(invalid='ignore', divide='ignore'):
             prec = np.where(cp + fp > 0, cp / np.maximum(cp + fp, 1), 0.0)
@@ -767,20 +786,38 @@ class JointEmbeddings:
         return self.pass_samples(phase='test', save_to_tensorboard=False)
 
     # ---- metrics -----------------------------------------------------------------------
+    # reference_exact_eval = True (default): the evaluation phase gives the reference's numbers on the same inputs (fixture F12), which
+    # includes what its chunk loops do -- `rows[ix:min(ix + bs, len - 1)]` never reaches the LAST image and the LAST label, whose rows
+    # stay zero (oe_h.py:1997-2011, 2230-2234); a zero label row has NaN energies, which rank last / fail every threshold test.
+    # False: every row is embedded (the corrected variant), in large chunks, with the image network in eval mode.
+    reference_exact_eval = True
+
     @torch.no_grad()
-    def embed_images(self, names, bs=256):
+    def embed_images(self, names, bs=256, skip_last=False):
+        """Rows of the image network's output for `names`, `bs` images per forward.  skip_last: the reference's chunk rule
+        (oe_h.py:1997-2003): every chunk ends at min(ix + bs, len - 1), so the last image is never embedded and its row stays zero
+        (an EMPTY last chunk -- len = 1 mod bs -- makes the reference's torch.stack raise; here it is skipped)."""
         ds = self.criterion.dataloader
         out = torch.zeros((len(names), self.embedding_dim), device=self.device)
-        for i in range(0, len(names), bs):
-            stack = torch.stack([ds.get_image(n) for n in names[i:i + bs]]).to(self.device)
-            out[i:i + len(stack)] = self.img_feat_net(stack).float()
+        n = len(names)
+        for i in range(0, n, bs):
+            hi = min(i + bs, n - 1) if skip_last else min(i + bs, n)
+            if hi <= i:
+                continue
+            stack = torch.stack([ds.get_image(nm) for nm in names[i:hi]]).to(self.device)
+            out[i:hi] = self.img_feat_net(stack).float()
         return out
 
     @torch.no_grad()
-    def calculate_classification_metrics(self, phase, k=[1, 3, 5]):
-        """oe_h.py:1971-2178 with the per-image python loop replaced by ONE all-pairs energy launch + per-level top-k on
-        the GPU.  (The reference's chunk loops skip the last image / label, leaving a zero row -- a bug that is not
-        reproduced; every row is embedded here.)"""
+    def calculate_classification_metrics(self, phase, k=[1, 3, 5], reference_exact=None):
+        """oe_h.py:1971-2178 with the per-image python loop replaced by ONE fused scoring + per-level top-k launch on the GPU
+        (lec_level_topk).  Same return dict as the reference (micro / macro metrics, hit@k, `level_metrics`, the two median norms) and
+        the same side effects (`self.img_rep`, `self.image_is_a_member_of` for phase 'train').  reference_exact (default: the
+        attribute `reference_exact_eval`): see above; pinned by fixture F12, the reference's own output on the same inputs.
+        One case is NOT reproduced: a split whose graph misses some label -- the reference indexes its label rows by POSITION in the
+        sorted list of the split's labels while slicing levels by label id (oe_h.py:2011-2036), i.e. it assumes every label occurs;
+        here rows are always addressed by label id."""
+        exact = self.reference_exact_eval if reference_exact is None else bool(reference_exact)
         G = self.graph_dict['G_{}'.format(phase)]
         nodes = list(G)
         images = [n for n in nodes if type(n) == str]
@@ -788,62 +825,97 @@ class JointEmbeddings:
         metrics = {}
         if not images:
             return {'m-f1': 0.0, 'accuracy': 0.0}
-        was_training = self.img_feat_net.training
-        self.img_feat_net.eval()
-        img_rep = self.embed_images(images)
-        self.img_feat_net.train(was_training)
-        label_rep = self.model(torch.arange(self.n_classes, device=self.device))
+        if exact:                                                   # chunks of 10, whatever mode the networks are in (oe_h.py:1972,1778,1792-1795)
+            img_rep = self.embed_images(images, bs=10, skip_last=True)
+        else:
+            was_training = self.img_feat_net.training
+            self.img_feat_net.eval()
+            img_rep = self.embed_images(images)
+            self.img_feat_net.train(was_training)
+        label_rep = self.model(torch.arange(self.n_classes, device=self.device)).detach().clone()
+        if exact:
+            label_rep[labels[-1]] = 0.0                             # the label row the reference's loop never fills
         metrics['median_img_norm'] = torch.median(torch.norm(img_rep, dim=1)).item()
         metrics['median_label_norm'] = torch.median(torch.norm(label_rep[labels], dim=1)).item()
         starts = list(self.labelmap.level_start[:self.n_levels]) + [self.labelmap.level_stop[self.n_levels - 1]]
         kk_all = min(max(k), 8)
-        top_idx, _ = ops.level_topk(label_rep.detach(), img_rep, starts, kk_all, getattr(self.criterion, 'K', None),
+        top_idx, _ = ops.level_topk(label_rep, img_rep, starts, kk_all, getattr(self.criterion, 'K', None),
                                     self.criterion.energy)           # [n_img, n_levels, k]: scoring + top-k in one launch
         member = np.zeros((len(images), self.n_levels), dtype=np.int64)
+        member_lists = {}
         for i, name in enumerate(images):
             m = sorted(G.predecessors(name))
             member[i, :len(m)] = m[:self.n_levels]
+            member_lists[i] = m
         member_t = torch.from_numpy(member).to(self.device)
-        tp = torch.zeros(self.n_classes, device=self.device); fp = torch.zeros_like(tp); fn = torch.zeros_like(tp); tn = torch.zeros_like(tp)
-        hit = {kv: torch.zeros(self.n_classes, device=self.device) for kv in k}
+        N = self.n_classes
+        cnt = {n: torch.zeros(N, dtype=torch.int64, device=self.device) for n in ('tp', 'fp', 'fn', 'tn')}
+        hit = {kv: torch.zeros(N, dtype=torch.int64, device=self.device) for kv in k}
         for lvl in range(self.n_levels):
             s, e = self.labelmap.level_start[lvl], self.labelmap.level_stop[lvl]
             kk = min(kk_all, e - s)
-            idx = top_idx[:, lvl, :kk].long().clamp_min(s)          # (-1 only where every energy of the level is NaN)
+            idx = top_idx[:, lvl, :kk].long()
+            # a slot the kernel left empty (-1): every remaining energy of the level is NaN.  torch.topk ranks NaN last, so the
+            # reference's list continues with the NaN label (there is at most one: the zero row)
+            idx = torch.where(idx < 0, torch.full_like(idx, labels[-1] if s <= labels[-1] < e else s), idx)
             truth = member_t[:, lvl]
             for kv in k:
-                h = (idx[:, :min(kv, kk)] == truth[:, None]).any(dim=1).float()
+                h = (idx[:, :min(kv, kk)] == truth[:, None]).any(dim=1).long()
                 hit[kv].index_add_(0, truth, h)
             correct = idx[:, 0] == truth
-            tp.index_add_(0, truth, correct.float())
-            fp.index_add_(0, idx[:, 0], (~correct).float())
-            fn.index_add_(0, truth, (~correct).float())
-            lvl_tn = torch.zeros(e - s, device=self.device) + correct.float().sum()
-            tn[s:e] += lvl_tn; tn.index_add_(0, truth, -correct.float())     # tn for every other label of the level
-        tot = {n: float(t[labels].sum()) for n, t in (('tp', tp), ('fp', fp), ('fn', fn), ('tn', tn))}
-        prec = tot['tp'] / max(tot['tp'] + tot['fp'], 1e-30); rec = tot['tp'] / max(tot['tp'] + tot['fn'], 1e-30)
-        metrics['accuracy'] = (tot['tp'] + tot['tn']) / max(sum(tot.values()), 1e-30)
+            cnt['tp'].index_add_(0, truth, correct.long())
+            cnt['fp'].index_add_(0, idx[:, 0], (~correct).long())
+            cnt['fn'].index_add_(0, truth, (~correct).long())
+            cnt['tn'][s:e] += correct.long().sum(); cnt['tn'].index_add_(0, truth, -correct.long())   # tn for every OTHER label of the level
+        # counts -> metrics on the host in python floats, in the reference's order of operations (oe_h.py:2064-2160)
+        c = {n: t.cpu().numpy() for n, t in cnt.items()}
+        hk = {kv: t.cpu().numpy() for kv, t in hit.items()}
+        tot = {n: int(c[n][labels].sum()) for n in c}
+        f1_of = {}; prec_of = {}; rec_of = {}
+        for l in labels:
+            tp_, fp_, fn_ = int(c['tp'][l]), int(c['fp'][l]), int(c['fn'][l])
+            prec_of[l] = 0.0 if tp_ + fp_ == 0 else tp_ / (tp_ + fp_)
+            rec_of[l] = 0.0 if tp_ + fn_ == 0 else tp_ / (tp_ + fn_)
+            f1_of[l] = 0.0 if prec_of[l] + rec_of[l] == 0 else (2 * prec_of[l] * rec_of[l]) / (prec_of[l] + rec_of[l])
+        prec = tot['tp'] / (tot['tp'] + tot['fp']); rec = tot['tp'] / (tot['tp'] + tot['fn'])
+        metrics['accuracy'] = (tot['tp'] + tot['tn']) / (tot['tp'] + tot['tn'] + tot['fp'] + tot['fn'])
         metrics['m-precision'], metrics['m-recall'] = prec, rec
-        metrics['m-f1'] = 0.0 if prec + rec == 0 else 2 * prec * rec / (prec + rec)
+        metrics['m-f1'] = 0.0 if prec + rec == 0 else (2 * prec * rec) / (prec + rec)
         for kv in k:
-            metrics['hit@{}'.format(kv)] = float(hit[kv][labels].sum()) / (self.n_levels * len(images))
-        lp = torch.where(tp + fp > 0, tp / (tp + fp).clamp_min(1), torch.zeros_like(tp))
-        lr_ = torch.where(tp + fn > 0, tp / (tp + fn).clamp_min(1), torch.zeros_like(tp))
-        lf = torch.where(lp + lr_ > 0, 2 * lp * lr_ / (lp + lr_).clamp_min(1e-30), torch.zeros_like(tp))
-        metrics['M-precision'] = float(lp[labels].mean()); metrics['M-recall'] = float(lr_[labels].mean()); metrics['M-f1'] = float(lf[labels].mean())
+            metrics['hit@{}'.format(kv)] = int(hk[kv][labels].sum()) / (self.n_levels * len(images))
+        metrics['M-precision'] = sum(prec_of[l] for l in labels) / len(labels)
+        metrics['M-recall'] = sum(rec_of[l] for l in labels) / len(labels)
+        metrics['M-f1'] = sum(f1_of[l] for l in labels) / len(labels)
+        metrics['level_metrics'] = {}
+        for lvl in range(self.n_levels):                            # oe_h.py:2123-2160 (M-f1 is divided by stop - start + 1 there)
+            s, e = self.labelmap.level_start[lvl], self.labelmap.level_stop[lvl]
+            tp_, tn_, fp_, fn_ = (int(c[n][s:e].sum()) for n in ('tp', 'tn', 'fp', 'fn'))
+            lm_ = {}
+            for kv in k:
+                lm_['hit@{}'.format(kv)] = int(hk[kv][s:e].sum()) / len(images)
+            lp = tp_ / (tp_ + fp_); lr_ = tp_ / (tp_ + fn_)
+            lm_['m-precision'], lm_['m-recall'] = lp, lr_
+            lm_['m-f1'] = 0.0 if lp + lr_ == 0 else (2 * lp * lr_) / (lp + lr_)
+            lm_['M-f1'] = sum(f1_of.get(l, 0.0) for l in range(s, e)) / (e - s + 1)
+            lm_['accuracy'] = (tp_ + tn_) / (tp_ + tn_ + fp_ + fn_)
+            metrics['level_metrics'][lvl] = lm_
         print('=' * 30, '{} - Classification metrics'.format(phase), '=' * 30)
         print('m-F1: {:.4f} Accuracy: {:.4f}'.format(metrics['m-f1'], metrics['accuracy']))
         if phase == 'train':
             self.img_rep = img_rep.unsqueeze(0).cpu()
+            self.image_is_a_member_of = member_lists
         return metrics
 
     def _score(self, label_rep, img_rep):
         return ops.energy_matrix(label_rep, img_rep, getattr(self.criterion, 'K', None), self.criterion.energy)
 
     @torch.no_grad()
-    def check_graph_embedding(self):
+    def check_graph_embedding(self, reference_exact=None):
         """oe_h.py:2180-2247: label-graph reconstruction F1 over ALL label pairs.  One all-pairs energy launch (N x N)
-        + a sort-based threshold sweep instead of N^2 python-indexed pairs and a process pool."""
+        + a sort-based threshold sweep instead of N^2 python-indexed pairs and a process pool.  reference_exact (default: the
+        attribute `reference_exact_eval`): the last label row stays zero as in the reference's chunk loop (:2230-2234) -- its NaN
+        energies as an apex count as "not above any threshold" in EmbeddingMetrics, exactly as torch's comparisons count them."""
+        exact = self.reference_exact_eval if reference_exact is None else bool(reference_exact)
         tc = self.graph_dict['graph_tc']
         N = self.n_classes
         hidden = self.levels_to_hide_for_epoch.get(self.epoch, []) if self.hide_levels else []
@@ -856,7 +928,9 @@ class JointEmbeddings:
                 continue
             pos[u, v] = True; keep[u] = True; keep[v] = True
         nodes = torch.nonzero(keep).flatten()
-        rep = self.model(nodes.to(self.device))
+        rep = self.model(nodes.to(self.device)).detach().clone()
+        if exact and len(nodes):
+            rep[-1] = 0.0
         E = self._score(rep, rep).t().cpu()                                 # E[u, v] = E(apex u, point v)
         sub_pos = pos[nodes][:, nodes]
         off = ~torch.eye(len(nodes), dtype=torch.bool)

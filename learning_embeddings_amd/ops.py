@@ -271,7 +271,7 @@ class MultiLevelCEFn(torch.autograd.Function):
     """MultiLevelCELoss.forward (network/loss.py:29-38) + backward in one launch."""
 
     @staticmethod
-    def forward(ctx, logits, level_labels, levels, level_weights):
+    def forward(ctx, logits, level_labels, levels, level_weights, class_weights=None):
         z = _rows(logits.float(), 'logits')
         B, Cc = z.shape
         lab = level_labels.to(torch.int64).contiguous()
@@ -281,15 +281,18 @@ class MultiLevelCEFn(torch.autograd.Function):
         loss = torch.empty(1, dtype=torch.float32, device=z.device)
         g = torch.empty(B, Cc, dtype=torch.float32, device=z.device) if logits.requires_grad else None
         ws = _workspace(z.device, 256 + 4 * 2048)
+        if class_weights is not None:
+            if class_weights.dtype != torch.float32 or class_weights.numel() != Cc or not class_weights.is_contiguous() or class_weights.device != z.device:
+                raise ValueError('class weights must be a contiguous float32 [n_classes] tensor on the logits\' device')
         check(lib.lec_multilevel_ce_fwd_bwd(dptr(z), _ld(z), dptr(lab), B, Cc, C.cast(sizes, C.c_void_p),
-                                            C.cast(wts, C.c_void_p) if wts is not None else None, L, dptr(loss),
+                                            C.cast(wts, C.c_void_p) if wts is not None else None, dptr(class_weights), L, dptr(loss),
                                             dptr(g), dptr(ws), ws.numel(), stream_ptr()))
         ctx.g = g; ctx.dt = logits.dtype
         return loss.view(())
 
     @staticmethod
     def backward(ctx, gl):
-        return (ctx.g * gl).to(ctx.dt), None, None, None
+        return (ctx.g * gl).to(ctx.dt), None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ fused BN (+add) (+ReLU)

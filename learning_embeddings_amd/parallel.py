@@ -320,6 +320,34 @@ class GradientReducer:
         self.reset()
 
 
+    def time_buckets(self, reps=5):
+        """Each bucket's (and each extra tensor's) SUM all-reduce alone, HIP-event timed on the current stream: [{'mb', 'ms'}].  The
+        buffers are saved and restored (the sums overflow harmlessly in between): training state is untouched.  Collective: every rank
+        must call it."""
+        out = []
+        if not self.enabled:
+            return out
+        spans = [self.arena.grad[lo:hi] for lo, hi in self._spans] + list(self.extra)
+        for t in spans:
+            keep = t.clone()
+            h = self._allreduce(t); h.wait()                                         # untimed first call
+            if t.is_cuda:
+                a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(reps):
+                    self._allreduce(t).wait()
+                b.record(); b.synchronize()
+                ms = a.elapsed_time(b) / reps
+            else:
+                import time
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    self._allreduce(t).wait()
+                ms = (time.perf_counter() - t0) / reps * 1e3
+            t.copy_(keep)
+            out.append({'mb': round(t.numel() * t.element_size() / 1e6, 2), 'ms': round(ms, 4)})
+        return out
+
     def _reduce_now(self):
         for lo, hi in self._spans:
             self.handles.append(self._allreduce(self.arena.grad[lo:hi]))

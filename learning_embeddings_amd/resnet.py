@@ -90,7 +90,7 @@ class WgradOverlap:
         slot (zeroed at the start of the step) -- no library kernel, zero-fill, cast or copy.  False when not applicable."""
         w = conv.weight
         if (MFMA_F32 and gy.dtype == torch.float32 and x.dtype == torch.float32 and w.grad is not None and w.grad.dtype == torch.float32
-                and w.grad.shape == w.shape and _f32_conv_ok(conv) and w.grad.is_contiguous(memory_format=torch.channels_last)
+                and w.grad.shape == w.shape and _f32_conv_ok(conv) and _f32_conv_fits(conv, x) and w.grad.is_contiguous(memory_format=torch.channels_last)
                 and gy.is_contiguous(memory_format=torch.channels_last) and x.is_contiguous(memory_format=torch.channels_last)):
             if conv.in_channels == 3:             # the stem: x carries the zero 4th channel (_pad_c4), its gradient column is dropped
                 dw4 = torch.empty((w.shape[0], 4, w.shape[2], w.shape[3]), dtype=torch.float32, device=w.device, memory_format=torch.channels_last).zero_()
@@ -209,6 +209,16 @@ def _f32_conv_ok(conv):
     return ops.conv_f32_supported(conv)
 
 
+def _f32_conv_fits(conv, x):
+    """lec_conv_f32_* address a tensor with 32-bit byte offsets (conv_geo.h conv_check): input and output must stay below 2 GiB
+    (ResNet at 224 x 224 in fp32: 668 rows).  Larger batches take the library convolution (or are chunked by the caller: engine.cnn_chunk)."""
+    n, c, h, w = x.shape
+    c = max(c, 4)
+    k, st, pd = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    ho, wo = (h + 2 * pd - k) // st + 1, (w + 2 * pd - k) // st + 1
+    return n * h * w * c * 4 < (1 << 31) and n * ho * wo * conv.out_channels * 4 < (1 << 31)
+
+
 def _pad_c4(t):
     """[N, 3, H, W] -> [N, 4, H, W] channels_last with a zero 4th channel (already 4 channels: returned as is)."""
     if t.shape[1] == 4:
@@ -241,7 +251,7 @@ class _OverlapConvFn(torch.autograd.Function):
         if nhwc and w16.dim() == 4 and not w16.is_contiguous(memory_format=torch.channels_last):
             w16 = w16.contiguous(memory_format=torch.channels_last)
         ctx.f32 = (MFMA_F32 and nhwc and x.dtype == torch.float32 and w16.dtype == torch.float32 and _f32_conv_ok(conv)
-                   and w16.is_contiguous(memory_format=torch.channels_last))
+                   and w16.is_contiguous(memory_format=torch.channels_last) and _f32_conv_fits(conv, x))
         if ctx.f32:
             # the reference's precision: liblecone's f32-MFMA implicit GEMM (every layer shape, stride and direction), with the
             # BatchNorm statistics of the output in its epilogue
@@ -356,7 +366,9 @@ class Conv2d(nn.Conv2d):
 
     def forward(self, x):
         ov = WgradOverlap.instance
-        if (ov is not None and ov.enabled and x.is_cuda and self.training and torch.is_grad_enabled() and self.bias is None
+        # (also under torch.no_grad(): the forward-only first pass of a chunked step must run the SAME kernels as the pass that is
+        # differentiated -- the loss gradient is evaluated at the first pass's outputs)
+        if (ov is not None and ov.enabled and x.is_cuda and self.training and self.bias is None
                 and x.dtype in (torch.bfloat16, torch.float16, torch.float32) and self.weight.requires_grad):
             return _OverlapConvFn.apply(x, self.weight, self)
         return super().forward(x)

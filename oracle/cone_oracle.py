@@ -368,18 +368,21 @@ def table_step_rsgd(W, g, lr, K):
 
 
 # --------------------------------------------------------------------------------------------
-# a13: MultiLevelCELoss (loss.py:29-38)
+# a13: MultiLevelCELoss (loss.py:5-38; class_weights = its `weight` argument, :16-25: CrossEntropyLoss(weight=slice, reduction='none')
+# scales a sample's term by its target class's weight)
 # --------------------------------------------------------------------------------------------
-def multilevel_ce(logits, level_labels, levels, level_weights=None):
+def multilevel_ce(logits, level_labels, levels, level_weights=None, class_weights=None):
     z = np.asarray(logits, np.float64); B = z.shape[0]
     lw = [1.0] * len(levels) if level_weights is None else list(level_weights)
+    cw = None if class_weights is None else np.asarray(class_weights, np.float64)
     per = np.zeros(B); g = np.zeros_like(z); s = 0
     for l, n in enumerate(levels):
         zl = z[:, s:s + n]; zm = zl - zl.max(axis=1, keepdims=True)
         lse = np.log(np.exp(zm).sum(axis=1)); lab = np.asarray(level_labels)[:, l]
-        per += lw[l] * (lse - zm[np.arange(B), lab])
+        wl = lw[l] * (cw[s + lab] if cw is not None else np.ones(B))
+        per += wl * (lse - zm[np.arange(B), lab])
         p = np.exp(zm - lse[:, None]); p[np.arange(B), lab] -= 1.0
-        g[:, s:s + n] = lw[l] * p / B
+        g[:, s:s + n] = wl[:, None] * p / B
         s += n
     return per.mean(), g
 

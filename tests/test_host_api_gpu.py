@@ -358,7 +358,8 @@ def test_config2_ethec_resnet18_step_matches_oracle():
 
 def _engine_vs_oracle(eng, n_images, steps=2, check_table=True):
     """Run `steps` engine steps; per step: negatives bit-equal to the pinned dense-matrix sampler's stream, loss / E+ / E- against
-    the oracle on the raw CNN outputs the fused kernel consumed, label-table update against the oracle's rescale -> Adam -> clip."""
+    the oracle on the raw CNN outputs the fused kernel consumed, the gradient that flows INTO the CNN (d loss / d raw outputs: what
+    fc and the backbone back-propagate) against the oracle's, label-table update against the oracle's rescale -> Adam -> clip."""
     lm = eng.labelmap
     leaf = (lm.level_start[-1] + eng.img_leaf).tolist()
     A = O.dense_negative_adjacency(lm.n_classes, sorted(lm.edges), leaf)
@@ -376,6 +377,8 @@ def _engine_vs_oracle(eng, n_images, steps=2, check_table=True):
         o = O.joint_loss_fwd_bwd(W0, got['f'], frm, N + np.arange(B), neg_o, eng.alpha, eng.K_cone)
         assert abs(loss.item() - o[0]) <= 1e-4 * max(1, abs(o[0]))
         assert np.abs(e_pos.cpu().numpy() - o[1]).max() <= 1e-4 and np.abs(e_neg.cpu().numpy() - o[2]).max() <= 1e-4
+        gfeat = eng.gfeat[:o[4].shape[0]].cpu().numpy()                       # what feats.backward() was fed this step
+        assert np.abs(gfeat - o[4]).max() <= 2e-3 * np.abs(o[4]).max(), 'gradient into the CNN differs from the oracle at step %d' % s
         if check_table:
             Wn, m_prev, v_prev = O.table_step_adam(W0, o[3].astype(np.float32), m_prev, v_prev, s + 1, eng.lr, eng.K_cone)
             assert np.abs(eng.table.cpu().numpy() - Wn).max() < 5e-6
@@ -637,9 +640,74 @@ def test_order_embeddings_images_legacy_trainer_step_vs_oracle():
     assert torch.isfinite(l2)
 
 
+def _f12_trainer(tmp_path):
+    """The repo's JointEmbeddings on fixture F12's inputs: same loaders, label table, in-memory images and linear stand-in image network
+    (followed by FeatCNN18.soft_clip) the reference ran on in tests/golden/make_golden_eval.py."""
+    import json
+    fx = json.load(open(os.path.join(GOLDEN, 'F12_eval_phase.json')))
+    z = np.load(os.path.join(GOLDEN, 'F12_eval_phase.npz'))
+    lm = SyntheticLabelMap(fx['levels'])
+    names = fx['names']
+    images = torch.from_numpy(z['images'])
+    dl = {s: [{'level_labels': np.asarray(b['level_labels']), 'image_filename': b['image_filename'],
+               'path_to_image': [images[names.index(f)] for f in b['image_filename']]} for b in bl] for s, bl in fx['loaders'].items()}
+    gd = oe_h.create_combined_graphs(dl, lm, pick_per_level=True)
+    crit = oe_h.EuclideanConesWithImagesHypernymLoss(lm, 5, {}, 0.01, True, K=fx['K_cone'], use_CNN=True)
+    tr = oe_h.JointEmbeddings(gd, dl, image_dir='', use_CNN=True, labelmap=lm, criterion=crit, lr=1e-3, n_workers=0,
+                              batch_size=16, experiment_name='f12', embedding_dim=fx['D'], neg_to_pos_ratio=5, image_fc7=None,
+                              normalize=None, alpha=0.01, experiment_dir=str(tmp_path), n_epochs=1, eval_interval=1)
+    tr.model.embeddings.weight.data.copy_(torch.from_numpy(z['W']))
+    lin_w, lin_b, Kc = torch.from_numpy(z['lin_w']).to(DEV), torch.from_numpy(z['lin_b']).to(DEV), fx['K_cone']
+
+    class Net(torch.nn.Module):
+        def forward(self, x):
+            return ops.ImageSoftClipFn.apply(x.flatten(1).float() @ lin_w.t() + lin_b, Kc)
+    tr.img_feat_net = Net()
+
+    class DS:
+        def get_image(self, fname):
+            return images[names.index(fname)]
+    tr.criterion.set_dataloader(DS())
+    return tr, fx, z
+
+
+def _close(a, b, tol=1e-9):
+    if isinstance(b, dict):
+        return set(map(str, a)) == set(b) and all(_close(a[k if k in a else int(k)], v, tol) for k, v in b.items())
+    return abs(float(a) - float(b)) <= tol
+
+
+def test_eval_phase_matches_the_reference_run_fixture_f12(tmp_path):
+    """calculate_classification_metrics('train' | 'val' | 'test') and check_graph_embedding() (oe_h.py:1971-2247) against the REFERENCE's
+    own return values on the same inputs (fixture F12): every entry of the metrics dict incl. `level_metrics`, the two median norms
+    (which see the zero rows the reference's chunk loops leave), `image_is_a_member_of`, and the reconstruction 7-tuple.  Counts are
+    integers, so the count-derived metrics must agree to the last bit of float64; norms / thresholds to fp32 tolerance.  The
+    corrected variant (reference_exact=False: every row embedded) must differ -- the switch does something."""
+    tr, fx, z = _f12_trainer(tmp_path)
+    assert tr.reference_exact_eval is True                         # the default reproduces the reference
+    for phase in ('train', 'val', 'test'):
+        want = fx['classification'][phase]
+        got = tr.calculate_classification_metrics(phase)
+        for key, w in want.items():
+            tol = 1e-5 if key.startswith('median') else 1e-12
+            assert _close(got[key], w, tol), (phase, key, got[key], w)
+    got_tr = tr.calculate_classification_metrics('train')
+    assert {str(k): [int(x) for x in v] for k, v in tr.image_is_a_member_of.items()} == fx['image_is_a_member_of']
+    assert np.abs(tr.img_rep[0].numpy() - z['img_rep_train']).max() < 1e-5 and not tr.img_rep[0][-1].any()
+    best = tr.check_graph_embedding()
+    want = fx['reconstruction']
+    assert abs(best[1] - want[1]) < 1e-4                           # threshold: an energy value (fp32 kernel against torch CPU)
+    for i in (0, 2, 3, 4, 5, 6):
+        assert abs(best[i] - want[i]) < 1e-12, (i, best, want)
+    fixed = tr.calculate_classification_metrics('val', reference_exact=False)
+    assert fixed['median_img_norm'] != got_tr['median_img_norm'] and fixed != fx['classification']['val']
+    assert tr.check_graph_embedding(reference_exact=False) != best
+
+
 def test_classification_metrics_and_reconstruction_vs_bruteforce(tmp_path):
-    """calculate_classification_metrics (oe_h.py:1971-2178) and check_graph_embedding (:2180-2247): the batched GPU
-    versions against a direct per-image / per-pair restatement of the reference's loops on the oracle's energies."""
+    """calculate_classification_metrics (oe_h.py:1971-2178) and check_graph_embedding (:2180-2247), corrected variant
+    (reference_exact=False: every image / label row embedded): the batched GPU versions against a direct per-image / per-pair
+    restatement of the reference's loops on the oracle's energies."""
     from test_host_cpu import _fake_loaders
     lm = SyntheticLabelMap([2, 4, 8])
     dl = _fake_loaders(lm, 24, 8)
@@ -653,7 +721,7 @@ def test_classification_metrics_and_reconstruction_vs_bruteforce(tmp_path):
                               normalize=None, alpha=0.05, experiment_dir=str(tmp_path), n_epochs=1, eval_interval=1)
     tr.criterion.set_dataloader(tr.datasets['val'])
     tr.model.eval(); tr.img_feat_net.eval()
-    got = tr.calculate_classification_metrics('val', k=[1, 3])
+    got = tr.calculate_classification_metrics('val', k=[1, 3], reference_exact=False)
     # ---- brute force on the same embeddings
     G = gd['G_val']
     images = [n for n in G if type(n) == str]; labels = sorted(n for n in G if type(n) != str)
@@ -681,7 +749,7 @@ def test_classification_metrics_and_reconstruction_vs_bruteforce(tmp_path):
     assert abs(got['m-f1'] - f1) < 1e-6 and abs(got['accuracy'] - (T['tp'] + T['tn']) / sum(T.values())) < 1e-6
     assert abs(got['hit@1'] - hit[1] / (3 * len(images))) < 1e-6 and abs(got['hit@3'] - hit[3] / (3 * len(images))) < 1e-6
     # ---- reconstruction: best-F1 threshold over all label pairs
-    best = tr.check_graph_embedding()
+    best = tr.check_graph_embedding(reference_exact=False)
     tc = gd['graph_tc']
     pos_pairs = [(u, v) for u, v in tc.edges()]
     nodes = sorted(set(u for u, _ in pos_pairs) | set(v for _, v in pos_pairs))

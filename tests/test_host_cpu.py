@@ -183,6 +183,15 @@ def test_pair_dataset_loads_image_files_and_collates(tmp_path):
     assert item['original_to'] == 'im0' and item['from'] == 2 and item['to'].shape == (3, 224, 224)
     plain = ds.get_image('im0')
     assert plain.dtype == torch.float32 and 0.0 <= plain.min() and plain.max() <= 1.0
+    # channel order is the reference's: cv2.imread gives B, G, R and ToPILImage does not swap (oe_h.py:700-712, 1463-1471), so tensor
+    # channel 0 is BLUE.  A three-colour file decides it: left third pure red, middle pure green, right pure blue.
+    tri = np.zeros((30, 90, 3), dtype=np.uint8); tri[:, :30, 0] = 255; tri[:, 30:60, 1] = 255; tri[:, 60:, 2] = 255
+    p3 = os.path.join(str(tmp_path), 'tri.png'); Image.fromarray(tri).save(p3)
+    ds.image_to_loc['tri'] = p3
+    t3 = ds.get_image('tri')                                            # [C, 224, 224]; columns ~ [0, 74) red, [75, 149) green, [150, 224) blue
+    assert t3[:, 112, 30].tolist() == [0.0, 0.0, 1.0]                    # red pixel   -> (B, G, R) = (0, 0, 1)
+    assert t3[:, 112, 112].tolist() == [0.0, 1.0, 0.0]                   # green pixel -> (0, 1, 0)
+    assert t3[:, 112, 190].tolist() == [1.0, 0.0, 0.0]                   # blue pixel  -> (1, 0, 0)
     assert torch.equal(item['to'], plain.flip(-1))                       # train transform applied only in __getitem__
     batch = oe_h.my_collate([ds[i] for i in range(len(ds))])
     assert isinstance(batch['from'], list) and batch['status'].tolist() == [1] * 7
@@ -307,6 +316,18 @@ def test_save_and_load_combined_graphs_round_trip_and_reference_written_folder(t
         load_combined_graphs(str(ref))                            # the dense matrix alone does not carry the level sizes
     back2 = load_combined_graphs(str(ref), labelmap=lm, pick_per_level=True)
     _same_graph_dict(gd, back2, lm, 24)
+    # reference_compatible=True: what the reference's nx.read_gpickle (pickle.load) expects -- real networkx.DiGraph objects
+    # (oe_h.py:2257-2263 calls .size() / .nodes() on them) and its dense neg_adjacency.npy
+    nx = pytest.importorskip('networkx')
+    rc = tmp_path / 'rc'
+    save_combined_graphs(gd, str(rc), reference_compatible=True)
+    for fname, key in zip(GRAPH_FILES, _GRAPH_KEYS):
+        with open(rc / fname, 'rb') as f:
+            G = pickle.load(f)
+        assert isinstance(G, nx.DiGraph) and G.size() == gd[key].size()
+        assert list(G.nodes()) == list(gd[key].nodes()) and list(G.edges()) == [tuple(e) for e in gd[key].edges()]
+    assert np.array_equal(np.load(rc / 'neg_adjacency.npy'), gd['G_train_neg'].to_dense())
+    _same_graph_dict(gd, load_combined_graphs(str(rc), pick_per_level=True), lm, 24)
 
 
 def test_closure_graph_from_the_samplers_csr_equals_transitive_closure():
@@ -324,3 +345,22 @@ def test_closure_graph_from_the_samplers_csr_equals_transitive_closure():
     for u in sk.nodes():
         n_sk = len(list(sk.successors(u)))
         assert list(got.successors(u))[:n_sk] == list(sk.successors(u))
+
+
+# ---------------------------------------------------------------------------------------------------- F12: evaluation phase
+def test_embedding_metrics_match_reference_fixture_including_nan_energies():
+    """EmbeddingMetrics (oe_h.py:447-503) against the reference's own outputs (fixture F12, tests/golden/make_golden_eval.py): the 'val'
+    threshold sweep (the reference: one pass per candidate threshold in a process pool; here sort + prefix sums) and the fixed-threshold
+    branch, on energies with ties, zeros and NaN (the energies of the label row the reference's chunk loop leaves zero), and on the very
+    energies its check_graph_embedding fed it.  Exact: same float64 results."""
+    fx = json.load(open(os.path.join(GOLDEN, 'F12_eval_phase.json')))
+    z = np.load(os.path.join(GOLDEN, 'F12_eval_phase.npz'))
+    for i, case in enumerate(fx['embedding_metrics']):
+        p, n = torch.from_numpy(z['em%d_pos' % i]), torch.from_numpy(z['em%d_neg' % i])
+        got = EmbeddingMetrics(p, n, 0.0, 'val').calculate_metrics()
+        assert np.array_equal(np.asarray(got, dtype=np.float64), np.asarray(case['val'])), (i, got, case['val'])
+        got = EmbeddingMetrics(p, n, 0.35, 'test').calculate_metrics()
+        assert np.array_equal(np.asarray(got, dtype=np.float64), np.asarray(case['fixed_0.35'])), (i, got)
+    assert np.isnan(z['neg_e']).sum() == 41                      # the zero row as an apex: one NaN per other node
+    got = EmbeddingMetrics(torch.from_numpy(z['pos_e']), torch.from_numpy(z['neg_e']), 0.0, 'val').calculate_metrics()
+    assert np.array_equal(np.asarray(got, dtype=np.float64), np.asarray(fx['reconstruction']))

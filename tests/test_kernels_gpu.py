@@ -270,6 +270,21 @@ def test_multilevel_ce_vs_reference_fixture(tag, w):
     assert np.abs(z.grad.cpu().numpy() - f[tag + '_glogits']).max() < 1e-6
 
 
+@pytest.mark.parametrize('tag,w', [('unw', None), ('w', 'level_weights_w')])
+def test_multilevel_ce_class_weights_vs_reference_fixture(tag, w):
+    """MultiLevelCELoss(labelmap, level_weights, weight=per-class weights) (loss.py:16-25) through the host mirror, against the
+    reference's own loss and gradient (fixture F8b)."""
+    from learning_embeddings_amd.loss import MultiLevelCELoss
+    from learning_embeddings_amd.hierarchy import SyntheticLabelMap
+    f = load('F8b_multilevel_ce_class_weights.npz')
+    crit = MultiLevelCELoss(SyntheticLabelMap(f['levels'].tolist()), level_weights=None if w is None else f[w].tolist(), weight=torch.from_numpy(f['class_weights']))
+    z = T(f['logits']).requires_grad_(True)
+    loss = crit(z, None, T(f['level_labels'], torch.int64))
+    loss.backward()
+    assert abs(loss.item() - float(f[tag + '_loss'])) < 1e-5 * abs(float(f[tag + '_loss']))
+    assert np.abs(z.grad.cpu().numpy() - f[tag + '_glogits']).max() < 1e-6
+
+
 def test_multilevel_ce_batch512():
     rs = np.random.RandomState(0)
     levels = [6, 21, 135, 561]

@@ -142,6 +142,14 @@ def test_F8_multilevel_ce(tag, w):
     assert np.abs(g - f[tag + '_glogits']).max() < 1e-6
 
 
+@pytest.mark.parametrize('tag,w', [('unw', None), ('w', 'level_weights_w')])
+def test_F8b_multilevel_ce_with_class_weights(tag, w):
+    f = load('F8b_multilevel_ce_class_weights.npz')
+    loss, g = O.multilevel_ce(f['logits'], f['level_labels'], f['levels'].tolist(), None if w is None else f[w], class_weights=f['class_weights'])
+    assert abs(loss - float(f[tag + '_loss'])) < 1e-5 * abs(float(f[tag + '_loss']))
+    assert np.abs(g - f[tag + '_glogits']).max() < 1e-6
+
+
 def test_F9_ethec_hierarchy():
     f = json.load(open(os.path.join(GOLDEN, 'F9_ethec_hierarchy.json')))
     assert f['levels'] == [6, 21, 135, 561] and len(f['edges']) == 717
