@@ -320,16 +320,19 @@ class ETHECHierarchyWithImages(torch.utils.data.Dataset):
     def map_ranges(input, output_range, input_range):
         return round(input * output_range / input_range)
 
-    def __getitem__(self, item):
+    def edge_of(self, item):
+        """The positive edge (u, v) item `item` stands for (oe_h.py:690-703): with half_half, even items walk the label-label edges
+        and odd items the label-image edges, each list stretched over half the dataset's length by map_ranges."""
         if self.half_half:
             if item % 2 == 0 and len(self.edge_list_ll) != 0:
                 item_ix = self.map_ranges(item // 2, len(self.edge_list_ll) - 1, round(self.__len__() / 2))
-                u, v = self.edge_list_ll[item_ix]
-            else:
-                item_ix = self.map_ranges(item // 2, len(self.edge_list_li) - 1, self.__len__() // 2)
-                u, v = self.edge_list_li[item_ix]
-        else:
-            u, v = self.edge_list[item]
+                return self.edge_list_ll[item_ix]
+            item_ix = self.map_ranges(item // 2, len(self.edge_list_li) - 1, self.__len__() // 2)
+            return self.edge_list_li[item_ix]
+        return self.edge_list[item]
+
+    def __getitem__(self, item):
+        u, v = self.edge_of(item)
         original_from, original_to = u, v
         if self.load_images:
             if type(u) == str:
@@ -649,9 +652,7 @@ class JointEmbeddings:
             for index, data_item in enumerate(self.dataloaders[phase]):
                 if global_batches is not None:                      # this rank's slice of the global batch
                     gb = global_batches[index]
-                    if self.half_half:
-                        raise NotImplementedError('half_half sampling under data parallelism')
-                    edges = [self.train_set.edge_list[i_] for i_ in gb]
+                    edges = [self.train_set.edge_of(i_) for i_ in gb]     # (half_half: the same item -> edge map __getitem__ uses)
                     g_from = np.fromiter((n2i[u] for u, _ in edges), dtype=np.int32, count=len(edges))
                     g_to = np.fromiter((n2i[v] for _, v in edges), dtype=np.int32, count=len(edges))
                     per = len(gb) // self.world

@@ -295,6 +295,93 @@ class MultiLevelCEFn(torch.autograd.Function):
         return (ctx.g * gl).to(ctx.dt), None, None, None, None
 
 
+# ------------------------------------------------------------------------------------------------ per-model fusion records
+# The fused paths hand work from one autograd node to another: a convolution leaves the BatchNorm statistics of its output in the
+# BatchNorm workspace, a BatchNorm leaves pass 2 of its backward to the convolution behind it, ...  Each hand-off is a record keyed by
+# the data_ptr() of the tensor it travels with.  The records (and the workspace the statistics sit in) belong to ONE backbone
+# instance: a `FusionContext`, owned by the ResNet module, made current for the duration of its forward and captured by every
+# autograd node created there (ctx.fc), whose backward makes it current again.  Two models alive in one process (train + eval copy,
+# the reference's oe.py / oe_h.py side by side) or interleaved forward / backward passes cannot see each other's records.
+# Ops called outside any model (tests, tools) use the process-wide default context; `_FORKS`, `_FOLDED`, ... are ITS dictionaries.
+import os as _os
+
+
+class FusionContext:
+    """forks: backward of a forked block output z = relu(bn(x) + residual) (two consumers: the next block's conv1 and its identity
+    branch) -- pass 1 of the BatchNorm backward can run in the epilogue of conv1's data gradient (lec_conv1x1_dgrad_bnfold), which needs
+    this layer's saved tensors and the identity branch's gradient: data_ptr of z -> those tensors (filled by forward, 'dres' by the
+    backward of the layer that took z as its residual, dropped by this layer's backward).
+    folded: data_ptr of a gradient that already is g = mask * (dy + dy2) -> number of partial rows its producer left in the workspace.
+    deferred: forward of conv3 -> bn3 (+ identity, ReLU): the convolution first runs as a statistics-only pass (conv1x1_stats_rows) and
+    hands BNActFn an UNWRITTEN output tensor: data_ptr of that tensor -> (input rows, weight); BNActFn.forward finalizes the
+    statistics and runs the convolution again with the BatchNorm apply in its epilogue, which writes both tensors.
+    lazy_ok / lazy_dx: backward of the same pair -- pass 2 of bn3's backward runs inside conv3's weight-gradient kernel
+    (lec_conv1x1_wgrad_bnapply).  lazy_ok: data_ptr of a BatchNorm input whose producer convolution can do that -> its input channels;
+    lazy_dx: data_ptr of the UNWRITTEN dx BNActFn.backward returned -> what the kernel needs.
+    ws_owner: (data_ptr of the tensor whose statistics partials sit in this context's BatchNorm workspace, number of partial rows)."""
+
+    def __init__(self):
+        self.forks, self.folded, self.deferred, self.lazy_ok, self.lazy_dx = {}, {}, {}, {}, {}
+        self.ws_owner = [0, 0]
+        self._ws = {}
+
+    def reset(self):
+        """Drop the records of a forward whose backward never ran (or raised)."""
+        for d in (self.forks, self.folded, self.deferred, self.lazy_ok, self.lazy_dx):
+            d.clear()
+        self.ws_owner[0] = 0
+
+    def workspace(self, device):
+        key = (device.type, device.index)
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = torch.zeros(int(lib.lec_bn_workspace_bytes(2048)), dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        return ws
+
+
+_DEFAULT_FUSION = FusionContext()
+_FUSION_STACK = [_DEFAULT_FUSION]
+
+
+def fusion():
+    """The current FusionContext (the innermost `use_fusion`, else the process-wide default)."""
+    return _FUSION_STACK[-1]
+
+
+class use_fusion:
+    def __init__(self, fc):
+        self.fc = fc if fc is not None else _DEFAULT_FUSION
+
+    def __enter__(self):
+        _FUSION_STACK.append(self.fc)
+        return self.fc
+
+    def __exit__(self, *exc):
+        _FUSION_STACK.pop()
+        return False
+
+
+def _with_ctx_fusion(backward):
+    """Decorator for autograd backward()s: run under the FusionContext the node's forward ran in."""
+    import functools
+
+    @functools.wraps(backward)
+    def wrapped(ctx, *grads):
+        with use_fusion(getattr(ctx, 'fc', None)):
+            return backward(ctx, *grads)
+    return wrapped
+
+
+FOLD_BN_BWD = _os.environ.get('LEC_FOLD_BN_BWD', '1') != '0'
+DEFER_BN_APPLY = _os.environ.get('LEC_DEFER_BN_APPLY', '1') != '0'
+LAZY_BN_PASS2 = _os.environ.get('LEC_LAZY_BN_PASS2', '1') != '0'
+# the default context's records under their historical names (ops called outside a model: tests, tools)
+_FORKS, _FOLDED, _DEFERRED, _LAZY_OK, _LAZY_DX = (_DEFAULT_FUSION.forks, _DEFAULT_FUSION.folded, _DEFAULT_FUSION.deferred,
+                                                  _DEFAULT_FUSION.lazy_ok, _DEFAULT_FUSION.lazy_dx)
+_BN_WS_OWNER = _DEFAULT_FUSION.ws_owner
+
+
 # ------------------------------------------------------------------------------------------------ fused BN (+add) (+ReLU)
 def _nhwc_rows(t, name):
     """[N, C, H, W] channels_last bf16 / fp32 tensor -> (M, C); raises unless the memory really is [M, C] with C innermost."""
@@ -332,6 +419,7 @@ class BNActFn(torch.autograd.Function):
         M, Cc = _nhwc_rows(x, 'x')
         if residual is not None and (_nhwc_rows(residual, 'residual') != (M, Cc) or residual.dtype != x.dtype):
             raise ValueError('residual shape / dtype mismatch')
+        ctx.fc = fusion()
         es = x.element_size()                         # 2 (bf16) or 4 (fp32) bytes per activation element
         y = torch.empty_like(x)                       # preserves channels_last
         save_mean = torch.empty(Cc, dtype=torch.float32, device=x.device); save_invstd = torch.empty_like(save_mean)
@@ -340,9 +428,9 @@ class BNActFn(torch.autograd.Function):
         mask = torch.empty(M * (Cc // 8), dtype=torch.uint8, device=x.device) if (relu and training) else None
         el = M * Cc                                   # algorithmic bytes: x (stats) + x + y [+ residual] [+ mask]
         # the convolution that produced x may have left its statistics partials in the workspace (conv1x1_rows)
-        prestat = _BN_WS_OWNER[1] if (training and _BN_WS_OWNER[0] == x.data_ptr()) else 0
-        _BN_WS_OWNER[0] = 0
-        dfr = _DEFERRED.pop(x.data_ptr(), None)
+        prestat = fusion().ws_owner[1] if (training and fusion().ws_owner[0] == x.data_ptr()) else 0
+        fusion().ws_owner[0] = 0
+        dfr = fusion().deferred.pop(x.data_ptr(), None)
         if dfr is not None:
             x_in, w2 = dfr
             cin = x_in.shape[1]
@@ -379,15 +467,16 @@ class BNActFn(torch.autograd.Function):
             ctx.res_ptr = residual.data_ptr() if residual is not None else 0
             ctx.out_ptr = y.data_ptr()
             if fork and FOLD_BN_BWD and residual is not None and ctx.needs_input_grad[0]:
-                if len(_FORKS) > 64:              # forward passes that never ran backward
-                    _FORKS.clear()
+                if len(fusion().forks) > 64:              # forward passes that never ran backward
+                    fusion().forks.clear()
                 # what the consumer convolution's data gradient needs to run pass 1 of THIS layer's backward in its epilogue
-                _FORKS[y.data_ptr()] = {'x': x, 'mask': mask, 'mean': save_mean, 'invstd': save_invstd, 'dres': None}
+                fusion().forks[y.data_ptr()] = {'x': x, 'mask': mask, 'mean': save_mean, 'invstd': save_invstd, 'dres': None}
         if fork:
             return y, y.as_strided(y.size(), y.stride())
         return y
 
     @staticmethod
+    @_with_ctx_fusion
     def backward(ctx, dy, dy2=None):
         x, mask, weight, save_mean, save_invstd = ctx.saved_tensors
         M, Cc, relu, has_res = ctx.meta
@@ -399,11 +488,11 @@ class BNActFn(torch.autograd.Function):
             dy = dy.contiguous(memory_format=torch.channels_last)
         if dy2 is not None and not dy2.is_contiguous(memory_format=torch.channels_last):
             dy2 = dy2.contiguous(memory_format=torch.channels_last)
-        _FORKS.pop(ctx.out_ptr, None)
+        fusion().forks.pop(ctx.out_ptr, None)
         pre = 0                                   # > 0: dy is already g = mask * (dy + dy2) and its partial sums sit in the workspace
-        if dy.data_ptr() in _FOLDED:
-            tag = _FOLDED.pop(dy.data_ptr())
-            if _BN_WS_OWNER[0] == dy.data_ptr() and _BN_WS_OWNER[1] == tag:
+        if dy.data_ptr() in fusion().folded:
+            tag = fusion().folded.pop(dy.data_ptr())
+            if fusion().ws_owner[0] == dy.data_ptr() and fusion().ws_owner[1] == tag:
                 pre = tag
             dy2 = None                            # already folded into dy, and so is the ReLU mask
             relu = False; mask = None
@@ -416,7 +505,7 @@ class BNActFn(torch.autograd.Function):
             sink = None
             dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device); dbeta = torch.empty_like(dgamma)
         ws = _bn_workspace(x.device)
-        _BN_WS_OWNER[0] = 0
+        fusion().ws_owner[0] = 0
         el = M * Cc                                   # 2 x (dy [+ dy2] + x [+ mask]) + dx [+ d residual]
         es = x.element_size()
         if dy.dtype != x.dtype:
@@ -428,10 +517,10 @@ class BNActFn(torch.autograd.Function):
         else:            # both passes read dy [+ dy2], x, mask; pass 2 writes dx
             nbytes = el * es * (2 * (2 + (1 if dy2 is not None else 0)) + 1) + (2 * (el // 8) if relu else 0)
         from .resnet import WgradOverlap as _WO
-        lazy = (LAZY_BN_PASS2 and has_res and x.data_ptr() in _LAZY_OK and x.dtype == torch.bfloat16
+        lazy = (LAZY_BN_PASS2 and has_res and x.data_ptr() in fusion().lazy_ok and x.dtype == torch.bfloat16
                 and _WO.instance is not None and _WO.instance.enabled       # the consumer that materialises dx is _OverlapConvFn.backward
-                and lib.lec_conv1x1_wgrad_bnapply_supported(_LAZY_OK[x.data_ptr()], Cc, M))
-        _LAZY_OK.pop(x.data_ptr(), None)
+                and lib.lec_conv1x1_wgrad_bnapply_supported(fusion().lazy_ok[x.data_ptr()], Cc, M))
+        fusion().lazy_ok.pop(x.data_ptr(), None)
         if lazy:
             # the convolution that produced x runs pass 2 inside its weight-gradient kernel (conv1x1_wgrad_bnapply_rows): here only
             # pass 1 (unless a data-gradient epilogue already did it) and the finalize; dx is handed on UNWRITTEN with a record
@@ -442,8 +531,8 @@ class BNActFn(torch.autograd.Function):
                 _bn_timed(lambda: check(_dt('lec_bn_bwd_pass1', x.dtype)(dptr(dy), dptr(dy2), dptr(mask) if relu else None, dptr(x), M, Cc, dptr(save_mean),
                                                              dptr(save_invstd), dptr(dres), dptr(dgamma), dptr(dbeta), dptr(ws), ws.numel(),
                                                              stream_ptr())), nb1)
-            _LAZY_DX.clear()
-            _LAZY_DX[dx.data_ptr()] = {'g': dres, 'x': x, 'gamma': weight, 'mean': save_mean, 'invstd': save_invstd, 'M': M, 'C': Cc}
+            fusion().lazy_dx.clear()
+            fusion().lazy_dx[dx.data_ptr()] = {'g': dres, 'x': x, 'gamma': weight, 'mean': save_mean, 'invstd': save_invstd, 'M': M, 'C': Cc}
         elif pre:
             nbytes = el * es * 3                  # pass 2 only: read g, x; write dx (pass 1 ran in the convolution's epilogue)
             _bn_timed(lambda: check(_dt('lec_bn_bwd_prereduced', x.dtype)(dptr(dy), dptr(x), M, Cc, dptr(weight), dptr(save_mean), dptr(save_invstd), pre,
@@ -452,37 +541,13 @@ class BNActFn(torch.autograd.Function):
             _bn_timed(lambda: check(_dt('lec_bn_bwd', x.dtype)(dptr(dy), dptr(dy2), None, dptr(mask), dptr(x), M, Cc, dptr(weight), dptr(save_mean),
                                                    dptr(save_invstd), dptr(dx), dptr(dres), dptr(dgamma), dptr(dbeta), int(relu),
                                                    dptr(ws), ws.numel(), stream_ptr())), nbytes)
-        if has_res and ctx.res_ptr in _FORKS:     # this layer's residual is a forked block output: its consumer convolution's data
-            _FORKS[ctx.res_ptr]['dres'] = dres    # gradient can fold this gradient into its epilogue (conv1x1_dgrad_bnfold_rows)
+        if has_res and ctx.res_ptr in fusion().forks:     # this layer's residual is a forked block output: its consumer convolution's data
+            fusion().forks[ctx.res_ptr]['dres'] = dres    # gradient can fold this gradient into its epilogue (conv1x1_dgrad_bnfold_rows)
         if sink is not None:
             if sink[2] is not None:
                 sink[2].mark_ready(sink[0]); sink[2].mark_ready(sink[1])
             return dx, dres, None, None, None, None, None, None, None, None, None, None
         return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None
-
-
-# Backward of a forked block output z = relu(bn(x) + residual) (two consumers: the next block's conv1 and its identity branch):
-# pass 1 of the BatchNorm backward can run in the epilogue of conv1's data gradient (lec_conv1x1_dgrad_bnfold), which needs this
-# layer's saved tensors and the identity branch's gradient.  _FORKS: data_ptr of z -> those tensors (filled by forward, 'dres' by
-# the backward of the layer that took z as its residual, dropped by this layer's backward).  _FOLDED: data_ptr of a gradient that
-# already is g = mask * (dy + dy2) -> number of partial rows its producer left in the BatchNorm workspace.
-import os as _os
-FOLD_BN_BWD = _os.environ.get('LEC_FOLD_BN_BWD', '1') != '0'
-_FORKS = {}
-_FOLDED = {}
-# Forward of conv3 -> bn3 (+ identity, ReLU): the convolution first runs as a statistics-only pass (conv1x1_stats_rows) and hands
-# BNActFn an UNWRITTEN output tensor; _DEFERRED: data_ptr of that tensor -> (input rows, weight).  BNActFn.forward finalizes the
-# statistics and runs the convolution again with the BatchNorm apply in its epilogue, which writes both tensors.
-DEFER_BN_APPLY = _os.environ.get('LEC_DEFER_BN_APPLY', '1') != '0'
-_DEFERRED = {}
-# Backward of the same pair: pass 2 of bn3's backward runs inside conv3's weight-gradient kernel (lec_conv1x1_wgrad_bnapply).
-# _LAZY_OK: data_ptr of a BatchNorm input whose producer convolution can do that -> its input channels (filled by the
-# convolution's forward); _LAZY_DX: data_ptr of the UNWRITTEN dx BNActFn.backward returned -> what the kernel needs.
-LAZY_BN_PASS2 = _os.environ.get('LEC_LAZY_BN_PASS2', '1') != '0'
-_LAZY_OK = {}
-_LAZY_DX = {}
-_bn_ws = {}
-_BN_WS_OWNER = [0, 0]        # (data_ptr of the tensor whose statistics partials sit in the BN workspace, number of partial rows)
 
 
 def conv1x1_supported(cin, cout, M):
@@ -505,7 +570,7 @@ def conv3x3_c64(x, w_clast, want_stats=False, w_transposed=False):
             w_clast = w_clast.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
         check(lib.lec_conv3x3_c128_fwd(dptr(x), dptr(w_clast), n, h, w, dptr(y), *args, stream_ptr()))
     if want_stats:
-        _BN_WS_OWNER[0], _BN_WS_OWNER[1] = y.data_ptr(), k.value
+        fusion().ws_owner[0], fusion().ws_owner[1] = y.data_ptr(), k.value
     return y
 
 
@@ -536,7 +601,7 @@ def conv1x1_wgrad_rows(dy_rows, x_rows, dw):
 
 
 def bn_bwd_apply_lazy(rec, dx):
-    """Pass 2 of a BatchNorm backward whose dx was handed on unwritten (_LAZY_DX) and whose consumer cannot run it itself."""
+    """Pass 2 of a BatchNorm backward whose dx was handed on unwritten (fusion().lazy_dx) and whose consumer cannot run it itself."""
     ws = _bn_workspace(dx.device)
     check(_dt('lec_bn_bwd_apply', rec['x'].dtype)(dptr(rec['g']), dptr(rec['x']), rec['M'], rec['C'], dptr(rec['gamma']), dptr(rec['mean']), dptr(rec['invstd']),
                                dptr(dx), dptr(ws), ws.numel(), stream_ptr()))
@@ -544,7 +609,7 @@ def bn_bwd_apply_lazy(rec, dx):
 
 def conv1x1_wgrad_bnapply_rows(rec, x_rows, dx, dw):
     """dx (the UNWRITTEN gradient of a 1x1 layer's output, [N, Cout, H, W] channels_last) := pass 2 of the BatchNorm backward
-    described by rec (_LAZY_DX), and dw [Cout, Cin] (fp32) += dx^T x_rows, in one kernel (lec_conv1x1_wgrad_bnapply)."""
+    described by rec (fusion().lazy_dx), and dw [Cout, Cin] (fp32) += dx^T x_rows, in one kernel (lec_conv1x1_wgrad_bnapply)."""
     M, cin = x_rows.shape
     cout = rec['C']
     if dw.dtype != torch.float32 or dw.numel() != cout * cin or not dw.is_contiguous():
@@ -570,23 +635,23 @@ def conv1x1_stats_rows(x_rows, w2):
     ws = _bn_workspace(x_rows.device)
     n = C.c_int(0)
     check(lib.lec_conv1x1_stats(dptr(x_rows), dptr(w2), M, cin, cout, dptr(ws), ws.numel(), C.byref(n), stream_ptr()))
-    _BN_WS_OWNER[0], _BN_WS_OWNER[1] = y.data_ptr(), n.value
-    _DEFERRED.clear()
-    _DEFERRED[y.data_ptr()] = (x_rows, w2)
-    if len(_LAZY_OK) > 64:
-        _LAZY_OK.clear()
-    _LAZY_OK[y.data_ptr()] = cin              # this layer's backward can run the following BatchNorm's pass 2 in its weight gradient
+    fusion().ws_owner[0], fusion().ws_owner[1] = y.data_ptr(), n.value
+    fusion().deferred.clear()
+    fusion().deferred[y.data_ptr()] = (x_rows, w2)
+    if len(fusion().lazy_ok) > 64:
+        fusion().lazy_ok.clear()
+    fusion().lazy_ok[y.data_ptr()] = cin              # this layer's backward can run the following BatchNorm's pass 2 in its weight gradient
     return y
 
 
 def materialise_deferred(y):
     """A consumer other than the fused BatchNorm got hold of a tensor conv1x1_stats_rows left unwritten (stock-torch fallback of
     BatchNormAct2d, a hook, a debugger): run the plain convolution into it now.  No-op for every other tensor."""
-    dfr = _DEFERRED.pop(y.data_ptr(), None)
+    dfr = fusion().deferred.pop(y.data_ptr(), None)
     if dfr is not None:
         x_in, w2 = dfr
-        if _BN_WS_OWNER[0] == y.data_ptr():
-            _BN_WS_OWNER[0] = 0
+        if fusion().ws_owner[0] == y.data_ptr():
+            fusion().ws_owner[0] = 0
         check(lib.lec_conv1x1_fwd(dptr(x_in), dptr(w2), 0, x_in.shape[0], x_in.shape[1], w2.shape[0], dptr(y), None, 0, None, stream_ptr()))
     return y
 
@@ -598,7 +663,7 @@ def conv1x1_dgrad_bnfold_supported(cin, cout, M):
 def conv1x1_dgrad_bnfold_rows(gy_rows, w2_fwd, entry):
     """Data gradient of a 1x1 layer whose input is a forked block output, with pass 1 of that output's BatchNorm backward in
     the epilogue (lec_conv1x1_dgrad_bnfold).  gy_rows [M, Cconv_out], w2_fwd the layer's forward weight [Cconv_out, C],
-    entry: the _FORKS record of the block output.  Returns g [M, C] = mask * (gy w + d identity) and tags it for BNActFn."""
+    entry: the fusion().forks record of the block output.  Returns g [M, C] = mask * (gy w + d identity) and tags it for BNActFn."""
     M, cin = gy_rows.shape
     cout = w2_fwd.shape[1]
     if w2_fwd.shape[0] != cin:
@@ -612,9 +677,9 @@ def conv1x1_dgrad_bnfold_rows(gy_rows, w2_fwd, entry):
     n = C.c_int(0)
     check(lib.lec_conv1x1_dgrad_bnfold(dptr(gy_rows), dptr(w2_fwd), 1, M, cin, cout, dptr(dres), dptr(xb), dptr(mask), dptr(entry['mean']),
                                        dptr(entry['invstd']), dptr(g), dptr(ws), ws.numel(), C.byref(n), stream_ptr()))
-    _BN_WS_OWNER[0], _BN_WS_OWNER[1] = g.data_ptr(), n.value
-    _FOLDED.clear()
-    _FOLDED[g.data_ptr()] = n.value
+    fusion().ws_owner[0], fusion().ws_owner[1] = g.data_ptr(), n.value
+    fusion().folded.clear()
+    fusion().folded[g.data_ptr()] = n.value
     return g
 
 
@@ -632,7 +697,7 @@ def conv1x1_rows(x_rows, w2, want_stats=False, w_transposed=False):
         ws = _bn_workspace(x_rows.device)
         n = C.c_int(0)
         check(lib.lec_conv1x1_fwd(dptr(x_rows), dptr(w2), int(bool(w_transposed)), M, cin, cout, dptr(y), dptr(ws), ws.numel(), C.byref(n), stream_ptr()))
-        _BN_WS_OWNER[0], _BN_WS_OWNER[1] = y.data_ptr(), n.value
+        fusion().ws_owner[0], fusion().ws_owner[1] = y.data_ptr(), n.value
     else:
         check(lib.lec_conv1x1_fwd(dptr(x_rows), dptr(w2), int(bool(w_transposed)), M, cin, cout, dptr(y), None, 0, None, stream_ptr()))
     return y
@@ -680,7 +745,7 @@ def conv_f32_fwd(x, w, stride, pad, want_stats=False):
         ws = _bn_workspace(x.device); k = C.c_int(0)
         _conv_timed(lambda: check(lib.lec_conv_f32_fwd(dptr(x), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), dptr(ws), ws.numel(),
                                                        C.byref(k), stream_ptr())), flops)
-        _BN_WS_OWNER[0], _BN_WS_OWNER[1] = y.data_ptr(), k.value
+        fusion().ws_owner[0], fusion().ws_owner[1] = y.data_ptr(), k.value
     else:
         _conv_timed(lambda: check(lib.lec_conv_f32_fwd(dptr(x), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), None, 0, None, stream_ptr())), flops)
     return y
@@ -742,7 +807,7 @@ def conv_f32x3_fwd(x, planes, stride, pad, want_stats=False):
         ws = _bn_workspace(x.device); k = C.c_int(0)
         _conv_timed(lambda: check(lib.lec_conv_f32x3_fwd(dptr(x), dptr(planes.fwd), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), dptr(ws), ws.numel(),
                                                          C.byref(k), stream_ptr())), flops)
-        _BN_WS_OWNER[0], _BN_WS_OWNER[1] = y.data_ptr(), k.value
+        fusion().ws_owner[0], fusion().ws_owner[1] = y.data_ptr(), k.value
     else:
         _conv_timed(lambda: check(lib.lec_conv_f32x3_fwd(dptr(x), dptr(planes.fwd), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), None, 0, None, stream_ptr())), flops)
     return y
@@ -780,12 +845,8 @@ def conv_f32x3_wgrad(dy, x, dw, stride, pad):
 
 
 def _bn_workspace(device):
-    key = (device.type, device.index)
-    ws = _bn_ws.get(key)
-    if ws is None:
-        ws = torch.zeros(int(lib.lec_bn_workspace_bytes(2048)), dtype=torch.uint8, device=device)
-        _bn_ws[key] = ws
-    return ws
+    """The current FusionContext's BatchNorm workspace on `device` (statistics partials + coefficient table)."""
+    return fusion().workspace(device)
 
 
 # ------------------------------------------------------------------------------------------------ stem max pooling

@@ -246,6 +246,7 @@ def _from_rows(m, n, h, w):
 class _OverlapConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, conv):
+        ctx.fc = _ops().fusion()                  # the owning backbone's fusion records (ops.FusionContext); backward restores it
         w16 = WgradOverlap.instance.weight_lp(conv, x.dtype)
         nhwc = x.is_contiguous(memory_format=torch.channels_last)
         if nhwc and w16.dim() == 4 and not w16.is_contiguous(memory_format=torch.channels_last):
@@ -301,10 +302,15 @@ class _OverlapConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
+        with _ops().use_fusion(ctx.fc):
+            return _OverlapConvFn._backward(ctx, gy)
+
+    @staticmethod
+    def _backward(ctx, gy):
         x, w16 = ctx.saved_tensors; conv = ctx.conv
         gx = None
         wgrad_done = False
-        lz = _ops()._LAZY_DX.pop(gy.data_ptr(), None)
+        lz = _ops().fusion().lazy_dx.pop(gy.data_ptr(), None)
         if lz is not None:
             # gy is UNWRITTEN: the BatchNorm behind this layer left pass 2 of its backward to us.  With the flat arena's fp32 gradient
             # slot at hand the weight-gradient kernel does it on the way (and writes gy for the data gradient below); otherwise
@@ -336,7 +342,7 @@ class _OverlapConvFn(torch.autograd.Function):
             elif (ctx.own and nhwc_g and _ops().conv1x1_supported(conv.out_channels, conv.in_channels, gy.shape[0] * gy.shape[2] * gy.shape[3])):
                 n, _, h, wd = gy.shape                          # dX = dY * W: the same kernel, W transposed as it is loaded
                 ops = _ops()
-                fork = ops._FORKS.get(x.data_ptr()) if ops.FOLD_BN_BWD else None
+                fork = ops.fusion().forks.get(x.data_ptr()) if ops.FOLD_BN_BWD else None
                 if (fork is not None and fork['dres'] is not None and fork['x'].shape == x.shape and fork['dres'].shape == x.shape
                         and fork['dres'].dtype == torch.bfloat16 and fork['dres'].is_contiguous(memory_format=torch.channels_last)
                         and ops.conv1x1_dgrad_bnfold_supported(conv.out_channels, conv.in_channels, n * h * wd)):
@@ -351,9 +357,10 @@ class _OverlapConvFn(torch.autograd.Function):
             else:
                 gx = torch.ops.aten.convolution_backward(gy, x, w16, None, conv.stride, conv.padding, conv.dilation, False,
                                                          [0, 0], conv.groups, [True, False, False])[0]
-        if gx is not None and x.data_ptr() in _ops()._FORKS:   # x is a forked block output and this layer one of its two consumers
-            rec = _ops()._FORKS[x.data_ptr()]
-            if rec['dres'] is None and x.data_ptr() not in _ops()._FOLDED and gx.data_ptr() not in _ops()._FOLDED:
+        fc = _ops().fusion()
+        if gx is not None and x.data_ptr() in fc.forks:         # x is a forked block output and this layer one of its two consumers
+            rec = fc.forks[x.data_ptr()]
+            if rec['dres'] is None and x.data_ptr() not in fc.folded and gx.data_ptr() not in fc.folded:
                 rec['dres'] = gx                                # (the other consumer's data gradient may fold it into its epilogue)
         if not wgrad_done:
             WgradOverlap.instance.submit(gy, x, w16, conv)
@@ -421,14 +428,14 @@ class Bottleneck(nn.Module):
         self.conv1 = conv1x1(cin, planes); self.bn1 = BatchNormAct2d(planes, relu=True)
         self.conv2 = conv3x3(planes, planes, stride); self.bn2 = BatchNormAct2d(planes, relu=True)   # stride on the 3x3 (v1.5)
         self.conv3 = conv1x1(planes, planes * 4); self.bn3 = BatchNormAct2d(planes * 4, relu=True)  # relu(bn3(.) + identity)
-        self.conv3.defer_bn = True                             # forward() hands conv3's output to bn3 and to nothing else (ops._DEFERRED)
+        self.conv3.defer_bn = True                             # forward() hands conv3's output to bn3 and to nothing else (FusionContext.deferred)
         self.downsample = downsample
 
     def forward(self, x, fork=False):
         xa, xb = x if isinstance(x, tuple) else (x, x)          # two handles on the block input: conv path / identity path
         out = self.bn1(self.conv1(xa))
         # the downsample branch is built AFTER conv1 / bn1: autograd runs later-built nodes first, so in backward the branch's
-        # gradient into the block input exists before conv1's data gradient runs and can be folded into it (ops._FORKS)
+        # gradient into the block input exists before conv1's data gradient runs and can be folded into it (FusionContext.forks)
         idt = xb if self.downsample is None else self.downsample(xb)
         out = self.bn2(self.conv2(out))
         return self.bn3(self.conv3(out), idt, fork)
@@ -467,7 +474,25 @@ class ResNet(nn.Module):
     def forward(self, x):
         if x.is_cuda and torch.is_autocast_enabled() and x.dtype == torch.float32:
             x = x.to(torch.get_autocast_dtype('cuda'))          # the stem conv sees low-precision input like every other layer
-        _ops()._FORKS.clear(); _ops()._FOLDED.clear(); _ops()._DEFERRED.clear(); _ops()._LAZY_OK.clear(); _ops()._LAZY_DX.clear()   # records of a forward whose backward never ran (or raised)
+        if not x.is_cuda:
+            return self._forward(x)
+        # the fused paths' hand-off records and BatchNorm workspace of THIS instance (ops.FusionContext): a second backbone in the
+        # process, or another forward of this one between its forward and backward (the chunked step), has its own
+        fc = self.__dict__.get('_fusion')
+        if fc is None:
+            fc = self.__dict__['_fusion'] = _ops().FusionContext()
+        fc.reset()                                              # records of a forward whose backward never ran (or raised)
+        with _ops().use_fusion(fc):
+            return self._forward(x)
+
+    @property
+    def fusion(self):
+        fc = self.__dict__.get('_fusion')
+        if fc is None:
+            fc = self.__dict__['_fusion'] = _ops().FusionContext()
+        return fc
+
+    def _forward(self, x):
         x = self.maxpool(self.bn1(self.conv1(x)))
         blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
         for i, b in enumerate(blocks):

@@ -529,3 +529,69 @@ def test_deferred_conv3_output_is_materialised_for_the_stock_batchnorm_fallback(
     assert calls['defer'] == 3 and calls['filled'] == 3 and not ops._DEFERRED
     assert torch.isfinite(res['defer']).all()
     assert torch.equal(res['defer'], res['plain'])
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_two_backbones_interleaved_in_one_process_do_not_share_fusion_records(dtype):
+    """The fused paths hand work between autograd nodes through records keyed by tensor addresses and through a statistics workspace;
+    both belong to ONE backbone (ops.FusionContext, owned by the ResNet instance).  Two ResNet-50s alive in one process with their
+    passes interleaved -- A.forward, B.forward, B.backward, A.backward -- must give what each gives alone, with every fused path on
+    (folded BatchNorm backward, deferred conv3 apply, lazy pass 2 at bf16; statistics epilogues at fp32) and actually taken."""
+    from learning_embeddings_amd import resnet as R
+    from learning_embeddings_amd.resnet import WgradOverlap
+
+    def make(seed):
+        torch.manual_seed(seed)
+        m = R.resnet50(num_classes=10).to(DEV).to(memory_format=torch.channels_last).train()
+        for p_ in m.parameters():
+            p_.grad = torch.zeros_like(p_)
+        return m
+
+    def fwd(m, x):
+        if dtype == torch.bfloat16:
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                return m(x).float()
+        return m(x)
+
+    def grads(m):
+        WgradOverlap.instance.join(); torch.cuda.synchronize()
+        return [p_.grad.double().clone() for p_ in m.parameters()]
+
+    xs = [torch.rand(4, 3, 64, 64, device=DEV, generator=torch.Generator(DEV).manual_seed(5 + i)).contiguous(memory_format=torch.channels_last) for i in range(2)]
+    gs = [torch.randn(4, 10, device=DEV, generator=torch.Generator(DEV).manual_seed(9 + i)) for i in range(2)]
+    calls = {}
+    names = ['conv1x1_dgrad_bnfold_rows', 'conv1x1_stats_rows', 'conv1x1_wgrad_bnapply_rows', 'conv_f32_fwd']
+    origs = {n: getattr(ops, n) for n in names}
+    tag = ['alone']
+    for n in names:
+        def counted(*a, _n=n, **k):
+            calls[(tag[0], _n)] = calls.get((tag[0], _n), 0) + 1
+            return origs[_n](*a, **k)
+        setattr(ops, n, counted)
+    WgradOverlap.instance = WgradOverlap()
+    try:
+        alone = []
+        for i in range(2):
+            m = make(i); y = fwd(m, xs[i]); y.backward(gs[i]); alone.append((y.detach().double(), grads(m)))
+            assert not m.fusion.forks and not m.fusion.lazy_dx and not m.fusion.deferred
+        tag[0] = 'mixed'
+        A, B = make(0), make(1)
+        assert A.fusion is not B.fusion and A.fusion.workspace(xs[0].device).data_ptr() != B.fusion.workspace(xs[0].device).data_ptr()
+        ya = fwd(A, xs[0]); yb = fwd(B, xs[1])
+        if dtype == torch.bfloat16:
+            assert A.fusion.forks and B.fusion.forks and not (set(A.fusion.forks) & set(B.fusion.forks))
+        yb.backward(gs[1]); ya.backward(gs[0])
+        mixed = [(ya.detach().double(), grads(A)), (yb.detach().double(), grads(B))]
+    finally:
+        WgradOverlap.instance = None
+        for n in names:
+            setattr(ops, n, origs[n])
+    for n in names:                                                # the fused paths ran as often interleaved as alone
+        assert calls.get(('mixed', n), 0) == calls.get(('alone', n), 0), (n, calls)
+    assert calls.get(('alone', 'conv1x1_dgrad_bnfold_rows' if dtype == torch.bfloat16 else 'conv_f32_fwd'), 0) > 0, calls
+    cos = lambda a, b: torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
+    for (y1, g1), (y2, g2) in zip(alone, mixed):
+        assert torch.equal(y1, y2)                                 # forward: deterministic kernels, same workspace discipline
+        for a, b in zip(g1, g2):
+            if a.numel() > 1 and a.norm() > 0:
+                assert cos(a, b) > 0.9999, (a.shape, cos(a, b))

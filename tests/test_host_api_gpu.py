@@ -286,7 +286,7 @@ def test_joint_embeddings_fast_path_matches_plain_autograd(tmp_path, dtype):
 
 
 # ------------------------------------------------------------------------------------------------ DP on one GPU (gloo)
-def _dp_trainer_worker(rank, world, port, tmp, q):
+def _dp_trainer_worker(rank, world, port, tmp, q, half_half=False):
     import os, sys
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
                       MASTER_PORT=str(port), LEC_DIST_BACKEND='gloo')
@@ -305,7 +305,8 @@ def _dp_trainer_worker(rank, world, port, tmp, q):
     crit = m.EuclideanConesWithImagesHypernymLoss(lm, 5, {}, 0.05, True, K=0.1, use_CNN=True)
     tr = m.JointEmbeddings(gd, dl, image_dir='', use_CNN=True, labelmap=lm, criterion=crit, lr=1e-3, n_workers=0,
                            batch_size=8, experiment_name='dp', embedding_dim=10, neg_to_pos_ratio=5, image_fc7=None,
-                           normalize=None, alpha=0.05, experiment_dir=os.path.join(tmp, 'r%d' % rank), n_epochs=1, eval_interval=5)
+                           normalize=None, alpha=0.05, experiment_dir=os.path.join(tmp, 'r%d' % rank), n_epochs=1, eval_interval=5,
+                           half_half=half_half)
     negs = []
     orig = crit.negative_G.draw_batch
     def spy(f, t_, k):
@@ -316,12 +317,15 @@ def _dp_trainer_worker(rank, world, port, tmp, q):
     t.distributed.barrier(); t.distributed.destroy_process_group()
 
 
-def test_joint_embeddings_data_parallel_two_ranks_share_one_gpu(tmp_path):
+@pytest.mark.parametrize('half_half', [False, True])
+def test_joint_embeddings_data_parallel_two_ranks_share_one_gpu(tmp_path, half_half):
+    """(half_half=True: oe_h.py:683-726's alternating label-label / label-image batches under data parallelism -- every rank maps the
+    global batch's item indices to edges with the dataset's own item -> edge rule.)"""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context('spawn'); q = ctx.Queue()
-    procs = [ctx.Process(target=_dp_trainer_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_trainer_worker, args=(r, 2, port, str(tmp_path), q, half_half)) for r in range(2)]
     for p in procs: p.start()
     res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda r: r[0])
     for p in procs: p.join(120)
@@ -767,7 +771,7 @@ def test_classification_metrics_and_reconstruction_vs_bruteforce(tmp_path):
     assert abs(best[0] - max(f1s)) < 1e-4
 
 
-def _dp_engine_worker(rank, world, port, overlap, q, graph=False):
+def _dp_engine_worker(rank, world, port, overlap, q, graph=False, chunk=None):
     import os, sys
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
                       MASTER_PORT=str(port), LEC_DIST_BACKEND='gloo')
@@ -775,7 +779,8 @@ def _dp_engine_worker(rank, world, port, overlap, q, graph=False):
     sys.path.insert(0, ROOT)
     import torch as t
     from learning_embeddings_amd.engine import StepEngine as SE
-    eng = SE('tiny', n_images=64, dtype='bf16', overlap_wgrad=overlap, use_graph=graph, graph_after=1)
+    eng = SE('tiny', n_images=64, dtype='bf16' if chunk is None else 'fp32', overlap_wgrad=overlap, use_graph=graph, graph_after=1, cnn_chunk=chunk)
+    assert eng.cnn_chunk == chunk
     negs = []
     for _ in range(3):
         eng.step(); negs.append(eng.last[5].copy())
@@ -785,17 +790,19 @@ def _dp_engine_worker(rank, world, port, overlap, q, graph=False):
     t.distributed.barrier(); eng.close(); t.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize('overlap,graph', [(False, False), (True, False), (True, True)])
-def test_step_engine_data_parallel_replicas_stay_identical(overlap, graph):
+@pytest.mark.parametrize('overlap,graph,chunk', [(False, False, None), (True, False, None), (True, True, None), (True, False, 8)])
+def test_step_engine_data_parallel_replicas_stay_identical(overlap, graph, chunk):
     """StepEngine under DP (2 ranks sharing the GPU over gloo), with the shadow-weight / direct-gradient path and with the
     side-stream weight gradients, and with the hipGraph launch mode (all-reduce after the replay): after 3 steps both ranks
     hold bit-identical CNN parameters and label table, and each rank's negatives are its slice of the single-process
-    global stream."""
+    global stream.  chunk=8: the CNN rows in two chunks per step (engine.cnn_chunk, fp32) -- one backward per chunk into the same
+    gradient slots: the buckets are reduced ONCE, after the last chunk (a reducer that fires after chunk 0 leaves the later chunks'
+    gradients local and the replicas drift apart)."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context('spawn'); q = ctx.Queue()
-    procs = [ctx.Process(target=_dp_engine_worker, args=(r, 2, port, overlap, q, graph)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_engine_worker, args=(r, 2, port, overlap, q, graph, chunk)) for r in range(2)]
     for p in procs: p.start()
     res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda r: r[0])
     for p in procs: p.join(120)
@@ -952,3 +959,23 @@ def test_step_engine_gradient_exchange_through_the_c_abi_rccl_layer():
     assert graphed and np.allclose(ls, ls_ref, rtol=1e-5)
     assert np.abs(table - ref.table.cpu().numpy()).max() < 1e-6
     ref.close()
+
+
+def test_bench_gpus_2_self_launches_on_one_gpu():
+    """The driver's plain command for N > 1, `python bench.py --gpus 2 ...` with no torchrun environment: bench.py starts the two ranks
+    itself (children of `python -m torch.distributed.run`), they share this box's single GPU (so the gradient exchange runs over gloo:
+    the launcher says so), and rank 0 prints ONE JSON line that reports the group it actually reduced over and identical replicas."""
+    import json, subprocess, sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '4', '--workload', 'tiny',
+                        '--secondary', 'none', '--through-trainer', '0', '--no-stress', '--no-cpu-baseline'],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['rccl_ranks'] == 2 and out['steps'] == 3 and out['scaling'] == 'weak'
+    dp = out['data_parallel']
+    assert dp['world_size'] == 2 and dp['replicas_identical_after_run'] is True and len(dp['buckets']) >= 2
+    assert out['config']['global_batch'] == 2 * 8 and out['value'] > 0

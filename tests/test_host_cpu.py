@@ -122,6 +122,8 @@ def _dp_worker(rank, world, port, q):
     net(X[lo:hi]).pow(2).sum().backward()                          # SUM loss over the shard
     table_grad += float(rank + 1)
     red.finish()
+    buckets = red.time_buckets(reps=2)                             # bench.py's per-bucket timing leaves the gradients as they were
+    assert len(buckets) == len(red.buckets) + 1 and all(b['ms'] >= 0 for b in buckets)
     # sampler: replicated mode -> shard of the global stream
     lm = LM([2, 4, 8])
     g = NG.from_labelmap(lm, n_images=16, pick_per_level=True, seed=0)
@@ -136,8 +138,8 @@ def _dp_worker(rank, world, port, q):
     torch.distributed.destroy_process_group()
 
 
-def test_dp_two_ranks_gloo_sum_allreduce_and_replicated_sampler():
-    world = 2
+@pytest.mark.parametrize('world', [2, 4])
+def test_dp_two_ranks_gloo_sum_allreduce_and_replicated_sampler(world):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
@@ -153,7 +155,7 @@ def test_dp_two_ranks_gloo_sum_allreduce_and_replicated_sampler():
     net(X).pow(2).sum().backward()
     for r in range(world):
         assert np.allclose(res[r][1], arena.grad.numpy(), rtol=1e-5, atol=1e-6)      # SUM (not mean) of shard grads
-        assert np.allclose(res[r][2], 3.0)                                             # extras ride along: 1 + 2
+        assert np.allclose(res[r][2], world * (world + 1) / 2)                         # extras ride along: 1 + 2 (+ 3 + 4)
     # negatives: concatenating the rank shards reproduces the single-process global stream bit for bit
     lm = SyntheticLabelMap([2, 4, 8])
     g = NegativeGraph.from_labelmap(lm, n_images=16, pick_per_level=True, seed=0)
@@ -364,3 +366,24 @@ def test_embedding_metrics_match_reference_fixture_including_nan_energies():
     assert np.isnan(z['neg_e']).sum() == 41                      # the zero row as an apex: one NaN per other node
     got = EmbeddingMetrics(torch.from_numpy(z['pos_e']), torch.from_numpy(z['neg_e']), 0.0, 'val').calculate_metrics()
     assert np.array_equal(np.asarray(got, dtype=np.float64), np.asarray(fx['reconstruction']))
+
+
+def test_bench_self_launch_starts_the_ranks_as_children(tmp_path):
+    """`python bench.py --gpus N` without a torchrun environment (the driver's plain command): bench.self_launch starts N ranks through
+    `python -m torch.distributed.run` as CHILD processes (never an exec), every rank sees RANK / WORLD_SIZE / MASTER_*, rank 0's single
+    line reaches stdout, and a failing rank makes the launcher's exit code non-zero.  Run here with a stand-in script (no GPU)."""
+    import subprocess
+    script = tmp_path / 'rank_script.py'
+    script.write_text('import os, sys, json\n'
+                      'r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])\n'
+                      'assert os.environ["MASTER_ADDR"] == "127.0.0.1" and "LOCAL_RANK" in os.environ\n'
+                      'if "--fail" in sys.argv and r == 1: sys.exit(3)\n'
+                      'if r == 0: print(json.dumps({"n_gpus": w, "argv": sys.argv[1:]}), flush=True)\n')
+    code = ('import sys; sys.path.insert(0, %r); import bench; sys.exit(bench.self_launch(2, script=%r, argv=sys.argv[1:], extra_env={"LEC_BENCH_NO_GPU_PROBE": "1"}))'
+            % (ROOT, str(script)))
+    ok = subprocess.run([sys.executable, '-c', code, '--gpus', '2', '--steps', '3'], capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    lines = [l for l in ok.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and json.loads(lines[0]) == {'n_gpus': 2, 'argv': ['--gpus', '2', '--steps', '3']}
+    bad = subprocess.run([sys.executable, '-c', code, '--fail'], capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0
