@@ -377,6 +377,32 @@ int lec_conv_f32_fwd(const float* x, const float* w, int N, int H, int W, int Ci
                      float* y, float* partials, int64_t partials_bytes, int* n_partials, lec_stream_t stream);
 int lec_conv_f32_dgrad(const float* dy, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                        float* dx, lec_stream_t stream);
+/*     Fused BatchNorm pieces (the fp32 convolutions are bound by the matrix pipe and leave HBM idle; BatchNorm passes are the reverse:
+ *     what moves from a BatchNorm pass into a convolution's loader or epilogue is hidden).  torchvision Bottleneck's
+ *     relu(bn(conv(.))) chain reached from oe_h.py:311,317, backward:
+ *     lec_conv_f32_dgrad_fused (stride-1 layers):
+ *       xsrc, coef (both or neither; 1x1 / pad 0): `dy` holds g, the masked gradient of the BatchNorm output behind this layer, xsrc
+ *         that BatchNorm's input; the kernel forms dy = coef[0][c] g + coef[1][c] xsrc + coef[2][c] while loading (coef [3][Cout]
+ *         from lec_bn_bwd_coeffs_f32): pass 2 of that BatchNorm's backward never runs as a kernel;
+ *       xbn, mean, invstd, partials, n_partials (all or none; dres, mask optional): the kernel writes g = mask * (dx + dres) instead of
+ *         dx -- pass 1 of the backward of the BatchNorm whose OUTPUT this layer consumed (xbn: its input [N, H, W, Cin]; mask: the ReLU
+ *         bitmask lec_bn_fwd_f32 wrote; dres: the gradient from the output's other consumer) -- and leaves n_partials (HOST int,
+ *         <= 512) rows of per-channel partial sums [2][Cin] (sum g, sum g * xhat) in `partials` for lec_bn_bwd_coeffs_f32 /
+ *         lec_bn_bwd_finalize.
+ *     lec_conv_f32_wgrad_fused: the same on-load form for the weight gradient of a 1x1 / stride 1 / pad 0 layer.
+ *     lec_bn_bwd_coeffs_f32: sums the partials -> dgamma, dbeta (overwritten) and coef[3][C] = (gamma invstd, -gamma invstd^2 c2,
+ *         gamma invstd (invstd c2 mean - c1)) with c1 = dbeta / M, c2 = dgamma / M, so that dx = coef0 g + coef1 x + coef2. */
+int lec_conv_f32_dgrad_fused(const float* dy, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                             float* dx, const float* xsrc, const float* coef, const float* dres, const float* xbn, const uint8_t* mask,
+                             const float* mean, const float* invstd, float* partials, int64_t partials_bytes, int* n_partials,
+                             lec_stream_t stream);
+int lec_conv_f32_wgrad_fused(const float* dy, const float* x, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                             float* dw, const float* xsrc, const float* coef, lec_stream_t stream);
+int lec_bn_bwd_pass1_coeffs_f32(const void* dy, const void* dy2, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* gamma,
+                                const float* save_mean, const float* save_invstd, void* g, float* dgamma, float* dbeta, float* coef,
+                                void* workspace, int64_t workspace_bytes, lec_stream_t stream);   /* pass 1 as a kernel (writes g) + the same coefficients */
+int lec_bn_bwd_coeffs_f32(int64_t M, int C, int n_partials, const float* gamma, const float* save_mean, const float* save_invstd,
+                          float* dgamma, float* dbeta, float* coef, void* workspace, int64_t workspace_bytes, lec_stream_t stream);
 int lec_conv_f32_wgrad(const float* dy, const float* x, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                        float* dw, lec_stream_t stream);
 

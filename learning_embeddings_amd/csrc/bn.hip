@@ -377,6 +377,21 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk,
   c1[c] = (float)(s / (double)M); c2[c] = (float)(q / (double)M);
 }
 
+// the same finalize for consumers that run pass 2 on their operand load (lec_conv_f32_dgrad_fused / _wgrad_fused): pass 2 is
+// dx = gamma invstd (g - c1 - xhat c2), xhat = (x - mean) invstd, i.e. dx = A g + B x + D with the per-channel A, B, D written here
+__global__ void bn_bwd_coeffs_kernel(const float* __restrict__ part, int nblk, int C, int64_t M, const float* __restrict__ gamma,
+                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+  const int c = blockIdx.x * kFinCh + threadIdx.x % kFinCh, split = threadIdx.x / kFinCh;
+  double s, q;
+  reduce_partials_256(part, nblk, C, c, split, s, q);
+  if (split != 0 || c >= C) return;
+  dbeta[c] = (float)s; dgamma[c] = (float)q;
+  const double c1 = s / (double)M, c2 = q / (double)M;
+  const double is = (double)invstd[c], gs = (double)gamma[c] * is;
+  coef[c] = (float)gs; coef[C + c] = (float)(-gs * is * c2); coef[2 * C + c] = (float)(gs * (is * c2 * (double)mean[c] - c1));
+}
+
 // backward, pass 2: dx = gamma*invstd * (g - mean(g) - xhat * mean(g*xhat));  d residual = g
 template <typename E, bool RES, int RELU>
 __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(const void* __restrict__ dy, const void* __restrict__ dy2,
@@ -552,6 +567,40 @@ extern "C" int lec_bn_bwd_finalize(int64_t M, int C, int n_partials, float* dgam
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, (hipStream_t)stream, part, n_partials, C, M, dgamma, dbeta,
                      c1, c2);
   LEC_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+  return LEC_OK;
+}
+
+extern "C" int lec_bn_bwd_coeffs_f32(int64_t M, int C, int n_partials, const float* gamma, const float* save_mean, const float* save_invstd,
+                                     float* dgamma, float* dbeta, float* coef, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+  using namespace lec;
+  if (int rc = bn_check("bn_bwd_coeffs", M, C)) return rc;
+  LEC_CHECK_ARG(gamma && save_mean && save_invstd && dgamma && dbeta && coef && workspace, "bn_bwd_coeffs: null pointer");
+  LEC_CHECK_ARG(n_partials >= 1 && n_partials <= kBnMaxBlocks, "bn_bwd_coeffs: n_partials=%d outside 1..%d", n_partials, kBnMaxBlocks);
+  LEC_CHECK_ARG(workspace_bytes >= lec_bn_workspace_bytes(C), "bn_bwd_coeffs: workspace too small");
+  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, (hipStream_t)stream, (const float*)workspace, n_partials, C, M,
+                     gamma, save_mean, save_invstd, dgamma, dbeta, coef);
+  LEC_CHECK_LAUNCH("bn_bwd_coeffs_kernel");
+  return LEC_OK;
+}
+
+// pass 1 (writes g = mask * (dy [+ dy2])) + the coefficient finalize, for a consumer that runs pass 2 on its operand load
+extern "C" int lec_bn_bwd_pass1_coeffs_f32(const void* dy, const void* dy2, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* gamma,
+                                           const float* save_mean, const float* save_invstd, void* g, float* dgamma, float* dbeta, float* coef,
+                                           void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+  using namespace lec;
+  typedef EF32 E;
+  if (int rc = bn_check("bn_bwd_pass1_coeffs", M, C)) return rc;
+  LEC_CHECK_ARG(dy && x && gamma && save_mean && save_invstd && g && dgamma && dbeta && coef && workspace, "bn_bwd_pass1_coeffs: null pointer");
+  LEC_CHECK_ARG(workspace_bytes >= lec_bn_workspace_bytes(C), "bn_bwd_pass1_coeffs: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  BnGeom geo = bn_geom(M, C);
+  float* part = (float*)workspace;
+#define R(M_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<E, M_>), dim3(geo.nrb, geo.NCH), dim3(kBnThreads), 0, st, dy, dy2, relu_mask, x, M, C, geo.CV, geo.CVB, geo.RPIB, save_mean, save_invstd, part, g)
+  if (relu_mask) R(2); else R(0);
+#undef R
+  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, geo.nrb, C, M, gamma, save_mean, save_invstd,
+                     dgamma, dbeta, coef);
+  LEC_CHECK_LAUNCH("bn_bwd_pass1_coeffs kernels");
   return LEC_OK;
 }
 

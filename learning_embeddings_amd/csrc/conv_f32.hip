@@ -90,9 +90,26 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ sA, const fl
 // forward / data gradient: A = gathered activations (k contiguous), B = weights (k contiguous: forward; k slow: data gradient)
 // TAPV: the tap of a 16-byte piece varies inside a chunk (source channels < chunk width: the stem's 4 channels, 8 taps per
 // chunk); otherwise a chunk lies inside ONE tap and everything but the per-row validity bit and one add per piece is scalar.
-template <bool B_KC, int WM, int WN, int TM, int TN, bool STATS, bool TAPV>
+// Fused BatchNorm pieces (round 3).  At fp32 the convolutions are bound by the matrix pipe and leave HBM idle, the BatchNorm passes are
+// bound by HBM and leave the matrix pipe idle: bytes moved from a BatchNorm pass into a convolution's loader or epilogue are hidden.
+//   XF (A operand on load, 1x1 layers): the kernel is handed g and the BatchNorm input x instead of dy and forms
+//       dy = cA[c] * g + cB[c] * x + cD[c]   (pass 2 of the BatchNorm backward BEHIND this layer; c = channel of dy = the k index)
+//     per 16-byte piece on its way from registers to LDS (coefficients from lec_bn_bwd_coeffs_f32: three 16-byte loads per chunk).
+//   FOLD (epilogue, dense destination): instead of dx the kernel writes g = mask * (dx + dres) -- pass 1 of the backward of the
+//     BatchNorm IN FRONT of this layer (whose output this layer consumed; dres = the gradient of that output's other consumer) -- and
+//     leaves the per-channel partials sum g, sum g * xhat (xhat from that BatchNorm's input) in lec_bn_bwd_f32's workspace layout.
+struct ActFuse {
+  const float* xsrc; const float* coef;                       // XF: second source tensor (same geometry as src), coefficients [3][Cs]
+  const float* dres; const float* xbn; const unsigned char* mask; const float* mean; const float* invstd;   // FOLD
+  uint32_t mask_bytes;
+};
+
+template <bool B_KC, int WM, int WN, int TM, int TN, bool STATS, bool TAPV, int FUSE = 0>
 __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
-                                                                     float* __restrict__ dst, ActGeo g, float* __restrict__ part) {
+                                                                     float* __restrict__ dst, ActGeo g, float* __restrict__ part,
+                                                                     ActFuse fz) {
+  constexpr bool XF = (FUSE & 1) != 0, FOLD = (FUSE & 2) != 0;
+  static_assert(!(XF && TAPV) && !(FOLD && STATS), "fused modes: one tap per chunk; one statistics epilogue at a time");
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   static_assert(WM * WN == 4, "four waves per workgroup");
   constexpr int NA = BM * kCfKQ / kCfThreads;                 // 16-byte pieces of the A tile per thread
@@ -109,6 +126,7 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
   const int kqA = tid & (kCfKQ - 1);                          // this thread's 16-byte column of a k-contiguous tile
   const int rowA = tid / kCfKQ;                               // ... and its first row (further rows: + kCfRP u)
   const rsrc_t rs_src = make_rsrc(src, g.src_bytes), rs_wgt = make_rsrc(wgt, g.wgt_bytes), rs_dst = make_rsrc(dst, g.dst_bytes);
+  const rsrc_t rs_x2 = make_rsrc(XF ? fz.xsrc : src, g.src_bytes), rs_coef = make_rsrc(XF ? fz.coef : src, XF ? (uint32_t)(3 * g.Cs * 4) : 0u);
   float st_s[TN], st_q[TN];
 #pragma unroll
   for (int jt = 0; jt < TN; ++jt) { st_s[jt] = 0.f; st_q[jt] = 0.f; }
@@ -162,6 +180,7 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
         for (int r = 0; r < 16; ++r) acc[it][jt][r] = 0.f;
 
     f32x4v ra[NA], rb[NB];
+    f32x4v rx[XF ? NA : 1], cfA, cfB, cfD;                      // XF: the second source's pieces and the chunk's coefficient vectors
     unsigned cur[NA];                                           // byte offset of this thread's A pieces at channel 0 of the CURRENT tap (kOob: no such pixel)
     int cur_tap = -1;
     auto load_chunk = [&](int ch) {
@@ -182,6 +201,12 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
         const unsigned c0b = (unsigned)c0 * 4u;
 #pragma unroll
         for (int u = 0; u < NA; ++u) ra[u] = bload4(rs_src, cur[u] + c0b);         // (a poisoned offset stays out of range: c0b < 2^14)
+        if (XF) {
+#pragma unroll
+          for (int u = 0; u < NA; ++u) rx[u] = bload4(rs_x2, cur[u] + c0b);
+          const unsigned cb = c0b + 16u * (unsigned)kqA, cs4 = (unsigned)g.Cs * 4u;
+          cfA = bload4(rs_coef, cb); cfB = bload4(rs_coef, cb + cs4); cfD = bload4(rs_coef, cb + 2u * cs4);
+        }
 #pragma unroll
         for (int u = 0; u < NB; ++u) rb[u] = bload4(rs_wgt, wB[u] + wsc);          // (likewise: wsc < 2^30)
         return;
@@ -221,6 +246,12 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
     };
     auto store_chunk = [&](int buf) {
       char* base = (char*)smem + buf * (SA + SB) * 4;
+      if (XF) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ra[u][e] = __builtin_fmaf(cfA[e], ra[u][e], __builtin_fmaf(cfB[e], rx[u][e], cfD[e]));
+      }
 #pragma unroll
       for (int u = 0; u < NA; ++u) *(f32x4v*)(base + ldsA + u * kCfRP * kCfLdk * 4) = ra[u];
 #pragma unroll
@@ -245,6 +276,57 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
     // epilogue: rows on the registers, 32 consecutive channels on the lanes; out-of-range rows / channels carry the kOob bit and
     // are dropped by the buffer's range check
     const int l31 = lane & 31, h = lane >> 5;
+    if (FOLD) {
+      // g = mask * (acc + dres), partial sums of g and g * xhat per channel; dense destination (host-checked).  A lane's TN columns:
+      // channel c -> (mean, invstd) and the position of its ReLU bit in lec_bn_fwd_f32's mask bytes: a thread-vector of that pass holds
+      // channels 4 cv .. + 3 (bits 0-3) and Cd / 2 + 4 cv .. + 3 (bits 4-7); byte index = row * (Cd / 8) + cv.
+      const rsrc_t rs_dres = make_rsrc(fz.dres ? fz.dres : dst, fz.dres ? g.dst_bytes : 0u), rs_xbn = make_rsrc(fz.xbn, g.dst_bytes);
+      const rsrc_t rs_mask = make_rsrc(fz.mask ? (const void*)fz.mask : (const void*)dst, fz.mask ? fz.mask_bytes : 0u);
+      const bool has_mask = fz.mask != nullptr;
+      const unsigned rowbytes = (unsigned)g.Cd * 4u, cvrow = (unsigned)g.Cd >> 3;
+      float mu[TN], is[TN]; unsigned coff[TN], mcv[TN], mbit[TN];
+#pragma unroll
+      for (int jt = 0; jt < TN; ++jt) {
+        const int c = n0 + wn0 + jt * 32 + l31; const bool okc = c < g.Cd;
+        mu[jt] = okc ? fz.mean[c] : 0.f; is[jt] = okc ? fz.invstd[c] : 0.f;
+        coff[jt] = okc ? (unsigned)c * 4u : kOob;
+        const int hc = g.Cd >> 1; const int cc = c < hc ? c : c - hc;
+        mcv[jt] = (unsigned)(cc >> 2); mbit[jt] = (unsigned)((cc & 3) + (c < hc ? 0 : 4));
+      }
+#pragma unroll
+      for (int it = 0; it < TM; ++it) {
+#pragma unroll
+        for (int r8 = 0; r8 < 16; r8 += 8) {
+          float dv[8][TN], xv[8][TN]; unsigned mb[8][TN];
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) {
+            const int r = r8 + rr;
+            const int m = m0 + wm0 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const unsigned poff = m < g.Mg ? (unsigned)m * rowbytes : kOob;
+#pragma unroll
+            for (int jt = 0; jt < TN; ++jt) {
+              const unsigned off = (poff + coff[jt]) | ((poff | coff[jt]) & kOob);
+              dv[rr][jt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dres, (int)off, 0, 0));
+              xv[rr][jt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_xbn, (int)off, 0, 0));
+              mb[rr][jt] = has_mask ? (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_mask, (int)(m < g.Mg ? (unsigned)m * cvrow + mcv[jt] : kOob), 0, 0) : 0xffu;
+            }
+          }
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) {
+            const int r = r8 + rr;
+            const int m = m0 + wm0 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const unsigned poff = m < g.Mg ? (unsigned)m * rowbytes : kOob;
+#pragma unroll
+            for (int jt = 0; jt < TN; ++jt) {
+              float a = acc[it][jt][r] + dv[rr][jt];
+              a = ((mb[rr][jt] >> mbit[jt]) & 1u) && m < g.Mg ? a : 0.f;
+              st_s[jt] += a; st_q[jt] += a * ((xv[rr][jt] - mu[jt]) * is[jt]);
+              bstore1(a, rs_dst, (poff + coff[jt]) | ((poff | coff[jt]) & kOob));
+            }
+          }
+        }
+      }
+    } else
     // Full tiles of a dense destination (the common case): one vector add per accumulator row, the column block as the store's immediate
     // offset, no per-row branch.  (The general path below spent 64 uniform branches and ~6 vector instructions per row on every tile.)
     if (dense_dst && m0 + BM <= g.Mg && n0 + BN <= g.Cd) {
@@ -292,7 +374,7 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
     }
   }
 
-  if (STATS) {
+  if (STATS || FOLD) {
     // lane halves -> waves of the same column block -> one partial row per workgroup: part[blockIdx.x][2][Cd]
     __syncthreads();
     float* red = smem;                                          // [WM][2 stats][BN]
@@ -321,9 +403,11 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
 // The tile is 64 (co) x 256 (tap, ci): a 256-wide B row is ONE wave-instruction (64 lanes x 16 bytes), so the pixel a piece
 // belongs to is wave-uniform and its decode runs on the scalar ALU; per lane only the (static) tap of its four columns matters.
 
-template <int WM, int WN, int TM, int TN, int WBK, bool DENSE>
+template <int WM, int WN, int TM, int TN, int WBK, bool DENSE, bool XF = false>
 __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                                       float* __restrict__ dw, WgGeo g) {
+                                                                       float* __restrict__ dw, WgGeo g, const float* __restrict__ xsrc = nullptr,
+                                                                       const float* __restrict__ coef = nullptr) {
+  static_assert(!XF || DENSE, "the on-load BatchNorm form serves the dense (1x1 / stride 1) layers");
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   static_assert(WM * WN == 4, "four waves per workgroup");
   static_assert(DENSE || BN == 256, "a gathered B row must be one wave-instruction (256 columns) for the scalar pixel decode");
@@ -338,6 +422,7 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const flo
   const int ntn = (g.Ng + BN - 1) / BN;
   const int nchunks_all = (g.Mpix + WBK - 1) / WBK;
   const rsrc_t rs_dy = make_rsrc(dy, g.dy_bytes), rs_x = make_rsrc(x, g.x_bytes);
+  const rsrc_t rs_x2 = make_rsrc(XF ? xsrc : dy, g.dy_bytes);
   // work items = (output tile, K split); a workgroup walks its share when LEC_WGRAD_WGS caps the grid.  (Measured on the fp32 step:
   // one workgroup per CU leaves the main stream's HBM-bound BatchNorm kernels room -- their time drops 63.8 -> 50.9 ms -- but the
   // convolutions beside it stretch more than that: 164.7 ms per step against 157.0 uncapped, so the default is no cap.)
@@ -361,6 +446,19 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const flo
   for (int u = 0; u < NA; ++u) {
     const int v = tid + kCfThreads * u; const int kr = v / PA, cq = v - kr * PA; const int co = co0 + 4 * cq;
     aoff[u] = co < g.Cout ? (unsigned)(kr * g.Cout + co) * 4u : kOob;
+  }
+  // XF: dy = cA * g + cB * xsrc + cD per output channel; a thread's A pieces keep their four channels for the whole work item
+  f32x4v cfA[XF ? NA : 1], cfB[XF ? NA : 1], cfD[XF ? NA : 1];
+  if (XF) {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int v = tid + kCfThreads * u; const int cq = v % PA; const int co = co0 + 4 * cq;
+      const bool ok = co < g.Cout;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        cfA[u][e] = ok ? coef[co + e] : 0.f; cfB[u][e] = ok ? coef[g.Cout + co + e] : 0.f; cfD[u][e] = ok ? coef[2 * g.Cout + co + e] : 0.f;
+      }
+    }
   }
   // B pieces.  DENSE (1x1 / stride 1: the source pixel of m is m): like A, on x.  Otherwise k row = wave + 4 u (wave-uniform),
   // columns j0 + 4 lane .. + 3 (inside one tap: Cin % 4 == 0), whose tap is a per-lane constant.
@@ -386,12 +484,16 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const flo
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[it][jt][r] = 0.f;
 
-  f32x4v ra[NA], rb[NB];
+  f32x4v ra[NA], rb[NB], rx[XF ? NA : 1];
   auto load_chunk = [&](int ch) {
     const int mbase = ch * WBK;
     const unsigned abase = (unsigned)(mbase * g.Cout) * 4u;
 #pragma unroll
     for (int u = 0; u < NA; ++u) ra[u] = bload4(rs_dy, aoff[u] + abase);
+    if (XF) {
+#pragma unroll
+      for (int u = 0; u < NA; ++u) rx[u] = bload4(rs_x2, aoff[u] + abase);
+    }
     if (DENSE) {
       const unsigned bbase = (unsigned)(mbase * g.Cin) * 4u;
 #pragma unroll
@@ -412,6 +514,12 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const flo
   };
   auto store_chunk = [&](int buf) {
     char* base = (char*)smem + buf * (SA + SB) * 4;
+    if (XF) {                                                   // (rows past Mpix become cD: their X rows are zero, the products vanish)
+#pragma unroll
+      for (int u = 0; u < NA; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ra[u][e] = __builtin_fmaf(cfA[u][e], ra[u][e], __builtin_fmaf(cfB[u][e], rx[u][e], cfD[u][e]));
+    }
 #pragma unroll
     for (int u = 0; u < NA; ++u) *(f32x4v*)(base + (tid + kCfThreads * u) * 16) = ra[u];
 #pragma unroll
@@ -449,26 +557,31 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const flo
 }
 
 
-template <bool B_KC, bool STATS>
-static int launch_act(const float* src, const float* wgt, float* dst, const ActGeo& g, float* part, int* nparts, hipStream_t st) {
+template <bool B_KC, bool STATS, int FUSE = 0>
+static int launch_act(const float* src, const float* wgt, float* dst, const ActGeo& g, float* part, int* nparts, hipStream_t st,
+                      const ActFuse& fz = ActFuse{}) {
   // column tile: 128 wide unless the layer has 64 output channels
   const bool narrow = g.Cd <= 64;
   const int BM = 128, BN = narrow ? 64 : 128;
   const int mtiles = (g.Mg + BM - 1) / BM, ntiles = (g.Cd + BN - 1) / BN;
   int gx = mtiles;
-  if (STATS) { const int cap = kCfMaxPart; if (gx > cap) gx = cap; }
+  if (STATS || (FUSE & 2)) { const int cap = kCfMaxPart; if (gx > cap) gx = cap; }
   else { const int cap = 2048 / (ntiles > 8 ? 8 : ntiles); if (gx > cap) gx = cap; }
   if (gx < 1) gx = 1;
   size_t lds = (size_t)2 * (BM * kCfLdk + (B_KC ? BN * kCfLdk : kCfBK * BN)) * 4;      // 74 / 55 KB: two workgroups per CU
   if (const char* e = getenv("LEC_CF_LDS_PAD")) lds += (size_t)atoi(e);                // experiments: force one workgroup per CU
   const bool tapv = g.Cs % kCfBK != 0;                          // source channels narrower than a chunk (the stem)
   LEC_CHECK_ARG(tapv || g.na * g.nb <= 32, "conv_f32: more than 32 taps per launch need the per-piece tap path");
-  if (tapv) {
-    if (narrow) hipLaunchKernelGGL((conv_f32_act_kernel<B_KC, 2, 2, 2, 1, STATS, true>), dim3(gx, ntiles), dim3(kCfThreads), lds, st, src, wgt, dst, g, part);
-    else hipLaunchKernelGGL((conv_f32_act_kernel<B_KC, 2, 2, 2, 2, STATS, true>), dim3(gx, ntiles), dim3(kCfThreads), lds, st, src, wgt, dst, g, part);
+  if (FUSE != 0) {
+    LEC_CHECK_ARG(!tapv, "conv_f32: the fused modes need source channels that are a multiple of the K chunk (%d)", kCfBK);
+    if (narrow) hipLaunchKernelGGL((conv_f32_act_kernel<B_KC, 2, 2, 2, 1, STATS, false, FUSE>), dim3(gx, ntiles), dim3(kCfThreads), lds, st, src, wgt, dst, g, part, fz);
+    else hipLaunchKernelGGL((conv_f32_act_kernel<B_KC, 2, 2, 2, 2, STATS, false, FUSE>), dim3(gx, ntiles), dim3(kCfThreads), lds, st, src, wgt, dst, g, part, fz);
+  } else if (tapv) {
+    if (narrow) hipLaunchKernelGGL((conv_f32_act_kernel<B_KC, 2, 2, 2, 1, STATS, true>), dim3(gx, ntiles), dim3(kCfThreads), lds, st, src, wgt, dst, g, part, fz);
+    else hipLaunchKernelGGL((conv_f32_act_kernel<B_KC, 2, 2, 2, 2, STATS, true>), dim3(gx, ntiles), dim3(kCfThreads), lds, st, src, wgt, dst, g, part, fz);
   } else {
-    if (narrow) hipLaunchKernelGGL((conv_f32_act_kernel<B_KC, 2, 2, 2, 1, STATS, false>), dim3(gx, ntiles), dim3(kCfThreads), lds, st, src, wgt, dst, g, part);
-    else hipLaunchKernelGGL((conv_f32_act_kernel<B_KC, 2, 2, 2, 2, STATS, false>), dim3(gx, ntiles), dim3(kCfThreads), lds, st, src, wgt, dst, g, part);
+    if (narrow) hipLaunchKernelGGL((conv_f32_act_kernel<B_KC, 2, 2, 2, 1, STATS, false>), dim3(gx, ntiles), dim3(kCfThreads), lds, st, src, wgt, dst, g, part, fz);
+    else hipLaunchKernelGGL((conv_f32_act_kernel<B_KC, 2, 2, 2, 2, STATS, false>), dim3(gx, ntiles), dim3(kCfThreads), lds, st, src, wgt, dst, g, part, fz);
   }
   if (nparts) *nparts = gx;
   LEC_CHECK_LAUNCH("conv_f32_act_kernel");
@@ -524,11 +637,57 @@ extern "C" int lec_conv_f32_dgrad(const float* dy, const float* w, int N, int H,
   return LEC_OK;
 }
 
+// Data gradient of a STRIDE-1 layer with BatchNorm pieces fused in (see ActFuse):
+//   xsrc / coef  (both or neither; 1x1, pad 0 only): dy is not materialised -- the kernel forms it from g = `dy` and the BatchNorm input
+//                xsrc with the per-channel coefficients coef[3][Cout] (lec_bn_bwd_coeffs_f32) while loading;
+//   xbn .. partials (all or none): the result is not dx but g = mask * (dx + dres), and the partial sums of pass 1 of the backward of
+//                the BatchNorm whose output this layer consumed are left in `partials` (n_partials rows of [2][Cin]).
+extern "C" int lec_conv_f32_dgrad_fused(const float* dy, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                                        float* dx, const float* xsrc, const float* coef, const float* dres, const float* xbn, const uint8_t* mask,
+                                        const float* mean, const float* invstd, float* partials, int64_t partials_bytes, int* n_partials,
+                                        lec_stream_t stream) {
+  using namespace lec;
+  if (int rc = conv_check("conv_f32_dgrad_fused", N, H, W, Cin, Cout, R, S, stride, pad)) return rc;
+  LEC_CHECK_ARG(dy && w && dx, "conv_f32_dgrad_fused: null pointer");
+  LEC_CHECK_ARG(stride == 1, "conv_f32_dgrad_fused: stride-1 layers only (a strided data gradient is several launches)");
+  const bool xf = xsrc || coef, fold = xbn || mean || invstd || partials;
+  LEC_CHECK_ARG(xf || fold, "conv_f32_dgrad_fused: nothing to fuse (use lec_conv_f32_dgrad)");
+  LEC_CHECK_ARG(!xf || (xsrc && coef && R == 1 && S == 1 && pad == 0), "conv_f32_dgrad_fused: the on-load form needs xsrc, coef and a 1x1 / pad 0 layer");
+  LEC_CHECK_ARG(!fold || (xbn && mean && invstd && partials && n_partials && Cin % 8 == 0), "conv_f32_dgrad_fused: the fold needs xbn, mean, invstd, partials, n_partials (Cin %% 8 == 0)");
+  LEC_CHECK_ARG(!fold || partials_bytes >= (int64_t)kCfMaxPart * 2 * Cin * (int64_t)sizeof(float), "conv_f32_dgrad_fused: partials buffer too small");
+  LEC_CHECK_ARG(Cout % kCfBK == 0, "conv_f32_dgrad_fused: Cout must be a multiple of %d", kCfBK);
+  const int Ho = H + 2 * pad - R + 1, Wo = W + 2 * pad - S + 1;
+  ActGeo g;
+  g.Hm = H; g.Wm = W; g.Mg = N * H * W; g.Hs = Ho; g.Ws = Wo; g.Cs = Cout; g.lgCs = ilog2_exact(Cout); g.sst = 1;
+  g.r0 = 0; g.s0 = 0; g.rstep = 1; g.sstep = 1; g.na = R; g.nb = S; g.oh0 = pad; g.ow0 = pad; g.sg = -1;   // lec_conv_f32_dgrad's formulas at stride 1
+  g.S = S; g.RS = R * S; g.Cd = Cin; g.Cin = Cin; g.Hd = H; g.Wd = W; g.dst_st = 1; g.dph = 0; g.dpw = 0;
+  g.Kg = R * S * Cout;
+  g.src_bytes = (uint32_t)((int64_t)N * Ho * Wo * Cout * 4); g.wgt_bytes = (uint32_t)((int64_t)Cout * R * S * Cin * 4);
+  g.dst_bytes = (uint32_t)((int64_t)N * H * W * Cin * 4);
+  g.dWm = make_fastdiv(g.Wm); g.dHm = make_fastdiv(g.Hm); g.dnb = make_fastdiv(g.nb);
+  ActFuse fz{};
+  fz.xsrc = xsrc; fz.coef = coef; fz.dres = dres; fz.xbn = xbn; fz.mask = mask; fz.mean = mean; fz.invstd = invstd;
+  fz.mask_bytes = (uint32_t)((int64_t)N * H * W * (Cin / 8));
+  hipStream_t st = (hipStream_t)stream;
+  if (xf && fold) return launch_act<false, false, 3>(dy, w, dx, g, partials, n_partials, st, fz);
+  if (fold) return launch_act<false, false, 2>(dy, w, dx, g, partials, n_partials, st, fz);
+  return launch_act<false, false, 1>(dy, w, dx, g, nullptr, nullptr, st, fz);
+}
+
 extern "C" int lec_conv_f32_wgrad(const float* dy, const float* x, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                                   float* dw, lec_stream_t stream) {
+  return lec_conv_f32_wgrad_fused(dy, x, N, H, W, Cin, Cout, R, S, stride, pad, dw, nullptr, nullptr, stream);
+}
+
+// Weight gradient; xsrc / coef (both or neither; 1x1 / stride 1 / pad 0 layers): dy is formed on load from g = `dy`, the BatchNorm input
+// xsrc and coef[3][Cout] exactly as in lec_conv_f32_dgrad_fused, so pass 2 of that BatchNorm's backward never runs as a kernel.
+extern "C" int lec_conv_f32_wgrad_fused(const float* dy, const float* x, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                                        float* dw, const float* xsrc, const float* coef, lec_stream_t stream) {
   using namespace lec;
   if (int rc = conv_check("conv_f32_wgrad", N, H, W, Cin, Cout, R, S, stride, pad)) return rc;
   LEC_CHECK_ARG(dy && x && dw, "conv_f32_wgrad: null pointer");
+  const bool xf = xsrc || coef;
+  LEC_CHECK_ARG(!xf || (xsrc && coef && R == 1 && S == 1 && stride == 1 && pad == 0), "conv_f32_wgrad_fused: the on-load form needs xsrc, coef and a 1x1 / stride 1 / pad 0 layer");
   WgGeo g;
   g.Ho = (H + 2 * pad - R) / stride + 1; g.Wo = (W + 2 * pad - S) / stride + 1; g.Mpix = N * g.Ho * g.Wo;
   g.H = H; g.W = W; g.Cin = Cin; g.lgCin = ilog2_exact(Cin); g.Cout = Cout; g.S = S; g.RS = R * S; g.stride = stride; g.pad = pad;
@@ -573,12 +732,20 @@ extern "C" int lec_conv_f32_wgrad(const float* dy, const float* x, int N, int H,
   const int total = 8 * ((tiles * split + 7) / 8);              // slots (see the kernel's slot -> item map)
   const dim3 grid(total < wg_cap ? total : wg_cap), blk(kCfThreads);
   hipStream_t st = (hipStream_t)stream;
-  if (big) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 4, kWgBK, false>), grid, blk, lds, st, dy, x, dw, g);
-  else if (!dense) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, false>), grid, blk, lds, st, dy, x, dw, g);
-  else if (BM == 64 && BN == 256) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, true>), grid, blk, lds, st, dy, x, dw, g);
-  else if (BM == 128) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 2, kWgBK, true>), grid, blk, lds, st, dy, x, dw, g);
-  else if (BM == 256) hipLaunchKernelGGL((conv_f32_wgrad_kernel<4, 1, 2, 2, kWgBK, true>), grid, blk, lds, st, dy, x, dw, g);
-  else hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 1, 1, 32, true>), grid, blk, lds, st, dy, x, dw, g);
+  const float* nof = nullptr;
+  if (xf) {
+    LEC_CHECK_ARG(dense, "conv_f32_wgrad_fused: dense layers only");
+    if (BM == 64 && BN == 256) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, true, true>), grid, blk, lds, st, dy, x, dw, g, xsrc, coef);
+    else if (BM == 128) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 2, kWgBK, true, true>), grid, blk, lds, st, dy, x, dw, g, xsrc, coef);
+    else if (BM == 256) hipLaunchKernelGGL((conv_f32_wgrad_kernel<4, 1, 2, 2, kWgBK, true, true>), grid, blk, lds, st, dy, x, dw, g, xsrc, coef);
+    else hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 1, 1, 32, true, true>), grid, blk, lds, st, dy, x, dw, g, xsrc, coef);
+  }
+  else if (big) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 4, kWgBK, false>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
+  else if (!dense) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, false>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
+  else if (BM == 64 && BN == 256) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
+  else if (BM == 128) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 2, kWgBK, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
+  else if (BM == 256) hipLaunchKernelGGL((conv_f32_wgrad_kernel<4, 1, 2, 2, kWgBK, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
+  else hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 1, 1, 32, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   LEC_CHECK_LAUNCH("conv_f32_wgrad_kernel");
   return LEC_OK;
 }

@@ -374,6 +374,10 @@ def _with_ctx_fusion(backward):
 
 
 FOLD_BN_BWD = _os.environ.get('LEC_FOLD_BN_BWD', '1') != '0'
+# fp32 counterparts (round 3): pass 1 of a BatchNorm backward in the epilogue of the fp32 data gradient that produces its gradient
+# (lec_conv_f32_dgrad_fused), pass 2 on the operand load of the 1x1 convolution behind the BatchNorm (data and weight gradient)
+FOLD_BN_BWD_F32 = _os.environ.get('LEC_FOLD_BN_BWD_F32', '1') != '0'
+LAZY_BN_PASS2_F32 = _os.environ.get('LEC_LAZY_BN_PASS2_F32', '1') != '0'
 DEFER_BN_APPLY = _os.environ.get('LEC_DEFER_BN_APPLY', '1') != '0'
 LAZY_BN_PASS2 = _os.environ.get('LEC_LAZY_BN_PASS2', '1') != '0'
 # the default context's records under their historical names (ops called outside a model: tests, tools)
@@ -471,6 +475,12 @@ class BNActFn(torch.autograd.Function):
                     fusion().forks.clear()
                 # what the consumer convolution's data gradient needs to run pass 1 of THIS layer's backward in its epilogue
                 fusion().forks[y.data_ptr()] = {'x': x, 'mask': mask, 'mean': save_mean, 'invstd': save_invstd, 'dres': None}
+            elif (not fork and FOLD_BN_BWD_F32 and x.dtype == torch.float32 and ctx.needs_input_grad[0]):
+                # fp32: an output with ONE consumer (bn1 -> conv2, bn2 -> conv3): that convolution's data gradient can run pass 1 in
+                # its epilogue with no second gradient to wait for
+                if len(fusion().forks) > 64:
+                    fusion().forks.clear()
+                fusion().forks[y.data_ptr()] = {'x': x, 'mask': mask, 'mean': save_mean, 'invstd': save_invstd, 'dres': None, 'single': True}
         if fork:
             return y, y.as_strided(y.size(), y.stride())
         return y
@@ -520,8 +530,26 @@ class BNActFn(torch.autograd.Function):
         lazy = (LAZY_BN_PASS2 and has_res and x.data_ptr() in fusion().lazy_ok and x.dtype == torch.bfloat16
                 and _WO.instance is not None and _WO.instance.enabled       # the consumer that materialises dx is _OverlapConvFn.backward
                 and lib.lec_conv1x1_wgrad_bnapply_supported(fusion().lazy_ok[x.data_ptr()], Cc, M))
+        # fp32: the 1x1 / stride-1 convolution that produced x forms dx on its operand load, in its data gradient AND in its weight gradient
+        # (lec_conv_f32_dgrad_fused / _wgrad_fused): pass 2 never runs as a kernel
+        lazy32 = (LAZY_BN_PASS2_F32 and x.dtype == torch.float32 and x.data_ptr() in fusion().lazy_ok
+                  and _WO.instance is not None and _WO.instance.enabled and ctx.needs_input_grad[0])
         fusion().lazy_ok.pop(x.data_ptr(), None)
-        if lazy:
+        if lazy32:
+            coef = torch.empty(3 * Cc, dtype=torch.float32, device=x.device)
+            if pre:
+                g = dy
+                _bn_timed(lambda: check(lib.lec_bn_bwd_coeffs_f32(M, Cc, pre, dptr(weight), dptr(save_mean), dptr(save_invstd), dptr(dgamma), dptr(dbeta),
+                                                                  dptr(coef), dptr(ws), ws.numel(), stream_ptr())), 0)
+            else:
+                g = dres if has_res else torch.empty_like(x)
+                nb1 = el * es * (2 + (1 if dy2 is not None else 0) + 1) + (el // 8 if relu else 0)
+                _bn_timed(lambda: check(lib.lec_bn_bwd_pass1_coeffs_f32(dptr(dy), dptr(dy2), dptr(mask) if relu else None, dptr(x), M, Cc, dptr(weight),
+                                                                        dptr(save_mean), dptr(save_invstd), dptr(g), dptr(dgamma), dptr(dbeta), dptr(coef),
+                                                                        dptr(ws), ws.numel(), stream_ptr())), nb1)
+            fusion().lazy_dx.clear()
+            fusion().lazy_dx[dx.data_ptr()] = {'g': g, 'x': x, 'coef': coef, 'gamma': weight, 'mean': save_mean, 'invstd': save_invstd, 'M': M, 'C': Cc}
+        elif lazy:
             # the convolution that produced x runs pass 2 inside its weight-gradient kernel (conv1x1_wgrad_bnapply_rows): here only
             # pass 1 (unless a data-gradient epilogue already did it) and the finalize; dx is handed on UNWRITTEN with a record
             if pre:
@@ -602,6 +630,10 @@ def conv1x1_wgrad_rows(dy_rows, x_rows, dw):
 
 def bn_bwd_apply_lazy(rec, dx):
     """Pass 2 of a BatchNorm backward whose dx was handed on unwritten (fusion().lazy_dx) and whose consumer cannot run it itself."""
+    if 'coef' in rec:                             # fp32 form: dx = A g + B x + D from the coefficient vectors (the workspace has moved on)
+        C_ = rec['C']; cf = rec['coef'].view(3, 1, C_, 1, 1) if dx.dim() == 4 else rec['coef'].view(3, 1, C_)
+        torch.add(torch.addcmul(cf[2].expand_as(dx), rec['x'], cf[1]), rec['g'] * cf[0], out=dx)
+        return
     ws = _bn_workspace(dx.device)
     check(_dt('lec_bn_bwd_apply', rec['x'].dtype)(dptr(rec['g']), dptr(rec['x']), rec['M'], rec['C'], dptr(rec['gamma']), dptr(rec['mean']), dptr(rec['invstd']),
                                dptr(dx), dptr(ws), ws.numel(), stream_ptr()))
@@ -761,11 +793,44 @@ def conv_f32_dgrad(dy, w, x_shape, stride, pad):
     return dx
 
 
-def conv_f32_wgrad(dy, x, dw, stride, pad):
-    """dw += weight gradient (lec_conv_f32_wgrad, float atomics).  dw [Cout, Cin, R, S] channels_last fp32."""
+def conv_f32_dgrad_fused(dy, w, x_shape, stride, pad, xf=None, fold=None):
+    """lec_conv_f32_dgrad_fused.  xf = (xsrc, coef): `dy` is g and the kernel forms the gradient A g + B xsrc + D on load (1x1 layers);
+    fold = a FusionContext.forks record {'x', 'mask', 'mean', 'invstd', 'dres'}: the result is g = mask * (dx + dres) of the BatchNorm whose
+    output this layer consumed, tagged for BNActFn.backward, its partial sums in the BatchNorm workspace."""
+    _nhwc_f32(dy, 'dy'); _nhwc_f32(w, 'w')
+    n, cin, h, wd = x_shape; cout, _, r, s_ = w.shape
+    dx = torch.empty((n, cin, h, wd), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last)
+    xs = cf = None
+    if xf is not None:
+        xs, cf = xf; _nhwc_f32(xs, 'xsrc')
+        if xs.shape != dy.shape or cf.numel() != 3 * cout:
+            raise ValueError('on-load form: xsrc must have dy\'s shape and coef 3 * Cout entries')
+    a = [None] * 5; ws = None; k = C.c_int(0)
+    if fold is not None:
+        xb = _nhwc_f32(fold['x'], 'fold x')
+        if tuple(xb.shape) != (n, cin, h, wd) or (fold['dres'] is not None and tuple(_nhwc_f32(fold['dres'], 'dres').shape) != (n, cin, h, wd)):
+            raise ValueError('fold record does not match the layer input')
+        ws = _bn_workspace(dy.device)
+        a = [dptr(fold['dres']), dptr(xb), dptr(fold['mask']), dptr(fold['mean']), dptr(fold['invstd'])]
+    _conv_timed(lambda: check(lib.lec_conv_f32_dgrad_fused(dptr(dy), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(dx), dptr(xs), dptr(cf),
+                                                           a[0], a[1], a[2], a[3], a[4], dptr(ws), ws.numel() if ws is not None else 0,
+                                                           C.byref(k) if ws is not None else None, stream_ptr())),
+                2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * cout * cin * r * s_)
+    if fold is not None:
+        fc = fusion()
+        fc.ws_owner[0], fc.ws_owner[1] = dx.data_ptr(), k.value
+        fc.folded.clear(); fc.folded[dx.data_ptr()] = k.value
+    return dx
+
+
+def conv_f32_wgrad(dy, x, dw, stride, pad, xf=None):
+    """dw += weight gradient (lec_conv_f32_wgrad, float atomics).  dw [Cout, Cin, R, S] channels_last fp32.  xf = (xsrc, coef): `dy`
+    is g and the gradient is formed on load (lec_conv_f32_wgrad_fused, 1x1 / stride 1 layers)."""
     _nhwc_f32(dy, 'dy'); _nhwc_f32(x, 'x'); _nhwc_f32(dw, 'dw')
     n, cin, h, wd = x.shape; cout, _, r, s_ = dw.shape
-    _conv_timed(lambda: check(lib.lec_conv_f32_wgrad(dptr(dy), dptr(x), n, h, wd, cin, cout, r, s_, stride, pad, dptr(dw), stream_ptr())),
+    xs, cf = xf if xf is not None else (None, None)
+    _conv_timed(lambda: check(lib.lec_conv_f32_wgrad_fused(dptr(dy), dptr(x), n, h, wd, cin, cout, r, s_, stride, pad, dptr(dw), dptr(xs), dptr(cf),
+                                                           stream_ptr())),
                 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * cout * cin * r * s_)
     return dw
 

@@ -85,7 +85,14 @@ class WgradOverlap:
         if self.reducer is not None:
             self.reducer.mark_ready(w)
 
-    def _own_wgrad(self, gy, x, conv):
+    @staticmethod
+    def _materialise(g, xf):
+        """The gradient a fused kernel would have formed on load, as a tensor (a weight gradient that falls back to the library)."""
+        dy = torch.empty_like(g)
+        _ops().bn_bwd_apply_lazy({'g': g, 'x': xf[0], 'coef': xf[1], 'C': g.shape[1]}, dy)
+        return dy
+
+    def _own_wgrad(self, gy, x, conv, xf=None):
         """The wide 1x1 layers: liblecone's MFMA weight-gradient kernel adds dY^T X straight into the arena's fp32 gradient
         slot (zeroed at the start of the step) -- no library kernel, zero-fill, cast or copy.  False when not applicable."""
         w = conv.weight
@@ -99,7 +106,7 @@ class WgradOverlap:
             elif F32_MODE == 'x3' and _ops().conv_f32x3_wgrad_preferred(conv.in_channels, conv.out_channels, *conv.kernel_size):
                 _ops().conv_f32x3_wgrad(gy, x, w.grad, conv.stride[0], conv.padding[0])  # bf16 matrix cores (layers of >= 128 channels)
             else:
-                _ops().conv_f32_wgrad(gy, x, w.grad, conv.stride[0], conv.padding[0])   # f32 MFMA, atomics straight into the gradient slot
+                _ops().conv_f32_wgrad(gy, x, w.grad, conv.stride[0], conv.padding[0], xf=xf)   # f32 MFMA, atomics straight into the gradient slot
             if self.reducer is not None:
                 self.reducer.mark_ready(w)
             return True
@@ -127,10 +134,13 @@ class WgradOverlap:
             self.reducer.mark_ready(w)
         return True
 
-    def submit(self, gy, x, w16, conv):
+    def submit(self, gy, x, w16, conv, xf=None):
+        """xf = (xsrc, coef): gy holds g and the kernel forms the gradient on load (fp32 1x1 layers, lec_conv_f32_wgrad_fused)."""
         if self.side is None:
-            if self._own_wgrad(gy, x, conv):
+            if self._own_wgrad(gy, x, conv, xf):
                 return
+            if xf is not None:
+                gy = self._materialise(gy, xf)
             gw = torch.ops.aten.convolution_backward(gy, x, w16, None, conv.stride, conv.padding, conv.dilation, False,
                                                      [0, 0], conv.groups, [False, True, False])[1]
             self._finish_wgrad(gw, conv)
@@ -139,7 +149,12 @@ class WgradOverlap:
         ev = torch.cuda.Event(); ev.record(main)
         with torch.cuda.stream(self.side):
             self.side.wait_event(ev)
-            own = self._own_wgrad(gy, x, conv)
+            own = self._own_wgrad(gy, x, conv, xf)
+            if xf is not None:
+                for t in xf:
+                    t.record_stream(self.side)
+            if not own and xf is not None:
+                gy = self._materialise(gy, xf)
             if not own:
                 gw = torch.ops.aten.convolution_backward(gy, x, w16, None, conv.stride, conv.padding, conv.dilation, False,
                                                          [0, 0], conv.groups, [False, True, False])[1]
@@ -268,6 +283,11 @@ class _OverlapConvFn(torch.autograd.Function):
                 y = _ops().conv_f32x3_fwd(x, planes, conv.stride[0], conv.padding[0], want_stats=True)
             else:
                 y = _ops().conv_f32_fwd(x, w16, conv.stride[0], conv.padding[0], want_stats=True)
+                if _ops().LAZY_BN_PASS2_F32 and getattr(conv, 'bn_exclusive', False) and _is_pointwise(conv) and not ctx.stem and conv.out_channels % 32 == 0:
+                    lz_ok = ctx.fc.lazy_ok                      # the BatchNorm behind this layer may leave pass 2 of its backward to
+                    if len(lz_ok) > 64:                         # this layer's operand loads (lec_conv_f32_dgrad_fused / _wgrad_fused)
+                        lz_ok.clear()
+                    lz_ok[y.data_ptr()] = conv.in_channels
             ctx.save_for_backward(x, w16); ctx.conv = conv
             ctx.pointwise = ctx.own = ctx.own3 = False
             return y
@@ -311,6 +331,15 @@ class _OverlapConvFn(torch.autograd.Function):
         gx = None
         wgrad_done = False
         lz = _ops().fusion().lazy_dx.pop(gy.data_ptr(), None)
+        xf = None
+        if lz is not None and 'coef' in lz:
+            # fp32: gy is UNWRITTEN; the BatchNorm behind this layer left (g, its input, the coefficient vectors): both gradient kernels
+            # form dy on their operand load.  Anything that cannot (the split mode, a layer this is not meant for) materialises it first.
+            if ctx.f32 and ctx.planes is None and not ctx.stem and _is_pointwise(conv) and lz['g'].shape == gy.shape:
+                xf = (lz['x'], lz['coef']); gy = lz['g']
+            else:
+                _ops().bn_bwd_apply_lazy(lz, gy)
+            lz = None
         if lz is not None:
             # gy is UNWRITTEN: the BatchNorm behind this layer left pass 2 of its backward to us.  With the flat arena's fp32 gradient
             # slot at hand the weight-gradient kernel does it on the way (and writes gy for the data gradient below); otherwise
@@ -331,10 +360,20 @@ class _OverlapConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             nhwc_g = gy.is_contiguous(memory_format=torch.channels_last)
             if ctx.f32:
+                ops = _ops()
+                rec = ops.fusion().forks.get(x.data_ptr()) if (ops.FOLD_BN_BWD_F32 and ctx.planes is None and not ctx.stem) else None
+                if rec is not None and not (conv.stride[0] == 1 and conv.out_channels % 32 == 0 and x.shape[1] % 8 == 0 and rec['x'].dtype == torch.float32
+                                            and rec['x'].shape == x.shape and (rec.get('single') or rec['dres'] is not None)
+                                            and (rec['dres'] is None or (rec['dres'].dtype == torch.float32 and rec['dres'].shape == x.shape
+                                                                         and rec['dres'].is_contiguous(memory_format=torch.channels_last)))):
+                    rec = None
                 if ctx.planes is not None and not ctx.stem:
-                    gx = _ops().conv_f32x3_dgrad(gy, ctx.planes, x.shape, conv.stride[0], conv.padding[0])
+                    gx = ops.conv_f32x3_dgrad(gy, ctx.planes, x.shape, conv.stride[0], conv.padding[0])
+                elif xf is not None or rec is not None:
+                    # pass 2 of the BatchNorm behind this layer on the operand load, pass 1 of the one in front of it in the epilogue
+                    gx = ops.conv_f32_dgrad_fused(gy, w16, x.shape, conv.stride[0], conv.padding[0], xf=xf, fold=rec)
                 else:
-                    gx = _ops().conv_f32_dgrad(gy, w16, x.shape, conv.stride[0], conv.padding[0])
+                    gx = ops.conv_f32_dgrad(gy, w16, x.shape, conv.stride[0], conv.padding[0])
                 if ctx.stem:
                     gx = gx[:, :3]
             elif ctx.own3 and nhwc_g:                             # dX = conv(dY, W flipped and transposed): the same kernel,
@@ -363,7 +402,7 @@ class _OverlapConvFn(torch.autograd.Function):
             if rec['dres'] is None and x.data_ptr() not in fc.folded and gx.data_ptr() not in fc.folded:
                 rec['dres'] = gx                                # (the other consumer's data gradient may fold it into its epilogue)
         if not wgrad_done:
-            WgradOverlap.instance.submit(gy, x, w16, conv)
+            WgradOverlap.instance.submit(gy, x, w16, conv, xf=xf)
         return gx, None, None
 
 
@@ -411,6 +450,7 @@ class BasicBlock(nn.Module):
         super().__init__()
         self.conv1 = conv3x3(cin, planes, stride); self.bn1 = BatchNormAct2d(planes, relu=True)
         self.conv2 = conv3x3(planes, planes); self.bn2 = BatchNormAct2d(planes, relu=True)     # relu(bn2(.) + identity)
+        self.conv1.bn_exclusive = self.conv2.bn_exclusive = True    # forward() hands each convolution's output to its BatchNorm and to nothing else
         self.downsample = downsample
 
     def forward(self, x, fork=False):
@@ -429,6 +469,8 @@ class Bottleneck(nn.Module):
         self.conv2 = conv3x3(planes, planes, stride); self.bn2 = BatchNormAct2d(planes, relu=True)   # stride on the 3x3 (v1.5)
         self.conv3 = conv1x1(planes, planes * 4); self.bn3 = BatchNormAct2d(planes * 4, relu=True)  # relu(bn3(.) + identity)
         self.conv3.defer_bn = True                             # forward() hands conv3's output to bn3 and to nothing else (FusionContext.deferred)
+        self.conv1.bn_exclusive = self.conv2.bn_exclusive = self.conv3.bn_exclusive = True   # ... and so for every convolution of the block:
+                                                               # its BatchNorm may leave pass 2 of the backward to the convolution's operand loads
         self.downsample = downsample
 
     def forward(self, x, fork=False):
@@ -465,6 +507,7 @@ class ResNet(nn.Module):
         if stride != 1 or self.inplanes != planes * block.expansion:
             downsample = nn.Sequential(conv1x1(self.inplanes, planes * block.expansion, stride),
                                        BatchNormAct2d(planes * block.expansion, relu=False))
+            downsample[0].bn_exclusive = True
         layers = [block(self.inplanes, planes, stride, downsample)]
         self.inplanes = planes * block.expansion
         for _ in range(1, blocks):

@@ -401,3 +401,147 @@ def test_resnet_f32_own_convolutions_match_stock_torch(arch, hw, n):
     for k in res['stock'][2]:
         c = cos(res['own'][2][k], res['stock'][2][k])
         assert c > 0.999, (k, c)
+
+
+# ------------------------------------------------------------------------------------------------ round 3: BatchNorm pieces inside the fp32 convolutions
+def _bn_record(N, C, H, W, seed, res=True, relu=True):
+    """A real fp32 BatchNorm(+residual)(+ReLU) forward through BNActFn: its input, output, ReLU bitmask (lec_bn_fwd_f32's layout) and
+    saved statistics, as the FusionContext record a consumer convolution's data gradient folds."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    xbn = _cl(torch.randn(N, C, H, W, generator=g) * 1.3 + 0.2)
+    r = _cl(torch.randn(N, C, H, W, generator=g)) if res else None
+    w = (torch.rand(C, generator=g) + 0.5).to(DEV); b = (torch.randn(C, generator=g) * 0.2).to(DEV)
+    rm = torch.zeros(C, device=DEV); rv = torch.ones(C, device=DEV)
+    xa = xbn.clone().requires_grad_(True)
+    ops.fusion().reset()
+    out = ops.BNActFn.apply(xa, r, w, b, rm, rv, True, 0.1, 1e-5, relu, res)      # fork <=> residual here
+    z = out[0] if res else out
+    rec = dict(ops.fusion().forks[z.data_ptr()])
+    ops.fusion().reset()
+    return z.detach(), rec, w
+
+
+@pytest.mark.parametrize('N,C,H,W,Cout,R,pad,res', [(4, 256, 14, 14, 64, 1, 0, True), (3, 64, 9, 7, 256, 1, 0, True), (2, 128, 12, 12, 128, 3, 1, False),
+                                                      (5, 512, 7, 7, 128, 1, 0, True), (2, 64, 20, 20, 64, 3, 1, False), (1, 1024, 5, 5, 256, 1, 0, True)])
+def test_conv_f32_dgrad_with_batchnorm_backward_pass1_in_the_epilogue(N, C, H, W, Cout, R, pad, res):
+    """lec_conv_f32_dgrad_fused, fold form: the data gradient of a stride-1 layer whose input z = relu(bn(x) [+ r]) is a BatchNorm output
+    writes g = mask * (dx [+ dres]) -- bit-equal to the plain data gradient followed by the add and the mask -- and leaves the partial
+    sums of pass 1 (sum g, sum g * xhat per channel) in the BatchNorm workspace: equal to float64 sums of that g to fp32 summation
+    error.  Mask bits come from a real lec_bn_fwd_f32 forward (its byte layout); dres is absent for single-consumer outputs."""
+    z, rec, _ = _bn_record(N, C, H, W, seed=C + R, res=res)
+    g = torch.Generator(device='cpu').manual_seed(77)
+    Ho, Wo = H + 2 * pad - R + 1, W + 2 * pad - R + 1
+    dy = _cl(torch.randn(N, Cout, Ho, Wo, generator=g))
+    w = _cl(torch.randn(Cout, C, R, R, generator=g) * 0.1)
+    dres = _cl(torch.randn(N, C, H, W, generator=g)) if res else None
+    rec['dres'] = dres
+    dx0 = ops.conv_f32_dgrad(dy, w, z.shape, 1, pad)
+    got = ops.conv_f32_dgrad_fused(dy, w, z.shape, 1, pad, fold=rec)
+    n = ops.fusion().ws_owner[1]
+    assert ops.fusion().ws_owner[0] == got.data_ptr() and ops.fusion().folded == {got.data_ptr(): n} and 1 <= n <= 512
+    want = (dx0 + dres if res else dx0) * (z > 0)
+    assert torch.equal(got, want)
+    part = ops._bn_workspace(dy.device)[:n * 2 * C * 4].view(torch.float32).view(n, 2, C).double().sum(0)
+    gd = want.double(); xh = (rec['x'].double() - rec['mean'].double().view(1, C, 1, 1)) * rec['invstd'].double().view(1, C, 1, 1)
+    s_ref = gd.sum(dim=(0, 2, 3)); q_ref = (gd * xh).sum(dim=(0, 2, 3))
+    scale = gd.abs().sum(dim=(0, 2, 3)).max().item()
+    assert (part[0] - s_ref).abs().max().item() <= 1e-5 * scale and (part[1] - q_ref).abs().max().item() <= 1e-5 * (gd * xh).abs().sum(dim=(0, 2, 3)).max().item()
+    ops.fusion().reset()
+
+
+@pytest.mark.parametrize('N,Cin,H,W,Cout', [(4, 64, 14, 14, 256), (3, 128, 9, 7, 512), (2, 256, 12, 12, 1024), (6, 512, 7, 7, 2048), (2, 64, 20, 20, 64)])
+def test_conv_f32_gradients_with_batchnorm_backward_pass2_on_the_operand_load(N, Cin, H, W, Cout):
+    """lec_conv_f32_dgrad_fused / lec_conv_f32_wgrad_fused, on-load form (1x1 / stride 1): handed g, the BatchNorm input x and the
+    coefficient vectors of lec_bn_bwd_coeffs_f32, both kernels form dy = A g + B x + D per output channel while loading.  Checked (a)
+    against the same kernels fed the materialised dy (fp32 fma of the same three terms: equal up to the fma's single rounding, a few
+    ulp of the operands), (b) the coefficients against float64 of lec_bn_bwd_f32's formula dx = gamma invstd (g - c1 - xhat c2)."""
+    gen = torch.Generator(device='cpu').manual_seed(Cout + Cin)
+    M = N * H * W
+    g_ = _cl(torch.randn(N, Cout, H, W, generator=gen)); xb = _cl(torch.randn(N, Cout, H, W, generator=gen) * 1.5 + 0.3)
+    xin = _cl(torch.randn(N, Cin, H, W, generator=gen)); w = _cl(torch.randn(Cout, Cin, 1, 1, generator=gen) * 0.1)
+    gamma = (torch.rand(Cout, generator=gen) + 0.5).to(DEV)
+    mean = xb.double().mean(dim=(0, 2, 3)); var = xb.double().var(dim=(0, 2, 3), unbiased=False)
+    invstd = (1.0 / torch.sqrt(var + 1e-5))
+    mean32, invstd32 = mean.float(), invstd.float()
+    # partial rows the way a reduce pass leaves them: here simply two rows that add up to the sums
+    xh = (xb.double() - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+    s = g_.double().sum(dim=(0, 2, 3)); q = (g_.double() * xh).sum(dim=(0, 2, 3))
+    ws = ops._bn_workspace(g_.device)
+    part = ws[:2 * 2 * Cout * 4].view(torch.float32).view(2, 2, Cout)
+    part[0, 0] = (s * 0.25).float(); part[1, 0] = (s - (s * 0.25).float().double()).float()
+    part[0, 1] = (q * 0.5).float(); part[1, 1] = (q - (q * 0.5).float().double()).float()
+    dgamma = torch.empty(Cout, device=DEV); dbeta = torch.empty(Cout, device=DEV); coef = torch.empty(3 * Cout, device=DEV)
+    from learning_embeddings_amd._lib import lib, check, dptr, stream_ptr
+    check(lib.lec_bn_bwd_coeffs_f32(M, Cout, 2, dptr(gamma), dptr(mean32), dptr(invstd32), dptr(dgamma), dptr(dbeta), dptr(coef), dptr(ws), ws.numel(), stream_ptr()))
+    c1, c2 = s / M, q / M
+    gs = gamma.double() * invstd32.double()
+    want_coef = torch.stack([gs, -gs * invstd32.double() * c2, gs * (invstd32.double() * c2 * mean32.double() - c1)])
+    assert (coef.view(3, Cout).double() - want_coef).abs().max().item() <= 2e-6 * want_coef.abs().max().item()
+    assert (dbeta.double() - s).abs().max().item() <= 1e-6 * s.abs().max().item() + 1e-6 and (dgamma.double() - q).abs().max().item() <= 1e-6 * q.abs().max().item() + 1e-6
+    A, B, D = (coef.view(3, Cout)[i].view(1, Cout, 1, 1) for i in range(3))
+    dy = torch.addcmul(torch.addcmul(D.expand_as(g_), xb, B), g_, A).contiguous(memory_format=torch.channels_last)
+    # (a) data gradient
+    dx_ref = ops.conv_f32_dgrad(dy, w, xin.shape, 1, 0)
+    dx = ops.conv_f32_dgrad_fused(g_, w, xin.shape, 1, 0, xf=(xb, coef))
+    tol = 4e-6 * (dy.abs().max().item() * w.abs().max().item() * Cout) ** 1.0
+    assert (dx - dx_ref).abs().max().item() <= tol, ((dx - dx_ref).abs().max().item(), tol)
+    # ... and against float64 of the BatchNorm formula followed by the convolution's data gradient
+    dy64 = gs.view(1, -1, 1, 1) * (g_.double() - c1.view(1, -1, 1, 1) - xh * c2.view(1, -1, 1, 1))
+    dx64 = torch.einsum('nohw,oi->nihw', dy64, w.double().view(Cout, Cin))
+    assert (dx.double() - dx64).abs().max().item() <= 3e-5 * dx64.abs().max().item()
+    # (b) weight gradient
+    dw_ref = torch.zeros(Cout, Cin, 1, 1, device=DEV).contiguous(memory_format=torch.channels_last); dw = dw_ref.clone()
+    ops.conv_f32_wgrad(dy, xin, dw_ref, 1, 0)
+    ops.conv_f32_wgrad(g_, xin, dw, 1, 0, xf=(xb, coef))
+    dw64 = torch.einsum('nohw,nihw->oi', dy64, xin.double())
+    assert (dw.view(Cout, Cin).double() - dw64).abs().max().item() <= 3e-5 * dw64.abs().max().item()
+    assert (dw - dw_ref).abs().max().item() <= 3e-5 * dw64.abs().max().item()
+
+
+@pytest.mark.parametrize('hw,n', [(64, 6), (96, 4)])
+def test_resnet50_f32_fused_batchnorm_backward_matches_the_unfused_path(hw, n):
+    """The whole fp32 ResNet-50 with the round-3 fusions -- pass 1 of every foldable BatchNorm backward in the epilogue of the data
+    gradient that produces its gradient, pass 2 on the operand load of the 1x1 convolution behind it -- against the same network with
+    both switched off (separate BatchNorm passes): outputs bit-equal (forward is untouched), input gradient and every parameter
+    gradient equal to fp32 summation-order error; and the fused kernels must actually have run."""
+    torch.manual_seed(0)
+    net = resnet50(num_classes=10).to(DEV).to(memory_format=torch.channels_last).train()
+    x0 = _cl(torch.rand(n, 3, hw, hw))
+    res, calls, g = {}, {}, None
+    orig = ops.conv_f32_dgrad_fused
+    keep = (ops.FOLD_BN_BWD_F32, ops.LAZY_BN_PASS2_F32)
+    try:
+        for tag in ('fused', 'plain'):
+            ops.FOLD_BN_BWD_F32 = ops.LAZY_BN_PASS2_F32 = tag == 'fused'
+            def counted(*a, _t=tag, **k):
+                key = (_t, 'xf' if k.get('xf') is not None else '', 'fold' if k.get('fold') is not None else '')
+                calls[key] = calls.get(key, 0) + 1
+                return orig(*a, **k)
+            ops.conv_f32_dgrad_fused = counted
+            for p_ in net.parameters():
+                p_.grad = torch.zeros_like(p_)
+            x = x0.clone().requires_grad_(True)
+            WgradOverlap.instance = WgradOverlap()
+            y = net(x)
+            if g is None:
+                g = torch.randn_like(y)
+            y.backward(g)
+            WgradOverlap.instance.join(); torch.cuda.synchronize()
+            res[tag] = (y.detach().clone(), x.grad.clone(), {k: p_.grad.clone() for k, p_ in net.named_parameters()})
+            assert not net.fusion.lazy_dx and not net.fusion.folded
+    finally:
+        WgradOverlap.instance = None
+        ops.conv_f32_dgrad_fused = orig
+        ops.FOLD_BN_BWD_F32, ops.LAZY_BN_PASS2_F32 = keep
+    assert not any(k[0] == 'plain' for k in calls), calls
+    n_fold = sum(v for k, v in calls.items() if k[2]); n_xf = sum(v for k, v in calls.items() if k[1])
+    # 16 conv1 (15 fold a block output, every conv1 forms its gradient on load), 13 stride-1 conv2 (fold bn1), 16 conv3 (fold bn2, on load)
+    assert n_fold >= 15 + 13 + 16 and n_xf >= 16 + 16, calls
+    assert torch.equal(res['fused'][0], res['plain'][0])
+    cos = lambda a, b: float(a.double().flatten() @ b.double().flatten() / (a.double().norm() * b.double().norm() + 1e-300))
+    assert cos(res['fused'][1], res['plain'][1]) > 0.999999
+    for k in res['plain'][2]:
+        a, b = res['fused'][2][k], res['plain'][2][k]
+        if b.norm() > 0:
+            assert cos(a, b) > 0.99999, (k, cos(a, b))
+            assert (a - b).abs().max().item() <= 2e-3 * b.abs().max().item(), (k, (a - b).abs().max().item(), b.abs().max().item())
