@@ -130,8 +130,8 @@ def measure(args, dtype, rank, world, stamp, primary):
     from learning_embeddings_amd import ops
     from learning_embeddings_amd.engine import StepEngine, WORKLOADS
     from learning_embeddings_amd.resnet import conv_macs
-    eng = StepEngine(args.workload, dtype=dtype, sampler_mode=args.sampler, batch=args.batch, overlap_wgrad=not args.no_overlap_wgrad,
-                     use_graph=args.launch != 'eager')
+    eng = StepEngine(args.workload, dtype=dtype, sampler_mode=args.sampler, batch=args.batch, overlap_wgrad=False if args.no_overlap_wgrad else args.overlap_wgrad,
+                     use_graph=args.launch != 'eager', passes=args.passes)
     dev = eng.device
     stamp('%s: engine built' % dtype)
     for i in range(args.warmup):
@@ -240,9 +240,9 @@ def measure(args, dtype, rank, world, stamp, primary):
     # The weight-gradient kernels run on a second stream next to the BatchNorm kernels, so per-kernel durations inside the
     # timed region include that sharing.  Three more steps with everything on ONE stream give the families' own durations.
     bn_isolated = conv_isolated = None
-    if primary and eng.overlap is not None and eng.overlap.side is not None and ('fused_bn' in phases or 'conv_f32' in phases):
-        side = eng.overlap.side
-        eng.overlap.side = None
+    if primary and eng.overlap is not None and (eng.overlap.side is not None or eng.passes > 1) and ('fused_bn' in phases or 'conv_f32' in phases):
+        side, n_pass = eng.overlap.side, eng.passes
+        eng.overlap.side = None; eng.passes = 1                 # one stream, one pass: every kernel has the GPU to itself
         ops.BN_TIMER = []; ops.CONV_TIMER = []
         n_iso = 2
         for _ in range(n_iso):
@@ -252,7 +252,7 @@ def measure(args, dtype, rank, world, stamp, primary):
             bn_isolated = sum(a.elapsed_time(b) for a, b, _ in ops.BN_TIMER) / n_iso
         if ops.CONV_TIMER:
             conv_isolated = sum(a.elapsed_time(b) for a, b, _ in ops.CONV_TIMER) / n_iso
-        eng.overlap.side = side
+        eng.overlap.side = side; eng.passes = n_pass
     ops.BN_TIMER = None; ops.CONV_TIMER = None
     if graph_mode:
         eng.set_launch_mode(True)
@@ -486,7 +486,9 @@ def main():
     ap.add_argument('--sampler', default='replicated', choices=['replicated', 'per_rank'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stress', action='store_true')
-    ap.add_argument('--no-overlap-wgrad', action='store_true', help='keep the conv weight-gradient kernels on the main stream (default: second HIP stream)')
+    ap.add_argument('--no-overlap-wgrad', action='store_true', help='keep the conv weight-gradient kernels in line')
+    ap.add_argument('--overlap-wgrad', action='store_true', default=None, help='weight gradients on their own HIP stream (default: only when the step runs as ONE pass)')
+    ap.add_argument('--passes', type=int, default=None, help='concurrent parts the CNN rows of a step go through the backbone in (default: 2 at fp32 -- positives | image negatives, one stream each -- 1 at bf16)')
     ap.add_argument('--check-replicas', action='store_true', help='(default at N > 1) after the run, assert that every rank holds identical parameters')
     ap.add_argument('--no-check-replicas', action='store_true', help='skip the replica comparison at N > 1')
     ap.add_argument('--launch', default='auto', choices=['auto', 'graph', 'eager'],
@@ -579,6 +581,7 @@ def main():
                           'global_batch': B * world, 'cnn_rows_per_step_per_gpu': eng.n_rows, 'cone_loss_dtype': 'f32',
                           'cnn_dtype': ('f32 activations and weights; every fp32 product computed as six exact bf16 x bf16 products on the matrix cores, fp32 accumulation (csrc/conv_f32x3.hip)' if args.conv_f32 == 'x3' else 'f32 activations, weights and accumulation (v_mfma_f32_32x32x2_f32: exact fp32)') if f32 else 'bf16 activations, fp32 master weights and accumulation',
                           'parallelism': 'dp%d' % world, 'sampler': args.sampler,
+                          'cnn_passes': ('%d concurrent passes of %d rows, one HIP stream each (BatchNorm batch = a pass: positives | image negatives, the reference\'s own separate forwards)' % (eng.passes, eng.n_rows // eng.passes)) if eng.passes > 1 else '1 pass of %d rows' % eng.n_rows,
                           'hbm_peak_allocated_gb': res['hbm_peak_allocated_gb'], 'launch_mode': res['launch_mode'], 'mean_loss': res['mean_loss']},
                'phases_ms': res['phases_ms'],
                # `roofline`: the kernel family that dominates the step's time at this precision; the others ride along

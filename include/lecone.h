@@ -401,6 +401,10 @@ int lec_conv_f32_wgrad_fused(const float* dy, const float* x, int N, int H, int 
 int lec_bn_bwd_pass1_coeffs_f32(const void* dy, const void* dy2, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* gamma,
                                 const float* save_mean, const float* save_invstd, void* g, float* dgamma, float* dbeta, float* coef,
                                 void* workspace, int64_t workspace_bytes, lec_stream_t stream);   /* pass 1 as a kernel (writes g) + the same coefficients */
+/*     lec_bn_bwd_accumulate(1): from now on every BatchNorm backward of this process ADDS d gamma / d beta into its output slots (float
+ *     atomics) instead of overwriting them -- for a step that runs several backward passes over the same parameters, possibly on
+ *     concurrent streams, and zeroes the slots once per step.  Returns the previous setting (process-wide; set it before the steps). */
+int lec_bn_bwd_accumulate(int on);
 int lec_bn_bwd_coeffs_f32(int64_t M, int C, int n_partials, const float* gamma, const float* save_mean, const float* save_invstd,
                           float* dgamma, float* dbeta, float* coef, void* workspace, int64_t workspace_bytes, lec_stream_t stream);
 int lec_conv_f32_wgrad(const float* dy, const float* x, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,

@@ -366,14 +366,19 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const void* _
   }
 }
 
+// Parameter gradients: overwritten, or (lec_bn_bwd_accumulate(1)) ADDED with float atomics -- a step that runs several backward passes
+// over the same parameters, possibly on concurrent streams (the engine's half-batch passes), zeroes the slots once per step.
+static int g_bn_accumulate = 0;
+
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, int64_t M,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ c1, float* __restrict__ c2) {
+                                       float* __restrict__ c1, float* __restrict__ c2, int accumulate) {
   const int c = blockIdx.x * kFinCh + threadIdx.x % kFinCh, split = threadIdx.x / kFinCh;
   double s, q;
   reduce_partials_256(part, nblk, C, c, split, s, q);
   if (split != 0 || c >= C) return;
-  dbeta[c] = (float)s; dgamma[c] = (float)q;
+  if (accumulate) { atomicAdd(dbeta + c, (float)s); atomicAdd(dgamma + c, (float)q); }
+  else { dbeta[c] = (float)s; dgamma[c] = (float)q; }
   c1[c] = (float)(s / (double)M); c2[c] = (float)(q / (double)M);
 }
 
@@ -381,12 +386,13 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk,
 // dx = gamma invstd (g - c1 - xhat c2), xhat = (x - mean) invstd, i.e. dx = A g + B x + D with the per-channel A, B, D written here
 __global__ void bn_bwd_coeffs_kernel(const float* __restrict__ part, int nblk, int C, int64_t M, const float* __restrict__ gamma,
                                      const float* __restrict__ mean, const float* __restrict__ invstd,
-                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef, int accumulate) {
   const int c = blockIdx.x * kFinCh + threadIdx.x % kFinCh, split = threadIdx.x / kFinCh;
   double s, q;
   reduce_partials_256(part, nblk, C, c, split, s, q);
   if (split != 0 || c >= C) return;
-  dbeta[c] = (float)s; dgamma[c] = (float)q;
+  if (accumulate) { atomicAdd(dbeta + c, (float)s); atomicAdd(dgamma + c, (float)q); }
+  else { dbeta[c] = (float)s; dgamma[c] = (float)q; }
   const double c1 = s / (double)M, c2 = q / (double)M;
   const double is = (double)invstd[c], gs = (double)gamma[c] * is;
   coef[c] = (float)gs; coef[C + c] = (float)(-gs * is * c2); coef[2 * C + c] = (float)(gs * (is * c2 * (double)mean[c] - c1));
@@ -444,6 +450,10 @@ static int bn_check(const char* who, int64_t M, int C) {
 
 }  // namespace lec
 
+extern "C" int lec_bn_bwd_accumulate(int on) {
+  const int prev = lec::g_bn_accumulate; lec::g_bn_accumulate = on ? 1 : 0; return prev;
+}
+
 extern "C" int64_t lec_bn_workspace_bytes(int C) {
   if (C <= 0) return LEC_E_ARG;
   return ((int64_t)lec::kBnMaxBlocks * 2 * C + 4 * (int64_t)C) * sizeof(float);
@@ -499,7 +509,7 @@ template <typename E> static int bn_bwd_impl(const void* dy, const void* dy2, co
 #define R(M_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<E, M_>), dim3(g.nrb, g.NCH), dim3(kBnThreads), 0, st, dy, dy2, ym, x, M, C, g.CV, g.CVB, g.RPIB, save_mean, save_invstd, part, dresidual)
   if (rm == 0) R(0); else if (rm == 1) R(1); else R(2);
 #undef R
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, g.nrb, C, M, dgamma, dbeta, c1, c2);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, g.nrb, C, M, dgamma, dbeta, c1, c2, g_bn_accumulate);
   int64_t nb = (M + g.RPI - 1) / g.RPI; nb = (nb + 1) / 2;
   const int nblk = (int)(nb < 1 ? 1 : (nb > bn_apply_cap() ? bn_apply_cap() : nb));
 #define A(RES_, RELU_) hipLaunchKernelGGL((bn_bwd_apply_kernel<E, RES_, RELU_>), dim3(nblk), dim3(kBnThreads), 0, st, dy, dy2, ym, x, M, g.CV, g.RPI, gamma, save_mean, save_invstd, c1, c2, dx, dresidual)
@@ -550,7 +560,7 @@ template <typename E> static int bn_bwd_pass1_impl(const void* dy, const void* d
 #define R(M_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<E, M_>), dim3(geo.nrb, geo.NCH), dim3(kBnThreads), 0, st, dy, dy2, relu_mask, x, M, C, geo.CV, geo.CVB, geo.RPIB, save_mean, save_invstd, part, g)
   if (relu_mask) R(2); else R(0);
 #undef R
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, geo.nrb, C, M, dgamma, dbeta, c1, c2);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, geo.nrb, C, M, dgamma, dbeta, c1, c2, g_bn_accumulate);
   LEC_CHECK_LAUNCH("bn_bwd_pass1 kernels");
   return LEC_OK;
 }
@@ -565,7 +575,7 @@ extern "C" int lec_bn_bwd_finalize(int64_t M, int C, int n_partials, float* dgam
   float* part = (float*)workspace;
   float* c1 = part + (int64_t)kBnMaxBlocks * 2 * C; float* c2 = c1 + C;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, (hipStream_t)stream, part, n_partials, C, M, dgamma, dbeta,
-                     c1, c2);
+                     c1, c2, g_bn_accumulate);
   LEC_CHECK_LAUNCH("bn_bwd_finalize_kernel");
   return LEC_OK;
 }
@@ -578,7 +588,7 @@ extern "C" int lec_bn_bwd_coeffs_f32(int64_t M, int C, int n_partials, const flo
   LEC_CHECK_ARG(n_partials >= 1 && n_partials <= kBnMaxBlocks, "bn_bwd_coeffs: n_partials=%d outside 1..%d", n_partials, kBnMaxBlocks);
   LEC_CHECK_ARG(workspace_bytes >= lec_bn_workspace_bytes(C), "bn_bwd_coeffs: workspace too small");
   hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, (hipStream_t)stream, (const float*)workspace, n_partials, C, M,
-                     gamma, save_mean, save_invstd, dgamma, dbeta, coef);
+                     gamma, save_mean, save_invstd, dgamma, dbeta, coef, g_bn_accumulate);
   LEC_CHECK_LAUNCH("bn_bwd_coeffs_kernel");
   return LEC_OK;
 }
@@ -599,7 +609,7 @@ extern "C" int lec_bn_bwd_pass1_coeffs_f32(const void* dy, const void* dy2, cons
   if (relu_mask) R(2); else R(0);
 #undef R
   hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, geo.nrb, C, M, gamma, save_mean, save_invstd,
-                     dgamma, dbeta, coef);
+                     dgamma, dbeta, coef, g_bn_accumulate);
   LEC_CHECK_LAUNCH("bn_bwd_pass1_coeffs kernels");
   return LEC_OK;
 }
@@ -632,7 +642,7 @@ template <typename E> static int bn_bwd_prereduced_impl(const void* g, const voi
   BnGeom geo = bn_geom(M, C);
   float* part = (float*)workspace;
   float* c1 = part + (int64_t)kBnMaxBlocks * 2 * C; float* c2 = c1 + C;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, n_partials, C, M, dgamma, dbeta, c1, c2);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, n_partials, C, M, dgamma, dbeta, c1, c2, g_bn_accumulate);
   int64_t nb = (M + geo.RPI - 1) / geo.RPI; nb = (nb + 1) / 2;
   const int nblk = (int)(nb < 1 ? 1 : (nb > bn_apply_cap() ? bn_apply_cap() : nb));
   hipLaunchKernelGGL((bn_bwd_apply_kernel<E, false, 0>), dim3(nblk), dim3(kBnThreads), 0, st, g, nullptr,

@@ -54,8 +54,8 @@ def make_labelmap(name):
 
 class StepEngine:
     def __init__(self, workload='cfg3', n_images=4096, pool_images=None, dtype='bf16', lr=1e-4, alpha=0.01, K_cone=0.1,
-                 sampler_mode='replicated', seed=0, batch=None, device=None, overlap_wgrad=True, use_graph=False,
-                 graph_after=3, table_dtype='fp32', cnn_chunk=None):
+                 sampler_mode='replicated', seed=0, batch=None, device=None, overlap_wgrad=None, use_graph=False,
+                 graph_after=3, table_dtype='fp32', cnn_chunk=None, passes=None):
         hier, arch, B, K, D, hw = WORKLOADS[workload]
         self.workload, self.arch, self.B, self.K, self.D, self.hw = workload, arch, batch or B, K, D, hw
         self.rank, self.local_rank, self.world = parallel.init_process_group()
@@ -116,6 +116,20 @@ class StepEngine:
             raise ValueError('workload %s at B=%d pushes %d images through %s per step (%d image negatives per positive): about %.0f GB of '
                              'activations, more than one MI355X holds; pass a smaller `batch` (e.g. %d)'
                              % (workload, self.B, self.n_rows, arch, self.cnt, self.n_rows * per_row_gb, max(1, int(200 / per_row_gb / (1 + self.cnt)))))
+        # Concurrent passes (fp32): the step's CNN rows go through the backbone as `passes` equal parts -- with one image negative per
+        # positive: the positives' images | the image negatives, the reference's own split into separate forwards (oe_h.py:980-985,
+        # 1003-1009: separate BatchNorm batches) -- each on its own HIP stream.  At fp32 the convolutions are bound by the matrix pipe
+        # and the BatchNorm passes by HBM: with ONE pass they alternate on one stream and the step is the sum of its kernels; with two,
+        # one pass's BatchNorm traffic runs under the other's convolutions (ResNet-50 fwd + bwd of 512 rows: 145.2 -> 133.7 ms,
+        # tools/exp_two_streams_f32.py).  The weight gradients then run in line (a third stream adds nothing once the matrix pipe is
+        # busy all the time: 137.1 ms).  The bf16 stack is HBM-bound everywhere and keeps one pass (measured in round 1: 53.5 vs 51.8 ms).
+        if passes is None:
+            passes = 2 if (dtype == 'fp32' and self.cnn_chunk is None and self.n_rows % 2 == 0 and self.n_rows >= 16) else 1
+        if passes > 1 and (self.cnn_chunk is not None or self.n_rows % passes):
+            raise ValueError('passes=%d needs an unchunked step whose %d CNN rows divide evenly' % (passes, self.n_rows))
+        self.passes = int(passes)
+        if overlap_wgrad is None:
+            overlap_wgrad = self.passes == 1
         torch.manual_seed(0)                                              # oe_h.py:1338: table init from seed 0
         self.criterion = EuclideanConesWithImagesHypernymLoss(lm, K, {}, alpha, pick_per_level=True, K=K_cone, use_CNN=True)
         self.model = Embedder(D, lm, None, K=K_cone).to(self.device)
@@ -167,6 +181,11 @@ class StepEngine:
         self.use_graph = bool(use_graph) and self.cnn_chunk is None      # the chunked step launches eagerly
         if self.cnn_chunk is not None and self.overlap is not None:
             self.overlap.accumulate = True
+        self.pass_streams = [torch.cuda.Stream() for _ in range(self.passes)] if self.passes > 1 else []
+        if self.passes > 1:
+            # several backward passes add into the same gradient slots from concurrent streams: BatchNorm's d gamma / d beta are ADDED
+            # with atomics (like the weight gradients); the arena is zeroed once per step
+            _lib.lib.lec_bn_bwd_accumulate(1)
         self.graph_after = graph_after
         self.hip_graph = None
         self.graph_out = None
@@ -308,6 +327,8 @@ class StepEngine:
         region the hipGraph captures."""
         if self.cnn_chunk is not None:
             return self._core_chunked(ev)
+        if self.passes > 1:
+            return self._core_passes(ev)
         codes = self.codes_dev
         pos_from = codes[:, 0].contiguous(); pos_to = codes[:, 1].contiguous(); negc = codes[:, 2:].contiguous()
         images = self.pool.index_select(0, self.idx_dev)
@@ -325,6 +346,58 @@ class StepEngine:
             self.overlap.join()                       # weight gradients from the side stream
         if self.graph_reduces and torch.cuda.is_current_stream_capturing():
             self.reducer.finish()                     # in-graph: the buckets launched by the hooks during backward join here
+        if ev: ev[3].record()
+        return loss, e_pos, e_neg
+
+    def _core_passes(self, ev=None):
+        """`_core` with the CNN rows as `passes` concurrent parts, one HIP stream each (see __init__): forward of every part, join, ONE
+        fused loss launch over all raw outputs, backward of every part, join.  BatchNorm statistics are per part; the running statistics
+        are updated in part order (ops.PASS_ORDER); parameter gradients of the parts add up in the arena (atomics)."""
+        codes = self.codes_dev
+        pos_from = codes[:, 0].contiguous(); pos_to = codes[:, 1].contiguous(); negc = codes[:, 2:].contiguous()
+        images = self.pool.index_select(0, self.idx_dev)
+        self.arena.zero_grad(); self.table_grad.zero_(); self.gfeat.zero_()
+        if ev: ev[0].record()
+        cur = torch.cuda.current_stream()
+        h = self.n_rows // self.passes
+        parts, order = [], {}
+        live = self.reducer.live
+        self.reducer.live = False                      # every parameter reports once per part: the buckets are reduced after the last part
+        try:
+            for p, st in enumerate(self.pass_streams):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    ops.PASS_ORDER = (order, p)
+                    try:
+                        f = self.img_feat_net.forward_raw(images[p * h:(p + 1) * h])
+                    finally:
+                        ops.PASS_ORDER = None
+                    parts.append(f)
+                    f.record_stream(cur)
+            for st in self.pass_streams:
+                images.record_stream(st)
+            for st in self.pass_streams:
+                cur.wait_stream(st)
+            feats = torch.cat([f.detach() for f in parts])
+            self.last_feats = feats
+            if ev: ev[1].record()
+            loss, e_pos, e_neg = ops.joint_loss_raw(self.table, feats, pos_from, pos_to, negc, None, self.K_cone,
+                                                    self.alpha, _lib.ENERGY_HYP_CONE, _lib.LABEL_HYP, _lib.IMAGE_SOFTCLIP,
+                                                    self.table_grad, self.gfeat, table_f16=self.table_h)
+            if ev: ev[2].record()
+            for p, st in enumerate(self.pass_streams):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    parts[p].backward(self.gfeat[p * h:(p + 1) * h])
+                    if self.overlap is not None:
+                        self.overlap.join()
+            for st in self.pass_streams:
+                cur.wait_stream(st)
+        finally:
+            self.reducer.live = live
+            self.reducer.reset()
+        if self.graph_reduces and torch.cuda.is_current_stream_capturing():
+            self.reducer.reduce_now()
         if ev: ev[3].record()
         return loss, e_pos, e_neg
 
@@ -393,6 +466,8 @@ class StepEngine:
 
     def close(self):
         self.prefetch.close()
+        if self.passes > 1:
+            _lib.lib.lec_bn_bwd_accumulate(0)
         if WgradOverlap.instance is self.overlap:
             WgradOverlap.instance = None
         _release_graphs(self)

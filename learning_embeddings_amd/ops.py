@@ -325,6 +325,10 @@ class FusionContext:
         self.ws_owner = [0, 0]
         self._ws = {}
 
+    def busy(self):
+        """Records of a forward whose backward has not finished yet are still here."""
+        return bool(self.forks or self.folded or self.deferred or self.lazy_ok or self.lazy_dx)
+
     def reset(self):
         """Drop the records of a forward whose backward never ran (or raised)."""
         for d in (self.forks, self.folded, self.deferred, self.lazy_ok, self.lazy_dx):
@@ -372,6 +376,12 @@ def _with_ctx_fusion(backward):
             return backward(ctx, *grads)
     return wrapped
 
+
+# A step that pushes its CNN rows through the backbone as several CONCURRENT passes (engine.StepEngine, one HIP stream per pass) sets
+# PASS_ORDER = (dict, pass index): the running statistics of a BatchNorm layer are then updated in pass order -- pass p's launch
+# waits for pass p - 1's launch of the same layer (an event per layer; pass p - 1 is always enqueued first and runs ahead) -- so
+# that they hold EMA(EMA(r, batch of pass 0), batch of pass 1), the reference's sequence of forwards, not a race between streams.
+PASS_ORDER = None
 
 FOLD_BN_BWD = _os.environ.get('LEC_FOLD_BN_BWD', '1') != '0'
 # fp32 counterparts (round 3): pass 1 of a BatchNorm backward in the epilogue of the fp32 data gradient that produces its gradient
@@ -424,6 +434,11 @@ class BNActFn(torch.autograd.Function):
         if residual is not None and (_nhwc_rows(residual, 'residual') != (M, Cc) or residual.dtype != x.dtype):
             raise ValueError('residual shape / dtype mismatch')
         ctx.fc = fusion()
+        order = PASS_ORDER if (training and PASS_ORDER is not None and x.is_cuda) else None
+        if order is not None and order[1] > 0:
+            prev_ev = order[0].get((running_mean.data_ptr(), order[1] - 1))
+            if prev_ev is not None:
+                torch.cuda.current_stream().wait_event(prev_ev)
         es = x.element_size()                         # 2 (bf16) or 4 (fp32) bytes per activation element
         y = torch.empty_like(x)                       # preserves channels_last
         save_mean = torch.empty(Cc, dtype=torch.float32, device=x.device); save_invstd = torch.empty_like(save_mean)
@@ -464,6 +479,9 @@ class BNActFn(torch.autograd.Function):
                                                    dptr(running_mean), dptr(running_var), int(bool(training)), dptr(save_mean),
                                                    dptr(save_invstd), dptr(y), int(bool(relu)), dptr(mask), dptr(ws), ws.numel(),
                                                    stream_ptr())), nbytes)
+        if order is not None:
+            done_ev = torch.cuda.Event(); done_ev.record()
+            order[0][(running_mean.data_ptr(), order[1])] = done_ev
         if training:
             ctx.save_for_backward(x, mask, weight, save_mean, save_invstd)
             ctx.meta = (M, Cc, bool(relu), residual is not None)
@@ -512,8 +530,8 @@ class BNActFn(torch.autograd.Function):
         if sink is not None and sink[0].grad is not None and sink[1].grad is not None:
             dgamma, dbeta = sink[0].grad, sink[1].grad           # the flat arena's slots: no AccumulateGrad kernels
         else:
-            sink = None
-            dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device); dbeta = torch.empty_like(dgamma)
+            sink = None                               # (zeros, not empty: under lec_bn_bwd_accumulate(1) the kernels ADD into these)
+            dgamma = torch.zeros(Cc, dtype=torch.float32, device=x.device); dbeta = torch.zeros_like(dgamma)
         ws = _bn_workspace(x.device)
         fusion().ws_owner[0] = 0
         el = M * Cc                                   # 2 x (dy [+ dy2] + x [+ mask]) + dx [+ d residual]

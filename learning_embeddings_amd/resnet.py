@@ -519,20 +519,32 @@ class ResNet(nn.Module):
             x = x.to(torch.get_autocast_dtype('cuda'))          # the stem conv sees low-precision input like every other layer
         if not x.is_cuda:
             return self._forward(x)
-        # the fused paths' hand-off records and BatchNorm workspace of THIS instance (ops.FusionContext): a second backbone in the
-        # process, or another forward of this one between its forward and backward (the chunked step), has its own
-        fc = self.__dict__.get('_fusion')
+        # The fused paths' hand-off records and BatchNorm workspace belong to ONE forward / backward pair of THIS instance
+        # (ops.FusionContext).  A second backbone in the process has its own; so has a second forward of this one that starts before the
+        # first one's backward has run (the engine's concurrent half-batch passes): the pool below hands out a context that is not in use.
+        pool = self.__dict__.setdefault('_fusions', [])
+        track = self.training and torch.is_grad_enabled()
+        fc = next((c for c in pool if not c.busy()), None)
         if fc is None:
-            fc = self.__dict__['_fusion'] = _ops().FusionContext()
-        fc.reset()                                              # records of a forward whose backward never ran (or raised)
+            if len(pool) < 4:
+                fc = _ops().FusionContext(); pool.append(fc)
+            else:                                               # forwards whose backward never ran (or raised): recycle the oldest
+                fc = pool.pop(0); pool.append(fc)
+        fc.reset()
+        self.__dict__['_fusion'] = fc
         with _ops().use_fusion(fc):
-            return self._forward(x)
+            y = self._forward(x)
+        if not track:
+            fc.reset()                                          # no backward will come for these records
+        return y
 
     @property
     def fusion(self):
+        """The FusionContext of the most recent forward."""
         fc = self.__dict__.get('_fusion')
         if fc is None:
-            fc = self.__dict__['_fusion'] = _ops().FusionContext()
+            fc = _ops().FusionContext()
+            self.__dict__.setdefault('_fusions', []).append(fc); self.__dict__['_fusion'] = fc
         return fc
 
     def _forward(self, x):

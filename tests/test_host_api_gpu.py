@@ -427,11 +427,11 @@ def test_chunked_cnn_rows_step_equals_unchunked_step_up_to_batchnorm_batches():
     """engine cnn_chunk: the step's CNN rows pushed through the backbone a chunk at a time (forward without saved activations, the
     loss on all outputs, re-forward + backward per chunk).  With ONE chunk covering every row the result must equal the plain step
     (same BatchNorm batch): loss, label-table update and image-network gradients."""
-    a = StepEngine('tiny', n_images=64, dtype='fp32')
+    a = StepEngine('tiny', n_images=64, dtype='fp32', passes=1)
     b = StepEngine('tiny', n_images=64, dtype='fp32', cnn_chunk=10 ** 6)           # >= n_rows: normalised to "no chunking"
     assert b.cnn_chunk is None
     b.close()
-    b = StepEngine('tiny', n_images=64, dtype='fp32')
+    b = StepEngine('tiny', n_images=64, dtype='fp32', passes=1)
     b.cnn_chunk = b.n_rows                                                          # force the chunked code path with a single chunk
     b.overlap.accumulate = True
     for _ in range(2):
@@ -979,3 +979,49 @@ def test_bench_gpus_2_self_launches_on_one_gpu():
     dp = out['data_parallel']
     assert dp['world_size'] == 2 and dp['replicas_identical_after_run'] is True and len(dp['buckets']) >= 2
     assert out['config']['global_batch'] == 2 * 8 and out['value'] > 0
+
+
+def test_step_engine_concurrent_half_batch_passes_equal_the_same_passes_in_turn():
+    """engine `passes=2` (the fp32 default): the step's CNN rows go through the backbone as two concurrent parts (positives' images |
+    image negatives), one HIP stream each, BatchNorm statistics per part.  Must equal the same two parts pushed through IN TURN on
+    one stream by plain autograd calls -- raw outputs bit for bit (deterministic forward kernels), loss, label-table update, the
+    parameter gradients up to float-atomic summation order, and the BatchNorm running statistics (updated in part order: positives,
+    then negatives) -- and differ from the one-pass step (whose BatchNorm batch is all rows)."""
+    a = StepEngine('tiny', n_images=64, dtype='fp32')
+    assert a.passes == 2 and a.overlap.side is None
+    b = StepEngine('tiny', n_images=64, dtype='fp32', passes=1, overlap_wgrad=False)
+    c = StepEngine('tiny', n_images=64, dtype='fp32', passes=1, overlap_wgrad=False)
+    b.img_feat_net.load_state_dict(a.img_feat_net.state_dict()); c.img_feat_net.load_state_dict(a.img_feat_net.state_dict())
+    h = b.n_rows // 2
+
+    def core_in_turn(ev=None):                                   # reference: the two parts one after the other, one stream
+        codes = b.codes_dev
+        images = b.pool.index_select(0, b.idx_dev)
+        b.arena.zero_grad(); b.table_grad.zero_(); b.gfeat.zero_()
+        from learning_embeddings_amd import _lib
+        _lib.lib.lec_bn_bwd_accumulate(1)
+        try:
+            parts = [b.img_feat_net.forward_raw(images[p * h:(p + 1) * h]) for p in range(2)]
+            feats = torch.cat([f.detach() for f in parts]); b.last_feats = feats
+            out = ops.joint_loss_raw(b.table, feats, codes[:, 0].contiguous(), codes[:, 1].contiguous(), codes[:, 2:].contiguous(), None, b.K_cone, b.alpha,
+                                     _lib.ENERGY_HYP_CONE, _lib.LABEL_HYP, _lib.IMAGE_SOFTCLIP, b.table_grad, b.gfeat)
+            for p in range(2):
+                parts[p].backward(b.gfeat[p * h:(p + 1) * h])
+        finally:
+            _lib.lib.lec_bn_bwd_accumulate(0)
+        return out
+    b._core = core_in_turn
+    for s_ in range(2):
+        la = a.step(); lb = b.step(); lc = c.step()
+        torch.cuda.synchronize()
+        assert torch.equal(a.last_feats, b.last_feats), s_
+        assert not torch.equal(a.last_feats, c.last_feats)          # one BatchNorm batch of all rows is a different function
+        assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(la)))
+        d = (a.arena.grad - b.arena.grad).double().norm().item() / b.arena.grad.double().norm().item()
+        assert d < 1e-5, d
+    assert (a.table - b.table).abs().max().item() < 1e-7
+    bufs_a = dict(a.img_feat_net.named_buffers()); bufs_b = dict(b.img_feat_net.named_buffers())
+    for k in bufs_a:
+        if 'running' in k:
+            assert torch.allclose(bufs_a[k], bufs_b[k], rtol=1e-6, atol=1e-7), k
+    a.close(); b.close(); c.close()
