@@ -350,9 +350,11 @@ class StepEngine:
         return loss, e_pos, e_neg
 
     def _core_passes(self, ev=None):
-        """`_core` with the CNN rows as `passes` concurrent parts, one HIP stream each (see __init__): forward of every part, join, ONE
-        fused loss launch over all raw outputs, backward of every part, join.  BatchNorm statistics are per part; the running statistics
-        are updated in part order (ops.PASS_ORDER); parameter gradients of the parts add up in the arena (atomics)."""
+        """`_core` with the CNN rows as `passes` concurrent parts, one HIP stream each (see __init__): backbone forward of every part up
+        to the pooled features, join, the fully connected layer over all rows + ONE fused loss launch + the layer's backward on the main
+        stream, backbone backward of every part, join.  BatchNorm statistics are per part; the running statistics are updated in part
+        order (ops.PASS_ORDER); the convolutions' and BatchNorms' parameter gradients of the parts add up in the arena (atomics); the
+        fully connected layer -- the only parameters whose gradients go through autograd's AccumulateGrad -- stays on ONE stream."""
         codes = self.codes_dev
         pos_from = codes[:, 0].contiguous(); pos_to = codes[:, 1].contiguous(); negc = codes[:, 2:].contiguous()
         images = self.pool.index_select(0, self.idx_dev)
@@ -369,7 +371,7 @@ class StepEngine:
                 with torch.cuda.stream(st):
                     ops.PASS_ORDER = (order, p)
                     try:
-                        f = self.img_feat_net.forward_raw(images[p * h:(p + 1) * h])
+                        f = self.img_feat_net.forward_pooled(images[p * h:(p + 1) * h])
                     finally:
                         ops.PASS_ORDER = None
                     parts.append(f)
@@ -378,17 +380,21 @@ class StepEngine:
                 images.record_stream(st)
             for st in self.pass_streams:
                 cur.wait_stream(st)
-            feats = torch.cat([f.detach() for f in parts])
-            self.last_feats = feats
+            pooled = torch.cat([f.detach() for f in parts]).requires_grad_(True)
+            feats = self.img_feat_net.head(pooled)
+            self.last_feats = feats.detach()
             if ev: ev[1].record()
-            loss, e_pos, e_neg = ops.joint_loss_raw(self.table, feats, pos_from, pos_to, negc, None, self.K_cone,
+            loss, e_pos, e_neg = ops.joint_loss_raw(self.table, feats.detach(), pos_from, pos_to, negc, None, self.K_cone,
                                                     self.alpha, _lib.ENERGY_HYP_CONE, _lib.LABEL_HYP, _lib.IMAGE_SOFTCLIP,
                                                     self.table_grad, self.gfeat, table_f16=self.table_h)
             if ev: ev[2].record()
+            feats.backward(self.gfeat)                 # fc: d weight, d bias (AccumulateGrad on this stream), d pooled
+            gp = pooled.grad
             for p, st in enumerate(self.pass_streams):
                 st.wait_stream(cur)
+                gp.record_stream(st)
                 with torch.cuda.stream(st):
-                    parts[p].backward(self.gfeat[p * h:(p + 1) * h])
+                    parts[p].backward(gp[p * h:(p + 1) * h])
                     if self.overlap is not None:
                         self.overlap.join()
             for st in self.pass_streams:

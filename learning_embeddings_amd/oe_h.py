@@ -108,6 +108,18 @@ class _ImageNetBase(nn.Module):
             y = self.model(x)
         return y.float()
 
+    def forward_pooled(self, x):
+        """The backbone up to its global average pooling, fp32 [n, fc.in_features]; `head` finishes forward_raw.  (fp32 only: the
+        engine's concurrent passes, which pool per pass and apply the fully connected layer once.)"""
+        if self.channels_last and x.dim() == 4:
+            x = x.contiguous(memory_format=torch.channels_last)
+        if self.compute_dtype != torch.float32:
+            raise NotImplementedError('forward_pooled serves the fp32 backbone')
+        return self.model(x, pooled_only=True)
+
+    def head(self, pooled):
+        return self.model.fc(pooled).float()
+
     def forward(self, x):
         y = self.forward_raw(x)
         return self.soft_clip(y) if self.K else y

@@ -514,11 +514,13 @@ class ResNet(nn.Module):
             layers.append(block(self.inplanes, planes))
         return nn.Sequential(*layers)
 
-    def forward(self, x):
+    def forward(self, x, pooled_only=False):
+        """pooled_only: stop after the global average pooling ([n, 512 * expansion] features); `self.fc` is then the caller's to apply --
+        the engine's concurrent half-batch passes pool per pass and run the fully connected layer ONCE over all rows."""
         if x.is_cuda and torch.is_autocast_enabled() and x.dtype == torch.float32:
             x = x.to(torch.get_autocast_dtype('cuda'))          # the stem conv sees low-precision input like every other layer
         if not x.is_cuda:
-            return self._forward(x)
+            return self._forward(x, pooled_only)
         # The fused paths' hand-off records and BatchNorm workspace belong to ONE forward / backward pair of THIS instance
         # (ops.FusionContext).  A second backbone in the process has its own; so has a second forward of this one that starts before the
         # first one's backward has run (the engine's concurrent half-batch passes): the pool below hands out a context that is not in use.
@@ -533,7 +535,7 @@ class ResNet(nn.Module):
         fc.reset()
         self.__dict__['_fusion'] = fc
         with _ops().use_fusion(fc):
-            y = self._forward(x)
+            y = self._forward(x, pooled_only)
         if not track:
             fc.reset()                                          # no backward will come for these records
         return y
@@ -547,13 +549,13 @@ class ResNet(nn.Module):
             self.__dict__.setdefault('_fusions', []).append(fc); self.__dict__['_fusion'] = fc
         return fc
 
-    def _forward(self, x):
+    def _forward(self, x, pooled_only=False):
         x = self.maxpool(self.bn1(self.conv1(x)))
         blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
         for i, b in enumerate(blocks):
             x = b(x, fork=i + 1 < len(blocks))                  # every block output but the last feeds two branches
         x = torch.flatten(self.avgpool(x), 1)
-        return self.fc(x)
+        return x if pooled_only else self.fc(x)
 
 
 def resnet18(num_classes=1000):

@@ -557,8 +557,8 @@ def test_two_backbones_interleaved_in_one_process_do_not_share_fusion_records(dt
         WgradOverlap.instance.join(); torch.cuda.synchronize()
         return [p_.grad.double().clone() for p_ in m.parameters()]
 
-    xs = [torch.rand(4, 3, 64, 64, device=DEV, generator=torch.Generator(DEV).manual_seed(5 + i)).contiguous(memory_format=torch.channels_last) for i in range(2)]
-    gs = [torch.randn(4, 10, device=DEV, generator=torch.Generator(DEV).manual_seed(9 + i)) for i in range(2)]
+    xs = [torch.rand(8, 3, 96, 96, device=DEV, generator=torch.Generator(DEV).manual_seed(5 + i)).contiguous(memory_format=torch.channels_last) for i in range(2)]
+    gs = [torch.randn(8, 10, device=DEV, generator=torch.Generator(DEV).manual_seed(9 + i)) for i in range(2)]
     calls = {}
     names = ['conv1x1_dgrad_bnfold_rows', 'conv1x1_stats_rows', 'conv1x1_wgrad_bnapply_rows', 'conv_f32_fwd']
     origs = {n: getattr(ops, n) for n in names}
@@ -570,10 +570,12 @@ def test_two_backbones_interleaved_in_one_process_do_not_share_fusion_records(dt
         setattr(ops, n, counted)
     WgradOverlap.instance = WgradOverlap()
     try:
-        alone = []
-        for i in range(2):
-            m = make(i); y = fwd(m, xs[i]); y.backward(gs[i]); alone.append((y.detach().double(), grads(m)))
-            assert not m.fusion.forks and not m.fusion.lazy_dx and not m.fusion.deferred
+        alone, again = [], []
+        for rep in (alone, again):                                 # twice: the second run is the yardstick for run-to-run noise (the library's
+            for i in range(2):                                     # bf16 convolutions and every float-atomic weight gradient are not bit-reproducible)
+                tag[0] = 'alone' if rep is alone else 'again'
+                m = make(i); y = fwd(m, xs[i]); y.backward(gs[i]); rep.append((y.detach().double(), grads(m)))
+                assert not m.fusion.forks and not m.fusion.lazy_dx and not m.fusion.deferred
         tag[0] = 'mixed'
         A, B = make(0), make(1)
         assert A.fusion is not B.fusion and A.fusion.workspace(xs[0].device).data_ptr() != B.fusion.workspace(xs[0].device).data_ptr()
@@ -590,11 +592,12 @@ def test_two_backbones_interleaved_in_one_process_do_not_share_fusion_records(dt
         assert calls.get(('mixed', n), 0) == calls.get(('alone', n), 0), (n, calls)
     assert calls.get(('alone', 'conv1x1_dgrad_bnfold_rows' if dtype == torch.bfloat16 else 'conv_f32_fwd'), 0) > 0, calls
     cos = lambda a, b: torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
-    for (y1, g1), (y2, g2) in zip(alone, mixed):
+    for (y1, g1), (y2, g2), (y3, g3) in zip(alone, mixed, again):
         if dtype == torch.float32:
             assert torch.equal(y1, y2)                             # forward: liblecone's deterministic kernels, same workspace discipline
         else:                                                      # the library's bf16 convolutions may settle on another solver between
             assert (y1 - y2).abs().max().item() <= 0.05 * (1 + y1.abs().max().item())    # the first and later calls: bf16 rounding level
-        for a, b in zip(g1, g2):
+        for a, b, c in zip(g1, g2, g3):
             if a.numel() > 1 and a.norm() > 0:
-                assert cos(a, b) > 0.9999, (a.shape, cos(a, b))
+                noise = 1.0 - cos(a, c)
+                assert 1.0 - cos(a, b) <= 10 * noise + 1e-4, (a.shape, 1.0 - cos(a, b), noise)

@@ -984,7 +984,7 @@ def test_bench_gpus_2_self_launches_on_one_gpu():
 def test_step_engine_concurrent_half_batch_passes_equal_the_same_passes_in_turn():
     """engine `passes=2` (the fp32 default): the step's CNN rows go through the backbone as two concurrent parts (positives' images |
     image negatives), one HIP stream each, BatchNorm statistics per part.  Must equal the same two parts pushed through IN TURN on
-    one stream by plain autograd calls -- raw outputs bit for bit (deterministic forward kernels), loss, label-table update, the
+    one stream by plain autograd calls -- raw outputs (deterministic forward kernels; one fully connected GEMM over all rows against two), loss, label-table update, the
     parameter gradients up to float-atomic summation order, and the BatchNorm running statistics (updated in part order: positives,
     then negatives) -- and differ from the one-pass step (whose BatchNorm batch is all rows)."""
     a = StepEngine('tiny', n_images=64, dtype='fp32')
@@ -1014,7 +1014,7 @@ def test_step_engine_concurrent_half_batch_passes_equal_the_same_passes_in_turn(
     for s_ in range(2):
         la = a.step(); lb = b.step(); lc = c.step()
         torch.cuda.synchronize()
-        assert torch.equal(a.last_feats, b.last_feats), s_
+        assert torch.allclose(a.last_feats, b.last_feats, rtol=1e-5, atol=1e-6), s_   # (the fully connected GEMM sees 16 rows here, 8 + 8 there)
         assert not torch.equal(a.last_feats, c.last_feats)          # one BatchNorm batch of all rows is a different function
         assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(la)))
         d = (a.arena.grad - b.arena.grad).double().norm().item() / b.arena.grad.double().norm().item()
