@@ -35,6 +35,10 @@
 // Roofline: MFMA (f32).  Algorithmic flops 2*M*N*K per launch; bytes are noise except for layer1's 1x1 layers.
 #include "conv_geo.h"
 
+#ifndef LEC_CF_UNCOND
+#define LEC_CF_UNCOND 0
+#endif
+
 namespace lec {
 
 
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
         if (tap != cur_tap) {
           cur_tap = tap;
           const int toff = (((g.sg * ta) * g.Ws + g.sg * tb) << g.lgCs) * 4;
-          const unsigned tapbit = 1u << tap;
+          const unsigned tapbit = tap < 32 ? 1u << tap : 0u;    // (LEC_CF_UNCOND loads one chunk past the end: no such tap, all pieces out of range)
 #pragma unroll
           for (int u = 0; u < NA; ++u) cur[u] = (tapmask[u] & tapbit) ? (unsigned)(rowoff[u] + toff) : kOob;
         }
@@ -266,9 +270,17 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
       for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
         const float* sA = smem + buf * (SA + SB);
+#if LEC_CF_UNCOND
+        // no branch around the prefetch: loads, MFMAs and LDS stores of an iteration are ONE basic block the scheduler can interleave
+        // (the chunk past the end falls out of every buffer's range and is never read back)
+        load_chunk(ch + 1);
+        mma_chunk<true, B_KC, 0, BN, TM, TN>(sA, sA + SA, wm0, wn0, lane, acc);
+        store_chunk(buf ^ 1);
+#else
         if (ch + 1 < nchunks) load_chunk(ch + 1);               // global -> registers, under this chunk's MFMAs
         mma_chunk<true, B_KC, 0, BN, TM, TN>(sA, sA + SA, wm0, wn0, lane, acc);
         if (ch + 1 < nchunks) store_chunk(buf ^ 1);             // (its last readers passed the barrier one chunk ago)
+#endif
         __syncthreads();
       }
     }
@@ -403,7 +415,13 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
 // The tile is 64 (co) x 256 (tap, ci): a 256-wide B row is ONE wave-instruction (64 lanes x 16 bytes), so the pixel a piece
 // belongs to is wave-uniform and its decode runs on the scalar ALU; per lane only the (static) tap of its four columns matters.
 
-template <int WM, int WN, int TM, int TN, int WBK, bool DENSE, bool XF = false>
+// SM (gathered layers with Cin >= 64: a 256-column tile spans at most four taps): the bounds test of a gathered piece runs on the SCALAR
+// unit.  The pixel of a piece is wave-uniform and so is each tap of the tile; which lanes belong to which tap is a constant 64-bit lane
+// mask per tap "slot" (ballot, once per work item): valid lanes of a piece = OR over the slots of (the slot's tap lands inside the image at
+// this pixel ? its lane mask : 0) -- scalar compares and selects, issued in the shadow of the wave's own MFMAs -- and reaches the
+// vector unit as the predicate of ONE v_cndmask per piece (round 2: two adds, two compares and a select per piece on the vector ALU,
+// 1.69 vector instructions per MFMA, which the f32 MFMA cannot overlap).
+template <int WM, int WN, int TM, int TN, int WBK, bool DENSE, bool XF = false, bool SM = false>
 __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                        float* __restrict__ dw, WgGeo g, const float* __restrict__ xsrc = nullptr,
                                                                        const float* __restrict__ coef = nullptr) {
@@ -473,6 +491,17 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const flo
   const int rL = fdiv(tapL, g.dS);
   const int drL = rL - g.pad, dsL = tapL - rL * g.S - g.pad;
   const bool okL = j < g.Ng;
+  constexpr int kSlots = 4;
+  unsigned long long slotmask[SM ? kSlots : 1]; int sdr[SM ? kSlots : 1], sds[SM ? kSlots : 1];
+  if (SM) {
+    const int tap0 = j0 >> g.lgCin;                             // scalar: first tap of this column tile
+#pragma unroll
+    for (int q = 0; q < kSlots; ++q) {
+      const int tq = tap0 + q; const int rq = fdiv(tq, g.dS);
+      sdr[q] = rq - g.pad; sds[q] = tq - rq * g.S - g.pad;
+      slotmask[q] = __builtin_amdgcn_ballot_w64(okL && tapL == tq);
+    }
+  }
   int laneoff = ((drL * g.W + dsL) * g.Cin + ciL) * 4;         // this lane's tap / channel relative to the pixel's (0, 0) tap, bytes
   asm volatile("" : "+v"(laneoff));                          // opaque: the compiler otherwise re-derives pixoff + laneoff from (h0 + drL, w0 + dsL)
                                                               // with a 64-bit multiply-add and a v_mul_lo per piece -- vector time the f32 MFMA pays for
@@ -507,8 +536,21 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const flo
         const int t2 = fdiv(mm, g.dWo); const int wo = mm - t2 * g.Wo; const int n = fdiv(t2, g.dHo); const int ho = t2 - n * g.Ho;
         const int h0 = ho * g.stride, w0 = wo * g.stride;       // all scalar up to here
         const int pixoff = ((n * g.H + h0) * g.W + w0) * g.Cin * 4;
-        const bool ok = live && okL && (unsigned)(h0 + drL) < (unsigned)g.H && (unsigned)(w0 + dsL) < (unsigned)g.W;
-        rb[u] = bload4(rs_x, ok ? (unsigned)(pixoff + laneoff) : kOob);
+        if (SM) {
+          unsigned long long vm = 0ull;
+#pragma unroll
+          for (int q = 0; q < kSlots; ++q) {
+            const bool in = (unsigned)(h0 + sdr[q]) < (unsigned)g.H && (unsigned)(w0 + sds[q]) < (unsigned)g.W;
+            vm |= in ? slotmask[q] : 0ull;
+          }
+          vm = live ? vm : 0ull;
+          unsigned off;                                         // lanes of vm: pixoff + laneoff, the others: out of range
+          asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(off) : "v"(kOob), "v"((unsigned)(pixoff + laneoff)), "s"(vm));
+          rb[u] = bload4(rs_x, off);
+        } else {
+          const bool ok = live && okL && (unsigned)(h0 + drL) < (unsigned)g.H && (unsigned)(w0 + dsL) < (unsigned)g.W;
+          rb[u] = bload4(rs_x, ok ? (unsigned)(pixoff + laneoff) : kOob);
+        }
       }
     }
   };
@@ -533,9 +575,15 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const flo
     for (int ch = ch_lo; ch < ch_hi; ++ch) {
       const int buf = (ch - ch_lo) & 1;
       const float* sA = smem + buf * (SA + SB);
+#if LEC_CF_UNCOND
+      load_chunk(ch + 1);                                       // (past ch_hi: the next split's rows, or out of range; never read back)
+      mma_chunk<false, false, BM, BN, TM, TN, WBK>(sA, sA + SA, wm0, wn0, lane, acc);
+      store_chunk(buf ^ 1);
+#else
       if (ch + 1 < ch_hi) load_chunk(ch + 1);
       mma_chunk<false, false, BM, BN, TM, TN, WBK>(sA, sA + SA, wm0, wn0, lane, acc);
       if (ch + 1 < ch_hi) store_chunk(buf ^ 1);
+#endif
       __syncthreads();
     }
     const int l31 = lane & 31, h = lane >> 5;
@@ -733,6 +781,9 @@ extern "C" int lec_conv_f32_wgrad_fused(const float* dy, const float* x, int N, 
   const dim3 grid(total < wg_cap ? total : wg_cap), blk(kCfThreads);
   hipStream_t st = (hipStream_t)stream;
   const float* nof = nullptr;
+  // scalar bounds masks: a 256-column tile must span at most 4 taps (Cin >= 64; the stem's 4 channels keep the vector test)
+  static const int wg_sm = [] { const char* e = getenv("LEC_WGRAD_SMASK"); return e ? atoi(e) : 1; }();
+  const bool sm = !dense && Cin >= 64 && wg_sm != 0;
   if (xf) {
     LEC_CHECK_ARG(dense, "conv_f32_wgrad_fused: dense layers only");
     if (BM == 64 && BN == 256) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, true, true>), grid, blk, lds, st, dy, x, dw, g, xsrc, coef);
@@ -740,7 +791,9 @@ extern "C" int lec_conv_f32_wgrad_fused(const float* dy, const float* x, int N, 
     else if (BM == 256) hipLaunchKernelGGL((conv_f32_wgrad_kernel<4, 1, 2, 2, kWgBK, true, true>), grid, blk, lds, st, dy, x, dw, g, xsrc, coef);
     else hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 1, 1, 32, true, true>), grid, blk, lds, st, dy, x, dw, g, xsrc, coef);
   }
+  else if (big && sm) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 4, kWgBK, false, false, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (big) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 4, kWgBK, false>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
+  else if (!dense && sm) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, false, false, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (!dense) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, false>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (BM == 64 && BN == 256) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (BM == 128) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 2, kWgBK, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);

@@ -460,11 +460,25 @@ class StepEngine:
             if rs:
                 for i, n in enumerate(ns):
                     res[n] = sum(ev[i].elapsed_time(ev[i + 1]) for ev in rs) / len(rs)
+        def busy(timer):
+            """Milliseconds per step during which AT LEAST ONE launch of the family was running: the union of the launches' intervals over
+            all streams (event timestamps share one clock).  With concurrent streams the plain sum counts shared time twice."""
+            ref = timer[0][0]
+            iv = sorted((ref.elapsed_time(a), ref.elapsed_time(b)) for a, b, _ in timer)
+            tot, lo, hi = 0.0, iv[0][0], iv[0][1]
+            for s_, e_ in iv[1:]:
+                if s_ > hi:
+                    tot += hi - lo; lo, hi = s_, e_
+                else:
+                    hi = max(hi, e_)
+            return (tot + hi - lo) / max(len(recs), 1)
         if ops.BN_TIMER:
+            res['fused_bn_busy'] = busy(ops.BN_TIMER)
             res['fused_bn'] = sum(a.elapsed_time(b) for a, b, _ in ops.BN_TIMER) / max(len(recs), 1)
             self.bn_bytes_per_step = sum(n for _, _, n in ops.BN_TIMER) / max(len(recs), 1)
             self.bn_launch_groups_per_step = len(ops.BN_TIMER) / max(len(recs), 1)
         if ops.CONV_TIMER:
+            res['conv_f32_busy'] = busy(ops.CONV_TIMER)
             res['conv_f32'] = sum(a.elapsed_time(b) for a, b, _ in ops.CONV_TIMER) / max(len(recs), 1)
             self.conv_flops_per_step = sum(n for _, _, n in ops.CONV_TIMER) / max(len(recs), 1)
             self.conv_launches_per_step = len(ops.CONV_TIMER) / max(len(recs), 1)

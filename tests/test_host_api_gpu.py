@@ -207,7 +207,12 @@ def test_step_engine_hipgraph_replay_matches_eager_launches(dtype):
         assert eng.hip_graph is None and eng._graph_saved is None and eng.graph_out is None      # close() destroys the graphs, not the GC later
     le, lg = runs[False][0], runs[True][0]
     assert all(np.array_equal(a, b) for a, b in zip(runs[False][1], runs[True][1]))
-    assert np.abs(le - lg).max() <= (1e-3 if dtype == 'fp32' else 0.15) * np.abs(le).max()     # bf16: two eager runs drift by ~5 % here on their own
+    # two runs of the same training agree while their gradients are bit-equal; float-atomic summation order (weight gradients, and
+    # at fp32 the two concurrent half-batch passes) is not reproducible, Adam's first steps move every weight by +-lr whatever the
+    # size of its gradient, and this workload's BatchNorm batches are 8 rows of 1 x 1 pixels in layer4: the trajectories part after
+    # two steps (bf16: two eager runs drift by ~5 % here on their own)
+    assert np.abs(le - lg)[:2].max() <= (1e-5 if dtype == 'fp32' else 0.15) * np.abs(le).max()
+    assert np.abs(le - lg).max() <= 0.15 * np.abs(le).max()
     assert len(set(np.round(lg, 4).tolist())) > 3                           # not a stale batch replayed over and over
     assert np.abs(runs[False][2] - runs[True][2]).max() < (5e-5 if dtype == 'fp32' else 5e-3)
 
@@ -937,7 +942,7 @@ def _dp_lecone_worker(q):
     os.environ.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29631', LEC_FORCE_DIST='1', LEC_DP_BACKEND='lecone')
     import torch as t
     from learning_embeddings_amd.engine import StepEngine
-    eng = StepEngine('tiny', n_images=64, dtype='fp32', use_graph=True, graph_after=2)
+    eng = StepEngine('tiny', n_images=64, dtype='fp32', use_graph=True, graph_after=2, passes=1)     # one pass: reproducible gradients
     assert eng.reducer.enabled and eng.reducer.comm is not None
     ls = [float(eng.step()) for _ in range(4)]
     t.cuda.synchronize()
@@ -953,7 +958,7 @@ def test_step_engine_gradient_exchange_through_the_c_abi_rccl_layer():
     ctx = mp.get_context('spawn'); q = ctx.Queue()
     p = ctx.Process(target=_dp_lecone_worker, args=(q,)); p.start()
     ls, table, graphed = q.get(timeout=300); p.join(60)
-    ref = StepEngine('tiny', n_images=64, dtype='fp32', use_graph=True, graph_after=2)
+    ref = StepEngine('tiny', n_images=64, dtype='fp32', use_graph=True, graph_after=2, passes=1)
     ls_ref = [float(ref.step()) for _ in range(4)]
     torch.cuda.synchronize()
     assert graphed and np.allclose(ls, ls_ref, rtol=1e-5)
@@ -1012,6 +1017,12 @@ def test_step_engine_concurrent_half_batch_passes_equal_the_same_passes_in_turn(
         return out
     b._core = core_in_turn
     for s_ in range(2):
+        if s_:                                                       # every step starts from ONE state: the float-atomic sums of the previous
+            for e in (b, c):                                         # step's gradients differ in their last bits, and Adam's early steps turn that
+                e.arena.data.copy_(a.arena.data); e.table.copy_(a.table)     # into +-lr on weights whose gradient is noise
+                e.arena.exp_avg.copy_(a.arena.exp_avg); e.arena.exp_avg_sq.copy_(a.arena.exp_avg_sq)
+                e.table_m.copy_(a.table_m); e.table_v.copy_(a.table_v)
+                e.img_feat_net.load_state_dict(a.img_feat_net.state_dict())
         la = a.step(); lb = b.step(); lc = c.step()
         torch.cuda.synchronize()
         assert torch.allclose(a.last_feats, b.last_feats, rtol=1e-5, atol=1e-6), s_   # (the fully connected GEMM sees 16 rows here, 8 + 8 there)
@@ -1019,9 +1030,9 @@ def test_step_engine_concurrent_half_batch_passes_equal_the_same_passes_in_turn(
         assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(la)))
         d = (a.arena.grad - b.arena.grad).double().norm().item() / b.arena.grad.double().norm().item()
         assert d < 1e-5, d
-    assert (a.table - b.table).abs().max().item() < 1e-7
-    bufs_a = dict(a.img_feat_net.named_buffers()); bufs_b = dict(b.img_feat_net.named_buffers())
-    for k in bufs_a:
-        if 'running' in k:
-            assert torch.allclose(bufs_a[k], bufs_b[k], rtol=1e-6, atol=1e-7), k
+        assert (a.table - b.table).abs().max().item() < 1e-6
+        bufs_a = dict(a.img_feat_net.named_buffers()); bufs_b = dict(b.img_feat_net.named_buffers())
+        for k in bufs_a:
+            if 'running' in k:
+                assert torch.allclose(bufs_a[k], bufs_b[k], rtol=1e-6, atol=1e-7), k
     a.close(); b.close(); c.close()

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 from learning_embeddings_amd import ops
 
 ap = argparse.ArgumentParser(); ap.add_argument('--rows', type=int, default=512); ap.add_argument('--iters', type=int, default=5)
-ap.add_argument('--json', default=None); ap.add_argument('--no-lib', action='store_true')
+ap.add_argument('--json', default=None); ap.add_argument('--no-lib', action='store_true'); ap.add_argument('--only', default='', help='comma-separated layer names')
 a = ap.parse_args()
 # (name, Cin, H, Cout, R, stride, pad): the distinct conv shapes of ResNet-50 at 224x224
 SHAPES = [('stem', 4, 224, 64, 7, 2, 3),
@@ -38,6 +38,8 @@ def timeit(fn, iters):
 res = []
 tot = {'own': 0.0, 'lib': 0.0}
 for name, cin, hw, cout, r, st, pad in SHAPES:
+    if a.only and name not in a.only.split(','):
+        continue
     N = a.rows
     x = torch.randn(N, cin, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
     w = (torch.randn(cout, cin, r, r, device=dev) / (cin * r * r) ** 0.5).contiguous(memory_format=torch.channels_last)
