@@ -49,6 +49,26 @@ def self_launch(n, script=None, argv=None, extra_env=None):
     return subprocess.run(cmd, env=env).returncode
 
 
+def cone_traffic(B, K, D, N):
+    """HBM bytes per launch of the fused loss kernel at this shape from the committed rocprofv3 passes (profiles/r03_cone_pmc.json:
+    FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes, tools/prof_cone_round3.sh) -- None (with the reason) if the shape was not
+    profiled or the kernel sources have changed since."""
+    import hashlib
+    try:
+        allm = json.load(open(os.path.join(ROOT, 'profiles', 'r03_cone_pmc.json')))
+        csrc = os.path.join(ROOT, 'learning_embeddings_amd', 'csrc')
+        stale = [f for f, h in allm['kernel_sources_sha256'].items()
+                 if not os.path.exists(os.path.join(csrc, f)) or hashlib.sha256(open(os.path.join(csrc, f), 'rb').read()).hexdigest() != h]
+        if stale:
+            return None, 'kernel sources changed since the PMC passes: ' + ', '.join(stale)
+        rec = allm['shapes'].get('%d_%d_%d_%d' % (B, K, D, N))
+        if rec is None or rec.get('traffic_bytes') is None:
+            return None, 'shape not in profiles/r03_cone_pmc.json'
+        return int(rec['traffic_bytes']), 'rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE per launch (profiles/r03_cone_pmc.md); %.1f us per launch under the profiler' % rec['avg_us']
+    except Exception as e:                                      # noqa: BLE001
+        return None, str(e)
+
+
 def cone_alg_bytes(B, K, D):
     """fwd+bwd algorithmic bytes per positive, rows de-duplicated inside a group, fp32."""
     return B * ((2 + 2 * K) * (2 * D * 4 + 4 * D + 4) + (1 + 2 * K) * 8)
@@ -574,9 +594,10 @@ def main():
         # ---- the fused cone-loss kernel at the workload's size (latency-bound there; see roofline_stress)
         cone_s = res['phases_ms'].get('eager_probe_cone_loss', res['phases_ms'].get('cone_loss', 0.0)) * 1e-3
         ab = cone_alg_bytes(B, K, D)
+        c_tr, c_note = cone_traffic(B, K, D, eng.N)
         roof_cone = {'kernel': 'joint_loss_kernel (fused cone loss fwd+bwd, f32)', 'bound': 'hbm',
                      'achieved': round(ab / cone_s / 1e9, 3) if cone_s else None, 'peak': 8000.0, 'unit': 'GB/s',
-                     'frac': round(ab / cone_s / 8e12, 6) if cone_s else None, 'traffic': None, 'alg_bytes_per_launch': ab,
+                     'frac': round(ab / cone_s / 8e12, 6) if cone_s else None, 'traffic': c_tr, 'traffic_note': c_note, 'alg_bytes_per_launch': ab,
                      'avg_launch_us': round(cone_s * 1e6, 2),
                      'note': 'at the north-star size (B=%d, K=%d, D=%d: %.2f MB per launch) the launch is latency-bound, not HBM-bound; see roofline_stress' % (B, K, D, ab / 1e6)}
         f32 = args.dtype == 'fp32'
@@ -613,8 +634,9 @@ def main():
                 atomic_b = b_ * (2 + 2 * k_) * d_ * 4
                 tbl_mb = n_ * d_ * 4 / 1e6
                 g_peak = 16800.0 if tbl_mb <= 4.0 else 8600.0
+                s_tr, s_note = cone_traffic(b_, k_, d_, n_)
                 st[tag] = {'bound': 'hbm', 'achieved': round(r['GBps'], 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(r['GBps'] / 8000.0, 4),
-                           'traffic': None, 'avg_launch_us': round(r['us'], 1), 'pairs': r['pairs'], 'alg_bytes_per_launch': int(r['alg_MB'] * 1e6),
+                           'traffic': s_tr, 'traffic_note': s_note, 'avg_launch_us': round(r['us'], 1), 'pairs': r['pairs'], 'alg_bytes_per_launch': int(r['alg_MB'] * 1e6),
                            'second_bounds': {
                                'cache_gather': {'achieved': round(gather_b / t_s / 1e9, 1), 'peak': g_peak, 'unit': 'GB/s', 'frac': round(gather_b / t_s / 1e9 / g_peak, 4),
                                                 'note': 'table of %.1f MB resident in %s' % (tbl_mb, 'L2' if tbl_mb <= 4.0 else 'the Infinity Cache')},

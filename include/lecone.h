@@ -398,6 +398,10 @@ int lec_conv_f32_dgrad_fused(const float* dy, const float* w, int N, int H, int 
                              lec_stream_t stream);
 int lec_conv_f32_wgrad_fused(const float* dy, const float* x, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                              float* dw, const float* xsrc, const float* coef, lec_stream_t stream);
+/*     lec_conv_f32_wgrad_c3: the 3-channel stem.  x4 [N, H, W, 4] carries a zero 4th channel (the kernels want >= 4), dw3 is the layer's
+ *       own [Cout][R][S][3] gradient: dw3 += with float atomics (safe under concurrent backward passes, unlike a separate add). */
+int lec_conv_f32_wgrad_c3(const float* dy, const float* x4, int N, int H, int W, int Cout, int R, int S, int stride, int pad,
+                          float* dw3, lec_stream_t stream);
 int lec_bn_bwd_pass1_coeffs_f32(const void* dy, const void* dy2, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* gamma,
                                 const float* save_mean, const float* save_invstd, void* g, float* dgamma, float* dbeta, float* coef,
                                 void* workspace, int64_t workspace_bytes, lec_stream_t stream);   /* pass 1 as a kernel (writes g) + the same coefficients */

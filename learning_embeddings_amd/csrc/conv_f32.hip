@@ -272,7 +272,8 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
         const float* sA = smem + buf * (SA + SB);
 #if LEC_CF_UNCOND
         // no branch around the prefetch: loads, MFMAs and LDS stores of an iteration are ONE basic block the scheduler can interleave
-        // (the chunk past the end falls out of every buffer's range and is never read back)
+        // (the chunk past the end falls out of every buffer's range and is never read back).  MEASURED (round 3, `make EXTRA=-DLEC_CF_UNCOND=1`,
+        // same box): within +-3 % of the branchy form on every layer tried, either direction -- hipcc does not interleave them: off.
         load_chunk(ch + 1);
         mma_chunk<true, B_KC, 0, BN, TM, TN>(sA, sA + SA, wm0, wn0, lane, acc);
         store_chunk(buf ^ 1);
@@ -421,6 +422,11 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
 // this pixel ? its lane mask : 0) -- scalar compares and selects, issued in the shadow of the wave's own MFMAs -- and reaches the
 // vector unit as the predicate of ONE v_cndmask per piece (round 2: two adds, two compares and a select per piece on the vector ALU,
 // 1.69 vector instructions per MFMA, which the f32 MFMA cannot overlap).
+// MEASURED (round 3, same box, 512 images, us per launch, vector test / scalar masks): 3x3 64 -> 64 @56 1689 / 1777, 128 -> 128 @28 1078 / 1114,
+// stride-2 128 -> 128 1080 / 1115, 256 -> 256 @14 1222 / 1297, 512 -> 512 @7 1131 / 1237, strided 1x1 512 -> 1024 871 / 909: 3 - 9 % SLOWER.  The
+// loader drops from 28 to 8 vector instructions per chunk but grows from ~140 to ~290 scalar ones, and a wave issues in order: the scalar
+// run sits between two MFMA blocks (the prefetch is a basic block of its own) and the matrix pipe waits for it.  Off by default
+// (LEC_WGRAD_SMASK=1 enables it); it pays only once the prefetch is interleaved with the MFMAs instruction by instruction.
 template <int WM, int WN, int TM, int TN, int WBK, bool DENSE, bool XF = false, bool SM = false>
 __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                        float* __restrict__ dw, WgGeo g, const float* __restrict__ xsrc = nullptr,
@@ -596,7 +602,12 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const flo
 #pragma unroll
           for (int jt = 0; jt < TN; ++jt) {
             const int jj = j0 + wn0 + jt * 32 + l31;
-            if (jj < g.Ng) atomicAdd(dw + (int64_t)co * g.Ng + jj, acc[it][jt][r]);
+            if (g.dCin == g.Cin) {
+              if (jj < g.Ng) atomicAdd(dw + (int64_t)co * g.Ng + jj, acc[it][jt][r]);
+            } else {                                            // the stem: the padded 4th input channel has no slot in dw
+              const int tp = jj >> g.lgCin, ci = jj & (g.Cin - 1);
+              if (jj < g.Ng && ci < g.dCin) atomicAdd(dw + ((int64_t)co * g.RS + tp) * g.dCin + ci, acc[it][jt][r]);
+            }
           }
         }
       }
@@ -729,8 +740,23 @@ extern "C" int lec_conv_f32_wgrad(const float* dy, const float* x, int N, int H,
 
 // Weight gradient; xsrc / coef (both or neither; 1x1 / stride 1 / pad 0 layers): dy is formed on load from g = `dy`, the BatchNorm input
 // xsrc and coef[3][Cout] exactly as in lec_conv_f32_dgrad_fused, so pass 2 of that BatchNorm's backward never runs as a kernel.
+static int conv_f32_wgrad_impl(const float* dy, const float* x, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                               float* dw, const float* xsrc, const float* coef, int dCin, lec_stream_t stream);
+
 extern "C" int lec_conv_f32_wgrad_fused(const float* dy, const float* x, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                                         float* dw, const float* xsrc, const float* coef, lec_stream_t stream) {
+  return conv_f32_wgrad_impl(dy, x, N, H, W, Cin, Cout, R, S, stride, pad, dw, xsrc, coef, Cin, stream);
+}
+
+// The stem (3 input channels): x is [N, H, W, 4] with a zero 4th channel, dw is the layer's own [Cout][R][S][3] gradient slot -- added
+// into with float atomics like every other weight gradient (several backward passes of a step may run concurrently).
+extern "C" int lec_conv_f32_wgrad_c3(const float* dy, const float* x4, int N, int H, int W, int Cout, int R, int S, int stride, int pad,
+                                     float* dw3, lec_stream_t stream) {
+  return conv_f32_wgrad_impl(dy, x4, N, H, W, 4, Cout, R, S, stride, pad, dw3, nullptr, nullptr, 3, stream);
+}
+
+static int conv_f32_wgrad_impl(const float* dy, const float* x, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                               float* dw, const float* xsrc, const float* coef, int dCin, lec_stream_t stream) {
   using namespace lec;
   if (int rc = conv_check("conv_f32_wgrad", N, H, W, Cin, Cout, R, S, stride, pad)) return rc;
   LEC_CHECK_ARG(dy && x && dw, "conv_f32_wgrad: null pointer");
@@ -739,7 +765,7 @@ extern "C" int lec_conv_f32_wgrad_fused(const float* dy, const float* x, int N, 
   WgGeo g;
   g.Ho = (H + 2 * pad - R) / stride + 1; g.Wo = (W + 2 * pad - S) / stride + 1; g.Mpix = N * g.Ho * g.Wo;
   g.H = H; g.W = W; g.Cin = Cin; g.lgCin = ilog2_exact(Cin); g.Cout = Cout; g.S = S; g.RS = R * S; g.stride = stride; g.pad = pad;
-  g.Ng = R * S * Cin;
+  g.Ng = R * S * Cin; g.dCin = dCin;
   g.dy_bytes = (uint32_t)((int64_t)g.Mpix * Cout * 4); g.x_bytes = (uint32_t)((int64_t)N * H * W * Cin * 4);
   g.dWo = make_fastdiv(g.Wo); g.dHo = make_fastdiv(g.Ho); g.dS = make_fastdiv(S);
   const bool dense = R == 1 && S == 1 && stride == 1 && pad == 0;
@@ -782,7 +808,7 @@ extern "C" int lec_conv_f32_wgrad_fused(const float* dy, const float* x, int N, 
   hipStream_t st = (hipStream_t)stream;
   const float* nof = nullptr;
   // scalar bounds masks: a 256-column tile must span at most 4 taps (Cin >= 64; the stem's 4 channels keep the vector test)
-  static const int wg_sm = [] { const char* e = getenv("LEC_WGRAD_SMASK"); return e ? atoi(e) : 1; }();
+  static const int wg_sm = [] { const char* e = getenv("LEC_WGRAD_SMASK"); return e ? atoi(e) : 0; }();
   const bool sm = !dense && Cin >= 64 && wg_sm != 0;
   if (xf) {
     LEC_CHECK_ARG(dense, "conv_f32_wgrad_fused: dense layers only");

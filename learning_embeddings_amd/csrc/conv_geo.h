@@ -72,6 +72,7 @@ struct WgGeo {
   int Ho, Wo, H, W, Cin, lgCin, Cout;
   int S, RS, stride, pad;
   int Ng;                                  // RS * Cin
+  int dCin;                                // channels of the DESTINATION dw [Cout][RS][dCin]: Cin, or 3 for the stem (x carries a zero 4th channel)
   int chunks_per_split, tiles, split;
   uint32_t dy_bytes, x_bytes;
   FastDiv dWo, dHo, dS;

@@ -97,10 +97,45 @@ class _ImageNetBase(nn.Module):
     def device(self):
         return next(self.parameters()).device
 
+    cnn_passes = 1           # > 1 (fp32, training): forward_raw pushes the batch through the backbone as that many concurrent parts
+
+    def _forward_raw_passes(self, x):
+        """forward_raw with the rows of x as `cnn_passes` parts, one HIP stream each: the backbone up to the pooled features per part
+        (BatchNorm statistics per part, running statistics updated in part order), then the fully connected layer once over all rows
+        on the caller's stream.  Autograd runs every part's backward on the stream its forward ran on and joins them itself.  The
+        caller zeroes the gradient slots once per step and has lec_bn_bwd_accumulate(1) set (trainers' train_step)."""
+        cur = torch.cuda.current_stream()
+        P = self.cnn_passes
+        streams = self.__dict__.setdefault('_pass_streams', [])
+        while len(streams) < P:
+            streams.append(torch.cuda.Stream())
+        n = x.shape[0]
+        h = -(-n // P)
+        parts, order, used = [], {}, []
+        for p in range(P):
+            xs = x[p * h:(p + 1) * h]
+            if xs.shape[0] == 0:
+                continue
+            st = streams[p]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                ops.PASS_ORDER = (order, p)
+                try:
+                    f = self.model(xs, pooled_only=True)
+                finally:
+                    ops.PASS_ORDER = None
+            f.record_stream(cur); parts.append(f); used.append(st)
+        for st in used:
+            x.record_stream(st); cur.wait_stream(st)
+        return self.model.fc(torch.cat(parts)).float()
+
     def forward_raw(self, x):
         """CNN output BEFORE soft_clip, fp32 [n, D] -- the fused loss applies soft_clip itself."""
         if self.channels_last and x.dim() == 4:
             x = x.contiguous(memory_format=torch.channels_last)
+        if (self.cnn_passes > 1 and x.is_cuda and self.compute_dtype == torch.float32 and self.training and torch.is_grad_enabled()
+                and x.dim() == 4 and x.shape[0] >= 4 * self.cnn_passes):
+            return self._forward_raw_passes(x)
         if self.compute_dtype != torch.float32:
             with torch.autocast('cuda', dtype=self.compute_dtype):
                 y = self.model(x)

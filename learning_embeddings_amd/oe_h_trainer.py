@@ -438,7 +438,7 @@ class JointEmbeddings:
                  lr_step=[], experiment_dir='../exp/', n_epochs=10, eval_interval=2, feature_extracting=True,
                  use_pretrained=True, load_wt=False, model_name=None, optimizer_method='adam', use_grayscale=False,
                  load_emb_from=None, load_cosine_emb=None, hide_levels=None, half_half=False,
-                 compute_dtype=torch.float32, cnn_weights=None, writer=None, fast_path=True):
+                 compute_dtype=torch.float32, cnn_weights=None, writer=None, fast_path=True, cnn_passes=None):
         Embedder, FeatCNN18, FeatCNN, FeatNet = self._model_classes()
         from .resnet import WgradOverlap
         WgradOverlap.instance = None            # set to this trainer's own instance around every train step (see train_step)
@@ -500,7 +500,15 @@ class JointEmbeddings:
         if self.use_CNN and fast_path and compute_dtype in (torch.float32, torch.bfloat16):
             if compute_dtype == torch.bfloat16:
                 self.arena.enable_lowp_shadow()
-            self.overlap = WgradOverlap(self.reducer, self.arena, side_stream=True)
+            # fp32: the CNN batch of a step goes through the backbone as two concurrent halves, one HIP stream each -- one half's HBM-bound
+            # BatchNorm passes under the other's matrix-bound convolutions (engine.StepEngine) -- with the weight
+            # gradients in line; bf16 (HBM-bound everywhere): one pass, weight gradients on a side stream.  cnn_passes overrides.
+            if cnn_passes is None:
+                cnn_passes = 2 if compute_dtype == torch.float32 else 1
+            self.cnn_passes = int(cnn_passes)
+            self.overlap = WgradOverlap(self.reducer, self.arena, side_stream=self.cnn_passes == 1)
+            if self.cnn_passes > 1:
+                self.img_feat_net.cnn_passes = self.cnn_passes
         self.check_graph_embedding_neg_graph = None
         self.check_reconstr_every = 1; self.save_model_every = 1
         self.reconstruction_f1 = self.reconstruction_threshold = self.reconstruction_accuracy = 0.0
@@ -611,6 +619,13 @@ class JointEmbeddings:
         pend = self.__dict__.setdefault('_steps_in_flight', [])
         if len(pend) >= 2:
             pend.pop(0).synchronize()
+        multi = getattr(self, 'cnn_passes', 1) > 1
+        live = self.reducer.live
+        if multi:
+            # two backward passes add into the same gradient slots from concurrent streams: BatchNorm's d gamma / d beta accumulate with
+            # atomics like the weight gradients, and the reducer's per-parameter hooks stay muted (every parameter reports once per
+            # pass): the buckets are reduced once, below
+            ops.lib.lec_bn_bwd_accumulate(1); self.reducer.live = False
         try:
             self.arena.zero_grad(); self.table_grad.zero_()
             loss, e_pos, e_neg = self.criterion(self.model, self.img_feat_net, data_item['from'], data_item['to'],
@@ -620,6 +635,8 @@ class JointEmbeddings:
                 ov.join()                                                   # weight gradients from the side stream
         finally:
             WgradOverlap.instance = prev
+            if multi:
+                ops.lib.lec_bn_bwd_accumulate(0); self.reducer.live = live; self.reducer.reset()
         self.reducer.finish()
         self.apply_updates()
         if loss.is_cuda:

@@ -841,6 +841,17 @@ def conv_f32_dgrad_fused(dy, w, x_shape, stride, pad, xf=None, fold=None):
     return dx
 
 
+def conv_f32_wgrad_c3(dy, x4, dw3, stride, pad):
+    """The stem's weight gradient: x4 [N, 4, H, W] (zero 4th channel), dw3 [Cout, 3, R, S] channels_last fp32, dw3 += (float atomics)."""
+    _nhwc_f32(dy, 'dy'); _nhwc_f32(x4, 'x4'); _nhwc_f32(dw3, 'dw3')
+    n, c4, h, wd = x4.shape; cout, c3, r, s_ = dw3.shape
+    if c4 != 4 or c3 != 3:
+        raise ValueError('conv_f32_wgrad_c3: x4 must have 4 channels and dw3 3')
+    _conv_timed(lambda: check(lib.lec_conv_f32_wgrad_c3(dptr(dy), dptr(x4), n, h, wd, cout, r, s_, stride, pad, dptr(dw3), stream_ptr())),
+                2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * cout * 4 * r * s_)
+    return dw3
+
+
 def conv_f32_wgrad(dy, x, dw, stride, pad, xf=None):
     """dw += weight gradient (lec_conv_f32_wgrad, float atomics).  dw [Cout, Cin, R, S] channels_last fp32.  xf = (xsrc, coef): `dy`
     is g and the gradient is formed on load (lec_conv_f32_wgrad_fused, 1x1 / stride 1 layers)."""

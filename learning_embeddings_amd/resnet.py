@@ -99,10 +99,10 @@ class WgradOverlap:
         if (MFMA_F32 and gy.dtype == torch.float32 and x.dtype == torch.float32 and w.grad is not None and w.grad.dtype == torch.float32
                 and w.grad.shape == w.shape and _f32_conv_ok(conv) and _f32_conv_fits(conv, x) and w.grad.is_contiguous(memory_format=torch.channels_last)
                 and gy.is_contiguous(memory_format=torch.channels_last) and x.is_contiguous(memory_format=torch.channels_last)):
-            if conv.in_channels == 3:             # the stem: x carries the zero 4th channel (_pad_c4), its gradient column is dropped
-                dw4 = torch.empty((w.shape[0], 4, w.shape[2], w.shape[3]), dtype=torch.float32, device=w.device, memory_format=torch.channels_last).zero_()
-                _ops().conv_f32_wgrad(gy, x, dw4, conv.stride[0], conv.padding[0])
-                w.grad.add_(dw4[:, :3])
+            if conv.in_channels == 3:             # the stem: x carries the zero 4th channel (_pad_c4), which has no slot in the gradient;
+                                                  # atomics straight into the 3-channel slot (a separate add would race between
+                                                  # concurrent backward passes)
+                _ops().conv_f32_wgrad_c3(gy, x, w.grad, conv.stride[0], conv.padding[0])
             elif F32_MODE == 'x3' and _ops().conv_f32x3_wgrad_preferred(conv.in_channels, conv.out_channels, *conv.kernel_size):
                 _ops().conv_f32x3_wgrad(gy, x, w.grad, conv.stride[0], conv.padding[0])  # bf16 matrix cores (layers of >= 128 channels)
             else:

@@ -192,6 +192,14 @@ def test_step_engine_hipgraph_replay_matches_eager_launches(dtype):
                 # loss and energies EQUAL the eager ones; the gradients differ by the order of their float atomics only
                 assert torch.equal(l1, l2) and torch.equal(ep1, ep2) and torch.equal(en1, en2)
                 rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+                if rel(ga1, eng.arena.grad) >= 1e-4:                        # say WHICH parameters differ before failing
+                    names = [n for n, p_ in eng.img_feat_net.named_parameters() if p_.requires_grad]
+                    for k_, (n_, o_) in enumerate(zip(names, eng.arena.offsets)):
+                        num = eng.arena.params[k_].numel()
+                        r_ = rel(ga1[o_:o_ + num], eng.arena.grad[o_:o_ + num])
+                        if r_ > 1e-4:
+                            print('%-36s rel %.3g  |replay| %.4g  |eager| %.4g' % (n_, r_, ga1[o_:o_ + num].norm().item(), eng.arena.grad[o_:o_ + num].norm().item()))
+                    print('pass streams', [s_.cuda_stream for s_ in eng.pass_streams], 'passes', eng.passes)
                 assert rel(gt1, eng.table_grad) < 1e-5 and rel(ga1, eng.arena.grad) < 1e-4
             else:
                 assert abs(l1.item() - l2.item()) <= 5e-2 * abs(l2.item())
@@ -268,7 +276,7 @@ def test_joint_embeddings_fast_path_matches_plain_autograd(tmp_path, dtype):
         tr = oe_h.JointEmbeddings(gd, dl, image_dir='', use_CNN=True, labelmap=lm, criterion=crit, lr=1e-3, n_workers=0,
                                   batch_size=16, experiment_name='f%d' % fast, embedding_dim=10, neg_to_pos_ratio=5, image_fc7=None,
                                   normalize=None, alpha=0.05, experiment_dir=str(tmp_path), n_epochs=1, eval_interval=5,
-                                  compute_dtype=dtype, fast_path=fast)
+                                  compute_dtype=dtype, fast_path=fast, cnn_passes=1)    # one CNN pass: the same BatchNorm batch on both sides
         assert (tr.overlap is not None) == fast
         crit.set_dataloader(tr.datasets['train'])
         tr.train_set.transform = None                                        # no random flip: identical batches on both sides
@@ -1003,17 +1011,13 @@ def test_step_engine_concurrent_half_batch_passes_equal_the_same_passes_in_turn(
         codes = b.codes_dev
         images = b.pool.index_select(0, b.idx_dev)
         b.arena.zero_grad(); b.table_grad.zero_(); b.gfeat.zero_()
-        from learning_embeddings_amd import _lib
-        _lib.lib.lec_bn_bwd_accumulate(1)
-        try:
-            parts = [b.img_feat_net.forward_raw(images[p * h:(p + 1) * h]) for p in range(2)]
-            feats = torch.cat([f.detach() for f in parts]); b.last_feats = feats
-            out = ops.joint_loss_raw(b.table, feats, codes[:, 0].contiguous(), codes[:, 1].contiguous(), codes[:, 2:].contiguous(), None, b.K_cone, b.alpha,
-                                     _lib.ENERGY_HYP_CONE, _lib.LABEL_HYP, _lib.IMAGE_SOFTCLIP, b.table_grad, b.gfeat)
-            for p in range(2):
-                parts[p].backward(b.gfeat[p * h:(p + 1) * h])
-        finally:
-            _lib.lib.lec_bn_bwd_accumulate(0)
+        from learning_embeddings_amd import _lib                    # (lec_bn_bwd_accumulate(1) is on, process-wide, since engine a exists)
+        parts = [b.img_feat_net.forward_raw(images[p * h:(p + 1) * h]) for p in range(2)]
+        feats = torch.cat([f.detach() for f in parts]); b.last_feats = feats
+        out = ops.joint_loss_raw(b.table, feats, codes[:, 0].contiguous(), codes[:, 1].contiguous(), codes[:, 2:].contiguous(), None, b.K_cone, b.alpha,
+                                 _lib.ENERGY_HYP_CONE, _lib.LABEL_HYP, _lib.IMAGE_SOFTCLIP, b.table_grad, b.gfeat)
+        for p in range(2):
+            parts[p].backward(b.gfeat[p * h:(p + 1) * h])
         return out
     b._core = core_in_turn
     for s_ in range(2):
@@ -1036,3 +1040,44 @@ def test_step_engine_concurrent_half_batch_passes_equal_the_same_passes_in_turn(
             if 'running' in k:
                 assert torch.allclose(bufs_a[k], bufs_b[k], rtol=1e-6, atol=1e-7), k
     a.close(); b.close(); c.close()
+
+
+def test_joint_embeddings_trainer_two_concurrent_cnn_passes_equal_two_passes_in_turn(tmp_path):
+    """JointEmbeddings.train_step at fp32 pushes the step's CNN batch through the backbone as two concurrent halves
+    (_ImageNetBase.forward_raw with cnn_passes = 2: one HIP stream per half, autograd runs each half's backward on its stream).  One
+    step must equal the same two halves pushed through one after the other on one stream: loss, label table, the image network's
+    gradient up to float-atomic order -- and differ from the one-pass step."""
+    from test_host_cpu import _fake_loaders
+    lm = SyntheticLabelMap([2, 4, 8])
+    dl = _fake_loaders(lm, 32, 8)
+    for split in dl.values():
+        for b in split:
+            b['path_to_image'] = [torch.rand(3, 64, 64, generator=torch.Generator().manual_seed(int(n[4:]))).to(DEV) for n in b['image_filename']]
+    gd = oe_h.create_combined_graphs(dl, lm, pick_per_level=True)
+    out = {}
+    for tag in ('concurrent', 'in_turn', 'one_pass'):
+        crit = oe_h.EuclideanConesWithImagesHypernymLoss(lm, 5, {}, 0.05, True, K=0.1, use_CNN=True)
+        tr = oe_h.JointEmbeddings(gd, dl, image_dir='', use_CNN=True, labelmap=lm, criterion=crit, lr=1e-3, n_workers=0,
+                                  batch_size=16, experiment_name=tag, embedding_dim=10, neg_to_pos_ratio=5, image_fc7=None,
+                                  normalize=None, alpha=0.05, experiment_dir=str(tmp_path), n_epochs=1, eval_interval=5,
+                                  cnn_passes=1 if tag == 'one_pass' else 2)
+        assert tr.cnn_passes == (1 if tag == 'one_pass' else 2) and (tr.overlap.side is None) == (tag != 'one_pass')
+        if tag == 'in_turn':                                     # the same two halves, one stream
+            net = tr.img_feat_net
+            def in_turn(x, _n=net):
+                h = -(-x.shape[0] // 2)
+                return _n.model.fc(torch.cat([_n.model(x[:h], pooled_only=True), _n.model(x[h:], pooled_only=True)])).float()
+            net._forward_raw_passes = in_turn
+        crit.set_dataloader(tr.datasets['train'])
+        tr.train_set.transform = None
+        tr.model.train(); tr.img_feat_net.train()
+        torch.manual_seed(1)
+        it = iter(tr.dataloaders['train'])
+        loss = float(tr.train_step(next(it))[0])
+        torch.cuda.synchronize()
+        out[tag] = (loss, tr.model.embeddings.weight.detach().clone(), tr.arena.grad.clone(), crit.last_cnn_rows)
+    a, b, c = out['concurrent'], out['in_turn'], out['one_pass']
+    assert a[3] == b[3] == c[3] and a[3] >= 16
+    assert abs(a[0] - b[0]) <= 1e-6 * max(1.0, abs(b[0])) and (a[1] - b[1]).abs().max().item() <= 1e-6
+    assert (a[2] - b[2]).double().norm().item() / b[2].double().norm().item() < 1e-5
+    assert abs(a[0] - c[0]) > 1e-6 * max(1.0, abs(c[0]))          # one BatchNorm batch of all rows is a different function
