@@ -38,6 +38,9 @@
 #ifndef LEC_CF_UNCOND
 #define LEC_CF_UNCOND 0
 #endif
+#ifndef LEC_WG_XF_BLOCKS
+#define LEC_WG_XF_BLOCKS 2             // workgroups per CU the on-load weight gradient is compiled for (4: 128 registers, a few spills)
+#endif
 
 namespace lec {
 
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
 // run sits between two MFMA blocks (the prefetch is a basic block of its own) and the matrix pipe waits for it.  Off by default
 // (LEC_WGRAD_SMASK=1 enables it); it pays only once the prefetch is interleaved with the MFMAs instruction by instruction.
 template <int WM, int WN, int TM, int TN, int WBK, bool DENSE, bool XF = false, bool SM = false>
-__global__ __launch_bounds__(kCfThreads, 2) void conv_f32_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(kCfThreads, (XF && WM <= 2 && TM * TN == 4) ? LEC_WG_XF_BLOCKS : 2) void conv_f32_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                        float* __restrict__ dw, WgGeo g, const float* __restrict__ xsrc = nullptr,
                                                                        const float* __restrict__ coef = nullptr) {
   static_assert(!XF || DENSE, "the on-load BatchNorm form serves the dense (1x1 / stride 1) layers");

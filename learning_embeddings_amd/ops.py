@@ -388,6 +388,16 @@ FOLD_BN_BWD = _os.environ.get('LEC_FOLD_BN_BWD', '1') != '0'
 # (lec_conv_f32_dgrad_fused), pass 2 on the operand load of the 1x1 convolution behind the BatchNorm (data and weight gradient)
 FOLD_BN_BWD_F32 = _os.environ.get('LEC_FOLD_BN_BWD_F32', '1') != '0'
 LAZY_BN_PASS2_F32 = _os.environ.get('LEC_LAZY_BN_PASS2_F32', '1') != '0'
+# Where the two forms pay (tools/bench_conv_f32_fused.py, one MI355X, 512 rows; the step now runs as two concurrent half-batch passes, so a
+# BatchNorm pass that stays a kernel is about half hidden under the other pass's convolutions, while every microsecond added to a
+# convolution is matrix-pipe time the step is bound by):
+#   * the fold loses on 64-channel destinations (the narrow-tile kernel's epilogue: +350 / +420 us against passes of 300 us on layer1's
+#     conv2 / conv3 data gradients) and wins from 128 channels on (+5 .. +250 us against 155 .. 590 us);
+#   * the on-load form adds ~70 us to the data gradient and 50 - 170 us to the weight gradient (its extra operand costs the weight gradient a
+#     workgroup per CU), which only a large pass 2 repays: bn3 of layer1 / layer2 (950 / 470 us), not bn1 anywhere (230 .. 30 us) nor
+#     bn3 of layer3 / layer4 (220 / 105 us).
+FOLD_F32_MIN_CHANNELS = int(_os.environ.get('LEC_FOLD_F32_MIN_CHANNELS', '128'))        # fold into data gradients whose destination has >= this many channels
+LAZY_F32_MIN_ELEMS = int(_os.environ.get('LEC_LAZY_F32_MIN_ELEMS', str(80 * 1000 * 1000)))   # on-load pass 2 for BatchNorms of >= this many elements per pass
 DEFER_BN_APPLY = _os.environ.get('LEC_DEFER_BN_APPLY', '1') != '0'
 LAZY_BN_PASS2 = _os.environ.get('LEC_LAZY_BN_PASS2', '1') != '0'
 # the default context's records under their historical names (ops called outside a model: tests, tools)
@@ -550,7 +560,7 @@ class BNActFn(torch.autograd.Function):
                 and lib.lec_conv1x1_wgrad_bnapply_supported(fusion().lazy_ok[x.data_ptr()], Cc, M))
         # fp32: the 1x1 / stride-1 convolution that produced x forms dx on its operand load, in its data gradient AND in its weight gradient
         # (lec_conv_f32_dgrad_fused / _wgrad_fused): pass 2 never runs as a kernel
-        lazy32 = (LAZY_BN_PASS2_F32 and x.dtype == torch.float32 and x.data_ptr() in fusion().lazy_ok
+        lazy32 = (LAZY_BN_PASS2_F32 and x.dtype == torch.float32 and x.data_ptr() in fusion().lazy_ok and el >= LAZY_F32_MIN_ELEMS
                   and _WO.instance is not None and _WO.instance.enabled and ctx.needs_input_grad[0])
         fusion().lazy_ok.pop(x.data_ptr(), None)
         if lazy32:

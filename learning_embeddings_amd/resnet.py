@@ -362,7 +362,8 @@ class _OverlapConvFn(torch.autograd.Function):
             if ctx.f32:
                 ops = _ops()
                 rec = ops.fusion().forks.get(x.data_ptr()) if (ops.FOLD_BN_BWD_F32 and ctx.planes is None and not ctx.stem) else None
-                if rec is not None and not (conv.stride[0] == 1 and conv.out_channels % 32 == 0 and x.shape[1] % 8 == 0 and rec['x'].dtype == torch.float32
+                if rec is not None and not (conv.stride[0] == 1 and conv.out_channels % 32 == 0 and x.shape[1] % 8 == 0 and x.shape[1] >= ops.FOLD_F32_MIN_CHANNELS
+                                            and rec['x'].dtype == torch.float32
                                             and rec['x'].shape == x.shape and (rec.get('single') or rec['dres'] is not None)
                                             and (rec['dres'] is None or (rec['dres'].dtype == torch.float32 and rec['dres'].shape == x.shape
                                                                          and rec['dres'].is_contiguous(memory_format=torch.channels_last)))):

@@ -509,7 +509,8 @@ def test_resnet50_f32_fused_batchnorm_backward_matches_the_unfused_path(hw, n):
     x0 = _cl(torch.rand(n, 3, hw, hw))
     res, calls, g = {}, {}, None
     orig = ops.conv_f32_dgrad_fused
-    keep = (ops.FOLD_BN_BWD_F32, ops.LAZY_BN_PASS2_F32)
+    keep = (ops.FOLD_BN_BWD_F32, ops.LAZY_BN_PASS2_F32, ops.FOLD_F32_MIN_CHANNELS, ops.LAZY_F32_MIN_ELEMS)
+    ops.FOLD_F32_MIN_CHANNELS = 0; ops.LAZY_F32_MIN_ELEMS = 0      # every eligible layer, whatever the size thresholds of the default policy
     try:
         for tag in ('fused', 'plain'):
             ops.FOLD_BN_BWD_F32 = ops.LAZY_BN_PASS2_F32 = tag == 'fused'
@@ -532,7 +533,7 @@ def test_resnet50_f32_fused_batchnorm_backward_matches_the_unfused_path(hw, n):
     finally:
         WgradOverlap.instance = None
         ops.conv_f32_dgrad_fused = orig
-        ops.FOLD_BN_BWD_F32, ops.LAZY_BN_PASS2_F32 = keep
+        ops.FOLD_BN_BWD_F32, ops.LAZY_BN_PASS2_F32, ops.FOLD_F32_MIN_CHANNELS, ops.LAZY_F32_MIN_ELEMS = keep
     assert not any(k[0] == 'plain' for k in calls), calls
     n_fold = sum(v for k, v in calls.items() if k[2]); n_xf = sum(v for k, v in calls.items() if k[1])
     # 16 conv1 (15 fold a block output, every conv1 forms its gradient on load), 13 stride-1 conv2 (fold bn1), 16 conv3 (fold bn2, on load)
