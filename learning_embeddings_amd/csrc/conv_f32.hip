@@ -38,6 +38,9 @@
 #ifndef LEC_CF_UNCOND
 #define LEC_CF_UNCOND 0
 #endif
+#ifndef LEC_CF_PF2
+#define LEC_CF_PF2 0                   // forward / data gradient: operands fetched two chunks ahead (two register sets)
+#endif
 #ifndef LEC_WG_XF_BLOCKS
 #define LEC_WG_XF_BLOCKS 2             // workgroups per CU the on-load weight gradient is compiled for (4: 128 registers, a few spills)
 #endif
@@ -116,6 +119,9 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
                                                                      float* __restrict__ dst, ActGeo g, float* __restrict__ part,
                                                                      ActFuse fz) {
   constexpr bool XF = (FUSE & 1) != 0, FOLD = (FUSE & 2) != 0;
+  // PF2: operands are fetched TWO chunks ahead into two register sets (the plain kernels have the registers: 2 waves per SIMD either way)
+  constexpr bool PF2 = LEC_CF_PF2 != 0 && FUSE == 0 && !TAPV;
+  constexpr int NSET = PF2 ? 2 : 1;
   static_assert(!(XF && TAPV) && !(FOLD && STATS), "fused modes: one tap per chunk; one statistics epilogue at a time");
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   static_assert(WM * WN == 4, "four waves per workgroup");
@@ -192,11 +198,11 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[it][jt][r] = 0.f;
 
-    f32x4v ra[NA], rb[NB];
+    f32x4v ra[NSET][NA], rb[NSET][NB];
     f32x4v rx[XF ? NA : 1], cfA, cfB, cfD;                      // XF: the second source's pieces and the chunk's coefficient vectors
     unsigned cur[NA];                                           // byte offset of this thread's A pieces at channel 0 of the CURRENT tap (kOob: no such pixel)
     int cur_tap = -1;
-    auto load_chunk = [&](int ch) {
+    auto load_chunk = [&](int ch, const int set = 0) {
       const int k0 = ch * kCfBK;
       if (!TAPV) {
         // the whole chunk lies in one tap: wave-uniform (scalar) decode; the per-row select runs once per TAP, a chunk adds a scalar
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
         const unsigned wsc = (unsigned)(B_KC ? tw * g.Cin + c0 : c0 * rsc + tw * g.Cin) * 4u;
         const unsigned c0b = (unsigned)c0 * 4u;
 #pragma unroll
-        for (int u = 0; u < NA; ++u) ra[u] = bload4(rs_src, cur[u] + c0b);         // (a poisoned offset stays out of range: c0b < 2^14)
+        for (int u = 0; u < NA; ++u) ra[set][u] = bload4(rs_src, cur[u] + c0b);         // (a poisoned offset stays out of range: c0b < 2^14)
         if (XF) {
 #pragma unroll
           for (int u = 0; u < NA; ++u) rx[u] = bload4(rs_x2, cur[u] + c0b);
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
           cfA = bload4(rs_coef, cb); cfB = bload4(rs_coef, cb + cs4); cfD = bload4(rs_coef, cb + 2u * cs4);
         }
 #pragma unroll
-        for (int u = 0; u < NB; ++u) rb[u] = bload4(rs_wgt, wB[u] + wsc);          // (likewise: wsc < 2^30)
+        for (int u = 0; u < NB; ++u) rb[set][u] = bload4(rs_wgt, wB[u] + wsc);          // (likewise: wsc < 2^30)
         return;
       }
       // one tap / channel position per 16-byte piece (the stem: 4 source channels, 8 taps per chunk)
@@ -234,14 +240,14 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
       for (int u = 0; u < NA; ++u) {
         const int hs = hb[u] + dh, ws = wb[u] + dw;
         const bool ok = tap_ok && pixn[u] >= 0 && (unsigned)hs < (unsigned)g.Hs && (unsigned)ws < (unsigned)g.Ws;
-        ra[u] = bload4(rs_src, ok ? (unsigned)(((pixn[u] + hs * g.Ws + ws) << g.lgCs) + cA) * 4u : kOob);
+        ra[set][u] = bload4(rs_src, ok ? (unsigned)(((pixn[u] + hs * g.Ws + ws) << g.lgCs) + cA) * 4u : kOob);
       }
       if (B_KC) {
         const int tw = (g.r0 + g.rstep * ta) * g.S + g.s0 + g.sstep * tb;
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
           const int co = n0 + rowA + kCfRP * u;
-          rb[u] = bload4(rs_wgt, (tap_ok && co < g.Cd) ? (unsigned)((co * g.RS + tw) * g.Cin + cA) * 4u : kOob);
+          rb[set][u] = bload4(rs_wgt, (tap_ok && co < g.Cd) ? (unsigned)((co * g.RS + tw) * g.Cin + cA) * 4u : kOob);
         }
       } else {
 #pragma unroll
@@ -253,25 +259,45 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
           const int ta2 = fdiv(tapB, g.dnb), tb2 = tapB - ta2 * g.nb;
           const int tw2 = (g.r0 + g.rstep * ta2) * g.S + g.s0 + g.sstep * tb2;
           const int ci = n0 + 4 * jq;
-          rb[u] = bload4(rs_wgt, (tapB < ntaps && ci < g.Cd) ? (unsigned)((cB * g.RS + tw2) * g.Cin + ci) * 4u : kOob);
+          rb[set][u] = bload4(rs_wgt, (tapB < ntaps && ci < g.Cd) ? (unsigned)((cB * g.RS + tw2) * g.Cin + ci) * 4u : kOob);
         }
       }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, const int set = 0) {
       char* base = (char*)smem + buf * (SA + SB) * 4;
       if (XF) {
 #pragma unroll
         for (int u = 0; u < NA; ++u)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) ra[u][e] = __builtin_fmaf(cfA[e], ra[u][e], __builtin_fmaf(cfB[e], rx[u][e], cfD[e]));
+          for (int e = 0; e < 4; ++e) ra[0][u][e] = __builtin_fmaf(cfA[e], ra[0][u][e], __builtin_fmaf(cfB[e], rx[u][e], cfD[e]));
       }
 #pragma unroll
-      for (int u = 0; u < NA; ++u) *(f32x4v*)(base + ldsA + u * kCfRP * kCfLdk * 4) = ra[u];
+      for (int u = 0; u < NA; ++u) *(f32x4v*)(base + ldsA + u * kCfRP * kCfLdk * 4) = ra[set][u];
 #pragma unroll
-      for (int u = 0; u < NB; ++u) *(f32x4v*)(base + ldsB + u * (B_KC ? kCfRP * kCfLdk * 4 : kCfThreads * 16)) = rb[u];
+      for (int u = 0; u < NB; ++u) *(f32x4v*)(base + ldsB + u * (B_KC ? kCfRP * kCfLdk * 4 : kCfThreads * 16)) = rb[set][u];
     };
 
-    if (nchunks > 0) {
+    if (PF2 && nchunks > 0) {
+      // two chunks in flight: a load is issued at the start of one iteration and consumed at the END of the next (two MFMA blocks, ~8 000
+      // cycles of slack instead of ~4 000).  Chunks past the end fall out of every buffer's range (or fetch weights nobody multiplies) and
+      // their LDS images are never read back: no branch around a load or a store.
+      const float* s0 = smem; const float* s1 = smem + (SA + SB);
+      load_chunk(0, 0); load_chunk(1, 1);
+      __syncthreads();                                          // the previous m-tile's reads of buffer 0 are done
+      store_chunk(0, 0);
+      __syncthreads();
+      for (int ch = 0; ch < nchunks; ch += 2) {
+        load_chunk(ch + 2, 0);
+        mma_chunk<true, B_KC, 0, BN, TM, TN>(s0, s0 + SA, wm0, wn0, lane, acc);
+        store_chunk(1, 1);
+        __syncthreads();
+        if (ch + 1 >= nchunks) break;
+        load_chunk(ch + 3, 1);
+        mma_chunk<true, B_KC, 0, BN, TM, TN>(s1, s1 + SA, wm0, wn0, lane, acc);
+        store_chunk(0, 0);
+        __syncthreads();
+      }
+    } else if (nchunks > 0) {
       load_chunk(0);
       __syncthreads();                                          // the previous m-tile's reads of buffer 0 are done
       store_chunk(0);
