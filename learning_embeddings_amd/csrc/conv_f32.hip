@@ -119,7 +119,16 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
                                                                      float* __restrict__ dst, ActGeo g, float* __restrict__ part,
                                                                      ActFuse fz) {
   constexpr bool XF = (FUSE & 1) != 0, FOLD = (FUSE & 2) != 0;
-  // PF2: operands are fetched TWO chunks ahead into two register sets (the plain kernels have the registers: 2 waves per SIMD either way)
+  // PF2 (`make EXTRA=-DLEC_CF_PF2=1`): operands are fetched TWO chunks ahead into two register sets (the plain kernels have the registers: 2 waves
+  // per SIMD either way).  MEASURED (round 3, same box, 512 images, us forward one ahead / two ahead): 3x3 128 -> 128 @28 973 / 945, 256 -> 256 @14
+  // 1016 / 966, 512 -> 512 @7 1124 / 1087, 1x1 1024 -> 256 @14 494 / 462; short K loses (the two chunks fetched past the end are a large share:
+  // 1x1 64 -> 256 647 / 696; data gradient 256 -> 64 @56 611 / 713).  Selected per launch for the forward of layers with K >= 1024 it takes 1 ms
+  // off the convolutions' isolated time and nothing measurable off the step (130.7 - 131.7 ms either way): off.
+  // Also tried (round 3): waves 0-3 of an 8-wave workgroup as consumers (fragment reads, MFMAs, epilogue) and waves 4-7 as producers (row decode,
+  // loads two chunks ahead, LDS stores), each role its own instantiation of the tile body (105 / 98 registers, four waves per SIMD): the plain data
+  // gradients gain 3 - 5 % (3x3 256 -> 256 @14 1021 -> 966 us, 128 -> 128 @28 959 -> 921), the forward nothing (979 / 981); but most data gradients
+  // of the step run the fold epilogue, which the split does not serve, and hosting the tile body in a generic lambda cost that epilogue half its
+  // speed (conv1 of layer1: 1236 -> 2439 us; fewer registers, serialized loads).  Not kept.
   constexpr bool PF2 = LEC_CF_PF2 != 0 && FUSE == 0 && !TAPV;
   constexpr int NSET = PF2 ? 2 : 1;
   static_assert(!(XF && TAPV) && !(FOLD && STATS), "fused modes: one tap per chunk; one statistics epilogue at a time");
