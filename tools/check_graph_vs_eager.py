@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""The step's captured hipGraph against eager launches of the same region, parameter by parameter, after engines of other precisions
+and launch modes have lived in the process (how the racing `w.grad.add_` of the stem's weight gradient was found in round 3: two
+concurrent passes, only under replay, only after other engines had shifted the timing).  usage: python tools/check_graph_vs_eager.py"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from learning_embeddings_amd.engine import StepEngine
