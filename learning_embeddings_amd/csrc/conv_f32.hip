@@ -847,7 +847,12 @@ static int conv_f32_wgrad_impl(const float* dy, const float* x, int N, int H, in
   const int tiles = ((Cout + BM - 1) / BM) * ((g.Ng + BN - 1) / BN);
   const int nchunks = (g.Mpix + WBK - 1) / WBK;
   static const int wg_target = [] { const char* e = getenv("LEC_WGRAD_ITEMS"); const int v = e ? atoi(e) : 1024; return v > 0 ? v : 1024; }();
-  int split = (wg_target + tiles - 1) / tiles;                 // ~4 workgroups per CU in total (LEC_WGRAD_ITEMS: experiments)
+  // K split: work items = tiles x split.  The items of a launch should fill the resident workgroup slots a WHOLE number of times: with
+  // split = ceil(target / tiles) (round 2) 18 tiles gave 18 x 57 = 1 026 items for 1 024 slots -- two items alone in a third round, a fifth
+  // of the launch -- and 5 tiles 1 025.  Round DOWN (LEC_WGRAD_SPLIT_FLOOR=0: the old rule): at most `target` items, and `target` is a
+  // multiple of the slots of every variant (512 for the 223-register 128 x 256 tile, 1 024 for the others).
+  static const int wg_floor = [] { const char* e = getenv("LEC_WGRAD_SPLIT_FLOOR"); return e ? atoi(e) : 1; }();
+  int split = wg_floor ? wg_target / tiles : (wg_target + tiles - 1) / tiles;
   if (split > nchunks) split = nchunks;
   if (split < 1) split = 1;
   g.chunks_per_split = (nchunks + split - 1) / split;

@@ -843,8 +843,12 @@ class JointEmbeddings:
         metrics = {}
         if not images:
             return {'m-f1': 0.0, 'accuracy': 0.0}
-        if exact:                                                   # chunks of 10, whatever mode the networks are in (oe_h.py:1972,1778,1792-1795)
-            img_rep = self.embed_images(images, bs=10, skip_last=True)
+        if exact:
+            # the reference's chunks of 10 images, in whatever mode the networks are in (oe_h.py:1972, 1778, 1792-1795).  In eval mode
+            # (the val / test phases) a row's embedding does not depend on what shares its forward (BatchNorm uses its running
+            # statistics), so larger chunks give the same rows; in training mode (the train phase's own call) the chunk IS the
+            # BatchNorm batch and stays 10.
+            img_rep = self.embed_images(images, bs=10 if self.img_feat_net.training else 250, skip_last=True)
         else:
             was_training = self.img_feat_net.training
             self.img_feat_net.eval()
