@@ -335,6 +335,11 @@ def measure(args, dtype, rank, world, stamp, primary):
                      'ms_per_step_sum_of_launch_durations': round(phases['conv_f32'], 3),
                      'avg_launch_us': round(phases['conv_f32'] * 1e3 / eng.conv_launches_per_step, 1),
                      'avg_launch_us_of_busy_time': round(phases['conv_f32_busy'] * 1e3 / eng.conv_launches_per_step, 1),
+                     # two ways to read the same launches: (a) as if they ran one after the other (what a per-kernel table of durations adds up to:
+                     # with two passes in flight every launch's duration holds the other pass's work too, so this UNDER-states the pipe), (b) the
+                     # lower bound nobody can argue with: the family's flops over the whole wall time of the step
+                     'frac_if_durations_were_serial': round(eng.conv_flops_per_step / (phases['conv_f32'] * 1e-3) / 1e12 / 157.3, 4),
+                     'frac_lower_bound_flops_over_step_wall_time': round(eng.conv_flops_per_step / (dt / args.steps) / 1e12 / 157.3, 4),
                      'note': probe_note + 'HIP events on the stream each kernel runs on; achieved = flops / union of the launch intervals over the concurrent streams (the sum of the durations counts shared time once per stream)'}
         if conv_isolated is not None:
             roof_conv['isolated'] = {'ms_per_step': round(conv_isolated, 3), 'achieved': round(eng.conv_flops_per_step / conv_isolated / 1e9, 2),
