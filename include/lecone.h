@@ -409,6 +409,18 @@ int lec_bn_bwd_pass1_coeffs_f32(const void* dy, const void* dy2, const uint8_t* 
  *     atomics) instead of overwriting them -- for a step that runs several backward passes over the same parameters, possibly on
  *     concurrent streams, and zeroes the slots once per step.  Returns the previous setting (process-wide; set it before the steps). */
 int lec_bn_bwd_accumulate(int on);
+/*     lec_conv_f32_scratch: scratch for the BALANCED form of lec_conv_f32_fwd / the stride-1 data gradients on `stream`.  A launch whose 128 x 128
+ *     output tiles would leave the last round of the chip's 512 workgroup slots mostly empty (ResNet-50 at the bench batch: 392 x 2^k tiles from
+ *     layer2 on) is cut into 512 equal runs of (tile, K chunk) iterations instead; tiles whose chunks fall to several workgroups are summed through
+ *     this scratch in a fixed order (same bits every run).  `buf`: lec_conv_f32_scratch_bytes() bytes, 16-byte aligned, ZEROED by the caller, alive
+ *     until unregistered (buf = null); one per stream that launches convolutions (launches of one stream are ordered, so they share it).  Streams
+ *     without a scratch use the tile-walk kernel.  With the balanced form the statistics / fold partials are one row per m-tile: n_partials can
+ *     reach 2048 (the row count lec_bn_workspace_bytes provides for). */
+int64_t lec_conv_f32_scratch_bytes(void);
+int lec_conv_f32_scratch(lec_stream_t stream, void* buf, int64_t bytes);
+/*     lec_conv_f32_balanced(mode): 0 never use the balanced form, 1 where it pays (default; LEC_CF_SK in the environment sets the start value),
+ *     2 wherever it applies (tests), -1 only report.  Returns the mode in force before the call (process-wide). */
+int lec_conv_f32_balanced(int mode);
 int lec_bn_bwd_coeffs_f32(int64_t M, int C, int n_partials, const float* gamma, const float* save_mean, const float* save_invstd,
                           float* dgamma, float* dbeta, float* coef, void* workspace, int64_t workspace_bytes, lec_stream_t stream);
 int lec_conv_f32_wgrad(const float* dy, const float* x, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,

@@ -91,7 +91,8 @@ struct EF32 {
 };
 
 constexpr int kBnThreads = 256;
-constexpr int kBnMaxBlocks = 512;
+constexpr int kBnMaxBlocks = 512;           // blocks of a reduction pass of this file
+constexpr int kBnMaxRows = 2048;            // partial rows the workspace holds (layout constant): a convolution's balanced form leaves one row per m-tile
 
 // Reduction passes: a block owns a channel chunk of CVB 16-byte vectors (<= 64: up to 1 KiB contiguous per row) and a
 // strided set of rows; grid = (nrb row blocks, NCH channel chunks), nrb * NCH <= 512 blocks (2 per CU, 8 loads in flight
@@ -456,7 +457,7 @@ extern "C" int lec_bn_bwd_accumulate(int on) {
 
 extern "C" int64_t lec_bn_workspace_bytes(int C) {
   if (C <= 0) return LEC_E_ARG;
-  return ((int64_t)lec::kBnMaxBlocks * 2 * C + 4 * (int64_t)C) * sizeof(float);
+  return ((int64_t)lec::kBnMaxRows * 2 * C + 4 * (int64_t)C) * sizeof(float);
 }
 
 template <typename E> static int bn_fwd_impl(const void* x, const void* residual, int64_t M, int C, const float* gamma, const float* beta,
@@ -471,7 +472,7 @@ template <typename E> static int bn_fwd_impl(const void* x, const void* residual
   hipStream_t st = (hipStream_t)stream;
   BnGeom g = bn_geom(M, C);
   float* part = (float*)workspace;
-  float* scale = part + (int64_t)kBnMaxBlocks * 2 * C; float* shift = scale + C;
+  float* scale = part + (int64_t)kBnMaxRows * 2 * C; float* shift = scale + C;
   if (training > 1) {                                      // statistics partials already in the workspace (training - 2 rows)
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, training - 2, C, M, gamma, beta, eps,
                        momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
@@ -505,7 +506,7 @@ template <typename E> static int bn_bwd_impl(const void* dy, const void* dy2, co
   hipStream_t st = (hipStream_t)stream;
   BnGeom g = bn_geom(M, C);
   float* part = (float*)workspace;
-  float* c1 = part + (int64_t)kBnMaxBlocks * 2 * C; float* c2 = c1 + C;
+  float* c1 = part + (int64_t)kBnMaxRows * 2 * C; float* c2 = c1 + C;
 #define R(M_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<E, M_>), dim3(g.nrb, g.NCH), dim3(kBnThreads), 0, st, dy, dy2, ym, x, M, C, g.CV, g.CVB, g.RPIB, save_mean, save_invstd, part, dresidual)
   if (rm == 0) R(0); else if (rm == 1) R(1); else R(2);
 #undef R
@@ -525,7 +526,7 @@ template <typename E> static int bn_bwd_impl(const void* dy, const void* dy2, co
 
 extern "C" int64_t lec_bn_workspace_coeff_offset(int C) {                // byte offset of scale[C], shift[C] (forward) inside the workspace
   if (C <= 0) return LEC_E_ARG;
-  return (int64_t)lec::kBnMaxBlocks * 2 * C * (int64_t)sizeof(float);
+  return (int64_t)lec::kBnMaxRows * 2 * C * (int64_t)sizeof(float);
 }
 
 extern "C" int lec_bn_fwd_finalize(int64_t M, int C, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
@@ -534,10 +535,10 @@ extern "C" int lec_bn_fwd_finalize(int64_t M, int C, const float* gamma, const f
   using namespace lec;
   if (int rc = bn_check("bn_fwd_finalize", M, C)) return rc;
   LEC_CHECK_ARG(gamma && beta && save_mean && save_invstd && workspace, "bn_fwd_finalize: null pointer");
-  LEC_CHECK_ARG(n_partials >= 1 && n_partials <= kBnMaxBlocks, "bn_fwd_finalize: n_partials=%d outside 1..%d", n_partials, kBnMaxBlocks);
+  LEC_CHECK_ARG(n_partials >= 1 && n_partials <= kBnMaxRows, "bn_fwd_finalize: n_partials=%d outside 1..%d", n_partials, kBnMaxRows);
   LEC_CHECK_ARG(workspace_bytes >= lec_bn_workspace_bytes(C), "bn_fwd_finalize: workspace too small");
   float* part = (float*)workspace;
-  float* scale = part + (int64_t)kBnMaxBlocks * 2 * C; float* shift = scale + C;
+  float* scale = part + (int64_t)kBnMaxRows * 2 * C; float* shift = scale + C;
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, (hipStream_t)stream, part, n_partials, C, M, gamma, beta,
                      eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
   LEC_CHECK_LAUNCH("bn_stats_finalize_kernel");
@@ -556,7 +557,7 @@ template <typename E> static int bn_bwd_pass1_impl(const void* dy, const void* d
   hipStream_t st = (hipStream_t)stream;
   BnGeom geo = bn_geom(M, C);
   float* part = (float*)workspace;
-  float* c1 = part + (int64_t)kBnMaxBlocks * 2 * C; float* c2 = c1 + C;
+  float* c1 = part + (int64_t)kBnMaxRows * 2 * C; float* c2 = c1 + C;
 #define R(M_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<E, M_>), dim3(geo.nrb, geo.NCH), dim3(kBnThreads), 0, st, dy, dy2, relu_mask, x, M, C, geo.CV, geo.CVB, geo.RPIB, save_mean, save_invstd, part, g)
   if (relu_mask) R(2); else R(0);
 #undef R
@@ -570,10 +571,10 @@ extern "C" int lec_bn_bwd_finalize(int64_t M, int C, int n_partials, float* dgam
   using namespace lec;
   if (int rc = bn_check("bn_bwd_finalize", M, C)) return rc;
   LEC_CHECK_ARG(dgamma && dbeta && workspace, "bn_bwd_finalize: null pointer");
-  LEC_CHECK_ARG(n_partials >= 1 && n_partials <= kBnMaxBlocks, "bn_bwd_finalize: n_partials=%d outside 1..%d", n_partials, kBnMaxBlocks);
+  LEC_CHECK_ARG(n_partials >= 1 && n_partials <= kBnMaxRows, "bn_bwd_finalize: n_partials=%d outside 1..%d", n_partials, kBnMaxRows);
   LEC_CHECK_ARG(workspace_bytes >= lec_bn_workspace_bytes(C), "bn_bwd_finalize: workspace too small");
   float* part = (float*)workspace;
-  float* c1 = part + (int64_t)kBnMaxBlocks * 2 * C; float* c2 = c1 + C;
+  float* c1 = part + (int64_t)kBnMaxRows * 2 * C; float* c2 = c1 + C;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, (hipStream_t)stream, part, n_partials, C, M, dgamma, dbeta,
                      c1, c2, g_bn_accumulate);
   LEC_CHECK_LAUNCH("bn_bwd_finalize_kernel");
@@ -585,7 +586,7 @@ extern "C" int lec_bn_bwd_coeffs_f32(int64_t M, int C, int n_partials, const flo
   using namespace lec;
   if (int rc = bn_check("bn_bwd_coeffs", M, C)) return rc;
   LEC_CHECK_ARG(gamma && save_mean && save_invstd && dgamma && dbeta && coef && workspace, "bn_bwd_coeffs: null pointer");
-  LEC_CHECK_ARG(n_partials >= 1 && n_partials <= kBnMaxBlocks, "bn_bwd_coeffs: n_partials=%d outside 1..%d", n_partials, kBnMaxBlocks);
+  LEC_CHECK_ARG(n_partials >= 1 && n_partials <= kBnMaxRows, "bn_bwd_coeffs: n_partials=%d outside 1..%d", n_partials, kBnMaxRows);
   LEC_CHECK_ARG(workspace_bytes >= lec_bn_workspace_bytes(C), "bn_bwd_coeffs: workspace too small");
   hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, (hipStream_t)stream, (const float*)workspace, n_partials, C, M,
                      gamma, save_mean, save_invstd, dgamma, dbeta, coef, g_bn_accumulate);
@@ -621,7 +622,7 @@ template <typename E> static int bn_bwd_apply_impl(const void* g, const void* x,
   LEC_CHECK_ARG(g && x && gamma && save_mean && save_invstd && dx && workspace, "bn_bwd_apply: null pointer");
   LEC_CHECK_ARG(workspace_bytes >= lec_bn_workspace_bytes(C), "bn_bwd_apply: workspace too small");
   BnGeom geo = bn_geom(M, C);
-  float* c1 = (float*)workspace + (int64_t)kBnMaxBlocks * 2 * C; float* c2 = c1 + C;
+  float* c1 = (float*)workspace + (int64_t)kBnMaxRows * 2 * C; float* c2 = c1 + C;
   int64_t nb = (M + geo.RPI - 1) / geo.RPI; nb = (nb + 1) / 2;
   const int nblk = (int)(nb < 1 ? 1 : (nb > bn_apply_cap() ? bn_apply_cap() : nb));
   hipLaunchKernelGGL((bn_bwd_apply_kernel<E, false, 0>), dim3(nblk), dim3(kBnThreads), 0, (hipStream_t)stream, g, nullptr,
@@ -636,12 +637,12 @@ template <typename E> static int bn_bwd_prereduced_impl(const void* g, const voi
   using namespace lec;
   if (int rc = bn_check("bn_bwd_prereduced", M, C)) return rc;
   LEC_CHECK_ARG(g && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && workspace, "bn_bwd_prereduced: null pointer");
-  LEC_CHECK_ARG(n_partials >= 1 && n_partials <= kBnMaxBlocks, "bn_bwd_prereduced: n_partials=%d outside 1..%d", n_partials, kBnMaxBlocks);
+  LEC_CHECK_ARG(n_partials >= 1 && n_partials <= kBnMaxRows, "bn_bwd_prereduced: n_partials=%d outside 1..%d", n_partials, kBnMaxRows);
   LEC_CHECK_ARG(workspace_bytes >= lec_bn_workspace_bytes(C), "bn_bwd_prereduced: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   BnGeom geo = bn_geom(M, C);
   float* part = (float*)workspace;
-  float* c1 = part + (int64_t)kBnMaxBlocks * 2 * C; float* c2 = c1 + C;
+  float* c1 = part + (int64_t)kBnMaxRows * 2 * C; float* c2 = c1 + C;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, n_partials, C, M, dgamma, dbeta, c1, c2, g_bn_accumulate);
   int64_t nb = (M + geo.RPI - 1) / geo.RPI; nb = (nb + 1) / 2;
   const int nblk = (int)(nb < 1 ? 1 : (nb > bn_apply_cap() ? bn_apply_cap() : nb));
@@ -655,7 +656,7 @@ template <typename E> static int bn_fwd_prestat_impl(const void* x, const void* 
                                   float eps, float momentum, float* running_mean, float* running_var, int n_partials,
                                   float* save_mean, float* save_invstd, void* y, int relu, uint8_t* relu_mask, void* workspace,
                                   int64_t workspace_bytes, lec_stream_t stream) {
-  LEC_CHECK_ARG(n_partials >= 1 && n_partials <= lec::kBnMaxBlocks, "bn_fwd_prestat: n_partials=%d outside 1..%d", n_partials, lec::kBnMaxBlocks);
+  LEC_CHECK_ARG(n_partials >= 1 && n_partials <= lec::kBnMaxRows, "bn_fwd_prestat: n_partials=%d outside 1..%d", n_partials, lec::kBnMaxRows);
   return bn_fwd_impl<E>(x, residual, M, C, gamma, beta, eps, momentum, running_mean, running_var, 2 + n_partials, save_mean, save_invstd,
                     y, relu, relu_mask, workspace, workspace_bytes, stream);
 }

@@ -34,6 +34,10 @@
 //
 // Roofline: MFMA (f32).  Algorithmic flops 2*M*N*K per launch; bytes are noise except for layer1's 1x1 layers.
 #include "conv_geo.h"
+#include <mutex>
+#include <atomic>
+#include <map>
+#include <utility>
 
 #ifndef LEC_CF_UNCOND
 #define LEC_CF_UNCOND 0
@@ -456,6 +460,281 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Balanced ("stream-K") form of the forward / stride-1 data gradient, for launches whose tiles do not fill whole rounds of workgroup slots.
+//
+// Why (tools/exp_tile_quantization.py, round 3): every ResNet-50 layer from layer2 on has 392 x 2^k equal 128 x 128 tiles at the bench batch --
+// 1 568 / 784 / 392, i.e. 3.06 / 1.53 / 0.77 rounds of the 512 resident workgroups -- and the kernel above runs them at 100 - 105 TFLOP/s; the SAME
+// kernel on a pixel count that fills whole rounds (1 024, 1 536 tiles) runs at 131 - 137.  The K loop was never the problem (94 % busy in steady state,
+// profiles/r03_conv_f32_pmc.md): a quarter of the time went to a last round that is nearly empty.
+//
+// How: the launch's work is the sequence of all (tile, k chunk) iterations, tile-major; workgroup w of G takes the contiguous share
+// [I w / G, I (w + 1) / G) -- equal work for everyone, whole tiles where the share covers them, at most one unfinished tile at each end.  A tile
+// whose chunks are spread over several workgroups is put together by the LAST of them to arrive (ticket counter per tile; nobody waits, so nothing
+// can deadlock): every contributor writes its partial accumulators to its own slot of a scratch buffer, and the finalizer sums the slots of ALL
+// contributors in workgroup order (its own included, read back from memory) -- a fixed order, so the output bits do not depend on who arrives
+// last -- and runs the epilogue (store / fold, statistics).  Statistics partials are written per TILE (row = m-tile index), again independent of
+// who computed them.  The slabs travel write-through: sc1 stores, each wave's vmcnt drain, barrier, one lane's agent-scope ticket; the finalizer reads
+// them with sc1 loads only (CDNA4 guide 6 G16, form R1 -- an agent-scope release fence per slab writes back the XCD's whole L2 and cost 100 - 160 us
+// per launch on the 1x1 layers).  Scratch: 2 slots of BM x BN floats per workgroup + one counter per tile, registered per stream
+// (lec_conv_f32_scratch); counters are zero between launches (the finalizer re-arms its tile's counter).
+struct SkArgs { float* slots; unsigned int* counters; int ntn; int tiles; };
+
+template <bool B_KC, int TM, int TN, bool STATS, int FUSE>
+__global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_sk_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
+                                                                        float* __restrict__ dst, ActGeo g, float* __restrict__ part,
+                                                                        ActFuse fz, SkArgs sk) {
+  constexpr int WM = 2, WN = 2;
+  constexpr bool FOLD = (FUSE & 2) != 0;
+  static_assert((FUSE & 1) == 0 && !(FOLD && STATS), "stream-K serves the plain and the fold epilogues");
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  constexpr int NA = BM * kCfKQ / kCfThreads, NB = BN * kCfKQ / kCfThreads;
+  constexpr int SA = BM * kCfLdk;
+  constexpr int SB = B_KC ? BN * kCfLdk : kCfBK * BN;
+  constexpr int PR = BN / 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WN) * 32 * TM, wn0 = (wave % WN) * 32 * TN;
+  const int nchunks = (g.Kg + kCfBK - 1) / kCfBK;
+  const int kqA = tid & (kCfKQ - 1), rowA = tid / kCfKQ;
+  const rsrc_t rs_src = make_rsrc(src, g.src_bytes), rs_wgt = make_rsrc(wgt, g.wgt_bytes), rs_dst = make_rsrc(dst, g.dst_bytes);
+  const int rsc = g.RS * g.Cin;
+  const unsigned ldsA = (unsigned)((rowA * kCfLdk + 4 * kqA) * 4);
+  const unsigned ldsB = (unsigned)((SA + (B_KC ? rowA * kCfLdk + 4 * kqA : tid * 4)) * 4);
+  const int ntaps = g.na * g.nb;
+  const int l31 = lane & 31, h = lane >> 5;
+  const long long I = (long long)sk.tiles * nchunks, G = gridDim.x;
+  const rsrc_t rs_slots = make_rsrc(sk.slots, (uint32_t)(gridDim.x * 2u * (unsigned)(BM * BN * 4)));
+  auto wg_start = [&](long long w) { return I * w / G; };
+  long long it0 = wg_start(blockIdx.x);
+  const long long it1 = wg_start(blockIdx.x + 1);
+
+  while (it0 < it1) {
+    const int tile = (int)(it0 / nchunks);
+    const int c0 = (int)(it0 - (long long)tile * nchunks);
+    const int c1 = (int)((it1 - it0) < (long long)(nchunks - c0) ? c0 + (it1 - it0) : nchunks);
+    it0 += c1 - c0;
+    const int mt = tile / sk.ntn, nt = tile - mt * sk.ntn;      // column tiles of the same rows are neighbours in the sequence
+    const int m0 = mt * BM, n0 = nt * BN;
+    unsigned wB[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      if (B_KC) { const int co = n0 + rowA + kCfRP * u; wB[u] = co < g.Cd ? (unsigned)(co * rsc + 4 * kqA) * 4u : kOob; }
+      else { const int v_ = tid + kCfThreads * u; const int kr = v_ / PR, jq = v_ - kr * PR; const int ci = n0 + 4 * jq;
+             wB[u] = ci < g.Cd ? (unsigned)(kr * rsc + ci) * 4u : kOob; }
+    }
+    int rowoff[NA]; unsigned tapmask[NA];
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int m = m0 + rowA + kCfRP * u;
+      const bool live = m < g.Mg;
+      const int mm = live ? m : 0;
+      const int t2 = fdiv(mm, g.dWm); const int mw = mm - t2 * g.Wm; const int n = fdiv(t2, g.dHm); const int mh = t2 - n * g.Hm;
+      const int hb = mh * g.sst + g.oh0, wb = mw * g.sst + g.ow0;
+      rowoff[u] = (((n * g.Hs + hb) * g.Ws + wb) << g.lgCs) * 4 + 16 * kqA;
+      unsigned msk = 0;
+      for (int t = 0; t < ntaps; ++t) {
+        const int ta = fdiv(t, g.dnb), tb = t - ta * g.nb;
+        const int hs = hb + g.sg * ta, ws = wb + g.sg * tb;
+        msk |= ((unsigned)hs < (unsigned)g.Hs && (unsigned)ws < (unsigned)g.Ws ? 1u : 0u) << t;
+      }
+      tapmask[u] = live ? msk : 0u;
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int it = 0; it < TM; ++it)
+#pragma unroll
+      for (int jt = 0; jt < TN; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[it][jt][r] = 0.f;
+    f32x4v ra[NA], rb[NB];
+    unsigned cur[NA];
+    int cur_tap = -1;
+    auto load_chunk = [&](int ch) {
+      const int k0 = ch * kCfBK;
+      const int tap = k0 >> g.lgCs, c0k = k0 & (g.Cs - 1);
+      const int ta = fdiv(tap, g.dnb), tb = tap - ta * g.nb;
+      if (tap != cur_tap) {
+        cur_tap = tap;
+        const int toff = (((g.sg * ta) * g.Ws + g.sg * tb) << g.lgCs) * 4;
+        const unsigned tapbit = tap < 32 ? 1u << tap : 0u;
+#pragma unroll
+        for (int u = 0; u < NA; ++u) cur[u] = (tapmask[u] & tapbit) ? (unsigned)(rowoff[u] + toff) : kOob;
+      }
+      const int tw = (g.r0 + g.rstep * ta) * g.S + g.s0 + g.sstep * tb;
+      const unsigned wsc = (unsigned)(B_KC ? tw * g.Cin + c0k : c0k * rsc + tw * g.Cin) * 4u;
+      const unsigned c0b = (unsigned)c0k * 4u;
+#pragma unroll
+      for (int u = 0; u < NA; ++u) ra[u] = bload4(rs_src, cur[u] + c0b);
+#pragma unroll
+      for (int u = 0; u < NB; ++u) rb[u] = bload4(rs_wgt, wB[u] + wsc);
+    };
+    auto store_chunk = [&](int buf) {
+      char* base = (char*)smem + buf * (SA + SB) * 4;
+#pragma unroll
+      for (int u = 0; u < NA; ++u) *(f32x4v*)(base + ldsA + u * kCfRP * kCfLdk * 4) = ra[u];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) *(f32x4v*)(base + ldsB + u * (B_KC ? kCfRP * kCfLdk * 4 : kCfThreads * 16)) = rb[u];
+    };
+    load_chunk(c0);
+    __syncthreads();                                            // the previous segment's reads of buffer 0 (and of the reduction scratch) are done
+    store_chunk(0);
+    __syncthreads();
+    for (int ch = c0; ch < c1; ++ch) {
+      const int buf = (ch - c0) & 1;
+      const float* sA = smem + buf * (SA + SB);
+      if (ch + 1 < c1) load_chunk(ch + 1);
+      mma_chunk<true, B_KC, 0, BN, TM, TN>(sA, sA + SA, wm0, wn0, lane, acc);
+      if (ch + 1 < c1) store_chunk(buf ^ 1);
+      __syncthreads();
+    }
+
+    bool finalize = c0 == 0 && c1 == nchunks;
+    if (!finalize) {
+      // contributors of this tile: the workgroups whose shares meet [T0, T1), in order
+      const long long T0 = (long long)tile * nchunks, T1 = T0 + nchunks;
+      long long wa = T0 * G / I; while (wg_start(wa + 1) <= T0) ++wa; while (wg_start(wa) > T0) --wa;
+      long long wb_ = (T1 - 1) * G / I; while (wg_start(wb_ + 1) <= T1 - 1) ++wb_; while (wg_start(wb_) > T1 - 1) --wb_;
+      const int nc = (int)(wb_ - wa + 1);
+      // the slab leaves this workgroup WRITE-THROUGH (sc1: no release fence, which would write back the whole XCD L2); every wave drains its
+      // stores, the barrier collects the waves, one lane draws the tile's ticket
+      const unsigned mine = (unsigned)((blockIdx.x * 2 + (c0 > 0 ? 0 : 1)) * (BM * BN * 4)) + (unsigned)tid * 16u;
+#pragma unroll
+      for (int it = 0; it < TM; ++it)
+#pragma unroll
+        for (int jt = 0; jt < TN; ++jt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4v v; v[0] = acc[it][jt][4 * q]; v[1] = acc[it][jt][4 * q + 1]; v[2] = acc[it][jt][4 * q + 2]; v[3] = acc[it][jt][4 * q + 3];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4r, v), rs_slots, (int)(mine + (unsigned)(((it * TN + jt) * 4 + q) * kCfThreads * 16)), 0, 16);
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(sk.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev == (unsigned)(nc - 1);
+        if (last) __hip_atomic_store(sk.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm for the next (stream-ordered) launch
+        s_last = last;
+      }
+      __syncthreads();
+      finalize = s_last != 0;
+      if (finalize) {
+        // the last arriver: every slab of the tile is in memory; EVERY load of them is an sc1 load (past this CU's L1, which no other CU's store
+        // refreshes).  Fixed order: the sum does not depend on who finalizes.
+#pragma unroll
+        for (int it = 0; it < TM; ++it)
+#pragma unroll
+          for (int jt = 0; jt < TN; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[it][jt][r] = 0.f;
+        for (long long w = wa; w <= wb_; ++w) {
+          const unsigned sl = (unsigned)(((int)w * 2 + (wg_start(w) > T0 ? 0 : 1)) * (BM * BN * 4)) + (unsigned)tid * 16u;
+#pragma unroll
+          for (int it = 0; it < TM; ++it)
+#pragma unroll
+            for (int jt = 0; jt < TN; ++jt)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const f32x4v v = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_slots, (int)(sl + (unsigned)(((it * TN + jt) * 4 + q) * kCfThreads * 16)), 0, 16));
+                acc[it][jt][4 * q] += v[0]; acc[it][jt][4 * q + 1] += v[1]; acc[it][jt][4 * q + 2] += v[2]; acc[it][jt][4 * q + 3] += v[3];
+              }
+        }
+      }
+    }
+    if (!finalize) continue;
+
+    // ---- epilogue of a complete tile (dense destination): plain store, or the fold; statistics partials per tile
+    float st_s[TN], st_q[TN];
+#pragma unroll
+    for (int jt = 0; jt < TN; ++jt) { st_s[jt] = 0.f; st_q[jt] = 0.f; }
+    unsigned coff[TN];
+#pragma unroll
+    for (int jt = 0; jt < TN; ++jt) { const int c = n0 + wn0 + jt * 32 + l31; coff[jt] = c < g.Cd ? (unsigned)c * 4u : kOob; }
+    const unsigned rowbytes = (unsigned)g.Cd * 4u;
+    if (FOLD) {
+      const rsrc_t rs_dres = make_rsrc(fz.dres ? fz.dres : dst, fz.dres ? g.dst_bytes : 0u), rs_xbn = make_rsrc(fz.xbn, g.dst_bytes);
+      const rsrc_t rs_mask = make_rsrc(fz.mask ? (const void*)fz.mask : (const void*)dst, fz.mask ? fz.mask_bytes : 0u);
+      const bool has_mask = fz.mask != nullptr;
+      const unsigned cvrow = (unsigned)g.Cd >> 3;
+      float mu[TN], is[TN]; unsigned mcv[TN], mbit[TN];
+#pragma unroll
+      for (int jt = 0; jt < TN; ++jt) {
+        const int c = n0 + wn0 + jt * 32 + l31; const bool okc = c < g.Cd;
+        mu[jt] = okc ? fz.mean[c] : 0.f; is[jt] = okc ? fz.invstd[c] : 0.f;
+        const int hc = g.Cd >> 1; const int cc = c < hc ? c : c - hc;
+        mcv[jt] = (unsigned)(cc >> 2); mbit[jt] = (unsigned)((cc & 3) + (c < hc ? 0 : 4));
+      }
+#pragma unroll
+      for (int it = 0; it < TM; ++it) {
+#pragma unroll
+        for (int r8 = 0; r8 < 16; r8 += 8) {
+          float dv[8][TN], xv[8][TN]; unsigned mb[8][TN];
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) {
+            const int r = r8 + rr;
+            const int m = m0 + wm0 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const unsigned poff = m < g.Mg ? (unsigned)m * rowbytes : kOob;
+#pragma unroll
+            for (int jt = 0; jt < TN; ++jt) {
+              const unsigned off = (poff + coff[jt]) | ((poff | coff[jt]) & kOob);
+              dv[rr][jt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dres, (int)off, 0, 0));
+              xv[rr][jt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_xbn, (int)off, 0, 0));
+              mb[rr][jt] = has_mask ? (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_mask, (int)(m < g.Mg ? (unsigned)m * cvrow + mcv[jt] : kOob), 0, 0) : 0xffu;
+            }
+          }
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) {
+            const int r = r8 + rr;
+            const int m = m0 + wm0 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const unsigned poff = m < g.Mg ? (unsigned)m * rowbytes : kOob;
+#pragma unroll
+            for (int jt = 0; jt < TN; ++jt) {
+              float a = acc[it][jt][r] + dv[rr][jt];
+              a = ((mb[rr][jt] >> mbit[jt]) & 1u) && m < g.Mg ? a : 0.f;
+              st_s[jt] += a; st_q[jt] += a * ((xv[rr][jt] - mu[jt]) * is[jt]);
+              bstore1(a, rs_dst, (poff + coff[jt]) | ((poff | coff[jt]) & kOob));
+            }
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < TM; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm0 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const unsigned poff = m < g.Mg ? (unsigned)m * rowbytes : kOob;
+#pragma unroll
+          for (int jt = 0; jt < TN; ++jt) {
+            bstore1(acc[it][jt][r], rs_dst, (poff + coff[jt]) | ((poff | coff[jt]) & kOob));
+            if (STATS) { const float v = acc[it][jt][r]; st_s[jt] += v; st_q[jt] += v * v; }    // rows past Mg are 0
+          }
+        }
+    }
+    if (STATS || FOLD) {
+      // lane halves -> the two waves of a column block -> the tile's partial row: part[mt][2][Cd]
+      float* red = smem;                                        // [WM][2 stats][BN]  (the K loop's last barrier has passed)
+#pragma unroll
+      for (int jt = 0; jt < TN; ++jt) {
+        st_s[jt] += __shfl_xor(st_s[jt], 32, kWave); st_q[jt] += __shfl_xor(st_q[jt], 32, kWave);
+        if (h == 0) {
+          red[((wave / WN) * 2 + 0) * BN + wn0 + jt * 32 + l31] = st_s[jt];
+          red[((wave / WN) * 2 + 1) * BN + wn0 + jt * 32 + l31] = st_q[jt];
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < 2 * BN; i += kCfThreads) {
+        const int sx = i / BN, c = i - sx * BN;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) v += red[(w * 2 + sx) * BN + c];
+        if (n0 + c < g.Cd) part[((int64_t)mt * 2 + sx) * g.Cd + n0 + c] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // weight gradient: A[co][k = pixel] = dY (k slow), B[k = pixel][(tap, ci)] = X gathered (k slow); split over K, float atomics.
 // The tile is 64 (co) x 256 (tap, ci): a 256-wide B row is ONE wave-instruction (64 lanes x 16 bytes), so the pixel a piece
 // belongs to is wave-uniform and its decode runs on the scalar ALU; per lane only the (static) tap of its four columns matters.
@@ -660,13 +939,61 @@ __global__ __launch_bounds__(kCfThreads, (XF && WM <= 2 && TM * TN == 4) ? LEC_W
 }
 
 
+// Scratch of the balanced kernel, one per stream (launches on a stream are ordered; two streams run side by side): counters first, slots behind.
+constexpr int kSkWgs = 512;               // workgroups of a balanced launch: the resident slots of the chip (256 CUs x 2)
+constexpr int kSkMaxTiles = 16384;
+struct SkScratch { float* slots; unsigned int* counters; };
+static std::mutex g_sk_mu;
+static std::map<std::pair<int, void*>, SkScratch> g_sk;   // (device, stream)
+static inline std::pair<int, void*> sk_key(hipStream_t st) { int d = 0; (void)hipGetDevice(&d); return {d, (void*)st}; }
+static inline int64_t sk_scratch_bytes() { return (int64_t)kSkMaxTiles * 4 + (int64_t)kSkWgs * 2 * 128 * 128 * 4; }
+static inline bool sk_lookup(hipStream_t st, SkScratch* out) {
+  std::lock_guard<std::mutex> lk(g_sk_mu);
+  auto it = g_sk.find(sk_key(st));
+  if (it == g_sk.end()) return false;
+  *out = it->second; return true;
+}
+// LEC_CF_SK: 0 never, 1 (default) where the tile count leaves the last round of workgroup slots under LEC_CF_SK_FILL (default 0.92) full, 2 wherever
+// the kernel applies (tests).
+static std::atomic<int> g_sk_mode{-1};      // lec_conv_f32_balanced(): overrides the environment
+static inline int sk_mode() {
+  static const int env = [] { const char* e = getenv("LEC_CF_SK"); return e ? atoi(e) : 1; }();
+  const int m = g_sk_mode.load(std::memory_order_relaxed);
+  return m >= 0 ? m : env;
+}
+static inline double sk_fill() { static const double v = [] { const char* e = getenv("LEC_CF_SK_FILL"); return e ? atof(e) : 0.92; }(); return v; }
+static inline int sk_min_chunks() { static const int v = [] { const char* e = getenv("LEC_CF_SK_MIN_CHUNKS"); return e ? atoi(e) : 8; }(); return v; }
+
 template <bool B_KC, bool STATS, int FUSE = 0>
 static int launch_act(const float* src, const float* wgt, float* dst, const ActGeo& g, float* part, int* nparts, hipStream_t st,
-                      const ActFuse& fz = ActFuse{}) {
+                      const ActFuse& fz = ActFuse{}, int part_rows = kCfMaxPart) {
   // column tile: 128 wide unless the layer has 64 output channels
   const bool narrow = g.Cd <= 64;
   const int BM = 128, BN = narrow ? 64 : 128;
   const int mtiles = (g.Mg + BM - 1) / BM, ntiles = (g.Cd + BN - 1) / BN;
+  if constexpr ((FUSE & 1) == 0) {
+    // the balanced form: 128 x 128 tiles of a dense destination, whole-tap chunks (see conv_f32_act_sk_kernel)
+    const int mode = sk_mode();
+    const long long tiles = (long long)mtiles * ntiles;
+    const int nchunks = (g.Kg + kCfBK - 1) / kCfBK;
+    SkScratch sc;
+    if (mode != 0 && !narrow && g.dst_st == 1 && g.Cs % kCfBK == 0 && g.na * g.nb <= 32 && nchunks > 0 && tiles <= kSkMaxTiles &&
+        (!(STATS || (FUSE & 2)) || mtiles <= part_rows) && sk_lookup(st, &sc)) {
+      const long long iters = tiles * nchunks;
+      const int G = (int)(iters < kSkWgs ? iters : kSkWgs);
+      const double rounds = (double)tiles / kSkWgs;
+      const double fill = rounds / (double)((tiles + kSkWgs - 1) / kSkWgs);
+      if (mode == 2 || (fill < sk_fill() && iters / G >= sk_min_chunks())) {
+        const size_t lds = (size_t)2 * (BM * kCfLdk + (B_KC ? BN * kCfLdk : kCfBK * BN)) * 4;
+        SkArgs sk{sc.slots, sc.counters, ntiles, (int)tiles};
+        ActGeo gg = g; gg.xcd_per = 0;
+        hipLaunchKernelGGL((conv_f32_act_sk_kernel<B_KC, 2, 2, STATS, FUSE>), dim3(G), dim3(kCfThreads), lds, st, src, wgt, dst, gg, part, fz, sk);
+        if (nparts) *nparts = mtiles;
+        LEC_CHECK_LAUNCH("conv_f32_act_sk_kernel");
+        return LEC_OK;
+      }
+    }
+  }
   int gx = mtiles;
   if (STATS || (FUSE & 2)) { const int cap = kCfMaxPart; if (gx > cap) gx = cap; }
   else { const int cap = 2048 / (ntiles > 8 ? 8 : ntiles); if (gx > cap) gx = cap; }
@@ -708,6 +1035,26 @@ static int launch_act(const float* src, const float* wgt, float* dst, const ActG
 
 }  // namespace lec
 
+// Scratch of the balanced forward / data-gradient kernel for the launches of ONE stream: `buf` holds lec_conv_f32_scratch_bytes() bytes, ZEROED
+// by the caller, and stays alive until it is unregistered (buf = null) -- also across replays of a graph captured meanwhile.  Without a
+// registered scratch the stream's launches use the tile-walk kernel (same results to the last few bits: the K sum is split differently).
+// 0: never the balanced form; 1: where it pays (the default); 2: wherever it applies (tests); -1: only report.  Returns the mode in force before.
+extern "C" int lec_conv_f32_balanced(int mode) {
+  const int prev = lec::sk_mode();
+  if (mode >= 0) lec::g_sk_mode.store(mode > 2 ? 2 : mode, std::memory_order_relaxed);
+  return prev;
+}
+extern "C" int64_t lec_conv_f32_scratch_bytes(void) { return lec::sk_scratch_bytes(); }
+extern "C" int lec_conv_f32_scratch(lec_stream_t stream, void* buf, int64_t bytes) {
+  using namespace lec;
+  LEC_CHECK_ARG(!buf || bytes >= sk_scratch_bytes(), "conv_f32_scratch: %lld bytes, need %lld", (long long)bytes, (long long)sk_scratch_bytes());
+  LEC_CHECK_ARG(((uintptr_t)buf & 15) == 0, "conv_f32_scratch: buffer must be 16-byte aligned");
+  std::lock_guard<std::mutex> lk(g_sk_mu);
+  if (!buf) { g_sk.erase(sk_key((hipStream_t)stream)); return LEC_OK; }
+  g_sk[sk_key((hipStream_t)stream)] = SkScratch{(float*)((char*)buf + (int64_t)kSkMaxTiles * 4), (unsigned int*)buf};
+  return LEC_OK;
+}
+
 extern "C" int lec_conv_f32_fwd(const float* x, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                                 float* y, float* partials, int64_t partials_bytes, int* n_partials, lec_stream_t stream) {
   using namespace lec;
@@ -723,7 +1070,8 @@ extern "C" int lec_conv_f32_fwd(const float* x, const float* w, int N, int H, in
   g.dWm = make_fastdiv(g.Wm); g.dHm = make_fastdiv(g.Hm); g.dnb = make_fastdiv(g.nb);
   if (partials) {
     LEC_CHECK_ARG(n_partials && partials_bytes >= (int64_t)kCfMaxPart * 2 * Cout * (int64_t)sizeof(float), "conv_f32_fwd: partials buffer too small");
-    return launch_act<true, true>(x, w, y, g, partials, n_partials, (hipStream_t)stream);
+    const int64_t rows = partials_bytes / ((int64_t)2 * Cout * (int64_t)sizeof(float));
+    return launch_act<true, true>(x, w, y, g, partials, n_partials, (hipStream_t)stream, ActFuse{}, (int)(rows < kCfMaxRows ? rows : kCfMaxRows));
   }
   return launch_act<true, false>(x, w, y, g, nullptr, nullptr, (hipStream_t)stream);
 }
@@ -786,8 +1134,9 @@ extern "C" int lec_conv_f32_dgrad_fused(const float* dy, const float* w, int N, 
   fz.xsrc = xsrc; fz.coef = coef; fz.dres = dres; fz.xbn = xbn; fz.mask = mask; fz.mean = mean; fz.invstd = invstd;
   fz.mask_bytes = (uint32_t)((int64_t)N * H * W * (Cin / 8));
   hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = fold ? partials_bytes / ((int64_t)2 * Cin * (int64_t)sizeof(float)) : 0;
   if (xf && fold) return launch_act<false, false, 3>(dy, w, dx, g, partials, n_partials, st, fz);
-  if (fold) return launch_act<false, false, 2>(dy, w, dx, g, partials, n_partials, st, fz);
+  if (fold) return launch_act<false, false, 2>(dy, w, dx, g, partials, n_partials, st, fz, (int)(rows < kCfMaxRows ? rows : kCfMaxRows));
   return launch_act<false, false, 1>(dy, w, dx, g, nullptr, nullptr, st, fz);
 }
 

@@ -16,7 +16,8 @@ constexpr int kCfLdk = kCfBK + 4;         // row stride of a k-contiguous LDS ti
 constexpr int kCfKQ = kCfBK / 4;          // 16-byte pieces per k-contiguous row
 constexpr int kCfRP = 256 / kCfKQ;        // rows staged per pass of the 256 threads
 constexpr int kCfThreads = 256;
-constexpr int kCfMaxPart = 512;           // = kBnMaxBlocks: statistics partial rows
+constexpr int kCfMaxPart = 512;           // statistics partial rows of the tile-walk kernels (the buffer a caller passes holds this many)
+constexpr int kCfMaxRows = 2048;          // = kBnMaxRows: rows the BatchNorm workspace holds; the balanced kernel leaves one row per m-tile
 #ifndef LEC_WG_BK
 #define LEC_WG_BK 16
 #endif

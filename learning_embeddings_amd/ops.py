@@ -793,12 +793,29 @@ def _conv_timed(call, flops):
     CONV_TIMER.append((a, b, flops))
 
 
+_conv_scratch_bufs = {}
+
+
+def _conv_scratch():
+    """Register the balanced convolution kernel's scratch for the current stream (lec_conv_f32_scratch) the first time the stream launches
+    a convolution.  Never inside a graph capture (an allocation there belongs to the graph's pool): the engine's eager warm-up steps run
+    first, on the same streams."""
+    s = torch.cuda.current_stream()
+    key = (s.device.index, s.cuda_stream)
+    if key in _conv_scratch_bufs or torch.cuda.is_current_stream_capturing():
+        return
+    buf = torch.zeros(int(lib.lec_conv_f32_scratch_bytes()), dtype=torch.uint8, device=s.device)
+    check(lib.lec_conv_f32_scratch(stream_ptr(), dptr(buf), buf.numel()))
+    _conv_scratch_bufs[key] = buf
+
+
 def conv_f32_fwd(x, w, stride, pad, want_stats=False):
     """y = conv2d(x, w) in exact fp32 on the f32 MFMA (lec_conv_f32_fwd).  x [N, Cin, H, W], w [Cout, Cin, R, S], both
     channels_last fp32.  want_stats: the BatchNorm statistics partials of y are left in the BatchNorm workspace."""
     _nhwc_f32(x, 'x'); _nhwc_f32(w, 'w')
     n, cin, h, wd = x.shape; cout, _, r, s_ = w.shape
     ho, wo = (h + 2 * pad - r) // stride + 1, (wd + 2 * pad - s_) // stride + 1
+    _conv_scratch()
     y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     flops = 2.0 * n * ho * wo * cout * cin * r * s_
     if want_stats:
@@ -816,6 +833,7 @@ def conv_f32_dgrad(dy, w, x_shape, stride, pad):
     _nhwc_f32(dy, 'dy'); _nhwc_f32(w, 'w')
     n, cin, h, wd = x_shape; cout, _, r, s_ = w.shape
     dx = torch.empty((n, cin, h, wd), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last)
+    _conv_scratch()
     _conv_timed(lambda: check(lib.lec_conv_f32_dgrad(dptr(dy), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(dx), stream_ptr())),
                 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * cout * cin * r * s_)
     return dx
@@ -828,6 +846,7 @@ def conv_f32_dgrad_fused(dy, w, x_shape, stride, pad, xf=None, fold=None):
     _nhwc_f32(dy, 'dy'); _nhwc_f32(w, 'w')
     n, cin, h, wd = x_shape; cout, _, r, s_ = w.shape
     dx = torch.empty((n, cin, h, wd), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last)
+    _conv_scratch()
     xs = cf = None
     if xf is not None:
         xs, cf = xf; _nhwc_f32(xs, 'xsrc')

@@ -449,6 +449,94 @@ def test_conv_f32_dgrad_with_batchnorm_backward_pass1_in_the_epilogue(N, C, H, W
     ops.fusion().reset()
 
 
+# ------------------------------------------------------------------------------------------------ round 3: the balanced (stream-K) kernel
+class _Balanced:
+    """lec_conv_f32_balanced(mode) for the duration of a block (2: the balanced kernel wherever it applies, 0: never)."""
+    def __init__(self, mode): self.mode = mode
+    def __enter__(self): self.prev = ops.lib.lec_conv_f32_balanced(self.mode)
+    def __exit__(self, *a): ops.lib.lec_conv_f32_balanced(self.prev)
+
+
+SK_CASES = [  # N, Cin, H, W, Cout, R, pad: one workgroup per K chunk (tiny), tiles over 3 - 4 workgroups, whole tiles + split ends, ragged rows / channels
+    (2, 64, 12, 12, 256, 1, 0), (1, 512, 7, 7, 512, 3, 1), (64, 256, 14, 14, 256, 3, 1), (32, 64, 56, 56, 256, 1, 0), (3, 256, 9, 7, 128, 1, 0),
+    (16, 128, 28, 28, 128, 3, 1), (5, 1024, 5, 5, 2048, 1, 0),
+]
+
+
+@pytest.mark.parametrize('N,Cin,H,W,Cout,R,pad', SK_CASES)
+def test_conv_f32_balanced_kernel_equals_float64_on_integers_and_is_run_to_run_identical(N, Cin, H, W, Cout, R, pad):
+    """conv_f32_act_sk_kernel (lec_conv_f32_balanced(2): every eligible launch): forward with statistics and the stride-1 data gradient.
+    Small-integer operands: every partial sum is exact, so the outputs and the per-channel statistics must EQUAL float64 whatever way the
+    K range of a tile was cut over workgroups (a lost, doubled or stale partial is a mismatch, not noise).  Random operands: fp32 noise
+    against float64, and bit-identical results over repeated launches (the fix-up adds the partials in workgroup order, not arrival
+    order; counters re-arm themselves)."""
+    g = torch.Generator(device='cpu').manual_seed(Cin + Cout + R + N)
+    for kind in ('int', 'rand'):
+        if kind == 'int':
+            x = torch.randint(-3, 4, (N, Cin, H, W), generator=g).float(); w = torch.randint(-2, 3, (Cout, Cin, R, R), generator=g).float()
+        else:
+            x = torch.randn(N, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, R, R, generator=g) / (Cin * R * R) ** 0.5
+        x = _cl(x); w = _cl(w)
+        yr = F.conv2d(x.double(), w.double(), None, 1, pad)
+        dy = _cl(torch.randint(-2, 3, yr.shape, generator=g).float() if kind == 'int' else torch.randn(yr.shape, generator=g))
+        dxr = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), 1, pad)
+        outs = []
+        with _Balanced(2):
+            for rep in range(3):
+                ops.fusion().reset()
+                y = ops.conv_f32_fwd(x, w, 1, pad, want_stats=True)
+                k = ops.fusion().ws_owner[1]
+                part = ops._bn_workspace(x.device).view(torch.float32)[:k * 2 * Cout].view(k, 2, Cout).clone()
+                dx = ops.conv_f32_dgrad(dy, w, x.shape, 1, pad)
+                outs.append((y, part, dx))
+        assert k == (N * yr.shape[2] * yr.shape[3] + 127) // 128, 'one statistics row per m-tile: the balanced kernel ran'
+        y, part, dx = outs[0]
+        for o in outs[1:]:
+            assert torch.equal(o[0], y) and torch.equal(o[1], part) and torch.equal(o[2], dx), 'repeated launches differ'
+        ps = part.double().sum(0)
+        if kind == 'int':
+            assert torch.equal(y.double(), yr), 'forward'
+            assert torch.equal(dx.double(), dxr), 'data gradient'
+            assert torch.equal(ps[0], yr.sum(dim=(0, 2, 3))) and torch.equal(ps[1], (yr ** 2).sum(dim=(0, 2, 3)))
+        else:
+            tol = lambda ref: 2e-5 * ref.abs().max().item()
+            assert (y.double() - yr).abs().max().item() <= tol(yr)
+            assert (dx.double() - dxr).abs().max().item() <= tol(dxr)
+            assert torch.allclose(ps[0], yr.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3 * (N * H * W / 288) ** 0.5)
+            with _Balanced(0):
+                y0 = ops.conv_f32_fwd(x, w, 1, pad); dx0 = ops.conv_f32_dgrad(dy, w, x.shape, 1, pad)
+            assert (y - y0).abs().max().item() <= 4e-6 * yr.abs().max().item() and (dx - dx0).abs().max().item() <= 4e-6 * dxr.abs().max().item()
+    ops.fusion().reset()
+
+
+@pytest.mark.parametrize('N,C,H,W,Cout,R,pad,res', [(4, 256, 14, 14, 64, 1, 0, True), (2, 128, 12, 12, 128, 3, 1, False), (48, 256, 14, 14, 256, 3, 1, False),
+                                                      (40, 512, 7, 7, 128, 1, 0, True), (24, 128, 28, 28, 512, 1, 0, True)])
+def test_conv_f32_balanced_kernel_with_the_fold_epilogue(N, C, H, W, Cout, R, pad, res):
+    """The balanced kernel's fold epilogue (pass 1 of the BatchNorm backward): g bit-equal to the balanced plain data gradient followed by the
+    add and the mask, the partial sums (one row per m-tile) equal to float64 sums of that g to fp32 error, repeated launches identical."""
+    z, rec, _ = _bn_record(N, C, H, W, seed=C + R, res=res)
+    g = torch.Generator(device='cpu').manual_seed(78)
+    Ho, Wo = H + 2 * pad - R + 1, W + 2 * pad - R + 1
+    dy = _cl(torch.randn(N, Cout, Ho, Wo, generator=g))
+    w = _cl(torch.randn(Cout, C, R, R, generator=g) * 0.1)
+    rec['dres'] = _cl(torch.randn(N, C, H, W, generator=g)) if res else None
+    with _Balanced(2):
+        dx0 = ops.conv_f32_dgrad(dy, w, z.shape, 1, pad)
+        got = ops.conv_f32_dgrad_fused(dy, w, z.shape, 1, pad, fold=rec)
+        n = ops.fusion().ws_owner[1]
+        part = ops._bn_workspace(dy.device)[:n * 2 * C * 4].view(torch.float32).view(n, 2, C).clone()
+        again = ops.conv_f32_dgrad_fused(dy, w, z.shape, 1, pad, fold=rec)
+        part2 = ops._bn_workspace(dy.device)[:n * 2 * C * 4].view(torch.float32).view(n, 2, C)
+    assert n == (N * H * W + 127) // 128
+    want = (dx0 + rec['dres'] if res else dx0) * (z > 0)
+    assert torch.equal(got, want) and torch.equal(again, got) and torch.equal(part2, part)
+    gd = want.double(); xh = (rec['x'].double() - rec['mean'].double().view(1, C, 1, 1)) * rec['invstd'].double().view(1, C, 1, 1)
+    ps = part.double().sum(0)
+    assert (ps[0] - gd.sum(dim=(0, 2, 3))).abs().max().item() <= 1e-5 * gd.abs().sum(dim=(0, 2, 3)).max().item()
+    assert (ps[1] - (gd * xh).sum(dim=(0, 2, 3))).abs().max().item() <= 1e-5 * (gd * xh).abs().sum(dim=(0, 2, 3)).max().item()
+    ops.fusion().reset()
+
+
 @pytest.mark.parametrize('N,Cin,H,W,Cout', [(4, 64, 14, 14, 256), (3, 128, 9, 7, 512), (2, 256, 12, 12, 1024), (6, 512, 7, 7, 2048), (2, 64, 20, 20, 64)])
 def test_conv_f32_gradients_with_batchnorm_backward_pass2_on_the_operand_load(N, Cin, H, W, Cout):
     """lec_conv_f32_dgrad_fused / lec_conv_f32_wgrad_fused, on-load form (1x1 / stride 1): handed g, the BatchNorm input x and the
