@@ -377,6 +377,13 @@ int lec_conv_f32_fwd(const float* x, const float* w, int N, int H, int W, int Ci
                      float* y, float* partials, int64_t partials_bytes, int* n_partials, lec_stream_t stream);
 int lec_conv_f32_dgrad(const float* dy, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                        float* dx, lec_stream_t stream);
+/*     lec_conv_f32_fwd_affine: the forward of an EVAL-mode network (FeatCNN.eval(): calculate_classification_metrics' image embedding in
+ *       the 'val' / 'test' phases, oe_h.py:1989-2011): y = [relu](conv(x, w) * scale[c] + shift[c] [+ res]) with scale = gamma / sqrt(running_var
+ *       + eps), shift = beta - running_mean * scale -- F.batch_norm(training=False) (+ the block's residual add and ReLU) in the convolution's
+ *       epilogue, in the arithmetic of lec_bn_fwd_f32's apply pass (bit-equal to the two-kernel form); the raw convolution output is never
+ *       written and inference runs without a BatchNorm pass.  res: null or [N, Ho, Wo, Cout]. */
+int lec_conv_f32_fwd_affine(const float* x, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                            float* y, const float* scale, const float* shift, const float* res, int relu, lec_stream_t stream);
 /*     Fused BatchNorm pieces (the fp32 convolutions are bound by the matrix pipe and leave HBM idle; BatchNorm passes are the reverse:
  *     what moves from a BatchNorm pass into a convolution's loader or epilogue is hidden).  torchvision Bottleneck's
  *     relu(bn(conv(.))) chain reached from oe_h.py:311,317, backward:

@@ -112,17 +112,22 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ sA, const fl
 //   FOLD (epilogue, dense destination): instead of dx the kernel writes g = mask * (dx + dres) -- pass 1 of the backward of the
 //     BatchNorm IN FRONT of this layer (whose output this layer consumed; dres = the gradient of that output's other consumer) -- and
 //     leaves the per-channel partials sum g, sum g * xhat (xhat from that BatchNorm's input) in lec_bn_bwd_f32's workspace layout.
+//   AFF (epilogue, forward of an eval-mode network): the BatchNorm behind the layer is a per-channel affine map of running statistics; the kernel
+//     applies it (+ residual, + ReLU) to the accumulators -- the arithmetic of bn_apply_kernel, bit for bit -- and the raw convolution output is
+//     never written: inference runs without a single BatchNorm pass.
 struct ActFuse {
   const float* xsrc; const float* coef;                       // XF: second source tensor (same geometry as src), coefficients [3][Cs]
   const float* dres; const float* xbn; const unsigned char* mask; const float* mean; const float* invstd;   // FOLD
   uint32_t mask_bytes;
+  const float* scale; const float* shift; const float* res; int relu;   // AFF: y = [relu](acc * scale[c] + shift[c] [+ res]) -- an eval-mode BatchNorm in the epilogue
 };
 
 template <bool B_KC, int WM, int WN, int TM, int TN, bool STATS, bool TAPV, int FUSE = 0>
 __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
                                                                      float* __restrict__ dst, ActGeo g, float* __restrict__ part,
                                                                      ActFuse fz) {
-  constexpr bool XF = (FUSE & 1) != 0, FOLD = (FUSE & 2) != 0;
+  constexpr bool XF = (FUSE & 1) != 0, FOLD = (FUSE & 2) != 0, AFF = (FUSE & 4) != 0;
+  static_assert(!AFF || FUSE == 4, "the affine epilogue stands alone");
   // PF2 (`make EXTRA=-DLEC_CF_PF2=1`): operands are fetched TWO chunks ahead into two register sets (the plain kernels have the registers: 2 waves
   // per SIMD either way).  MEASURED (round 3, same box, 512 images, us forward one ahead / two ahead): 3x3 128 -> 128 @28 973 / 945, 256 -> 256 @14
   // 1016 / 966, 512 -> 512 @7 1124 / 1087, 1x1 1024 -> 256 @14 494 / 462; short K loses (the two chunks fetched past the end are a large share:
@@ -337,6 +342,47 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
     // epilogue: rows on the registers, 32 consecutive channels on the lanes; out-of-range rows / channels carry the kOob bit and
     // are dropped by the buffer's range check
     const int l31 = lane & 31, h = lane >> 5;
+    if (AFF) {
+      // y = [relu](acc * scale + shift [+ res]): bn_apply_kernel's expression (separate multiply and add); dense destination (forward)
+      const rsrc_t rs_res = make_rsrc(fz.res ? fz.res : dst, fz.res ? g.dst_bytes : 0u);
+      const bool has_res = fz.res != nullptr, relu = fz.relu != 0;
+      const unsigned rowbytes = (unsigned)g.Cd * 4u;
+      float sc[TN], sh[TN]; unsigned coffa[TN];
+#pragma unroll
+      for (int jt = 0; jt < TN; ++jt) {
+        const int c = n0 + wn0 + jt * 32 + l31; const bool okc = c < g.Cd;
+        sc[jt] = okc ? fz.scale[c] : 0.f; sh[jt] = okc ? fz.shift[c] : 0.f; coffa[jt] = okc ? (unsigned)c * 4u : kOob;
+      }
+#pragma unroll
+      for (int it = 0; it < TM; ++it) {
+#pragma unroll
+        for (int r8 = 0; r8 < 16; r8 += 8) {
+          float rv[8][TN];
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) {
+            const int r = r8 + rr;
+            const int m = m0 + wm0 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const unsigned poff = m < g.Mg ? (unsigned)m * rowbytes : kOob;
+#pragma unroll
+            for (int jt = 0; jt < TN; ++jt)
+              rv[rr][jt] = has_res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, (int)((poff + coffa[jt]) | ((poff | coffa[jt]) & kOob)), 0, 0)) : 0.f;
+          }
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) {
+            const int r = r8 + rr;
+            const int m = m0 + wm0 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const unsigned poff = m < g.Mg ? (unsigned)m * rowbytes : kOob;
+#pragma unroll
+            for (int jt = 0; jt < TN; ++jt) {
+              float v = acc[it][jt][r] * sc[jt] + sh[jt];
+              if (has_res) v += rv[rr][jt];
+              if (relu) v = v > 0.0f ? v : 0.0f;
+              bstore1(v, rs_dst, (poff + coffa[jt]) | ((poff | coffa[jt]) & kOob));
+            }
+          }
+        }
+      }
+    } else
     if (FOLD) {
       // g = mask * (acc + dres), partial sums of g and g * xhat per channel; dense destination (host-checked).  A lane's TN columns:
       // channel c -> (mean, invstd) and the position of its ReLU bit in lec_bn_fwd_f32's mask bytes: a thread-vector of that pass holds
@@ -484,8 +530,8 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_sk_kernel(const fl
                                                                         float* __restrict__ dst, ActGeo g, float* __restrict__ part,
                                                                         ActFuse fz, SkArgs sk) {
   constexpr int WM = 2, WN = 2;
-  constexpr bool FOLD = (FUSE & 2) != 0;
-  static_assert((FUSE & 1) == 0 && !(FOLD && STATS), "stream-K serves the plain and the fold epilogues");
+  constexpr bool FOLD = (FUSE & 2) != 0, AFF = (FUSE & 4) != 0;
+  static_assert((FUSE & 1) == 0 && !(FOLD && STATS) && (!AFF || FUSE == 4), "stream-K serves the plain, the fold and the affine epilogues");
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr int NA = BM * kCfKQ / kCfThreads, NB = BN * kCfKQ / kCfThreads;
   constexpr int SA = BM * kCfLdk;
@@ -651,6 +697,46 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_sk_kernel(const fl
 #pragma unroll
     for (int jt = 0; jt < TN; ++jt) { const int c = n0 + wn0 + jt * 32 + l31; coff[jt] = c < g.Cd ? (unsigned)c * 4u : kOob; }
     const unsigned rowbytes = (unsigned)g.Cd * 4u;
+    if (AFF) {
+      // y = [relu](acc * scale + shift [+ res]): bn_apply_kernel's expression (separate multiply and add); dense destination (forward)
+      const rsrc_t rs_res = make_rsrc(fz.res ? fz.res : dst, fz.res ? g.dst_bytes : 0u);
+      const bool has_res = fz.res != nullptr, relu = fz.relu != 0;
+      float sc[TN], sh[TN]; unsigned coffa[TN];
+#pragma unroll
+      for (int jt = 0; jt < TN; ++jt) {
+        const int c = n0 + wn0 + jt * 32 + l31; const bool okc = c < g.Cd;
+        sc[jt] = okc ? fz.scale[c] : 0.f; sh[jt] = okc ? fz.shift[c] : 0.f; coffa[jt] = okc ? (unsigned)c * 4u : kOob;
+      }
+#pragma unroll
+      for (int it = 0; it < TM; ++it) {
+#pragma unroll
+        for (int r8 = 0; r8 < 16; r8 += 8) {
+          float rv[8][TN];
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) {
+            const int r = r8 + rr;
+            const int m = m0 + wm0 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const unsigned poff = m < g.Mg ? (unsigned)m * rowbytes : kOob;
+#pragma unroll
+            for (int jt = 0; jt < TN; ++jt)
+              rv[rr][jt] = has_res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, (int)((poff + coffa[jt]) | ((poff | coffa[jt]) & kOob)), 0, 0)) : 0.f;
+          }
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) {
+            const int r = r8 + rr;
+            const int m = m0 + wm0 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const unsigned poff = m < g.Mg ? (unsigned)m * rowbytes : kOob;
+#pragma unroll
+            for (int jt = 0; jt < TN; ++jt) {
+              float v = acc[it][jt][r] * sc[jt] + sh[jt];
+              if (has_res) v += rv[rr][jt];
+              if (relu) v = v > 0.0f ? v : 0.0f;
+              bstore1(v, rs_dst, (poff + coffa[jt]) | ((poff | coffa[jt]) & kOob));
+            }
+          }
+        }
+      }
+    } else
     if (FOLD) {
       const rsrc_t rs_dres = make_rsrc(fz.dres ? fz.dres : dst, fz.dres ? g.dst_bytes : 0u), rs_xbn = make_rsrc(fz.xbn, g.dst_bytes);
       const rsrc_t rs_mask = make_rsrc(fz.mask ? (const void*)fz.mask : (const void*)dst, fz.mask ? fz.mask_bytes : 0u);
@@ -1016,6 +1102,15 @@ static int launch_act(const float* src, const float* wgt, float* dst, const ActG
   if (const char* e = getenv("LEC_CF_LDS_PAD")) lds += (size_t)atoi(e);                // experiments: force one workgroup per CU
   const bool tapv = g.Cs % kCfBK != 0;                          // source channels narrower than a chunk (the stem)
   LEC_CHECK_ARG(tapv || g.na * g.nb <= 32, "conv_f32: more than 32 taps per launch need the per-piece tap path");
+  if constexpr (FUSE == 4) {
+    if (tapv) {                                                 // the stem with an eval-mode BatchNorm behind it
+      if (narrow) hipLaunchKernelGGL((conv_f32_act_kernel<B_KC, 2, 2, 2, 1, STATS, true, 4>), dim3(gx, ntiles), dim3(kCfThreads), lds, st, src, wgt, dst, gg, part, fz);
+      else hipLaunchKernelGGL((conv_f32_act_kernel<B_KC, 2, 2, 2, 2, STATS, true, 4>), dim3(gx, ntiles), dim3(kCfThreads), lds, st, src, wgt, dst, gg, part, fz);
+      if (nparts) *nparts = gx;
+      LEC_CHECK_LAUNCH("conv_f32_act_kernel");
+      return LEC_OK;
+    }
+  }
   if (FUSE != 0) {
     LEC_CHECK_ARG(!tapv, "conv_f32: the fused modes need source channels that are a multiple of the K chunk (%d)", kCfBK);
     if (narrow) hipLaunchKernelGGL((conv_f32_act_kernel<B_KC, 2, 2, 2, 1, STATS, false, FUSE>), dim3(gx, ntiles), dim3(kCfThreads), lds, st, src, wgt, dst, gg, part, fz);
@@ -1074,6 +1169,26 @@ extern "C" int lec_conv_f32_fwd(const float* x, const float* w, int N, int H, in
     return launch_act<true, true>(x, w, y, g, partials, n_partials, (hipStream_t)stream, ActFuse{}, (int)(rows < kCfMaxRows ? rows : kCfMaxRows));
   }
   return launch_act<true, false>(x, w, y, g, nullptr, nullptr, (hipStream_t)stream);
+}
+
+// Forward with an eval-mode BatchNorm (+ residual, + ReLU) in the epilogue: y = [relu](conv(x, w) * scale[c] + shift[c] [+ res]) -- see ActFuse AFF.
+// scale / shift: Cout floats each (gamma / sqrt(running_var + eps), beta - running_mean * scale); res: null or a tensor of y's shape.
+extern "C" int lec_conv_f32_fwd_affine(const float* x, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                                       float* y, const float* scale, const float* shift, const float* res, int relu, lec_stream_t stream) {
+  using namespace lec;
+  if (int rc = conv_check("conv_f32_fwd_affine", N, H, W, Cin, Cout, R, S, stride, pad)) return rc;
+  LEC_CHECK_ARG(x && w && y && scale && shift, "conv_f32_fwd_affine: null pointer");
+  const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+  ActGeo g;
+  g.Mg = N * Ho * Wo; g.Hm = Ho; g.Wm = Wo; g.Hs = H; g.Ws = W; g.Cs = Cin; g.lgCs = ilog2_exact(Cin); g.sst = stride;
+  g.oh0 = -pad; g.ow0 = -pad; g.sg = 1; g.na = R; g.nb = S; g.r0 = 0; g.rstep = 1; g.s0 = 0; g.sstep = 1; g.S = S; g.RS = R * S;
+  g.Cd = Cout; g.Cin = Cin; g.Hd = Ho; g.Wd = Wo; g.dst_st = 1; g.dph = 0; g.dpw = 0; g.Kg = R * S * Cin;
+  g.src_bytes = (uint32_t)((int64_t)N * H * W * Cin * 4); g.wgt_bytes = (uint32_t)((int64_t)Cout * R * S * Cin * 4);
+  g.dst_bytes = (uint32_t)((int64_t)g.Mg * Cout * 4);
+  g.dWm = make_fastdiv(g.Wm); g.dHm = make_fastdiv(g.Hm); g.dnb = make_fastdiv(g.nb);
+  ActFuse fz{};
+  fz.scale = scale; fz.shift = shift; fz.res = res; fz.relu = relu;
+  return launch_act<true, false, 4>(x, w, y, g, nullptr, nullptr, (hipStream_t)stream, fz);
 }
 
 extern "C" int lec_conv_f32_dgrad(const float* dy, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,

@@ -828,6 +828,23 @@ def conv_f32_fwd(x, w, stride, pad, want_stats=False):
     return y
 
 
+def conv_f32_fwd_affine(x, w, stride, pad, scale, shift, residual=None, relu=False):
+    """lec_conv_f32_fwd_affine: y = [relu](conv2d(x, w) * scale[c] + shift[c] [+ residual]) -- an eval-mode BatchNorm (+ the block's
+    residual add and ReLU) in the convolution's epilogue.  x, w, residual channels_last fp32; scale / shift fp32 [Cout]."""
+    _nhwc_f32(x, 'x'); _nhwc_f32(w, 'w')
+    n, cin, h, wd = x.shape; cout, _, r, s_ = w.shape
+    ho, wo = (h + 2 * pad - r) // stride + 1, (wd + 2 * pad - s_) // stride + 1
+    if scale.numel() != cout or shift.numel() != cout or scale.dtype != torch.float32 or shift.dtype != torch.float32:
+        raise ValueError('conv_f32_fwd_affine: scale / shift must be fp32 vectors of Cout entries')
+    if residual is not None and tuple(_nhwc_f32(residual, 'residual').shape) != (n, cout, ho, wo):
+        raise ValueError('conv_f32_fwd_affine: residual must have the output\'s shape')
+    y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    _conv_scratch()
+    _conv_timed(lambda: check(lib.lec_conv_f32_fwd_affine(dptr(x), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), dptr(scale), dptr(shift),
+                                                          dptr(residual), 1 if relu else 0, stream_ptr())), 2.0 * n * ho * wo * cout * cin * r * s_)
+    return y
+
+
 def conv_f32_dgrad(dy, w, x_shape, stride, pad):
     """dx of the same convolution (lec_conv_f32_dgrad): dy [N, Cout, Ho, Wo], w the FORWARD weight, x_shape = (N, Cin, H, W)."""
     _nhwc_f32(dy, 'dy'); _nhwc_f32(w, 'w')

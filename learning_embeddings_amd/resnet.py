@@ -25,6 +25,19 @@ class BatchNormAct2d(nn.BatchNorm2d):
         super().__init__(num_features)
         self.fuse_relu = relu
 
+    def eval_affine(self):
+        """(scale, shift) of the eval-mode map y = x * scale + shift: gamma / sqrt(running_var + eps), beta - running_mean * scale -- the
+        arithmetic of bn_eval_coeff_kernel (division by the square root, not a reciprocal square root), cached until a parameter or a
+        running statistic changes (tensor version counters)."""
+        key = (self.weight._version, self.bias._version, self.running_mean._version, self.running_var._version, self.weight.data_ptr(), self.weight.device)
+        c = getattr(self, '_affine_cache', None)
+        if c is None or c[0] != key:
+            with torch.no_grad():
+                scale = (self.weight.float() / torch.sqrt(self.running_var.float() + self.eps)).contiguous()
+                shift = (self.bias.float() - self.running_mean.float() * scale).contiguous()
+            c = self._affine_cache = (key, scale, shift)
+        return c[1], c[2]
+
     def forward(self, x, residual=None, fork=False):
         """fork=True: return TWO handles (y, y_alias) on the output, one per consuming branch of the next block (its conv
         path and its identity / downsample path): the fused backward then adds the two branch gradients on the fly."""
@@ -258,6 +271,29 @@ def _from_rows(m, n, h, w):
     return m.view(n, h, w, m.shape[1]).permute(0, 3, 1, 2)
 
 
+def _inference_f32(conv, x):
+    """An fp32 channels_last CUDA forward that nobody will differentiate, of a layer lec_conv_f32_* serve."""
+    return (MFMA_F32 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.weight.dtype == torch.float32
+            and not (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad))
+            and x.is_contiguous(memory_format=torch.channels_last) and _f32_conv_ok(conv) and _f32_conv_fits(conv, x))
+
+
+def conv_bn(conv, bn, x, residual=None, fork=False):
+    """bn(conv(x) [, residual]) -- in an eval-mode fp32 inference forward as ONE kernel: the BatchNorm is a per-channel affine map of its
+    running statistics and runs, with the residual add and the ReLU, in the convolution's epilogue (lec_conv_f32_fwd_affine)."""
+    if (not bn.training and BatchNormAct2d.fused_enabled and isinstance(conv, Conv2d) and _inference_f32(conv, x)
+            and (residual is None or (residual.dtype == x.dtype and residual.is_contiguous(memory_format=torch.channels_last)))):
+        scale, shift = bn.eval_affine()
+        w = conv.weight if conv.weight.is_contiguous(memory_format=torch.channels_last) else conv.weight.contiguous(memory_format=torch.channels_last)
+        if conv.in_channels == 3:
+            x, w = _pad_c4(x), _pad_c4(w)
+        y = _ops().conv_f32_fwd_affine(x, w, conv.stride[0], conv.padding[0], scale, shift, residual, bn.fuse_relu)
+        return (y, y) if fork else y
+    if residual is None and not fork:
+        return bn(conv(x))
+    return bn(conv(x), residual, fork)
+
+
 class _OverlapConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, conv):
@@ -418,6 +454,13 @@ class Conv2d(nn.Conv2d):
         if (ov is not None and ov.enabled and x.is_cuda and self.training and self.bias is None
                 and x.dtype in (torch.bfloat16, torch.float16, torch.float32) and self.weight.requires_grad):
             return _OverlapConvFn.apply(x, self.weight, self)
+        if _inference_f32(self, x):
+            # no gradient will be asked for (the evaluation phases embed images under torch.no_grad()): liblecone's fp32 kernel directly, with
+            # the statistics of a train-mode BatchNorm behind it in its epilogue (the reference embeds 'train'-phase images in train mode)
+            w = self.weight if self.weight.is_contiguous(memory_format=torch.channels_last) else self.weight.contiguous(memory_format=torch.channels_last)
+            if self.in_channels == 3:
+                x, w = _pad_c4(x), _pad_c4(w)
+            return _ops().conv_f32_fwd(x, w, self.stride[0], self.padding[0], want_stats=self.training)
         return super().forward(x)
 
 
@@ -444,6 +487,13 @@ def conv1x1(cin, cout, stride=1):
     return Conv2d(cin, cout, kernel_size=1, stride=stride, bias=False)
 
 
+def _downsample(seq, x):
+    """A block's downsample branch (conv1x1 + BatchNorm as nn.Sequential, torchvision's state-dict keys) through conv_bn."""
+    if isinstance(seq, nn.Sequential) and len(seq) == 2 and isinstance(seq[1], BatchNormAct2d):
+        return conv_bn(seq[0], seq[1], x)
+    return seq(x)
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -456,9 +506,9 @@ class BasicBlock(nn.Module):
 
     def forward(self, x, fork=False):
         xa, xb = x if isinstance(x, tuple) else (x, x)          # two handles on the block input: conv path / identity path
-        idt = xb if self.downsample is None else self.downsample(xb)
-        out = self.bn1(self.conv1(xa))
-        return self.bn2(self.conv2(out), idt, fork)
+        idt = xb if self.downsample is None else _downsample(self.downsample, xb)
+        out = conv_bn(self.conv1, self.bn1, xa)
+        return conv_bn(self.conv2, self.bn2, out, idt, fork)
 
 
 class Bottleneck(nn.Module):
@@ -476,12 +526,12 @@ class Bottleneck(nn.Module):
 
     def forward(self, x, fork=False):
         xa, xb = x if isinstance(x, tuple) else (x, x)          # two handles on the block input: conv path / identity path
-        out = self.bn1(self.conv1(xa))
+        out = conv_bn(self.conv1, self.bn1, xa)
         # the downsample branch is built AFTER conv1 / bn1: autograd runs later-built nodes first, so in backward the branch's
         # gradient into the block input exists before conv1's data gradient runs and can be folded into it (FusionContext.forks)
-        idt = xb if self.downsample is None else self.downsample(xb)
-        out = self.bn2(self.conv2(out))
-        return self.bn3(self.conv3(out), idt, fork)
+        idt = xb if self.downsample is None else _downsample(self.downsample, xb)
+        out = conv_bn(self.conv2, self.bn2, out)
+        return conv_bn(self.conv3, self.bn3, out, idt, fork)
 
 
 class ResNet(nn.Module):
@@ -551,7 +601,7 @@ class ResNet(nn.Module):
         return fc
 
     def _forward(self, x, pooled_only=False):
-        x = self.maxpool(self.bn1(self.conv1(x)))
+        x = self.maxpool(conv_bn(self.conv1, self.bn1, x))
         blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
         for i, b in enumerate(blocks):
             x = b(x, fork=i + 1 < len(blocks))                  # every block output but the last feeds two branches

@@ -169,6 +169,7 @@ def test_split_mode_cone_energies_within_the_north_star_tolerance(monkeypatch):
     out = {}
     for tag in ('native', 'x3', 'stock'):
         monkeypatch.setattr(R, 'F32_MODE', 'x3' if tag == 'x3' else 'native')
+        monkeypatch.setattr(R, 'MFMA_F32', tag != 'stock')          # (off: also the no-grad inference branch of Conv2d.forward takes the library)
         WgradOverlap.instance = WgradOverlap() if tag != 'stock' else None
         try:
             with torch.no_grad():
@@ -446,6 +447,88 @@ def test_conv_f32_dgrad_with_batchnorm_backward_pass1_in_the_epilogue(N, C, H, W
     s_ref = gd.sum(dim=(0, 2, 3)); q_ref = (gd * xh).sum(dim=(0, 2, 3))
     scale = gd.abs().sum(dim=(0, 2, 3)).max().item()
     assert (part[0] - s_ref).abs().max().item() <= 1e-5 * scale and (part[1] - q_ref).abs().max().item() <= 1e-5 * (gd * xh).abs().sum(dim=(0, 2, 3)).max().item()
+    ops.fusion().reset()
+
+
+# ------------------------------------------------------------------------------------------------ round 3: inference forward (evaluation phases)
+AFF_CASES = [  # N, Cin, H, W, Cout, R, stride, pad, residual, relu
+    (2, 64, 12, 12, 256, 1, 1, 0, True, True), (3, 256, 9, 7, 64, 1, 1, 0, False, True), (2, 128, 12, 12, 128, 3, 2, 1, False, True),
+    (2, 4, 32, 32, 64, 7, 2, 3, False, True), (2, 256, 8, 8, 512, 1, 2, 0, False, False), (1, 512, 7, 7, 512, 3, 1, 1, False, True),
+    (40, 256, 14, 14, 1024, 1, 1, 0, True, True), (24, 256, 14, 14, 256, 3, 1, 1, False, True), (5, 64, 9, 9, 64, 3, 1, 1, True, True),
+]
+
+
+@pytest.mark.parametrize('N,Cin,H,W,Cout,R,stride,pad,res,relu', AFF_CASES)
+def test_conv_f32_fwd_affine_equals_convolution_then_eval_mode_batchnorm(N, Cin, H, W, Cout, R, stride, pad, res, relu):
+    """lec_conv_f32_fwd_affine: F.batch_norm(training=False) (+ residual add, + ReLU) in the convolution's epilogue.  Bit-equal to the two-kernel
+    form (lec_conv_f32_fwd, then the fused BatchNorm layer in eval mode: same multiply, add, add, max) with the tile walk and with the balanced
+    kernel, and equal to float64 F.conv2d + F.batch_norm to fp32 noise."""
+    g = torch.Generator(device='cpu').manual_seed(N + Cin + Cout)
+    x = _cl(torch.randn(N, Cin, H, W, generator=g)); w = _cl(torch.randn(Cout, Cin, R, R, generator=g) / (Cin * R * R) ** 0.5)
+    bn = BatchNormAct2d(Cout, relu=relu).to(DEV).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(Cout, generator=g) + 0.5); bn.bias.copy_(torch.randn(Cout, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(Cout, generator=g) * 0.2); bn.running_var.copy_(torch.rand(Cout, generator=g) + 0.3)
+    Ho = (H + 2 * pad - R) // stride + 1; Wo = (W + 2 * pad - R) // stride + 1
+    r = _cl(torch.randn(N, Cout, Ho, Wo, generator=g)) if res else None
+    scale, shift = bn.eval_affine()
+    with torch.no_grad():
+        for mode in (0, 2):
+            with _Balanced(mode):
+                y0 = ops.conv_f32_fwd(x, w, stride, pad)
+                want = bn(y0, r) if res else bn(y0)
+                got = ops.conv_f32_fwd_affine(x, w, stride, pad, scale, shift, r, relu)
+            assert torch.equal(got, want), 'mode %d' % mode
+        ref = F.batch_norm(F.conv2d(x.double(), w.double(), None, stride, pad), bn.running_mean.double(), bn.running_var.double(),
+                           bn.weight.double(), bn.bias.double(), False, 0.1, bn.eps)
+        if res:
+            ref = ref + r.double()
+        if relu:
+            ref = ref.relu()
+    assert (got.double() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
+    # the cache follows the parameters
+    with torch.no_grad():
+        bn.running_var.mul_(2.0)
+    s2, _ = bn.eval_affine()
+    assert not torch.equal(s2, scale)
+
+
+@pytest.mark.parametrize('arch,n,hw', [('resnet18', 6, 64), ('resnet50', 10, 96)])
+def test_inference_forward_runs_liblecone_kernels_and_matches_stock_torch(arch, n, hw, monkeypatch):
+    """An fp32 forward nobody differentiates (torch.no_grad(): the evaluation phases' image embedding, oe_h.py:1989-2011) takes liblecone's
+    kernels: in eval mode every convolution + BatchNorm (+ add) (+ ReLU) is ONE launch (lec_conv_f32_fwd_affine), in train mode (the reference
+    embeds the 'train' phase's images with batch statistics) the convolutions leave the statistics to the fused BatchNorm.  Against stock
+    torch fp32 (MIOpen convolutions, F.batch_norm) on the same weights: to fp32 noise, running statistics updated alike."""
+    from learning_embeddings_amd import resnet as R
+    import copy
+    torch.manual_seed(0)
+    net = (resnet18 if arch == 'resnet18' else R.resnet50)(num_classes=10).to(DEV).to(memory_format=torch.channels_last)
+    with torch.no_grad():                                      # running statistics / affine parameters away from their init values
+        for m in net.modules():
+            if isinstance(m, BatchNormAct2d):
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.1)
+    x = _cl(torch.rand(n, 3, hw, hw))
+    calls = {'affine': 0, 'fwd': 0}
+    fa, ff = ops.conv_f32_fwd_affine, ops.conv_f32_fwd
+    monkeypatch.setattr(ops, 'conv_f32_fwd_affine', lambda *a, **k: (calls.__setitem__('affine', calls['affine'] + 1), fa(*a, **k))[1])
+    monkeypatch.setattr(ops, 'conv_f32_fwd', lambda *a, **k: (calls.__setitem__('fwd', calls['fwd'] + 1), ff(*a, **k))[1])
+    n_conv = sum(isinstance(m, torch.nn.Conv2d) for m in net.modules())
+    for train in (False, True):
+        ref_net = copy.deepcopy(net); net.train(train); ref_net.train(train)
+        calls['affine'] = calls['fwd'] = 0
+        with torch.no_grad():
+            y = net(x)
+            monkeypatch.setattr(R, 'MFMA_F32', False); BatchNormAct2d.fused_enabled = False
+            try:
+                y_ref = ref_net(x)
+            finally:
+                monkeypatch.setattr(R, 'MFMA_F32', True); BatchNormAct2d.fused_enabled = True
+        assert (calls['fwd'], calls['affine']) == ((n_conv, 0) if train else (0, n_conv)), calls
+        assert (y - y_ref).abs().max().item() <= 2e-4 * (1 + y_ref.abs().max().item())
+        if train:
+            for (k, a), (_, b) in zip(net.named_buffers(), ref_net.named_buffers()):
+                if a.dtype.is_floating_point:
+                    assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), k
     ops.fusion().reset()
 
 

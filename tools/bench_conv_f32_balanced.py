@@ -9,7 +9,7 @@ import torch
 from learning_embeddings_amd import ops
 
 ap = argparse.ArgumentParser(); ap.add_argument('--rows', type=int, default=256); ap.add_argument('--iters', type=int, default=10)
-ap.add_argument('--json', default=None)
+ap.add_argument('--json', default=None); ap.add_argument('--net', action='store_true', help='only the end-to-end ResNet-50 forward (the evaluation phase embeds images on ONE stream)')
 a = ap.parse_args()
 SHAPES = [('l1.c1a', 64, 56, 64, 1, 1, 0), ('l1.c2', 64, 56, 64, 3, 1, 1), ('l1.c3', 64, 56, 256, 1, 1, 0), ('l1.c1', 256, 56, 64, 1, 1, 0),
           ('l2.c1a', 256, 56, 128, 1, 1, 0), ('l2.c2s', 128, 56, 128, 3, 2, 1), ('l2.c3', 128, 28, 512, 1, 1, 0), ('l2.ds', 256, 56, 512, 1, 2, 0),
@@ -33,6 +33,36 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+
+
+def net_forward():
+    """ResNet-50 -> D = 10, fp32, no_grad, one stream: images / s of the embedding forward with the tile walk and with the launcher's choice."""
+    from learning_embeddings_amd.oe_h import FeatCNN
+    torch.manual_seed(0)
+    net = FeatCNN(None, output_dim=10, K=0.1).cuda()
+    out = {}
+    for rows, train in ((250, False), (256, True), (512, True)):          # eval-mode batches of 250 (reference_exact_eval=False); train-mode statistics
+        net.train(train)
+        x = torch.rand(rows, 3, 224, 224, device='cuda')
+        with torch.no_grad():
+            timeit(lambda: net(x), 3)
+            tm = {0: [], 1: []}
+            for rep in range(3):
+                for mode in (0, 1):
+                    prev = ops.lib.lec_conv_f32_balanced(mode)
+                    tm[mode].append(timeit(lambda: net(x), 5))
+                    ops.lib.lec_conv_f32_balanced(prev)
+        a0, a1 = sorted(tm[0])[1], sorted(tm[1])[1]
+        out['rows_%d_%s' % (rows, 'train' if train else 'eval')] = {'tile_walk_ms': round(a0 / 1e3, 2), 'balanced_ms': round(a1 / 1e3, 2),
+                                                                   'images_per_s_tile_walk': round(rows / a0 * 1e6), 'images_per_s_balanced': round(rows / a1 * 1e6)}
+    return out
+
+
+if a.net:
+    r = net_forward(); print(json.dumps(r))
+    if a.json:
+        json.dump(r, open(a.json, 'w'), indent=1)
+    sys.exit(0)
 res = []; tot = {}
 for name, cin, hw, cout, r, st, pad in SHAPES:
     N = a.rows
