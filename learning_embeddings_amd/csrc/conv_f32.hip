@@ -1065,11 +1065,17 @@ static int launch_act(const float* src, const float* wgt, float* dst, const ActG
     SkScratch sc;
     if (mode != 0 && !narrow && g.dst_st == 1 && g.Cs % kCfBK == 0 && g.na * g.nb <= 32 && nchunks > 0 && tiles <= kSkMaxTiles &&
         (!(STATS || (FUSE & 2)) || mtiles <= part_rows) && sk_lookup(st, &sc)) {
+      // workgroups: the chip's 512 slots, fewer when that would leave a workgroup under LEC_CF_SK_MIN_CHUNKS (8) chunks of work (small batches: the
+      // reference's 10-image evaluation chunks give layer3 / layer4 16 - 128 tiles of 32 - 144 chunks each; cut along K they occupy the chip)
       const long long iters = tiles * nchunks;
-      const int G = (int)(iters < kSkWgs ? iters : kSkWgs);
+      long long gmax = mode == 2 ? iters : iters / sk_min_chunks();
+      if (gmax < 1) gmax = 1;
+      const int G = (int)(gmax < kSkWgs ? gmax : kSkWgs);
       const double rounds = (double)tiles / kSkWgs;
       const double fill = rounds / (double)((tiles + kSkWgs - 1) / kSkWgs);
-      if (mode == 2 || (fill < sk_fill() && iters / G >= sk_min_chunks())) {
+      // ... taken where the tile walk's last round is poorly filled AND the cut gives more parallel work than whole tiles would (tiles < 512), or
+      // the same 512 workgroups an even share (tiles > 512)
+      if (mode == 2 || (fill < sk_fill() && (tiles >= kSkWgs ? G == kSkWgs : (long long)G * 4 >= tiles * 5))) {
         const size_t lds = (size_t)2 * (BM * kCfLdk + (B_KC ? BN * kCfLdk : kCfBK * BN)) * 4;
         SkArgs sk{sc.slots, sc.counters, ntiles, (int)tiles};
         ActGeo gg = g; gg.xcd_per = 0;

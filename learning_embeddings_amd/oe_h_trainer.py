@@ -823,8 +823,60 @@ class JointEmbeddings:
             if hi <= i:
                 continue
             stack = torch.stack([ds.get_image(nm) for nm in names[i:hi]]).to(self.device)
-            out[i:hi] = self.img_feat_net(stack).float()
+            out[i:hi] = self._embed_forward(stack, full=(hi - i == bs))
         return out
+
+    # The embedding forward of a full chunk is replayed as a hipGraph from its third occurrence on (eval_graphs = False: always eager).  Why: the
+    # reference's own chunk size in the 'train' phase is 10 images (oe_h.py:1972), a forward of ~270 launches whose kernels take ~1 ms and whose
+    # Python / ctypes enqueue takes 4.7 -- launch-bound; replayed, the same kernels run back to back.  Same kernels, same order, same results: in
+    # train mode a replay updates the BatchNorm running statistics exactly as the eager forward (and the reference's) does.  The graph holds raw
+    # pointers to the parameters: load_model / optimizer steps write in place and are seen (an eval-mode graph also holds the BatchNorm layers'
+    # cached scale / shift vectors, which BatchNormAct2d.eval_affine refreshes in place: checked before every replay); `drop_eval_graphs()` after
+    # anything that re-allocates parameters.
+    eval_graphs = True
+
+    def drop_eval_graphs(self):
+        self._eval_graphs = {}
+
+    def _embed_forward(self, stack, full):
+        net = self.img_feat_net
+        if not (self.eval_graphs and full and stack.is_cuda and stack.dim() == 4 and getattr(net, 'compute_dtype', None) == torch.float32
+                and not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()):
+            return net(stack).float()
+        cache = self.__dict__.setdefault('_eval_graphs', {})
+        key = (tuple(stack.shape), bool(net.training))
+        ent = cache.get(key)
+        if ent is None:
+            ent = cache[key] = {'seen': 0, 'graph': None, 'stream': torch.cuda.Stream(device=stack.device)}
+        if ent['graph'] is None:
+            ent['seen'] += 1
+            cur = torch.cuda.current_stream()
+            if ent['seen'] <= 2:
+                # eager, on the stream the graph will be captured on (its convolution scratch gets registered: ops._conv_scratch)
+                ent['stream'].wait_stream(cur)
+                with torch.cuda.stream(ent['stream']):
+                    y = net(stack).float()
+                stack.record_stream(ent['stream']); y.record_stream(cur)
+                cur.wait_stream(ent['stream'])
+                return y
+            try:
+                ent['in'] = torch.empty_like(stack, memory_format=torch.channels_last)
+                ent['in'].copy_(stack)
+                torch.cuda.synchronize(stack.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=ent['stream']):
+                    ent['out'] = net(ent['in']).float()
+                ent['graph'] = g
+            except Exception as e:                              # a capture that fails costs nothing but the replay: say so and stay eager
+                print('embed_images: graph capture failed (%s: %s); eager launches from here on' % (type(e).__name__, e))
+                self.eval_graphs = False
+                return net(stack).float()
+        if not net.training:
+            for bn in ent.setdefault('bns', [m for m in net.modules() if hasattr(m, 'eval_affine')]):
+                bn.eval_affine()                                # running statistics moved since the capture (a training epoch in between): refresh in place
+        ent['in'].copy_(stack)
+        ent['graph'].replay()
+        return ent['out'].clone()
 
     @torch.no_grad()
     def calculate_classification_metrics(self, phase, k=[1, 3, 5], reference_exact=None):

@@ -35,6 +35,9 @@ class BatchNormAct2d(nn.BatchNorm2d):
             with torch.no_grad():
                 scale = (self.weight.float() / torch.sqrt(self.running_var.float() + self.eps)).contiguous()
                 shift = (self.bias.float() - self.running_mean.float() * scale).contiguous()
+                if c is not None and c[0][4:] == key[4:]:
+                    # same parameter storage, new values: refresh IN PLACE -- a captured inference graph holds these two pointers
+                    c[1].copy_(scale); c[2].copy_(shift); scale, shift = c[1], c[2]
             c = self._affine_cache = (key, scale, shift)
         return c[1], c[2]
 

@@ -290,11 +290,16 @@ def test_conv_f32x3_exact_on_integers_and_fp32_grade_vs_float64(N, Cin, H, W, Co
         else:
             err = lambda t, ref: (t.double() - ref).abs().max().item() / ref.abs().max().item()
             cb = torch.ops.aten.convolution_backward
-            y1 = ops.conv_f32_fwd(x, w, stride, pad); yl = F.conv2d(x, w, None, stride, pad)
+            # (yardstick: the exact kernels' error with the SAME summation structure -- whole-K chains, i.e. the tile walk; cut along K the exact
+            # kernels sum shorter chains and err 2 - 3 x less on these small launches)
+            with _Balanced(0):
+                y1 = ops.conv_f32_fwd(x, w, stride, pad)
+            yl = F.conv2d(x, w, None, stride, pad)
             e3, e1, el = err(y, yr.detach()), err(y1, yr.detach()), err(yl, yr.detach())
             assert e3 <= 2.0 * max(e1, el) + 1e-7 and e3 < 5e-6, ('forward', e3, e1, el)
             if dx is not None:
-                d1 = ops.conv_f32_dgrad(dy, w, x.shape, stride, pad)
+                with _Balanced(0):
+                    d1 = ops.conv_f32_dgrad(dy, w, x.shape, stride, pad)
                 dl = cb(dy, x, w, None, [stride] * 2, [pad] * 2, [1, 1], False, [0, 0], 1, [True, False, False])[0]
                 e3, e1, el = err(dx, xr.grad), err(d1, xr.grad), err(dl, xr.grad)
                 assert e3 <= 2.0 * max(e1, el) + 1e-7 and e3 < 5e-6, ('data gradient', e3, e1, el)
@@ -486,11 +491,13 @@ def test_conv_f32_fwd_affine_equals_convolution_then_eval_mode_batchnorm(N, Cin,
         if relu:
             ref = ref.relu()
     assert (got.double() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
-    # the cache follows the parameters
+    # the cache follows the parameters, IN PLACE (a captured inference graph holds the two pointers)
+    before = scale.clone()
     with torch.no_grad():
         bn.running_var.mul_(2.0)
     s2, _ = bn.eval_affine()
-    assert not torch.equal(s2, scale)
+    assert s2.data_ptr() == scale.data_ptr() and not torch.equal(s2, before)
+    assert torch.equal(s2, bn.weight / torch.sqrt(bn.running_var + bn.eps))
 
 
 @pytest.mark.parametrize('arch,n,hw', [('resnet18', 6, 64), ('resnet50', 10, 96)])
@@ -589,6 +596,28 @@ def test_conv_f32_balanced_kernel_equals_float64_on_integers_and_is_run_to_run_i
             with _Balanced(0):
                 y0 = ops.conv_f32_fwd(x, w, 1, pad); dx0 = ops.conv_f32_dgrad(dy, w, x.shape, 1, pad)
             assert (y - y0).abs().max().item() <= 4e-6 * yr.abs().max().item() and (dx - dx0).abs().max().item() <= 4e-6 * dxr.abs().max().item()
+    ops.fusion().reset()
+
+
+@pytest.mark.parametrize('N,Cin,H,W,Cout,R,pad,wgs', [(10, 256, 14, 14, 256, 3, 1, 288), (10, 1024, 14, 14, 256, 1, 0, 128), (10, 512, 7, 7, 512, 3, 1, 288),
+                                                        (10, 256, 14, 14, 1024, 1, 0, 0), (256, 256, 14, 14, 256, 3, 1, 512)])
+def test_conv_f32_launcher_cuts_small_batches_along_k(N, Cin, H, W, Cout, R, pad, wgs):
+    """The launcher's own choice (lec_conv_f32_balanced(1)): a 10-image batch (the reference's evaluation chunk) gives layer3 / layer4 a few dozen
+    tiles -- the balanced kernel cuts them along K into `wgs` workgroups of >= 8 chunks (0: the cut would not add parallel work, the tile walk runs).
+    Which kernel ran shows in the number of statistics rows (one per m-tile when balanced); results exact on integers either way."""
+    g = torch.Generator(device='cpu').manual_seed(N + Cin + Cout + R)
+    x = _cl(torch.randint(-3, 4, (N, Cin, H, W), generator=g).float()); w = _cl(torch.randint(-2, 3, (Cout, Cin, R, R), generator=g).float())
+    yr = F.conv2d(x.double(), w.double(), None, 1, pad)
+    with _Balanced(1):
+        ops.fusion().reset()
+        y = ops.conv_f32_fwd(x, w, 1, pad, want_stats=True)
+        k = ops.fusion().ws_owner[1]
+        part = ops._bn_workspace(x.device).view(torch.float32)[:k * 2 * Cout].view(k, 2, Cout).double().sum(0)
+    mtiles = (N * H * W + 127) // 128
+    tiles = mtiles * (Cout // 128); nchunks = Cin * R * R // 32
+    assert (min(512, tiles * nchunks // 8) if wgs else 0) == wgs            # the launcher's arithmetic, restated
+    assert k == (mtiles if wgs else min(mtiles, 512))
+    assert torch.equal(y.double(), yr) and torch.equal(part[0], yr.sum(dim=(0, 2, 3))) and torch.equal(part[1], (yr ** 2).sum(dim=(0, 2, 3)))
     ops.fusion().reset()
 
 

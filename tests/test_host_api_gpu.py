@@ -258,6 +258,67 @@ def test_joint_embeddings_trainer_runs_and_learns(tmp_path):
     assert list(sd) == ['module.embeddings.weight']                          # the reference's DataParallel key prefix
 
 
+def test_embed_images_replayed_forward_equals_eager_forward(tmp_path):
+    """JointEmbeddings.embed_images replays the forward of a full chunk as a hipGraph from its third occurrence on (the reference's 'train'-phase
+    chunks are 10 images: launch-bound).  Against eval_graphs = False on a copy of the same networks: eval mode -- rows bit-equal, also after the
+    weights and running statistics have moved (the captured graph holds the BatchNorm layers' scale / shift vectors, refreshed in place);
+    train mode -- rows bit-equal chunk by chunk and the running statistics after all chunks equal (every replay updates them like a forward)."""
+    import copy
+    from test_host_cpu import _fake_loaders
+    lm = SyntheticLabelMap([2, 4, 8])
+    dl = _fake_loaders(lm, 48, 8)
+    for split in dl.values():
+        for b in split:
+            b['path_to_image'] = [torch.rand(3, 32, 32, generator=torch.Generator().manual_seed(int(n[4:]))) for n in b['image_filename']]
+    gd = oe_h.create_combined_graphs(dl, lm, pick_per_level=True)
+    crit = oe_h.EuclideanConesWithImagesHypernymLoss(lm, 5, {}, 0.05, True, K=0.1, use_CNN=True)
+    tr = oe_h.JointEmbeddings(gd, dl, image_dir='', use_CNN=True, labelmap=lm, criterion=crit, lr=1e-3, n_workers=0,
+                              batch_size=16, experiment_name='t', embedding_dim=10, neg_to_pos_ratio=5, image_fc7=None,
+                              normalize=None, alpha=0.05, experiment_dir=str(tmp_path), n_epochs=1, eval_interval=1)
+    crit.set_dataloader(tr.datasets['train'])
+    names = [n for n in gd['G_train'] if type(n) == str]
+    assert len(names) >= 44
+    names = names[:44]                                                       # 5 full chunks of 8 (two eager, capture + replay, two replays) and one of 4 (eager)
+    with torch.no_grad():
+        for m in tr.img_feat_net.modules():
+            if hasattr(m, 'eval_affine'):
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+    for train in (False, True):
+        tr.img_feat_net.train(train)
+        ref_net = copy.deepcopy(tr.img_feat_net)
+        tr.drop_eval_graphs()
+        with torch.no_grad():
+            got = tr.embed_images(names, bs=8)
+            assert tr._eval_graphs[((8, 3, 32, 32), train)]['graph'] is not None
+            live, tr.img_feat_net, tr.eval_graphs = tr.img_feat_net, ref_net, False
+            try:
+                want = tr.embed_images(names, bs=8)
+            finally:
+                tr.img_feat_net, tr.eval_graphs = live, True
+        assert torch.equal(got, want), 'train=%s' % train
+        for (k, a), (_, b) in zip(live.named_buffers(), ref_net.named_buffers()):
+            assert torch.equal(a, b), k
+        if not train:
+            # parameters and running statistics move (a training epoch between two evaluation phases): the SAME graph must follow
+            with torch.no_grad():
+                for net in (live, ref_net):
+                    g = torch.Generator(device='cpu').manual_seed(5)
+                    for m in net.modules():
+                        if hasattr(m, 'eval_affine'):
+                            m.running_var.mul_(1.5); m.running_mean.add_(0.05); m.weight.mul_(0.9)
+                    for prm in net.parameters():
+                        prm.add_(torch.randn(prm.shape, generator=g).to(prm.device) * 1e-3)
+                gid = id(tr._eval_graphs[((8, 3, 32, 32), False)]['graph'])
+                got2 = tr.embed_images(names, bs=8)
+                assert id(tr._eval_graphs[((8, 3, 32, 32), False)]['graph']) == gid
+                tr.img_feat_net, tr.eval_graphs = ref_net, False
+                try:
+                    want2 = tr.embed_images(names, bs=8)
+                finally:
+                    tr.img_feat_net, tr.eval_graphs = live, True
+            assert torch.equal(got2, want2) and not torch.equal(got2, got)
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_joint_embeddings_fast_path_matches_plain_autograd(tmp_path, dtype):
     """JointEmbeddings.train_step through liblecone's convolutions / fused BatchNorm / arena gradients / side stream (the path

@@ -41,7 +41,7 @@ def net_forward():
     torch.manual_seed(0)
     net = FeatCNN(None, output_dim=10, K=0.1).cuda()
     out = {}
-    for rows, train in ((250, False), (256, True), (512, True)):          # eval-mode batches of 250 (reference_exact_eval=False); train-mode statistics
+    for rows, train in ((250, False), (10, True), (256, True), (512, True)):      # (10, train): the reference's own chunks of the 'train' phase (oe_h.py:1972)          # eval-mode batches of 250 (reference_exact_eval=False); train-mode statistics
         net.train(train)
         x = torch.rand(rows, 3, 224, 224, device='cuda')
         with torch.no_grad():
@@ -53,8 +53,20 @@ def net_forward():
                     tm[mode].append(timeit(lambda: net(x), 5))
                     ops.lib.lec_conv_f32_balanced(prev)
         a0, a1 = sorted(tm[0])[1], sorted(tm[1])[1]
+        # the same forward replayed as a hipGraph (JointEmbeddings.embed_images does this from a chunk shape's third occurrence on)
+        st = torch.cuda.Stream()
+        with torch.no_grad():
+            with torch.cuda.stream(st):
+                net(x); net(x)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                y = net(x)
+            gr = timeit(lambda: g.replay(), 10)
+            del g, y
         out['rows_%d_%s' % (rows, 'train' if train else 'eval')] = {'tile_walk_ms': round(a0 / 1e3, 2), 'balanced_ms': round(a1 / 1e3, 2),
-                                                                   'images_per_s_tile_walk': round(rows / a0 * 1e6), 'images_per_s_balanced': round(rows / a1 * 1e6)}
+                                                                   'images_per_s_tile_walk': round(rows / a0 * 1e6), 'images_per_s_balanced': round(rows / a1 * 1e6),
+                                                                   'replayed_ms': round(gr / 1e3, 2), 'images_per_s_replayed': round(rows / gr * 1e6)}
     return out
 
 
