@@ -471,7 +471,8 @@ def measure_trainer(args, dtype, stamp, n_steps, n_warm):
             out.append({'level_labels': np.asarray([chain(j) for j in js]), 'image_filename': ['img_%06d' % j for j in js],
                         'path_to_image': [pool[j % P] for j in js]})
         return out
-    dl = {'train': loader(0, M), 'val': loader(M, M + 8), 'test': loader(M + 8, M + 16)}
+    MV = 1000                                                   # evaluation split: every leaf occurs (the metric code wants each label present)
+    dl = {'train': loader(0, M), 'val': loader(M, M + MV), 'test': loader(M + MV, M + MV + 16)}
     gd = oe_h.create_combined_graphs(dl, lm, pick_per_level=True)
     li = DiGraph()                                               # the (label, image) positives only: every batch entry brings an image
     for u, v in gd['G_train_tc'].edges():
@@ -498,8 +499,25 @@ def measure_trainer(args, dtype, stamp, n_steps, n_warm):
         rows += crit.last_cnn_rows                                # distinct images of the batch: positives' images + image negatives not among them
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the evaluation phase (calculate_classification_metrics, oe_h.py:1971-2178) on the same trainer: image embedding + all-pairs
+    # scoring + per-level top-k + the metric arithmetic, reference-exact mode.  'val': eval-mode networks, 250 images per forward (BatchNorm in
+    # the convolution epilogue); 'train': the reference calls it with the networks in TRAIN mode, 10 images per forward (replayed as a hipGraph).
+    ev = {}
+    if dtype == 'fp32':
+        try:
+            for phase, train_mode in (('val', False), ('train', True)):
+                tr.model.train(train_mode); tr.img_feat_net.train(train_mode)
+                n_img = sum(len(b['image_filename']) for b in dl[phase])
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                m = tr.calculate_classification_metrics(phase)
+                torch.cuda.synchronize(); d1 = time.perf_counter() - t1
+                ev[phase] = {'images': n_img, 'seconds': round(d1, 3), 'images_per_s': round(n_img / d1, 1), 'm-f1': round(float(m['m-f1']), 4),
+                             'networks_in': 'train mode, 10 images per forward' if train_mode else 'eval mode, 250 images per forward'}
+        except Exception as e:                                   # the headline does not depend on it
+            ev['error'] = '%s: %s' % (type(e).__name__, e)
+        tr.model.train(); tr.img_feat_net.train()
     return {'value': round(B * n_steps / dt, 2), 'unit': 'images/sec', 'ms_per_step': round(dt / n_steps * 1e3, 3), 'steps': n_steps, 'dtype': 'f32' if dtype == 'fp32' else dtype,
-            'cnn_rows_per_step': round(rows / n_steps, 1), 'launch_mode': 'eager',
+            'cnn_rows_per_step': round(rows / n_steps, 1), 'launch_mode': 'eager', 'evaluation_phase': ev,
             'api': 'JointEmbeddings.train_step over its own DataLoader / my_collate / criterion(...) (oe_h.py:1734-1774 mirror), images resident in HBM'}
 
 

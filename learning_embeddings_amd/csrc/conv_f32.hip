@@ -523,6 +523,15 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
 // them with sc1 loads only (CDNA4 guide 6 G16, form R1 -- an agent-scope release fence per slab writes back the XCD's whole L2 and cost 100 - 160 us
 // per launch on the 1x1 layers).  Scratch: 2 slots of BM x BN floats per workgroup + one counter per tile, registered per stream
 // (lec_conv_f32_scratch); counters are zero between launches (the finalizer re-arms its tile's counter).
+#ifndef LEC_SK_LOAD_AUX
+#define LEC_SK_LOAD_AUX 16
+#endif
+#ifndef LEC_SK_STORE_AUX
+#define LEC_SK_STORE_AUX 16
+#endif
+#ifndef LEC_SK_ACQ
+#define LEC_SK_ACQ 0
+#endif
 struct SkArgs { float* slots; unsigned int* counters; int ntn; int tiles; };
 
 template <bool B_KC, int TM, int TN, bool STATS, int FUSE>
@@ -652,7 +661,7 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_sk_kernel(const fl
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             f32x4v v; v[0] = acc[it][jt][4 * q]; v[1] = acc[it][jt][4 * q + 1]; v[2] = acc[it][jt][4 * q + 2]; v[3] = acc[it][jt][4 * q + 3];
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4r, v), rs_slots, (int)(mine + (unsigned)(((it * TN + jt) * 4 + q) * kCfThreads * 16)), 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4r, v), rs_slots, (int)(mine + (unsigned)(((it * TN + jt) * 4 + q) * kCfThreads * 16)), 0, LEC_SK_STORE_AUX);
           }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -665,6 +674,10 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_sk_kernel(const fl
       __syncthreads();
       finalize = s_last != 0;
       if (finalize) {
+#if LEC_SK_ACQ
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         // the last arriver: every slab of the tile is in memory; EVERY load of them is an sc1 load (past this CU's L1, which no other CU's store
         // refreshes).  Fixed order: the sum does not depend on who finalizes.
 #pragma unroll
@@ -681,7 +694,7 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_sk_kernel(const fl
             for (int jt = 0; jt < TN; ++jt)
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                const f32x4v v = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_slots, (int)(sl + (unsigned)(((it * TN + jt) * 4 + q) * kCfThreads * 16)), 0, 16));
+                const f32x4v v = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_slots, (int)(sl + (unsigned)(((it * TN + jt) * 4 + q) * kCfThreads * 16)), 0, LEC_SK_LOAD_AUX));
                 acc[it][jt][4 * q] += v[0]; acc[it][jt][4 * q + 1] += v[1]; acc[it][jt][4 * q + 2] += v[2]; acc[it][jt][4 * q + 3] += v[3];
               }
         }

@@ -342,21 +342,31 @@ def test_joint_embeddings_fast_path_matches_plain_autograd(tmp_path, dtype):
         crit.set_dataloader(tr.datasets['train'])
         tr.train_set.transform = None                                        # no random flip: identical batches on both sides
         tr.model.train(); tr.img_feat_net.train()
+        signs = {}
+        from learning_embeddings_amd.resnet import BatchNormAct2d
+        for name, m in tr.img_feat_net.named_modules():
+            if isinstance(m, BatchNormAct2d) and m.fuse_relu:
+                m.register_forward_hook(lambda mod, inp, o, name=name: signs.__setitem__(name, ((o[0] if isinstance(o, tuple) else o).detach() > 0)))
         torch.manual_seed(1)
         it = iter(tr.dataloaders['train'])
         losses = [float(tr.train_step(next(it))[0])]
         torch.cuda.synchronize()
         # the image network is compared through its GRADIENT (what the two paths compute); Adam's first update is lr * sign(g),
         # which turns rounding noise on near-zero gradients into +-lr on the parameter
-        out[fast] = (losses, tr.model.embeddings.weight.detach().clone(), tr.arena.grad.clone())
+        out[fast] = (losses, tr.model.embeddings.weight.detach().clone(), tr.arena.grad.clone(), signs)
     tol = 2e-4 if dtype == torch.float32 else 5e-2
     for a, b in zip(out[True][0], out[False][0]):
         assert abs(a - b) <= tol * max(1.0, abs(b)), (out[True][0], out[False][0])
     assert (out[True][1] - out[False][1]).abs().max().item() <= (1e-5 if dtype == torch.float32 else 3e-3)
     d = (out[True][2] - out[False][2]).double().norm().item() / out[False][2].double().norm().item()
     # bf16: two different kernel sets on a random-init network differ by bf16 rounding noise amplified through 18 layers
-    # (test_resnet_fused_path_matches_unfused_paths measures cosine 0.93-0.94 between ANY two bf16 paths); fp32: tight
-    assert d < (1e-4 if dtype == torch.float32 else 0.5), d
+    # (test_resnet_fused_path_matches_unfused_paths measures cosine 0.93-0.94 between ANY two bf16 paths); fp32: tight -- unless the two
+    # forwards (1e-6 apart: different summation order) land on different sides of a ReLU somewhere: ONE activation of 3.6e-7 against 0.0 in
+    # layer2.1.bn1 moved this 22-image gradient by 5.5e-3 when the small convolutions began to be cut along K.  The derivative is discontinuous
+    # there, both gradients are right; the tight bound holds when every ReLU decision agrees.
+    flips = sum(int((out[True][3][k] != out[False][3][k]).sum().item()) for k in out[True][3])
+    assert flips <= 4, flips
+    assert d < ((1e-4 if flips == 0 else 3e-2) if dtype == torch.float32 else 0.5), (d, flips)
 
 
 # ------------------------------------------------------------------------------------------------ DP on one GPU (gloo)
