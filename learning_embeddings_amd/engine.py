@@ -365,6 +365,9 @@ class StepEngine:
         parts, order = [], {}
         live = self.reducer.live
         self.reducer.live = False                      # every parameter reports once per part: the buckets are reduced after the last part
+        # concurrent parts fill each other's last rounds of workgroup slots: the balanced (stream-K) convolution kernel buys nothing here (131.0 ms
+        # with the tile walk, 131.5 with it) and moves 32 GB more per step (slabs, operand re-reads: profiles/r03_conv_f32_balanced.md): tile walk
+        balanced = _lib.lib.lec_conv_f32_balanced(0)
         try:
             for p, st in enumerate(self.pass_streams):
                 st.wait_stream(cur)
@@ -400,6 +403,7 @@ class StepEngine:
             for st in self.pass_streams:
                 cur.wait_stream(st)
         finally:
+            _lib.lib.lec_conv_f32_balanced(balanced)
             self.reducer.live = live
             self.reducer.reset()
         if self.graph_reduces and torch.cuda.is_current_stream_capturing():

@@ -626,6 +626,7 @@ class JointEmbeddings:
             # atomics like the weight gradients, and the reducer's per-parameter hooks stay muted (every parameter reports once per
             # pass): the buckets are reduced once, below
             ops.lib.lec_bn_bwd_accumulate(1); self.reducer.live = False
+            balanced = ops.lib.lec_conv_f32_balanced(0)                     # concurrent passes fill each other's tails: tile walk (engine._core_passes)
         try:
             self.arena.zero_grad(); self.table_grad.zero_()
             loss, e_pos, e_neg = self.criterion(self.model, self.img_feat_net, data_item['from'], data_item['to'],
@@ -637,6 +638,7 @@ class JointEmbeddings:
             WgradOverlap.instance = prev
             if multi:
                 ops.lib.lec_bn_bwd_accumulate(0); self.reducer.live = live; self.reducer.reset()
+                ops.lib.lec_conv_f32_balanced(balanced)
         self.reducer.finish()
         self.apply_updates()
         if loss.is_cuda:
