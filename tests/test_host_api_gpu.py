@@ -1083,12 +1083,14 @@ def test_step_engine_concurrent_half_batch_passes_equal_the_same_passes_in_turn(
         images = b.pool.index_select(0, b.idx_dev)
         b.arena.zero_grad(); b.table_grad.zero_(); b.gfeat.zero_()
         from learning_embeddings_amd import _lib                    # (lec_bn_bwd_accumulate(1) is on, process-wide, since engine a exists)
+        prev = _lib.lib.lec_conv_f32_balanced(0)                    # the kernels engine a's passes run (a multi-pass step uses the tile walk): same summation order
         parts = [b.img_feat_net.forward_raw(images[p * h:(p + 1) * h]) for p in range(2)]
         feats = torch.cat([f.detach() for f in parts]); b.last_feats = feats
         out = ops.joint_loss_raw(b.table, feats, codes[:, 0].contiguous(), codes[:, 1].contiguous(), codes[:, 2:].contiguous(), None, b.K_cone, b.alpha,
                                  _lib.ENERGY_HYP_CONE, _lib.LABEL_HYP, _lib.IMAGE_SOFTCLIP, b.table_grad, b.gfeat)
         for p in range(2):
             parts[p].backward(b.gfeat[p * h:(p + 1) * h])
+        _lib.lib.lec_conv_f32_balanced(prev)
         return out
     b._core = core_in_turn
     for s_ in range(2):
