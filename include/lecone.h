@@ -382,6 +382,10 @@ int lec_conv_f32_dgrad(const float* dy, const float* w, int N, int H, int W, int
  *       + eps), shift = beta - running_mean * scale -- F.batch_norm(training=False) (+ the block's residual add and ReLU) in the convolution's
  *       epilogue, in the arithmetic of lec_bn_fwd_f32's apply pass (bit-equal to the two-kernel form); the raw convolution output is never
  *       written and inference runs without a BatchNorm pass.  res: null or [N, Ho, Wo, Cout]. */
+/*     lec_bn_eval_coeffs_f32: the scale / shift vectors of an eval-mode BatchNorm, computed on the stream (so that they follow the parameters and
+ *       running statistics earlier launches wrote; a captured inference graph recomputes them on every replay). */
+int lec_bn_eval_coeffs_f32(int C, const float* gamma, const float* beta, float eps, const float* running_mean, const float* running_var,
+                           float* scale, float* shift, lec_stream_t stream);
 int lec_conv_f32_fwd_affine(const float* x, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                             float* y, const float* scale, const float* shift, const float* res, int relu, lec_stream_t stream);
 /*     Fused BatchNorm pieces (the fp32 convolutions are bound by the matrix pipe and leave HBM idle; BatchNorm passes are the reverse:

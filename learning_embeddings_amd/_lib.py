@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LEC_LIB_PATH') or os.path.join(_HERE, 'liblecone.so')     # LEC_LIB_PATH: A/B builds of the same ABI
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 OK, E_ARG, E_HIP, E_EMPTY, E_STATE = 0, -1, -2, -3, -4
 ENERGY_HYP_CONE, ENERGY_ORDER, ENERGY_EUC_CONE = 0, 1, 2
@@ -103,6 +103,7 @@ def _load():
         'lec_conv_f32_wgrad_c3': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, p, p]),
         'lec_conv_f32_wgrad_fused': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p, p, p]),
         'lec_bn_bwd_accumulate': (i32, [i32]),
+        'lec_bn_eval_coeffs_f32': (i32, [i32, p, p, f32, p, p, p, p, p]),
         'lec_conv_f32_scratch_bytes': (i64, []),
         'lec_conv_f32_balanced': (i32, [i32]),
         'lec_conv_f32_scratch': (i32, [p, p, i64]),

@@ -529,6 +529,18 @@ extern "C" int64_t lec_bn_workspace_coeff_offset(int C) {                // byte
   return (int64_t)lec::kBnMaxRows * 2 * C * (int64_t)sizeof(float);
 }
 
+// scale / shift of an eval-mode BatchNorm (F.batch_norm(training=False)): the vectors lec_conv_f32_fwd_affine applies in its epilogue.  One small
+// launch, in stream order: parameters and running statistics that earlier launches on the stream wrote (optimizer step, training forwards)
+// are the ones it reads -- nothing on the host has to notice that they changed.
+extern "C" int lec_bn_eval_coeffs_f32(int C, const float* gamma, const float* beta, float eps, const float* running_mean, const float* running_var,
+                                      float* scale, float* shift, lec_stream_t stream) {
+  using namespace lec;
+  LEC_CHECK_ARG(C >= 1 && gamma && beta && running_mean && running_var && scale && shift, "bn_eval_coeffs: bad argument");
+  hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, gamma, beta, eps, running_mean, running_var, scale, shift);
+  LEC_CHECK_LAUNCH("bn_eval_coeff_kernel");
+  return LEC_OK;
+}
+
 extern "C" int lec_bn_fwd_finalize(int64_t M, int C, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                                    float* running_var, int n_partials, float* save_mean, float* save_invstd, void* workspace,
                                    int64_t workspace_bytes, lec_stream_t stream) {

@@ -99,6 +99,18 @@ class _ImageNetBase(nn.Module):
 
     cnn_passes = 1           # > 1 (fp32, training): forward_raw pushes the batch through the backbone as that many concurrent parts
 
+    def __deepcopy__(self, memo):
+        """copy.deepcopy of a network that has trained: the HIP streams of its concurrent passes are per-object launch resources, not state
+        (a Stream cannot be copied); the copy creates its own on first use."""
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k != '_pass_streams':
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
     def _forward_raw_passes(self, x):
         """forward_raw with the rows of x as `cnn_passes` parts, one HIP stream each: the backbone up to the pooled features per part
         (BatchNorm statistics per part, running statistics updated in part order), then the fully connected layer once over all rows

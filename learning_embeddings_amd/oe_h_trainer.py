@@ -832,9 +832,9 @@ class JointEmbeddings:
     # reference's own chunk size in the 'train' phase is 10 images (oe_h.py:1972), a forward of ~270 launches whose kernels take ~1 ms and whose
     # Python / ctypes enqueue takes 4.7 -- launch-bound; replayed, the same kernels run back to back.  Same kernels, same order, same results: in
     # train mode a replay updates the BatchNorm running statistics exactly as the eager forward (and the reference's) does.  The graph holds raw
-    # pointers to the parameters: load_model / optimizer steps write in place and are seen (an eval-mode graph also holds the BatchNorm layers'
-    # cached scale / shift vectors, which BatchNormAct2d.eval_affine refreshes in place: checked before every replay); `drop_eval_graphs()` after
-    # anything that re-allocates parameters.
+    # pointers to the parameters: load_model / optimizer steps write in place and are seen (an eval-mode graph recomputes every BatchNorm's
+    # scale / shift vectors from them on each replay: lec_bn_eval_coeffs_f32 is part of the graph); `drop_eval_graphs()` after anything that
+    # re-allocates parameters.
     eval_graphs = True
 
     def drop_eval_graphs(self):
@@ -873,9 +873,6 @@ class JointEmbeddings:
                 print('embed_images: graph capture failed (%s: %s); eager launches from here on' % (type(e).__name__, e))
                 self.eval_graphs = False
                 return net(stack).float()
-        if not net.training:
-            for bn in ent.setdefault('bns', [m for m in net.modules() if hasattr(m, 'eval_affine')]):
-                bn.eval_affine()                                # running statistics moved since the capture (a training epoch in between): refresh in place
         ent['in'].copy_(stack)
         ent['graph'].replay()
         return ent['out'].clone()

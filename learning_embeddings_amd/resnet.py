@@ -26,20 +26,18 @@ class BatchNormAct2d(nn.BatchNorm2d):
         self.fuse_relu = relu
 
     def eval_affine(self):
-        """(scale, shift) of the eval-mode map y = x * scale + shift: gamma / sqrt(running_var + eps), beta - running_mean * scale -- the
-        arithmetic of bn_eval_coeff_kernel (division by the square root, not a reciprocal square root), cached until a parameter or a
-        running statistic changes (tensor version counters)."""
-        key = (self.weight._version, self.bias._version, self.running_mean._version, self.running_var._version, self.weight.data_ptr(), self.weight.device)
-        c = getattr(self, '_affine_cache', None)
-        if c is None or c[0] != key:
-            with torch.no_grad():
-                scale = (self.weight.float() / torch.sqrt(self.running_var.float() + self.eps)).contiguous()
-                shift = (self.bias.float() - self.running_mean.float() * scale).contiguous()
-                if c is not None and c[0][4:] == key[4:]:
-                    # same parameter storage, new values: refresh IN PLACE -- a captured inference graph holds these two pointers
-                    c[1].copy_(scale); c[2].copy_(shift); scale, shift = c[1], c[2]
-            c = self._affine_cache = (key, scale, shift)
-        return c[1], c[2]
+        """(scale, shift) of the eval-mode map y = x * scale + shift: gamma / sqrt(running_var + eps), beta - running_mean * scale, computed by a
+        small launch ON THE STREAM into two vectors this layer owns (lec_bn_eval_coeffs_f32) -- every call: the parameters live in the flat
+        arena and the running statistics are written by liblecone's kernels through raw pointers, so no tensor version counter would tell the
+        host that they moved; in stream order the launch reads what the optimizer step / the training forwards before it wrote, and a captured
+        inference graph recomputes the vectors on every replay (their addresses never change)."""
+        buf = getattr(self, '_affine', None)
+        if buf is None or buf.device != self.weight.device:
+            buf = self._affine = torch.empty((2, self.num_features), dtype=torch.float32, device=self.weight.device)
+        from . import ops
+        ops.check(ops.lib.lec_bn_eval_coeffs_f32(self.num_features, ops.dptr(self.weight), ops.dptr(self.bias), float(self.eps), ops.dptr(self.running_mean),
+                                                 ops.dptr(self.running_var), ops.dptr(buf[0]), ops.dptr(buf[1]), ops.stream_ptr()))
+        return buf[0], buf[1]
 
     def forward(self, x, residual=None, fork=False):
         """fork=True: return TWO handles (y, y_alias) on the output, one per consuming branch of the next block (its conv
@@ -284,7 +282,8 @@ def _inference_f32(conv, x):
 def conv_bn(conv, bn, x, residual=None, fork=False):
     """bn(conv(x) [, residual]) -- in an eval-mode fp32 inference forward as ONE kernel: the BatchNorm is a per-channel affine map of its
     running statistics and runs, with the residual add and the ReLU, in the convolution's epilogue (lec_conv_f32_fwd_affine)."""
-    if (not bn.training and BatchNormAct2d.fused_enabled and isinstance(conv, Conv2d) and _inference_f32(conv, x)
+    if (not bn.training and BatchNormAct2d.fused_enabled and isinstance(conv, Conv2d) and _inference_f32(conv, x) and bn.weight.dtype == torch.float32
+            and bn.running_mean is not None and bn.running_mean.dtype == torch.float32
             and (residual is None or (residual.dtype == x.dtype and residual.is_contiguous(memory_format=torch.channels_last)))):
         scale, shift = bn.eval_affine()
         w = conv.weight if conv.weight.is_contiguous(memory_format=torch.channels_last) else conv.weight.contiguous(memory_format=torch.channels_last)
@@ -593,6 +592,17 @@ class ResNet(nn.Module):
         if not track:
             fc.reset()                                          # no backward will come for these records
         return y
+
+    def __deepcopy__(self, memo):
+        """The fusion contexts (hand-off records of forwards in flight, BatchNorm workspaces) are launch resources of THIS object, not state:
+        a copy starts with none and creates its own."""
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k not in ('_fusions', '_fusion'):
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
     @property
     def fusion(self):

@@ -317,6 +317,22 @@ def test_embed_images_replayed_forward_equals_eager_forward(tmp_path):
                 finally:
                     tr.img_feat_net, tr.eval_graphs = live, True
             assert torch.equal(got2, want2) and not torch.equal(got2, got)
+            # ... and after REAL training steps: liblecone's optimizer and BatchNorm kernels write parameters and running statistics through raw
+            # pointers (no tensor version counter moves), the replayed graph recomputes its scale / shift vectors from them on the stream
+            crit.set_dataloader(tr.datasets['train']); tr.model.train(); tr.img_feat_net.train()
+            it = iter(tr.dataloaders['train'])
+            for _ in range(2):
+                tr.train_step(next(it))
+            tr.img_feat_net.eval()
+            with torch.no_grad():
+                got3 = tr.embed_images(names, bs=8)
+                assert id(tr._eval_graphs[((8, 3, 32, 32), False)]['graph']) == gid
+                tr.eval_graphs = False                              # (eval mode mutates nothing: the same network, launched eagerly, is the reference)
+                try:
+                    want3 = tr.embed_images(names, bs=8)
+                finally:
+                    tr.eval_graphs = True
+            assert torch.equal(got3, want3) and not torch.equal(got3, got2)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
