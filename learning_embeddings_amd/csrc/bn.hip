@@ -90,6 +90,14 @@ struct EF32 {
   static __device__ __forceinline__ float rnd(float v) { return v; }
 };
 
+// LEC_BN_NUM_VGPR (build-time experiment, `make EXTRA=-DLEC_BN_NUM_VGPR=64`): cap the streaming kernels' registers so that their waves fit beside the two
+// 192 - 256-register convolution waves a SIMD of the OTHER pass stream holds.  MEASURED (round 3, same box, alternating, bench step): no cap 131.5 / 131.0 ms, 64 registers
+// 131.3, 96 registers 131.5 (no spills either way) -- room in the register file is not what keeps the step at the sum of its kernels' chip-time.  Off.
+#ifdef LEC_BN_NUM_VGPR
+#define LEC_BN_REGS __attribute__((amdgpu_num_vgpr(LEC_BN_NUM_VGPR)))
+#else
+#define LEC_BN_REGS
+#endif
 constexpr int kBnThreads = 256;
 constexpr int kBnMaxBlocks = 512;           // blocks of a reduction pass of this file
 constexpr int kBnMaxRows = 2048;            // partial rows the workspace holds (layout constant): a convolution's balanced form leaves one row per m-tile
@@ -138,7 +146,7 @@ __device__ __forceinline__ void block_reduce_rows(float (&acc)[NV][8], int CV, i
 // ---------------------------------------------------------------------------------------------------------------
 // forward, pass 1: per-block partial sum / sum of squares per channel -> part[rb][2][C]
 template <typename E>
-__global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const void* __restrict__ x, int64_t M, int C, int CV, int CVB,
+__global__ __launch_bounds__(kBnThreads) LEC_BN_REGS void bn_stats_kernel(const void* __restrict__ x, int64_t M, int C, int CV, int CVB,
                                                               int RPIB, float* __restrict__ part) {
   __shared__ float smem[kBnThreads * 8];
   const int tid = threadIdx.x;
@@ -248,7 +256,7 @@ __global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, con
 // forward, pass 2: y = [relu]( x * scale + shift [+ residual] )
 // `mask` (optional, RELU only): one byte per thread-vector, bit j = [y_j > 0] -- backward reads it instead of y (1/16 the bytes)
 template <typename E, bool RES, bool RELU>
-__global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const void* __restrict__ x, const void* __restrict__ res,
+__global__ __launch_bounds__(kBnThreads) LEC_BN_REGS void bn_apply_kernel(const void* __restrict__ x, const void* __restrict__ res,
                                                               int64_t M, int CV, int RPI, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, void* __restrict__ y,
                                                               unsigned char* __restrict__ mask) {
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const void* __rest
 // pass 2 then reads this one tensor instead of dy, dy2 and the mask again (8.1 -> 7.1 bytes-units per element on the
 // forked block outputs).  The sums are taken over the rounded g so that both passes see the same values.
 template <typename E, int RELU>
-__global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const void* __restrict__ dy, const void* __restrict__ dy2,
+__global__ __launch_bounds__(kBnThreads) LEC_BN_REGS void bn_bwd_reduce_kernel(const void* __restrict__ dy, const void* __restrict__ dy2,
                                                                    const void* __restrict__ y,
                                                                    const void* __restrict__ x, int64_t M, int C, int CV,
                                                                    int CVB, int RPI, const float* __restrict__ mean,
@@ -401,7 +409,7 @@ __global__ void bn_bwd_coeffs_kernel(const float* __restrict__ part, int nblk, i
 
 // backward, pass 2: dx = gamma*invstd * (g - mean(g) - xhat * mean(g*xhat));  d residual = g
 template <typename E, bool RES, int RELU>
-__global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(const void* __restrict__ dy, const void* __restrict__ dy2,
+__global__ __launch_bounds__(kBnThreads) LEC_BN_REGS void bn_bwd_apply_kernel(const void* __restrict__ dy, const void* __restrict__ dy2,
                                                                   const void* __restrict__ y,
                                                                   const void* __restrict__ x, int64_t M, int CV, int RPI,
                                                                   const float* __restrict__ gamma, const float* __restrict__ mean,
