@@ -652,12 +652,17 @@ def conv_macs(model, hw):
             hooks.append(m.register_forward_hook(conv_hook))
         elif isinstance(m, nn.Linear):
             hooks.append(m.register_forward_hook(fc_hook))
-    was = model.training
+    global MFMA_F32
+    was, own = model.training, MFMA_F32
     model.eval()
-    with torch.no_grad():
-        dev = next(model.parameters()).device
-        model(torch.zeros(1, 3, hw, hw, device=dev, dtype=next(model.parameters()).dtype))
-    model.train(was)
+    MFMA_F32 = False                                            # the inference forward calls liblecone directly (conv_bn): walk the MODULES
+    try:
+        with torch.no_grad():
+            dev = next(model.parameters()).device
+            model(torch.zeros(1, 3, hw, hw, device=dev, dtype=next(model.parameters()).dtype))
+    finally:
+        MFMA_F32 = own
+        model.train(was)
     for h in hooks:
         h.remove()
     return macs

@@ -540,6 +540,15 @@ def test_inference_forward_runs_liblecone_kernels_and_matches_stock_torch(arch, 
     ops.fusion().reset()
 
 
+def test_conv_macs_walks_the_modules_on_the_gpu_too():
+    """bench.py's analytic flops come from resnet.conv_macs, a forward with hooks on the convolution MODULES: the inference forward bypasses
+    the modules (conv_bn calls liblecone directly), so the walk must take the module path (it once counted 0.7 instead of 24.5 GFLOP per image)."""
+    from learning_embeddings_amd.resnet import conv_macs
+    net = resnet50(num_classes=10).to(DEV).to(memory_format=torch.channels_last)
+    assert abs(conv_macs(net, 224) / 1e9 - 4.0872) < 0.05
+    assert net.training
+
+
 # ------------------------------------------------------------------------------------------------ round 3: the balanced (stream-K) kernel
 class _Balanced:
     """lec_conv_f32_balanced(mode) for the duration of a block (2: the balanced kernel wherever it applies, 0: never)."""

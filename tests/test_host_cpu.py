@@ -387,3 +387,12 @@ def test_bench_self_launch_starts_the_ranks_as_children(tmp_path):
     assert len(lines) == 1 and json.loads(lines[0]) == {'n_gpus': 2, 'argv': ['--gpus', '2', '--steps', '3']}
     bad = subprocess.run([sys.executable, '-c', code, '--fail'], capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0
+
+
+def test_conv_macs_matches_the_analytic_resnet_figures():
+    """resnet.conv_macs (the denominator of bench.py's whole-CNN roofline line): SURVEY.md 8(d) quotes 1.8136 GMAC (ResNet-18) and 4.0872 GMAC
+    (ResNet-50) per forward at 224 x 224, convolutions + the classifier's 1000-way fc excluded / included as the walk finds it."""
+    from learning_embeddings_amd.resnet import resnet18, resnet50, conv_macs
+    for net, gmac in ((resnet18(num_classes=10), 1.8136), (resnet50(num_classes=10), 4.0872)):
+        m = conv_macs(net, 224)
+        assert abs(m / 1e9 - gmac) < 0.01 * gmac, (m, gmac)
