@@ -523,6 +523,8 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
 // them with sc1 loads only (CDNA4 guide 6 G16, form R1 -- an agent-scope release fence per slab writes back the XCD's whole L2 and cost 100 - 160 us
 // per launch on the 1x1 layers).  Scratch: 2 slots of BM x BN floats per workgroup + one counter per tile, registered per stream
 // (lec_conv_f32_scratch); counters are zero between launches (the finalizer re-arms its tile's counter).
+// (LEC_SK_LOAD_AUX / LEC_SK_STORE_AUX = 17: sc0 sc1 on the slab accesses, LEC_SK_ACQ = 1: an agent-scope acquire in front of the finalizer's loads -- built while
+// chasing a 5.5e-3 gradient discrepancy that turned out to be ONE ReLU decision flipped by the different summation order; all three gave the same bits as the defaults.)
 #ifndef LEC_SK_LOAD_AUX
 #define LEC_SK_LOAD_AUX 16
 #endif
@@ -686,17 +688,36 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_sk_kernel(const fl
           for (int jt = 0; jt < TN; ++jt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[it][jt][r] = 0.f;
-        for (long long w = wa; w <= wb_; ++w) {
-          const unsigned sl = (unsigned)(((int)w * 2 + (wg_start(w) > T0 ? 0 : 1)) * (BM * BN * 4)) + (unsigned)tid * 16u;
+        // two slabs' loads in flight at a time (32 x 16 bytes per lane), added in workgroup order
+        constexpr int NQ = TM * TN * 4;
+        auto slab = [&](long long w) { return (unsigned)(((int)w * 2 + (wg_start(w) > T0 ? 0 : 1)) * (BM * BN * 4)) + (unsigned)tid * 16u; };
+        auto add = [&](const f32x4v (&v)[NQ]) {
 #pragma unroll
           for (int it = 0; it < TM; ++it)
 #pragma unroll
             for (int jt = 0; jt < TN; ++jt)
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                const f32x4v v = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_slots, (int)(sl + (unsigned)(((it * TN + jt) * 4 + q) * kCfThreads * 16)), 0, LEC_SK_LOAD_AUX));
-                acc[it][jt][4 * q] += v[0]; acc[it][jt][4 * q + 1] += v[1]; acc[it][jt][4 * q + 2] += v[2]; acc[it][jt][4 * q + 3] += v[3];
+                const f32x4v& x = v[(it * TN + jt) * 4 + q];
+                acc[it][jt][4 * q] += x[0]; acc[it][jt][4 * q + 1] += x[1]; acc[it][jt][4 * q + 2] += x[2]; acc[it][jt][4 * q + 3] += x[3];
               }
+        };
+        long long w = wa;
+        for (; w + 1 <= wb_; w += 2) {
+          const unsigned s0 = slab(w), s1 = slab(w + 1);
+          f32x4v v0[NQ], v1[NQ];
+#pragma unroll
+          for (int i = 0; i < NQ; ++i) v0[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_slots, (int)(s0 + (unsigned)(i * kCfThreads * 16)), 0, LEC_SK_LOAD_AUX));
+#pragma unroll
+          for (int i = 0; i < NQ; ++i) v1[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_slots, (int)(s1 + (unsigned)(i * kCfThreads * 16)), 0, LEC_SK_LOAD_AUX));
+          add(v0); add(v1);
+        }
+        if (w <= wb_) {
+          const unsigned s0 = slab(w);
+          f32x4v v0[NQ];
+#pragma unroll
+          for (int i = 0; i < NQ; ++i) v0[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_slots, (int)(s0 + (unsigned)(i * kCfThreads * 16)), 0, LEC_SK_LOAD_AUX));
+          add(v0);
         }
       }
     }
