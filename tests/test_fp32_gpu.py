@@ -609,6 +609,43 @@ def test_conv_f32_balanced_kernel_equals_float64_on_integers_and_is_run_to_run_i
     ops.fusion().reset()
 
 
+FULL_CASES = [  # N, Cin, H, W, Cout, R, stride, pad: layer shapes of the bench step at the rows of a pass (256) and of a whole step (512)
+    (512, 256, 14, 14, 256, 3, 1, 1), (256, 1024, 14, 14, 256, 1, 1, 0), (256, 128, 56, 56, 128, 3, 2, 1), (512, 512, 7, 7, 512, 3, 1, 1), (256, 256, 14, 14, 1024, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize('N,Cin,H,W,Cout,R,stride,pad', FULL_CASES)
+def test_conv_f32_full_size_layers_are_exact_on_integers_with_either_schedule(N, Cin, H, W, Cout, R, stride, pad):
+    """BASELINE-size layers (392 x 2^k tiles: the launches the balanced kernel was built for) on operands from {-1, 0, 1}: every partial sum is
+    exactly representable, so forward, data gradient and weight gradient must EQUAL the float64 convolution -- with the tile walk and with the
+    balanced kernel (512 workgroups, every tile boundary inside some workgroup's run), whatever the fix-up order or the atomics' order -- and
+    the per-tile statistics rows must add up to the exact per-channel sums."""
+    g = torch.Generator(device='cpu').manual_seed(N + Cin + Cout + R)
+    x = _cl(torch.randint(-1, 2, (N, Cin, H, W), generator=g).float()); w = _cl(torch.randint(-1, 2, (Cout, Cin, R, R), generator=g).float())
+    yr = F.conv2d(x.double(), w.double(), None, stride, pad)
+    dy = _cl(torch.randint(-1, 2, yr.shape, generator=g).float())
+    dxr = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), stride, pad)
+    dwr = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), stride, pad)
+    rows = {}
+    for mode in (0, 1):
+        with _Balanced(mode):
+            ops.fusion().reset()
+            y = ops.conv_f32_fwd(x, w, stride, pad, want_stats=True)
+            k = ops.fusion().ws_owner[1]; rows[mode] = k
+            s0 = ops._bn_workspace(x.device).view(torch.float32)[:k * 2 * Cout].view(k, 2, Cout)[:, 0].double().sum(0)
+            dx = ops.conv_f32_dgrad(dy, w, x.shape, stride, pad)
+        assert torch.equal(y.double(), yr), 'forward, mode %d' % mode
+        assert torch.equal(s0, yr.sum(dim=(0, 2, 3))), 'statistics, mode %d' % mode
+        assert torch.equal(dx.double(), dxr), 'data gradient, mode %d' % mode
+        del y, dx
+    mtiles = (N * yr.shape[2] * yr.shape[3] + 127) // 128
+    assert rows[0] == min(mtiles, 512) and rows[1] == (mtiles if mtiles <= 2048 else min(mtiles, 512))     # the balanced kernel ran where expected
+    dw = torch.zeros_like(w)
+    ops.conv_f32_wgrad(dy, x, dw, stride, pad)
+    assert torch.equal(dw.double(), dwr), 'weight gradient'
+    ops.fusion().reset()
+
+
 @pytest.mark.parametrize('N,Cin,H,W,Cout,R,pad,wgs', [(10, 256, 14, 14, 256, 3, 1, 288), (10, 1024, 14, 14, 256, 1, 0, 128), (10, 512, 7, 7, 512, 3, 1, 288),
                                                         (10, 256, 14, 14, 1024, 1, 0, 0), (256, 256, 14, 14, 256, 3, 1, 512)])
 def test_conv_f32_launcher_cuts_small_batches_along_k(N, Cin, H, W, Cout, R, pad, wgs):
