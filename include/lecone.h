@@ -473,6 +473,20 @@ int lec_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, int N, int H, in
 int lec_maxpool3x3s2_fwd_f32(const void* x, int N, int H, int W, int C, void* y, uint8_t* argmax, lec_stream_t stream);   /* fp32 x, y */
 int lec_maxpool3x3s2_bwd_f32(const void* dy, const uint8_t* argmax, int N, int H, int W, int C, void* dx, lec_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * (9) HBM-resident image store (csrc/image_store.hip): the input side of the step.  Replaces, for every image row of a step's CNN
+ *     batch, the reference's host-side ToTensor (+ RandomHorizontalFlip for positives) + torch.stack + .to(device): oe_h.py:700-712 and
+ *     1463-1471 (positives, DataLoader workers), oe_h.py:668-677 called from 980-983 / 1003-1007 (every image drawn as a negative,
+ *     synchronously in the training thread).  The caller keeps the RESIZED uint8 images (what cv2.imread -> ToPILImage -> Resize gives,
+ *     [H, W, 3], channel order as decoded) in one device buffer and asks for the float batch:
+ *     store: DEVICE uint8 [n_slots, H, W, 3];  slots: DEVICE int32 [n];  flip: DEVICE uint8 [n] or NULL (nonzero = mirrored along W);
+ *     out:   DEVICE fp32 [n, H, W, c_out] (NHWC = a channels_last [n, c_out, H, W] tensor), c_out = 3, or 4 with a zero 4th channel
+ *            (what the f32 stem convolution consumes).  out[i, h, w, c] = float(store[slots[i], h, flip ? W-1-w : w, c]) / 255 with an
+ *            IEEE fp32 division: bit-identical to ToTensor.  A slot outside [0, n_slots) gives a black image.
+ * ------------------------------------------------------------------------------------------------------------- */
+int lec_image_gather_u8(const uint8_t* store, int64_t n_slots, const int32_t* slots, const uint8_t* flip, int n, int H, int W,
+                        int c_out, float* out, lec_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,7 @@ import torch.nn.functional as F
 
 from . import _lib, ops
 from .hierarchy import NegativeGraph
+from .image_store import ImageRef
 from .resnet import resnet18, resnet50
 
 random.seed(0)                                                   # oe_h.py:42
@@ -347,7 +348,15 @@ class _JointCriterionBase(torch.nn.Module):
         ix_from = np.fromiter((n2i[o] for o in original_from), dtype=np.int32, count=B)
         ix_to = np.fromiter((n2i[o] for o in original_to), dtype=np.int32, count=B)
         dp = getattr(self, 'dp_global', None)
-        if dp is None:
+        pre = getattr(self, 'predrawn', None)
+        if pre is not None:
+            # the trainer's lookahead drew this batch's negatives one step ahead, in the reference's stream order, and asked the image
+            # store for the images among them (oe_h_trainer.JointEmbeddings.train_epoch); same indices as the draw below would give
+            self.predrawn = None
+            p_from, p_to, neg = pre
+            if not (np.array_equal(p_from, ix_from) and np.array_equal(p_to, ix_to)):
+                raise RuntimeError('negatives were drawn ahead for a different batch than the one passed in')
+        elif dp is None:
             neg = self.negative_G.draw_batch(ix_from, ix_to, Kn)         # oe_h.py:940-957, bit-exact stream
         else:
             # data parallel: every rank walks the GLOBAL batch's stream (same order as a single process would) and keeps
@@ -357,25 +366,40 @@ class _JointCriterionBase(torch.nn.Module):
                 raise RuntimeError('data-parallel shard does not match the global batch order')
             neg = self.negative_G.draw_batch(g_from, g_to, Kn)[lo:hi]
         self.last_negatives = neg
-        # one CNN forward over the DISTINCT images of the step: the batch's own tensors + images drawn as negatives
-        slot, stack = {}, []
+        # one CNN forward over the DISTINCT images of the step: the batch's own images + images drawn as negatives.  A row is either a
+        # float tensor (the reference's host path) or (name, mirrored) for the image store to build on the GPU.
+        store = getattr(self, 'image_store', None)
+        i2n = self.mapping_from_ix_to_node
+
+        def by_name(name):
+            if store is not None and store.holds(name):
+                return (name, False)                                     # get_image: the val/test transform, no flip (oe_h.py:668-677)
+            return self.dataloader.get_image(name)
+
+        slot, rows = {}, []
         for elem, ix in zip(list(inputs_from) + list(inputs_to), np.concatenate([ix_from, ix_to]).tolist()):
             if ix >= N and ix not in slot:
-                if not torch.is_tensor(elem):
-                    elem = self.dataloader.get_image(self.mapping_from_ix_to_node[ix])
-                slot[ix] = len(stack); stack.append(elem)
+                if isinstance(elem, ImageRef):
+                    if store is None:
+                        raise RuntimeError('the batch carries ImageRef handles but the criterion has no image_store')
+                    if elem.pixels is not None:
+                        store.offer(elem.name, elem.pixels)
+                    elem = (elem.name, elem.flip)
+                elif not torch.is_tensor(elem):
+                    elem = by_name(i2n[ix])
+                slot[ix] = len(rows); rows.append(elem)
         for ix in np.unique(neg[neg >= N]).tolist():
             if ix not in slot:
-                slot[ix] = len(stack); stack.append(self.dataloader.get_image(self.mapping_from_ix_to_node[ix]))
+                slot[ix] = len(rows); rows.append(by_name(i2n[ix]))
         dev = _unwrap(model).embeddings.weight.device
         feats, image_proj = None, _lib.IMAGE_RAW
-        self.last_cnn_rows = len(stack)                                 # distinct images of the step = rows of the one CNN batch
-        if stack:
-            batch = torch.stack([s.to(dev, non_blocking=True) for s in stack])
+        self.last_cnn_rows = len(rows)                                  # distinct images of the step = rows of the one CNN batch
+        if rows:
+            batch = self._image_batch(rows, dev, store)
             if self.use_CNN and hasattr(img_feat_net, 'forward_raw') and getattr(img_feat_net, 'K', None):
                 feats = img_feat_net.forward_raw(batch); image_proj = self.default_image_proj
             else:
-                feats = _unwrap(img_feat_net)(batch).reshape(len(stack), -1).float()
+                feats = _unwrap(img_feat_net)(batch).reshape(len(rows), -1).float()
 
         def codes(a):
             a = np.asarray(a, dtype=np.int64)
@@ -390,6 +414,35 @@ class _JointCriterionBase(torch.nn.Module):
             return torch.from_numpy(a.astype(np.int32)).to(dev, non_blocking=True)
 
         return self.forward_indices(model, feats, codes(ix_from), codes(ix_to), codes(neg), image_proj=image_proj)
+
+    def _image_batch(self, rows, dev, store):
+        """The step's CNN batch on the device.  Store-backed rows: ONE gather kernel (image_store.ImageStore.batch).  Tensor rows (the
+        reference's host path, in-memory synthetic stores): one stack -- host tensors through a pinned buffer and ONE asynchronous copy
+        instead of a pageable copy per image."""
+        st = [j for j, r in enumerate(rows) if isinstance(r, tuple)]
+        if len(st) == len(rows):
+            return store.batch([r[0] for r in rows], [r[1] for r in rows])
+        tens = [r for r in rows if not isinstance(r, tuple)]
+        if all(t.device == dev for t in tens):
+            t = torch.stack(tens)
+        elif all(not t.is_cuda for t in tens) and all(t.shape == tens[0].shape and t.dtype == tens[0].dtype for t in tens):
+            pin = self.__dict__.get('_pin')
+            if pin is None or pin[0].shape[1:] != tens[0].shape or pin[0].dtype != tens[0].dtype or pin[0].shape[0] < len(tens):
+                pin = self.__dict__['_pin'] = [torch.empty((max(len(tens), 64),) + tuple(tens[0].shape), dtype=tens[0].dtype).pin_memory(), None]
+            if pin[1] is not None:
+                pin[1].synchronize()                                     # the previous step's copy out of this buffer
+            torch.stack(tens, out=pin[0][:len(tens)])
+            t = pin[0][:len(tens)].to(dev, non_blocking=True)
+            pin[1] = torch.cuda.Event(); pin[1].record()
+        else:
+            t = torch.stack([x.to(dev, non_blocking=True) for x in tens])
+        if not st:
+            return t
+        out = torch.empty((len(rows),) + tuple(t.shape[1:]), dtype=torch.float32, device=dev)
+        tt = [j for j, r in enumerate(rows) if not isinstance(r, tuple)]
+        out[torch.tensor(st, device=dev)] = store.batch([rows[j][0] for j in st], [rows[j][1] for j in st])
+        out[torch.tensor(tt, device=dev)] = t.float()
+        return out
 
     def forward_indices(self, model, feats, pos_from, pos_to, neg, weights=None, image_proj=None):
         """The device part of the train step: node codes in, (loss, e_pos [B], e_neg [B,2K,1]) out, one kernel."""

@@ -19,6 +19,7 @@ import torch.nn as nn
 
 from . import _lib, ops, parallel
 from .hierarchy import NegativeGraph
+from .image_store import ImageRef, ImageStore, decode_u8
 
 
 # ------------------------------------------------------------------------------------------------ tiny graph type
@@ -295,26 +296,39 @@ class ETHECHierarchyWithImages(torch.utils.data.Dataset):
         else:
             self.edge_list = [e for e in self.edge_list_complete if not self._hidden(*e)]
 
+    # An image store (image_store.ImageStore, set by the trainer) turns file-backed items into ImageRef handles: the float tensor is built on
+    # the GPU from the store's uint8 copy (bit-identical to this class's own tensor path, tests/test_image_store_gpu.py).
+    store_view = None
+
     def _load(self, filename, train_transform):
         loc = self.image_to_loc[filename]
+        sv = self.store_view
+        if (sv is not None and isinstance(loc, (str, os.PathLike)) and filename in sv.index_of
+                and (not (train_transform and self.transform) or hasattr(self.transform, 'decide'))):
+            flip = bool(train_transform and self.transform and self.transform.decide())
+            pixels = None
+            if not sv.is_resident(filename) and torch.utils.data.get_worker_info() is not None:
+                pixels = torch.from_numpy(decode_u8(loc, self.input_size))    # a DataLoader worker decodes what it was going to decode anyway
+            return ImageRef(filename, flip, pixels)
         if torch.is_tensor(loc):
             img = loc
         elif callable(loc):
             img = loc()
         else:
-            # The reference decodes with cv2.imread (B, G, R channel order, 8-bit, no alpha) and hands the array to ToPILImage without a
-            # channel swap (oe_h.py:668-677, 700-712, 1463-1471): tensor channel 0 is BLUE.  Same layout here, so that a backbone trained
-            # by the reference sees the channels it was trained on (resize is per channel: swapping before or after it is the same).
-            from PIL import Image
-            pil = Image.open(loc).convert('RGB').resize((self.input_size, self.input_size), Image.BILINEAR)
-            img = torch.from_numpy(np.asarray(pil)[:, :, ::-1].copy()).permute(2, 0, 1).float().div_(255.0)
+            # decode_u8: the reference's decode + ToPILImage + Resize (oe_h.py:668-677, 700-712, 1463-1471; B, G, R channel order); ToTensor:
+            img = torch.from_numpy(decode_u8(loc, self.input_size)).permute(2, 0, 1).float().div_(255.0)
         if train_transform and self.transform:
             img = self.transform(img)
         return img
 
     def get_image(self, filename):
-        """oe_h.py:668-677: the val/test transform (no flip) -- used for images drawn as negatives."""
-        return self._load(filename, False)
+        """oe_h.py:668-677: the val/test transform (no flip) -- used for images drawn as negatives.  Always the float tensor, like the
+        reference's (the criterion itself goes through the image store when there is one)."""
+        sv, self.store_view = self.store_view, None
+        try:
+            return self._load(filename, False)
+        finally:
+            self.store_view = sv
 
     @staticmethod
     def map_ranges(input, output_range, input_range):
@@ -345,6 +359,20 @@ class ETHECHierarchyWithImages(torch.utils.data.Dataset):
         if self.half_half:
             return max(2 * len(self.edge_list_ll), 2 * len(self.edge_list_li))
         return len(self.edge_list)
+
+
+class RandomHorizontalFlip:
+    """transforms.RandomHorizontalFlip of the train transform (oe_h.py:1465) on a [3, H, W] tensor; `decide()` is the same draw without the
+    image, for items that travel as ImageRef handles (the mirror then happens in lec_image_gather_u8)."""
+
+    def __init__(self, p=0.5):
+        self.p = p
+
+    def decide(self):
+        return bool(torch.rand(()) < self.p)
+
+    def __call__(self, img):
+        return img.flip(-1) if self.decide() else img
 
 
 class EmbeddingMetrics:
@@ -438,7 +466,8 @@ class JointEmbeddings:
                  lr_step=[], experiment_dir='../exp/', n_epochs=10, eval_interval=2, feature_extracting=True,
                  use_pretrained=True, load_wt=False, model_name=None, optimizer_method='adam', use_grayscale=False,
                  load_emb_from=None, load_cosine_emb=None, hide_levels=None, half_half=False,
-                 compute_dtype=torch.float32, cnn_weights=None, writer=None, fast_path=True, cnn_passes=None):
+                 compute_dtype=torch.float32, cnn_weights=None, writer=None, fast_path=True, cnn_passes=None,
+                 image_store=True, image_store_gb=None):
         Embedder, FeatCNN18, FeatCNN, FeatNet = self._model_classes()
         from .resnet import WgradOverlap
         WgradOverlap.instance = None            # set to this trainer's own instance around every train step (see train_step)
@@ -455,6 +484,9 @@ class JointEmbeddings:
         self.best_model_wts = None; self.best_score = 0.0
         self.epoch = 0; self.exp_dir = experiment_dir; self.load_wt = load_wt
         self.criterion = criterion
+        # image_store: keep the resized uint8 copy of every image FILE the datasets name in HBM (image_store.ImageStore; image_store_gb
+        # caps it, default: all of them) and build the step's float batch on the GPU; False: the reference's host tensors
+        self.use_image_store = bool(image_store); self.image_store_gb = image_store_gb; self.image_store = None
         if not torch.cuda.is_available():
             raise RuntimeError('JointEmbeddings runs on the MI355X only (no CPU fallback)')
         self.rank, self.local_rank, self.world = parallel.init_process_group()
@@ -528,8 +560,7 @@ class JointEmbeddings:
         random.seed(0)                                                      # oe_h.py:1472
         self.criterion.seed_sampler(0)
 
-        def flip(img):                                                      # RandomHorizontalFlip (train only, :1465)
-            return img.flip(-1) if torch.rand(()) < 0.5 else img
+        flip = RandomHorizontalFlip(0.5)                                    # train only (:1465)
         il = self.imageless_dataloaders
         mk = lambda key, tr, hh: ETHECHierarchyWithImages(self.graph_dict[key], labelmap=self.labelmap,
                                                           imageless_dataloaders=il[tr] if (self.use_CNN and il) else None,
@@ -539,6 +570,19 @@ class JointEmbeddings:
         self.train_set = train_set
         self.datasets = {'train': train_set, 'val': val_set, 'test': test_set}
         self.dataset_length = {k: len(v) for k, v in self.datasets.items()}
+        locs = {}
+        for ds in (train_set, val_set, test_set):
+            for nm, loc in ds.image_to_loc.items():
+                if isinstance(loc, (str, os.PathLike)):
+                    locs.setdefault(nm, loc)
+        if self.use_CNN and self.use_image_store and locs:
+            per = train_set.input_size * train_set.input_size * 3
+            cap = None if self.image_store_gb is None else max(4 * self.batch_size * (1 + 2 * self.neg_to_pos_ratio), int(self.image_store_gb * 1e9) // per)
+            self.image_store = ImageStore(locs, self.device, hw=train_set.input_size, capacity=cap, decode_threads=max(2, self.n_workers))
+            for ds in (train_set, val_set, test_set):
+                ds.store_view = self.image_store.view()
+            print('Image store: %d image files, %d slots of %d bytes in HBM' % (len(locs), self.image_store.capacity, per))
+        self.criterion.image_store = self.image_store
         self._make_train_loader()
         from .oe_h import my_collate
         self.dataloaders['val'] = torch.utils.data.DataLoader(val_set, batch_size=self.batch_size, collate_fn=my_collate,
@@ -659,28 +703,75 @@ class JointEmbeddings:
                                 clip=bool(Kc) and self.riemannian_table_step)
             self.arena.adam_step(lr)
 
+    negative_lookahead = True                # draw step t+1's negatives (and start decoding their images) while step t runs
+
+    def train_epoch(self, max_steps=None, on_step=None):
+        """The train branch's loop over the DataLoader (oe_h.py:1734-1774), one `train_step` per batch.  Returns (summed loss on the device,
+        steps run).  The batches of the epoch are known up front (GlobalBatchSampler's permutation), so a host thread walks them one step
+        AHEAD of the GPU: it draws each batch's negatives -- in batch order, on the GLOBAL batch when data parallel: the sampler's MT19937
+        stream is consumed exactly as the reference's training thread consumes it (oe_h.py:940-957) whatever the world size -- and asks
+        the image store to decode the negative images it does not hold yet, off the training thread (the reference decodes them
+        synchronously in it: oe_h.py:980-983, 1003-1007)."""
+        self.criterion.set_dataloader(self.datasets['train'])
+        self.model.train(); self.img_feat_net.train()
+        running = torch.zeros((), device=self.device)
+        self.train_sampler.set_epoch(self.epoch)
+        global_batches = self.train_sampler.global_batches()
+        if max_steps is not None:
+            global_batches = global_batches[:max_steps]
+        n2i = self.graph_dict['mapping_node_to_ix']; i2n = self.graph_dict['mapping_ix_to_node']
+        N = self.n_classes
+        store = self.image_store
+
+        def shard_of(s):
+            if s >= len(global_batches):
+                return None
+            gb = global_batches[s]
+            edges = [self.train_set.edge_of(i_) for i_ in gb]         # (half_half: the same item -> edge map __getitem__ uses)
+            g_from = np.fromiter((n2i[u] for u, _ in edges), dtype=np.int32, count=len(edges))
+            g_to = np.fromiter((n2i[v] for _, v in edges), dtype=np.int32, count=len(edges))
+            return g_from, g_to
+
+        def on_item(item):
+            if store is not None:
+                neg = item[2]
+                names = [i2n[ix] for ix in np.unique(neg[neg >= N]).tolist()]
+                store.request([nm for nm in names if store.holds(nm)])
+
+        look = None
+        if self.negative_lookahead:
+            look = parallel.NegativePrefetcher(self.criterion.negative_G, shard_of, self.neg_to_pos_ratio, mode='replicated', depth=2,
+                                               on_item=on_item, rank=self.rank, world=self.world)
+        steps = 0
+        try:
+            for index, data_item in enumerate(self.dataloaders['train']):
+                if max_steps is not None and index >= max_steps:
+                    break
+                if look is not None:
+                    self.criterion.predrawn = look.next()
+                elif self.world > 1:                                    # this rank's slice of the global batch (SURVEY.md 8e)
+                    g_from, g_to = shard_of(index)
+                    per = len(g_from) // self.world
+                    self.criterion.dp_global = (g_from, g_to, self.rank * per, (self.rank + 1) * per)
+                loss, _, _ = self.train_step(data_item)
+                running += loss
+                steps += 1
+                if on_step is not None:
+                    on_step(steps)
+        finally:
+            self.criterion.dp_global = None; self.criterion.predrawn = None
+            if look is not None:
+                look.close()
+        if self.world > 1:
+            torch.distributed.all_reduce(running)
+        return running, steps
+
     def pass_samples(self, phase, save_to_tensorboard=True):
         self.criterion.set_dataloader(self.datasets[phase])
         if phase == 'train':
             self.model.train(); self.img_feat_net.train()
-            running = torch.zeros((), device=self.device)
-            self.train_sampler.set_epoch(self.epoch)
-            index = -1
-            global_batches = self.train_sampler.global_batches() if self.world > 1 else None
-            n2i = self.graph_dict['mapping_node_to_ix']
-            for index, data_item in enumerate(self.dataloaders[phase]):
-                if global_batches is not None:                      # this rank's slice of the global batch
-                    gb = global_batches[index]
-                    edges = [self.train_set.edge_of(i_) for i_ in gb]     # (half_half: the same item -> edge map __getitem__ uses)
-                    g_from = np.fromiter((n2i[u] for u, _ in edges), dtype=np.int32, count=len(edges))
-                    g_to = np.fromiter((n2i[v] for _, v in edges), dtype=np.int32, count=len(edges))
-                    per = len(gb) // self.world
-                    self.criterion.dp_global = (g_from, g_to, self.rank * per, (self.rank + 1) * per)
-                loss, _, _ = self.train_step(data_item)
-                running += loss
-            self.criterion.dp_global = None
-            if self.world > 1:
-                torch.distributed.all_reduce(running)
+            running, index = self.train_epoch()
+            index -= 1
             classification_metrics = self.calculate_classification_metrics(phase)
             epoch_loss = running.item() / max(1, (index + 1) * self.batch_size * self.world * self.neg_to_pos_ratio * 2)   # :1780
             if save_to_tensorboard:
@@ -818,13 +909,19 @@ class JointEmbeddings:
         (oe_h.py:1997-2003): every chunk ends at min(ix + bs, len - 1), so the last image is never embedded and its row stays zero
         (an EMPTY last chunk -- len = 1 mod bs -- makes the reference's torch.stack raise; here it is skipped)."""
         ds = self.criterion.dataloader
+        store = self.image_store
         out = torch.zeros((len(names), self.embedding_dim), device=self.device)
         n = len(names)
         for i in range(0, n, bs):
             hi = min(i + bs, n - 1) if skip_last else min(i + bs, n)
             if hi <= i:
                 continue
-            stack = torch.stack([ds.get_image(nm) for nm in names[i:hi]]).to(self.device)
+            chunk = names[i:hi]
+            if store is not None and all(store.holds(nm) for nm in chunk):
+                store.request([nm for nm in names[hi:hi + 2 * bs] if store.holds(nm)])    # the next chunks decode while this one runs
+                stack = store.batch(chunk)
+            else:
+                stack = torch.stack([ds.get_image(nm) for nm in chunk]).to(self.device)
             out[i:hi] = self._embed_forward(stack, full=(hi - i == bs))
         return out
 

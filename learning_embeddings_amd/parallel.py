@@ -379,33 +379,49 @@ class NegativePrefetcher:
     every rank walks the GLOBAL batch's stream and keeps its shard, which makes the indices bit-identical to the
     single-process run whatever the world size, with no collective."""
 
-    def __init__(self, graph, positives_fn, K, mode='replicated', depth=2):
+    def __init__(self, graph, positives_fn, K, mode='replicated', depth=2, on_item=None, rank=None, world=None):
+        """positives_fn(s) -> (from, to) global positives of step s, or None when there is no step s (the thread ends).  on_item(item): called
+        on the producer thread with every (from, to, neg) shard before it is queued (the trainer starts image decodes there)."""
         self.graph, self.positives_fn, self.K, self.mode = graph, positives_fn, K, mode
+        self.on_item, self.rank, self.world = on_item, rank, world
         self.q = queue.Queue(maxsize=depth)
         self.step = 0
         self._stop = False
         self.th = threading.Thread(target=self._run, daemon=True)
         self.th.start()
 
+    def _put(self, x):
+        while not self._stop:
+            try:
+                self.q.put(x, timeout=0.1); return
+            except queue.Full:
+                pass
+
     def _run(self):
         s = 0
         try:
             while not self._stop:
-                frm, to = self.positives_fn(s)                 # global positives of step s (numpy int32)
+                pos = self.positives_fn(s)                     # global positives of step s (numpy int32)
+                if pos is None:
+                    self._put((-2, None)); return
+                frm, to = pos
+                lo, hi = shard_range(len(frm), self.rank, self.world)
                 if self.mode == 'replicated':
                     neg = self.graph.draw_batch(frm, to, self.K)
-                    lo, hi = shard_range(len(frm))
                     item = (frm[lo:hi], to[lo:hi], neg[lo:hi])
                 else:                                          # 'per_rank': independent stream per rank
-                    lo, hi = shard_range(len(frm))
                     item = (frm[lo:hi], to[lo:hi], self.graph.draw_batch(frm[lo:hi], to[lo:hi], self.K))
-                self.q.put((s, item))
+                if self.on_item is not None:
+                    self.on_item(item)
+                self._put((s, item))
                 s += 1
         except Exception as e:                                 # surface sampler errors in the consumer
-            self.q.put((-1, e))
+            self._put((-1, e))
 
     def next(self):
         s, item = self.q.get()
+        if s == -2:
+            raise StopIteration('no more steps to draw negatives for')
         if s < 0:
             raise item
         return item
@@ -417,3 +433,5 @@ class NegativePrefetcher:
                 self.q.get_nowait()
         except queue.Empty:
             pass
+        if self.th is not threading.current_thread():
+            self.th.join(timeout=5.0)                           # the sampler is the caller's again only once the producer has left it

@@ -533,3 +533,22 @@ def dense_negative_adjacency(n_labels, label_edges, image_leaf=None):
             A[a, n_labels + j] = 0
     np.fill_diagonal(A, 0)
     return A
+
+
+# --------------------------------------------------------------------------------------------
+# image tensors of a step (network/oe_h.py:668-677, 700-712, 1463-1471)
+# --------------------------------------------------------------------------------------------
+def image_batch(u8, flips=None, c_out=3):
+    """What the reference's transforms make of RESIZED uint8 images `u8` [n, H, W, 3] (the output of
+    cv2.imread -> ToPILImage -> Resize((224, 224)), oe_h.py:623-626 / 1464-1471; channel order as decoded):
+    RandomHorizontalFlip (oe_h.py:1465, train items only: `flips[i]` is its coin) mirrors along W, then
+    ToTensor = HWC uint8 -> CHW float32, `img.to(float32).div(255)` (torchvision functional.to_tensor,
+    third party: pinned by tests/test_image_store_cpu.py against torch's own uint8 -> float32 division).
+    Returned [n, c_out, H, W] float32; c_out = 4 appends the zero channel the f32 stem kernel consumes."""
+    u8 = np.asarray(u8)
+    assert u8.dtype == np.uint8 and u8.ndim == 4 and u8.shape[3] == 3
+    out = np.zeros((u8.shape[0], c_out, u8.shape[1], u8.shape[2]), dtype=F32)
+    for i in range(u8.shape[0]):
+        a = u8[i, :, ::-1, :] if (flips is not None and flips[i]) else u8[i]
+        out[i, :3] = np.transpose(a, (2, 0, 1)).astype(F32) / F32(255)
+    return out
