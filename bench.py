@@ -147,7 +147,7 @@ def measure(args, dtype, rank, world, stamp, primary):
     collect the per-kernel probes.  Returns (result dict for rank 0, engine) -- the engine is still open."""
     import torch
     import torch.distributed as dist
-    from learning_embeddings_amd import ops
+    from learning_embeddings_amd import _lib
     from learning_embeddings_amd.engine import StepEngine, WORKLOADS
     from learning_embeddings_amd.resnet import conv_macs
     eng = StepEngine(args.workload, dtype=dtype, sampler_mode=args.sampler, batch=args.batch, overlap_wgrad=False if args.no_overlap_wgrad else args.overlap_wgrad,
@@ -195,7 +195,7 @@ def measure(args, dtype, rank, world, stamp, primary):
     eng.enable_timers()
     auto_eager = launch_probe is not None and launch_probe['chosen'] == 'eager'
     if auto_eager:
-        ops.BN_TIMER = None; ops.CONV_TIMER = None              # per-kernel events only in the probe steps after the timed region
+        eng.kernel_timers(False)                                # per-kernel events only in the probe steps after the timed region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -245,12 +245,12 @@ def measure(args, dtype, rank, world, stamp, primary):
             eng.step()
         probe_step(); torch.cuda.synchronize()
         eng.timers['records'] = [r for r in eng.timers['records'] if len(r) == 4]
-        ops.BN_TIMER = []; ops.CONV_TIMER = []
+        eng.kernel_timers(True)
         for _ in range(3 if primary else 2):
             probe_step()
         torch.cuda.synchronize()
     elif auto_eager:
-        ops.BN_TIMER = []; ops.CONV_TIMER = []
+        eng.kernel_timers(True)
         n_rec = len(eng.timers['records'])
         for _ in range(3 if primary else 2):
             eng.step()
@@ -263,17 +263,20 @@ def measure(args, dtype, rank, world, stamp, primary):
     if primary and eng.overlap is not None and (eng.overlap.side is not None or eng.passes > 1) and ('fused_bn' in phases or 'conv_f32' in phases):
         side, n_pass = eng.overlap.side, eng.passes
         eng.overlap.side = None; eng.passes = 1                 # one stream, one pass: every kernel has the GPU to itself
-        ops.BN_TIMER = []; ops.CONV_TIMER = []
+        sched = eng.backbone.conv_schedule
+        if n_pass > 1:
+            eng.backbone.conv_schedule = _lib.SCHEDULE_TILE_WALK    # the SAME kernels the timed multi-pass step runs (it never takes the balanced form)
+        tm = eng.kernel_timers(True)
         n_iso = 2
         for _ in range(n_iso):
             eng.step()
         torch.cuda.synchronize()
-        if ops.BN_TIMER:
-            bn_isolated = sum(a.elapsed_time(b) for a, b, _ in ops.BN_TIMER) / n_iso
-        if ops.CONV_TIMER:
-            conv_isolated = sum(a.elapsed_time(b) for a, b, _ in ops.CONV_TIMER) / n_iso
-        eng.overlap.side = side; eng.passes = n_pass
-    ops.BN_TIMER = None; ops.CONV_TIMER = None
+        if tm['bn']:
+            bn_isolated = sum(a.elapsed_time(b) for a, b, _ in tm['bn']) / n_iso
+        if tm['conv']:
+            conv_isolated = sum(a.elapsed_time(b) for a, b, _ in tm['conv']) / n_iso
+        eng.overlap.side = side; eng.passes = n_pass; eng.backbone.conv_schedule = sched
+    eng.kernel_timers(False)
     if graph_mode:
         eng.set_launch_mode(True)
     loss_mean = float(eng.loss_acc.item()) / max(eng.step_no, 1)
@@ -440,10 +443,10 @@ def measure_classifier(args, dtype, rank, world, stamp):
                          'achieved': round(flops / step_s / 1e12, 3), 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': round(flops / step_s / 1e12 / peak_tf, 5), 'traffic': None}}
 
 
-def measure_trainer(args, dtype, stamp, n_steps, n_warm):
-    """The same cfg3 step driven through the reference's trainer API instead of the synthetic-input engine: JointEmbeddings
-    (oe_h.py:1318-1774 mirror) built from create_combined_graphs, its DataLoader / my_collate / criterion call / train_step,
-    on in-memory images that are resident in HBM.  Eager launches (the batch composition varies from step to step)."""
+def _bench_trainer(args, dtype, M, MV, path_of, n_workers, **kw):
+    """JointEmbeddings (oe_h.py:1318-1774 mirror) over the workload's hierarchy with M train images whose "path" is path_of(j): an
+    in-memory tensor (resident in HBM) or an image file.  The dataset holds the (label, image) positives only: every batch entry brings
+    an image, like the engine's batch."""
     import tempfile
     import numpy as np, torch
     from learning_embeddings_amd import oe_h
@@ -452,10 +455,6 @@ def measure_trainer(args, dtype, stamp, n_steps, n_warm):
     hier, arch, B, K, D, hw = WORKLOADS[args.workload]
     B = args.batch or B
     lm = make_labelmap(hier)
-    M, P = 4096, 2 * B
-    dev = torch.device('cuda', torch.cuda.current_device())
-    g = torch.Generator(device='cpu').manual_seed(1234)
-    pool = torch.rand(P, 3, hw, hw, generator=g).to(dev)
     L = len(lm.levels)
     par = lm.parents()
     def chain(j):
@@ -469,9 +468,8 @@ def measure_trainer(args, dtype, stamp, n_steps, n_warm):
         for i in range(lo, hi, bs):
             js = list(range(i, min(i + bs, hi)))
             out.append({'level_labels': np.asarray([chain(j) for j in js]), 'image_filename': ['img_%06d' % j for j in js],
-                        'path_to_image': [pool[j % P] for j in js]})
+                        'path_to_image': [path_of(j) for j in js]})
         return out
-    MV = 1000                                                   # evaluation split: every leaf occurs (the metric code wants each label present)
     dl = {'train': loader(0, M), 'val': loader(M, M + MV), 'test': loader(M + MV, M + MV + 16)}
     gd = oe_h.create_combined_graphs(dl, lm, pick_per_level=True)
     li = DiGraph()                                               # the (label, image) positives only: every batch entry brings an image
@@ -481,10 +479,98 @@ def measure_trainer(args, dtype, stamp, n_steps, n_warm):
     gd = dict(gd, G_train_tc=li)
     crit = oe_h.EuclideanConesWithImagesHypernymLoss(lm, K, {}, 0.01, pick_per_level=True, K=0.1, use_CNN=True)
     tmp = tempfile.mkdtemp(prefix='lec_bench_')
-    tr = oe_h.JointEmbeddings(gd, dl, image_dir='', use_CNN=True, labelmap=lm, criterion=crit, lr=1e-4, n_workers=0, batch_size=B,
+    tr = oe_h.JointEmbeddings(gd, dl, image_dir='', use_CNN=True, labelmap=lm, criterion=crit, lr=1e-4, n_workers=n_workers, batch_size=B,
                                experiment_name='bench', embedding_dim=D, neg_to_pos_ratio=K, image_fc7=None, normalize=None, alpha=0.01,
                                experiment_dir=tmp, n_epochs=1, eval_interval=10, model_name=arch,
-                               compute_dtype=torch.float32 if dtype == 'fp32' else torch.bfloat16)
+                               compute_dtype=torch.float32 if dtype == 'fp32' else torch.bfloat16, **kw)
+    return tr, crit, dl, (hier, arch, B, K, D, hw)
+
+
+def write_image_files(d, n, w=400, h=300, seed=0):
+    """n synthetic JPEG files (quality 90, w x h: smooth colour fields + texture, so that the decoder does real entropy decoding and IDCT
+    work).  Returns the paths."""
+    import numpy as np
+    from PIL import Image
+    r = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    tex = r.randint(0, 48, size=(h, w, 3)).astype(np.int16)
+    bases = []
+    for _ in range(8):
+        ph = r.rand(3) * 6.28; fx = 0.01 + r.rand(3) * 0.04; fy = 0.01 + r.rand(3) * 0.04
+        bases.append(np.stack([127 + 100 * np.sin(fx[c] * xx + fy[c] * yy + ph[c]) for c in range(3)], axis=2).astype(np.int16))
+    def one(j):                                                 # every file differs: a base field and the texture, each shifted by its own amount
+        img = np.roll(bases[j % 8], (j * 13) % w, axis=1) + np.roll(tex, (j * 7) % h, axis=0)
+        p = os.path.join(d, 'img_%06d.jpg' % j)
+        Image.fromarray(np.clip(img, 0, 255).astype(np.uint8)).save(p, quality=90)
+        return p
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:      # the JPEG encoder releases the GIL
+        return list(ex.map(one, range(n)))
+
+
+def measure_trainer_files(args, dtype, stamp, n_images=2048, epochs=3):
+    """The drop-in trainer fed from image FILES (VERDICT r03 "what's missing" #1): JointEmbeddings.train_epoch over its own
+    DataLoader (n_workers > 0) with the HBM image store (image_store.py).  Epoch 1 is cold: every image is decoded once -- positives by the
+    DataLoader workers, negatives one step ahead by the store's decode pool -- and uploaded as uint8; from epoch 2 on every image of a
+    step is resident and the step's float batch is one gather kernel.  Reported: per-epoch ms/step and images/s, the decode rate of epoch 1
+    and the host's core count."""
+    import shutil, tempfile
+    import numpy as np, torch
+    cores = os.cpu_count() or 1
+    n_workers = max(2, min(8, cores // 4))
+    d = tempfile.mkdtemp(prefix='lec_bench_imgs_')
+    t0 = time.perf_counter()
+    MV = 64
+    paths = write_image_files(d, n_images + MV + 16)
+    t_write = time.perf_counter() - t0
+    stamp('through-trainer-files: %d JPEG files written in %.1f s' % (len(paths), t_write))
+    try:
+        tr, crit, dl, (hier, arch, B, K, D, hw) = _bench_trainer(args, dtype, n_images, MV, lambda j: paths[j], n_workers)
+        st = tr.image_store
+        per_epoch = []
+        for ep in range(epochs):
+            tr.epoch = ep
+            rows = []
+            before = dict(st.stats)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            running, steps = tr.train_epoch(on_step=lambda s_: rows.append(crit.last_cnn_rows))
+            torch.cuda.synchronize(); dt = time.perf_counter() - t1
+            dec = (st.stats['decoded_here'] - before['decoded_here']) + (st.stats['decoded_by_workers'] - before['decoded_by_workers'])
+            per_epoch.append({'epoch': ep + 1, 'steps': steps, 'seconds': round(dt, 3), 'ms_per_step': round(dt / steps * 1e3, 3),
+                              'images_per_s': round(B * steps / dt, 2), 'cnn_rows_per_step': round(float(np.mean(rows)), 1),
+                              'files_decoded': int(dec), 'decodes_per_s': round(dec / dt, 1) if dec else 0.0,
+                              'uploaded_mb': round((st.stats['upload_bytes'] - before['upload_bytes']) / 1e6, 1),
+                              'mean_loss_per_positive': round(float(running) / (steps * B), 5)})
+            stamp('through-trainer-files %s: epoch %d: %d steps, %.1f ms/step, %d files decoded' % (dtype, ep + 1, steps, dt / steps * 1e3, dec))
+        warm = per_epoch[1:] or per_epoch
+        ms = float(np.mean([e['ms_per_step'] for e in warm]))
+        tr.image_store.close()
+        return {'value': round(B / ms * 1e3, 2), 'unit': 'images/sec', 'ms_per_step': round(ms, 3), 'dtype': 'f32' if dtype == 'fp32' else dtype,
+                'what': 'epochs >= 2 (every image resident in the HBM store); epoch 1 (cold: decode + upload) is in `epochs`',
+                'epochs': per_epoch, 'cnn_rows_per_step': round(float(np.mean([e['cnn_rows_per_step'] for e in warm])), 1),
+                'image_files': {'count': n_images, 'format': 'JPEG quality 90, 400x300', 'store_slots': st.capacity, 'store_bytes_per_image': hw * hw * 3,
+                                'decoder': 'PIL (libjpeg-turbo) + bilinear resize to %dx%d' % (hw, hw)},
+                'host': {'cores': cores, 'dataloader_workers': n_workers, 'decode_threads': n_workers},
+                'launch_mode': 'eager',
+                'api': 'JointEmbeddings.train_epoch over its own DataLoader / my_collate / criterion(...) (oe_h.py:1734-1774 mirror) on image files'}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def measure_trainer(args, dtype, stamp, n_steps, n_warm):
+    """The same cfg3 step driven through the reference's trainer API instead of the synthetic-input engine: JointEmbeddings
+    (oe_h.py:1318-1774 mirror) built from create_combined_graphs, its DataLoader / my_collate / criterion call / train_step,
+    on in-memory images that are resident in HBM.  Eager launches (the batch composition varies from step to step)."""
+    import numpy as np, torch
+    from learning_embeddings_amd.engine import WORKLOADS
+    M = 2048
+    hw = WORKLOADS[args.workload][5]
+    P = 2 * (args.batch or WORKLOADS[args.workload][2])
+    dev = torch.device('cuda', torch.cuda.current_device())
+    g = torch.Generator(device='cpu').manual_seed(1234)
+    pool = torch.rand(P, 3, hw, hw, generator=g).to(dev)
+    MV = 1000                                                   # evaluation split: every leaf occurs (the metric code wants each label present)
+    tr, crit, dl, (hier, arch, B, K, D, hw) = _bench_trainer(args, dtype, M, MV, lambda j: pool[j % P], 0)
     crit.set_dataloader(tr.datasets['train'])
     tr.model.train(); tr.img_feat_net.train()
     it = iter(tr.dataloaders['train'])
@@ -550,6 +636,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='same as --launch eager')
     ap.add_argument('--cudnn-benchmark', action='store_true', help='let MIOpen benchmark every solver per conv shape (slow start)')
     ap.add_argument('--through-trainer', type=int, default=8, help='also time N steps of the same workload driven through JointEmbeddings.train_step (0: skip)')
+    ap.add_argument('--through-trainer-files', type=int, default=2048,
+                    help='also run the trainer from this many synthetic JPEG FILES through the HBM image store, three epochs (0: skip)')
     args = ap.parse_args()
     if args.no_graph:
         args.launch = 'eager'
@@ -681,6 +769,12 @@ def main():
         tt['vs_engine_per_cnn_row'] = round((tt['cnn_rows_per_step'] / tt['ms_per_step']) / (out['config']['cnn_rows_per_step_per_gpu'] / out['ms_per_step']), 4)
         out['through_trainer'] = tt
         torch.cuda.empty_cache()
+        if args.through_trainer_files > 0:
+            tf = measure_trainer_files(args, args.dtype, stamp, n_images=args.through_trainer_files)
+            tf['vs_through_trainer'] = round(tf['value'] / tt['value'], 4)
+            tf['vs_through_trainer_per_cnn_row'] = round((tf['cnn_rows_per_step'] / tf['ms_per_step']) / (tt['cnn_rows_per_step'] / tt['ms_per_step']), 4)
+            out['through_trainer_files'] = tf
+            torch.cuda.empty_cache()
 
     if args.dtype == 'fp32' and args.conv_f32 == 'native' and args.secondary != 'none' and args.workload in ('cfg2', 'cfg3', 'cfg3_ethec'):
         # the same fp32 step with the convolutions' fp32 products computed on the bf16 matrix cores (csrc/conv_f32x3.hip)

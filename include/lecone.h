@@ -244,7 +244,7 @@ int lec_bn_fwd(const void* x, const void* residual, int64_t M, int C, const floa
                lec_stream_t stream);
 int lec_bn_bwd(const void* dy, const void* dy2, const void* y, const uint8_t* relu_mask, const void* x, int64_t M, int C,
                const float* gamma, const float* save_mean, const float* save_invstd, void* dx, void* dresidual,
-               float* dgamma, float* dbeta, int relu, void* workspace, int64_t workspace_bytes, lec_stream_t stream);
+               float* dgamma, float* dbeta, int relu, void* workspace, int64_t workspace_bytes, int accumulate, lec_stream_t stream);
 /* The same kernels on fp32 activations -- the reference's own precision (oe_h.py:281-328 runs torchvision's ResNet in fp32,
  * no AMP anywhere): x, residual, y, dy, dy2, dx, dresidual are fp32 [M, C]; everything else as above.  The `_f32` twins of the
  * staged entry points further down (lec_bn_fwd_prestat, lec_bn_bwd_pass1 / _apply / _prereduced) and of the max pooling follow
@@ -255,7 +255,7 @@ int lec_bn_fwd_f32(const void* x, const void* residual, int64_t M, int C, const 
                    lec_stream_t stream);
 int lec_bn_bwd_f32(const void* dy, const void* dy2, const void* y, const uint8_t* relu_mask, const void* x, int64_t M, int C,
                    const float* gamma, const float* save_mean, const float* save_invstd, void* dx, void* dresidual,
-                   float* dgamma, float* dbeta, int relu, void* workspace, int64_t workspace_bytes, lec_stream_t stream);
+                   float* dgamma, float* dbeta, int relu, void* workspace, int64_t workspace_bytes, int accumulate, lec_stream_t stream);
 
 /* 1x1 stride-1 convolution on NHWC bf16 as an HBM-bound MFMA GEMM, y[M, Cout] = x[M, Cin] * w[Cout, Cin]^T, optionally with
  * the BatchNorm statistics of its output in the epilogue: replaces the library convolution AND the statistics pass of
@@ -301,10 +301,10 @@ int lec_conv1x1_dgrad_bnfold(const void* dy, const void* w, int w_transposed, in
  * g itself. */
 int lec_bn_bwd_prereduced(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean,
                           const float* save_invstd, int n_partials, void* dx, float* dgamma, float* dbeta, void* workspace,
-                          int64_t workspace_bytes, lec_stream_t stream);
+                          int64_t workspace_bytes, int accumulate, lec_stream_t stream);
 int lec_bn_bwd_prereduced_f32(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean,
                               const float* save_invstd, int n_partials, void* dx, float* dgamma, float* dbeta, void* workspace,
-                              int64_t workspace_bytes, lec_stream_t stream);
+                              int64_t workspace_bytes, int accumulate, lec_stream_t stream);
 /* Weight gradient of the 3x3 / stride 1 / pad 1 / 64 -> 64 convolution (torchvision Bottleneck.conv2 of layer1, reached from
  * oe_h.py:311,317): dw[co][ky][kx][ci] (fp32, the channels_last weight layout) += sum over pixels of dy[.., co] * x[shifted by tap, ci],
  * accumulated with float atomics into the caller's gradient buffer.  dy, x: [N, H, W, 64] bf16; H % 8 == 0 and W % 8 == 0. */
@@ -315,13 +315,13 @@ int lec_conv3x3_c64_wgrad(const void* dy, const void* x, int N, int H, int W, fl
  * into the workspace).  lec_bn_bwd_finalize: the finalize alone, from n_partials partial rows a convolution epilogue left.
  * lec_bn_bwd_apply: pass 2 alone (dx from g, x and the c1, c2 in the workspace). */
 int lec_bn_bwd_pass1(const void* dy, const void* dy2, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* save_mean,
-                     const float* save_invstd, void* g, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, lec_stream_t stream);
+                     const float* save_invstd, void* g, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, int accumulate, lec_stream_t stream);
 int lec_bn_bwd_finalize(int64_t M, int C, int n_partials, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
-                        lec_stream_t stream);
+                        int accumulate, lec_stream_t stream);
 int lec_bn_bwd_apply(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd,
                      void* dx, void* workspace, int64_t workspace_bytes, lec_stream_t stream);
 int lec_bn_bwd_pass1_f32(const void* dy, const void* dy2, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* save_mean,
-                         const float* save_invstd, void* g, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, lec_stream_t stream);
+                         const float* save_invstd, void* g, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, int accumulate, lec_stream_t stream);
 int lec_bn_bwd_apply_f32(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd,
                          void* dx, void* workspace, int64_t workspace_bytes, lec_stream_t stream);
 /* conv3 behind bn3, backward: the weight gradient of the 1x1 layer AND pass 2 of the BatchNorm backward in one kernel.  g [M, Cout] is
@@ -374,9 +374,9 @@ int lec_bn_fwd_prestat_f32(const void* x, const void* residual, int64_t M, int C
  *     lec_conv_f32_wgrad: dw += (float atomics over the split reduction; zero it first for a plain gradient).
  * ------------------------------------------------------------------------------------------------------------- */
 int lec_conv_f32_fwd(const float* x, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
-                     float* y, float* partials, int64_t partials_bytes, int* n_partials, lec_stream_t stream);
+                     float* y, float* partials, int64_t partials_bytes, int* n_partials, int schedule, lec_stream_t stream);
 int lec_conv_f32_dgrad(const float* dy, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
-                       float* dx, lec_stream_t stream);
+                       float* dx, int schedule, lec_stream_t stream);
 /*     lec_conv_f32_fwd_affine: the forward of an EVAL-mode network (FeatCNN.eval(): calculate_classification_metrics' image embedding in
  *       the 'val' / 'test' phases, oe_h.py:1989-2011): y = [relu](conv(x, w) * scale[c] + shift[c] [+ res]) with scale = gamma / sqrt(running_var
  *       + eps), shift = beta - running_mean * scale -- F.batch_norm(training=False) (+ the block's residual add and ReLU) in the convolution's
@@ -387,7 +387,7 @@ int lec_conv_f32_dgrad(const float* dy, const float* w, int N, int H, int W, int
 int lec_bn_eval_coeffs_f32(int C, const float* gamma, const float* beta, float eps, const float* running_mean, const float* running_var,
                            float* scale, float* shift, lec_stream_t stream);
 int lec_conv_f32_fwd_affine(const float* x, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
-                            float* y, const float* scale, const float* shift, const float* res, int relu, lec_stream_t stream);
+                            float* y, const float* scale, const float* shift, const float* res, int relu, int schedule, lec_stream_t stream);
 /*     Fused BatchNorm pieces (the fp32 convolutions are bound by the matrix pipe and leave HBM idle; BatchNorm passes are the reverse:
  *     what moves from a BatchNorm pass into a convolution's loader or epilogue is hidden).  torchvision Bottleneck's
  *     relu(bn(conv(.))) chain reached from oe_h.py:311,317, backward:
@@ -406,7 +406,7 @@ int lec_conv_f32_fwd_affine(const float* x, const float* w, int N, int H, int W,
 int lec_conv_f32_dgrad_fused(const float* dy, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                              float* dx, const float* xsrc, const float* coef, const float* dres, const float* xbn, const uint8_t* mask,
                              const float* mean, const float* invstd, float* partials, int64_t partials_bytes, int* n_partials,
-                             lec_stream_t stream);
+                             int schedule, lec_stream_t stream);
 int lec_conv_f32_wgrad_fused(const float* dy, const float* x, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                              float* dw, const float* xsrc, const float* coef, lec_stream_t stream);
 /*     lec_conv_f32_wgrad_c3: the 3-channel stem.  x4 [N, H, W, 4] carries a zero 4th channel (the kernels want >= 4), dw3 is the layer's
@@ -415,11 +415,11 @@ int lec_conv_f32_wgrad_c3(const float* dy, const float* x4, int N, int H, int W,
                           float* dw3, lec_stream_t stream);
 int lec_bn_bwd_pass1_coeffs_f32(const void* dy, const void* dy2, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* gamma,
                                 const float* save_mean, const float* save_invstd, void* g, float* dgamma, float* dbeta, float* coef,
-                                void* workspace, int64_t workspace_bytes, lec_stream_t stream);   /* pass 1 as a kernel (writes g) + the same coefficients */
-/*     lec_bn_bwd_accumulate(1): from now on every BatchNorm backward of this process ADDS d gamma / d beta into its output slots (float
- *     atomics) instead of overwriting them -- for a step that runs several backward passes over the same parameters, possibly on
- *     concurrent streams, and zeroes the slots once per step.  Returns the previous setting (process-wide; set it before the steps). */
-int lec_bn_bwd_accumulate(int on);
+                                void* workspace, int64_t workspace_bytes, int accumulate, lec_stream_t stream);   /* pass 1 as a kernel (writes g) + the same coefficients */
+/*     `accumulate` (every BatchNorm backward entry point that produces d gamma / d beta: lec_bn_bwd, _pass1, _finalize, _prereduced,
+ *     _coeffs_f32, _pass1_coeffs_f32 and their _f32 twins): nonzero = ADD d gamma / d beta into the output slots (float atomics) instead of
+ *     overwriting them -- for a step that runs several backward passes over the same parameters, possibly on concurrent streams, and zeroes
+ *     the slots once per step.  A per-call argument: there is no process-wide switch, two trainers in one process do not see each other. */
 /*     lec_conv_f32_scratch: scratch for the BALANCED form of lec_conv_f32_fwd / the stride-1 data gradients on `stream`.  A launch whose 128 x 128
  *     output tiles would leave the last round of the chip's 512 workgroup slots mostly empty (ResNet-50 at the bench batch: 392 x 2^k tiles from
  *     layer2 on) is cut into 512 equal runs of (tile, K chunk) iterations instead; tiles whose chunks fall to several workgroups are summed through
@@ -429,11 +429,16 @@ int lec_bn_bwd_accumulate(int on);
  *     reach 2048 (the row count lec_bn_workspace_bytes provides for). */
 int64_t lec_conv_f32_scratch_bytes(void);
 int lec_conv_f32_scratch(lec_stream_t stream, void* buf, int64_t bytes);
-/*     lec_conv_f32_balanced(mode): 0 never use the balanced form, 1 where it pays (default; LEC_CF_SK in the environment sets the start value),
- *     2 wherever it applies (tests), -1 only report.  Returns the mode in force before the call (process-wide). */
-int lec_conv_f32_balanced(int mode);
+/*     `schedule` (lec_conv_f32_fwd, _fwd_affine, _dgrad, _dgrad_fused): which of the two forms the call takes, per call (no process-wide switch):
+ *     LEC_SCHEDULE_DEFAULT what LEC_CF_SK in the environment says (default: AUTO), LEC_SCHEDULE_TILE_WALK never the balanced form (what a step
+ *     running concurrent passes wants: they fill each other's tails), LEC_SCHEDULE_AUTO the balanced form where it pays, LEC_SCHEDULE_BALANCED
+ *     wherever it applies (tests).  Both forms give the same values to the last few bits (the K sum is split differently). */
+#define LEC_SCHEDULE_DEFAULT   (-1)
+#define LEC_SCHEDULE_TILE_WALK   0
+#define LEC_SCHEDULE_AUTO        1
+#define LEC_SCHEDULE_BALANCED    2
 int lec_bn_bwd_coeffs_f32(int64_t M, int C, int n_partials, const float* gamma, const float* save_mean, const float* save_invstd,
-                          float* dgamma, float* dbeta, float* coef, void* workspace, int64_t workspace_bytes, lec_stream_t stream);
+                          float* dgamma, float* dbeta, float* coef, void* workspace, int64_t workspace_bytes, int accumulate, lec_stream_t stream);
 int lec_conv_f32_wgrad(const float* dy, const float* x, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                        float* dw, lec_stream_t stream);
 

@@ -5,12 +5,13 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LEC_LIB_PATH') or os.path.join(_HERE, 'liblecone.so')     # LEC_LIB_PATH: A/B builds of the same ABI
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 OK, E_ARG, E_HIP, E_EMPTY, E_STATE = 0, -1, -2, -3, -4
 ENERGY_HYP_CONE, ENERGY_ORDER, ENERGY_EUC_CONE = 0, 1, 2
 LABEL_RAW, LABEL_HYP, LABEL_SOFTCLIP_K = 0, 1, 2
 IMAGE_RAW, IMAGE_SOFTCLIP, IMAGE_SOFTCLIP_K = 0, 1, 2
+SCHEDULE_DEFAULT, SCHEDULE_TILE_WALK, SCHEDULE_AUTO, SCHEDULE_BALANCED = -1, 0, 1, 2
 
 
 class LeconeError(RuntimeError):
@@ -72,7 +73,7 @@ def _load():
         'lec_multilevel_ce_fwd_bwd': (i32, [p, i64, p, i32, i32, p, p, p, i32, p, p, p, i64, p]),
         'lec_bn_workspace_bytes': (i64, [i32]),
         'lec_bn_fwd': (i32, [p, p, i64, i32, p, p, f32, f32, p, p, i32, p, p, p, i32, p, p, i64, p]),
-        'lec_bn_bwd': (i32, [p, p, p, p, p, i64, i32, p, p, p, p, p, p, p, i32, p, i64, p]),
+        'lec_bn_bwd': (i32, [p, p, p, p, p, i64, i32, p, p, p, p, p, p, p, i32, p, i64, i32, p]),
         'lec_conv1x1_supported': (i32, [i32, i32, i64]),
         'lec_conv1x1_fwd': (i32, [p, p, i32, i64, i32, i32, p, p, i64, p, p]),
         'lec_conv1x1_bnapply_supported': (i32, [i32, i32, i64]),
@@ -82,11 +83,11 @@ def _load():
         'lec_conv1x1_fwd_bnapply': (i32, [p, p, i64, i32, i32, p, p, p, p, p, p, p]),
         'lec_conv1x1_dgrad_bnfold_supported': (i32, [i32, i32, i64]),
         'lec_conv1x1_dgrad_bnfold': (i32, [p, p, i32, i64, i32, i32, p, p, p, p, p, p, p, i64, p, p]),
-        'lec_bn_bwd_prereduced': (i32, [p, p, i64, i32, p, p, p, i32, p, p, p, p, i64, p]),
+        'lec_bn_bwd_prereduced': (i32, [p, p, i64, i32, p, p, p, i32, p, p, p, p, i64, i32, p]),
         'lec_conv3x3_c64_wgrad_supported': (i32, [i32, i32, i32]),
         'lec_conv3x3_c64_wgrad': (i32, [p, p, i32, i32, i32, p, p]),
-        'lec_bn_bwd_pass1': (i32, [p, p, p, p, i64, i32, p, p, p, p, p, p, i64, p]),
-        'lec_bn_bwd_finalize': (i32, [i64, i32, i32, p, p, p, i64, p]),
+        'lec_bn_bwd_pass1': (i32, [p, p, p, p, i64, i32, p, p, p, p, p, p, i64, i32, p]),
+        'lec_bn_bwd_finalize': (i32, [i64, i32, i32, p, p, p, i64, i32, p]),
         'lec_bn_bwd_apply': (i32, [p, p, i64, i32, p, p, p, p, p, i64, p]),
         'lec_conv1x1_wgrad_bnapply_supported': (i32, [i32, i32, i64]),
         'lec_conv1x1_wgrad_bnapply': (i32, [p, p, p, i64, i32, i32, p, p, p, p, p, p, p, p]),
@@ -95,20 +96,18 @@ def _load():
         'lec_conv3x3_c64_fwd': (i32, [p, p, i32, i32, i32, i32, p, p, i64, p, p]),
         'lec_conv3x3_c128_fwd': (i32, [p, p, i32, i32, i32, p, p, i64, p, p]),
         'lec_bn_fwd_prestat': (i32, [p, p, i64, i32, p, p, f32, f32, p, p, i32, p, p, p, i32, p, p, i64, p]),
-        'lec_conv_f32_fwd': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p, i64, p, p]),
-        'lec_conv_f32_fwd_affine': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p, p, p, i32, p]),
-        'lec_conv_f32_dgrad': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p]),
+        'lec_conv_f32_fwd': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p, i64, p, i32, p]),
+        'lec_conv_f32_fwd_affine': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p, p, p, i32, i32, p]),
+        'lec_conv_f32_dgrad': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, i32, p]),
         'lec_conv_f32_wgrad': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p]),
-        'lec_conv_f32_dgrad_fused': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p, p, p, p, p, p, p, p, i64, p, p]),
+        'lec_conv_f32_dgrad_fused': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p, p, p, p, p, p, p, p, i64, p, i32, p]),
         'lec_conv_f32_wgrad_c3': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, p, p]),
         'lec_conv_f32_wgrad_fused': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p, p, p]),
-        'lec_bn_bwd_accumulate': (i32, [i32]),
         'lec_bn_eval_coeffs_f32': (i32, [i32, p, p, f32, p, p, p, p, p]),
         'lec_conv_f32_scratch_bytes': (i64, []),
-        'lec_conv_f32_balanced': (i32, [i32]),
         'lec_conv_f32_scratch': (i32, [p, p, i64]),
-        'lec_bn_bwd_coeffs_f32': (i32, [i64, i32, i32, p, p, p, p, p, p, p, i64, p]),
-        'lec_bn_bwd_pass1_coeffs_f32': (i32, [p, p, p, p, i64, i32, p, p, p, p, p, p, p, p, i64, p]),
+        'lec_bn_bwd_coeffs_f32': (i32, [i64, i32, i32, p, p, p, p, p, p, p, i64, i32, p]),
+        'lec_bn_bwd_pass1_coeffs_f32': (i32, [p, p, p, p, i64, i32, p, p, p, p, p, p, p, p, i64, i32, p]),
         'lec_conv_f32x3_planes_elems': (i64, [i32, i32, i32, i32]),
         'lec_conv_f32x3_split_weights': (i32, [p, i32, i32, i32, p, p, p]),
         'lec_conv_f32x3_fwd': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p, i64, p, p]),

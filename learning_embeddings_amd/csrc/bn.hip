@@ -375,9 +375,8 @@ __global__ __launch_bounds__(kBnThreads) LEC_BN_REGS void bn_bwd_reduce_kernel(c
   }
 }
 
-// Parameter gradients: overwritten, or (lec_bn_bwd_accumulate(1)) ADDED with float atomics -- a step that runs several backward passes
-// over the same parameters, possibly on concurrent streams (the engine's half-batch passes), zeroes the slots once per step.
-static int g_bn_accumulate = 0;
+// Parameter gradients: overwritten, or (the entry point's `accumulate` argument) ADDED with float atomics -- a step that runs several backward
+// passes over the same parameters, possibly on concurrent streams (the engine's half-batch passes), zeroes the slots once per step.
 
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, int64_t M,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -459,10 +458,6 @@ static int bn_check(const char* who, int64_t M, int C) {
 
 }  // namespace lec
 
-extern "C" int lec_bn_bwd_accumulate(int on) {
-  const int prev = lec::g_bn_accumulate; lec::g_bn_accumulate = on ? 1 : 0; return prev;
-}
-
 extern "C" int64_t lec_bn_workspace_bytes(int C) {
   if (C <= 0) return LEC_E_ARG;
   return ((int64_t)lec::kBnMaxRows * 2 * C + 4 * (int64_t)C) * sizeof(float);
@@ -503,7 +498,7 @@ template <typename E> static int bn_fwd_impl(const void* x, const void* residual
 template <typename E> static int bn_bwd_impl(const void* dy, const void* dy2, const void* y, const uint8_t* relu_mask, const void* x, int64_t M, int C,
                           const float* gamma, const float* save_mean, const float* save_invstd, void* dx,
                           void* dresidual, float* dgamma, float* dbeta, int relu, void* workspace,
-                          int64_t workspace_bytes, lec_stream_t stream) {
+                          int64_t workspace_bytes, int accumulate, lec_stream_t stream) {
   using namespace lec;
   if (int rc = bn_check("bn_bwd", M, C)) return rc;
   LEC_CHECK_ARG(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && workspace, "bn_bwd: null pointer");
@@ -518,7 +513,7 @@ template <typename E> static int bn_bwd_impl(const void* dy, const void* dy2, co
 #define R(M_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<E, M_>), dim3(g.nrb, g.NCH), dim3(kBnThreads), 0, st, dy, dy2, ym, x, M, C, g.CV, g.CVB, g.RPIB, save_mean, save_invstd, part, dresidual)
   if (rm == 0) R(0); else if (rm == 1) R(1); else R(2);
 #undef R
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, g.nrb, C, M, dgamma, dbeta, c1, c2, g_bn_accumulate);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, g.nrb, C, M, dgamma, dbeta, c1, c2, accumulate ? 1 : 0);
   int64_t nb = (M + g.RPI - 1) / g.RPI; nb = (nb + 1) / 2;
   const int nblk = (int)(nb < 1 ? 1 : (nb > bn_apply_cap() ? bn_apply_cap() : nb));
 #define A(RES_, RELU_) hipLaunchKernelGGL((bn_bwd_apply_kernel<E, RES_, RELU_>), dim3(nblk), dim3(kBnThreads), 0, st, dy, dy2, ym, x, M, g.CV, g.RPI, gamma, save_mean, save_invstd, c1, c2, dx, dresidual)
@@ -569,7 +564,7 @@ extern "C" int lec_bn_fwd_finalize(int64_t M, int C, const float* gamma, const f
 // finalize alone (partials left by a convolution epilogue), and pass 2 alone from the c1 / c2 the finalize left in the workspace.
 template <typename E> static int bn_bwd_pass1_impl(const void* dy, const void* dy2, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* save_mean,
                                 const float* save_invstd, void* g, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
-                                lec_stream_t stream) {
+                                int accumulate, lec_stream_t stream) {
   using namespace lec;
   if (int rc = bn_check("bn_bwd_pass1", M, C)) return rc;
   LEC_CHECK_ARG(dy && x && save_mean && save_invstd && g && dgamma && dbeta && workspace, "bn_bwd_pass1: null pointer");
@@ -581,13 +576,13 @@ template <typename E> static int bn_bwd_pass1_impl(const void* dy, const void* d
 #define R(M_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<E, M_>), dim3(geo.nrb, geo.NCH), dim3(kBnThreads), 0, st, dy, dy2, relu_mask, x, M, C, geo.CV, geo.CVB, geo.RPIB, save_mean, save_invstd, part, g)
   if (relu_mask) R(2); else R(0);
 #undef R
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, geo.nrb, C, M, dgamma, dbeta, c1, c2, g_bn_accumulate);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, geo.nrb, C, M, dgamma, dbeta, c1, c2, accumulate ? 1 : 0);
   LEC_CHECK_LAUNCH("bn_bwd_pass1 kernels");
   return LEC_OK;
 }
 
 extern "C" int lec_bn_bwd_finalize(int64_t M, int C, int n_partials, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
-                                   lec_stream_t stream) {
+                                   int accumulate, lec_stream_t stream) {
   using namespace lec;
   if (int rc = bn_check("bn_bwd_finalize", M, C)) return rc;
   LEC_CHECK_ARG(dgamma && dbeta && workspace, "bn_bwd_finalize: null pointer");
@@ -596,20 +591,20 @@ extern "C" int lec_bn_bwd_finalize(int64_t M, int C, int n_partials, float* dgam
   float* part = (float*)workspace;
   float* c1 = part + (int64_t)kBnMaxRows * 2 * C; float* c2 = c1 + C;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, (hipStream_t)stream, part, n_partials, C, M, dgamma, dbeta,
-                     c1, c2, g_bn_accumulate);
+                     c1, c2, accumulate ? 1 : 0);
   LEC_CHECK_LAUNCH("bn_bwd_finalize_kernel");
   return LEC_OK;
 }
 
 extern "C" int lec_bn_bwd_coeffs_f32(int64_t M, int C, int n_partials, const float* gamma, const float* save_mean, const float* save_invstd,
-                                     float* dgamma, float* dbeta, float* coef, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+                                     float* dgamma, float* dbeta, float* coef, void* workspace, int64_t workspace_bytes, int accumulate, lec_stream_t stream) {
   using namespace lec;
   if (int rc = bn_check("bn_bwd_coeffs", M, C)) return rc;
   LEC_CHECK_ARG(gamma && save_mean && save_invstd && dgamma && dbeta && coef && workspace, "bn_bwd_coeffs: null pointer");
   LEC_CHECK_ARG(n_partials >= 1 && n_partials <= kBnMaxRows, "bn_bwd_coeffs: n_partials=%d outside 1..%d", n_partials, kBnMaxRows);
   LEC_CHECK_ARG(workspace_bytes >= lec_bn_workspace_bytes(C), "bn_bwd_coeffs: workspace too small");
   hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, (hipStream_t)stream, (const float*)workspace, n_partials, C, M,
-                     gamma, save_mean, save_invstd, dgamma, dbeta, coef, g_bn_accumulate);
+                     gamma, save_mean, save_invstd, dgamma, dbeta, coef, accumulate ? 1 : 0);
   LEC_CHECK_LAUNCH("bn_bwd_coeffs_kernel");
   return LEC_OK;
 }
@@ -617,7 +612,7 @@ extern "C" int lec_bn_bwd_coeffs_f32(int64_t M, int C, int n_partials, const flo
 // pass 1 (writes g = mask * (dy [+ dy2])) + the coefficient finalize, for a consumer that runs pass 2 on its operand load
 extern "C" int lec_bn_bwd_pass1_coeffs_f32(const void* dy, const void* dy2, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* gamma,
                                            const float* save_mean, const float* save_invstd, void* g, float* dgamma, float* dbeta, float* coef,
-                                           void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+                                           void* workspace, int64_t workspace_bytes, int accumulate, lec_stream_t stream) {
   using namespace lec;
   typedef EF32 E;
   if (int rc = bn_check("bn_bwd_pass1_coeffs", M, C)) return rc;
@@ -630,7 +625,7 @@ extern "C" int lec_bn_bwd_pass1_coeffs_f32(const void* dy, const void* dy2, cons
   if (relu_mask) R(2); else R(0);
 #undef R
   hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, geo.nrb, C, M, gamma, save_mean, save_invstd,
-                     dgamma, dbeta, coef, g_bn_accumulate);
+                     dgamma, dbeta, coef, accumulate ? 1 : 0);
   LEC_CHECK_LAUNCH("bn_bwd_pass1_coeffs kernels");
   return LEC_OK;
 }
@@ -653,7 +648,7 @@ template <typename E> static int bn_bwd_apply_impl(const void* g, const void* x,
 
 template <typename E> static int bn_bwd_prereduced_impl(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean,
                                      const float* save_invstd, int n_partials, void* dx, float* dgamma, float* dbeta, void* workspace,
-                                     int64_t workspace_bytes, lec_stream_t stream) {
+                                     int64_t workspace_bytes, int accumulate, lec_stream_t stream) {
   using namespace lec;
   if (int rc = bn_check("bn_bwd_prereduced", M, C)) return rc;
   LEC_CHECK_ARG(g && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && workspace, "bn_bwd_prereduced: null pointer");
@@ -663,7 +658,7 @@ template <typename E> static int bn_bwd_prereduced_impl(const void* g, const voi
   BnGeom geo = bn_geom(M, C);
   float* part = (float*)workspace;
   float* c1 = part + (int64_t)kBnMaxRows * 2 * C; float* c2 = c1 + C;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, n_partials, C, M, dgamma, dbeta, c1, c2, g_bn_accumulate);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, n_partials, C, M, dgamma, dbeta, c1, c2, accumulate ? 1 : 0);
   int64_t nb = (M + geo.RPI - 1) / geo.RPI; nb = (nb + 1) / 2;
   const int nblk = (int)(nb < 1 ? 1 : (nb > bn_apply_cap() ? bn_apply_cap() : nb));
   hipLaunchKernelGGL((bn_bwd_apply_kernel<E, false, 0>), dim3(nblk), dim3(kBnThreads), 0, st, g, nullptr,
@@ -688,17 +683,17 @@ extern "C" int lec_bn_fwd(const void* x, const void* residual, int64_t M, int C,
 extern "C" int lec_bn_fwd_f32(const void* x, const void* residual, int64_t M, int C, const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var, int training, float* save_mean, float* save_invstd, void* y, int relu, uint8_t* relu_mask, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
   return bn_fwd_impl<lec::EF32>(x, residual, M, C, gamma, beta, eps, momentum, running_mean, running_var, training, save_mean, save_invstd, y, relu, relu_mask, workspace, workspace_bytes, stream);
 }
-extern "C" int lec_bn_bwd(const void* dy, const void* dy2, const void* y, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta, int relu, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
-  return bn_bwd_impl<lec::EBf16>(dy, dy2, y, relu_mask, x, M, C, gamma, save_mean, save_invstd, dx, dresidual, dgamma, dbeta, relu, workspace, workspace_bytes, stream);
+extern "C" int lec_bn_bwd(const void* dy, const void* dy2, const void* y, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta, int relu, void* workspace, int64_t workspace_bytes, int accumulate, lec_stream_t stream) {
+  return bn_bwd_impl<lec::EBf16>(dy, dy2, y, relu_mask, x, M, C, gamma, save_mean, save_invstd, dx, dresidual, dgamma, dbeta, relu, workspace, workspace_bytes, accumulate, stream);
 }
-extern "C" int lec_bn_bwd_f32(const void* dy, const void* dy2, const void* y, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta, int relu, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
-  return bn_bwd_impl<lec::EF32>(dy, dy2, y, relu_mask, x, M, C, gamma, save_mean, save_invstd, dx, dresidual, dgamma, dbeta, relu, workspace, workspace_bytes, stream);
+extern "C" int lec_bn_bwd_f32(const void* dy, const void* dy2, const void* y, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta, int relu, void* workspace, int64_t workspace_bytes, int accumulate, lec_stream_t stream) {
+  return bn_bwd_impl<lec::EF32>(dy, dy2, y, relu_mask, x, M, C, gamma, save_mean, save_invstd, dx, dresidual, dgamma, dbeta, relu, workspace, workspace_bytes, accumulate, stream);
 }
-extern "C" int lec_bn_bwd_pass1(const void* dy, const void* dy2, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* save_mean, const float* save_invstd, void* g, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
-  return bn_bwd_pass1_impl<lec::EBf16>(dy, dy2, relu_mask, x, M, C, save_mean, save_invstd, g, dgamma, dbeta, workspace, workspace_bytes, stream);
+extern "C" int lec_bn_bwd_pass1(const void* dy, const void* dy2, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* save_mean, const float* save_invstd, void* g, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, int accumulate, lec_stream_t stream) {
+  return bn_bwd_pass1_impl<lec::EBf16>(dy, dy2, relu_mask, x, M, C, save_mean, save_invstd, g, dgamma, dbeta, workspace, workspace_bytes, accumulate, stream);
 }
-extern "C" int lec_bn_bwd_pass1_f32(const void* dy, const void* dy2, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* save_mean, const float* save_invstd, void* g, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
-  return bn_bwd_pass1_impl<lec::EF32>(dy, dy2, relu_mask, x, M, C, save_mean, save_invstd, g, dgamma, dbeta, workspace, workspace_bytes, stream);
+extern "C" int lec_bn_bwd_pass1_f32(const void* dy, const void* dy2, const uint8_t* relu_mask, const void* x, int64_t M, int C, const float* save_mean, const float* save_invstd, void* g, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, int accumulate, lec_stream_t stream) {
+  return bn_bwd_pass1_impl<lec::EF32>(dy, dy2, relu_mask, x, M, C, save_mean, save_invstd, g, dgamma, dbeta, workspace, workspace_bytes, accumulate, stream);
 }
 extern "C" int lec_bn_bwd_apply(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd, void* dx, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
   return bn_bwd_apply_impl<lec::EBf16>(g, x, M, C, gamma, save_mean, save_invstd, dx, workspace, workspace_bytes, stream);
@@ -706,11 +701,11 @@ extern "C" int lec_bn_bwd_apply(const void* g, const void* x, int64_t M, int C, 
 extern "C" int lec_bn_bwd_apply_f32(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd, void* dx, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
   return bn_bwd_apply_impl<lec::EF32>(g, x, M, C, gamma, save_mean, save_invstd, dx, workspace, workspace_bytes, stream);
 }
-extern "C" int lec_bn_bwd_prereduced(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd, int n_partials, void* dx, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
-  return bn_bwd_prereduced_impl<lec::EBf16>(g, x, M, C, gamma, save_mean, save_invstd, n_partials, dx, dgamma, dbeta, workspace, workspace_bytes, stream);
+extern "C" int lec_bn_bwd_prereduced(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd, int n_partials, void* dx, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, int accumulate, lec_stream_t stream) {
+  return bn_bwd_prereduced_impl<lec::EBf16>(g, x, M, C, gamma, save_mean, save_invstd, n_partials, dx, dgamma, dbeta, workspace, workspace_bytes, accumulate, stream);
 }
-extern "C" int lec_bn_bwd_prereduced_f32(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd, int n_partials, void* dx, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
-  return bn_bwd_prereduced_impl<lec::EF32>(g, x, M, C, gamma, save_mean, save_invstd, n_partials, dx, dgamma, dbeta, workspace, workspace_bytes, stream);
+extern "C" int lec_bn_bwd_prereduced_f32(const void* g, const void* x, int64_t M, int C, const float* gamma, const float* save_mean, const float* save_invstd, int n_partials, void* dx, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, int accumulate, lec_stream_t stream) {
+  return bn_bwd_prereduced_impl<lec::EF32>(g, x, M, C, gamma, save_mean, save_invstd, n_partials, dx, dgamma, dbeta, workspace, workspace_bytes, accumulate, stream);
 }
 extern "C" int lec_bn_fwd_prestat(const void* x, const void* residual, int64_t M, int C, const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var, int n_partials, float* save_mean, float* save_invstd, void* y, int relu, uint8_t* relu_mask, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
   return bn_fwd_prestat_impl<lec::EBf16>(x, residual, M, C, gamma, beta, eps, momentum, running_mean, running_var, n_partials, save_mean, save_invstd, y, relu, relu_mask, workspace, workspace_bytes, stream);

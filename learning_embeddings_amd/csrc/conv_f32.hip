@@ -1075,25 +1075,24 @@ static inline bool sk_lookup(hipStream_t st, SkScratch* out) {
 }
 // LEC_CF_SK: 0 never, 1 (default) where the tile count leaves the last round of workgroup slots under LEC_CF_SK_FILL (default 0.92) full, 2 wherever
 // the kernel applies (tests).
-static std::atomic<int> g_sk_mode{-1};      // lec_conv_f32_balanced(): overrides the environment
-static inline int sk_mode() {
+// The entry points' `schedule` argument (LEC_SCHEDULE_*) decides per call; LEC_SCHEDULE_DEFAULT (-1) defers to the environment.
+static inline int sk_mode(int schedule) {
   static const int env = [] { const char* e = getenv("LEC_CF_SK"); return e ? atoi(e) : 1; }();
-  const int m = g_sk_mode.load(std::memory_order_relaxed);
-  return m >= 0 ? m : env;
+  return schedule >= 0 ? (schedule > 2 ? 2 : schedule) : env;
 }
 static inline double sk_fill() { static const double v = [] { const char* e = getenv("LEC_CF_SK_FILL"); return e ? atof(e) : 0.92; }(); return v; }
 static inline int sk_min_chunks() { static const int v = [] { const char* e = getenv("LEC_CF_SK_MIN_CHUNKS"); return e ? atoi(e) : 8; }(); return v; }
 
 template <bool B_KC, bool STATS, int FUSE = 0>
 static int launch_act(const float* src, const float* wgt, float* dst, const ActGeo& g, float* part, int* nparts, hipStream_t st,
-                      const ActFuse& fz = ActFuse{}, int part_rows = kCfMaxPart) {
+                      const ActFuse& fz = ActFuse{}, int part_rows = kCfMaxPart, int schedule = -1) {
   // column tile: 128 wide unless the layer has 64 output channels
   const bool narrow = g.Cd <= 64;
   const int BM = 128, BN = narrow ? 64 : 128;
   const int mtiles = (g.Mg + BM - 1) / BM, ntiles = (g.Cd + BN - 1) / BN;
   if constexpr ((FUSE & 1) == 0) {
     // the balanced form: 128 x 128 tiles of a dense destination, whole-tap chunks (see conv_f32_act_sk_kernel)
-    const int mode = sk_mode();
+    const int mode = sk_mode(schedule);
     const long long tiles = (long long)mtiles * ntiles;
     const int nchunks = (g.Kg + kCfBK - 1) / kCfBK;
     SkScratch sc;
@@ -1173,12 +1172,8 @@ static int launch_act(const float* src, const float* wgt, float* dst, const ActG
 // Scratch of the balanced forward / data-gradient kernel for the launches of ONE stream: `buf` holds lec_conv_f32_scratch_bytes() bytes, ZEROED
 // by the caller, and stays alive until it is unregistered (buf = null) -- also across replays of a graph captured meanwhile.  Without a
 // registered scratch the stream's launches use the tile-walk kernel (same results to the last few bits: the K sum is split differently).
-// 0: never the balanced form; 1: where it pays (the default); 2: wherever it applies (tests); -1: only report.  Returns the mode in force before.
-extern "C" int lec_conv_f32_balanced(int mode) {
-  const int prev = lec::sk_mode();
-  if (mode >= 0) lec::g_sk_mode.store(mode > 2 ? 2 : mode, std::memory_order_relaxed);
-  return prev;
-}
+// Which form a call takes is its own `schedule` argument: LEC_SCHEDULE_TILE_WALK (0) never the balanced form, LEC_SCHEDULE_AUTO (1) where it pays,
+// LEC_SCHEDULE_BALANCED (2) wherever it applies, LEC_SCHEDULE_DEFAULT (-1) what LEC_CF_SK in the environment says (default 1).
 extern "C" int64_t lec_conv_f32_scratch_bytes(void) { return lec::sk_scratch_bytes(); }
 extern "C" int lec_conv_f32_scratch(lec_stream_t stream, void* buf, int64_t bytes) {
   using namespace lec;
@@ -1191,7 +1186,7 @@ extern "C" int lec_conv_f32_scratch(lec_stream_t stream, void* buf, int64_t byte
 }
 
 extern "C" int lec_conv_f32_fwd(const float* x, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
-                                float* y, float* partials, int64_t partials_bytes, int* n_partials, lec_stream_t stream) {
+                                float* y, float* partials, int64_t partials_bytes, int* n_partials, int schedule, lec_stream_t stream) {
   using namespace lec;
   if (int rc = conv_check("conv_f32_fwd", N, H, W, Cin, Cout, R, S, stride, pad)) return rc;
   LEC_CHECK_ARG(x && w && y, "conv_f32_fwd: null pointer");
@@ -1206,15 +1201,15 @@ extern "C" int lec_conv_f32_fwd(const float* x, const float* w, int N, int H, in
   if (partials) {
     LEC_CHECK_ARG(n_partials && partials_bytes >= (int64_t)kCfMaxPart * 2 * Cout * (int64_t)sizeof(float), "conv_f32_fwd: partials buffer too small");
     const int64_t rows = partials_bytes / ((int64_t)2 * Cout * (int64_t)sizeof(float));
-    return launch_act<true, true>(x, w, y, g, partials, n_partials, (hipStream_t)stream, ActFuse{}, (int)(rows < kCfMaxRows ? rows : kCfMaxRows));
+    return launch_act<true, true>(x, w, y, g, partials, n_partials, (hipStream_t)stream, ActFuse{}, (int)(rows < kCfMaxRows ? rows : kCfMaxRows), schedule);
   }
-  return launch_act<true, false>(x, w, y, g, nullptr, nullptr, (hipStream_t)stream);
+  return launch_act<true, false>(x, w, y, g, nullptr, nullptr, (hipStream_t)stream, ActFuse{}, kCfMaxPart, schedule);
 }
 
 // Forward with an eval-mode BatchNorm (+ residual, + ReLU) in the epilogue: y = [relu](conv(x, w) * scale[c] + shift[c] [+ res]) -- see ActFuse AFF.
 // scale / shift: Cout floats each (gamma / sqrt(running_var + eps), beta - running_mean * scale); res: null or a tensor of y's shape.
 extern "C" int lec_conv_f32_fwd_affine(const float* x, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
-                                       float* y, const float* scale, const float* shift, const float* res, int relu, lec_stream_t stream) {
+                                       float* y, const float* scale, const float* shift, const float* res, int relu, int schedule, lec_stream_t stream) {
   using namespace lec;
   if (int rc = conv_check("conv_f32_fwd_affine", N, H, W, Cin, Cout, R, S, stride, pad)) return rc;
   LEC_CHECK_ARG(x && w && y && scale && shift, "conv_f32_fwd_affine: null pointer");
@@ -1228,11 +1223,11 @@ extern "C" int lec_conv_f32_fwd_affine(const float* x, const float* w, int N, in
   g.dWm = make_fastdiv(g.Wm); g.dHm = make_fastdiv(g.Hm); g.dnb = make_fastdiv(g.nb);
   ActFuse fz{};
   fz.scale = scale; fz.shift = shift; fz.res = res; fz.relu = relu;
-  return launch_act<true, false, 4>(x, w, y, g, nullptr, nullptr, (hipStream_t)stream, fz);
+  return launch_act<true, false, 4>(x, w, y, g, nullptr, nullptr, (hipStream_t)stream, fz, kCfMaxPart, schedule);
 }
 
 extern "C" int lec_conv_f32_dgrad(const float* dy, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
-                                  float* dx, lec_stream_t stream) {
+                                  float* dx, int schedule, lec_stream_t stream) {
   using namespace lec;
   if (int rc = conv_check("conv_f32_dgrad", N, H, W, Cin, Cout, R, S, stride, pad)) return rc;
   LEC_CHECK_ARG(dy && w && dx, "conv_f32_dgrad: null pointer");
@@ -1251,7 +1246,7 @@ extern "C" int lec_conv_f32_dgrad(const float* dy, const float* w, int N, int H,
       g.src_bytes = (uint32_t)((int64_t)N * Ho * Wo * Cout * 4); g.wgt_bytes = (uint32_t)((int64_t)Cout * R * S * Cin * 4);
       g.dst_bytes = (uint32_t)((int64_t)N * H * W * Cin * 4);
       g.dWm = make_fastdiv(g.Wm); g.dHm = make_fastdiv(g.Hm); g.dnb = make_fastdiv(g.nb);   // (Kg = 0: the loop is empty, zeros are stored)
-      if (int rc = launch_act<false, false>(dy, w, dx, g, nullptr, nullptr, (hipStream_t)stream)) return rc;
+      if (int rc = launch_act<false, false>(dy, w, dx, g, nullptr, nullptr, (hipStream_t)stream, ActFuse{}, kCfMaxPart, schedule)) return rc;
     }
   }
   return LEC_OK;
@@ -1265,7 +1260,7 @@ extern "C" int lec_conv_f32_dgrad(const float* dy, const float* w, int N, int H,
 extern "C" int lec_conv_f32_dgrad_fused(const float* dy, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                                         float* dx, const float* xsrc, const float* coef, const float* dres, const float* xbn, const uint8_t* mask,
                                         const float* mean, const float* invstd, float* partials, int64_t partials_bytes, int* n_partials,
-                                        lec_stream_t stream) {
+                                        int schedule, lec_stream_t stream) {
   using namespace lec;
   if (int rc = conv_check("conv_f32_dgrad_fused", N, H, W, Cin, Cout, R, S, stride, pad)) return rc;
   LEC_CHECK_ARG(dy && w && dx, "conv_f32_dgrad_fused: null pointer");
@@ -1291,7 +1286,7 @@ extern "C" int lec_conv_f32_dgrad_fused(const float* dy, const float* w, int N, 
   hipStream_t st = (hipStream_t)stream;
   const int64_t rows = fold ? partials_bytes / ((int64_t)2 * Cin * (int64_t)sizeof(float)) : 0;
   if (xf && fold) return launch_act<false, false, 3>(dy, w, dx, g, partials, n_partials, st, fz);
-  if (fold) return launch_act<false, false, 2>(dy, w, dx, g, partials, n_partials, st, fz, (int)(rows < kCfMaxRows ? rows : kCfMaxRows));
+  if (fold) return launch_act<false, false, 2>(dy, w, dx, g, partials, n_partials, st, fz, (int)(rows < kCfMaxRows ? rows : kCfMaxRows), schedule);
   return launch_act<false, false, 1>(dy, w, dx, g, nullptr, nullptr, st, fz);
 }
 

@@ -154,9 +154,11 @@ class StepEngine:
             if self.compute_dtype == torch.bfloat16:
                 self.arena.enable_lowp_shadow()
             # fp32 (the reference's precision): the convolutions read the arena's master weights directly
-            self.overlap = WgradOverlap.instance = WgradOverlap(self.reducer, self.arena, side_stream=overlap_wgrad)
-        else:
-            WgradOverlap.instance = None
+            self.overlap = WgradOverlap(self.reducer, self.arena, side_stream=overlap_wgrad)
+        # this engine's settings travel with ITS backbone (resnet.ResNet.wgrad_overlap / bn_grad_accumulate / conv_schedule -> the
+        # FusionContext of every forward): no process-wide switch is touched, a second engine or trainer in the process keeps its own
+        self.backbone = self.img_feat_net.model
+        self.backbone.wgrad_overlap = self.overlap if self.overlap is not None else False
         # synthetic image pool resident in HBM: torch.rand in [0,1) like ToTensor output (oe_h.py:1463-1471), seed 0
         P = pool_images or min(n_images, 2 * self.B)
         g = torch.Generator(device='cpu').manual_seed(1234 + self.rank)
@@ -185,7 +187,7 @@ class StepEngine:
         if self.passes > 1:
             # several backward passes add into the same gradient slots from concurrent streams: BatchNorm's d gamma / d beta are ADDED
             # with atomics (like the weight gradients); the arena is zeroed once per step
-            _lib.lib.lec_bn_bwd_accumulate(1)
+            self.backbone.bn_grad_accumulate = True
         self.graph_after = graph_after
         self.hip_graph = None
         self.graph_out = None
@@ -210,8 +212,13 @@ class StepEngine:
     def enable_timers(self):
         mk = lambda: torch.cuda.Event(enable_timing=True)
         self.timers = {'records': [], 'mk': mk}
-        ops.BN_TIMER = []
-        ops.CONV_TIMER = []
+        self.kernel_timers(True)
+
+    def kernel_timers(self, on):
+        """Per-launch HIP events of this engine's BatchNorm / fp32 convolution kernels (ResNet.step_timers): True = start with empty lists,
+        False = stop.  Returns the lists' dict (or None)."""
+        self.backbone.step_timers = {'bn': [], 'conv': []} if on else None
+        return self.backbone.step_timers
 
     def step(self):
         B, K = self.B, self.K
@@ -353,7 +360,7 @@ class StepEngine:
         """`_core` with the CNN rows as `passes` concurrent parts, one HIP stream each (see __init__): backbone forward of every part up
         to the pooled features, join, the fully connected layer over all rows + ONE fused loss launch + the layer's backward on the main
         stream, backbone backward of every part, join.  BatchNorm statistics are per part; the running statistics are updated in part
-        order (ops.PASS_ORDER); the convolutions' and BatchNorms' parameter gradients of the parts add up in the arena (atomics); the
+        order (ResNet.forward's pass_order); the convolutions' and BatchNorms' parameter gradients of the parts add up in the arena (atomics); the
         fully connected layer -- the only parameters whose gradients go through autograd's AccumulateGrad -- stays on ONE stream."""
         codes = self.codes_dev
         pos_from = codes[:, 0].contiguous(); pos_to = codes[:, 1].contiguous(); negc = codes[:, 2:].contiguous()
@@ -367,16 +374,13 @@ class StepEngine:
         self.reducer.live = False                      # every parameter reports once per part: the buckets are reduced after the last part
         # concurrent parts fill each other's last rounds of workgroup slots: the balanced (stream-K) convolution kernel buys nothing here (131.0 ms
         # with the tile walk, 131.5 with it) and moves 32 GB more per step (slabs, operand re-reads: profiles/r03_conv_f32_balanced.md): tile walk
-        balanced = _lib.lib.lec_conv_f32_balanced(0)
+        schedule = self.backbone.conv_schedule
+        self.backbone.conv_schedule = _lib.SCHEDULE_TILE_WALK
         try:
             for p, st in enumerate(self.pass_streams):
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
-                    ops.PASS_ORDER = (order, p)
-                    try:
-                        f = self.img_feat_net.forward_pooled(images[p * h:(p + 1) * h])
-                    finally:
-                        ops.PASS_ORDER = None
+                    f = self.img_feat_net.forward_pooled(images[p * h:(p + 1) * h], pass_order=(order, p))
                     parts.append(f)
                     f.record_stream(cur)
             for st in self.pass_streams:
@@ -403,7 +407,7 @@ class StepEngine:
             for st in self.pass_streams:
                 cur.wait_stream(st)
         finally:
-            _lib.lib.lec_conv_f32_balanced(balanced)
+            self.backbone.conv_schedule = schedule
             self.reducer.live = live
             self.reducer.reset()
         if self.graph_reduces and torch.cuda.is_current_stream_capturing():
@@ -415,14 +419,12 @@ class StepEngine:
         """Capture `_core` into a hipGraph (after eager steps have sized every workspace and MIOpen has settled on its
         solvers).  Under capture the gradient reducer's per-parameter hooks are muted: the all-reduce runs after the
         replay.  On any capture error the engine stays in eager launch mode and says so."""
-        saved_timer = ops.BN_TIMER
-        saved_ctimer = ops.CONV_TIMER
+        saved_timers = self.backbone.step_timers
         try:
             torch.cuda.synchronize()
             self.reducer.live = self.graph_reduces    # hooks muted unless the collectives are captured with the step
             self.reducer.reset()
-            ops.BN_TIMER = None
-            ops.CONV_TIMER = None
+            self.backbone.step_timers = None           # a captured launch cannot carry timing events
             g = torch.cuda.CUDAGraph()
             # thread_local: RCCL's watchdog thread polls events while we capture; only THIS thread's calls may fail the capture
             # (capturing the main chain on a HIGH-priority stream, so that its nodes outrank the side stream's weight gradients, was
@@ -440,8 +442,7 @@ class StepEngine:
             print('[StepEngine] hipGraph capture failed, staying in eager launch mode: %s' % self.graph_error, file=sys.stderr)
             torch.cuda.synchronize()
         finally:
-            ops.BN_TIMER = saved_timer
-            ops.CONV_TIMER = saved_ctimer
+            self.backbone.step_timers = saved_timers
 
     def set_launch_mode(self, graph):
         """Switch between replaying the captured graph and eager launches (bench.py times per-kernel phases with HIP
@@ -476,24 +477,22 @@ class StepEngine:
                 else:
                     hi = max(hi, e_)
             return (tot + hi - lo) / max(len(recs), 1)
-        if ops.BN_TIMER:
-            res['fused_bn_busy'] = busy(ops.BN_TIMER)
-            res['fused_bn'] = sum(a.elapsed_time(b) for a, b, _ in ops.BN_TIMER) / max(len(recs), 1)
-            self.bn_bytes_per_step = sum(n for _, _, n in ops.BN_TIMER) / max(len(recs), 1)
-            self.bn_launch_groups_per_step = len(ops.BN_TIMER) / max(len(recs), 1)
-        if ops.CONV_TIMER:
-            res['conv_f32_busy'] = busy(ops.CONV_TIMER)
-            res['conv_f32'] = sum(a.elapsed_time(b) for a, b, _ in ops.CONV_TIMER) / max(len(recs), 1)
-            self.conv_flops_per_step = sum(n for _, _, n in ops.CONV_TIMER) / max(len(recs), 1)
-            self.conv_launches_per_step = len(ops.CONV_TIMER) / max(len(recs), 1)
+        tm = self.backbone.step_timers or {'bn': [], 'conv': []}
+        bn_t, conv_t = tm['bn'], tm['conv']
+        if bn_t:
+            res['fused_bn_busy'] = busy(bn_t)
+            res['fused_bn'] = sum(a.elapsed_time(b) for a, b, _ in bn_t) / max(len(recs), 1)
+            self.bn_bytes_per_step = sum(n for _, _, n in bn_t) / max(len(recs), 1)
+            self.bn_launch_groups_per_step = len(bn_t) / max(len(recs), 1)
+        if conv_t:
+            res['conv_f32_busy'] = busy(conv_t)
+            res['conv_f32'] = sum(a.elapsed_time(b) for a, b, _ in conv_t) / max(len(recs), 1)
+            self.conv_flops_per_step = sum(n for _, _, n in conv_t) / max(len(recs), 1)
+            self.conv_launches_per_step = len(conv_t) / max(len(recs), 1)
         return res
 
     def close(self):
         self.prefetch.close()
-        if self.passes > 1:
-            _lib.lib.lec_bn_bwd_accumulate(0)
-        if WgradOverlap.instance is self.overlap:
-            WgradOverlap.instance = None
         _release_graphs(self)
 
 

@@ -131,22 +131,17 @@ class ETHECExperiment(Experiment):
             if compute_dtype == torch.bfloat16:
                 self.arena.enable_lowp_shadow()
             self.overlap = WgradOverlap(self.reducer, self.arena, side_stream=True)
+        self.model.wgrad_overlap = self.overlap if self.overlap is not None else False    # this trainer's own (resnet.ResNet.wgrad_overlap)
 
     def fwd_bwd(self, inputs, level_labels, labels=None):
         """Forward, criterion, backward of one batch already on the device (NHWC): the region a hipGraph can capture."""
-        from .resnet import WgradOverlap
-        prev = WgradOverlap.instance
-        WgradOverlap.instance = self.overlap
-        try:
-            self.arena.zero_grad()
-            with torch.autocast('cuda', dtype=self.compute_dtype, enabled=self.compute_dtype != torch.float32):
-                outputs = self.model(inputs)
-            loss = self.criterion(outputs.float(), labels, level_labels)
-            loss.backward()
-            if self.overlap is not None:
-                self.overlap.join()
-        finally:
-            WgradOverlap.instance = prev
+        self.arena.zero_grad()
+        with torch.autocast('cuda', dtype=self.compute_dtype, enabled=self.compute_dtype != torch.float32):
+            outputs = self.model(inputs)
+        loss = self.criterion(outputs.float(), labels, level_labels)
+        loss.backward()
+        if self.overlap is not None:
+            self.overlap.join()
         # detached: a live `outputs` would keep this step's autograd graph (and its AccumulateGrad nodes, bound to this step's
         # stream) alive into the next one -- under hipGraph capture that ends in a crash inside capture_end
         return loss.detach(), outputs.detach()

@@ -112,43 +112,42 @@ class _ImageNetBase(nn.Module):
                 new.__dict__[k] = copy.deepcopy(v, memo)
         return new
 
-    def _forward_raw_passes(self, x):
-        """forward_raw with the rows of x as `cnn_passes` parts, one HIP stream each: the backbone up to the pooled features per part
+    def _forward_raw_passes(self, x, split=None):
+        """forward_raw with the rows of x as concurrent parts, one HIP stream each: the backbone up to the pooled features per part
         (BatchNorm statistics per part, running statistics updated in part order), then the fully connected layer once over all rows
-        on the caller's stream.  Autograd runs every part's backward on the stream its forward ran on and joins them itself.  The
-        caller zeroes the gradient slots once per step and has lec_bn_bwd_accumulate(1) set (trainers' train_step)."""
+        on the caller's stream.  `split` (the criterion passes it): rows [0, split) are the positives' images, the rest images drawn as
+        negatives -- the parts are then the reference's own separate forwards (oe_h.py:980-985 | 1003-1009); without it, `cnn_passes` equal
+        parts.  Autograd runs every part's backward on the stream its forward ran on and joins them itself.  The caller zeroes the gradient
+        slots once per step and has set the backbone's bn_grad_accumulate (trainers' __init__)."""
         cur = torch.cuda.current_stream()
-        P = self.cnn_passes
-        streams = self.__dict__.setdefault('_pass_streams', [])
-        while len(streams) < P:
-            streams.append(torch.cuda.Stream())
         n = x.shape[0]
-        h = -(-n // P)
+        if split is not None and 0 < split < n:
+            bounds = [0, int(split), n]
+        else:
+            h = -(-n // self.cnn_passes)
+            bounds = list(range(0, n, h)) + [n]
+        streams = self.__dict__.setdefault('_pass_streams', [])
+        while len(streams) < len(bounds) - 1:
+            streams.append(torch.cuda.Stream())
         parts, order, used = [], {}, []
-        for p in range(P):
-            xs = x[p * h:(p + 1) * h]
-            if xs.shape[0] == 0:
-                continue
+        for p in range(len(bounds) - 1):
+            xs = x[bounds[p]:bounds[p + 1]]
             st = streams[p]
             st.wait_stream(cur)
             with torch.cuda.stream(st):
-                ops.PASS_ORDER = (order, p)
-                try:
-                    f = self.model(xs, pooled_only=True)
-                finally:
-                    ops.PASS_ORDER = None
+                f = self.model(xs, pooled_only=True, pass_order=(order, p))
             f.record_stream(cur); parts.append(f); used.append(st)
         for st in used:
             x.record_stream(st); cur.wait_stream(st)
         return self.model.fc(torch.cat(parts)).float()
 
-    def forward_raw(self, x):
-        """CNN output BEFORE soft_clip, fp32 [n, D] -- the fused loss applies soft_clip itself."""
+    def forward_raw(self, x, split=None):
+        """CNN output BEFORE soft_clip, fp32 [n, D] -- the fused loss applies soft_clip itself.  split: see _forward_raw_passes."""
         if self.channels_last and x.dim() == 4:
             x = x.contiguous(memory_format=torch.channels_last)
         if (self.cnn_passes > 1 and x.is_cuda and self.compute_dtype == torch.float32 and self.training and torch.is_grad_enabled()
-                and x.dim() == 4 and x.shape[0] >= 4 * self.cnn_passes):
-            return self._forward_raw_passes(x)
+                and x.dim() == 4 and x.shape[0] >= 4 * self.cnn_passes and (split is None or 2 <= split <= x.shape[0] - 2)):
+            return self._forward_raw_passes(x, split)
         if self.compute_dtype != torch.float32:
             with torch.autocast('cuda', dtype=self.compute_dtype):
                 y = self.model(x)
@@ -156,14 +155,14 @@ class _ImageNetBase(nn.Module):
             y = self.model(x)
         return y.float()
 
-    def forward_pooled(self, x):
+    def forward_pooled(self, x, pass_order=None):
         """The backbone up to its global average pooling, fp32 [n, fc.in_features]; `head` finishes forward_raw.  (fp32 only: the
         engine's concurrent passes, which pool per pass and apply the fully connected layer once.)"""
         if self.channels_last and x.dim() == 4:
             x = x.contiguous(memory_format=torch.channels_last)
         if self.compute_dtype != torch.float32:
             raise NotImplementedError('forward_pooled serves the fp32 backbone')
-        return self.model(x, pooled_only=True)
+        return self.model(x, pooled_only=True, pass_order=pass_order)
 
     def head(self, pooled):
         return self.model.fc(pooled).float()
@@ -388,6 +387,7 @@ class _JointCriterionBase(torch.nn.Module):
                 elif not torch.is_tensor(elem):
                     elem = by_name(i2n[ix])
                 slot[ix] = len(rows); rows.append(elem)
+        n_pos_rows = len(rows)                                          # rows [0, n_pos_rows): the batch's own images; behind them: image negatives
         for ix in np.unique(neg[neg >= N]).tolist():
             if ix not in slot:
                 slot[ix] = len(rows); rows.append(by_name(i2n[ix]))
@@ -397,7 +397,11 @@ class _JointCriterionBase(torch.nn.Module):
         if rows:
             batch = self._image_batch(rows, dev, store)
             if self.use_CNN and hasattr(img_feat_net, 'forward_raw') and getattr(img_feat_net, 'K', None):
-                feats = img_feat_net.forward_raw(batch); image_proj = self.default_image_proj
+                if isinstance(_unwrap(img_feat_net), _ImageNetBase):
+                    feats = img_feat_net.forward_raw(batch, split=n_pos_rows)       # concurrent passes cut at the positives | negatives boundary
+                else:
+                    feats = img_feat_net.forward_raw(batch)
+                image_proj = self.default_image_proj
             else:
                 feats = _unwrap(img_feat_net)(batch).reshape(len(rows), -1).float()
 

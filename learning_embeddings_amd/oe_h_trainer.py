@@ -470,7 +470,6 @@ class JointEmbeddings:
                  image_store=True, image_store_gb=None):
         Embedder, FeatCNN18, FeatCNN, FeatNet = self._model_classes()
         from .resnet import WgradOverlap
-        WgradOverlap.instance = None            # set to this trainer's own instance around every train step (see train_step)
         torch.manual_seed(0)                                               # oe_h.py:1338
         self.classes = labelmap.classes; self.n_classes = labelmap.n_classes
         self.levels = labelmap.levels; self.n_levels = len(self.levels); self.level_names = labelmap.level_names
@@ -541,6 +540,16 @@ class JointEmbeddings:
             self.overlap = WgradOverlap(self.reducer, self.arena, side_stream=self.cnn_passes == 1)
             if self.cnn_passes > 1:
                 self.img_feat_net.cnn_passes = self.cnn_passes
+        if self.use_CNN:
+            # this trainer's settings travel with ITS backbone (resnet.ResNet.wgrad_overlap / bn_grad_accumulate / conv_schedule -> the
+            # FusionContext of each forward): nothing process-wide is switched around a step, a second trainer in the process keeps its own
+            bb = self.img_feat_net.model
+            bb.wgrad_overlap = self.overlap if self.overlap is not None else False
+            if getattr(self, 'cnn_passes', 1) > 1:
+                # two backward passes add into the same gradient slots from concurrent streams: BatchNorm's d gamma / d beta accumulate with
+                # atomics like the weight gradients; concurrent passes fill each other's tails: tile walk (engine._core_passes)
+                bb.bn_grad_accumulate = True
+                bb.conv_schedule = _lib.SCHEDULE_TILE_WALK
         self.check_graph_embedding_neg_graph = None
         self.check_reconstr_every = 1; self.save_model_every = 1
         self.reconstruction_f1 = self.reconstruction_threshold = self.reconstruction_accuracy = 0.0
@@ -653,10 +662,7 @@ class JointEmbeddings:
         """oe_h.py:1734-1774 for one batch.  Returns the (device) loss; nothing here synchronises with the host.
         Exactly one forward / backward of the image network per step: the weight-gradient kernels ADD into the arena's gradient
         slots (zeroed here), BatchNorm gradients are written in place."""
-        from .resnet import WgradOverlap
         ov = self.overlap
-        prev = WgradOverlap.instance
-        WgradOverlap.instance = ov
         # The host may run at most two steps ahead of the GPU.  Nothing below synchronises, and activations the side stream has
         # touched go back to the allocator only when its events have passed: a caller that never reads the loss (a timing loop)
         # would otherwise pile up one step's activations per step of run-ahead (measured: 234 GB live after 11 fp32 steps).
@@ -666,11 +672,8 @@ class JointEmbeddings:
         multi = getattr(self, 'cnn_passes', 1) > 1
         live = self.reducer.live
         if multi:
-            # two backward passes add into the same gradient slots from concurrent streams: BatchNorm's d gamma / d beta accumulate with
-            # atomics like the weight gradients, and the reducer's per-parameter hooks stay muted (every parameter reports once per
-            # pass): the buckets are reduced once, below
-            ops.lib.lec_bn_bwd_accumulate(1); self.reducer.live = False
-            balanced = ops.lib.lec_conv_f32_balanced(0)                     # concurrent passes fill each other's tails: tile walk (engine._core_passes)
+            # every parameter reports once per pass: the reducer's per-parameter hooks stay muted, the buckets are reduced once, below
+            self.reducer.live = False
         try:
             self.arena.zero_grad(); self.table_grad.zero_()
             loss, e_pos, e_neg = self.criterion(self.model, self.img_feat_net, data_item['from'], data_item['to'],
@@ -679,10 +682,8 @@ class JointEmbeddings:
             if ov is not None:
                 ov.join()                                                   # weight gradients from the side stream
         finally:
-            WgradOverlap.instance = prev
             if multi:
-                ops.lib.lec_bn_bwd_accumulate(0); self.reducer.live = live; self.reducer.reset()
-                ops.lib.lec_conv_f32_balanced(balanced)
+                self.reducer.live = live; self.reducer.reset()
         self.reducer.finish()
         self.apply_updates()
         if loss.is_cuda:

@@ -13,7 +13,9 @@ _workspaces = {}
 
 
 def _workspace(device, nbytes):
-    key = (device.type, device.index)
+    """Scratch of the loss kernels (arrival counter + partials), one per device AND stream: launches that share it must be stream-ordered
+    (lec_common.h block_publish_and_finalize), and two trainers of one process may run on different streams."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.zeros(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
@@ -324,16 +326,26 @@ class FusionContext:
         self.forks, self.folded, self.deferred, self.lazy_ok, self.lazy_dx = {}, {}, {}, {}, {}
         self.ws_owner = [0, 0]
         self._ws = {}
+        # settings of the forward / backward pair this context serves, copied from the owning backbone when its forward starts (ResNet.forward).
+        # They used to be process-wide switches (a C static, class attributes): two trainers in one process, or two threads, then raced.
+        self.overlap = None             # resnet.WgradOverlap the convolutions / BatchNorms of this pass report to (None: the process default, False: none)
+        self.accumulate = False         # BatchNorm backward ADDS d gamma / d beta (several backward passes per step share the gradient slots)
+        self.schedule = _lib.SCHEDULE_DEFAULT   # LEC_SCHEDULE_* of the fp32 forward / data-gradient launches
+        self.pass_order = None          # (dict, pass index): running statistics are updated in pass order (see BNActFn.forward)
+        self.bn_timer = None            # lists of (start event, end event, bytes | flops) per launch when the owner profiles its step
+        self.conv_timer = None
+        self.in_flight = False          # a training forward has run and its backward has not reached the stem yet
 
     def busy(self):
-        """Records of a forward whose backward has not finished yet are still here."""
-        return bool(self.forks or self.folded or self.deferred or self.lazy_ok or self.lazy_dx)
+        """A forward whose backward has not finished yet owns this context (its records and its BatchNorm workspace)."""
+        return bool(self.in_flight or self.forks or self.folded or self.deferred or self.lazy_ok or self.lazy_dx)
 
     def reset(self):
         """Drop the records of a forward whose backward never ran (or raised)."""
         for d in (self.forks, self.folded, self.deferred, self.lazy_ok, self.lazy_dx):
             d.clear()
         self.ws_owner[0] = 0
+        self.in_flight = False
 
     def workspace(self, device):
         key = (device.type, device.index)
@@ -345,12 +357,32 @@ class FusionContext:
 
 
 _DEFAULT_FUSION = FusionContext()
-_FUSION_STACK = [_DEFAULT_FUSION]
+import threading as _threading
+_TLS = _threading.local()               # the stack is per THREAD: autograd runs backward on its own thread, a host may drive two trainers from two
+
+
+def _stack():
+    st = getattr(_TLS, 'stack', None)
+    if st is None:
+        st = _TLS.stack = [_DEFAULT_FUSION]
+    return st
 
 
 def fusion():
-    """The current FusionContext (the innermost `use_fusion`, else the process-wide default)."""
-    return _FUSION_STACK[-1]
+    """The current FusionContext of this thread (the innermost `use_fusion`, else the process-wide default)."""
+    return _stack()[-1]
+
+
+def overlap():
+    """The WgradOverlap the current pass reports to: its context's own, else the process default `WgradOverlap.instance` (ops called outside
+    a model: tests, tools)."""
+    ov = fusion().overlap
+    if ov is False:                     # the owner said: none (stock autograd convolutions)
+        return None
+    if ov is not None:
+        return ov
+    from .resnet import WgradOverlap
+    return WgradOverlap.instance
 
 
 class use_fusion:
@@ -358,11 +390,11 @@ class use_fusion:
         self.fc = fc if fc is not None else _DEFAULT_FUSION
 
     def __enter__(self):
-        _FUSION_STACK.append(self.fc)
+        _stack().append(self.fc)
         return self.fc
 
     def __exit__(self, *exc):
-        _FUSION_STACK.pop()
+        _stack().pop()
         return False
 
 
@@ -377,8 +409,9 @@ def _with_ctx_fusion(backward):
     return wrapped
 
 
-# A step that pushes its CNN rows through the backbone as several CONCURRENT passes (engine.StepEngine, one HIP stream per pass) sets
-# PASS_ORDER = (dict, pass index): the running statistics of a BatchNorm layer are then updated in pass order -- pass p's launch
+# A step that pushes its CNN rows through the backbone as several CONCURRENT passes (engine.StepEngine, one HIP stream per pass) gives each
+# forward `pass_order = (dict, pass index)` (ResNet.forward -> FusionContext.pass_order; the module-level PASS_ORDER below is the default
+# context's, for ops called outside a model): the running statistics of a BatchNorm layer are then updated in pass order -- pass p's launch
 # waits for pass p - 1's launch of the same layer (an event per layer; pass p - 1 is always enqueued first and runs ahead) -- so
 # that they hold EMA(EMA(r, batch of pass 0), batch of pass 1), the reference's sequence of forwards, not a race between streams.
 PASS_ORDER = None
@@ -426,11 +459,12 @@ BN_TIMER = None     # set to a list to record (start_event, end_event, algorithm
 
 
 def _bn_timed(call, nbytes):
-    if BN_TIMER is None:
+    timer = fusion().bn_timer if fusion().bn_timer is not None else BN_TIMER
+    if timer is None:
         return call()
     a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
     a.record(); call(); b.record()
-    BN_TIMER.append((a, b, nbytes))
+    timer.append((a, b, nbytes))
 
 
 class BNActFn(torch.autograd.Function):
@@ -444,7 +478,8 @@ class BNActFn(torch.autograd.Function):
         if residual is not None and (_nhwc_rows(residual, 'residual') != (M, Cc) or residual.dtype != x.dtype):
             raise ValueError('residual shape / dtype mismatch')
         ctx.fc = fusion()
-        order = PASS_ORDER if (training and PASS_ORDER is not None and x.is_cuda) else None
+        order = fusion().pass_order if fusion().pass_order is not None else PASS_ORDER
+        order = order if (training and order is not None and x.is_cuda) else None
         if order is not None and order[1] > 0:
             prev_ev = order[0].get((running_mean.data_ptr(), order[1] - 1))
             if prev_ev is not None:
@@ -540,10 +575,11 @@ class BNActFn(torch.autograd.Function):
         if sink is not None and sink[0].grad is not None and sink[1].grad is not None:
             dgamma, dbeta = sink[0].grad, sink[1].grad           # the flat arena's slots: no AccumulateGrad kernels
         else:
-            sink = None                               # (zeros, not empty: under lec_bn_bwd_accumulate(1) the kernels ADD into these)
+            sink = None                               # (zeros, not empty: with `accumulate` the kernels ADD into these)
             dgamma = torch.zeros(Cc, dtype=torch.float32, device=x.device); dbeta = torch.zeros_like(dgamma)
         ws = _bn_workspace(x.device)
         fusion().ws_owner[0] = 0
+        acc = 1 if fusion().accumulate else 0         # several backward passes of a step share the gradient slots (zeroed once per step)
         el = M * Cc                                   # 2 x (dy [+ dy2] + x [+ mask]) + dx [+ d residual]
         es = x.element_size()
         if dy.dtype != x.dtype:
@@ -554,49 +590,49 @@ class BNActFn(torch.autograd.Function):
             nbytes = el * es * ((2 + (1 if dy2 is not None else 0) + 1) + (2 + 1)) + (el // 8 if relu else 0)
         else:            # both passes read dy [+ dy2], x, mask; pass 2 writes dx
             nbytes = el * es * (2 * (2 + (1 if dy2 is not None else 0)) + 1) + (2 * (el // 8) if relu else 0)
-        from .resnet import WgradOverlap as _WO
+        _ov = overlap()
         lazy = (LAZY_BN_PASS2 and has_res and x.data_ptr() in fusion().lazy_ok and x.dtype == torch.bfloat16
-                and _WO.instance is not None and _WO.instance.enabled       # the consumer that materialises dx is _OverlapConvFn.backward
+                and _ov is not None and _ov.enabled       # the consumer that materialises dx is _OverlapConvFn.backward
                 and lib.lec_conv1x1_wgrad_bnapply_supported(fusion().lazy_ok[x.data_ptr()], Cc, M))
         # fp32: the 1x1 / stride-1 convolution that produced x forms dx on its operand load, in its data gradient AND in its weight gradient
         # (lec_conv_f32_dgrad_fused / _wgrad_fused): pass 2 never runs as a kernel
         lazy32 = (LAZY_BN_PASS2_F32 and x.dtype == torch.float32 and x.data_ptr() in fusion().lazy_ok and el >= LAZY_F32_MIN_ELEMS
-                  and _WO.instance is not None and _WO.instance.enabled and ctx.needs_input_grad[0])
+                  and _ov is not None and _ov.enabled and ctx.needs_input_grad[0])
         fusion().lazy_ok.pop(x.data_ptr(), None)
         if lazy32:
             coef = torch.empty(3 * Cc, dtype=torch.float32, device=x.device)
             if pre:
                 g = dy
                 _bn_timed(lambda: check(lib.lec_bn_bwd_coeffs_f32(M, Cc, pre, dptr(weight), dptr(save_mean), dptr(save_invstd), dptr(dgamma), dptr(dbeta),
-                                                                  dptr(coef), dptr(ws), ws.numel(), stream_ptr())), 0)
+                                                                  dptr(coef), dptr(ws), ws.numel(), acc, stream_ptr())), 0)
             else:
                 g = dres if has_res else torch.empty_like(x)
                 nb1 = el * es * (2 + (1 if dy2 is not None else 0) + 1) + (el // 8 if relu else 0)
                 _bn_timed(lambda: check(lib.lec_bn_bwd_pass1_coeffs_f32(dptr(dy), dptr(dy2), dptr(mask) if relu else None, dptr(x), M, Cc, dptr(weight),
                                                                         dptr(save_mean), dptr(save_invstd), dptr(g), dptr(dgamma), dptr(dbeta), dptr(coef),
-                                                                        dptr(ws), ws.numel(), stream_ptr())), nb1)
+                                                                        dptr(ws), ws.numel(), acc, stream_ptr())), nb1)
             fusion().lazy_dx.clear()
             fusion().lazy_dx[dx.data_ptr()] = {'g': g, 'x': x, 'coef': coef, 'gamma': weight, 'mean': save_mean, 'invstd': save_invstd, 'M': M, 'C': Cc}
         elif lazy:
             # the convolution that produced x runs pass 2 inside its weight-gradient kernel (conv1x1_wgrad_bnapply_rows): here only
             # pass 1 (unless a data-gradient epilogue already did it) and the finalize; dx is handed on UNWRITTEN with a record
             if pre:
-                _bn_timed(lambda: check(lib.lec_bn_bwd_finalize(M, Cc, pre, dptr(dgamma), dptr(dbeta), dptr(ws), ws.numel(), stream_ptr())), 0)
+                _bn_timed(lambda: check(lib.lec_bn_bwd_finalize(M, Cc, pre, dptr(dgamma), dptr(dbeta), dptr(ws), ws.numel(), acc, stream_ptr())), 0)
             else:
                 nb1 = el * es * (2 + (1 if dy2 is not None else 0) + 1) + (el // 8 if relu else 0)
                 _bn_timed(lambda: check(_dt('lec_bn_bwd_pass1', x.dtype)(dptr(dy), dptr(dy2), dptr(mask) if relu else None, dptr(x), M, Cc, dptr(save_mean),
                                                              dptr(save_invstd), dptr(dres), dptr(dgamma), dptr(dbeta), dptr(ws), ws.numel(),
-                                                             stream_ptr())), nb1)
+                                                             acc, stream_ptr())), nb1)
             fusion().lazy_dx.clear()
             fusion().lazy_dx[dx.data_ptr()] = {'g': dres, 'x': x, 'gamma': weight, 'mean': save_mean, 'invstd': save_invstd, 'M': M, 'C': Cc}
         elif pre:
             nbytes = el * es * 3                  # pass 2 only: read g, x; write dx (pass 1 ran in the convolution's epilogue)
             _bn_timed(lambda: check(_dt('lec_bn_bwd_prereduced', x.dtype)(dptr(dy), dptr(x), M, Cc, dptr(weight), dptr(save_mean), dptr(save_invstd), pre,
-                                                              dptr(dx), dptr(dgamma), dptr(dbeta), dptr(ws), ws.numel(), stream_ptr())), nbytes)
+                                                              dptr(dx), dptr(dgamma), dptr(dbeta), dptr(ws), ws.numel(), acc, stream_ptr())), nbytes)
         else:
             _bn_timed(lambda: check(_dt('lec_bn_bwd', x.dtype)(dptr(dy), dptr(dy2), None, dptr(mask), dptr(x), M, Cc, dptr(weight), dptr(save_mean),
                                                    dptr(save_invstd), dptr(dx), dptr(dres), dptr(dgamma), dptr(dbeta), int(relu),
-                                                   dptr(ws), ws.numel(), stream_ptr())), nbytes)
+                                                   dptr(ws), ws.numel(), acc, stream_ptr())), nbytes)
         if has_res and ctx.res_ptr in fusion().forks:     # this layer's residual is a forked block output: its consumer convolution's data
             fusion().forks[ctx.res_ptr]['dres'] = dres    # gradient can fold this gradient into its epilogue (conv1x1_dgrad_bnfold_rows)
         if sink is not None:
@@ -786,14 +822,16 @@ CONV_TIMER = None    # set to a list to record (start_event, end_event, flops) p
 
 
 def _conv_timed(call, flops):
-    if CONV_TIMER is None:
+    timer = fusion().conv_timer if fusion().conv_timer is not None else CONV_TIMER
+    if timer is None:
         return call()
     a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
     a.record(); call(); b.record()
-    CONV_TIMER.append((a, b, flops))
+    timer.append((a, b, flops))
 
 
 _conv_scratch_bufs = {}
+_conv_scratch_lock = _threading.Lock()
 
 
 def _conv_scratch():
@@ -804,9 +842,12 @@ def _conv_scratch():
     key = (s.device.index, s.cuda_stream)
     if key in _conv_scratch_bufs or torch.cuda.is_current_stream_capturing():
         return
-    buf = torch.zeros(int(lib.lec_conv_f32_scratch_bytes()), dtype=torch.uint8, device=s.device)
-    check(lib.lec_conv_f32_scratch(stream_ptr(), dptr(buf), buf.numel()))
-    _conv_scratch_bufs[key] = buf
+    with _conv_scratch_lock:                # two host threads launching on one stream register ONE buffer
+        if key in _conv_scratch_bufs:
+            return
+        buf = torch.zeros(int(lib.lec_conv_f32_scratch_bytes()), dtype=torch.uint8, device=s.device)
+        check(lib.lec_conv_f32_scratch(stream_ptr(), dptr(buf), buf.numel()))
+        _conv_scratch_bufs[key] = buf
 
 
 def conv_f32_fwd(x, w, stride, pad, want_stats=False):
@@ -821,10 +862,10 @@ def conv_f32_fwd(x, w, stride, pad, want_stats=False):
     if want_stats:
         ws = _bn_workspace(x.device); k = C.c_int(0)
         _conv_timed(lambda: check(lib.lec_conv_f32_fwd(dptr(x), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), dptr(ws), ws.numel(),
-                                                       C.byref(k), stream_ptr())), flops)
+                                                       C.byref(k), fusion().schedule, stream_ptr())), flops)
         fusion().ws_owner[0], fusion().ws_owner[1] = y.data_ptr(), k.value
     else:
-        _conv_timed(lambda: check(lib.lec_conv_f32_fwd(dptr(x), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), None, 0, None, stream_ptr())), flops)
+        _conv_timed(lambda: check(lib.lec_conv_f32_fwd(dptr(x), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), None, 0, None, fusion().schedule, stream_ptr())), flops)
     return y
 
 
@@ -841,7 +882,7 @@ def conv_f32_fwd_affine(x, w, stride, pad, scale, shift, residual=None, relu=Fal
     y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     _conv_scratch()
     _conv_timed(lambda: check(lib.lec_conv_f32_fwd_affine(dptr(x), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), dptr(scale), dptr(shift),
-                                                          dptr(residual), 1 if relu else 0, stream_ptr())), 2.0 * n * ho * wo * cout * cin * r * s_)
+                                                          dptr(residual), 1 if relu else 0, fusion().schedule, stream_ptr())), 2.0 * n * ho * wo * cout * cin * r * s_)
     return y
 
 
@@ -851,7 +892,7 @@ def conv_f32_dgrad(dy, w, x_shape, stride, pad):
     n, cin, h, wd = x_shape; cout, _, r, s_ = w.shape
     dx = torch.empty((n, cin, h, wd), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last)
     _conv_scratch()
-    _conv_timed(lambda: check(lib.lec_conv_f32_dgrad(dptr(dy), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(dx), stream_ptr())),
+    _conv_timed(lambda: check(lib.lec_conv_f32_dgrad(dptr(dy), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(dx), fusion().schedule, stream_ptr())),
                 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * cout * cin * r * s_)
     return dx
 
@@ -878,7 +919,7 @@ def conv_f32_dgrad_fused(dy, w, x_shape, stride, pad, xf=None, fold=None):
         a = [dptr(fold['dres']), dptr(xb), dptr(fold['mask']), dptr(fold['mean']), dptr(fold['invstd'])]
     _conv_timed(lambda: check(lib.lec_conv_f32_dgrad_fused(dptr(dy), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(dx), dptr(xs), dptr(cf),
                                                            a[0], a[1], a[2], a[3], a[4], dptr(ws), ws.numel() if ws is not None else 0,
-                                                           C.byref(k) if ws is not None else None, stream_ptr())),
+                                                           C.byref(k) if ws is not None else None, fusion().schedule, stream_ptr())),
                 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * cout * cin * r * s_)
     if fold is not None:
         fc = fusion()
@@ -949,7 +990,7 @@ def conv_f32x3_fwd(x, planes, stride, pad, want_stats=False):
                                                          C.byref(k), stream_ptr())), flops)
         fusion().ws_owner[0], fusion().ws_owner[1] = y.data_ptr(), k.value
     else:
-        _conv_timed(lambda: check(lib.lec_conv_f32x3_fwd(dptr(x), dptr(planes.fwd), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), None, 0, None, stream_ptr())), flops)
+        _conv_timed(lambda: check(lib.lec_conv_f32x3_fwd(dptr(x), dptr(planes.fwd), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), None, 0, None, fusion().schedule, stream_ptr())), flops)
     return y
 
 
@@ -960,7 +1001,7 @@ def conv_f32x3_dgrad(dy, planes, x_shape, stride, pad):
     if planes.t is None:
         raise ValueError('these planes were split without the data-gradient layout')
     dx = torch.empty((n, cin, h, wd), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last)
-    _conv_timed(lambda: check(lib.lec_conv_f32x3_dgrad(dptr(dy), dptr(planes.t), n, h, wd, cin, cout, r, s_, stride, pad, dptr(dx), stream_ptr())),
+    _conv_timed(lambda: check(lib.lec_conv_f32x3_dgrad(dptr(dy), dptr(planes.t), n, h, wd, cin, cout, r, s_, stride, pad, dptr(dx), fusion().schedule, stream_ptr())),
                 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * cout * cin * r * s_)
     return dx
 

@@ -47,7 +47,7 @@ class BatchNormAct2d(nn.BatchNorm2d):
                 and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape
                                           and residual.is_contiguous(memory_format=torch.channels_last)))):
             from . import ops
-            ov = WgradOverlap.instance
+            ov = ops.overlap()
             sink = (self.weight, self.bias, ov.reducer) if (ov is not None and ov.enabled and ov.arena is not None and self.training and not ov.accumulate) else None
             return ops.BNActFn.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var,
                                      self.training, self.momentum, self.eps, self.fuse_relu, fork and self.training, sink)
@@ -69,7 +69,8 @@ class WgradOverlap:
     following layers instead of lengthening the chain.  The side stream adds the result into the parameter's `.grad`
     (the flat arena view) and tells the gradient reducer the parameter is ready; `join()` makes the main stream wait."""
 
-    instance = None
+    instance = None     # the PROCESS DEFAULT, for ops called outside a model (tests, tools) and models that name no overlap of their own.  A
+                        # trainer / engine gives its backbone its own (`ResNet.wgrad_overlap`): nothing on the step path writes this attribute.
 
     def __init__(self, reducer=None, arena=None, side_stream=True):
         """`arena` (a FlatArena with a bf16 shadow) lets convolutions read their weights in low precision without a cast
@@ -300,7 +301,7 @@ class _OverlapConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, conv):
         ctx.fc = _ops().fusion()                  # the owning backbone's fusion records (ops.FusionContext); backward restores it
-        w16 = WgradOverlap.instance.weight_lp(conv, x.dtype)
+        w16 = _ops().overlap().weight_lp(conv, x.dtype)
         nhwc = x.is_contiguous(memory_format=torch.channels_last)
         if nhwc and w16.dim() == 4 and not w16.is_contiguous(memory_format=torch.channels_last):
             w16 = w16.contiguous(memory_format=torch.channels_last)
@@ -382,7 +383,7 @@ class _OverlapConvFn(torch.autograd.Function):
             # gy is UNWRITTEN: the BatchNorm behind this layer left pass 2 of its backward to us.  With the flat arena's fp32 gradient
             # slot at hand the weight-gradient kernel does it on the way (and writes gy for the data gradient below); otherwise
             # pass 2 runs on its own first.
-            ov = WgradOverlap.instance
+            ov = _ops().overlap()
             w = conv.weight
             if (ov is not None and ov.arena is not None and w.grad is not None and w.grad.dtype == torch.float32 and _is_pointwise(conv)
                     and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
@@ -441,16 +442,18 @@ class _OverlapConvFn(torch.autograd.Function):
             if rec['dres'] is None and x.data_ptr() not in fc.folded and gx.data_ptr() not in fc.folded:
                 rec['dres'] = gx                                # (the other consumer's data gradient may fold it into its epilogue)
         if not wgrad_done:
-            WgradOverlap.instance.submit(gy, x, w16, conv, xf=xf)
+            _ops().overlap().submit(gy, x, w16, conv, xf=xf)
+        if getattr(conv, 'is_stem', False):
+            fc.in_flight = False                                # the stem's backward is the last node of the backbone's: the context is free again
         return gx, None, None
 
 
 class Conv2d(nn.Conv2d):
-    """nn.Conv2d whose weight gradient can be computed on the side stream of `WgradOverlap.instance` (GPU, low-precision
+    """nn.Conv2d whose weight gradient can be computed on the side stream of the pass's WgradOverlap (`ops.overlap()`; GPU, low-precision
     activations, training).  Same parameters and state-dict keys as nn.Conv2d."""
 
     def forward(self, x):
-        ov = WgradOverlap.instance
+        ov = _ops().overlap()
         # (also under torch.no_grad(): the forward-only first pass of a chunked step must run the SAME kernels as the pass that is
         # differentiated -- the loss gradient is evaluated at the first pass's outputs)
         if (ov is not None and ov.enabled and x.is_cuda and self.training and self.bias is None
@@ -541,6 +544,7 @@ class ResNet(nn.Module):
         super().__init__()
         self.inplanes = 64
         self.conv1 = Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.conv1.is_stem = True                               # its backward is the last node of the backbone's backward (FusionContext.in_flight)
         self.bn1 = BatchNormAct2d(64, relu=True)
         self.maxpool = MaxPool3x3s2()
         self.layer1 = self._make_layer(block, 64, layers[0])
@@ -567,9 +571,17 @@ class ResNet(nn.Module):
             layers.append(block(self.inplanes, planes))
         return nn.Sequential(*layers)
 
-    def forward(self, x, pooled_only=False):
+    # Settings of THIS backbone's forward / backward passes, copied into the FusionContext of every forward (ops.FusionContext) -- per object,
+    # not per process: two trainers / engines in one process, or driven from two threads, do not see each other's.
+    wgrad_overlap = None            # the WgradOverlap its convolutions / BatchNorms report to (None: the process default WgradOverlap.instance)
+    bn_grad_accumulate = False      # BatchNorm backward ADDS d gamma / d beta (a step of several backward passes zeroes the slots once)
+    conv_schedule = -1              # LEC_SCHEDULE_* of the fp32 forward / data-gradient launches (-1: the library default)
+    step_timers = None              # {'bn': [], 'conv': []}: per-launch HIP events while the owner profiles its step (bench.py)
+
+    def forward(self, x, pooled_only=False, pass_order=None):
         """pooled_only: stop after the global average pooling ([n, 512 * expansion] features); `self.fc` is then the caller's to apply --
-        the engine's concurrent half-batch passes pool per pass and run the fully connected layer ONCE over all rows."""
+        the engine's concurrent half-batch passes pool per pass and run the fully connected layer ONCE over all rows.
+        pass_order = (dict shared by the passes of a step, index of this pass): see ops.BNActFn.forward."""
         if x.is_cuda and torch.is_autocast_enabled() and x.dtype == torch.float32:
             x = x.to(torch.get_autocast_dtype('cuda'))          # the stem conv sees low-precision input like every other layer
         if not x.is_cuda:
@@ -586,11 +598,16 @@ class ResNet(nn.Module):
             else:                                               # forwards whose backward never ran (or raised): recycle the oldest
                 fc = pool.pop(0); pool.append(fc)
         fc.reset()
+        fc.overlap, fc.accumulate, fc.schedule, fc.pass_order = self.wgrad_overlap, bool(self.bn_grad_accumulate), int(self.conv_schedule), pass_order
+        tm = self.step_timers
+        fc.bn_timer, fc.conv_timer = (tm['bn'], tm['conv']) if tm is not None else (None, None)
         self.__dict__['_fusion'] = fc
         with _ops().use_fusion(fc):
             y = self._forward(x, pooled_only)
         if not track:
             fc.reset()                                          # no backward will come for these records
+        else:
+            fc.in_flight = True                                 # until the stem's backward has run (or the pool recycles it)
         return y
 
     def __deepcopy__(self, memo):
@@ -600,7 +617,7 @@ class ResNet(nn.Module):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k not in ('_fusions', '_fusion'):
+            if k not in ('_fusions', '_fusion', 'wgrad_overlap', 'step_timers'):    # (streams, events: launch resources of the original's owner)
                 new.__dict__[k] = copy.deepcopy(v, memo)
         return new
 

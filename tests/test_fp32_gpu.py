@@ -551,10 +551,11 @@ def test_conv_macs_walks_the_modules_on_the_gpu_too():
 
 # ------------------------------------------------------------------------------------------------ round 3: the balanced (stream-K) kernel
 class _Balanced:
-    """lec_conv_f32_balanced(mode) for the duration of a block (2: the balanced kernel wherever it applies, 0: never)."""
+    """The `schedule` argument of the fp32 forward / data-gradient entry points (LEC_SCHEDULE_*) for the ops called in a block -- through the
+    current FusionContext, as a backbone's conv_schedule reaches them (2: the balanced kernel wherever it applies, 0: never)."""
     def __init__(self, mode): self.mode = mode
-    def __enter__(self): self.prev = ops.lib.lec_conv_f32_balanced(self.mode)
-    def __exit__(self, *a): ops.lib.lec_conv_f32_balanced(self.prev)
+    def __enter__(self): self.fc = ops.fusion(); self.prev = self.fc.schedule; self.fc.schedule = self.mode
+    def __exit__(self, *a): self.fc.schedule = self.prev
 
 
 SK_CASES = [  # N, Cin, H, W, Cout, R, pad: one workgroup per K chunk (tiny), tiles over 3 - 4 workgroups, whole tiles + split ends, ragged rows / channels
@@ -565,7 +566,7 @@ SK_CASES = [  # N, Cin, H, W, Cout, R, pad: one workgroup per K chunk (tiny), ti
 
 @pytest.mark.parametrize('N,Cin,H,W,Cout,R,pad', SK_CASES)
 def test_conv_f32_balanced_kernel_equals_float64_on_integers_and_is_run_to_run_identical(N, Cin, H, W, Cout, R, pad):
-    """conv_f32_act_sk_kernel (lec_conv_f32_balanced(2): every eligible launch): forward with statistics and the stride-1 data gradient.
+    """conv_f32_act_sk_kernel (schedule LEC_SCHEDULE_BALANCED: every eligible launch): forward with statistics and the stride-1 data gradient.
     Small-integer operands: every partial sum is exact, so the outputs and the per-channel statistics must EQUAL float64 whatever way the
     K range of a tile was cut over workgroups (a lost, doubled or stale partial is a mismatch, not noise).  Random operands: fp32 noise
     against float64, and bit-identical results over repeated launches (the fix-up adds the partials in workgroup order, not arrival
@@ -649,7 +650,7 @@ def test_conv_f32_full_size_layers_are_exact_on_integers_with_either_schedule(N,
 @pytest.mark.parametrize('N,Cin,H,W,Cout,R,pad,wgs', [(10, 256, 14, 14, 256, 3, 1, 288), (10, 1024, 14, 14, 256, 1, 0, 128), (10, 512, 7, 7, 512, 3, 1, 288),
                                                         (10, 256, 14, 14, 1024, 1, 0, 0), (256, 256, 14, 14, 256, 3, 1, 512)])
 def test_conv_f32_launcher_cuts_small_batches_along_k(N, Cin, H, W, Cout, R, pad, wgs):
-    """The launcher's own choice (lec_conv_f32_balanced(1)): a 10-image batch (the reference's evaluation chunk) gives layer3 / layer4 a few dozen
+    """The launcher's own choice (schedule LEC_SCHEDULE_AUTO): a 10-image batch (the reference's evaluation chunk) gives layer3 / layer4 a few dozen
     tiles -- the balanced kernel cuts them along K into `wgs` workgroups of >= 8 chunks (0: the cut would not add parallel work, the tile walk runs).
     Which kernel ran shows in the number of statistics rows (one per m-tile when balanced); results exact on integers either way."""
     g = torch.Generator(device='cpu').manual_seed(N + Cin + Cout + R)
@@ -719,7 +720,7 @@ def test_conv_f32_gradients_with_batchnorm_backward_pass2_on_the_operand_load(N,
     part[0, 1] = (q * 0.5).float(); part[1, 1] = (q - (q * 0.5).float().double()).float()
     dgamma = torch.empty(Cout, device=DEV); dbeta = torch.empty(Cout, device=DEV); coef = torch.empty(3 * Cout, device=DEV)
     from learning_embeddings_amd._lib import lib, check, dptr, stream_ptr
-    check(lib.lec_bn_bwd_coeffs_f32(M, Cout, 2, dptr(gamma), dptr(mean32), dptr(invstd32), dptr(dgamma), dptr(dbeta), dptr(coef), dptr(ws), ws.numel(), stream_ptr()))
+    check(lib.lec_bn_bwd_coeffs_f32(M, Cout, 2, dptr(gamma), dptr(mean32), dptr(invstd32), dptr(dgamma), dptr(dbeta), dptr(coef), dptr(ws), ws.numel(), 0, stream_ptr()))
     c1, c2 = s / M, q / M
     gs = gamma.double() * invstd32.double()
     want_coef = torch.stack([gs, -gs * invstd32.double() * c2, gs * (invstd32.double() * c2 * mean32.double() - c1)])

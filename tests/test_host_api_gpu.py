@@ -1098,15 +1098,15 @@ def test_step_engine_concurrent_half_batch_passes_equal_the_same_passes_in_turn(
         codes = b.codes_dev
         images = b.pool.index_select(0, b.idx_dev)
         b.arena.zero_grad(); b.table_grad.zero_(); b.gfeat.zero_()
-        from learning_embeddings_amd import _lib                    # (lec_bn_bwd_accumulate(1) is on, process-wide, since engine a exists)
-        prev = _lib.lib.lec_conv_f32_balanced(0)                    # the kernels engine a's passes run (a multi-pass step uses the tile walk): same summation order
+        from learning_embeddings_amd import _lib
+        b.backbone.bn_grad_accumulate = True                        # two backward passes add into b's gradient slots (engine b's OWN setting: a's is not seen here)
+        b.backbone.conv_schedule = _lib.SCHEDULE_TILE_WALK          # the kernels engine a's passes run (a multi-pass step uses the tile walk): same summation order
         parts = [b.img_feat_net.forward_raw(images[p * h:(p + 1) * h]) for p in range(2)]
         feats = torch.cat([f.detach() for f in parts]); b.last_feats = feats
         out = ops.joint_loss_raw(b.table, feats, codes[:, 0].contiguous(), codes[:, 1].contiguous(), codes[:, 2:].contiguous(), None, b.K_cone, b.alpha,
                                  _lib.ENERGY_HYP_CONE, _lib.LABEL_HYP, _lib.IMAGE_SOFTCLIP, b.table_grad, b.gfeat)
         for p in range(2):
             parts[p].backward(b.gfeat[p * h:(p + 1) * h])
-        _lib.lib.lec_conv_f32_balanced(prev)
         return out
     b._core = core_in_turn
     for s_ in range(2):
@@ -1153,8 +1153,8 @@ def test_joint_embeddings_trainer_two_concurrent_cnn_passes_equal_two_passes_in_
         assert tr.cnn_passes == (1 if tag == 'one_pass' else 2) and (tr.overlap.side is None) == (tag != 'one_pass')
         if tag == 'in_turn':                                     # the same two halves, one stream
             net = tr.img_feat_net
-            def in_turn(x, _n=net):
-                h = -(-x.shape[0] // 2)
+            def in_turn(x, split=None, _n=net):
+                h = split if (split is not None and 0 < split < x.shape[0]) else -(-x.shape[0] // 2)   # the criterion's cut: positives | negatives
                 return _n.model.fc(torch.cat([_n.model(x[:h], pooled_only=True), _n.model(x[h:], pooled_only=True)])).float()
             net._forward_raw_passes = in_turn
         crit.set_dataloader(tr.datasets['train'])
@@ -1170,3 +1170,82 @@ def test_joint_embeddings_trainer_two_concurrent_cnn_passes_equal_two_passes_in_
     assert abs(a[0] - b[0]) <= 1e-6 * max(1.0, abs(b[0])) and (a[1] - b[1]).abs().max().item() <= 1e-6
     assert (a[2] - b[2]).double().norm().item() / b[2].double().norm().item() < 1e-5
     assert abs(a[0] - c[0]) > 1e-6 * max(1.0, abs(c[0]))          # one BatchNorm batch of all rows is a different function
+
+
+def test_two_trainers_on_two_threads_with_different_settings_equal_each_alone(tmp_path):
+    """No process-wide switches on the step path: the BatchNorm `accumulate` flag and the convolution
+    `schedule` are per-call arguments of the C ABI fed from the owning backbone (ResNet.bn_grad_accumulate / conv_schedule / wgrad_overlap ->
+    the FusionContext of each forward), and the context stack is per thread.  Trainer A (two concurrent CNN passes: BatchNorm gradients
+    ADD, tile-walk convolutions, weight gradients in line) and trainer B (one pass: BatchNorm gradients OVERWRITE, balanced convolutions
+    wherever they apply, weight gradients on a side stream) step at the same time from two Python threads; each must do what it does alone.
+    With a shared switch A's BatchNorm gradients would lose a pass (or B's would pile up): far outside the tolerance below."""
+    import threading
+    from test_host_cpu import _fake_loaders
+    from learning_embeddings_amd import _lib
+    lm = SyntheticLabelMap([2, 4, 8])
+    dl = _fake_loaders(lm, 32, 8)
+    for split in dl.values():
+        for b in split:
+            b['path_to_image'] = [torch.rand(3, 64, 64, generator=torch.Generator().manual_seed(int(n[4:]))).to(DEV) for n in b['image_filename']]
+    gd = oe_h.create_combined_graphs(dl, lm, pick_per_level=True)
+    n_steps = 3
+
+    def build(tag, passes):
+        crit = oe_h.EuclideanConesWithImagesHypernymLoss(lm, 5, {}, 0.05, True, K=0.1, use_CNN=True)
+        tr = oe_h.JointEmbeddings(gd, dl, image_dir='', use_CNN=True, labelmap=lm, criterion=crit, lr=1e-4, n_workers=0,
+                                  batch_size=16, experiment_name=tag, embedding_dim=10, neg_to_pos_ratio=5, image_fc7=None,
+                                  normalize=None, alpha=0.05, experiment_dir=str(tmp_path), n_epochs=1, eval_interval=5, cnn_passes=passes)
+        bb = tr.img_feat_net.model
+        if passes == 1:
+            bb.conv_schedule = _lib.SCHEDULE_BALANCED
+        assert bb.bn_grad_accumulate == (passes == 2) and bb.wgrad_overlap is tr.overlap
+        crit.set_dataloader(tr.datasets['train']); tr.train_set.transform = None
+        tr.model.train(); tr.img_feat_net.train()
+        items = []
+        it = iter(tr.dataloaders['train'])
+        for _ in range(n_steps):
+            items.append(next(it))
+        return tr, items
+
+    def run(tr, items, out, barrier=None):
+        try:
+            for k, item in enumerate(items):
+                if barrier is not None:
+                    barrier.wait(timeout=60)
+                loss = tr.train_step(item)[0]
+                if k == 0:
+                    out['grad0'] = tr.arena.grad.clone()
+                    bn = [p.grad for n_, p in tr.img_feat_net.named_parameters() if 'bn' in n_ and p.grad is not None]
+                    out['bn_grad0'] = torch.cat([g.flatten() for g in bn]).clone()
+                out.setdefault('loss', []).append(loss)
+            torch.cuda.synchronize()
+            out['loss'] = [float(l) for l in out['loss']]
+            out['table'] = tr.model.embeddings.weight.detach().clone()
+        except Exception as e:                                  # noqa: BLE001  (surface it in the main thread)
+            out['error'] = e
+
+    alone = {}
+    for tag, passes in (('A', 2), ('B', 1)):
+        tr, items = build(tag + '_alone', passes)
+        alone[tag] = {}
+        run(tr, items, alone[tag])
+        assert 'error' not in alone[tag], alone[tag].get('error')
+    both = {'A': {}, 'B': {}}
+    trA, itA = build('A_thread', 2); trB, itB = build('B_thread', 1)
+    bar = threading.Barrier(2)
+    ths = [threading.Thread(target=run, args=(trA, itA, both['A'], bar)), threading.Thread(target=run, args=(trB, itB, both['B'], bar))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    for tag in ('A', 'B'):
+        got, want = both[tag], alone[tag]
+        assert 'error' not in got, got.get('error')
+        assert abs(got['loss'][0] - want['loss'][0]) <= 1e-6 * max(1.0, abs(want['loss'][0])), tag
+        np.testing.assert_allclose(got['loss'], want['loss'], rtol=1e-3)
+        rel = lambda a, b: (a - b).double().norm().item() / max(b.double().norm().item(), 1e-30)
+        assert rel(got['bn_grad0'], want['bn_grad0']) < 1e-4, (tag, rel(got['bn_grad0'], want['bn_grad0']))
+        assert rel(got['grad0'], want['grad0']) < 1e-4, tag
+        assert (got['table'] - want['table']).abs().max().item() <= 1e-5, tag
+    # and the two really ran differently: A's BatchNorm batch is a pass, B's all rows
+    assert abs(alone['A']['loss'][0] - alone['B']['loss'][0]) > 1e-6

@@ -149,9 +149,10 @@ def test_store_rows_are_bit_equal_to_get_image_and_getitem(tmp_path):
     g4 = st.gather(st.resolve(names), None, c_out=4)
     assert torch.equal(g4[:, :3].cpu(), torch.stack([ds.get_image(n) for n in names])) and not g4[:, 3].any()
     # a train item: the ref's flip applied on the GPU == the tensor path's transform on the host
-    torch.manual_seed(5); refs = [ds[i]['to'] for i in range(10)]
+    items = [i for i in range(len(ds)) if type(ds.edge_of(i)[1]) == str][:10]
+    torch.manual_seed(5); refs = [ds[i]['to'] for i in items]
     sv, ds.store_view = ds.store_view, None
-    torch.manual_seed(5); tens = [ds[i]['to'] for i in range(10)]
+    torch.manual_seed(5); tens = [ds[i]['to'] for i in items]
     ds.store_view = sv
     assert any(r.flip for r in refs)
     got = st.batch([r.name for r in refs], [r.flip for r in refs])
@@ -190,7 +191,8 @@ def test_trainer_from_files_store_path_equals_host_tensor_path(tmp_path, lookahe
         assert a.shape == b.shape and torch.equal(a, b.to(a.device))
     st = runs['store'][4].image_store.stats
     assert st['decoded_here'] > 0 and st['uploads'] >= 1
-    np.testing.assert_allclose(s[2], h[2], rtol=2e-3)
+    assert s[2][0] == h[2][0]                                           # same weights, same batch, a forward without atomics: the same loss
+    np.testing.assert_allclose(s[2], h[2], rtol=3e-2)                   # later steps: the weight gradients' float atomics, through Adam at lr 1e-3
 
 
 def test_trainer_from_files_with_dataloader_workers(tmp_path):

@@ -607,10 +607,10 @@ def test_conv1x1_dgrad_with_batchnorm_backward_pass1_in_the_epilogue(cin, cout, 
     # finish the backward from the partials; against lec_bn_bwd on the unfused inputs
     dx = torch.empty_like(xbn); dgam = torch.empty(cout, device=DEV); dbet = torch.empty(cout, device=DEV)
     check(lib.lec_bn_bwd_prereduced(dptr(g), dptr(xbn), M, cout, dptr(gamma), dptr(mean), dptr(invstd), n, dptr(dx), dptr(dgam), dptr(dbet),
-                                    dptr(ws), ws.numel(), stream_ptr()))
+                                    dptr(ws), ws.numel(), 0, stream_ptr()))
     dx2 = torch.empty_like(xbn); dres2 = torch.empty_like(xbn); dgam2 = torch.empty_like(dgam); dbet2 = torch.empty_like(dbet)
     check(lib.lec_bn_bwd(dptr(nhwc(dyc)), dptr(dy2), None, dptr(mask), dptr(xbn), M, cout, dptr(gamma), dptr(mean), dptr(invstd), dptr(dx2),
-                         dptr(dres2), dptr(dgam2), dptr(dbet2), 1, dptr(ws), ws.numel(), stream_ptr()))
+                         dptr(dres2), dptr(dgam2), dptr(dbet2), 1, dptr(ws), ws.numel(), 0, stream_ptr()))
     assert torch.equal(dres2.permute(0, 2, 3, 1).reshape(M, cout), g)
     assert torch.allclose(dgam, dgam2, rtol=1e-4, atol=1e-3) and torch.allclose(dbet, dbet2, rtol=1e-4, atol=1e-3)
     assert (dx.float() - dx2.float()).abs().max().item() <= 2e-2 * dx2.float().abs().max().item()
@@ -676,7 +676,7 @@ def test_conv1x1_wgrad_with_batchnorm_backward_pass2_in_its_staging(cin, cout, M
     ws[:2 * cout * 4].view(torch.float32).copy_(part.flatten())
     dx_ref = torch.empty_like(g); dgam = torch.empty(cout, device=DEV); dbet = torch.empty(cout, device=DEV)
     check(lib.lec_bn_bwd_prereduced(dptr(g), dptr(xbn), M, cout, dptr(gamma), dptr(mean), dptr(invstd), 1, dptr(dx_ref), dptr(dgam), dptr(dbet),
-                                    dptr(ws), ws.numel(), stream_ptr()))
+                                    dptr(ws), ws.numel(), 0, stream_ptr()))
     off = lib.lec_bn_workspace_coeff_offset(cout)
     dx = torch.empty_like(g); dw = torch.full((cout, cin), 0.5, device=DEV)
     check(lib.lec_conv1x1_wgrad_bnapply(dptr(g), dptr(xbn), dptr(x), M, cin, cout, dptr(gamma), dptr(mean), dptr(invstd),

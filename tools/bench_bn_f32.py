@@ -33,7 +33,7 @@ for (N, Cc, H) in [(512, 256, 56), (512, 64, 56), (512, 512, 28), (512, 1024, 14
     f = lambda name: getattr(lib, name + sfx)
     fwd = lambda: check(f('lec_bn_fwd')(dptr(x), dptr(r), M, Cc, dptr(w), dptr(b), 1e-5, 0.1, dptr(rm), dptr(rv), 1, dptr(sm), dptr(si), dptr(y), 1, dptr(mask), dptr(ws), ws.numel(), stream_ptr()))
     fwd_pre = lambda: check(f('lec_bn_fwd_prestat')(dptr(x), dptr(r), M, Cc, dptr(w), dptr(b), 1e-5, 0.1, dptr(rm), dptr(rv), 64, dptr(sm), dptr(si), dptr(y), 1, dptr(mask), dptr(ws), ws.numel(), stream_ptr()))
-    p1 = lambda: check(f('lec_bn_bwd_pass1')(dptr(dy), dptr(r), dptr(mask), dptr(x), M, Cc, dptr(sm), dptr(si), dptr(g), dptr(dg), dptr(db), dptr(ws), ws.numel(), stream_ptr()))
+    p1 = lambda: check(f('lec_bn_bwd_pass1')(dptr(dy), dptr(r), dptr(mask), dptr(x), M, Cc, dptr(sm), dptr(si), dptr(g), dptr(dg), dptr(db), dptr(ws), ws.numel(), 0, stream_ptr()))
     p2 = lambda: check(f('lec_bn_bwd_apply')(dptr(g), dptr(x), M, Cc, dptr(w), dptr(sm), dptr(si), dptr(dx), dptr(ws), ws.numel(), stream_ptr()))
     el = M * Cc
     t_f, t_fp, t_1, t_2 = t(fwd), t(fwd_pre), t(p1), t(p2)

@@ -92,7 +92,7 @@ def time_bn(N=512, C=256, H=56, W=56, residual=True, iters=20):
         check(lib.lec_bn_fwd(dptr(x), dptr(r), M, C, dptr(w), dptr(b), 1e-5, 0.1, dptr(rm), dptr(rv), 1, dptr(sm), dptr(si), dptr(y), 1,
                              dptr(mask), dptr(ws), ws.numel(), stream_ptr()))
         check(lib.lec_bn_bwd(dptr(dy), None, None, dptr(mask), dptr(x), M, C, dptr(w), dptr(sm), dptr(si), dptr(dx), dptr(dr), dptr(dg), dptr(db), 1,
-                             dptr(ws), ws.numel(), stream_ptr()))
+                             dptr(ws), ws.numel(), 0, stream_ptr()))
     for _ in range(3): run()
     torch.cuda.synchronize()
     a = torch.cuda.Event(enable_timing=True); c = torch.cuda.Event(enable_timing=True)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The balanced (stream-K) form of the fp32 forward / stride-1 data gradient against the tile walk, layer by layer: ResNet-50's convolution
 shapes at the rows one pass of the step carries (default 256: the bench's 512 rows run as two concurrent passes).  Per layer: tiles, rounds of
-the 512 workgroup slots, microseconds and TFLOP/s with lec_conv_f32_balanced(0) (tile walk), (2) (balanced wherever it applies) and (1) (the
+the 512 workgroup slots, microseconds and TFLOP/s with schedule 0 (tile walk), 2 (balanced wherever it applies) and (1) (the
 launcher's choice).  usage: python tools/bench_conv_f32_balanced.py [--rows 256] [--iters 10] [--json out.json]"""
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -49,9 +49,9 @@ def net_forward():
             tm = {0: [], 1: []}
             for rep in range(3):
                 for mode in (0, 1):
-                    prev = ops.lib.lec_conv_f32_balanced(mode)
+                    net.model.conv_schedule = mode                    # ResNet.conv_schedule -> the `schedule` argument of every launch of this forward
                     tm[mode].append(timeit(lambda: net(x), 5))
-                    ops.lib.lec_conv_f32_balanced(prev)
+                    net.model.conv_schedule = -1
         a0, a1 = sorted(tm[0])[1], sorted(tm[1])[1]
         # the same forward replayed as a hipGraph (JointEmbeddings.embed_images does this from a chunk shape's third occurrence on)
         st = torch.cuda.Stream()
@@ -90,10 +90,10 @@ for name, cin, hw, cout, r, st, pad in SHAPES:
     tm = {m: {'f': [], 'd': []} for m in (0, 2, 1)}
     for rep in range(3):
         for mode in (0, 2, 1):
-            prev = ops.lib.lec_conv_f32_balanced(mode)
+            prev = ops.fusion().schedule; ops.fusion().schedule = mode
             tm[mode]['f'].append(timeit(lambda: ops.conv_f32_fwd(x, w, st, pad, want_stats=True), a.iters))
             tm[mode]['d'].append(timeit(lambda: ops.conv_f32_dgrad(dy, w, x.shape, st, pad), a.iters) if st == 1 else float('nan'))
-            ops.lib.lec_conv_f32_balanced(prev)
+            ops.fusion().schedule = prev
     for mode in (0, 2, 1):
         t_f = sorted(tm[mode]['f'])[1]; t_d = sorted(tm[mode]['d'])[1]
         row['fwd_us_%d' % mode] = round(t_f, 1); row['dgrad_us_%d' % mode] = round(t_d, 1)

@@ -55,7 +55,7 @@ for name, cin, hw, cout, r, pad in SHAPES:
     ws = ops._bn_workspace(xin.device)
     dg = torch.empty(cin, device=dev); db = torch.empty(cin, device=dev); gout = torch.empty_like(xin)
     row['bn_pass1_in'] = timeit(lambda: check(lib.lec_bn_bwd_pass1_f32(dptr(xin), dptr(dres), dptr(mask), dptr(xbn_in), M, cin, dptr(mean_i), dptr(inv_i), dptr(gout),
-                                                                       dptr(dg), dptr(db), dptr(ws), ws.numel(), stream_ptr())), a.iters)
+                                                                       dptr(dg), dptr(db), dptr(ws), ws.numel(), 0, stream_ptr())), a.iters)
     dxo = torch.empty_like(g)
     row['bn_pass2_out'] = timeit(lambda: check(lib.lec_bn_bwd_apply_f32(dptr(g), dptr(xbn_out), M, cout, dptr(gamma_o), dptr(mean_o), dptr(inv_o), dptr(dxo),
                                                                         dptr(ws), ws.numel(), stream_ptr())), a.iters)

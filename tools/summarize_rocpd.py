@@ -8,6 +8,8 @@ ap = argparse.ArgumentParser(); ap.add_argument('db'); ap.add_argument('--steps'
 ap.add_argument('--marker', default='joint_loss_kernel'); ap.add_argument('--skip-last', type=int, default=3)
 ap.add_argument('--grid', type=int, default=0, help='grid_x of the bench-step launch of the marker kernel (0: any)')
 ap.add_argument('--top', type=int, default=45)
+ap.add_argument('--conv-tflop-per-step', type=float, default=0.0, help='algorithmic convolution TFLOP of one step (bench.py: roofline.alg_flops_per_step / 1e12): prints the family\'s roofline fraction')
+ap.add_argument('--peak-tflops', type=float, default=157.3)
 a = ap.parse_args()
 c = sqlite3.connect(a.db)
 rows = c.execute('select name, start, end, grid_x, vgpr_count, lds_size from kernels order by start').fetchall()
@@ -50,3 +52,46 @@ for k, d in sorted(cats.items(), key=lambda kv: -kv[1]):
 print('\n| kernel | ms/step | share | launches/step | avg us |\n|---|---|---|---|---|')
 for k, (d, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:a.top]:
     print('| `%s` | %.3f | %.1f %% | %.0f | %.1f |' % (k, d / n / 1e6, 100 * d / tot, cnt / n, d / cnt / 1e3))
+
+
+
+# ---- kernel FAMILIES: sum of launch durations AND the union of their launch intervals (launches of a family overlap when the step runs as
+# concurrent passes / streams: the sum then counts shared time once per stream, the union is the time the family had the GPU at all)
+def family(k):
+    if 'conv_f32' in k or 'conv1x1' in k or 'conv3x3' in k or 'wgrad' in k: return 'convolutions (conv_f32.hip / conv_mfma.hip / conv_f32x3.hip)'
+    if 'lec::bn_' in k or 'lec::bn' in k: return 'BatchNorm family (bn.hip)'
+    if 'joint_loss' in k: return 'fused cone loss (joint_loss.hip)'
+    if 'lec::' in k: return 'other liblecone kernels'
+    return 'library / framework kernels'
+
+
+def union_ns(iv):
+    iv = sorted(iv); tot = 0; cs, ce = iv[0]
+    for s_, e_ in iv[1:]:
+        if s_ > ce:
+            tot += ce - cs; cs, ce = s_, e_
+        else:
+            ce = max(ce, e_)
+    return tot + ce - cs
+
+
+fam_iv = collections.defaultdict(list)
+for nm, s_, e_, g, v, l in sel:
+    fam_iv[family(short(nm))].append((s_, e_))
+print('\n## kernel families: sum of launch durations vs union of launch intervals (ms per step)\n')
+print('| family | launches/step | sum of durations | union of intervals | union / step wall |\n|---|---|---|---|---|')
+wall = (hi - lo) / n / 1e6
+for k, iv in sorted(fam_iv.items(), key=lambda kv: -sum(e_ - s_ for s_, e_ in kv[1])):
+    u = union_ns(iv) / n / 1e6
+    print('| %s | %.0f | %.3f | %.3f | %.3f |' % (k, len(iv) / n, sum(e_ - s_ for s_, e_ in iv) / n / 1e6, u, u / wall))
+print('| ALL kernels | %.0f | %.3f | %.3f | %.3f |' % (len(sel) / n, tot / n / 1e6, union_ns([(r[1], r[2]) for r in sel]) / n / 1e6,
+                                                     union_ns([(r[1], r[2]) for r in sel]) / n / 1e6 / wall))
+if a.conv_tflop_per_step:
+    ck = [k for k in fam_iv if k.startswith('convolutions')]
+    if ck:
+        u = union_ns(fam_iv[ck[0]]) / n / 1e9
+        sm = sum(e_ - s_ for s_, e_ in fam_iv[ck[0]]) / n / 1e9
+        print('\nconvolution family roofline (%.3f algorithmic TFLOP per step, peak %.1f TFLOP/s):\n' % (a.conv_tflop_per_step, a.peak_tflops))
+        print('| basis | seconds/step | TFLOP/s | fraction of peak |\n|---|---|---|---|')
+        for nm_, t_ in (('union of the family\'s launch intervals (bench.py roofline.frac)', u), ('step wall time (lower bound)', wall / 1e3), ('sum of launch durations (as if serial)', sm)):
+            print('| %s | %.6f | %.2f | %.4f |' % (nm_, t_, a.conv_tflop_per_step / t_, a.conv_tflop_per_step / t_ / a.peak_tflops))
