@@ -990,7 +990,7 @@ def conv_f32x3_fwd(x, planes, stride, pad, want_stats=False):
                                                          C.byref(k), stream_ptr())), flops)
         fusion().ws_owner[0], fusion().ws_owner[1] = y.data_ptr(), k.value
     else:
-        _conv_timed(lambda: check(lib.lec_conv_f32x3_fwd(dptr(x), dptr(planes.fwd), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), None, 0, None, fusion().schedule, stream_ptr())), flops)
+        _conv_timed(lambda: check(lib.lec_conv_f32x3_fwd(dptr(x), dptr(planes.fwd), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), None, 0, None, stream_ptr())), flops)
     return y
 
 
@@ -1001,7 +1001,7 @@ def conv_f32x3_dgrad(dy, planes, x_shape, stride, pad):
     if planes.t is None:
         raise ValueError('these planes were split without the data-gradient layout')
     dx = torch.empty((n, cin, h, wd), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last)
-    _conv_timed(lambda: check(lib.lec_conv_f32x3_dgrad(dptr(dy), dptr(planes.t), n, h, wd, cin, cout, r, s_, stride, pad, dptr(dx), fusion().schedule, stream_ptr())),
+    _conv_timed(lambda: check(lib.lec_conv_f32x3_dgrad(dptr(dy), dptr(planes.t), n, h, wd, cin, cout, r, s_, stride, pad, dptr(dx), stream_ptr())),
                 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * cout * cin * r * s_)
     return dx
 

@@ -54,3 +54,34 @@ def test_conv_f32x3_host_geometry_queries():
     assert lib.lec_conv_f32x3_wgrad_supported(128, 128, 3, 3) == 1 and lib.lec_conv_f32x3_wgrad_supported(2048, 512, 1, 1) == 1
     assert lib.lec_conv_f32x3_wgrad_supported(64, 256, 1, 1) == 1 and lib.lec_conv_f32x3_wgrad_supported(256, 64, 3, 3) == 1
     assert lib.lec_conv_f32x3_wgrad_supported(192, 128, 1, 1) == 0 and lib.lec_conv_f32x3_wgrad_supported(4, 64, 7, 7) == 0 and lib.lec_conv_f32x3_wgrad_supported(32, 64, 1, 1) == 0
+
+
+def test_every_ctypes_call_site_passes_the_declared_number_of_arguments():
+    """ctypes lets a cdecl call pass MORE arguments than `argtypes` names (and a shifted argument list is a segfault on the GPU box, not a
+    Python error): every `lib.lec_*(...)` / `_dt('lec_*', ...)(...)` call in the package, the tests, the tools and bench.py is checked against
+    the signature table of learning_embeddings_amd/_lib.py."""
+    import ast, glob, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, 'learning_embeddings_amd', '_lib.py')).read()
+    sig = {m.group(1): len([a for a in m.group(3).split(',') if a.strip()]) for m in re.finditer(r"'(lec_\w+)': \((\w+), \[(.*?)\]\)", src)}
+    twins = re.search(r"for base in \((.*?)\):\s+sig\[base \+ '_f32'\]", src, re.S).group(1)
+    for base in re.findall(r"'(lec_\w+)'", twins):
+        sig[base + '_f32'] = sig[base]
+    assert len(sig) > 80
+    files = [f for pat in ('learning_embeddings_amd/*.py', 'tests/*.py', 'tools/*.py', 'bench.py', '__graft_entry__.py') for f in glob.glob(os.path.join(root, pat))]
+    bad, seen = [], 0
+    for f in files:
+        for node in ast.walk(ast.parse(open(f).read())):
+            if not isinstance(node, ast.Call):
+                continue
+            fn, name = node.func, None
+            if isinstance(fn, ast.Attribute) and fn.attr.startswith('lec_'):
+                name = fn.attr
+            elif (isinstance(fn, ast.Call) and fn.args and isinstance(fn.args[0], ast.Constant) and str(fn.args[0].value).startswith('lec_')
+                  and getattr(fn.func, 'id', getattr(fn.func, 'attr', '')) in ('_dt', 'f')):
+                name = fn.args[0].value
+            if name in sig and not any(isinstance(a, ast.Starred) for a in node.args):
+                seen += 1
+                if len(node.args) != sig[name]:
+                    bad.append('%s:%d %s passes %d arguments, the ABI takes %d' % (os.path.relpath(f, root), node.lineno, name, len(node.args), sig[name]))
+    assert seen > 100 and not bad, '\n'.join(bad)
