@@ -196,7 +196,8 @@ class FeatCNN18(_ImageNetBase):
             self.model = self.model.to(memory_format=torch.channels_last)
 
     def load_model(self, weights=None):
-        self.model = resnet18() if self.arch == 'resnet18' else resnet50()
+        # arch: 'resnet18' | 'resnet50' | a callable returning a resnet.ResNet (narrow stand-in backbones of the parity fixtures)
+        self.model = self.arch() if callable(self.arch) else (resnet18() if self.arch == 'resnet18' else resnet50())
         if weights is not None:
             sd = torch.load(weights, map_location='cpu') if isinstance(weights, str) else weights
             sd = {k[len('module.'):] if k.startswith('module.') else k: v for k, v in sd.items()}
@@ -367,30 +368,18 @@ class _JointCriterionBase(torch.nn.Module):
         self.last_negatives = neg
         # one CNN forward over the DISTINCT images of the step: the batch's own images + images drawn as negatives.  A row is either a
         # float tensor (the reference's host path) or (name, mirrored) for the image store to build on the GPU.
+        if getattr(self, 'reference_exact_batches', False):
+            return self._forward_reference_batches(model, img_feat_net, inputs_from, inputs_to, original_from, original_to, neg)
         store = getattr(self, 'image_store', None)
         i2n = self.mapping_from_ix_to_node
-
-        def by_name(name):
-            if store is not None and store.holds(name):
-                return (name, False)                                     # get_image: the val/test transform, no flip (oe_h.py:668-677)
-            return self.dataloader.get_image(name)
-
         slot, rows = {}, []
         for elem, ix in zip(list(inputs_from) + list(inputs_to), np.concatenate([ix_from, ix_to]).tolist()):
             if ix >= N and ix not in slot:
-                if isinstance(elem, ImageRef):
-                    if store is None:
-                        raise RuntimeError('the batch carries ImageRef handles but the criterion has no image_store')
-                    if elem.pixels is not None:
-                        store.offer(elem.name, elem.pixels)
-                    elem = (elem.name, elem.flip)
-                elif not torch.is_tensor(elem):
-                    elem = by_name(i2n[ix])
-                slot[ix] = len(rows); rows.append(elem)
+                slot[ix] = len(rows); rows.append(self._image_row(elem, i2n[ix]))
         n_pos_rows = len(rows)                                          # rows [0, n_pos_rows): the batch's own images; behind them: image negatives
         for ix in np.unique(neg[neg >= N]).tolist():
             if ix not in slot:
-                slot[ix] = len(rows); rows.append(by_name(i2n[ix]))
+                slot[ix] = len(rows); rows.append(self._image_row(i2n[ix], i2n[ix]))
         dev = _unwrap(model).embeddings.weight.device
         feats, image_proj = None, _lib.IMAGE_RAW
         self.last_cnn_rows = len(rows)                                  # distinct images of the step = rows of the one CNN batch
@@ -418,6 +407,49 @@ class _JointCriterionBase(torch.nn.Module):
             return torch.from_numpy(a.astype(np.int32)).to(dev, non_blocking=True)
 
         return self.forward_indices(model, feats, codes(ix_from), codes(ix_to), codes(neg), image_proj=image_proj)
+
+    def _image_row(self, elem, name):
+        """One row of a CNN batch: a float tensor (the reference's host path: an item's tensor, or get_image(name)) or (name, mirrored) for the
+        image store to build on the GPU.  `elem`: what the batch carries for the image (tensor / ImageRef) or its name (images drawn as
+        negatives: get_image's val/test transform, no flip -- oe_h.py:668-677)."""
+        store = getattr(self, 'image_store', None)
+        if isinstance(elem, ImageRef):
+            if store is None:
+                raise RuntimeError('the batch carries ImageRef handles but the criterion has no image_store')
+            if elem.pixels is not None:
+                store.offer(elem.name, elem.pixels)
+            return (elem.name, elem.flip)
+        if torch.is_tensor(elem):
+            return elem
+        if store is not None and store.holds(name):
+            return (name, False)
+        return self.dataloader.get_image(name)
+
+    def _forward_reference_batches(self, model, img_feat_net, inputs_from, inputs_to, original_from, original_to, neg):
+        """reference_exact_batches = True: the train branch composed exactly like the reference's (oe_h.py:929-967), CNN batch by CNN batch.
+        The default path embeds every DISTINCT image of a step once; the reference runs up to four separate forwards -- the image ends of
+        the positives' from side, of their to side (oe_h.py:980-985, 1003-1009 through calculate_from_and_to_emb: the batch's own tensors,
+        train transform), then of the 2K B negative pairs' from side and to side, where every FIXED image end is embedded again, K times,
+        through get_image (no flip) -- each forward its own BatchNorm batch (duplicates included) and its own update of the running
+        statistics.  Same kernels as everywhere (Embedder / soft_clip / E_operator / the backbone), unfused: the loss is assembled by
+        autograd over them as the reference assembles it.  Opt-in: it costs (1 + K) times the CNN rows."""
+        B, Kn = len(original_from), self.neg_to_pos_ratio
+        i2n = self.mapping_from_ix_to_node
+        pf, pt = self.calculate_from_and_to_emb(model, img_feat_net, inputs_from, inputs_to)
+        e_pos = self.positive_pair(pf, pt)
+        negative_from, negative_to = [None] * (2 * Kn * B), [None] * (2 * Kn * B)
+        for b in range(B):                                              # oe_h.py:940-957 (the indices are the ones already drawn)
+            for p in range(Kn):
+                negative_from[2 * Kn * b + p] = original_from[b]
+                negative_to[2 * Kn * b + p] = i2n[int(neg[b, p])]
+                negative_from[2 * Kn * b + p + Kn] = i2n[int(neg[b, p + Kn])]
+                negative_to[2 * Kn * b + p + Kn] = original_to[b]
+        nf, nt = self.calculate_from_and_to_emb(model, img_feat_net, negative_from, negative_to)
+        _, e_neg = self.negative_pair(nf, nt)
+        e_neg = e_neg.view(B, 2 * Kn, -1)
+        loss = torch.sum(self.get_image_label_loss(e_pos.reshape(-1), e_neg.reshape(B, 2 * Kn), [1.0] * B))
+        self.last_cnn_rows = sum(1 for lst in (inputs_from, inputs_to, negative_from, negative_to) for e in lst if not isinstance(e, (int, np.integer)))
+        return loss, e_pos, e_neg
 
     def _image_batch(self, rows, dev, store):
         """The step's CNN batch on the device.  Store-backed rows: ONE gather kernel (image_store.ImageStore.batch).  Tensor rows (the
@@ -479,8 +511,8 @@ class _JointCriterionBase(torch.nn.Module):
             out = None
             if img_ix:
                 if self.use_CNN:
-                    imgs = [elems[i] if torch.is_tensor(elems[i]) else self.dataloader.get_image(elems[i]) for i in img_ix]
-                    img_emb = img_feat_net(torch.stack(imgs).to(dev))
+                    rows = [self._image_row(elems[i], elems[i]) for i in img_ix]
+                    img_emb = img_feat_net(self._image_batch(rows, dev, getattr(self, 'image_store', None)))
                 else:
                     img_emb = img_feat_net(self.get_img_features([elems[i] for i in img_ix]).to(dev)).reshape(len(img_ix), -1)
                 out = torch.zeros((len(elems), img_emb.shape[-1]), device=dev)

@@ -467,7 +467,7 @@ class JointEmbeddings:
                  use_pretrained=True, load_wt=False, model_name=None, optimizer_method='adam', use_grayscale=False,
                  load_emb_from=None, load_cosine_emb=None, hide_levels=None, half_half=False,
                  compute_dtype=torch.float32, cnn_weights=None, writer=None, fast_path=True, cnn_passes=None,
-                 image_store=True, image_store_gb=None):
+                 image_store=True, image_store_gb=None, img_feat_net=None, reference_exact_batches=False):
         Embedder, FeatCNN18, FeatCNN, FeatNet = self._model_classes()
         from .resnet import WgradOverlap
         torch.manual_seed(0)                                               # oe_h.py:1338
@@ -504,7 +504,9 @@ class JointEmbeddings:
         self.model = Embedder(embedding_dim=self.embedding_dim, labelmap=labelmap, normalize=self.normalize,
                               K=criterion.K if is_hyp else None)
         self.model.to(self.device)
-        if self.use_CNN:
+        if img_feat_net is not None:
+            self.img_feat_net = img_feat_net.to(self.device)     # the caller's own image network (an oe_h.FeatCNN18 / FeatNet-like module)
+        elif self.use_CNN:
             cls = FeatCNN if (model_name or '').lower() == 'resnet50' else FeatCNN18      # reference hard-wires resnet18 (:1404)
             self.img_feat_net = cls(image_dir=self.image_dir, output_dim=self.embedding_dim,
                                     K=criterion.K if is_hyp else None, weights=cnn_weights,
@@ -540,7 +542,14 @@ class JointEmbeddings:
             self.overlap = WgradOverlap(self.reducer, self.arena, side_stream=self.cnn_passes == 1)
             if self.cnn_passes > 1:
                 self.img_feat_net.cnn_passes = self.cnn_passes
-        if self.use_CNN:
+        # reference_exact_batches: the reference's own CNN batches -- up to four forwards per step, every fixed image end embedded K more times,
+        # each its own BatchNorm batch (criterion._forward_reference_batches; oe_h.py:929-967, 980-985, 1003-1009) -- instead of one
+        # forward per distinct image.  (1 + K) x the CNN rows; for parity runs against the reference (fixture F13).
+        self.reference_exact_batches = bool(reference_exact_batches)
+        self.criterion.reference_exact_batches = self.reference_exact_batches
+        if self.reference_exact_batches and self.use_CNN:
+            self.cnn_passes = 1; self.img_feat_net.cnn_passes = 1     # every forward of the step is ONE BatchNorm batch
+        if self.use_CNN and hasattr(self.img_feat_net, 'model'):
             # this trainer's settings travel with ITS backbone (resnet.ResNet.wgrad_overlap / bn_grad_accumulate / conv_schedule -> the
             # FusionContext of each forward): nothing process-wide is switched around a step, a second trainer in the process keeps its own
             bb = self.img_feat_net.model
@@ -550,6 +559,8 @@ class JointEmbeddings:
                 # atomics like the weight gradients; concurrent passes fill each other's tails: tile walk (engine._core_passes)
                 bb.bn_grad_accumulate = True
                 bb.conv_schedule = _lib.SCHEDULE_TILE_WALK
+            if self.reference_exact_batches:
+                bb.bn_grad_accumulate = True                        # several forwards / backwards of the backbone per step share the slots
         self.check_graph_embedding_neg_graph = None
         self.check_reconstr_every = 1; self.save_model_every = 1
         self.reconstruction_f1 = self.reconstruction_threshold = self.reconstruction_accuracy = 0.0
@@ -669,7 +680,7 @@ class JointEmbeddings:
         pend = self.__dict__.setdefault('_steps_in_flight', [])
         if len(pend) >= 2:
             pend.pop(0).synchronize()
-        multi = getattr(self, 'cnn_passes', 1) > 1
+        multi = getattr(self, 'cnn_passes', 1) > 1 or self.reference_exact_batches     # several backward passes over the parameters per step
         live = self.reducer.live
         if multi:
             # every parameter reports once per pass: the reducer's per-parameter hooks stay muted, the buckets are reduced once, below

@@ -540,19 +540,21 @@ class Bottleneck(nn.Module):
 
 
 class ResNet(nn.Module):
-    def __init__(self, block, layers, num_classes=1000):
+    def __init__(self, block, layers, num_classes=1000, width=64):
+        """width: channels of the stem and of layer1 (torchvision: 64; a power of two >= 8 keeps every layer on liblecone's kernels --
+        narrow instances are the stand-in backbones of the parity fixtures)."""
         super().__init__()
-        self.inplanes = 64
-        self.conv1 = Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.inplanes = width
+        self.conv1 = Conv2d(3, width, kernel_size=7, stride=2, padding=3, bias=False)
         self.conv1.is_stem = True                               # its backward is the last node of the backbone's backward (FusionContext.in_flight)
-        self.bn1 = BatchNormAct2d(64, relu=True)
+        self.bn1 = BatchNormAct2d(width, relu=True)
         self.maxpool = MaxPool3x3s2()
-        self.layer1 = self._make_layer(block, 64, layers[0])
-        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
-        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
-        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.layer1 = self._make_layer(block, width, layers[0])
+        self.layer2 = self._make_layer(block, 2 * width, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 4 * width, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 8 * width, layers[3], stride=2)
         self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
-        self.fc = nn.Linear(512 * block.expansion, num_classes)
+        self.fc = nn.Linear(8 * width * block.expansion, num_classes)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')

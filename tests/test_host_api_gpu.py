@@ -1249,3 +1249,68 @@ def test_two_trainers_on_two_threads_with_different_settings_equal_each_alone(tm
         assert (got['table'] - want['table']).abs().max().item() <= 1e-5, tag
     # and the two really ran differently: A's BatchNorm batch is a pass, B's all rows
     assert abs(alone['A']['loss'][0] - alone['B']['loss'][0]) > 1e-6
+
+
+def test_reference_exact_batches_train_step_matches_the_reference_run_fixture_f13(tmp_path):
+    """Fixture F13 (tests/golden/make_golden_step.py, generated by IMPORTING the reference): one whole train step of the reference's joint
+    trainer -- criterion.forward's train branch with its FOUR separate CNN forwards (every fixed image end embedded K more times, unflipped;
+    each forward its own BatchNorm batch), loss.backward(), the lambda-rescale, ONE Adam over table + CNN at lr, the clip (oe_h.py:904-967,
+    980-985, 1003-1009, 1523, 1766-1771) -- on a BatchNorm-bearing CNN (a ResNet-10 of width 8).  Here: JointEmbeddings.train_step with
+    reference_exact_batches=True on the same network built from THIS package's modules (liblecone's convolution / BatchNorm / pooling /
+    loss / optimizer kernels).  Negatives bit-exact; loss and energies 1e-4; table 2e-6; BatchNorm running statistics 1e-5; gradients 1e-3 of
+    their scale; parameters after Adam: a first Adam step moves every weight by lr * g / (|g| + 1e-8), so an entry is compared to 2 % of lr
+    where its gradient is above 1e-6 (below that the quotient amplifies float noise of the gradient itself)."""
+    from test_host_cpu import _fake_loaders
+    from learning_embeddings_amd.resnet import ResNet, BasicBlock
+    z = np.load(os.path.join(GOLDEN, 'F13_train_step.npz'))
+    lm = SyntheticLabelMap([int(v) for v in z['levels']])
+    assert sorted(lm.edges) == [tuple(int(a) for a in e) for e in z['edges']]
+    n_img, Kc, D, Kneg, lr = int(z['n_images']), float(z['K']), int(z['D']), int(z['Kneg']), float(z['lr'])
+    imgs = torch.from_numpy(z['images_u8']).permute(0, 3, 1, 2).contiguous().float().div(255)
+    dl = _fake_loaders(lm, n_img, 8)
+    for split in dl.values():
+        for b in split:
+            b['path_to_image'] = [imgs[int(n[4:]) % n_img] for n in b['image_filename']]
+    gd = oe_h.create_combined_graphs(dl, lm, pick_per_level=True)
+    N = lm.n_classes
+    assert gd['mapping_ix_to_node'][N + 3] == 'img_000003'
+    crit = oe_h.EuclideanConesWithImagesHypernymLoss(lm, Kneg, {}, float(z['alpha']), True, K=Kc, use_CNN=True)
+    net = oe_h.FeatCNN18(image_dir='', output_dim=D, K=Kc, arch=lambda: ResNet(BasicBlock, [1, 1, 1, 1], width=int(z['width'])))
+    tr = oe_h.JointEmbeddings(gd, dl, image_dir='', use_CNN=True, labelmap=lm, criterion=crit, lr=lr, n_workers=0, batch_size=len(z['from']),
+                              experiment_name='f13', embedding_dim=D, neg_to_pos_ratio=Kneg, image_fc7=None, normalize=None, alpha=float(z['alpha']),
+                              experiment_dir=str(tmp_path), n_epochs=1, eval_interval=5, img_feat_net=net, reference_exact_batches=True)
+    assert tr.img_feat_net is net and tr.cnn_passes == 1 and net.model.bn_grad_accumulate
+    sd0 = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('sd0/')}
+    sd1 = {k[4:]: z[k] for k in z.files if k.startswith('sd1/')}
+    assert set(sd0) == set(net.state_dict())                        # torchvision's key names on both sides
+    net.load_state_dict(sd0)
+    tr.model.embeddings.weight.data.copy_(torch.from_numpy(z['W0']))
+    i2n = gd['mapping_ix_to_node']
+    of = [i2n[int(i)] for i in z['from']]; ot = [i2n[int(i)] for i in z['to']]
+    item = {'from': list(of), 'to': [(imgs[int(i) - N].flip(-1) if f else imgs[int(i) - N]) if int(i) >= N else int(i) for i, f in zip(z['to'], z['flips'])],
+            'status': torch.ones(len(of)), 'original_from': of, 'original_to': ot}
+    crit.set_dataloader(tr.datasets['train']); tr.train_set.transform = None
+    tr.model.train(); tr.img_feat_net.train()
+    crit.seed_sampler(0)
+    loss, e_pos, e_neg = tr.train_step(item)
+    torch.cuda.synchronize()
+    assert np.array_equal(crit.last_negatives, z['neg'])
+    assert crit.last_cnn_rows == 8 + int((z['neg'] >= N).sum()) + Kneg * 8      # positives' images + image negatives + K re-embeds of every fixed image end
+    assert abs(float(loss) - float(z['loss'])) <= 1e-4 * max(1.0, abs(float(z['loss'])))
+    assert np.abs(e_pos.detach().cpu().numpy().reshape(-1) - z['e_pos'].reshape(-1)).max() <= 1e-4
+    assert np.abs(e_neg.detach().cpu().numpy().reshape(-1) - z['e_neg'].reshape(-1)).max() <= 1e-4
+    assert np.abs(tr.model.embeddings.weight.detach().cpu().numpy() - z['W1']).max() <= 2e-6
+    got = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    params = dict(net.named_parameters())
+    for k, want in sd1.items():
+        if 'running_' in k:
+            assert np.abs(got[k] - want).max() <= 1e-5, k               # four forwards, four momentum updates, in the reference's order
+        elif 'num_batches_tracked' in k:
+            continue                                                    # (not advanced here: it only matters for momentum=None, resnet.py)
+        else:
+            g_ref = z['grad/' + k]; g = params[k].grad.detach().cpu().numpy()
+            scale = np.abs(g_ref).max()
+            assert np.abs(g - g_ref).max() <= 1e-3 * scale + 1e-7, (k, np.abs(g - g_ref).max(), scale)
+            big = np.abs(g_ref) > 1e-6
+            assert np.abs(got[k] - want)[big].max(initial=0.0) <= 2e-2 * lr, (k, np.abs(got[k] - want)[big].max(initial=0.0))
+            assert np.abs(got[k] - want).max() <= 2.0 * lr + 1e-7, k    # nobody moves further than an Adam step
