@@ -1187,10 +1187,10 @@ def test_two_trainers_on_two_threads_with_different_settings_equal_each_alone(tm
     for split in dl.values():
         for b in split:
             b['path_to_image'] = [torch.rand(3, 64, 64, generator=torch.Generator().manual_seed(int(n[4:]))).to(DEV) for n in b['image_filename']]
-    gd = oe_h.create_combined_graphs(dl, lm, pick_per_level=True)
     n_steps = 3
 
     def build(tag, passes):
+        gd = oe_h.create_combined_graphs(dl, lm, pick_per_level=True)       # its own graphs: the negative sampler (one MT19937 stream) is a trainer's state
         crit = oe_h.EuclideanConesWithImagesHypernymLoss(lm, 5, {}, 0.05, True, K=0.1, use_CNN=True)
         tr = oe_h.JointEmbeddings(gd, dl, image_dir='', use_CNN=True, labelmap=lm, criterion=crit, lr=1e-4, n_workers=0,
                                   batch_size=16, experiment_name=tag, embedding_dim=10, neg_to_pos_ratio=5, image_fc7=None,
