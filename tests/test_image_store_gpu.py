@@ -124,9 +124,9 @@ def _file_trainer(tmp_path, tag, image_store, n_workers=0, batch_size=12, n_trai
 def _capture_batches(tr):
     seen = []
     orig = tr.img_feat_net.forward_raw
-    def spy(x):
+    def spy(x, split=None):
         seen.append(x.detach().clone())
-        return orig(x)
+        return orig(x, split=split)
     tr.img_feat_net.forward_raw = spy
     return seen
 
