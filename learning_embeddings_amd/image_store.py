@@ -85,6 +85,8 @@ class ImageStore:
         self._decoder = decoder or decode_u8
         self._pool = ThreadPoolExecutor(max_workers=max(1, int(decode_threads)), thread_name_prefix='lec-decode')
         self._staging = []                                       # ring of [pinned uint8 buffer, event that frees it]
+        from .parallel import PinnedRing
+        self._h2d = PinnedRing()                                 # slot numbers / flip bits of a step travel through pinned memory
         self.stats = {'hits': 0, 'decoded_here': 0, 'decoded_by_workers': 0, 'uploads': 0, 'upload_bytes': 0, 'evicted': 0}
 
     # ---- host side -----------------------------------------------------------------------------------------------------------------
@@ -184,8 +186,10 @@ class ImageStore:
     def gather(self, slots, flips=None, c_out=3):
         """Float batch of the images in `slots` (numpy / list / device int32): fp32 `[n, c_out, H, W]` in channels_last memory,
         `uint8 / 255` (= ToTensor), mirrored along W where `flips` says so.  c_out = 4: zero 4th channel (the f32 stem's operand)."""
+        ring = self._h2d
+        ring.begin_step()
         if not torch.is_tensor(slots):
-            slots = torch.from_numpy(np.ascontiguousarray(np.asarray(slots, dtype=np.int32))).to(self.device, non_blocking=True)
+            slots = ring.upload(np.asarray(slots, dtype=np.int32), self.device)
         n = int(slots.shape[0])
         out = torch.empty((n, c_out, self.hw, self.hw), dtype=torch.float32, device=self.device, memory_format=torch.channels_last)
         if n == 0:
@@ -193,10 +197,11 @@ class ImageStore:
         fl = None
         if flips is not None:
             if not torch.is_tensor(flips):
-                flips = np.ascontiguousarray(np.asarray(flips, dtype=np.uint8))
-                fl = torch.from_numpy(flips).to(self.device, non_blocking=True) if flips.any() else None
+                flips = np.asarray(flips, dtype=np.uint8)
+                fl = ring.upload(flips, self.device) if flips.any() else None
             else:
                 fl = flips.to(torch.uint8)
+        ring.end_step()
         _lib.check(_lib.lib.lec_image_gather_u8(_lib.dptr(self.store), self.capacity, _lib.dptr(slots), _lib.dptr(fl), n, self.hw, self.hw,
                                                 c_out, _lib.dptr(out), _lib.stream_ptr()))
         return out

@@ -394,6 +394,12 @@ class _JointCriterionBase(torch.nn.Module):
             else:
                 feats = _unwrap(img_feat_net)(batch).reshape(len(rows), -1).float()
 
+        ring = self.__dict__.get('_h2d')
+        if ring is None:
+            from .parallel import PinnedRing
+            ring = self.__dict__['_h2d'] = PinnedRing()
+        ring.begin_step()
+
         def codes(a):
             a = np.asarray(a, dtype=np.int64)
             if slot:
@@ -404,9 +410,11 @@ class _JointCriterionBase(torch.nn.Module):
                 out = a.copy()
                 out[img] = -1 - lut[a[img] - N]
                 a = out
-            return torch.from_numpy(a.astype(np.int32)).to(dev, non_blocking=True)
+            return ring.upload(a.astype(np.int32), dev)             # pinned: see parallel.PinnedRing
 
-        return self.forward_indices(model, feats, codes(ix_from), codes(ix_to), codes(neg), image_proj=image_proj)
+        c_from, c_to, c_neg = codes(ix_from), codes(ix_to), codes(neg)
+        ring.end_step()
+        return self.forward_indices(model, feats, c_from, c_to, c_neg, image_proj=image_proj)
 
     def _image_row(self, elem, name):
         """One row of a CNN batch: a float tensor (the reference's host path: an item's tensor, or get_image(name)) or (name, mirrored) for the

@@ -610,13 +610,22 @@ class JointEmbeddings:
         self.dataloaders['test'] = torch.utils.data.DataLoader(test_set, batch_size=self.batch_size, collate_fn=my_collate,
                                                                num_workers=self.n_workers, shuffle=False)
 
+    # DataLoader workers are started ONCE per loader and kept (persistent_workers): forking a process that holds a live HIP context stalls its
+    # GPU work once, for seconds (measured on the MI355X box with 8 workers: ONE step of 2.7 s right after every fork, every other step
+    # 124 ms -- tools/probe_trainer_files.py; spawned workers do not stall but take 7 s to start), and a loader that forks per epoch pays
+    # that every epoch.  The workers' view of "resident in HBM" is a shared-memory flag array, so long-lived workers stay correct.
+    persistent_workers = True
+    worker_context = None                    # multiprocessing context of the workers (None: the platform default, fork)
+
     def _make_train_loader(self):
         from .oe_h import my_collate
         self.train_sampler = GlobalBatchSampler(len(self.train_set), self.batch_size, shuffle=True, seed=0,
                                                 rank=getattr(self, 'rank', 0), world=getattr(self, 'world', 1))
         self.dataloaders = getattr(self, 'dataloaders', {})
         self.dataloaders['train'] = torch.utils.data.DataLoader(self.train_set, batch_sampler=self.train_sampler,
-                                                                num_workers=self.n_workers, collate_fn=my_collate)
+                                                                num_workers=self.n_workers, collate_fn=my_collate,
+                                                                persistent_workers=bool(getattr(self, 'persistent_workers', False)) and self.n_workers > 0,
+                                                                multiprocessing_context=(getattr(self, 'worker_context', None) if self.n_workers > 0 else None))
         self.datasets['train'] = self.train_set
         self.dataset_length['train'] = len(self.train_set)
 

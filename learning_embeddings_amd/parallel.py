@@ -122,6 +122,49 @@ class FlatArena:
 
 
 # ------------------------------------------------------------------------------------------------ process group
+class PinnedRing:
+    """Small host -> device uploads of a step (index arrays: node codes, image slots, flip bits) through PINNED memory: a ring of `slots`
+    page-locked buffers, one per step in flight, each guarded by an event recorded after the step's last copy was enqueued.  A copy from
+    pageable memory (`torch.from_numpy(a).to(device)`) goes through the runtime's own staging and is not asynchronous to the host; from a
+    pinned buffer it is one DMA the stream orders, and the host moves on."""
+
+    def __init__(self, slots=4, nbytes=1 << 16):
+        self.bufs = [None] * slots; self.events = [None] * slots
+        self.nbytes = nbytes; self.cur = 0; self.off = 0
+
+    def begin_step(self):
+        self.cur = (self.cur + 1) % len(self.bufs); self.off = 0
+        ev = self.events[self.cur]
+        if ev is not None:
+            ev.synchronize()                                   # copies of `slots` steps ago: long done, this only makes reuse safe by construction
+
+    def upload(self, arr, device):
+        """numpy array -> device tensor of the same dtype / shape (asynchronous copy on the current stream)."""
+        import numpy as np, torch
+        arr = np.ascontiguousarray(arr)
+        n = arr.nbytes
+        start = (self.off + 15) & ~15
+        buf = self.bufs[self.cur]
+        if buf is None or start + n > buf.numel():
+            if buf is not None and self.off > 0:               # the slot's buffer is in use by earlier uploads of this step: leave it, take a new one
+                self._keep = getattr(self, '_keep', []) + [buf]
+            buf = self.bufs[self.cur] = torch.empty(max(self.nbytes, 2 * (start + n)), dtype=torch.uint8).pin_memory()
+            start = 0
+        view = buf[start:start + n].view(torch.from_numpy(arr[:0]).dtype if n else torch.uint8)
+        if n:
+            view.numpy()[...] = arr.reshape(-1)
+        self.off = start + n
+        return view.to(device, non_blocking=True).view(arr.shape)
+
+    def end_step(self):
+        import torch
+        ev = self.events[self.cur]
+        if ev is None:
+            ev = self.events[self.cur] = torch.cuda.Event()
+        ev.record()
+        self._keep = []
+
+
 def env_rank():
     return int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
 
