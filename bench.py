@@ -510,14 +510,14 @@ def write_image_files(d, n, w=400, h=300, seed=0):
 
 def measure_trainer_files(args, dtype, stamp, n_images=2048, epochs=3):
     """The drop-in trainer fed from image FILES (VERDICT r03 "what's missing" #1): JointEmbeddings.train_epoch over its own
-    DataLoader (n_workers > 0) with the HBM image store (image_store.py).  Epoch 1 is cold: every image is decoded once -- positives by the
-    DataLoader workers, negatives one step ahead by the store's decode pool -- and uploaded as uint8; from epoch 2 on every image of a
-    step is resident and the step's float batch is one gather kernel.  Reported: per-epoch ms/step and images/s, the decode rate of epoch 1
+    DataLoader with the HBM image store (image_store.py; n_workers > 0 sizes its decode pool).  Epoch 1 is cold: every image is decoded once,
+    one step ahead of its use, by the store's decode threads (positives and negatives alike: train_epoch's lookahead) and uploaded as
+    uint8; from epoch 2 on every image of a step is resident and the step's float batch is one gather kernel.  Reported: per-epoch ms/step and images/s, the decode rate of epoch 1
     and the host's core count."""
     import shutil, tempfile
     import numpy as np, torch
     cores = os.cpu_count() or 1
-    n_workers = max(2, min(8, cores // 4))
+    n_workers = max(2, min(16, cores // 8))                    # with the image store: the size of its decode pool (threads); the loader forks no workers
     d = tempfile.mkdtemp(prefix='lec_bench_imgs_')
     t0 = time.perf_counter()
     MV = 64
@@ -550,7 +550,7 @@ def measure_trainer_files(args, dtype, stamp, n_images=2048, epochs=3):
                 'epochs': per_epoch, 'cnn_rows_per_step': round(float(np.mean([e['cnn_rows_per_step'] for e in warm])), 1),
                 'image_files': {'count': n_images, 'format': 'JPEG quality 90, 400x300', 'store_slots': st.capacity, 'store_bytes_per_image': hw * hw * 3,
                                 'decoder': 'PIL (libjpeg-turbo) + bilinear resize to %dx%d' % (hw, hw)},
-                'host': {'cores': cores, 'dataloader_workers': n_workers, 'decode_threads': n_workers},
+                'host': {'cores': cores, 'decode_threads': tr.image_store._pool._max_workers, 'dataloader_worker_processes': tr.dataloaders['train'].num_workers},
                 'launch_mode': 'eager',
                 'api': 'JointEmbeddings.train_epoch over its own DataLoader / my_collate / criterion(...) (oe_h.py:1734-1774 mirror) on image files'}
     finally:

@@ -598,7 +598,7 @@ class JointEmbeddings:
         if self.use_CNN and self.use_image_store and locs:
             per = train_set.input_size * train_set.input_size * 3
             cap = None if self.image_store_gb is None else max(4 * self.batch_size * (1 + 2 * self.neg_to_pos_ratio), int(self.image_store_gb * 1e9) // per)
-            self.image_store = ImageStore(locs, self.device, hw=train_set.input_size, capacity=cap, decode_threads=max(2, self.n_workers))
+            self.image_store = ImageStore(locs, self.device, hw=train_set.input_size, capacity=cap, decode_threads=max(4, self.n_workers))
             for ds in (train_set, val_set, test_set):
                 ds.store_view = self.image_store.view()
             print('Image store: %d image files, %d slots of %d bytes in HBM' % (len(locs), self.image_store.capacity, per))
@@ -610,22 +610,29 @@ class JointEmbeddings:
         self.dataloaders['test'] = torch.utils.data.DataLoader(test_set, batch_size=self.batch_size, collate_fn=my_collate,
                                                                num_workers=self.n_workers, shuffle=False)
 
-    # DataLoader workers are started ONCE per loader and kept (persistent_workers): forking a process that holds a live HIP context stalls its
-    # GPU work once, for seconds (measured on the MI355X box with 8 workers: ONE step of 2.7 s right after every fork, every other step
-    # 124 ms -- tools/probe_trainer_files.py; spawned workers do not stall but take 7 s to start), and a loader that forks per epoch pays
-    # that every epoch.  The workers' view of "resident in HBM" is a shared-memory flag array, so long-lived workers stay correct.
+    # Who decodes image files.  With the HBM image store (the default for file-backed datasets) the train loader runs WITHOUT worker processes:
+    # its items are ImageRef handles, and every file a step needs -- positives and negatives alike -- is requested from the store's decode
+    # THREADS one step ahead by train_epoch's lookahead (`n_workers` sizes that pool; PIL releases the GIL while it decodes and resizes).
+    # Forking DataLoader workers from the training process is what the reference does, and on this stack it is a hazard: the process holds a
+    # live HIP context and a dozen threads (autograd, RCCL / gloo, decode pool, lookahead).  Measured on the MI355X box
+    # (tools/probe_trainer_files.py, tools/dp8_trainer_files.py): every fork of 8 workers stalls the GPU work of the parent ONCE for
+    # 2.7 s (a loader that forks per epoch pays it every epoch: 233 ms per step instead of 108 over 16-step epochs), and under
+    # torch.distributed.run with gloo threads alive the forked workers never delivered a batch at all (the classic fork-with-threads
+    # deadlock).  Without the store (image_store=False, or in-memory tensors) the loader keeps the reference's `n_workers` processes,
+    # started once and kept (persistent_workers) so that the stall is paid once.
     persistent_workers = True
-    worker_context = None                    # multiprocessing context of the workers (None: the platform default, fork)
+    worker_context = None                    # multiprocessing context of those workers (None: the platform default, fork)
 
     def _make_train_loader(self):
         from .oe_h import my_collate
         self.train_sampler = GlobalBatchSampler(len(self.train_set), self.batch_size, shuffle=True, seed=0,
                                                 rank=getattr(self, 'rank', 0), world=getattr(self, 'world', 1))
         self.dataloaders = getattr(self, 'dataloaders', {})
+        nw = 0 if getattr(self, 'image_store', None) is not None else self.n_workers
         self.dataloaders['train'] = torch.utils.data.DataLoader(self.train_set, batch_sampler=self.train_sampler,
-                                                                num_workers=self.n_workers, collate_fn=my_collate,
-                                                                persistent_workers=bool(getattr(self, 'persistent_workers', False)) and self.n_workers > 0,
-                                                                multiprocessing_context=(getattr(self, 'worker_context', None) if self.n_workers > 0 else None))
+                                                                num_workers=nw, collate_fn=my_collate,
+                                                                persistent_workers=bool(self.persistent_workers) and nw > 0,
+                                                                multiprocessing_context=(self.worker_context if nw > 0 else None))
         self.datasets['train'] = self.train_set
         self.dataset_length['train'] = len(self.train_set)
 
@@ -754,9 +761,9 @@ class JointEmbeddings:
             return g_from, g_to
 
         def on_item(item):
-            if store is not None:
-                neg = item[2]
-                names = [i2n[ix] for ix in np.unique(neg[neg >= N]).tolist()]
+            if store is not None:                                       # every image file of this rank's shard of the step, positives and negatives
+                ixs = np.unique(np.concatenate([np.asarray(x).reshape(-1) for x in item]))
+                names = [i2n[ix] for ix in ixs[ixs >= N].tolist()]
                 store.request([nm for nm in names if store.holds(nm)])
 
         look = None

@@ -195,12 +195,14 @@ def test_trainer_from_files_store_path_equals_host_tensor_path(tmp_path, lookahe
     np.testing.assert_allclose(s[2], h[2], rtol=3e-2)                   # later steps: the weight gradients' float atomics, through Adam at lr 1e-3
 
 
-def test_trainer_from_files_with_dataloader_workers(tmp_path):
-    """n_workers = 2: the workers decode the positives' files (uint8 pixels travel, not float tensors) and skip what the shared flags mark
-    resident; every CNN row of a step is the oracle's tensor of its file (mirrored or not for positives, never for negatives); in a second
-    pass over the same positives the workers decode nothing."""
+def test_trainer_from_files_decodes_ahead_on_the_stores_threads(tmp_path):
+    """With the image store the train loader forks NO worker processes (JointEmbeddings.persistent_workers' comment: the measured fork stall
+    and deadlock); n_workers sizes the store's decode pool, and train_epoch's lookahead requests every file of step t+1 -- positives and
+    negatives -- while step t runs.  Every CNN row of a step is the oracle's tensor of its file (mirrored or not for positives, never for
+    negatives); a second pass over the same positives decodes nothing for them."""
     torch.manual_seed(0)
-    tr, crit, gd, dl = _file_trainer(tmp_path, 'w', True, n_workers=2)
+    tr, crit, gd, dl = _file_trainer(tmp_path, 'w', True, n_workers=3)
+    assert tr.dataloaders['train'].num_workers == 0 and tr.image_store._pool._max_workers == 4
     seen = _capture_batches(tr)
     rows_of = []
     orig_batch = crit._image_batch
@@ -210,7 +212,7 @@ def test_trainer_from_files_with_dataloader_workers(tmp_path):
     running, steps = tr.train_epoch(max_steps=4)
     torch.cuda.synchronize()
     st = tr.image_store
-    assert steps == 4 and st.stats['decoded_by_workers'] > 0
+    assert steps == 4 and st.stats['decoded_by_workers'] == 0 and st.stats['decoded_here'] > 0
     locs = st.locs
     n_pos = 12
     for rows, x in zip(rows_of, seen):
@@ -226,6 +228,5 @@ def test_trainer_from_files_with_dataloader_workers(tmp_path):
     tr.epoch = 0
     tr.train_epoch(max_steps=4)
     torch.cuda.synchronize()
-    assert st.stats['decoded_by_workers'] == before['decoded_by_workers']      # (new negatives may still meet an image for the first time)
-    assert st.stats['hits'] > before['hits']
+    assert st.stats['hits'] > before['hits'] and st.stats['decoded_here'] - before['decoded_here'] < 12      # (a new negative may still meet an image for the first time)
     assert np.isfinite(float(running))
