@@ -695,7 +695,9 @@ class JointEmbeddings:
         # would otherwise pile up one step's activations per step of run-ahead (measured: 234 GB live after 11 fp32 steps).
         pend = self.__dict__.setdefault('_steps_in_flight', [])
         if len(pend) >= 2:
+            t_w = time.perf_counter()
             pend.pop(0).synchronize()
+            self.host_wait_s = getattr(self, 'host_wait_s', 0.0) + time.perf_counter() - t_w      # (bench / tools: host time of a step = wall - waits)
         multi = getattr(self, 'cnn_passes', 1) > 1 or self.reference_exact_batches     # several backward passes over the parameters per step
         live = self.reducer.live
         if multi:
@@ -711,7 +713,9 @@ class JointEmbeddings:
         finally:
             if multi:
                 self.reducer.live = live; self.reducer.reset()
+        t_w = time.perf_counter()
         self.reducer.finish()
+        self.host_wait_s = getattr(self, 'host_wait_s', 0.0) + time.perf_counter() - t_w
         self.apply_updates()
         if loss.is_cuda:
             done = torch.cuda.Event(); done.record(); pend.append(done)
