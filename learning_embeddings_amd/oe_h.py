@@ -117,7 +117,7 @@ class _ImageNetBase(nn.Module):
         (BatchNorm statistics per part, running statistics updated in part order), then the fully connected layer once over all rows
         on the caller's stream.  `split` (the criterion passes it): rows [0, split) are the positives' images, the rest images drawn as
         negatives -- the parts are then the reference's own separate forwards (oe_h.py:980-985 | 1003-1009); without it, `cnn_passes` equal
-        parts.  Autograd runs every part's backward on the stream its forward ran on and joins them itself.  The caller zeroes the gradient
+        parts.  Autograd runs every part's backward on the stream its forward ran on; the caller calls join_passes() after backward, zeroes the gradient
         slots once per step and has set the backbone's bn_grad_accumulate (trainers' __init__)."""
         cur = torch.cuda.current_stream()
         n = x.shape[0]
@@ -139,7 +139,17 @@ class _ImageNetBase(nn.Module):
             f.record_stream(cur); parts.append(f); used.append(st)
         for st in used:
             x.record_stream(st); cur.wait_stream(st)
+        self.__dict__['_passes_in_flight'] = used                   # their backward runs on these streams: join_passes() after loss.backward()
         return self.model.fc(torch.cat(parts)).float()
+
+    def join_passes(self):
+        """Make the current stream wait for the streams the concurrent passes' backward ran on.  Autograd only joins the streams on which an
+        AccumulateGrad node ran; this backbone's parameter gradients are written in place by its kernels (weight gradients, BatchNorm
+        d gamma / d beta into the flat arena), so nothing tells the engine about the pass streams: whoever reads the gradients next
+        (all-reduce, optimizer) must wait for them explicitly."""
+        cur = torch.cuda.current_stream()
+        for st in self.__dict__.pop('_passes_in_flight', []):
+            cur.wait_stream(st)
 
     def forward_raw(self, x, split=None):
         """CNN output BEFORE soft_clip, fp32 [n, D] -- the fused loss applies soft_clip itself.  split: see _forward_raw_passes."""

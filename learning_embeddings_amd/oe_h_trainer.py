@@ -710,6 +710,8 @@ class JointEmbeddings:
             loss.backward()                                                 # oe_h.py:1766
             if ov is not None:
                 ov.join()                                                   # weight gradients from the side stream
+            if hasattr(self.img_feat_net, 'join_passes'):
+                self.img_feat_net.join_passes()                             # ... and the concurrent passes' backward from their streams
         finally:
             if multi:
                 self.reducer.live = live; self.reducer.reset()
