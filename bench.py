@@ -729,7 +729,10 @@ def main():
                # `roofline`: the kernel family that dominates the step's time at this precision; the others ride along
                'roofline': dominant, 'roofline_conv': res['roofline_conv'], 'roofline_bn': res['roofline_bn'], 'roofline_cone': roof_cone,
                'roofline_cnn': res['roofline_cnn'],
-               'sampler_us_per_negative': round(sampler_us, 4), 'allreduce_ms': res['allreduce_ms'], 'data_parallel': res['data_parallel'],
+               'sampler_us_per_negative': round(sampler_us, 4), 'allreduce_ms': res['allreduce_ms'],
+               # gradient exchange time the step does NOT hide: graph launch mode reduces every bucket in one sweep after the replay (all of it exposed);
+               # eager launches reduce bucket by bucket from backward hooks and this is the wait for the last handles
+               'allreduce_exposed_ms': res['allreduce_ms'], 'data_parallel': res['data_parallel'],
                'rccl_ranks': (res['data_parallel'] or {}).get('rccl_ranks', 1)}
         if not args.no_stress:
             # the loss kernel where it IS bandwidth-bound: config 5's label-embedding stress shape (K=256) and a D=128 table
