@@ -422,13 +422,18 @@ static bool joint_geometry(int B, int K, int D, JointGeom& g) {
   }
   const int ppw = 64 / g.T, NP = 1 + 2 * K;
   const int64_t group_iters = (NP + ppw - 1) / ppw;                      // wave iterations one group needs
-  // aim for ~1.5k waves, never more than 6 iterations per task.  (Round 1 aimed for 6k waves / at most 8 iterations; a sweep on the
-  // MI355X -- B x K x D = 256 x 256 x 10: 34.0 us at 2 304 waves, 20.1 at 1 152; 1 024 x 256 x 10: 57.5 -> 33.8 us; 4 096 x 256 x 10:
-  // 131.8 us at 8 iterations, 119.5 at 6 -- shows the per-wave fixed work (u_b / v_b projection, the block's loss partial and ticket)
-  // outweighing the extra residency rounds.)
-  int64_t iters = ((int64_t)B * group_iters + 1535) / 1536;
-  if (iters > 6) iters = 6;
-  if (iters > group_iters) iters = group_iters;
+  // How many waves share one positive's group of 1 + 2K pairs.  Every wave projects u_b and v_b itself and ends with two row scatters, a loss
+  // partial and a ticket: fixed work per wave, so FEWER, LONGER waves win as long as the chip stays full.  Measured on the MI355X
+  // (tools/sweep_cone_r4b.sh, profiles/r04_cone_sweep.md): lane-per-pair geometries (T <= 2) want ~1.5k waves (B x K x D = 256 x 256 x 10:
+  // 34.0 us at 2 304 waves, 22.3 at 1 280, 22.7 at 768), lanes-per-row geometries (T >= 4) ~3k (256 x 256 x 128: 77.8 us at 5 632 waves, 59.2 at
+  // 3 072, 69.6 at 1 536); beyond that ONE wave per group, however many iterations that takes (4 096 x 256 x 10: 123.7 us with two waves
+  // of 6 + 3 iterations per group -- the old cap of 6 -- 88.5 with one wave of 9; 4 096 x 64 x 128: 287.8 -> 183.3 us).  The split is balanced:
+  // `tasks` waves of ceil(group_iters / tasks) iterations each.
+  const int64_t target_waves = g.T <= 2 ? 1536 : 3072;
+  int64_t tasks = (target_waves + B - 1) / B;
+  if (tasks > group_iters) tasks = group_iters;
+  if (tasks < 1) tasks = 1;
+  int64_t iters = (group_iters + tasks - 1) / tasks;
   if (iters < 1) iters = 1;
   if (iters_override > 0) iters = iters_override;
   g.iters = (int)iters;
