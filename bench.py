@@ -50,12 +50,12 @@ def self_launch(n, script=None, argv=None, extra_env=None):
 
 
 def cone_traffic(B, K, D, N):
-    """HBM bytes per launch of the fused loss kernel at this shape from the committed rocprofv3 passes (profiles/r03_cone_pmc.json:
-    FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes, tools/prof_cone_round3.sh) -- None (with the reason) if the shape was not
+    """HBM bytes per launch of the fused loss kernel at this shape from the committed rocprofv3 passes (profiles/r04_cone_pmc.json:
+    FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes, tools/prof_cone_round4.sh) -- None (with the reason) if the shape was not
     profiled or the kernel sources have changed since."""
     import hashlib
     try:
-        allm = json.load(open(os.path.join(ROOT, 'profiles', 'r03_cone_pmc.json')))
+        allm = json.load(open(os.path.join(ROOT, 'profiles', 'r04_cone_pmc.json')))
         csrc = os.path.join(ROOT, 'learning_embeddings_amd', 'csrc')
         stale = [f for f, h in allm['kernel_sources_sha256'].items()
                  if not os.path.exists(os.path.join(csrc, f)) or hashlib.sha256(open(os.path.join(csrc, f), 'rb').read()).hexdigest() != h]
@@ -63,8 +63,8 @@ def cone_traffic(B, K, D, N):
             return None, 'kernel sources changed since the PMC passes: ' + ', '.join(stale)
         rec = allm['shapes'].get('%d_%d_%d_%d' % (B, K, D, N))
         if rec is None or rec.get('traffic_bytes') is None:
-            return None, 'shape not in profiles/r03_cone_pmc.json'
-        return int(rec['traffic_bytes']), 'rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE per launch (profiles/r03_cone_pmc.md); %.1f us per launch under the profiler' % rec['avg_us']
+            return None, 'shape not in profiles/r04_cone_pmc.json'
+        return int(rec['traffic_bytes']), 'rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE per launch (profiles/r04_cone_pmc.md); %.1f us per launch under the profiler' % rec['avg_us']
     except Exception as e:                                      # noqa: BLE001
         return None, str(e)
 
@@ -743,11 +743,9 @@ def main():
                                           'B4096_K256_D10': (4096, 256, 10, 50000)}.items():
                 r = bench_cone.time_joint(b_, k_, d_, n_, b_, iters=30)
                 t_s = r['us'] * 1e-6
-                # the bounds the launch actually sits under: the table (2 MB at D = 10, 25.6 MB at D = 128) lives in L2 / Infinity Cache,
-                # so its rows are GATHERED from cache (MI355X_MICROARCH.md "Indexed rows": 16.8 TB/s from L2, 8.6 TB/s from the Infinity
-                # Cache), and the gradient rows leave as scattered float atomics (chip-wide 1.3 TB/s for whole-row segments)
+                # the table (2 MB at D = 10, 25.6 MB at D = 128) lives in L2 / Infinity Cache, so its rows are GATHERED from cache
+                # (MI355X_MICROARCH.md "Indexed rows": 16.8 TB/s from L2, 8.6 TB/s from the Infinity Cache); what binds is in `binding_resource`
                 gather_b = b_ * (2 + 2 * k_) * d_ * 4 * 2                  # rows read by the forward and again by the backward half
-                atomic_b = b_ * (2 + 2 * k_) * d_ * 4
                 tbl_mb = n_ * d_ * 4 / 1e6
                 g_peak = 16800.0 if tbl_mb <= 4.0 else 8600.0
                 s_tr, s_note = cone_traffic(b_, k_, d_, n_)
@@ -756,8 +754,10 @@ def main():
                            'second_bounds': {
                                'cache_gather': {'achieved': round(gather_b / t_s / 1e9, 1), 'peak': g_peak, 'unit': 'GB/s', 'frac': round(gather_b / t_s / 1e9 / g_peak, 4),
                                                 'note': 'table of %.1f MB resident in %s' % (tbl_mb, 'L2' if tbl_mb <= 4.0 else 'the Infinity Cache')},
-                               'float_atomics': {'achieved': round(atomic_b / t_s / 1e9, 1), 'peak': 1300.0, 'unit': 'GB/s', 'frac': round(atomic_b / t_s / 1e9 / 1300.0, 4)},
-                               'launch_floor_us': 16.5, 'note': 'forward-only launch of the cfg5 shape: 16.5 us (tools/sweep_cone.py) -- three dependent cache round trips + the deterministic loss reduction; the launch is latency-bound, none of the throughput bounds is near'}}
+                               'binding_resource': 'vector ALU issue (profiles/r04_cone_pmc.md: VALU-active cycles are twice the cycles waiting on any instruction; ~700 VALU instructions per pair: '
+                                                   'acosf / asinf / sqrtf / divisions at the reference\'s op-by-op fp32 rounding); L2 atomics are 26 k - 83 k requests per launch (~1 000 / us: only pairs inside '
+                                                   'the margin scatter a gradient) and HBM traffic is 0.14 - 0.8 x the algorithmic bytes: neither binds',
+                               'launch_floor_us': 16.5, 'note': 'forward-only launch of the cfg5 shape: 16.5 us (tools/sweep_cone.py): at 256 positives the launch is a dependent chain on a partly filled chip'}}
             out['roofline_stress'] = st
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(eng)

@@ -66,18 +66,26 @@ for r in rows:
         r['B'], r['K'], r['D'], r['N'], r['N'] * r['D'] * 4 / 1e6, '%.1f' % us if us else '-', r['alg_bytes'] / 1e6, f2(r['hbm_read_bytes']), f2(r['hbm_write_bytes']),
         '%.2f' % (r['traffic_bytes'] / r['alg_bytes']) if r['traffic_bytes'] else '-', '%.1f' % (r['alg_bytes'] / us / 1e3) if us else '-',
         '%.4f' % (r['alg_bytes'] / us / 1e3 / 8000.0) if us else '-'))
-print('\n## what the launch waits for (per-launch counter averages)\n')
-print('| B x K x D | waves | wave-cycles busy | of them waiting on any instruction | VALU active | VMEM active | L2 requests | L2 hit rate | L2 atomic requests | atomic requests / us | float atomics issued (= rows x D) | HBM-side atomics (TCC_EA0_ATOMIC) |')
-print('|---|---|---|---|---|---|---|---|---|---|---|---|')
+print('\n## what the launch waits for (per-launch counter averages; SQ_* are summed over the chip)\n')
+print('| B x K x D | waves | VALU instructions per wave | SQ_ACTIVE_INST_VALU | SQ_WAIT_INST_ANY | wait : VALU-active | SQ_ACTIVE_INST_VMEM | L2 requests | L2 hit rate | L2 atomic requests | atomic requests / us | gradient elements a launch COULD scatter (rows x D) | TCC_EA0_ATOMIC |')
+print('|---|---|---|---|---|---|---|---|---|---|---|---|---|')
 for r in rows:
     c = r['counters_per_launch']; us = r['avg_us'] or 0
     g = lambda k: c.get(k)
-    pct = lambda a, b: '-' if (a is None or not b) else '%.0f %%' % (100.0 * a / b)
     num = lambda v: '-' if v is None else ('%.3g' % v)
-    n_atomic_elems = r['B'] * (2 + 2 * r['K']) * r['D']
-    print('| %d x %d x %d | %s | %s | %s | %s | %s | %s | %s | %s | %s | %.3g | %s |' % (
-        r['B'], r['K'], r['D'], num(g('SQ_WAVES')), num(g('SQ_BUSY_CYCLES')), pct(g('SQ_WAIT_INST_ANY'), g('SQ_BUSY_CYCLES')),
-        pct(g('SQ_ACTIVE_INST_VALU'), g('SQ_BUSY_CYCLES')), pct(g('SQ_ACTIVE_INST_VMEM'), g('SQ_BUSY_CYCLES')), num(g('TCC_REQ_sum')),
-        pct(g('TCC_HIT_sum'), g('TCC_REQ_sum')), num(g('TCC_ATOMIC')), '-' if (g('TCC_ATOMIC') is None or not us) else '%.0f' % (g('TCC_ATOMIC') / us),
-        n_atomic_elems, num(g('TCC_EA0_ATOMIC'))))
+    ratio = lambda a, b: '-' if (a is None or not b) else '%.2f' % (a / b)
+    n_elems = r['B'] * (2 + 2 * r['K']) * r['D']
+    print('| %d x %d x %d | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s | %.3g | %s |' % (
+        r['B'], r['K'], r['D'], num(g('SQ_WAVES')), ratio(g('SQ_INSTS_VALU'), g('SQ_WAVES')), num(g('SQ_ACTIVE_INST_VALU')), num(g('SQ_WAIT_INST_ANY')),
+        ratio(g('SQ_WAIT_INST_ANY'), g('SQ_ACTIVE_INST_VALU')), num(g('SQ_ACTIVE_INST_VMEM')), num(g('TCC_REQ_sum')),
+        '-' if not g('TCC_REQ_sum') else '%.0f %%' % (100.0 * (g('TCC_HIT_sum') or 0) / g('TCC_REQ_sum')), num(g('TCC_ATOMIC')),
+        '-' if (g('TCC_ATOMIC') is None or not us) else '%.0f' % (g('TCC_ATOMIC') / us), n_elems, num(g('TCC_EA0_ATOMIC'))))
+print('\nReading.  HBM: traffic is 0.14 - 0.8 x the algorithmic bytes at D = 10 (the 2 MB table and its gradient live in L2: 72 - 94 % hit rate) -- bandwidth is not the')
+print('bound at any of these sizes.  Atomics: only pairs whose loss term is live scatter a gradient (positives, and negatives inside the margin: a few percent of the')
+print('2K B pairs once energies spread), so the L2 sees 26 k - 83 k atomic requests per launch, ~1 000 per microsecond -- two orders of magnitude under the rate the')
+print('guide quotes for whole-row segments; the "float-atomic bound" of round 3 was a guess the counters do not support.  What the waves do: vector-ALU issue cycles are')
+print('about TWICE the cycles spent waiting on any instruction at the K = 256 shapes (the cone energy is ~50 correctly rounded fp32 operations per pair with acosf,')
+print('asinf, sqrtf and divisions, evaluated for every pair; -ffp-contract=off, no fast math: the reference\'s op-by-op rounding), and at the north-star size (256 x 5 x 10: 256 waves on 1 024')
+print('SIMDs, 9 us) the launch is a dependent chain on a quarter-full chip: latency, not throughput.  Binding resource: the vector ALU at K = 256, launch + dependent-load')
+print('latency at K = 5.')
 json.dump(out, open(os.path.join(d, 'r04_cone_pmc.json'), 'w'), indent=1)
