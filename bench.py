@@ -343,6 +343,9 @@ def measure(args, dtype, rank, world, stamp, primary):
                      # lower bound nobody can argue with: the family's flops over the whole wall time of the step
                      'frac_if_durations_were_serial': round(eng.conv_flops_per_step / (phases['conv_f32'] * 1e-3) / 1e12 / 157.3, 4),
                      'frac_lower_bound_flops_over_step_wall_time': round(eng.conv_flops_per_step / (dt / args.steps) / 1e12 / 157.3, 4),
+                     'frac_basis': 'HEADLINE `frac` = algorithmic flops / union of the family\'s launch intervals (HIP events, all streams); the wall-based figure rides along as '
+                                   'frac_lower_bound_flops_over_step_wall_time.  Both can be re-derived from the tracked rocprofv3 kernel trace: profiles/r04_bench_cfg3_f32_steady_state.md '
+                                   '("convolution family roofline": union 0.6293, wall 0.5925 in a profiled run whose own HIP-event union read 0.6262)',
                      'note': probe_note + 'HIP events on the stream each kernel runs on; achieved = flops / union of the launch intervals over the concurrent streams (the sum of the durations counts shared time once per stream)'}
         if conv_isolated is not None:
             roof_conv['isolated'] = {'ms_per_step': round(conv_isolated, 3), 'achieved': round(eng.conv_flops_per_step / conv_isolated / 1e9, 2),
@@ -542,6 +545,22 @@ def measure_trainer_files(args, dtype, stamp, n_images=2048, epochs=3):
                               'uploaded_mb': round((st.stats['upload_bytes'] - before['upload_bytes']) / 1e6, 1),
                               'mean_loss_per_positive': round(float(running) / (steps * B), 5)})
             stamp('through-trainer-files %s: epoch %d: %d steps, %.1f ms/step, %d files decoded' % (dtype, ep + 1, steps, dt / steps * 1e3, dec))
+        # the store's one kernel, alone: 512 resident rows gathered into the float batch (HIP events, 20 launches)
+        n_g = min(512, st.capacity)
+        slots = torch.arange(n_g, dtype=torch.int32, device=st.device) % max(1, min(st.capacity, n_images))
+        flips = (torch.arange(n_g, device=st.device) % 2).to(torch.uint8)
+        for _ in range(3):
+            st.gather(slots, flips)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            st.gather(slots, flips)
+        e1.record(); e1.synchronize()
+        g_us = e0.elapsed_time(e1) / 20 * 1e3
+        g_bytes = n_g * hw * hw * (3 + 3 * 4)                       # 3 B read + 12 B written per pixel (c_out = 3)
+        roof_gather = {'kernel': 'lec::image_gather4_kernel<3> (csrc/image_store.hip: gather by slot + mirror + uint8 / 255 -> fp32 NHWC)', 'bound': 'hbm',
+                       'achieved': round(g_bytes / g_us / 1e3, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(g_bytes / g_us / 1e3 / 8000.0, 4), 'traffic': None,
+                       'alg_bytes_per_launch': g_bytes, 'avg_launch_us': round(g_us, 1), 'rows': n_g}
         warm = per_epoch[1:] or per_epoch
         ms = float(np.mean([e['ms_per_step'] for e in warm]))
         tr.image_store.close()
@@ -550,6 +569,7 @@ def measure_trainer_files(args, dtype, stamp, n_images=2048, epochs=3):
                 'epochs': per_epoch, 'cnn_rows_per_step': round(float(np.mean([e['cnn_rows_per_step'] for e in warm])), 1),
                 'image_files': {'count': n_images, 'format': 'JPEG quality 90, 400x300', 'store_slots': st.capacity, 'store_bytes_per_image': hw * hw * 3,
                                 'decoder': 'PIL (libjpeg-turbo) + bilinear resize to %dx%d' % (hw, hw)},
+                'roofline_image_gather': roof_gather,
                 'host': {'cores': cores, 'decode_threads': tr.image_store._pool._max_workers, 'dataloader_worker_processes': tr.dataloaders['train'].num_workers},
                 'launch_mode': 'eager',
                 'api': 'JointEmbeddings.train_epoch over its own DataLoader / my_collate / criterion(...) (oe_h.py:1734-1774 mirror) on image files'}
