@@ -37,7 +37,7 @@ def self_launch(n, script=None, argv=None, extra_env=None):
         # fewer GPUs on the box than ranks asked for (a 1-GPU test box): RCCL refuses two ranks on one device, gloo reduces device tensors
         try:
             import torch
-            n_dev = torch.cuda.device_count()                   # counting devices does not initialise the GPU
+            n_dev = torch.cuda.device_count()                   # (on ROCm this calls hipGetDeviceCount; harmless here: the ranks are fresh CHILD processes, nothing is exec'd)
         except Exception:                                       # noqa: BLE001
             n_dev = n
         if 0 < n_dev < n:

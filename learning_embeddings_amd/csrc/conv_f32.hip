@@ -532,8 +532,8 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
 #define LEC_SK_STORE_AUX 16
 #endif
 #ifndef LEC_SK_ACQ
-#define LEC_SK_ACQ 0
-#endif
+#define LEC_SK_ACQ 1        // the finalizer's agent-scope ACQUIRE (round 4): it only invalidates this CU's L1 and runs in at most one workgroup per
+#endif                      // tile; with it the hand-off no longer leans on the sc1 loads alone (the relaxed ticket orders nothing by itself)
 struct SkArgs { float* slots; unsigned int* counters; int ntn; int tiles; };
 
 template <bool B_KC, int TM, int TN, bool STATS, int FUSE>
