@@ -643,6 +643,8 @@ def main():
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--sampler', default='replicated', choices=['replicated', 'per_rank'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-rows', type=int, default=64, help='CNN rows of the cpu_baseline step (64: the bounded sample of the default run; 512: the full workload, minutes)')
+    ap.add_argument('--cpu-baseline-budget', type=float, default=25.0, help='seconds of CPU work the cpu_baseline leg may spend after its warm-up step')
     ap.add_argument('--no-stress', action='store_true')
     ap.add_argument('--no-overlap-wgrad', action='store_true', help='keep the conv weight-gradient kernels in line')
     ap.add_argument('--overlap-wgrad', action='store_true', default=None, help='weight gradients on their own HIP stream (default: only when the step runs as ONE pass)')
@@ -780,7 +782,7 @@ def main():
                                'launch_floor_us': 16.5, 'note': 'forward-only launch of the cfg5 shape: 16.5 us (tools/sweep_cone.py): at 256 positives the launch is a dependent chain on a partly filled chip'}}
             out['roofline_stress'] = st
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(eng)
+            out['cpu_baseline'] = cpu_baseline(eng, budget_s=args.cpu_baseline_budget, rows=args.cpu_baseline_rows)
     eng.close()
     del eng
     torch.cuda.empty_cache()
