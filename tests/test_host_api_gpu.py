@@ -1162,8 +1162,17 @@ def test_joint_embeddings_trainer_two_concurrent_cnn_passes_equal_two_passes_in_
         tr.model.train(); tr.img_feat_net.train()
         torch.manual_seed(1)
         it = iter(tr.dataloaders['train'])
-        loss = float(tr.train_step(next(it))[0])
+        batches = []                                             # rows of every backbone forward of the step = its BatchNorm batches
+        hk = tr.img_feat_net.model.conv1.register_forward_hook(lambda m_, i_, o_: batches.append(int(i_[0].shape[0])))
+        item = next(it)
+        loss = float(tr.train_step(item)[0])
+        hk.remove()
         torch.cuda.synchronize()
+        if tag == 'concurrent':
+            # the two passes are cut at the positives | image-negatives boundary (the reference's own separate forwards,
+            # oe_h.py:980-985 | 1003-1009), not at the midpoint of the de-duplicated stack
+            n_pos = len({o for o in item['original_to'] if type(o) == str} | {o for o in item['original_from'] if type(o) == str})
+            assert batches == [n_pos, crit.last_cnn_rows - n_pos] and n_pos != -(-crit.last_cnn_rows // 2), (batches, n_pos, crit.last_cnn_rows)
         out[tag] = (loss, tr.model.embeddings.weight.detach().clone(), tr.arena.grad.clone(), crit.last_cnn_rows)
     a, b, c = out['concurrent'], out['in_turn'], out['one_pass']
     assert a[3] == b[3] == c[3] and a[3] >= 16
