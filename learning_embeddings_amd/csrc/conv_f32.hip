@@ -870,11 +870,19 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_sk_kernel(const fl
 // loader drops from 28 to 8 vector instructions per chunk but grows from ~140 to ~290 scalar ones, and a wave issues in order: the scalar
 // run sits between two MFMA blocks (the prefetch is a basic block of its own) and the matrix pipe waits for it.  Off by default
 // (LEC_WGRAD_SMASK=1 enables it); it pays only once the prefetch is interleaved with the MFMAs instruction by instruction.
-template <int WM, int WN, int TM, int TN, int WBK, bool DENSE, bool XF = false, bool SM = false>
+// SH ("shifted dense", round 4): a stride-1 layer whose output grid equals its input grid (3x3 / pad 1) and whose column tile lies inside ONE tap.
+// Then dW[co][tap][ci] = sum_m dY[m][co] * X[m + shift(tap)][ci] over the pixels m whose tap lands inside the image: the B operand is the DENSE
+// loader on x at a constant byte offset (no per-piece pixel decode, no bounds test, no scalar work at all; rows that fall off the tensor are the
+// buffer's range check), and the pixels whose tap leaves the image are zeroed on the A side -- the dY row -- by ONE table lookup per piece: a
+// 16-bit tap-validity mask per pixel position of an image, built once per workgroup in LDS, walked incrementally (pix += WBK, one conditional
+// subtract).  With it the tile can follow the layer (128 x 128 for Cin = 128: no half-empty fifth 256-column tile) and the kernel is the dense
+// split-K weight gradient, which holds the matrix pipe 83 % busy where the gathered form holds it 76 %.
+template <int WM, int WN, int TM, int TN, int WBK, bool DENSE, bool XF = false, bool SM = false, bool SH = false>
 __global__ __launch_bounds__(kCfThreads, (XF && WM <= 2 && TM * TN == 4) ? LEC_WG_XF_BLOCKS : 2) void conv_f32_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                        float* __restrict__ dw, WgGeo g, const float* __restrict__ xsrc = nullptr,
                                                                        const float* __restrict__ coef = nullptr) {
   static_assert(!XF || DENSE, "the on-load BatchNorm form serves the dense (1x1 / stride 1) layers");
+  static_assert(!SH || (DENSE && !XF && !SM), "the shifted-dense form is the dense loader");
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   static_assert(WM * WN == 4, "four waves per workgroup");
   static_assert(DENSE || BN == 256, "a gathered B row must be one wave-instruction (256 columns) for the scalar pixel decode");
@@ -890,6 +898,19 @@ __global__ __launch_bounds__(kCfThreads, (XF && WM <= 2 && TM * TN == 4) ? LEC_W
   const int nchunks_all = (g.Mpix + WBK - 1) / WBK;
   const rsrc_t rs_dy = make_rsrc(dy, g.dy_bytes), rs_x = make_rsrc(x, g.x_bytes);
   const rsrc_t rs_x2 = make_rsrc(XF ? xsrc : dy, g.dy_bytes);
+  unsigned short* vtab = (unsigned short*)(smem + 2 * (SA + SB));      // SH: tap-validity mask of every pixel position of an image
+  if (SH) {
+    for (int i = tid; i < g.HoWo; i += kCfThreads) {
+      const int ho = fdiv(i, g.dWo), wo = i - ho * g.Wo;
+      unsigned m = 0;
+      for (int tp = 0; tp < g.RS; ++tp) {
+        const int r = fdiv(tp, g.dS), s_ = tp - r * g.S;
+        if ((unsigned)(ho + r - g.pad) < (unsigned)g.H && (unsigned)(wo + s_ - g.pad) < (unsigned)g.W) m |= 1u << tp;
+      }
+      vtab[i] = (unsigned short)m;
+    }
+    __syncthreads();
+  }
   // work items = (output tile, K split); a workgroup walks its share when LEC_WGRAD_WGS caps the grid.  (Measured on the fp32 step:
   // one workgroup per CU leaves the main stream's HBM-bound BatchNorm kernels room -- their time drops 63.8 -> 50.9 ms -- but the
   // convolutions beside it stretch more than that: 164.7 ms per step against 157.0 uncapped, so the default is no cap.)
@@ -930,10 +951,21 @@ __global__ __launch_bounds__(kCfThreads, (XF && WM <= 2 && TM * TN == 4) ? LEC_W
   // B pieces.  DENSE (1x1 / stride 1: the source pixel of m is m): like A, on x.  Otherwise k row = wave + 4 u (wave-uniform),
   // columns j0 + 4 lane .. + 3 (inside one tap: Cin % 4 == 0), whose tap is a per-lane constant.
   unsigned boff[NB];
+  const int tapT = SH ? (j0 >> g.lgCin) : 0;                   // SH: the ONE tap of this column tile (scalar)
+  int shiftB = 0;
+  if (SH) { const int rT = fdiv(tapT, g.dS); shiftB = (((rT - g.pad) * g.W + (tapT - rT * g.S - g.pad)) * g.Cin) * 4; }
 #pragma unroll
   for (int u = 0; u < NB; ++u) {
     const int v = tid + kCfThreads * u; const int kr = v / PB, jq = v - kr * PB; const int jj = j0 + 4 * jq;
-    boff[u] = jj < g.Ng ? (unsigned)(kr * g.Cin + jj) * 4u : kOob;
+    boff[u] = jj < g.Ng ? (unsigned)(kr * g.Cin + (SH ? (jj & (g.Cin - 1)) : jj)) * 4u : kOob;
+  }
+  int apix[SH ? NA : 1]; unsigned aval[SH ? NA : 1];           // SH: pixel position (inside its image) of each A piece's row in the NEXT chunk to load
+  if (SH) {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int m0 = ch_lo * WBK + (tid + kCfThreads * u) / PA;
+      apix[u] = m0 - fdiv(m0, g.dHW) * g.HoWo;
+    }
   }
   const int j = j0 + 4 * lane;
   const int tapL = j >> g.lgCin, ciL = j & (g.Cin - 1);
@@ -972,8 +1004,15 @@ __global__ __launch_bounds__(kCfThreads, (XF && WM <= 2 && TM * TN == 4) ? LEC_W
 #pragma unroll
       for (int u = 0; u < NA; ++u) rx[u] = bload4(rs_x2, aoff[u] + abase);
     }
+    if (SH) {                                                   // chunks are loaded in order: the walk advances by one chunk per call
+#pragma unroll
+      for (int u = 0; u < NA; ++u) {
+        aval[u] = (unsigned)vtab[apix[u]];
+        apix[u] += WBK; apix[u] -= apix[u] >= g.HoWo ? g.HoWo : 0;
+      }
+    }
     if (DENSE) {
-      const unsigned bbase = (unsigned)(mbase * g.Cin) * 4u;
+      const unsigned bbase = (unsigned)(mbase * g.Cin) * 4u + (unsigned)shiftB;
 #pragma unroll
       for (int u = 0; u < NB; ++u) rb[u] = bload4(rs_x, boff[u] + bbase);
     } else {
@@ -1005,6 +1044,14 @@ __global__ __launch_bounds__(kCfThreads, (XF && WM <= 2 && TM * TN == 4) ? LEC_W
   };
   auto store_chunk = [&](int buf) {
     char* base = (char*)smem + buf * (SA + SB) * 4;
+    if (SH) {                                                   // the dY rows of pixels whose tap leaves the image: zero
+#pragma unroll
+      for (int u = 0; u < NA; ++u) {
+        const bool ok = (aval[u] >> tapT) & 1u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ra[u][e] = ok ? ra[u][e] : 0.f;
+      }
+    }
     if (XF) {                                                   // (rows past Mpix become cD: their X rows are zero, the products vanish)
 #pragma unroll
       for (int u = 0; u < NA; ++u)
@@ -1325,6 +1372,7 @@ static int conv_f32_wgrad_impl(const float* dy, const float* x, int N, int H, in
   g.Ng = R * S * Cin; g.dCin = dCin;
   g.dy_bytes = (uint32_t)((int64_t)g.Mpix * Cout * 4); g.x_bytes = (uint32_t)((int64_t)N * H * W * Cin * 4);
   g.dWo = make_fastdiv(g.Wo); g.dHo = make_fastdiv(g.Ho); g.dS = make_fastdiv(S);
+  g.HoWo = g.Ho * g.Wo; g.dHW = make_fastdiv(g.HoWo);
   const bool dense = R == 1 && S == 1 && stride == 1 && pad == 0;
   // tile (BM over Cout) x (BN over R*S*Cin), chunk width WBK: gathered layers 64 x 256; dense 1x1 layers whatever fits their shape
   int BM = 64, BN = 256, WBK = kWgBK;
@@ -1341,7 +1389,14 @@ static int conv_f32_wgrad_impl(const float* dy, const float* x, int N, int H, in
   // of 128: beside this variant no BatchNorm wave fits a SIMD, so the step gains less than the kernels (144.4 -> 144.0 ms).
   // LEC_WGRAD_BM128 = 0: off, 2: every eligible layer.
   static const int wg_bm128 = [] { const char* e = getenv("LEC_WGRAD_BM128"); return e ? atoi(e) : 1; }();
-  const bool big = !dense && Cout % 128 == 0 && (wg_bm128 == 2 || (wg_bm128 == 1 && (R * S == 1 || Cout <= 256)));
+  // Shifted-dense form (see the kernel): stride-1 layers whose output grid is their input grid, tile inside one tap.  LEC_WGRAD_SHIFT=0: off.
+  static const int wg_shift = [] { const char* e = getenv("LEC_WGRAD_SHIFT"); return e ? atoi(e) : 1; }();
+  const bool shifted = wg_shift && !dense && !xf && stride == 1 && g.Ho == H && g.Wo == W && R * S <= 16 && R * S > 1 && Cin >= 128 && dCin == Cin
+                       && g.HoWo >= WBK && Cout % 64 == 0;
+  if (shifted) {
+    if (Cin == 128 && Cout % 128 == 0) { BM = 128; BN = 128; } else { BM = 64; BN = 256; }
+  }
+  const bool big = !shifted && !dense && Cout % 128 == 0 && (wg_bm128 == 2 || (wg_bm128 == 1 && (R * S == 1 || Cout <= 256)));
   if (big) BM = 128;
   const int tiles = ((Cout + BM - 1) / BM) * ((g.Ng + BN - 1) / BN);
   const int nchunks = (g.Mpix + WBK - 1) / WBK;
@@ -1357,7 +1412,7 @@ static int conv_f32_wgrad_impl(const float* dy, const float* x, int N, int H, in
   g.chunks_per_split = (nchunks + split - 1) / split;
   split = (nchunks + g.chunks_per_split - 1) / g.chunks_per_split;
   g.tiles = tiles; g.split = split;
-  size_t lds = (size_t)2 * WBK * (BM + BN) * 4;
+  size_t lds = (size_t)2 * WBK * (BM + BN) * 4 + (shifted ? (size_t)((g.HoWo * 2 + 15) / 16 * 16) : 0);
   // Residency knob (LEC_WGRAD_LDS_PAD = extra LDS bytes): the tiles need 32 - 40 KB, so four workgroups share a CU and the main stream's
   // HBM-bound BatchNorm kernels (this kernel runs on the side stream) find no registers to land on.  14336 extra bytes keep it at two workgroups
   // per CU: BatchNorm 61.6 -> 52.2 ms inside the step, these kernels 44 -> 47.5 ms, the step 157.5 -> 155.8 ms (same-box A/B, 1 %); left off by
@@ -1379,6 +1434,8 @@ static int conv_f32_wgrad_impl(const float* dy, const float* x, int N, int H, in
     else if (BM == 256) hipLaunchKernelGGL((conv_f32_wgrad_kernel<4, 1, 2, 2, kWgBK, true, true>), grid, blk, lds, st, dy, x, dw, g, xsrc, coef);
     else hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 1, 1, 32, true, true>), grid, blk, lds, st, dy, x, dw, g, xsrc, coef);
   }
+  else if (shifted && BM == 128) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 2, kWgBK, true, false, false, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
+  else if (shifted) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, true, false, false, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (big && sm) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 4, kWgBK, false, false, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (big) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 4, kWgBK, false>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (!dense && sm) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, false, false, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);

@@ -78,6 +78,8 @@ struct WgGeo {
   int chunks_per_split, tiles, split;
   uint32_t dy_bytes, x_bytes;
   FastDiv dWo, dHo, dS;
+  int HoWo;                                // pixels per image (the shifted-dense form's validity table has one entry each)
+  FastDiv dHW;
 };
 
 static inline int ilog2_exact(int v) {
