@@ -1376,7 +1376,12 @@ static int conv_f32_wgrad_impl(const float* dy, const float* x, int N, int H, in
   const bool dense = R == 1 && S == 1 && stride == 1 && pad == 0;
   // tile (BM over Cout) x (BN over R*S*Cin), chunk width WBK: gathered layers 64 x 256; dense 1x1 layers whatever fits their shape
   int BM = 64, BN = 256, WBK = kWgBK;
-  if (dense) {
+  static const int wg_dense_tile = [] { const char* e = getenv("LEC_WGRAD_DENSE_TILE"); return e ? atoi(e) : 1; }();
+  // dense 1x1 layers: 128 x 128 wherever it fits (round 4: 2 - 4 % under the 64 x 256 tile on all eleven shapes of ResNet-50, e.g. 256 -> 128 @56 910 -> 881 us,
+  // 512 -> 128 @28 453 -> 435, 1024 -> 512 @14 811 -> 781).  LEC_WGRAD_DENSE_TILE: 0 = the round-3 rule, 2 = 128 x 256 (experiment).
+  if (dense && !xf && wg_dense_tile == 2 && Cout % 128 == 0 && g.Ng % 256 == 0) { BM = 128; BN = 256; }
+  else if (dense && wg_dense_tile != 0 && Cout % 128 == 0 && g.Ng % 128 == 0) { BM = 128; BN = 128; }
+  else if (dense) {
     if (g.Ng >= 256) { BM = 64; BN = 256; }
     else if (g.Ng >= 128) { BM = 128; BN = 128; }
     else if (Cout >= 256) { BM = 256; BN = 64; }
@@ -1393,8 +1398,11 @@ static int conv_f32_wgrad_impl(const float* dy, const float* x, int N, int H, in
   static const int wg_shift = [] { const char* e = getenv("LEC_WGRAD_SHIFT"); return e ? atoi(e) : 1; }();
   const bool shifted = wg_shift && !dense && !xf && stride == 1 && g.Ho == H && g.Wo == W && R * S <= 16 && R * S > 1 && Cin >= 128 && dCin == Cin
                        && g.HoWo >= WBK && Cout % 64 == 0;
+  static const int wg_shift_tile = [] { const char* e = getenv("LEC_WGRAD_SHIFT_TILE"); return e ? atoi(e) : 0; }();   // experiments: 1 = 128x128, 2 = 64x256, 3 = 128x256
   if (shifted) {
-    if (Cin == 128 && Cout % 128 == 0) { BM = 128; BN = 128; } else { BM = 64; BN = 256; }
+    if (Cout % 128 == 0) { BM = 128; BN = 128; } else { BM = 64; BN = 256; }     // 128 x 128: 928 / 904 / 902 us on the 3x3 layers @28 / 14 / 7 against 957 / 1104 / 1133 (64 x 256), 952 / 934 / 930 (128 x 256)
+    if (wg_shift_tile == 2) { BM = 64; BN = Cin >= 256 ? 256 : 128; if (BN == 128) BM = 128; }
+    if (wg_shift_tile == 3 && Cout % 128 == 0 && Cin >= 256) { BM = 128; BN = 256; }
   }
   const bool big = !shifted && !dense && Cout % 128 == 0 && (wg_bm128 == 2 || (wg_bm128 == 1 && (R * S == 1 || Cout <= 256)));
   if (big) BM = 128;
@@ -1434,12 +1442,14 @@ static int conv_f32_wgrad_impl(const float* dy, const float* x, int N, int H, in
     else if (BM == 256) hipLaunchKernelGGL((conv_f32_wgrad_kernel<4, 1, 2, 2, kWgBK, true, true>), grid, blk, lds, st, dy, x, dw, g, xsrc, coef);
     else hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 1, 1, 32, true, true>), grid, blk, lds, st, dy, x, dw, g, xsrc, coef);
   }
+  else if (shifted && BM == 128 && BN == 256) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 4, kWgBK, true, false, false, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (shifted && BM == 128) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 2, kWgBK, true, false, false, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (shifted) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, true, false, false, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (big && sm) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 4, kWgBK, false, false, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (big) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 4, kWgBK, false>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (!dense && sm) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, false, false, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (!dense) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, false>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
+  else if (BM == 128 && BN == 256) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 4, kWgBK, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (BM == 64 && BN == 256) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (BM == 128) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 2, kWgBK, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (BM == 256) hipLaunchKernelGGL((conv_f32_wgrad_kernel<4, 1, 2, 2, kWgBK, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
