@@ -877,7 +877,10 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_sk_kernel(const fl
 // 16-bit tap-validity mask per pixel position of an image, built once per workgroup in LDS, walked incrementally (pix += WBK, one conditional
 // subtract).  With it the tile can follow the layer (128 x 128 for Cin = 128: no half-empty fifth 256-column tile) and the kernel is the dense
 // split-K weight gradient, which holds the matrix pipe 83 % busy where the gathered form holds it 76 %.
-template <int WM, int WN, int TM, int TN, int WBK, bool DENSE, bool XF = false, bool SM = false, bool SH = false>
+// SH = 2: the same for STRIDE-2 layers whose input grid is exactly twice the output grid (3x3 / pad 1 and the 1x1 downsample layers of ResNet):
+// the source pixel of output pixel m = (n, ho, wo) under tap (r, s) is 4 m - 2 wo + const -- affine in m but for the column wo, which every B piece
+// walks incrementally like the A pieces walk their pixel position (wo += WBK mod Wo, one conditional subtract).
+template <int WM, int WN, int TM, int TN, int WBK, bool DENSE, bool XF = false, bool SM = false, int SH = 0>
 __global__ __launch_bounds__(kCfThreads, (XF && WM <= 2 && TM * TN == 4) ? LEC_WG_XF_BLOCKS : 2) void conv_f32_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                        float* __restrict__ dw, WgGeo g, const float* __restrict__ xsrc = nullptr,
                                                                        const float* __restrict__ coef = nullptr) {
@@ -905,7 +908,7 @@ __global__ __launch_bounds__(kCfThreads, (XF && WM <= 2 && TM * TN == 4) ? LEC_W
       unsigned m = 0;
       for (int tp = 0; tp < g.RS; ++tp) {
         const int r = fdiv(tp, g.dS), s_ = tp - r * g.S;
-        if ((unsigned)(ho + r - g.pad) < (unsigned)g.H && (unsigned)(wo + s_ - g.pad) < (unsigned)g.W) m |= 1u << tp;
+        if ((unsigned)(ho * g.stride + r - g.pad) < (unsigned)g.H && (unsigned)(wo * g.stride + s_ - g.pad) < (unsigned)g.W) m |= 1u << tp;
       }
       vtab[i] = (unsigned short)m;
     }
@@ -957,9 +960,10 @@ __global__ __launch_bounds__(kCfThreads, (XF && WM <= 2 && TM * TN == 4) ? LEC_W
 #pragma unroll
   for (int u = 0; u < NB; ++u) {
     const int v = tid + kCfThreads * u; const int kr = v / PB, jq = v - kr * PB; const int jj = j0 + 4 * jq;
-    boff[u] = jj < g.Ng ? (unsigned)(kr * g.Cin + (SH ? (jj & (g.Cin - 1)) : jj)) * 4u : kOob;
+    boff[u] = jj < g.Ng ? (unsigned)((SH == 2 ? 4 * kr : kr) * g.Cin + (SH ? (jj & (g.Cin - 1)) : jj)) * 4u : kOob;
   }
   int apix[SH ? NA : 1]; unsigned aval[SH ? NA : 1];           // SH: pixel position (inside its image) of each A piece's row in the NEXT chunk to load
+  int bwo[SH == 2 ? NB : 1];                                    // SH = 2: output column wo of each B piece's row in the NEXT chunk to load
   if (SH) {
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
@@ -967,6 +971,15 @@ __global__ __launch_bounds__(kCfThreads, (XF && WM <= 2 && TM * TN == 4) ? LEC_W
       apix[u] = m0 - fdiv(m0, g.dHW) * g.HoWo;
     }
   }
+  if (SH == 2) {
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int m0 = ch_lo * WBK + (tid + kCfThreads * u) / PB;
+      bwo[u] = m0 - fdiv(m0, g.dWo) * g.Wo;
+    }
+  }
+  const int wstep = SH == 2 ? WBK - fdiv(WBK, g.dWo) * g.Wo : 0;  // WBK mod Wo
+  const int k2 = SH == 2 ? 2 * g.Cin * 4 : 0;                   // bytes per unit of wo in "4 m - 2 wo"
   const int j = j0 + 4 * lane;
   const int tapL = j >> g.lgCin, ciL = j & (g.Cin - 1);
   const int rL = fdiv(tapL, g.dS);
@@ -1012,9 +1025,16 @@ __global__ __launch_bounds__(kCfThreads, (XF && WM <= 2 && TM * TN == 4) ? LEC_W
       }
     }
     if (DENSE) {
-      const unsigned bbase = (unsigned)(mbase * g.Cin) * 4u + (unsigned)shiftB;
+      const unsigned bbase = (unsigned)((SH == 2 ? 4 * mbase : mbase) * g.Cin) * 4u + (unsigned)shiftB;
 #pragma unroll
-      for (int u = 0; u < NB; ++u) rb[u] = bload4(rs_x, boff[u] + bbase);
+      for (int u = 0; u < NB; ++u) {
+        if (SH == 2) {
+          rb[u] = bload4(rs_x, boff[u] + bbase - (unsigned)(bwo[u] * k2));
+          bwo[u] += wstep; bwo[u] -= bwo[u] >= g.Wo ? g.Wo : 0;
+        } else {
+          rb[u] = bload4(rs_x, boff[u] + bbase);
+        }
+      }
     } else {
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
@@ -1396,13 +1416,11 @@ static int conv_f32_wgrad_impl(const float* dy, const float* x, int N, int H, in
   static const int wg_bm128 = [] { const char* e = getenv("LEC_WGRAD_BM128"); return e ? atoi(e) : 1; }();
   // Shifted-dense form (see the kernel): stride-1 layers whose output grid is their input grid, tile inside one tap.  LEC_WGRAD_SHIFT=0: off.
   static const int wg_shift = [] { const char* e = getenv("LEC_WGRAD_SHIFT"); return e ? atoi(e) : 1; }();
-  const bool shifted = wg_shift && !dense && !xf && stride == 1 && g.Ho == H && g.Wo == W && R * S <= 16 && R * S > 1 && Cin >= 128 && dCin == Cin
-                       && g.HoWo >= WBK && Cout % 64 == 0;
-  static const int wg_shift_tile = [] { const char* e = getenv("LEC_WGRAD_SHIFT_TILE"); return e ? atoi(e) : 0; }();   // experiments: 1 = 128x128, 2 = 64x256, 3 = 128x256
+  const bool same1 = stride == 1 && g.Ho == H && g.Wo == W && R * S > 1, half2 = stride == 2 && H == 2 * g.Ho && W == 2 * g.Wo;
+  const bool shifted = wg_shift && !dense && !xf && (same1 || (half2 && wg_shift != 3)) && R * S <= 16 && Cin >= 128 && dCin == Cin
+                       && g.HoWo >= WBK && g.Wo >= 2 && Cout % 64 == 0 && (Cout % 128 == 0 || Cin >= 256);      // (the column tile must lie inside one tap)
   if (shifted) {
     if (Cout % 128 == 0) { BM = 128; BN = 128; } else { BM = 64; BN = 256; }     // 128 x 128: 928 / 904 / 902 us on the 3x3 layers @28 / 14 / 7 against 957 / 1104 / 1133 (64 x 256), 952 / 934 / 930 (128 x 256)
-    if (wg_shift_tile == 2) { BM = 64; BN = Cin >= 256 ? 256 : 128; if (BN == 128) BM = 128; }
-    if (wg_shift_tile == 3 && Cout % 128 == 0 && Cin >= 256) { BM = 128; BN = 256; }
   }
   const bool big = !shifted && !dense && Cout % 128 == 0 && (wg_bm128 == 2 || (wg_bm128 == 1 && (R * S == 1 || Cout <= 256)));
   if (big) BM = 128;
@@ -1442,9 +1460,10 @@ static int conv_f32_wgrad_impl(const float* dy, const float* x, int N, int H, in
     else if (BM == 256) hipLaunchKernelGGL((conv_f32_wgrad_kernel<4, 1, 2, 2, kWgBK, true, true>), grid, blk, lds, st, dy, x, dw, g, xsrc, coef);
     else hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 1, 1, 32, true, true>), grid, blk, lds, st, dy, x, dw, g, xsrc, coef);
   }
-  else if (shifted && BM == 128 && BN == 256) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 4, kWgBK, true, false, false, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
-  else if (shifted && BM == 128) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 2, kWgBK, true, false, false, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
-  else if (shifted) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, true, false, false, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
+  else if (shifted && stride == 2 && BM == 128) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 2, kWgBK, true, false, false, 2>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
+  else if (shifted && stride == 2) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, true, false, false, 2>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
+  else if (shifted && BM == 128) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 2, kWgBK, true, false, false, 1>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
+  else if (shifted) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, true, false, false, 1>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (big && sm) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 4, kWgBK, false, false, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (big) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 4, kWgBK, false>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (!dense && sm) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, false, false, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);

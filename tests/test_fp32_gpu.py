@@ -193,6 +193,8 @@ CONV_CASES = [  # N, Cin, H, W, Cout, R, stride, pad
     (2, 4, 32, 32, 64, 7, 2, 3), (1, 1024, 5, 5, 2048, 1, 2, 0), (5, 64, 3, 3, 128, 3, 1, 1), (2, 8, 6, 6, 16, 3, 1, 1),
     # the shifted-dense weight gradient (round 4: stride-1 'same' layers with Cin >= 128): ragged, non-square, 128 x 128 and 64 x 256 tiles, a 3 x 3 image (falls back)
     (3, 128, 9, 7, 128, 3, 1, 1), (2, 256, 10, 6, 64, 3, 1, 1), (2, 128, 5, 5, 256, 3, 1, 1), (7, 128, 3, 3, 128, 3, 1, 1), (33, 128, 28, 28, 128, 3, 1, 1),
+    # ... its stride-2 form (input grid = 2 x output grid): 3x3 / pad 1 non-square, a downsample 1x1, 64 output channels (64 x 256 tile), one that falls back (Cin = 128, Cout = 64)
+    (3, 256, 12, 8, 128, 3, 2, 1), (2, 512, 14, 14, 1024, 1, 2, 0), (2, 256, 12, 12, 64, 3, 2, 1), (2, 128, 16, 16, 64, 3, 2, 1), (9, 128, 28, 28, 128, 3, 2, 1),
 ]
 
 
