@@ -1417,10 +1417,12 @@ static int conv_f32_wgrad_impl(const float* dy, const float* x, int N, int H, in
   // Shifted-dense form (see the kernel): stride-1 layers whose output grid is their input grid, tile inside one tap.  LEC_WGRAD_SHIFT=0: off.
   static const int wg_shift = [] { const char* e = getenv("LEC_WGRAD_SHIFT"); return e ? atoi(e) : 1; }();
   const bool same1 = stride == 1 && g.Ho == H && g.Wo == W && R * S > 1, half2 = stride == 2 && H == 2 * g.Ho && W == 2 * g.Wo;
-  const bool shifted = wg_shift && !dense && !xf && (same1 || (half2 && wg_shift != 3)) && R * S <= 16 && Cin >= 128 && dCin == Cin
-                       && g.HoWo >= WBK && g.Wo >= 2 && Cout % 64 == 0 && (Cout % 128 == 0 || Cin >= 256);      // (the column tile must lie inside one tap)
+  static const int wg_shift64 = [] { const char* e = getenv("LEC_WGRAD_SHIFT64"); return e ? atoi(e) : 1; }();       // the 64 -> 64 3x3 layers on a 64 x 64 tile: 1376 - 1412 -> 1103 - 1122 us @56 (library 1290 - 1305)
+  const bool shifted = wg_shift && !dense && !xf && (same1 || (half2 && wg_shift != 3)) && R * S <= 16 && (Cin >= 128 || (wg_shift64 && Cin == 64 && Cout == 64 && stride == 1)) && dCin == Cin
+                       && g.HoWo >= 32 && g.Wo >= 2 && Cout % 64 == 0 && (Cout % 128 == 0 || Cin >= 256 || Cin == 64);      // (the column tile must lie inside one tap)
   if (shifted) {
-    if (Cout % 128 == 0) { BM = 128; BN = 128; } else { BM = 64; BN = 256; }     // 128 x 128: 928 / 904 / 902 us on the 3x3 layers @28 / 14 / 7 against 957 / 1104 / 1133 (64 x 256), 952 / 934 / 930 (128 x 256)
+    if (Cin == 64) { BM = 64; BN = 64; WBK = 32; }
+    else if (Cout % 128 == 0) { BM = 128; BN = 128; } else { BM = 64; BN = 256; }     // 128 x 128: 928 / 904 / 902 us on the 3x3 layers @28 / 14 / 7 against 957 / 1104 / 1133 (64 x 256), 952 / 934 / 930 (128 x 256)
   }
   const bool big = !shifted && !dense && Cout % 128 == 0 && (wg_bm128 == 2 || (wg_bm128 == 1 && (R * S == 1 || Cout <= 256)));
   if (big) BM = 128;
@@ -1462,6 +1464,7 @@ static int conv_f32_wgrad_impl(const float* dy, const float* x, int N, int H, in
   }
   else if (shifted && stride == 2 && BM == 128) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 2, kWgBK, true, false, false, 2>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (shifted && stride == 2) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, true, false, false, 2>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
+  else if (shifted && BN == 64) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 1, 1, 32, true, false, false, 1>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (shifted && BM == 128) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 2, kWgBK, true, false, false, 1>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (shifted) hipLaunchKernelGGL((conv_f32_wgrad_kernel<1, 4, 2, 2, kWgBK, true, false, false, 1>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   else if (big && sm) hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 2, 4, kWgBK, false, false, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
