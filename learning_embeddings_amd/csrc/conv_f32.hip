@@ -468,6 +468,14 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
           // valid offsets are < 2^31 and coff < 2^14: the sum of two valid parts cannot reach the kOob bit, and a poisoned part keeps it
 #pragma unroll
           for (int jt = 0; jt < TN; ++jt) bstore1(acc[it][jt][r], rs_dst, (poff + coff[jt]) | ((poff | coff[jt]) & kOob));
+          if (g.zfill) {                                        // stride-2 1x1 data gradient: the pixels no output pixel reaches are zero (one launch instead of four)
+            const unsigned rowb = (unsigned)g.Cd * 4u, lineb = (unsigned)g.Wd * rowb;
+#pragma unroll
+            for (int jt = 0; jt < TN; ++jt) {
+              const unsigned o = (poff + coff[jt]) | ((poff | coff[jt]) & kOob);
+              bstore1(0.f, rs_dst, o + rowb); bstore1(0.f, rs_dst, o + lineb); bstore1(0.f, rs_dst, o + lineb + rowb);
+            }
+          }
         }
       }
     }
@@ -1259,6 +1267,7 @@ extern "C" int lec_conv_f32_fwd(const float* x, const float* w, int N, int H, in
   LEC_CHECK_ARG(x && w && y, "conv_f32_fwd: null pointer");
   const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
   ActGeo g;
+  g.zfill = 0;
   g.Mg = N * Ho * Wo; g.Hm = Ho; g.Wm = Wo; g.Hs = H; g.Ws = W; g.Cs = Cin; g.lgCs = ilog2_exact(Cin); g.sst = stride;
   g.oh0 = -pad; g.ow0 = -pad; g.sg = 1; g.na = R; g.nb = S; g.r0 = 0; g.rstep = 1; g.s0 = 0; g.sstep = 1; g.S = S; g.RS = R * S;
   g.Cd = Cout; g.Cin = Cin; g.Hd = Ho; g.Wd = Wo; g.dst_st = 1; g.dph = 0; g.dpw = 0; g.Kg = R * S * Cin;
@@ -1282,6 +1291,7 @@ extern "C" int lec_conv_f32_fwd_affine(const float* x, const float* w, int N, in
   LEC_CHECK_ARG(x && w && y && scale && shift, "conv_f32_fwd_affine: null pointer");
   const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
   ActGeo g;
+  g.zfill = 0;
   g.Mg = N * Ho * Wo; g.Hm = Ho; g.Wm = Wo; g.Hs = H; g.Ws = W; g.Cs = Cin; g.lgCs = ilog2_exact(Cin); g.sst = stride;
   g.oh0 = -pad; g.ow0 = -pad; g.sg = 1; g.na = R; g.nb = S; g.r0 = 0; g.rstep = 1; g.s0 = 0; g.sstep = 1; g.S = S; g.RS = R * S;
   g.Cd = Cout; g.Cin = Cin; g.Hd = Ho; g.Wd = Wo; g.dst_st = 1; g.dph = 0; g.dpw = 0; g.Kg = R * S * Cin;
@@ -1299,9 +1309,12 @@ extern "C" int lec_conv_f32_dgrad(const float* dy, const float* w, int N, int H,
   if (int rc = conv_check("conv_f32_dgrad", N, H, W, Cin, Cout, R, S, stride, pad)) return rc;
   LEC_CHECK_ARG(dy && w && dx, "conv_f32_dgrad: null pointer");
   const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
-  for (int ph = 0; ph < stride; ++ph) {
-    for (int pw = 0; pw < stride; ++pw) {
+  // a 1x1 / stride-2 layer with an even input grid: only the (0, 0) parity class has a tap; its launch also writes the zeros of the other three
+  const bool one_launch = stride == 2 && R == 1 && S == 1 && pad == 0 && H % 2 == 0 && W % 2 == 0;
+  for (int ph = 0; ph < (one_launch ? 1 : stride); ++ph) {
+    for (int pw = 0; pw < (one_launch ? 1 : stride); ++pw) {
       ActGeo g;
+      g.zfill = one_launch ? 1 : 0;
       g.Hm = (H - ph + stride - 1) / stride; g.Wm = (W - pw + stride - 1) / stride;
       if (g.Hm <= 0 || g.Wm <= 0) continue;
       g.Mg = N * g.Hm * g.Wm; g.Hs = Ho; g.Ws = Wo; g.Cs = Cout; g.lgCs = ilog2_exact(Cout); g.sst = 1;
@@ -1340,6 +1353,7 @@ extern "C" int lec_conv_f32_dgrad_fused(const float* dy, const float* w, int N, 
   LEC_CHECK_ARG(Cout % kCfBK == 0, "conv_f32_dgrad_fused: Cout must be a multiple of %d", kCfBK);
   const int Ho = H + 2 * pad - R + 1, Wo = W + 2 * pad - S + 1;
   ActGeo g;
+  g.zfill = 0;
   g.Hm = H; g.Wm = W; g.Mg = N * H * W; g.Hs = Ho; g.Ws = Wo; g.Cs = Cout; g.lgCs = ilog2_exact(Cout); g.sst = 1;
   g.r0 = 0; g.s0 = 0; g.rstep = 1; g.sstep = 1; g.na = R; g.nb = S; g.oh0 = pad; g.ow0 = pad; g.sg = -1;   // lec_conv_f32_dgrad's formulas at stride 1
   g.S = S; g.RS = R * S; g.Cd = Cin; g.Cin = Cin; g.Hd = H; g.Wd = W; g.dst_st = 1; g.dph = 0; g.dpw = 0;

@@ -781,6 +781,7 @@ extern "C" int lec_conv_f32x3_fwd(const float* x, const uint16_t* w_planes, int 
   LEC_CHECK_ARG(x && w_planes && y, "conv_f32x3_fwd: null pointer");
   const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
   ActGeo g;
+  g.zfill = 0;
   g.Mg = N * Ho * Wo; g.Hm = Ho; g.Wm = Wo; g.Hs = H; g.Ws = W; g.Cs = Cin; g.lgCs = ilog2_exact(Cin); g.sst = stride;
   g.oh0 = -pad; g.ow0 = -pad; g.sg = 1; g.na = R; g.nb = S; g.r0 = 0; g.rstep = 1; g.s0 = 0; g.sstep = 1; g.S = S; g.RS = R * S;
   g.Cd = Cout; g.Cin = Cin; g.Hd = Ho; g.Wd = Wo; g.dst_st = 1; g.dph = 0; g.dpw = 0; g.Kg = R * S * Cin;
@@ -807,6 +808,7 @@ extern "C" int lec_conv_f32x3_dgrad(const float* dy, const uint16_t* w_planes_t,
   for (int ph = 0; ph < stride; ++ph) {
     for (int pw = 0; pw < stride; ++pw) {
       ActGeo g;
+      g.zfill = 0;
       g.Hm = (H - ph + stride - 1) / stride; g.Wm = (W - pw + stride - 1) / stride;
       if (g.Hm <= 0 || g.Wm <= 0) continue;
       g.Mg = N * g.Hm * g.Wm; g.Hs = Ho; g.Ws = Wo; g.Cs = Cout; g.lgCs = ilog2_exact(Cout); g.sst = 1;

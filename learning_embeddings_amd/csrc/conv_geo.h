@@ -64,6 +64,7 @@ struct ActGeo {
   int Cin;                                 // the layer's input channels (innermost weight dimension)
   int Hd, Wd, dst_st, dph, dpw;            // destination pixel of m: (n, mh * dst_st + dph, mw * dst_st + dpw) of [N, Hd, Wd, Cd]
   int Kg;                                  // na * nb * Cs
+  int zfill;                               // strided destination of a 1x1 layer: the three other pixels of every 2 x 2 block are written as zeros by this launch
   int xcd_per;                             // > 0: m-tiles are dealt to the 8 XCDs in contiguous runs of this many (see launch_act); 0: round-robin
   uint32_t src_bytes, wgt_bytes, dst_bytes;
   FastDiv dWm, dHm, dnb;                   // divisions by Wm, Hm, nb
