@@ -345,7 +345,7 @@ def measure(args, dtype, rank, world, stamp, primary):
                      'frac_lower_bound_flops_over_step_wall_time': round(eng.conv_flops_per_step / (dt / args.steps) / 1e12 / 157.3, 4),
                      'frac_basis': 'HEADLINE `frac` = algorithmic flops / union of the family\'s launch intervals (HIP events, all streams); the wall-based figure rides along as '
                                    'frac_lower_bound_flops_over_step_wall_time.  Both can be re-derived from the tracked rocprofv3 kernel trace: profiles/r04_bench_cfg3_f32_steady_state.md '
-                                   '("convolution family roofline": union 0.6293, wall 0.5925 in a profiled run whose own HIP-event union read 0.6262)',
+                                   '("convolution family roofline": union 0.6560, wall 0.6186 in a profiled run whose own HIP-event union read 0.6530)',
                      'note': probe_note + 'HIP events on the stream each kernel runs on; achieved = flops / union of the launch intervals over the concurrent streams (the sum of the durations counts shared time once per stream)'}
         if conv_isolated is not None:
             roof_conv['isolated'] = {'ms_per_step': round(conv_isolated, 3), 'achieved': round(eng.conv_flops_per_step / conv_isolated / 1e9, 2),
