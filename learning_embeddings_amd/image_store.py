@@ -136,8 +136,10 @@ class ImageStore:
             for i in miss.tolist():                              # nobody asked ahead: decode now, in parallel
                 if i not in self._pending and i not in self._offered:
                     self._pending[i] = self._pool.submit(self._decoder, self.locs[self.names[i]], self.hw)
-            futs = {i: self._pending.pop(i) for i in miss.tolist() if i in self._pending}
-            offered = {i: self._offered.pop(i) for i in miss.tolist() if i in self._offered}
+            # (the entries stay in _pending / _offered until the slots below are assigned: a request() from the lookahead thread in between
+            # must keep seeing these images as "on their way", or it decodes them a second time into a future nobody collects)
+            futs = {i: self._pending[i] for i in miss.tolist() if i in self._pending}
+            offered = {i: self._offered[i] for i in miss.tolist() if i in self._offered}
         arrays = {}
         for i, f in futs.items():
             arrays[i] = f.result()                               # (outside the lock: the lookahead thread keeps requesting)
@@ -167,6 +169,7 @@ class ImageStore:
                     self.slot_of_id[old] = -1; self.flags[old] = 0; self.stats['evicted'] += 1
                 self.id_of_slot[s] = i; self.slot_of_id[i] = s; keep.add(s)
                 new_slots[j] = s
+                self._pending.pop(i, None); self._offered.pop(i, None)
         # one asynchronous copy per run of consecutive slots (a cold store: ONE copy for all misses of the step)
         a = 0
         while a < m:
