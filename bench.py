@@ -511,7 +511,7 @@ def write_image_files(d, n, w=400, h=300, seed=0):
         return list(ex.map(one, range(n)))
 
 
-def measure_trainer_files(args, dtype, stamp, n_images=2048, epochs=3):
+def measure_trainer_files(args, dtype, stamp, n_images=4096, epochs=3):
     """The drop-in trainer fed from image FILES (VERDICT r03 "what's missing" #1): JointEmbeddings.train_epoch over its own
     DataLoader with the HBM image store (image_store.py; n_workers > 0 sizes its decode pool).  Epoch 1 is cold: every image is decoded once,
     one step ahead of its use, by the store's decode threads (positives and negatives alike: train_epoch's lookahead) and uploaded as
@@ -583,7 +583,7 @@ def measure_trainer(args, dtype, stamp, n_steps, n_warm):
     on in-memory images that are resident in HBM.  Eager launches (the batch composition varies from step to step)."""
     import numpy as np, torch
     from learning_embeddings_amd.engine import WORKLOADS
-    M = 2048
+    M = 4096
     hw = WORKLOADS[args.workload][5]
     P = 2 * (args.batch or WORKLOADS[args.workload][2])
     dev = torch.device('cuda', torch.cuda.current_device())
@@ -657,8 +657,8 @@ def main():
                          'half-batch passes the replay runs at the eager step\'s speed (132.9 vs 132.8 ms) with 4 ms of host time per step instead of 25 and 44 GB of HBM')
     ap.add_argument('--no-graph', action='store_true', help='same as --launch eager')
     ap.add_argument('--cudnn-benchmark', action='store_true', help='let MIOpen benchmark every solver per conv shape (slow start)')
-    ap.add_argument('--through-trainer', type=int, default=8, help='also time N steps of the same workload driven through JointEmbeddings.train_step (0: skip)')
-    ap.add_argument('--through-trainer-files', type=int, default=2048,
+    ap.add_argument('--through-trainer', type=int, default=16, help='also time N steps of the same workload driven through JointEmbeddings.train_step (0: skip)')
+    ap.add_argument('--through-trainer-files', type=int, default=4096,
                     help='also run the trainer from this many synthetic JPEG FILES through the HBM image store, three epochs (0: skip)')
     args = ap.parse_args()
     if args.no_graph:
