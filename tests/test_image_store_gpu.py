@@ -230,3 +230,28 @@ def test_trainer_from_files_decodes_ahead_on_the_stores_threads(tmp_path):
     torch.cuda.synchronize()
     assert st.stats['hits'] > before['hits'] and st.stats['decoded_here'] - before['decoded_here'] < 12      # (a new negative may still meet an image for the first time)
     assert np.isfinite(float(running))
+
+
+def test_reference_exact_batches_from_files_through_the_store(tmp_path):
+    """reference_exact_batches=True fed from image files: the reference's four forwards are assembled from the store (positives as ImageRef
+    handles with their flip, every fixed image end K more times by name, unflipped), and one step runs."""
+    torch.manual_seed(0)
+    tr, crit, gd, dl = _file_trainer(tmp_path, 'x', True, reference_exact_batches=True)
+    assert tr.reference_exact_batches and crit.reference_exact_batches and tr.cnn_passes == 1
+    batches = []
+    hk = tr.img_feat_net.model.conv1.register_forward_hook(lambda m_, i_, o_: batches.append(int(i_[0].shape[0])))
+    rows_of = []
+    orig_batch = crit._image_batch
+    def spy(rows, dev, store):
+        rows_of.append(list(rows)); return orig_batch(rows, dev, store)
+    crit._image_batch = spy
+    running, steps = tr.train_epoch(max_steps=1)
+    hk.remove(); torch.cuda.synchronize()
+    assert steps == 1 and np.isfinite(float(running))
+    neg = crit.last_negatives
+    N = tr.n_classes
+    n_img_pos = sum(1 for r in rows_of[0] if isinstance(r, tuple))        # the positives' to-side forward comes first (no image on a from side here)
+    assert batches[0] == n_img_pos and sum(batches) == crit.last_cnn_rows
+    assert crit.last_cnn_rows == n_img_pos + int((neg >= N).sum()) + crit.neg_to_pos_ratio * n_img_pos
+    assert all(isinstance(r, tuple) for rows in rows_of for r in rows)     # every row came from the store
+    assert not any(flip for rows in rows_of[1:] for _, flip in rows)       # re-embedded fixed ends and image negatives: get_image's transform, never mirrored
