@@ -14,10 +14,12 @@ namespace lec {
 
 struct alignas(16) if32x4 { float v[4]; };
 
-// W % 4 == 0: one thread = 4 consecutive output pixels of a row = 12 source bytes (three aligned dwords, mirrored or not).
-// Measured (512 rows of 224 x 224, one MI355X): 111 us = 3.4 TB/s of algorithmic bytes at c_out = 3.  Tried in round 4 without gain: rows walked with
-// 32-bit indices (no 64-bit divisions per item): 118 us; one pixel per thread with ONE contiguous 12- / 16-byte store per lane: 162 / 174 us (the byte loads cost more
-// than the coalesced stores save).  0.1 ms of a 131 ms step: left here.
+// W % 4 == 0: one thread = 4 consecutive output pixels of a row = 12 source bytes (three aligned dwords, mirrored or not).  A block walks image rows:
+// its 256 threads are RPB = 256 / Q rows of Q = W / 4 quads (224 wide: 4 rows of 56), 32-bit indices, one division per thread per row.
+// History (512 rows of 224 x 224, c_out = 3, one MI355X): the first version indexed byte / float ARRAYS under `fl ? x[a] : x[b]`; the compiler selected the
+// INDEX and then indexed the register array dynamically -- a 130-deep compare / select chain, 883 instructions per 4 pixels, bound by the vector ALU:
+// 111 us = 3.4 TB/s.  One pixel per thread with one contiguous store per lane: 162 us (byte loads).  Named scalars + bit-select + this row walk: see bench.py's
+// `roofline_image_gather`.
 template <int CO>
 __global__ __launch_bounds__(256) void image_gather4_kernel(const uint8_t* __restrict__ store, const int32_t* __restrict__ slots,
                                                             const uint8_t* __restrict__ flip, int n, int H, int W,
@@ -26,35 +28,42 @@ __global__ __launch_bounds__(256) void image_gather4_kernel(const uint8_t* __res
   lut[threadIdx.x] = __fdiv_rn((float)threadIdx.x, 255.0f);
   __syncthreads();
   const int Q = W >> 2;
-  const int64_t total = (int64_t)n * H * Q;
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-    const int q = (int)(t % Q); int64_t r = t / Q;
-    const int h = (int)(r % H); const int i = (int)(r / H);
+  const int RPB = Q >= 256 ? 1 : 256 / Q;                     // rows per block pass
+  const int rib = (int)threadIdx.x / Q, q0 = (int)threadIdx.x - rib * Q;
+  const int rows = n * H;
+  if (rib >= RPB) return;                                     // (after the barrier: the idle tail of the block)
+  for (int row = blockIdx.x * RPB + rib; row < rows; row += gridDim.x * RPB) {
+    const int i = row / H, h = row - i * H;
     const int64_t slot = slots[i];
     const bool fl = flip != nullptr && flip[i] != 0;
-    const int src = fl ? W - 4 - 4 * q : 4 * q;
-    uint32_t w0 = 0u, w1 = 0u, w2 = 0u;                      // a slot outside the store reads as a black image
-    if (slot >= 0 && slot < n_slots) {
-      const uint32_t* p = (const uint32_t*)(store + ((slot * H + h) * (int64_t)W + src) * 3);
-      w0 = p[0]; w1 = p[1]; w2 = p[2];
-    }
-    uint8_t b[12];
+    const bool ok = slot >= 0 && slot < n_slots;              // a slot outside the store reads as a black image
+    const uint8_t* srow = store + (ok ? (slot * H + h) * (int64_t)W * 3 : 0);
+    float* orow = out + (int64_t)row * W * CO;
+    const unsigned m = fl ? 0xffffffffu : 0u;
+    for (int q = q0; q < Q; q += 256) {                       // (Q > 256: images wider than 1024 pixels)
+      const uint32_t* p = (const uint32_t*)(srow + (fl ? W - 4 - 4 * q : 4 * q) * 3);
+      const uint32_t w0 = ok ? p[0] : 0u, w1 = ok ? p[1] : 0u, w2 = ok ? p[2] : 0u;
+      const float a0 = lut[w0 & 255u], a1 = lut[(w0 >> 8) & 255u], a2 = lut[(w0 >> 16) & 255u];       // source pixel 0
+      const float b0 = lut[w0 >> 24], b1 = lut[w1 & 255u], b2 = lut[(w1 >> 8) & 255u];                // source pixel 1
+      const float c0 = lut[(w1 >> 16) & 255u], c1 = lut[w1 >> 24], c2 = lut[w2 & 255u];               // source pixel 2
+      const float d0 = lut[(w2 >> 8) & 255u], d1 = lut[(w2 >> 16) & 255u], d2 = lut[w2 >> 24];        // source pixel 3
+      // mirrored: output pixel j is source pixel 3 - j (one v_bfi per value)
+#define LEC_SEL(x, y) __uint_as_float((__float_as_uint(x) & m) | (__float_as_uint(y) & ~m))
+      float f[4 * CO];
+      f[0 * CO + 0] = LEC_SEL(d0, a0); f[0 * CO + 1] = LEC_SEL(d1, a1); f[0 * CO + 2] = LEC_SEL(d2, a2);
+      f[1 * CO + 0] = LEC_SEL(c0, b0); f[1 * CO + 1] = LEC_SEL(c1, b1); f[1 * CO + 2] = LEC_SEL(c2, b2);
+      f[2 * CO + 0] = LEC_SEL(b0, c0); f[2 * CO + 1] = LEC_SEL(b1, c1); f[2 * CO + 2] = LEC_SEL(b2, c2);
+      f[3 * CO + 0] = LEC_SEL(a0, d0); f[3 * CO + 1] = LEC_SEL(a1, d1); f[3 * CO + 2] = LEC_SEL(a2, d2);
+#undef LEC_SEL
+      if (CO == 4) { f[3] = 0.0f; f[7] = 0.0f; f[11] = 0.0f; f[15] = 0.0f; }
+      if32x4* o = (if32x4*)(orow + 4 * q * CO);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { b[k] = (w0 >> (8 * k)) & 255u; b[4 + k] = (w1 >> (8 * k)) & 255u; b[8 + k] = (w2 >> (8 * k)) & 255u; }
-    float f[4 * CO];
+      for (int k = 0; k < CO; ++k) {
+        if32x4 v;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) f[j * CO + c] = lut[fl ? b[3 * (3 - j) + c] : b[3 * j + c]];   // constant indices + a select: registers
-      if (CO == 4) f[j * CO + 3] = 0.0f;
-    }
-    if32x4* o = (if32x4*)(out + (((int64_t)i * H + h) * W + 4 * q) * CO);
-#pragma unroll
-    for (int k = 0; k < CO; ++k) {
-      if32x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v.v[e] = f[4 * k + e];
-      o[k] = v;
+        for (int e = 0; e < 4; ++e) v.v[e] = f[4 * k + e];
+        o[k] = v;
+      }
     }
   }
 }
@@ -95,8 +104,11 @@ extern "C" int lec_image_gather_u8(const uint8_t* store, int64_t n_slots, const 
   LEC_CHECK_ARG(((uintptr_t)store & 3) == 0 && ((uintptr_t)out & 15) == 0, "image_gather_u8: store must be 4-byte and out 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const bool quad = (W % 4) == 0;
-  const int64_t total = (int64_t)n * H * (quad ? W / 4 : W);
-  int64_t nb = (total + 255) / 256; const int nblk = (int)(nb > 16384 ? 16384 : nb);
+  int64_t nb;
+  if (quad) { const int Q = W / 4, RPB = Q >= 256 ? 1 : 256 / Q; nb = ((int64_t)n * H + RPB - 1) / RPB; }   // one pass of a block = RPB image rows
+  else nb = ((int64_t)n * H * W + 255) / 256;
+  LEC_CHECK_ARG((int64_t)n * H < (1ll << 31), "image_gather_u8: n * H must stay below 2^31");
+  const int nblk = (int)(nb > 16384 ? 16384 : nb);
   if (quad) {
     if (c_out == 4) hipLaunchKernelGGL((image_gather4_kernel<4>), dim3(nblk), dim3(256), 0, st, store, slots, flip, n, H, W, n_slots, out);
     else            hipLaunchKernelGGL((image_gather4_kernel<3>), dim3(nblk), dim3(256), 0, st, store, slots, flip, n, H, W, n_slots, out);
