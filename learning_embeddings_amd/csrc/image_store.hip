@@ -18,8 +18,9 @@ struct alignas(16) if32x4 { float v[4]; };
 // its 256 threads are RPB = 256 / Q rows of Q = W / 4 quads (224 wide: 4 rows of 56), 32-bit indices, one division per thread per row.
 // History (512 rows of 224 x 224, c_out = 3, one MI355X): the first version indexed byte / float ARRAYS under `fl ? x[a] : x[b]`; the compiler selected the
 // INDEX and then indexed the register array dynamically -- a 130-deep compare / select chain, 883 instructions per 4 pixels, bound by the vector ALU:
-// 111 us = 3.4 TB/s.  One pixel per thread with one contiguous store per lane: 162 us (byte loads).  Named scalars + bit-select + this row walk: see bench.py's
-// `roofline_image_gather`.
+// 111 us = 3.4 TB/s.  One pixel per thread with one contiguous store per lane: 162 us (byte loads).  Named scalars + bit-select + this row walk: 115 us (so it
+// was not the ALU alone); + ONE 12-byte load per lane and a grid of exactly one pass per block: 97.5 us = 3.95 TB/s (c_out = 4: 149.5 us).  A plain fill
+// of the same tensor runs at 6.9 TB/s on this chip and a copy at 5.3: the 48- / 64-byte lane stride of the stores is what is left.
 template <int CO>
 __global__ __launch_bounds__(256) void image_gather4_kernel(const uint8_t* __restrict__ store, const int32_t* __restrict__ slots,
                                                             const uint8_t* __restrict__ flip, int n, int H, int W,
@@ -41,8 +42,9 @@ __global__ __launch_bounds__(256) void image_gather4_kernel(const uint8_t* __res
     float* orow = out + (int64_t)row * W * CO;
     const unsigned m = fl ? 0xffffffffu : 0u;
     for (int q = q0; q < Q; q += 256) {                       // (Q > 256: images wider than 1024 pixels)
-      const uint32_t* p = (const uint32_t*)(srow + (fl ? W - 4 - 4 * q : 4 * q) * 3);
-      const uint32_t w0 = ok ? p[0] : 0u, w1 = ok ? p[1] : 0u, w2 = ok ? p[2] : 0u;
+      uint3 w = make_uint3(0u, 0u, 0u);
+      if (ok) w = *(const uint3*)(srow + (fl ? W - 4 - 4 * q : 4 * q) * 3);        // one 12-byte load per lane: a wave reads 768 contiguous bytes
+      const uint32_t w0 = w.x, w1 = w.y, w2 = w.z;
       const float a0 = lut[w0 & 255u], a1 = lut[(w0 >> 8) & 255u], a2 = lut[(w0 >> 16) & 255u];       // source pixel 0
       const float b0 = lut[w0 >> 24], b1 = lut[w1 & 255u], b2 = lut[(w1 >> 8) & 255u];                // source pixel 1
       const float c0 = lut[(w1 >> 16) & 255u], c1 = lut[w1 >> 24], c2 = lut[w2 & 255u];               // source pixel 2
@@ -108,7 +110,7 @@ extern "C" int lec_image_gather_u8(const uint8_t* store, int64_t n_slots, const 
   if (quad) { const int Q = W / 4, RPB = Q >= 256 ? 1 : 256 / Q; nb = ((int64_t)n * H + RPB - 1) / RPB; }   // one pass of a block = RPB image rows
   else nb = ((int64_t)n * H * W + 255) / 256;
   LEC_CHECK_ARG((int64_t)n * H < (1ll << 31), "image_gather_u8: n * H must stay below 2^31");
-  const int nblk = (int)(nb > 16384 ? 16384 : nb);
+  const int nblk = (int)(nb > (1 << 20) ? (1 << 20) : nb);          // one pass per block whenever possible: no ragged last round
   if (quad) {
     if (c_out == 4) hipLaunchKernelGGL((image_gather4_kernel<4>), dim3(nblk), dim3(256), 0, st, store, slots, flip, n, H, W, n_slots, out);
     else            hipLaunchKernelGGL((image_gather4_kernel<3>), dim3(nblk), dim3(256), 0, st, store, slots, flip, n, H, W, n_slots, out);
