@@ -189,7 +189,10 @@ __global__ __launch_bounds__(kBnThreads) LEC_BN_REGS void bn_stats_kernel(const 
 // Small blocks on purpose: these kernels are a few microseconds of latency-bound work that must find a free slot on a
 // GPU whose CUs are full of weight-gradient workgroups from the second stream; a 1024-thread block waited 30-60 us
 // for one CU to drain (rocprof, profiles/r01_*_final.md), a 4-wave block is placed at once.
-constexpr int kFinCh = 8, kFinSplit = 32, kFinThreads = kFinCh * kFinSplit;
+#ifndef LEC_BN_FIN_SPLIT
+#define LEC_BN_FIN_SPLIT 32
+#endif
+constexpr int kFinCh = 8, kFinSplit = LEC_BN_FIN_SPLIT, kFinThreads = kFinCh * kFinSplit;
 __device__ __forceinline__ void reduce_partials_256(const float* __restrict__ part, int nblk, int C, int c, int split,
                                                     double& s, double& q) {
   __shared__ double sh[2][kFinSplit][kFinCh + 1];
