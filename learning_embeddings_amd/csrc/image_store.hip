@@ -20,7 +20,9 @@ struct alignas(16) if32x4 { float v[4]; };
 // INDEX and then indexed the register array dynamically -- a 130-deep compare / select chain, 883 instructions per 4 pixels, bound by the vector ALU:
 // 111 us = 3.4 TB/s.  One pixel per thread with one contiguous store per lane: 162 us (byte loads).  Named scalars + bit-select + this row walk: 115 us (so it
 // was not the ALU alone); + ONE 12-byte load per lane and a grid of exactly one pass per block: 97.5 us = 3.95 TB/s (c_out = 4: 149.5 us).  A plain fill
-// of the same tensor runs at 6.9 TB/s on this chip and a copy at 5.3: the 48- / 64-byte lane stride of the stores is what is left.
+// of the same tensor runs at 6.9 TB/s on this chip and a copy at 5.3.  Two more forms measured slower and were dropped: source rows staged through LDS with
+// one contiguous 12- / 16-byte pixel store per lane (128 / 146 us: the stores' lane stride is NOT what limits the quad form), and four rows per thread with their
+// loads issued together (111 / 161 us: nor is it load latency).  What binds the remaining factor of two is not identified.
 template <int CO>
 __global__ __launch_bounds__(256) void image_gather4_kernel(const uint8_t* __restrict__ store, const int32_t* __restrict__ slots,
                                                             const uint8_t* __restrict__ flip, int n, int H, int W,
@@ -70,50 +72,6 @@ __global__ __launch_bounds__(256) void image_gather4_kernel(const uint8_t* __res
   }
 }
 
-// W % 4 == 0, RPB * W * 3 <= 12 KB: the source rows of a block pass go through LDS.  Loads: consecutive lanes fetch consecutive dwords of a source row
-// (672 bytes at W = 224); stores: consecutive lanes write consecutive PIXELS (12 or 16 bytes each), so every store instruction of a wave covers
-// contiguous memory -- the quad kernel above gives a lane 4 pixels, i.e. three or four 16-byte stores at a 48- / 64-byte lane stride.  The byte -> float
-// table and the mirror are as above (three ds_read_u8 + three table reads per pixel).
-struct if32x3 { float v[3]; };
-template <int CO>
-__global__ __launch_bounds__(256) void image_gather_lds_kernel(const uint8_t* __restrict__ store, const int32_t* __restrict__ slots,
-                                                               const uint8_t* __restrict__ flip, int n, int H, int W, int RPB,
-                                                               int64_t n_slots, float* __restrict__ out) {
-  __shared__ float lut[256];
-  __shared__ uint32_t srow[3072];                              // RPB source rows, W * 3 bytes each, packed
-  __shared__ int rowflip[16];
-  const int tid = threadIdx.x;
-  lut[tid] = __fdiv_rn((float)tid, 255.0f);
-  const int rows = n * H, DW = (W * 3) >> 2;                   // dwords per source row
-  for (int row0 = blockIdx.x * RPB; row0 < rows; row0 += gridDim.x * RPB) {
-    const int nr = min(RPB, rows - row0);
-    __syncthreads();                                            // (the table; the previous pass's readers)
-    for (int d = tid; d < nr * DW; d += 256) {
-      const int r = d / DW, dw = d - r * DW;
-      const int row = row0 + r, i = row / H, h = row - i * H;
-      const int64_t slot = slots[i];
-      uint32_t v = 0u;                                          // a slot outside the store reads as a black image
-      if (slot >= 0 && slot < n_slots) v = ((const uint32_t*)(store + (slot * H + h) * (int64_t)W * 3))[dw];
-      srow[d] = v;
-      if (dw == 0) rowflip[r] = (flip != nullptr && flip[i] != 0) ? 1 : 0;
-    }
-    __syncthreads();
-    const uint8_t* sb = (const uint8_t*)srow;
-    float* obase = out + (int64_t)row0 * W * CO;
-    int r = 0, w = tid;
-    while (w >= W) { w -= W; ++r; }
-    for (int pix = tid; pix < nr * W; pix += 256) {
-      const int sw = rowflip[r] ? W - 1 - w : w;
-      const uint8_t* p = sb + (r * W + sw) * 3;
-      const float c0 = lut[p[0]], c1 = lut[p[1]], c2 = lut[p[2]];
-      if (CO == 4) { if32x4 v; v.v[0] = c0; v.v[1] = c1; v.v[2] = c2; v.v[3] = 0.f; *(if32x4*)(obase + (int64_t)pix * 4) = v; }
-      else { if32x3 v; v.v[0] = c0; v.v[1] = c1; v.v[2] = c2; *(if32x3*)(obase + (int64_t)pix * 3) = v; }
-      w += 256;
-      while (w >= W) { w -= W; ++r; }
-    }
-  }
-}
-
 // any W: one thread per output pixel
 template <int CO>
 __global__ __launch_bounds__(256) void image_gather1_kernel(const uint8_t* __restrict__ store, const int32_t* __restrict__ slots,
@@ -155,15 +113,7 @@ extern "C" int lec_image_gather_u8(const uint8_t* store, int64_t n_slots, const 
   else nb = ((int64_t)n * H * W + 255) / 256;
   LEC_CHECK_ARG((int64_t)n * H < (1ll << 31), "image_gather_u8: n * H must stay below 2^31");
   const int nblk = (int)(nb > (1 << 20) ? (1 << 20) : nb);          // one pass per block whenever possible: no ragged last round
-  static const int use_lds = [] { const char* e = getenv("LEC_IMAGE_GATHER_LDS"); return e ? atoi(e) : 1; }();
-  if (quad && use_lds && W * 3 <= 12288) {
-    int RPB = 12288 / (W * 3); if (RPB > 16) RPB = 16;
-    while (RPB > 1 && RPB * W > 1024) --RPB;                   // ~4 pixels per thread per pass
-    const int64_t nb2 = ((int64_t)n * H + RPB - 1) / RPB;
-    const int nblk2 = (int)(nb2 > (1 << 20) ? (1 << 20) : nb2);
-    if (c_out == 4) hipLaunchKernelGGL((image_gather_lds_kernel<4>), dim3(nblk2), dim3(256), 0, st, store, slots, flip, n, H, W, RPB, n_slots, out);
-    else            hipLaunchKernelGGL((image_gather_lds_kernel<3>), dim3(nblk2), dim3(256), 0, st, store, slots, flip, n, H, W, RPB, n_slots, out);
-  } else if (quad) {
+  if (quad) {
     if (c_out == 4) hipLaunchKernelGGL((image_gather4_kernel<4>), dim3(nblk), dim3(256), 0, st, store, slots, flip, n, H, W, n_slots, out);
     else            hipLaunchKernelGGL((image_gather4_kernel<3>), dim3(nblk), dim3(256), 0, st, store, slots, flip, n, H, W, n_slots, out);
   } else {
