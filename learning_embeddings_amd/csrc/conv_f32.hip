@@ -881,13 +881,14 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_sk_kernel(const fl
 // SH ("shifted dense", round 4): a stride-1 layer whose output grid equals its input grid (3x3 / pad 1) and whose column tile lies inside ONE tap.
 // Then dW[co][tap][ci] = sum_m dY[m][co] * X[m + shift(tap)][ci] over the pixels m whose tap lands inside the image: the B operand is the DENSE
 // loader on x at a constant byte offset (no per-piece pixel decode, no bounds test, no scalar work at all; rows that fall off the tensor are the
-// buffer's range check), and the pixels whose tap leaves the image are zeroed on the A side -- the dY row -- by ONE table lookup per piece: a
-// 16-bit tap-validity mask per pixel position of an image, built once per workgroup in LDS, walked incrementally (pix += WBK, one conditional
-// subtract).  With it the tile can follow the layer (128 x 128 for Cin = 128: no half-empty fifth 256-column tile) and the kernel is the dense
+// buffer's range check), and the pixels whose tap leaves the image are dropped on the A side -- the dY row -- by ONE table lookup per piece: a
+// 16-bit mask of the taps that leave the image per pixel position, built once per workgroup in LDS; the position walk is scalar, the entry is read
+// one chunk ahead and lands in bit 31 of the load's OFFSET (out of range: the load returns zeros) -- three vector instructions per piece where
+// selects on the loaded data and a per-lane walk took eleven (1.11 -> see profiles/r04_conv_f32_pmc.md).  With it the tile can follow the layer (128 x 128 for Cin = 128: no half-empty fifth 256-column tile) and the kernel is the dense
 // split-K weight gradient, which holds the matrix pipe 83 % busy where the gathered form holds it 76 %.
 // SH = 2: the same for STRIDE-2 layers whose input grid is exactly twice the output grid (3x3 / pad 1 and the 1x1 downsample layers of ResNet):
 // the source pixel of output pixel m = (n, ho, wo) under tap (r, s) is 4 m - 2 wo + const -- affine in m but for the column wo, which every B piece
-// walks incrementally like the A pieces walk their pixel position (wo += WBK mod Wo, one conditional subtract).
+// reads from a second wrapped table ((i mod Wo) * bytes) at "scalar column of the chunk's first row + own row", one chunk ahead like the A side.
 template <int WM, int WN, int TM, int TN, int WBK, bool DENSE, bool XF = false, bool SM = false, int SH = 0>
 __global__ __launch_bounds__(kCfThreads, (XF && WM <= 2 && TM * TN == 4) ? LEC_WG_XF_BLOCKS : 2) void conv_f32_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                        float* __restrict__ dw, WgGeo g, const float* __restrict__ xsrc = nullptr,
@@ -909,17 +910,24 @@ __global__ __launch_bounds__(kCfThreads, (XF && WM <= 2 && TM * TN == 4) ? LEC_W
   const int nchunks_all = (g.Mpix + WBK - 1) / WBK;
   const rsrc_t rs_dy = make_rsrc(dy, g.dy_bytes), rs_x = make_rsrc(x, g.x_bytes);
   const rsrc_t rs_x2 = make_rsrc(XF ? xsrc : dy, g.dy_bytes);
-  unsigned short* vtab = (unsigned short*)(smem + 2 * (SA + SB));      // SH: tap-validity mask of every pixel position of an image
+  // SH tables in LDS, built once per workgroup, both with WBK wrapped entries at the end so that "position of the chunk's first row (scalar) + row of
+  // the piece (per-thread constant)" indexes them without a modulo: vtab[i] = taps that LEAVE the image at pixel position i mod HoWo (bit t = tap t);
+  // SH = 2: wtab[i] = (i mod Wo) * 2 Cin * 4, the bytes "- 2 wo" takes off the source offset
+  unsigned short* vtab = (unsigned short*)(smem + 2 * (SA + SB));
+  int* wtab = (int*)(vtab + ((g.HoWo + WBK + 1) & ~1));
   if (SH) {
-    for (int i = tid; i < g.HoWo; i += kCfThreads) {
-      const int ho = fdiv(i, g.dWo), wo = i - ho * g.Wo;
+    for (int i = tid; i < g.HoWo + WBK; i += kCfThreads) {
+      const int p = i < g.HoWo ? i : i - g.HoWo;
+      const int ho = fdiv(p, g.dWo), wo = p - ho * g.Wo;
       unsigned m = 0;
       for (int tp = 0; tp < g.RS; ++tp) {
         const int r = fdiv(tp, g.dS), s_ = tp - r * g.S;
-        if ((unsigned)(ho * g.stride + r - g.pad) < (unsigned)g.H && (unsigned)(wo * g.stride + s_ - g.pad) < (unsigned)g.W) m |= 1u << tp;
+        if (!((unsigned)(ho * g.stride + r - g.pad) < (unsigned)g.H && (unsigned)(wo * g.stride + s_ - g.pad) < (unsigned)g.W)) m |= 1u << tp;
       }
       vtab[i] = (unsigned short)m;
     }
+    if (SH == 2)
+      for (int i = tid; i < g.Wo + WBK; i += kCfThreads) wtab[i] = (i - fdiv(i, g.dWo) * g.Wo) * 2 * g.Cin * 4;
     __syncthreads();
   }
   // work items = (output tile, K split); a workgroup walks its share when LEC_WGRAD_WGS caps the grid.  (Measured on the fp32 step:
@@ -970,24 +978,25 @@ __global__ __launch_bounds__(kCfThreads, (XF && WM <= 2 && TM * TN == 4) ? LEC_W
     const int v = tid + kCfThreads * u; const int kr = v / PB, jq = v - kr * PB; const int jj = j0 + 4 * jq;
     boff[u] = jj < g.Ng ? (unsigned)((SH == 2 ? 4 * kr : kr) * g.Cin + (SH ? (jj & (g.Cin - 1)) : jj)) * 4u : kOob;
   }
-  int apix[SH ? NA : 1]; unsigned aval[SH ? NA : 1];           // SH: pixel position (inside its image) of each A piece's row in the NEXT chunk to load
-  int bwo[SH == 2 ? NB : 1];                                    // SH = 2: output column wo of each B piece's row in the NEXT chunk to load
-  if (SH) {
-#pragma unroll
-    for (int u = 0; u < NA; ++u) {
-      const int m0 = ch_lo * WBK + (tid + kCfThreads * u) / PA;
-      apix[u] = m0 - fdiv(m0, g.dHW) * g.HoWo;
-    }
-  }
-  if (SH == 2) {
-#pragma unroll
-    for (int u = 0; u < NB; ++u) {
-      const int m0 = ch_lo * WBK + (tid + kCfThreads * u) / PB;
-      bwo[u] = m0 - fdiv(m0, g.dWo) * g.Wo;
-    }
-  }
+  // SH: the walk over pixel positions is SCALAR (position of the first row of the next chunk whose table entries get read: spix inside its image, swo
+  // inside its output row); a piece adds its own row (constant) and reads the wrapped table ONE CHUNK AHEAD of the load that uses the entry, so the
+  // LDS latency sits behind a whole chunk of MFMAs.  aval: invalid-tap bits of each A piece's row; bdel: "2 wo" bytes of each B piece's row.
+  unsigned aval[SH ? NA : 1]; int bdel[SH == 2 ? NB : 1];
+  int spix = 0, swo = 0;
   const int wstep = SH == 2 ? WBK - fdiv(WBK, g.dWo) * g.Wo : 0;  // WBK mod Wo
-  const int k2 = SH == 2 ? 2 * g.Cin * 4 : 0;                   // bytes per unit of wo in "4 m - 2 wo"
+  if (SH) {
+    const int m0 = ch_lo * WBK;
+    spix = m0 - fdiv(m0, g.dHW) * g.HoWo;
+#pragma unroll
+    for (int u = 0; u < NA; ++u) aval[u] = (unsigned)vtab[spix + (tid + kCfThreads * u) / PA];
+    spix += WBK; spix -= spix >= g.HoWo ? g.HoWo : 0;
+    if (SH == 2) {
+      swo = m0 - fdiv(m0, g.dWo) * g.Wo;
+#pragma unroll
+      for (int u = 0; u < NB; ++u) bdel[u] = wtab[swo + (tid + kCfThreads * u) / PB];
+      swo += wstep; swo -= swo >= g.Wo ? g.Wo : 0;
+    }
+  }
   const int j = j0 + 4 * lane;
   const int tapL = j >> g.lgCin, ciL = j & (g.Cin - 1);
   const int rL = fdiv(tapL, g.dS);
@@ -1019,29 +1028,31 @@ __global__ __launch_bounds__(kCfThreads, (XF && WM <= 2 && TM * TN == 4) ? LEC_W
   auto load_chunk = [&](int ch) {
     const int mbase = ch * WBK;
     const unsigned abase = (unsigned)(mbase * g.Cout) * 4u;
+    if (SH) {                                                   // a dY row whose tap leaves the image: the load itself returns zeros (offset bit 31 = out of range)
 #pragma unroll
-    for (int u = 0; u < NA; ++u) ra[u] = bload4(rs_dy, aoff[u] + abase);
+      for (int u = 0; u < NA; ++u) ra[u] = bload4(rs_dy, (aoff[u] + abase) | (((aval[u] >> tapT) & 1u) << 31));
+#pragma unroll
+      for (int u = 0; u < NA; ++u) aval[u] = (unsigned)vtab[spix + (tid + kCfThreads * u) / PA];     // chunks are loaded in order: the entries of the NEXT call
+      spix += WBK; spix -= spix >= g.HoWo ? g.HoWo : 0;
+    } else {
+#pragma unroll
+      for (int u = 0; u < NA; ++u) ra[u] = bload4(rs_dy, aoff[u] + abase);
+    }
     if (XF) {
 #pragma unroll
       for (int u = 0; u < NA; ++u) rx[u] = bload4(rs_x2, aoff[u] + abase);
-    }
-    if (SH) {                                                   // chunks are loaded in order: the walk advances by one chunk per call
-#pragma unroll
-      for (int u = 0; u < NA; ++u) {
-        aval[u] = (unsigned)vtab[apix[u]];
-        apix[u] += WBK; apix[u] -= apix[u] >= g.HoWo ? g.HoWo : 0;
-      }
     }
     if (DENSE) {
       const unsigned bbase = (unsigned)((SH == 2 ? 4 * mbase : mbase) * g.Cin) * 4u + (unsigned)shiftB;
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
-        if (SH == 2) {
-          rb[u] = bload4(rs_x, boff[u] + bbase - (unsigned)(bwo[u] * k2));
-          bwo[u] += wstep; bwo[u] -= bwo[u] >= g.Wo ? g.Wo : 0;
-        } else {
-          rb[u] = bload4(rs_x, boff[u] + bbase);
-        }
+        if (SH == 2) rb[u] = bload4(rs_x, boff[u] + bbase - (unsigned)bdel[u]);
+        else rb[u] = bload4(rs_x, boff[u] + bbase);
+      }
+      if (SH == 2) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) bdel[u] = wtab[swo + (tid + kCfThreads * u) / PB];
+        swo += wstep; swo -= swo >= g.Wo ? g.Wo : 0;
       }
     } else {
 #pragma unroll
@@ -1072,14 +1083,6 @@ __global__ __launch_bounds__(kCfThreads, (XF && WM <= 2 && TM * TN == 4) ? LEC_W
   };
   auto store_chunk = [&](int buf) {
     char* base = (char*)smem + buf * (SA + SB) * 4;
-    if (SH) {                                                   // the dY rows of pixels whose tap leaves the image: zero
-#pragma unroll
-      for (int u = 0; u < NA; ++u) {
-        const bool ok = (aval[u] >> tapT) & 1u;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ra[u][e] = ok ? ra[u][e] : 0.f;
-      }
-    }
     if (XF) {                                                   // (rows past Mpix become cD: their X rows are zero, the products vanish)
 #pragma unroll
       for (int u = 0; u < NA; ++u)
@@ -1454,7 +1457,7 @@ static int conv_f32_wgrad_impl(const float* dy, const float* x, int N, int H, in
   g.chunks_per_split = (nchunks + split - 1) / split;
   split = (nchunks + g.chunks_per_split - 1) / g.chunks_per_split;
   g.tiles = tiles; g.split = split;
-  size_t lds = (size_t)2 * WBK * (BM + BN) * 4 + (shifted ? (size_t)((g.HoWo * 2 + 15) / 16 * 16) : 0);
+  size_t lds = (size_t)2 * WBK * (BM + BN) * 4 + (shifted ? (size_t)(((g.HoWo + WBK + 1) * 2 + (g.Wo + WBK) * 4 + 15) / 16 * 16) : 0);
   // Residency knob (LEC_WGRAD_LDS_PAD = extra LDS bytes): the tiles need 32 - 40 KB, so four workgroups share a CU and the main stream's
   // HBM-bound BatchNorm kernels (this kernel runs on the side stream) find no registers to land on.  14336 extra bytes keep it at two workgroups
   // per CU: BatchNorm 61.6 -> 52.2 ms inside the step, these kernels 44 -> 47.5 ms, the step 157.5 -> 155.8 ms (same-box A/B, 1 %); left off by
