@@ -126,391 +126,20 @@ template <bool B_KC, int WM, int WN, int TM, int TN, bool STATS, bool TAPV, int 
 __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
                                                                      float* __restrict__ dst, ActGeo g, float* __restrict__ part,
                                                                      ActFuse fz) {
-  constexpr bool XF = (FUSE & 1) != 0, FOLD = (FUSE & 2) != 0, AFF = (FUSE & 4) != 0;
-  static_assert(!AFF || FUSE == 4, "the affine epilogue stands alone");
-  // PF2 (`make EXTRA=-DLEC_CF_PF2=1`): operands are fetched TWO chunks ahead into two register sets (the plain kernels have the registers: 2 waves
-  // per SIMD either way).  MEASURED (round 3, same box, 512 images, us forward one ahead / two ahead): 3x3 128 -> 128 @28 973 / 945, 256 -> 256 @14
-  // 1016 / 966, 512 -> 512 @7 1124 / 1087, 1x1 1024 -> 256 @14 494 / 462; short K loses (the two chunks fetched past the end are a large share:
-  // 1x1 64 -> 256 647 / 696; data gradient 256 -> 64 @56 611 / 713).  Selected per launch for the forward of layers with K >= 1024 it takes 1 ms
-  // off the convolutions' isolated time and nothing measurable off the step (130.7 - 131.7 ms either way): off.
-  // Also tried (round 3): waves 0-3 of an 8-wave workgroup as consumers (fragment reads, MFMAs, epilogue) and waves 4-7 as producers (row decode,
-  // loads two chunks ahead, LDS stores), each role its own instantiation of the tile body (105 / 98 registers, four waves per SIMD): the plain data
-  // gradients gain 3 - 5 % (3x3 256 -> 256 @14 1021 -> 966 us, 128 -> 128 @28 959 -> 921), the forward nothing (979 / 981); but most data gradients
-  // of the step run the fold epilogue, which the split does not serve, and hosting the tile body in a generic lambda cost that epilogue half its
-  // speed (conv1 of layer1: 1236 -> 2439 us; fewer registers, serialized loads).  Not kept.
-  constexpr bool PF2 = LEC_CF_PF2 != 0 && FUSE == 0 && !TAPV;
-  constexpr int NSET = PF2 ? 2 : 1;
-  static_assert(!(XF && TAPV) && !(FOLD && STATS), "fused modes: one tap per chunk; one statistics epilogue at a time");
-  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  static_assert(WM * WN == 4, "four waves per workgroup");
-  constexpr int NA = BM * kCfKQ / kCfThreads;                 // 16-byte pieces of the A tile per thread
-  constexpr int NB = BN * kCfKQ / kCfThreads;                 // ... of the B tile (same count in either orientation)
-  constexpr int SA = BM * kCfLdk;
-  constexpr int SB = B_KC ? BN * kCfLdk : kCfBK * BN;
-  constexpr int PR = BN / 4;                                  // 16-byte pieces per k row of a k-slow B tile
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave / WN) * 32 * TM, wn0 = (wave % WN) * 32 * TN;
-  const int n0 = blockIdx.y * BN;
-  const int nchunks = (g.Kg + kCfBK - 1) / kCfBK;
-  const int mtiles = (g.Mg + BM - 1) / BM;
-  const int kqA = tid & (kCfKQ - 1);                          // this thread's 16-byte column of a k-contiguous tile
-  const int rowA = tid / kCfKQ;                               // ... and its first row (further rows: + kCfRP u)
-  const rsrc_t rs_src = make_rsrc(src, g.src_bytes), rs_wgt = make_rsrc(wgt, g.wgt_bytes), rs_dst = make_rsrc(dst, g.dst_bytes);
-  const rsrc_t rs_x2 = make_rsrc(XF ? fz.xsrc : src, g.src_bytes), rs_coef = make_rsrc(XF ? fz.coef : src, XF ? (uint32_t)(3 * g.Cs * 4) : 0u);
-  float st_s[TN], st_q[TN];
-#pragma unroll
-  for (int jt = 0; jt < TN; ++jt) { st_s[jt] = 0.f; st_q[jt] = 0.f; }
-  // per-piece constants of the B tile (they do not depend on the m-tile): byte offset inside the weights, kOob past the channels
-  const int rsc = g.RS * g.Cin;
-  unsigned wB[NB];
-#pragma unroll
-  for (int u = 0; u < NB; ++u) {
-    if (B_KC) { const int co = n0 + rowA + kCfRP * u; wB[u] = co < g.Cd ? (unsigned)(co * rsc + 4 * kqA) * 4u : kOob; }
-    else { const int v_ = tid + kCfThreads * u; const int kr = v_ / PR, jq = v_ - kr * PR; const int ci = n0 + 4 * jq;
-           wB[u] = ci < g.Cd ? (unsigned)(kr * rsc + ci) * 4u : kOob; }
-  }
-  // LDS byte offsets of this thread's pieces inside a buffer
-  const unsigned ldsA = (unsigned)((rowA * kCfLdk + 4 * kqA) * 4);
-  const unsigned ldsB = (unsigned)((SA + (B_KC ? rowA * kCfLdk + 4 * kqA : tid * 4)) * 4);
-  const bool dense_dst = g.dst_st == 1;                        // destination pixel index == m (forward, stride-1 data gradient)
-  const int ntaps = g.na * g.nb;
+#include "conv_f32_act_body.inc"
+}
 
-  // (Loading the next tile's first chunk before this tile's epilogue -- so that its latency and the acknowledgement of the epilogue's stores
-  // overlap -- was built and measured: forward 38.8 -> 38.9 ms, data gradient 37.4 -> 37.4 ms over the step's layers, same box.  The second
-  // workgroup of the CU already fills a tile's prologue.)
-  // Tile walk.  Workgroup ids go round-robin over the 8 XCDs (one L2 each): with xcd_per > 0 XCD x owns the CONTIGUOUS run of m-tiles
-  // [x * xcd_per, (x + 1) * xcd_per) -- neighbouring tiles share their 3x3 halo rows and, at any moment, the 64 tiles resident on an XCD are
-  // one compact block of the input (their taps hit that XCD's L2 instead of being re-fetched through the fabric).
-  const int nslots = g.xcd_per > 0 ? 8 * g.xcd_per : mtiles;
-  for (int slot = blockIdx.x; slot < nslots; slot += gridDim.x) {
-    const int mt = g.xcd_per > 0 ? (slot & 7) * g.xcd_per + (slot >> 3) : slot;
-    if (mt >= mtiles) continue;
-    const int m0 = mt * BM;
-    // rows of the A tile this thread stages (rowA + kCfRP u): byte offset of the row's source pixel at tap offset (0, 0) and
-    // a bit per tap: the row exists and the tap's source pixel lies inside the image
-    int rowoff[NA]; unsigned tapmask[NA]; int hb[NA], wb[NA], pixn[NA];
-#pragma unroll
-    for (int u = 0; u < NA; ++u) {
-      const int m = m0 + rowA + kCfRP * u;
-      const bool live = m < g.Mg;
-      const int mm = live ? m : 0;
-      const int t2 = fdiv(mm, g.dWm); const int mw = mm - t2 * g.Wm; const int n = fdiv(t2, g.dHm); const int mh = t2 - n * g.Hm;
-      hb[u] = mh * g.sst + g.oh0; wb[u] = mw * g.sst + g.ow0; pixn[u] = live ? n * g.Hs * g.Ws : -1;
-      rowoff[u] = (((n * g.Hs + hb[u]) * g.Ws + wb[u]) << g.lgCs) * 4 + 16 * kqA;
-      unsigned msk = 0;
-      if (!TAPV) {
-        for (int t = 0; t < ntaps; ++t) {
-          const int ta = fdiv(t, g.dnb), tb = t - ta * g.nb;
-          const int hs = hb[u] + g.sg * ta, ws = wb[u] + g.sg * tb;
-          msk |= ((unsigned)hs < (unsigned)g.Hs && (unsigned)ws < (unsigned)g.Ws ? 1u : 0u) << t;
-        }
-      }
-      tapmask[u] = live ? msk : 0u;
-    }
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int it = 0; it < TM; ++it)
-#pragma unroll
-      for (int jt = 0; jt < TN; ++jt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[it][jt][r] = 0.f;
-
-    f32x4v ra[NSET][NA], rb[NSET][NB];
-    f32x4v rx[XF ? NA : 1], cfA, cfB, cfD;                      // XF: the second source's pieces and the chunk's coefficient vectors
-    unsigned cur[NA];                                           // byte offset of this thread's A pieces at channel 0 of the CURRENT tap (kOob: no such pixel)
-    int cur_tap = -1;
-    auto load_chunk = [&](int ch, const int set = 0) {
-      const int k0 = ch * kCfBK;
-      if (!TAPV) {
-        // the whole chunk lies in one tap: wave-uniform (scalar) decode; the per-row select runs once per TAP, a chunk adds a scalar
-        const int tap = k0 >> g.lgCs, c0 = k0 & (g.Cs - 1);
-        const int ta = fdiv(tap, g.dnb), tb = tap - ta * g.nb;
-        if (tap != cur_tap) {
-          cur_tap = tap;
-          const int toff = (((g.sg * ta) * g.Ws + g.sg * tb) << g.lgCs) * 4;
-          const unsigned tapbit = tap < 32 ? 1u << tap : 0u;    // (LEC_CF_UNCOND loads one chunk past the end: no such tap, all pieces out of range)
-#pragma unroll
-          for (int u = 0; u < NA; ++u) cur[u] = (tapmask[u] & tapbit) ? (unsigned)(rowoff[u] + toff) : kOob;
-        }
-        const int tw = (g.r0 + g.rstep * ta) * g.S + g.s0 + g.sstep * tb;
-        const unsigned wsc = (unsigned)(B_KC ? tw * g.Cin + c0 : c0 * rsc + tw * g.Cin) * 4u;
-        const unsigned c0b = (unsigned)c0 * 4u;
-#pragma unroll
-        for (int u = 0; u < NA; ++u) ra[set][u] = bload4(rs_src, cur[u] + c0b);         // (a poisoned offset stays out of range: c0b < 2^14)
-        if (XF) {
-#pragma unroll
-          for (int u = 0; u < NA; ++u) rx[u] = bload4(rs_x2, cur[u] + c0b);
-          const unsigned cb = c0b + 16u * (unsigned)kqA, cs4 = (unsigned)g.Cs * 4u;
-          cfA = bload4(rs_coef, cb); cfB = bload4(rs_coef, cb + cs4); cfD = bload4(rs_coef, cb + 2u * cs4);
-        }
-#pragma unroll
-        for (int u = 0; u < NB; ++u) rb[set][u] = bload4(rs_wgt, wB[u] + wsc);          // (likewise: wsc < 2^30)
-        return;
-      }
-      // one tap / channel position per 16-byte piece (the stem: 4 source channels, 8 taps per chunk)
-      const int kA = k0 + 4 * kqA;
-      const int tapA = kA >> g.lgCs, cA = kA & (g.Cs - 1);
-      const int ta = fdiv(tapA, g.dnb), tb = tapA - ta * g.nb;
-      const int dh = g.sg * ta, dw = g.sg * tb;
-      const bool tap_ok = tapA < ntaps;
-#pragma unroll
-      for (int u = 0; u < NA; ++u) {
-        const int hs = hb[u] + dh, ws = wb[u] + dw;
-        const bool ok = tap_ok && pixn[u] >= 0 && (unsigned)hs < (unsigned)g.Hs && (unsigned)ws < (unsigned)g.Ws;
-        ra[set][u] = bload4(rs_src, ok ? (unsigned)(((pixn[u] + hs * g.Ws + ws) << g.lgCs) + cA) * 4u : kOob);
-      }
-      if (B_KC) {
-        const int tw = (g.r0 + g.rstep * ta) * g.S + g.s0 + g.sstep * tb;
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-          const int co = n0 + rowA + kCfRP * u;
-          rb[set][u] = bload4(rs_wgt, (tap_ok && co < g.Cd) ? (unsigned)((co * g.RS + tw) * g.Cin + cA) * 4u : kOob);
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-          const int v_ = tid + kCfThreads * u;
-          const int kr = v_ / PR, jq = v_ - kr * PR;
-          const int kB = k0 + kr;
-          const int tapB = kB >> g.lgCs, cB = kB & (g.Cs - 1);
-          const int ta2 = fdiv(tapB, g.dnb), tb2 = tapB - ta2 * g.nb;
-          const int tw2 = (g.r0 + g.rstep * ta2) * g.S + g.s0 + g.sstep * tb2;
-          const int ci = n0 + 4 * jq;
-          rb[set][u] = bload4(rs_wgt, (tapB < ntaps && ci < g.Cd) ? (unsigned)((cB * g.RS + tw2) * g.Cin + ci) * 4u : kOob);
-        }
-      }
-    };
-    auto store_chunk = [&](int buf, const int set = 0) {
-      char* base = (char*)smem + buf * (SA + SB) * 4;
-      if (XF) {
-#pragma unroll
-        for (int u = 0; u < NA; ++u)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) ra[0][u][e] = __builtin_fmaf(cfA[e], ra[0][u][e], __builtin_fmaf(cfB[e], rx[u][e], cfD[e]));
-      }
-#pragma unroll
-      for (int u = 0; u < NA; ++u) *(f32x4v*)(base + ldsA + u * kCfRP * kCfLdk * 4) = ra[set][u];
-#pragma unroll
-      for (int u = 0; u < NB; ++u) *(f32x4v*)(base + ldsB + u * (B_KC ? kCfRP * kCfLdk * 4 : kCfThreads * 16)) = rb[set][u];
-    };
-
-    if (PF2 && nchunks > 0) {
-      // two chunks in flight: a load is issued at the start of one iteration and consumed at the END of the next (two MFMA blocks, ~8 000
-      // cycles of slack instead of ~4 000).  Chunks past the end fall out of every buffer's range (or fetch weights nobody multiplies) and
-      // their LDS images are never read back: no branch around a load or a store.
-      const float* s0 = smem; const float* s1 = smem + (SA + SB);
-      load_chunk(0, 0); load_chunk(1, 1);
-      __syncthreads();                                          // the previous m-tile's reads of buffer 0 are done
-      store_chunk(0, 0);
-      __syncthreads();
-      for (int ch = 0; ch < nchunks; ch += 2) {
-        load_chunk(ch + 2, 0);
-        mma_chunk<true, B_KC, 0, BN, TM, TN>(s0, s0 + SA, wm0, wn0, lane, acc);
-        store_chunk(1, 1);
-        __syncthreads();
-        if (ch + 1 >= nchunks) break;
-        load_chunk(ch + 3, 1);
-        mma_chunk<true, B_KC, 0, BN, TM, TN>(s1, s1 + SA, wm0, wn0, lane, acc);
-        store_chunk(0, 0);
-        __syncthreads();
-      }
-    } else if (nchunks > 0) {
-      load_chunk(0);
-      __syncthreads();                                          // the previous m-tile's reads of buffer 0 are done
-      store_chunk(0);
-      __syncthreads();
-      for (int ch = 0; ch < nchunks; ++ch) {
-        const int buf = ch & 1;
-        const float* sA = smem + buf * (SA + SB);
-#if LEC_CF_UNCOND
-        // no branch around the prefetch: loads, MFMAs and LDS stores of an iteration are ONE basic block the scheduler can interleave
-        // (the chunk past the end falls out of every buffer's range and is never read back).  MEASURED (round 3, `make EXTRA=-DLEC_CF_UNCOND=1`,
-        // same box): within +-3 % of the branchy form on every layer tried, either direction -- hipcc does not interleave them: off.
-        load_chunk(ch + 1);
-        mma_chunk<true, B_KC, 0, BN, TM, TN>(sA, sA + SA, wm0, wn0, lane, acc);
-        store_chunk(buf ^ 1);
-#else
-        if (ch + 1 < nchunks) load_chunk(ch + 1);               // global -> registers, under this chunk's MFMAs
-        mma_chunk<true, B_KC, 0, BN, TM, TN>(sA, sA + SA, wm0, wn0, lane, acc);
-        if (ch + 1 < nchunks) store_chunk(buf ^ 1);             // (its last readers passed the barrier one chunk ago)
-#endif
-        __syncthreads();
-      }
-    }
-
-    // epilogue: rows on the registers, 32 consecutive channels on the lanes; out-of-range rows / channels carry the kOob bit and
-    // are dropped by the buffer's range check
-    const int l31 = lane & 31, h = lane >> 5;
-    if (AFF) {
-      // y = [relu](acc * scale + shift [+ res]): bn_apply_kernel's expression (separate multiply and add); dense destination (forward)
-      const rsrc_t rs_res = make_rsrc(fz.res ? fz.res : dst, fz.res ? g.dst_bytes : 0u);
-      const bool has_res = fz.res != nullptr, relu = fz.relu != 0;
-      const unsigned rowbytes = (unsigned)g.Cd * 4u;
-      float sc[TN], sh[TN]; unsigned coffa[TN];
-#pragma unroll
-      for (int jt = 0; jt < TN; ++jt) {
-        const int c = n0 + wn0 + jt * 32 + l31; const bool okc = c < g.Cd;
-        sc[jt] = okc ? fz.scale[c] : 0.f; sh[jt] = okc ? fz.shift[c] : 0.f; coffa[jt] = okc ? (unsigned)c * 4u : kOob;
-      }
-#pragma unroll
-      for (int it = 0; it < TM; ++it) {
-#pragma unroll
-        for (int r8 = 0; r8 < 16; r8 += 8) {
-          float rv[8][TN];
-#pragma unroll
-          for (int rr = 0; rr < 8; ++rr) {
-            const int r = r8 + rr;
-            const int m = m0 + wm0 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const unsigned poff = m < g.Mg ? (unsigned)m * rowbytes : kOob;
-#pragma unroll
-            for (int jt = 0; jt < TN; ++jt)
-              rv[rr][jt] = has_res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, (int)((poff + coffa[jt]) | ((poff | coffa[jt]) & kOob)), 0, 0)) : 0.f;
-          }
-#pragma unroll
-          for (int rr = 0; rr < 8; ++rr) {
-            const int r = r8 + rr;
-            const int m = m0 + wm0 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const unsigned poff = m < g.Mg ? (unsigned)m * rowbytes : kOob;
-#pragma unroll
-            for (int jt = 0; jt < TN; ++jt) {
-              float v = acc[it][jt][r] * sc[jt] + sh[jt];
-              if (has_res) v += rv[rr][jt];
-              if (relu) v = v > 0.0f ? v : 0.0f;
-              bstore1(v, rs_dst, (poff + coffa[jt]) | ((poff | coffa[jt]) & kOob));
-            }
-          }
-        }
-      }
-    } else
-    if (FOLD) {
-      // g = mask * (acc + dres), partial sums of g and g * xhat per channel; dense destination (host-checked).  A lane's TN columns:
-      // channel c -> (mean, invstd) and the position of its ReLU bit in lec_bn_fwd_f32's mask bytes: a thread-vector of that pass holds
-      // channels 4 cv .. + 3 (bits 0-3) and Cd / 2 + 4 cv .. + 3 (bits 4-7); byte index = row * (Cd / 8) + cv.
-      const rsrc_t rs_dres = make_rsrc(fz.dres ? fz.dres : dst, fz.dres ? g.dst_bytes : 0u), rs_xbn = make_rsrc(fz.xbn, g.dst_bytes);
-      const rsrc_t rs_mask = make_rsrc(fz.mask ? (const void*)fz.mask : (const void*)dst, fz.mask ? fz.mask_bytes : 0u);
-      const bool has_mask = fz.mask != nullptr;
-      const unsigned rowbytes = (unsigned)g.Cd * 4u, cvrow = (unsigned)g.Cd >> 3;
-      float mu[TN], is[TN]; unsigned coff[TN], mcv[TN], mbit[TN];
-#pragma unroll
-      for (int jt = 0; jt < TN; ++jt) {
-        const int c = n0 + wn0 + jt * 32 + l31; const bool okc = c < g.Cd;
-        mu[jt] = okc ? fz.mean[c] : 0.f; is[jt] = okc ? fz.invstd[c] : 0.f;
-        coff[jt] = okc ? (unsigned)c * 4u : kOob;
-        const int hc = g.Cd >> 1; const int cc = c < hc ? c : c - hc;
-        mcv[jt] = (unsigned)(cc >> 2); mbit[jt] = (unsigned)((cc & 3) + (c < hc ? 0 : 4));
-      }
-#pragma unroll
-      for (int it = 0; it < TM; ++it) {
-#pragma unroll
-        for (int r8 = 0; r8 < 16; r8 += 8) {
-          float dv[8][TN], xv[8][TN]; unsigned mb[8][TN];
-#pragma unroll
-          for (int rr = 0; rr < 8; ++rr) {
-            const int r = r8 + rr;
-            const int m = m0 + wm0 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const unsigned poff = m < g.Mg ? (unsigned)m * rowbytes : kOob;
-#pragma unroll
-            for (int jt = 0; jt < TN; ++jt) {
-              const unsigned off = (poff + coff[jt]) | ((poff | coff[jt]) & kOob);
-              dv[rr][jt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dres, (int)off, 0, 0));
-              xv[rr][jt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_xbn, (int)off, 0, 0));
-              mb[rr][jt] = has_mask ? (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_mask, (int)(m < g.Mg ? (unsigned)m * cvrow + mcv[jt] : kOob), 0, 0) : 0xffu;
-            }
-          }
-#pragma unroll
-          for (int rr = 0; rr < 8; ++rr) {
-            const int r = r8 + rr;
-            const int m = m0 + wm0 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const unsigned poff = m < g.Mg ? (unsigned)m * rowbytes : kOob;
-#pragma unroll
-            for (int jt = 0; jt < TN; ++jt) {
-              float a = acc[it][jt][r] + dv[rr][jt];
-              a = ((mb[rr][jt] >> mbit[jt]) & 1u) && m < g.Mg ? a : 0.f;
-              st_s[jt] += a; st_q[jt] += a * ((xv[rr][jt] - mu[jt]) * is[jt]);
-              bstore1(a, rs_dst, (poff + coff[jt]) | ((poff | coff[jt]) & kOob));
-            }
-          }
-        }
-      }
-    } else
-    // Full tiles of a dense destination (the common case): one vector add per accumulator row, the column block as the store's immediate
-    // offset, no per-row branch.  (The general path below spent 64 uniform branches and ~6 vector instructions per row on every tile.)
-    if (dense_dst && m0 + BM <= g.Mg && n0 + BN <= g.Cd) {
-      const unsigned rowbytes = (unsigned)g.Cd * 4u;
-      const unsigned base = (unsigned)(m0 + wm0 + 4 * h) * rowbytes + (unsigned)(n0 + wn0 + l31) * 4u;
-#pragma unroll
-      for (int it = 0; it < TM; ++it)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const unsigned off = base + (unsigned)(it * 32 + (r & 3) + 8 * (r >> 2)) * rowbytes;
-#pragma unroll
-          for (int jt = 0; jt < TN; ++jt) bstore1(acc[it][jt][r], rs_dst, off + (unsigned)jt * 128u);
-        }
-    } else {
-      unsigned coff[TN];
-#pragma unroll
-      for (int jt = 0; jt < TN; ++jt) { const int c = n0 + wn0 + jt * 32 + l31; coff[jt] = c < g.Cd ? (unsigned)c * 4u : kOob; }
-#pragma unroll
-      for (int it = 0; it < TM; ++it) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm0 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          unsigned poff;
-          if (dense_dst) {
-            poff = m < g.Mg ? (unsigned)(m * g.Cd) * 4u : kOob;
-          } else {
-            const int mm = m < g.Mg ? m : 0;
-            const int t2 = fdiv(mm, g.dWm); const int mw = mm - t2 * g.Wm; const int n = fdiv(t2, g.dHm); const int mh = t2 - n * g.Hm;
-            const int pix = (n * g.Hd + mh * g.dst_st + g.dph) * g.Wd + mw * g.dst_st + g.dpw;
-            poff = m < g.Mg ? (unsigned)(pix * g.Cd) * 4u : kOob;
-          }
-          // valid offsets are < 2^31 and coff < 2^14: the sum of two valid parts cannot reach the kOob bit, and a poisoned part keeps it
-#pragma unroll
-          for (int jt = 0; jt < TN; ++jt) bstore1(acc[it][jt][r], rs_dst, (poff + coff[jt]) | ((poff | coff[jt]) & kOob));
-          if (g.zfill) {                                        // stride-2 1x1 data gradient: the pixels no output pixel reaches are zero (one launch instead of four)
-            const unsigned rowb = (unsigned)g.Cd * 4u, lineb = (unsigned)g.Wd * rowb;
-#pragma unroll
-            for (int jt = 0; jt < TN; ++jt) {
-              const unsigned o = (poff + coff[jt]) | ((poff | coff[jt]) & kOob);
-              bstore1(0.f, rs_dst, o + rowb); bstore1(0.f, rs_dst, o + lineb); bstore1(0.f, rs_dst, o + lineb + rowb);
-            }
-          }
-        }
-      }
-    }
-    if (STATS) {
-#pragma unroll
-      for (int jt = 0; jt < TN; ++jt)
-#pragma unroll
-        for (int it = 0; it < TM; ++it)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { const float v = acc[it][jt][r]; st_s[jt] += v; st_q[jt] += v * v; }   // rows past Mg are 0
-    }
-  }
-
-  if (STATS || FOLD) {
-    // lane halves -> waves of the same column block -> one partial row per workgroup: part[blockIdx.x][2][Cd]
-    __syncthreads();
-    float* red = smem;                                          // [WM][2 stats][BN]
-    const int l31 = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int jt = 0; jt < TN; ++jt) {
-      st_s[jt] += __shfl_xor(st_s[jt], 32, kWave); st_q[jt] += __shfl_xor(st_q[jt], 32, kWave);
-      if (h == 0) {
-        red[((wave / WN) * 2 + 0) * BN + wn0 + jt * 32 + l31] = st_s[jt];
-        red[((wave / WN) * 2 + 1) * BN + wn0 + jt * 32 + l31] = st_q[jt];
-      }
-    }
-    __syncthreads();
-    for (int i = tid; i < 2 * BN; i += kCfThreads) {
-      const int s = i / BN, c = i - s * BN;
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) v += red[(w * 2 + s) * BN + c];
-      if (n0 + c < g.Cd) part[((int64_t)blockIdx.x * 2 + s) * g.Cd + n0 + c] = v;
-    }
-  }
+// The parity classes of a STRIDED data gradient as ONE launch (round 4): blockIdx.z = class, the classes ordered by their tap count, longest first.
+// As four launches of one stream every class ended in a round of workgroup slots of its own (3x3 / stride 2 at 512 images: 784 tiles on 512 slots, four
+// times over); as one grid the hardware deals 1-, 2- and 4-tap tiles to whichever slot frees up, longest first, and the launch has one tail.
+struct ActGeoSet { ActGeo g[4]; };
+template <int TN>
+__global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_classes_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
+                                                                             float* __restrict__ dst, ActGeoSet gs) {
+  constexpr bool B_KC = false, STATS = false, TAPV = false; constexpr int WM = 2, WN = 2, TM = 2, FUSE = 0;
+  const ActGeo g = gs.g[blockIdx.z];
+  float* const part = nullptr; const ActFuse fz{};
+#include "conv_f32_act_body.inc"
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1314,6 +943,10 @@ extern "C" int lec_conv_f32_dgrad(const float* dy, const float* w, int N, int H,
   const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
   // a 1x1 / stride-2 layer with an even input grid: only the (0, 0) parity class has a tap; its launch also writes the zeros of the other three
   const bool one_launch = stride == 2 && R == 1 && S == 1 && pad == 0 && H % 2 == 0 && W % 2 == 0;
+  // every other strided layer whose chunks lie inside one tap: its parity classes as ONE grid (conv_f32_act_classes_kernel).  LEC_DGRAD_CLASSES=0: one launch per class
+  static const int dg_classes = [] { const char* e = getenv("LEC_DGRAD_CLASSES"); return e ? atoi(e) : 1; }();
+  const bool merged = dg_classes && stride == 2 && !one_launch && Cout % kCfBK == 0;
+  ActGeoSet gs; int ncls = 0;
   for (int ph = 0; ph < (one_launch ? 1 : stride); ++ph) {
     for (int pw = 0; pw < (one_launch ? 1 : stride); ++pw) {
       ActGeo g;
@@ -1329,8 +962,25 @@ extern "C" int lec_conv_f32_dgrad(const float* dy, const float* w, int N, int H,
       g.src_bytes = (uint32_t)((int64_t)N * Ho * Wo * Cout * 4); g.wgt_bytes = (uint32_t)((int64_t)Cout * R * S * Cin * 4);
       g.dst_bytes = (uint32_t)((int64_t)N * H * W * Cin * 4);
       g.dWm = make_fastdiv(g.Wm); g.dHm = make_fastdiv(g.Hm); g.dnb = make_fastdiv(g.nb);   // (Kg = 0: the loop is empty, zeros are stored)
+      if (merged) { g.xcd_per = 0; gs.g[ncls++] = g; continue; }
       if (int rc = launch_act<false, false>(dy, w, dx, g, nullptr, nullptr, (hipStream_t)stream, ActFuse{}, kCfMaxPart, schedule)) return rc;
     }
+  }
+  if (merged && ncls > 0) {
+    for (int a = 1; a < ncls; ++a)                              // longest K first (insertion sort of at most four)
+      for (int b = a; b > 0 && gs.g[b].Kg > gs.g[b - 1].Kg; --b) { const ActGeo t = gs.g[b]; gs.g[b] = gs.g[b - 1]; gs.g[b - 1] = t; }
+    for (int a = ncls; a < 4; ++a) { gs.g[a] = gs.g[0]; gs.g[a].Mg = 0; }
+    const bool narrow = Cin <= 64;
+    const int BM = 128, BN = narrow ? 64 : 128;
+    const int ntiles = (Cin + BN - 1) / BN;
+    int gx = 1;
+    for (int a = 0; a < ncls; ++a) { LEC_CHECK_ARG(gs.g[a].na * gs.g[a].nb <= 32, "conv_f32_dgrad: more than 32 taps per class"); const int mt = (gs.g[a].Mg + BM - 1) / BM; if (mt > gx) gx = mt; }
+    const int cap = 2048 / (ntiles > 8 ? 8 : ntiles);
+    if (gx > cap) gx = cap;
+    const size_t lds = (size_t)2 * (BM * kCfLdk + kCfBK * BN) * 4;
+    if (narrow) hipLaunchKernelGGL((conv_f32_act_classes_kernel<1>), dim3(gx, ntiles, ncls), dim3(kCfThreads), lds, (hipStream_t)stream, dy, w, dx, gs);
+    else hipLaunchKernelGGL((conv_f32_act_classes_kernel<2>), dim3(gx, ntiles, ncls), dim3(kCfThreads), lds, (hipStream_t)stream, dy, w, dx, gs);
+    LEC_CHECK_LAUNCH("conv_f32_act_classes_kernel");
   }
   return LEC_OK;
 }
