@@ -477,6 +477,16 @@ int lec_maxpool3x3s2_fwd(const void* x, int N, int H, int W, int C, void* y, uin
 int lec_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, int N, int H, int W, int C, void* dx, lec_stream_t stream);
 int lec_maxpool3x3s2_fwd_f32(const void* x, int N, int H, int W, int C, void* y, uint8_t* argmax, lec_stream_t stream);   /* fp32 x, y */
 int lec_maxpool3x3s2_bwd_f32(const void* dy, const uint8_t* argmax, int N, int H, int W, int C, void* dx, lec_stream_t stream);
+/* The stem's tail as ONE op (fp32; csrc/bn.hip): p = maxpool3x3s2(relu(x * scale + shift)) -- torchvision ResNet `maxpool(relu(bn1(conv1(x))))`, reached from
+ * FeatCNN18 / FeatCNN's backbone (oe_h.py:311,317; the train-mode BatchNorm of oe_h.py's `img_feat_net.train()` phases).  scale / shift: the vectors
+ * lec_bn_fwd_finalize left in the BatchNorm workspace (lec_bn_workspace_coeff_offset).  p and argmax are bit for bit what lec_bn_fwd_prestat_f32(relu = 1) followed by
+ * lec_maxpool3x3s2_fwd_f32 produce; the normalised activation is never written.  Backward: from dp, argmax and x both passes of the BatchNorm backward
+ * (d gamma, d beta as lec_bn_bwd_f32 leaves them -- `accumulate` as there -- and dx, the gradient of the convolution output x); the pooling's input gradient
+ * is never written either.  C / 8 must divide 256 (C <= 512); H, W even. */
+int lec_bn_relu_maxpool_fwd_f32(const void* x, int N, int H, int W, int C, const float* scale, const float* shift, void* p, uint8_t* argmax, lec_stream_t stream);
+int lec_bn_relu_maxpool_bwd_f32(const void* dp, const uint8_t* argmax, const void* x, int N, int H, int W, int C, const float* gamma, const float* beta,
+                                const float* save_mean, const float* save_invstd, void* dx, float* dgamma, float* dbeta, void* workspace,
+                                int64_t workspace_bytes, int accumulate, lec_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * (9) HBM-resident image store (csrc/image_store.hip): the input side of the step.  Replaces, for every image row of a step's CNN

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LEC_LIB_PATH') or os.path.join(_HERE, 'liblecone.so')     # LEC_LIB_PATH: A/B builds of the same ABI
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 OK, E_ARG, E_HIP, E_EMPTY, E_STATE = 0, -1, -2, -3, -4
 ENERGY_HYP_CONE, ENERGY_ORDER, ENERGY_EUC_CONE = 0, 1, 2
@@ -117,6 +117,8 @@ def _load():
         'lec_maxpool3x3s2_fwd': (i32, [p, i32, i32, i32, i32, p, p, p]),
         'lec_maxpool3x3s2_bwd': (i32, [p, p, i32, i32, i32, i32, p, p]),
         'lec_image_gather_u8': (i32, [p, i64, p, p, i32, i32, i32, i32, p, p]),
+        'lec_bn_relu_maxpool_fwd_f32': (i32, [p, i32, i32, i32, i32, p, p, p, p, p]),
+        'lec_bn_relu_maxpool_bwd_f32': (i32, [p, p, p, i32, i32, i32, i32, p, p, p, p, p, p, p, p, i64, i32, p]),
     }
     for base in ('lec_bn_fwd', 'lec_bn_bwd', 'lec_bn_bwd_pass1', 'lec_bn_bwd_apply', 'lec_bn_bwd_prereduced', 'lec_bn_fwd_prestat',
                  'lec_maxpool3x3s2_fwd', 'lec_maxpool3x3s2_bwd'):

@@ -453,6 +453,166 @@ __global__ __launch_bounds__(kBnThreads) LEC_BN_REGS void bn_bwd_apply_kernel(co
   for (; r < M; r += stride) one(r * CV + cv);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The stem's tail as ONE op (fp32, round 4): p = maxpool3x3s2(relu(bn(x))) -- torchvision ResNet `maxpool(relu(bn1(conv1(x))))`, oe_h.py:311,317.
+// As three ops the 112 x 112 x 64 activation crossed HBM seven times forward (apply: read x, write z; pool: read z) and backward (pool backward:
+// write dz; reduce: read dz, x; apply: read dz, x) at the two ends of every pass, where no convolution of that pass overlaps with them.  Here z and dz
+// never exist in memory: forward applies scale / shift / ReLU to x on the pooling window's loads (p and the one-byte argmax are the outputs: the
+// same bits the separate kernels produce); backward rebuilds dz for a 2 x 2 input patch from the <= 4 pooled gradients covering it (the gather of
+// maxpool_bwd_kernel), masks it with [x * scale + shift > 0] and feeds BOTH BatchNorm passes from that.
+// Layout as everywhere in this file (EF32): a thread holds 8 channels of a pixel as two runs of 4; argmax: one byte per pooled element, 8 per thread.
+struct alignas(8) u8x8v { unsigned char v[8]; };
+
+__global__ __launch_bounds__(kBnThreads) void bn_relu_pool_fwd_kernel(const void* __restrict__ x, int N, int H, int W, int CV, const float* __restrict__ scale,
+                                                                      const float* __restrict__ shift, void* __restrict__ p, u8x8v* __restrict__ idx) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)N * Ho * Wo * CV;
+  const int cv = threadIdx.x % CV;                              // (the grid stride is a multiple of CV: a thread keeps its channels)
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = scale[EF32::chan(cv, j, CV)]; sh[j] = shift[EF32::chan(cv, j, CV)]; }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i / CV;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho); const int n = (int)(r / Ho);
+    float best[8]; unsigned char arg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; arg[j] = 0; }
+    bool first = true;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int h = 2 * ho - 1 + kh;
+      if (h < 0 || h >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int w = 2 * wo - 1 + kw;
+        if (w < 0 || w >= W) continue;
+        float v[8];
+        EF32::ld(x, (((int64_t)n * H + h) * W + w) * CV + cv, v, cv, CV);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float f = v[j] * sc[j] + sh[j];                        // bn_apply_kernel's arithmetic, then its ReLU
+          f = f > 0.0f ? f : 0.0f;
+          if (first || f > best[j] || f != f) { best[j] = f; arg[j] = (unsigned char)(kh * 3 + kw); }   // maxpool_fwd_kernel's rule: first max wins; NaN propagates
+        }
+        first = false;
+      }
+    }
+    u8x8v a;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a.v[j] = arg[j];
+    EF32::st(p, i, best, cv, CV);
+    idx[i] = a;
+  }
+}
+
+// g (the gradient of the BatchNorm OUTPUT) and x for the 2 x 2 input patch (rows 2i, 2i+1; columns 2j, 2j+1) of one channel vector
+__device__ __forceinline__ void bn_pool_patch(const void* __restrict__ dp, const u8x8v* __restrict__ idx, const void* __restrict__ x, int n, int i, int j, int cv,
+                                              int H, int W, int CV, const float (&sc)[8], const float (&sh)[8], float (&g)[4][8], float (&xv)[4][8]) {
+  const int Ho = H / 2, Wo = W / 2;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    EF32::ld(x, (((int64_t)n * H + 2 * i + (q >> 1)) * W + 2 * j + (q & 1)) * CV + cv, xv[q], cv, CV);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) g[q][c] = 0.0f;
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int ho = i + a, wo = j + b;
+      if (ho >= Ho || wo >= Wo) continue;
+      const int64_t o = (((int64_t)n * Ho + ho) * Wo + wo) * CV + cv;
+      const u8x8v am = idx[o];
+      float d[8];
+      EF32::ld(dp, o, d, cv, CV);
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {                          // window (ho, wo) covers rows 2 ho - 1 .. 2 ho + 1: patch row pr sits at kh = pr + 1 - 2 a
+        const int kh = pr + 1 - 2 * a;
+        if (kh < 0 || kh > 2) continue;
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+          const int kw = pc + 1 - 2 * b;
+          if (kw < 0 || kw > 2) continue;
+          const int code = kh * 3 + kw;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) if (am.v[c] == code) g[pr * 2 + pc][c] += d[c];     // (the order of maxpool_bwd_kernel's sums)
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) g[q][c] = xv[q][c] * sc[c] + sh[c] > 0.0f ? g[q][c] : 0.0f;      // the ReLU between the BatchNorm and the pooling
+}
+
+// pass 1: partial sums of g and g * xhat per block -> part[block][2][C]  (bn_bwd_reduce_kernel's layout: bn_bwd_finalize_kernel takes it from there)
+__global__ __launch_bounds__(kBnThreads) void bn_pool_bwd_reduce_kernel(const void* __restrict__ dp, const u8x8v* __restrict__ idx, const void* __restrict__ x,
+                                                                        int N, int H, int W, int C, int CV, const float* __restrict__ gamma,
+                                                                        const float* __restrict__ beta, const float* __restrict__ mean,
+                                                                        const float* __restrict__ invstd, float* __restrict__ part) {
+  __shared__ float smem[kBnThreads * 8];
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)N * Ho * Wo * CV;
+  const int cv = threadIdx.x % CV;
+  float sc[8], sh[8], mu[8], is[8], acc[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = EF32::chan(cv, j, CV);
+    mu[j] = mean[c]; is[j] = invstd[c]; sc[j] = gamma[c] * is[j]; sh[j] = beta[c] - mu[j] * sc[j];       // bn_stats_finalize_kernel's scale / shift, bit for bit
+    acc[0][j] = 0.f; acc[1][j] = 0.f;
+  }
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = t / CV;
+    const int j = (int)(r % Wo); r /= Wo;
+    const int i = (int)(r % Ho); const int n = (int)(r / Ho);
+    float g[4][8], xv[4][8];
+    bn_pool_patch(dp, idx, x, n, i, j, cv, H, W, CV, sc, sh, g, xv);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { acc[0][c] += g[q][c]; acc[1][c] += g[q][c] * ((xv[q][c] - mu[c]) * is[c]); }
+  }
+  block_reduce_rows<2>(acc, CV, kBnThreads / CV, smem);
+  if (threadIdx.x < CV) {
+    float* pp = part + (int64_t)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { pp[EF32::chan(cv, j, CV)] = acc[0][j]; pp[C + EF32::chan(cv, j, CV)] = acc[1][j]; }
+  }
+}
+
+// pass 2: dx = gamma invstd (g - c1 - xhat c2) for the four positions of the patch
+__global__ __launch_bounds__(kBnThreads) void bn_pool_bwd_apply_kernel(const void* __restrict__ dp, const u8x8v* __restrict__ idx, const void* __restrict__ x,
+                                                                       int N, int H, int W, int CV, const float* __restrict__ gamma,
+                                                                       const float* __restrict__ beta, const float* __restrict__ mean,
+                                                                       const float* __restrict__ invstd, const float* __restrict__ c1,
+                                                                       const float* __restrict__ c2, void* __restrict__ dx) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)N * Ho * Wo * CV;
+  const int cv = threadIdx.x % CV;
+  float sc[8], sh[8], mu[8], is[8], k1[8], k2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = EF32::chan(cv, j, CV);
+    mu[j] = mean[c]; is[j] = invstd[c]; sc[j] = gamma[c] * is[j]; sh[j] = beta[c] - mu[j] * sc[j]; k1[j] = c1[c]; k2[j] = c2[c];
+  }
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = t / CV;
+    const int j = (int)(r % Wo); r /= Wo;
+    const int i = (int)(r % Ho); const int n = (int)(r / Ho);
+    float g[4][8], xv[4][8];
+    bn_pool_patch(dp, idx, x, n, i, j, cv, H, W, CV, sc, sh, g, xv);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float o[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { const float xh = (xv[q][c] - mu[c]) * is[c]; o[c] = sc[c] * (g[q][c] - k1[c] - xh * k2[c]); }   // (sc = gamma invstd)
+      EF32::st(dx, (((int64_t)n * H + 2 * i + (q >> 1)) * W + 2 * j + (q & 1)) * CV + cv, o, cv, CV);
+    }
+  }
+}
+
 static int bn_check(const char* who, int64_t M, int C) {
   LEC_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0 && C <= 2048 && (C <= 512 || C % 512 == 0),
                 "%s: need M > 0 and C a multiple of 8 up to 512, or 1024 / 1536 / 2048 (M=%lld C=%d)", who, (long long)M, C);
@@ -715,4 +875,49 @@ extern "C" int lec_bn_fwd_prestat(const void* x, const void* residual, int64_t M
 }
 extern "C" int lec_bn_fwd_prestat_f32(const void* x, const void* residual, int64_t M, int C, const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var, int n_partials, float* save_mean, float* save_invstd, void* y, int relu, uint8_t* relu_mask, void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
   return bn_fwd_prestat_impl<lec::EF32>(x, residual, M, C, gamma, beta, eps, momentum, running_mean, running_var, n_partials, save_mean, save_invstd, y, relu, relu_mask, workspace, workspace_bytes, stream);
+}
+
+
+// ---- the stem's tail as one op (kernels above) --------------------------------------------------------------------------------------------
+static int bn_pool_check(const char* who, int N, int H, int W, int C) {
+  LEC_CHECK_ARG(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C >= 8 && C <= 512 && C % 8 == 0 && lec::kBnThreads % (C / 8) == 0,
+                "%s: need even H, W and C / 8 a divisor of %d up to 64 (N=%d H=%d W=%d C=%d)", who, lec::kBnThreads, N, H, W, C);
+  LEC_CHECK_ARG((int64_t)N * H * W * C * 4 < (1ll << 40), "%s: tensor too large", who);
+  return LEC_OK;
+}
+
+extern "C" int lec_bn_relu_maxpool_fwd_f32(const void* x, int N, int H, int W, int C, const float* scale, const float* shift, void* p, uint8_t* argmax,
+                                           lec_stream_t stream) {
+  using namespace lec;
+  if (int rc = bn_pool_check("bn_relu_maxpool_fwd", N, H, W, C)) return rc;
+  LEC_CHECK_ARG(x && scale && shift && p && argmax, "bn_relu_maxpool_fwd: null pointer");
+  const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
+  int64_t nb = (total + kBnThreads - 1) / kBnThreads; const int nblk = (int)(nb > 8192 ? 8192 : nb);
+  hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(nblk), dim3(kBnThreads), 0, (hipStream_t)stream, x, N, H, W, C / 8, scale, shift, p, (u8x8v*)argmax);
+  LEC_CHECK_LAUNCH("bn_relu_pool_fwd_kernel");
+  return LEC_OK;
+}
+
+extern "C" int lec_bn_relu_maxpool_bwd_f32(const void* dp, const uint8_t* argmax, const void* x, int N, int H, int W, int C, const float* gamma, const float* beta,
+                                           const float* save_mean, const float* save_invstd, void* dx, float* dgamma, float* dbeta, void* workspace,
+                                           int64_t workspace_bytes, int accumulate, lec_stream_t stream) {
+  using namespace lec;
+  if (int rc = bn_pool_check("bn_relu_maxpool_bwd", N, H, W, C)) return rc;
+  LEC_CHECK_ARG(dp && argmax && x && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta && workspace, "bn_relu_maxpool_bwd: null pointer");
+  LEC_CHECK_ARG(workspace_bytes >= lec_bn_workspace_bytes(C), "bn_relu_maxpool_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t M = (int64_t)N * H * W;
+  const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
+  float* part = (float*)workspace;
+  float* c1 = part + (int64_t)kBnMaxRows * 2 * C; float* c2 = c1 + C;
+  int64_t nb = (total + kBnThreads - 1) / kBnThreads;
+  const int nred = (int)(nb > kBnMaxBlocks ? kBnMaxBlocks : nb);
+  hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(nred), dim3(kBnThreads), 0, st, dp, (const u8x8v*)argmax, x, N, H, W, C, C / 8, gamma, beta, save_mean,
+                     save_invstd, part);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, nred, C, M, dgamma, dbeta, c1, c2, accumulate ? 1 : 0);
+  const int napp = (int)(nb > 16384 ? 16384 : nb);
+  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(napp), dim3(kBnThreads), 0, st, dp, (const u8x8v*)argmax, x, N, H, W, C / 8, gamma, beta, save_mean, save_invstd,
+                     c1, c2, dx);
+  LEC_CHECK_LAUNCH("bn_relu_maxpool_bwd kernels");
+  return LEC_OK;
 }

@@ -17,6 +17,7 @@ launches stay outside (the Adam step number is a launch argument).  Replays make
 Workloads: hierarchy S3 = [8,64,384,1544] (or the real ETHEC DAG), image j hangs under leaf j mod n_leaf,
 positive b of a step pairs image (step*B_global + b) mod M with its ancestor at level b mod L.
 """
+import os
 import time
 import numpy as np
 import torch
@@ -51,6 +52,24 @@ def make_labelmap(name):
         return SyntheticLabelMap([2, 4, 8])
     return SyntheticLabelMap(SYNTHETIC[name])
 
+
+
+def _resident_pool(pool, device, compute_dtype, backbone, rows):
+    """The synthetic image pool as it sits in HBM: channels_last, in the compute dtype.  For the fp32 backbone on liblecone's convolutions the pixels
+    are stored as FOUR floats -- the 16-byte pixel with a zero 4th channel that the f32 stem reads (resnet._pad_c4; the image store's gather emits the
+    same layout, image_store.gather(c_out=4)) -- so a step's `index_select` produces the stem's operand itself.  Before, every pass started with a strided
+    zero-fill and a strided 3 -> 4 channel copy of its rows behind the gather: ~0.6 ms at the head of the step with nothing to overlap with."""
+    from . import resnet
+    pool = pool.to(device).contiguous(memory_format=torch.channels_last)
+    if compute_dtype != torch.float32:
+        return pool.to(compute_dtype)                         # the backbone's first op would cast it anyway; same values
+    conv1 = getattr(backbone, 'conv1', None)
+    ov = getattr(backbone, 'wgrad_overlap', None)
+    if ov is None:
+        ov = resnet.WgradOverlap.instance                       # (the process default, as ops.overlap() resolves it)
+    own_stem = (resnet.MFMA_F32 and isinstance(conv1, resnet.Conv2d) and conv1.in_channels == 3 and conv1.bias is None and ov not in (None, False)
+                and ov.enabled and rows * pool.shape[2] * pool.shape[3] * 16 < (1 << 31) and os.environ.get('LEC_POOL_C4', '1') != '0')     # (0: A/B runs)
+    return resnet._pad_c4(pool) if own_stem else pool
 
 class StepEngine:
     def __init__(self, workload='cfg3', n_images=4096, pool_images=None, dtype='bf16', lr=1e-4, alpha=0.01, K_cone=0.1,
@@ -163,9 +182,7 @@ class StepEngine:
         P = pool_images or min(n_images, 2 * self.B)
         g = torch.Generator(device='cpu').manual_seed(1234 + self.rank)
         pool = torch.rand(P, 3, hw, hw, generator=g)
-        self.pool = pool.to(self.device).contiguous(memory_format=torch.channels_last)
-        if self.compute_dtype != torch.float32:
-            self.pool = self.pool.to(self.compute_dtype)      # the backbone's first op would cast it anyway; same values
+        self.pool = _resident_pool(pool, self.device, self.compute_dtype, self.backbone, self.n_rows_pad)
         self.P = P
         self.gfeat = torch.zeros(self.n_rows_pad, D, device=self.device)
         self.pin = [torch.empty((self.B, 2 + 2 * K), dtype=torch.int32).pin_memory() for _ in range(2)]
@@ -545,8 +562,7 @@ class ClassifierEngine:
             chains[i] = [c[l] - lm.level_start[l] for l in range(L)]
         self.P = P = self.B
         g = torch.Generator(device='cpu').manual_seed(4321 + self.rank)
-        pool = torch.rand(P, 3, hw, hw, generator=g).to(self.device).contiguous(memory_format=torch.channels_last)
-        self.pool = pool if self.compute_dtype == torch.float32 else pool.to(self.compute_dtype)
+        self.pool = _resident_pool(torch.rand(P, 3, hw, hw, generator=g), self.device, self.compute_dtype, getattr(self.exp.model, 'module', self.exp.model), self.B)
         self.pool_levels = torch.from_numpy(chains[np.arange(P) % nleaf]).to(self.device)
         self.idx_dev = torch.zeros(self.B, dtype=torch.int64, device=self.device)
         self.pin = [torch.empty(self.B, dtype=torch.int64).pin_memory() for _ in range(2)]

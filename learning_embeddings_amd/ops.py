@@ -1030,6 +1030,86 @@ def _bn_workspace(device):
     return fusion().workspace(device)
 
 
+# ------------------------------------------------------------------------------------------------ the stem's tail as one op
+FUSE_STEM_POOL = _os.environ.get('LEC_FUSE_STEM_POOL', '1') != '0'
+
+
+def stem_pool_supported(x, bn):
+    """maxpool(relu(bn(x))) of the stem as BNReluPoolFn: fp32 NHWC output of an fp32 convolution that left its statistics partials in the workspace."""
+    if not (FUSE_STEM_POOL and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
+        return False
+    N, Cc, H, W = x.shape
+    return (Cc % 8 == 0 and Cc <= 512 and 256 % (Cc // 8) == 0 and H % 2 == 0 and W % 2 == 0 and bn.training and bn.fuse_relu
+            and bn.weight.dtype == torch.float32 and fusion().ws_owner[0] == x.data_ptr() and fusion().ws_owner[1] > 0)
+
+
+class BNReluPoolFn(torch.autograd.Function):
+    """p = maxpool3x3s2(relu(batch_norm(x))) for the fp32 stem (torchvision ResNet `maxpool(relu(bn1(conv1(x))))`, oe_h.py:311,317), train mode, the
+    statistics partials of x already in the workspace (the convolution's epilogue): finalize + ONE pooling launch that normalises on load; backward = two
+    launches that rebuild the pooling's input gradient on the fly (lec_bn_relu_maxpool_fwd_f32 / _bwd_f32).  Same p, argmax, running statistics as
+    BNActFn + MaxPool3x3s2Fn, bit for bit; the gradients agree to summation order."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, sink=None):
+        N, Cc, H, W = x.shape
+        M = N * H * W
+        ctx.fc = fusion()
+        order = fusion().pass_order if fusion().pass_order is not None else PASS_ORDER
+        if order is not None and order[1] > 0:                # running statistics in pass order (see PASS_ORDER)
+            prev_ev = order[0].get((running_mean.data_ptr(), order[1] - 1))
+            if prev_ev is not None:
+                torch.cuda.current_stream().wait_event(prev_ev)
+        prestat = fusion().ws_owner[1]
+        fusion().ws_owner[0] = 0
+        save_mean = torch.empty(Cc, dtype=torch.float32, device=x.device); save_invstd = torch.empty_like(save_mean)
+        ws = _bn_workspace(x.device)
+        p = torch.empty((N, Cc, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        arg = torch.empty(N * (H // 2) * (W // 2) * Cc, dtype=torch.uint8, device=x.device)
+        off = lib.lec_bn_workspace_coeff_offset(Cc)
+
+        def run():
+            check(lib.lec_bn_fwd_finalize(M, Cc, dptr(weight), dptr(bias), float(eps), float(momentum), dptr(running_mean), dptr(running_var),
+                                          prestat, dptr(save_mean), dptr(save_invstd), dptr(ws), ws.numel(), stream_ptr()))
+            check(lib.lec_bn_relu_maxpool_fwd_f32(dptr(x), N, H, W, Cc, C.c_void_p(ws.data_ptr() + off), C.c_void_p(ws.data_ptr() + off + 4 * Cc),
+                                                  dptr(p), dptr(arg), stream_ptr()))
+        _bn_timed(run, M * Cc * 4 + (M * Cc // 4) * 5)          # read x; write p and its argmax bytes
+        if order is not None:
+            done_ev = torch.cuda.Event(); done_ev.record()
+            order[0][(running_mean.data_ptr(), order[1])] = done_ev
+        ctx.save_for_backward(x, arg, weight, bias, save_mean, save_invstd)
+        ctx.sink = sink
+        return p
+
+    @staticmethod
+    @_with_ctx_fusion
+    def backward(ctx, dp):
+        x, arg, weight, bias, save_mean, save_invstd = ctx.saved_tensors
+        N, Cc, H, W = x.shape
+        if dp.dtype != x.dtype:
+            dp = dp.to(x.dtype)
+        if not dp.is_contiguous(memory_format=torch.channels_last):
+            dp = dp.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x)
+        sink = ctx.sink
+        if sink is not None and sink[0].grad is not None and sink[1].grad is not None:
+            dgamma, dbeta = sink[0].grad, sink[1].grad           # the flat arena's slots: no AccumulateGrad kernels
+        else:
+            sink = None                                          # (zeros, not empty: with `accumulate` the kernels ADD into these)
+            dgamma = torch.zeros(Cc, dtype=torch.float32, device=x.device); dbeta = torch.zeros_like(dgamma)
+        ws = _bn_workspace(x.device)
+        fusion().ws_owner[0] = 0
+        acc = 1 if fusion().accumulate else 0
+        el = N * H * W * Cc
+        _bn_timed(lambda: check(lib.lec_bn_relu_maxpool_bwd_f32(dptr(dp), dptr(arg), dptr(x), N, H, W, Cc, dptr(weight), dptr(bias), dptr(save_mean),
+                                                                dptr(save_invstd), dptr(dx), dptr(dgamma), dptr(dbeta), dptr(ws), ws.numel(), acc,
+                                                                stream_ptr())), el * 4 * 3 + (el // 4) * 5 * 2)   # x twice, dx; dp + argmax twice
+        if sink is not None:
+            if sink[2] is not None:
+                sink[2].mark_ready(sink[0]); sink[2].mark_ready(sink[1])
+            return dx, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
 # ------------------------------------------------------------------------------------------------ stem max pooling
 class MaxPool3x3s2Fn(torch.autograd.Function):
     """3x3 / stride 2 / pad 1 max pooling on NHWC bf16 with a one-byte argmax and a gather backward."""

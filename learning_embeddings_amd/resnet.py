@@ -297,6 +297,21 @@ def conv_bn(conv, bn, x, residual=None, fork=False):
     return bn(conv(x), residual, fork)
 
 
+def conv_bn_pool(conv, bn, pool, x):
+    """The stem: pool(relu(bn(conv(x)))).  Train mode at fp32 on liblecone's kernels: the BatchNorm apply, the ReLU and the pooling are ONE launch over the
+    convolution's output (ops.BNReluPoolFn: the normalised 112 x 112 activation and, in backward, the pooling's input gradient never exist in memory)."""
+    if (bn.training and BatchNormAct2d.fused_enabled and isinstance(pool, MaxPool3x3s2) and isinstance(bn, BatchNormAct2d) and bn.fuse_relu
+            and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()):
+        y = conv(x)
+        ops = _ops()
+        if ops.stem_pool_supported(y, bn):
+            ov = ops.overlap()
+            sink = (bn.weight, bn.bias, ov.reducer) if (ov is not None and ov.enabled and ov.arena is not None and not ov.accumulate) else None
+            return ops.BNReluPoolFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, sink)
+        return pool(bn(y))
+    return pool(conv_bn(conv, bn, x))
+
+
 class _OverlapConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, conv):
@@ -633,7 +648,7 @@ class ResNet(nn.Module):
         return fc
 
     def _forward(self, x, pooled_only=False):
-        x = self.maxpool(conv_bn(self.conv1, self.bn1, x))
+        x = conv_bn_pool(self.conv1, self.bn1, self.maxpool, x)
         blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
         for i, b in enumerate(blocks):
             x = b(x, fork=i + 1 < len(blocks))                  # every block output but the last feeds two branches

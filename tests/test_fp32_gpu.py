@@ -7,7 +7,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from learning_embeddings_amd import ops  # noqa: E402
+from learning_embeddings_amd import ops, _lib  # noqa: E402
 from learning_embeddings_amd.resnet import resnet18, resnet50, BatchNormAct2d, WgradOverlap  # noqa: E402
 
 DEV = 'cuda'
@@ -798,3 +798,93 @@ def test_resnet50_f32_fused_batchnorm_backward_matches_the_unfused_path(hw, n):
         if b.norm() > 0:
             assert cos(a, b) > 0.99999, (k, cos(a, b))
             assert (a - b).abs().max().item() <= 2e-3 * b.abs().max().item(), (k, (a - b).abs().max().item(), b.abs().max().item())
+
+
+@pytest.mark.parametrize('shape', [(6, 40, 24), (4, 64, 64)])
+def test_stem_tail_as_one_op_equals_batchnorm_relu_then_maxpool(shape):
+    """ops.BNReluPoolFn (lec_bn_relu_maxpool_fwd_f32 / _bwd_f32): the stem's maxpool(relu(bn1(conv1(x)))) with the BatchNorm apply and the ReLU on the
+    pooling's loads, and in backward the pooling's input gradient rebuilt on the fly inside both BatchNorm passes.  Against the separate ops
+    (BNActFn + MaxPool3x3s2Fn, LEC_FUSE_STEM_POOL off) on the same ResNet-18: output and running statistics bit for bit (forward is the same
+    arithmetic), every parameter gradient to summation order."""
+    from learning_embeddings_amd import resnet as R
+    from learning_embeddings_amd.resnet import WgradOverlap
+    n, h, w = shape
+    x = torch.rand(n, 3, h, w, device=DEV, generator=torch.Generator(DEV).manual_seed(3)).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(n, 10, device=DEV, generator=torch.Generator(DEV).manual_seed(4))
+    calls = {'fused': 0}
+    orig = ops.BNReluPoolFn.forward
+
+    def counted(ctx, *a, **k):
+        calls['fused'] += 1
+        return orig(ctx, *a, **k)
+    res = {}
+    old_inst, old_flag = WgradOverlap.instance, ops.FUSE_STEM_POOL
+    WgradOverlap.instance = WgradOverlap()
+    ops.BNReluPoolFn.forward = staticmethod(counted)
+    try:
+        for tag in ('separate', 'fused'):
+            ops.FUSE_STEM_POOL = tag == 'fused'
+            torch.manual_seed(0)
+            m = R.resnet18(num_classes=10).to(DEV).to(memory_format=torch.channels_last).train()
+            for p_ in m.parameters():
+                p_.grad = torch.zeros_like(p_)
+            feats = {}
+            hook = m.maxpool.register_forward_hook(lambda mod, i, o: feats.__setitem__('p', o.detach().clone()))
+            y = m(x)
+            hook.remove()
+            y.backward(gy)
+            WgradOverlap.instance.join(); torch.cuda.synchronize()
+            res[tag] = (y.detach().clone(), m.bn1.running_mean.clone(), m.bn1.running_var.clone(), {k: p_.grad.double().clone() for k, p_ in m.named_parameters()})
+        assert calls['fused'] == 1                                 # (the module hook does not fire on the fused path: the pooling module is not called)
+    finally:
+        ops.BNReluPoolFn.forward = staticmethod(orig)
+        WgradOverlap.instance, ops.FUSE_STEM_POOL = old_inst, old_flag
+    ya, rma, rva, ga = res['separate']; yb, rmb, rvb, gb = res['fused']
+    assert torch.equal(rma, rmb) and torch.equal(rva, rvb)
+    assert torch.equal(ya, yb)                                     # same pooled activation, same network behind it
+    for k in ga:
+        scale = ga[k].abs().max().item() + 1e-12
+        assert (ga[k] - gb[k]).abs().max().item() <= 2e-4 * scale, (k, (ga[k] - gb[k]).abs().max().item(), scale)
+    assert gb['bn1.weight'].abs().max() > 0 and gb['conv1.weight'].abs().max() > 0
+
+
+def test_stem_tail_kernels_against_torch():
+    """The fused kernels through the C ABI against plain torch ops in float64: p / argmax semantics (first maximum wins), dx, d gamma, d beta."""
+    import torch.nn.functional as F
+    g = torch.Generator(DEV).manual_seed(11)
+    N, C_, H, W = 3, 16, 12, 20
+    x = torch.randn(N, C_, H, W, device=DEV, generator=g).contiguous(memory_format=torch.channels_last)
+    gamma = torch.rand(C_, device=DEV, generator=g) + 0.5; beta = torch.randn(C_, device=DEV, generator=g) * 0.3
+    xd = x.double().requires_grad_(True); gd = gamma.double().requires_grad_(True); bd = beta.double().requires_grad_(True)
+    mean = x.double().mean((0, 2, 3)); var = x.double().var((0, 2, 3), unbiased=False)
+    invstd = (1.0 / torch.sqrt(var + 1e-5))
+    z = F.relu((xd - mean[None, :, None, None]) * invstd[None, :, None, None] * gd[None, :, None, None] + bd[None, :, None, None])
+    # batch statistics depend on x: differentiate through them like F.batch_norm(training=True)
+    mean_g = xd.mean((0, 2, 3)); var_g = xd.var((0, 2, 3), unbiased=False)
+    zg = F.relu((xd - mean_g[None, :, None, None]) / torch.sqrt(var_g + 1e-5)[None, :, None, None] * gd[None, :, None, None] + bd[None, :, None, None])
+    pd = F.max_pool2d(zg, 3, 2, 1)
+    dp = torch.randn(N, C_, H // 2, W // 2, device=DEV, generator=g).contiguous(memory_format=torch.channels_last)
+    pd.backward(dp.double())
+    save_mean = mean.float().contiguous(); save_invstd = invstd.float().contiguous()
+    scale = (gamma * save_invstd).contiguous(); shift = (beta - save_mean * scale).contiguous()
+    p = torch.empty((N, C_, H // 2, W // 2), device=DEV, memory_format=torch.channels_last)
+    arg = torch.empty(N * (H // 2) * (W // 2) * C_, dtype=torch.uint8, device=DEV)
+    _lib.check(_lib.lib.lec_bn_relu_maxpool_fwd_f32(_lib.dptr(x), N, H, W, C_, _lib.dptr(scale), _lib.dptr(shift), _lib.dptr(p), _lib.dptr(arg), _lib.stream_ptr()))
+    assert torch.allclose(p.double(), pd.detach(), rtol=1e-5, atol=1e-6)
+    dx = torch.empty_like(x); dgamma = torch.zeros(C_, device=DEV); dbeta = torch.zeros(C_, device=DEV)
+    ws = torch.zeros(_lib.lib.lec_bn_workspace_bytes(C_), dtype=torch.uint8, device=DEV)
+    _lib.check(_lib.lib.lec_bn_relu_maxpool_bwd_f32(_lib.dptr(dp), _lib.dptr(arg), _lib.dptr(x), N, H, W, C_, _lib.dptr(gamma), _lib.dptr(beta), _lib.dptr(save_mean),
+                                                    _lib.dptr(save_invstd), _lib.dptr(dx), _lib.dptr(dgamma), _lib.dptr(dbeta), _lib.dptr(ws), ws.numel(), 0,
+                                                    _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.allclose(dx.double(), xd.grad, rtol=1e-4, atol=2e-5), (dx.double() - xd.grad).abs().max()
+    assert torch.allclose(dgamma.double(), gd.grad, rtol=1e-4, atol=1e-4) and torch.allclose(dbeta.double(), bd.grad, rtol=1e-4, atol=1e-4)
+    # accumulate = 1 ADDS into the parameter gradients
+    _lib.check(_lib.lib.lec_bn_relu_maxpool_bwd_f32(_lib.dptr(dp), _lib.dptr(arg), _lib.dptr(x), N, H, W, C_, _lib.dptr(gamma), _lib.dptr(beta), _lib.dptr(save_mean),
+                                                    _lib.dptr(save_invstd), _lib.dptr(dx), _lib.dptr(dgamma), _lib.dptr(dbeta), _lib.dptr(ws), ws.numel(), 1,
+                                                    _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.allclose(dgamma.double(), 2 * gd.grad, rtol=1e-4, atol=2e-4)
+    # arguments the kernels cannot serve are refused, not mis-run
+    with pytest.raises(_lib.LeconeError):
+        _lib.check(_lib.lib.lec_bn_relu_maxpool_fwd_f32(_lib.dptr(x), N, H + 1, W, C_, _lib.dptr(scale), _lib.dptr(shift), _lib.dptr(p), _lib.dptr(arg), _lib.stream_ptr()))
