@@ -62,14 +62,28 @@ def _resident_pool(pool, device, compute_dtype, backbone, rows):
     from . import resnet
     pool = pool.to(device).contiguous(memory_format=torch.channels_last)
     if compute_dtype != torch.float32:
-        return pool.to(compute_dtype)                         # the backbone's first op would cast it anyway; same values
+        return _rows_first(pool.to(compute_dtype))            # the backbone's first op would cast it anyway; same values
     conv1 = getattr(backbone, 'conv1', None)
     ov = getattr(backbone, 'wgrad_overlap', None)
     if ov is None:
         ov = resnet.WgradOverlap.instance                       # (the process default, as ops.overlap() resolves it)
     own_stem = (resnet.MFMA_F32 and isinstance(conv1, resnet.Conv2d) and conv1.in_channels == 3 and conv1.bias is None and ov not in (None, False)
                 and ov.enabled and rows * pool.shape[2] * pool.shape[3] * 16 < (1 << 31) and os.environ.get('LEC_POOL_C4', '1') != '0')     # (0: A/B runs)
-    return resnet._pad_c4(pool) if own_stem else pool
+    return _rows_first(resnet._pad_c4(pool) if own_stem else pool)
+
+
+def _rows_first(pool_cl):
+    """[P, C, H, W] channels_last -> the same memory as a plain [P, H, W, C] tensor: what `_gather_images` selects rows of."""
+    return pool_cl.permute(0, 2, 3, 1)
+
+
+def _gather_images(pool, idx):
+    """The images `idx` of the resident pool as an [n, C, H, W] channels_last batch.  `index_select` on the plain [P, H, W, C] tensor is a row copy
+    (132 us for 512 x 224 x 224 x 4 floats, 6.2 TB/s, `tools/microbench/gather_rows_bench.py`); on the channels_last [P, C, H, W] view of the same memory it takes
+    365 us AND returns an NCHW-contiguous tensor that the backbone then converts back (another ~150 us per pass)."""
+    if os.environ.get('LEC_GATHER_ROWS', '1') == '0':             # A/B: the former path
+        return pool.permute(0, 3, 1, 2).index_select(0, idx)
+    return pool.index_select(0, idx).permute(0, 3, 1, 2)
 
 class StepEngine:
     def __init__(self, workload='cfg3', n_images=4096, pool_images=None, dtype='bf16', lr=1e-4, alpha=0.01, K_cone=0.1,
@@ -320,7 +334,7 @@ class StepEngine:
         try:
             with torch.no_grad():
                 for lo in range(0, R, C):
-                    feats[lo:lo + C] = self.img_feat_net.forward_raw(self.pool.index_select(0, self.idx_dev[lo:lo + C]))
+                    feats[lo:lo + C] = self.img_feat_net.forward_raw(_gather_images(self.pool, self.idx_dev[lo:lo + C]))
         finally:
             for m, mom in zip(bns, saved):
                 m.momentum = mom
@@ -336,7 +350,7 @@ class StepEngine:
         self.reducer.live = False
         try:
             for lo in range(0, R, C):
-                f = self.img_feat_net.forward_raw(self.pool.index_select(0, self.idx_dev[lo:lo + C]))
+                f = self.img_feat_net.forward_raw(_gather_images(self.pool, self.idx_dev[lo:lo + C]))
                 f.backward(self.gfeat[lo:lo + C])
                 if self.overlap is not None:
                     self.overlap.join()
@@ -355,7 +369,7 @@ class StepEngine:
             return self._core_passes(ev)
         codes = self.codes_dev
         pos_from = codes[:, 0].contiguous(); pos_to = codes[:, 1].contiguous(); negc = codes[:, 2:].contiguous()
-        images = self.pool.index_select(0, self.idx_dev)
+        images = _gather_images(self.pool, self.idx_dev)
         self.arena.zero_grad(); self.table_grad.zero_(); self.gfeat.zero_()
         if ev: ev[0].record()
         feats = self.img_feat_net.forward_raw(images)
@@ -381,7 +395,7 @@ class StepEngine:
         fully connected layer -- the only parameters whose gradients go through autograd's AccumulateGrad -- stays on ONE stream."""
         codes = self.codes_dev
         pos_from = codes[:, 0].contiguous(); pos_to = codes[:, 1].contiguous(); negc = codes[:, 2:].contiguous()
-        images = self.pool.index_select(0, self.idx_dev)
+        images = _gather_images(self.pool, self.idx_dev)
         self.arena.zero_grad(); self.table_grad.zero_(); self.gfeat.zero_()
         if ev: ev[0].record()
         cur = torch.cuda.current_stream()
@@ -573,7 +587,7 @@ class ClassifierEngine:
         self.loss_acc = torch.zeros((), device=self.device)
 
     def _core(self):
-        images = self.pool.index_select(0, self.idx_dev)
+        images = _gather_images(self.pool, self.idx_dev)
         lvl = self.pool_levels.index_select(0, self.idx_dev)
         return self.exp.fwd_bwd(images, lvl)
 

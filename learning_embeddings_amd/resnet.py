@@ -297,6 +297,35 @@ def conv_bn(conv, bn, x, residual=None, fork=False):
     return bn(conv(x), residual, fork)
 
 
+AVGPOOL_FN = os.environ.get('LEC_AVGPOOL_FN', '1') != '0'        # (0: the framework's backward, for A/B runs)
+
+
+class _GlobalAvgPoolFn(torch.autograd.Function):
+    """flatten(AdaptiveAvgPool2d(1)(x)) with a backward that writes the gradient of a channels_last x IN channels_last: dx[n, :, h, w] = g[n, :] / (H W),
+    one coalesced broadcast store.  The framework's backward produces an NCHW-contiguous tensor (34 us) which the BatchNorm backward behind it then
+    converts (a 7 x 7-row transpose: 216 us for [256, 2048, 7, 7] at 0.5 TB/s) -- on the step's critical path between forward and backward, with nothing
+    of either pass to overlap with.  Forward is the framework's kernel (same bits as before)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        ctx.cl = x.is_contiguous(memory_format=torch.channels_last)
+        return torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        n, c, h, w = ctx.shape
+        dx = torch.empty(ctx.shape, dtype=g.dtype, device=g.device, memory_format=torch.channels_last if ctx.cl else torch.contiguous_format)
+        dx.copy_((g / float(h * w)).view(n, c, 1, 1).expand(n, c, h, w))
+        return dx
+
+
+def _global_avgpool(pool, x):
+    if AVGPOOL_FN and x.is_cuda and x.dim() == 4 and isinstance(pool, nn.AdaptiveAvgPool2d) and pool.output_size in (1, (1, 1)):
+        return _GlobalAvgPoolFn.apply(x)
+    return torch.flatten(pool(x), 1)
+
+
 def conv_bn_pool(conv, bn, pool, x):
     """The stem: pool(relu(bn(conv(x)))).  Train mode at fp32 on liblecone's kernels: the BatchNorm apply, the ReLU and the pooling are ONE launch over the
     convolution's output (ops.BNReluPoolFn: the normalised 112 x 112 activation and, in backward, the pooling's input gradient never exist in memory)."""
@@ -652,7 +681,7 @@ class ResNet(nn.Module):
         blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
         for i, b in enumerate(blocks):
             x = b(x, fork=i + 1 < len(blocks))                  # every block output but the last feeds two branches
-        x = torch.flatten(self.avgpool(x), 1)
+        x = _global_avgpool(self.avgpool, x)
         return x if pooled_only else self.fc(x)
 
 

@@ -888,3 +888,18 @@ def test_stem_tail_kernels_against_torch():
     # arguments the kernels cannot serve are refused, not mis-run
     with pytest.raises(_lib.LeconeError):
         _lib.check(_lib.lib.lec_bn_relu_maxpool_fwd_f32(_lib.dptr(x), N, H + 1, W, C_, _lib.dptr(scale), _lib.dptr(shift), _lib.dptr(p), _lib.dptr(arg), _lib.stream_ptr()))
+
+
+def test_global_avgpool_backward_is_channels_last_and_equals_the_framework_op():
+    """resnet._GlobalAvgPoolFn: same forward bits as flatten(adaptive_avg_pool2d(x, 1)); its backward writes the gradient of a channels_last input in
+    channels_last (the BatchNorm backward behind it takes it without a layout conversion) and equals the framework's."""
+    from learning_embeddings_amd import resnet as R
+    g = torch.Generator(DEV).manual_seed(2)
+    x = torch.randn(6, 64, 7, 7, device=DEV, generator=g).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(6, 64, device=DEV, generator=g)
+    xa = x.clone().requires_grad_(True); xb = x.clone().requires_grad_(True)
+    ya = R._global_avgpool(torch.nn.AdaptiveAvgPool2d((1, 1)), xa); yb = torch.flatten(F.adaptive_avg_pool2d(xb, 1), 1)
+    assert torch.equal(ya, yb)
+    ya.backward(gy); yb.backward(gy)
+    assert xa.grad.is_contiguous(memory_format=torch.channels_last)
+    assert torch.allclose(xa.grad, xb.grad, rtol=1e-6, atol=0)

@@ -1096,7 +1096,8 @@ def test_step_engine_concurrent_half_batch_passes_equal_the_same_passes_in_turn(
 
     def core_in_turn(ev=None):                                   # reference: the two parts one after the other, one stream
         codes = b.codes_dev
-        images = b.pool.index_select(0, b.idx_dev)
+        from learning_embeddings_amd.engine import _gather_images
+        images = _gather_images(b.pool, b.idx_dev)
         b.arena.zero_grad(); b.table_grad.zero_(); b.gfeat.zero_()
         from learning_embeddings_amd import _lib
         b.backbone.bn_grad_accumulate = True                        # two backward passes add into b's gradient slots (engine b's OWN setting: a's is not seen here)
