@@ -105,9 +105,12 @@ constexpr int kBnMaxRows = 2048;            // partial rows the workspace holds 
 // Reduction passes: a block owns a channel chunk of CVB 16-byte vectors (<= 64: up to 1 KiB contiguous per row) and a
 // strided set of rows; grid = (nrb row blocks, NCH channel chunks), nrb * NCH <= 512 blocks (2 per CU, 8 loads in flight
 // per thread).  Per channel there are nrb partials, reduced by a 1024-thread finalize kernel (32 channels x 32 splits).
-// Apply passes: a block covers whole rows (CV vectors), up to 2048 blocks.
+// Apply passes: a block covers whole rows (CV vectors), up to 1536 blocks.  (2048 blocks of 4 waves are ALL 32 wave slots of all 256 CUs, held for the whole
+// pass by grid-stride loops: the other pass's small dependent launches -- its statistics finalize -- then wait for the pass to END before a workgroup of
+// theirs is placed (finalize launches of 230 us in the step's trace).  With 1536 blocks 8 slots per CU stay free.  MEASURED (round 4, same box, bench
+// step, three alternating runs each, ms): 2048: 126.45, 125.87, 125.56; 1536: 125.59, 125.27, 125.47; 1280: 125.24, 125.90, 125.29; 1024: 125.90, 125.97, 125.62.)
 static inline int bn_apply_cap() {                         // blocks of an apply pass (experiments: LEC_BN_BLOCKS)
-  static const int v = [] { const char* e = getenv("LEC_BN_BLOCKS"); const int x = e ? atoi(e) : 2048; return x > 0 ? x : 2048; }();
+  static const int v = [] { const char* e = getenv("LEC_BN_BLOCKS"); const int x = e ? atoi(e) : 1536; return x > 0 ? x : 1536; }();
   return v;
 }
 struct BnGeom { int CV, RPI, CVB, NCH, RPIB, nrb; };

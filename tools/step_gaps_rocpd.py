@@ -55,6 +55,29 @@ for s, e in gaps:
 print('| interval length | ms per step |\n|---|---|')
 for k in ('< 20 us', '20 - 100 us', '100 - 300 us', '300 us - 1 ms', '>= 1 ms'):
     print('| %s | %.3f |' % (k, hist[k] / n / 1e6))
+# who fills the intervals: every interval's time split over the kernels in flight (equal shares while several run), summed per kernel name
+share = collections.Counter(); idle_tot = 0
+for s, e in gaps:
+    ev = []
+    for nm, s_, e_, g in sel:
+        if s_ < e and e_ > s and not is_conv(nm):
+            ev.append((max(s, s_), 1, short(nm))); ev.append((min(e, e_), -1, short(nm)))
+    ev.sort(key=lambda x: (x[0], x[1]))
+    live = collections.Counter(); t = s
+    for tt, d, nm in ev:
+        if tt > t:
+            k = sum(live.values())
+            if k == 0: idle_tot += tt - t
+            else:
+                for nm2, c2 in live.items():
+                    if c2 > 0: share[nm2] += (tt - t) * c2 / k
+            t = tt
+        live[nm] += d
+    if e > t: idle_tot += e - t
+print('\n| kernels in flight while no convolution is (time shared equally between concurrent ones) | ms per step |\n|---|---|')
+for nm, v in share.most_common(14):
+    print('| `%s` | %.3f |' % (nm.replace('lec::', '').replace('at::native::', ''), v / n / 1e6))
+print('| (nothing in flight) | %.3f |' % (idle_tot / n / 1e6))
 print('\n| interval (us) | at (ms into the window) | idle inside (us) | kernels inside (us each, in start order) |\n|---|---|---|---|')
 for s, e in sorted(gaps, key=lambda g: g[0] - g[1])[:a.top * n]:
     inside = [(nm, max(s, s_), min(e, e_)) for nm, s_, e_, g in sel if s_ < e and e_ > s and not is_conv(nm)]
