@@ -212,6 +212,10 @@ class StepEngine:
         self.codes_dev = torch.zeros((self.B, 2 + 2 * K), dtype=torch.int32, device=self.device)
         self.idx_dev = torch.zeros(self.n_rows_pad, dtype=torch.int64, device=self.device)
         self.use_graph = bool(use_graph) and self.cnn_chunk is None      # the chunked step launches eagerly
+        if self.passes > 1 and self.overlap is not None and self.overlap.side is not None:
+            # concurrent passes AND a weight-gradient side stream (an opt-in combination that measures slower: 130.5 against 125 ms): capturing it
+            # aborts inside the runtime (the side stream is forked from two capturing pass streams at once), so this combination launches eagerly
+            self.use_graph = False
         if self.cnn_chunk is not None and self.overlap is not None:
             self.overlap.accumulate = True
         self.pass_streams = [torch.cuda.Stream() for _ in range(self.passes)] if self.passes > 1 else []
@@ -222,7 +226,7 @@ class StepEngine:
         self.graph_after = graph_after
         self.hip_graph = None
         self.graph_out = None
-        self.graph_error = None
+        self.graph_error = None if (self.use_graph or not use_graph or self.cnn_chunk is not None) else 'not captured: concurrent passes with a weight-gradient side stream launch eagerly'
         self._graph_saved = None
         # With liblecone's own RCCL layer (LEC_DP_BACKEND=lecone) the bucket all-reduces are plain stream-ordered RCCL calls and are
         # captured INTO the step graph on the reducer's launch stream, where they overlap the rest of backward; torch.distributed's
