@@ -50,6 +50,31 @@ struct Row {
   float A, Bc;
 };
 
+// Packed fp32 arithmetic for the per-lane row loops (round 4).  At K = 256 the kernel is bound by vector-ALU issue (profiles/r04_cone_pmc.md: ~700 vector
+// instructions per pair, most of them one multiply or one add of a row element); gfx950 issues v_pk_mul_f32 / v_pk_add_f32 on TWO elements at the rate of one.
+// Element arithmetic is unchanged (IEEE multiply and add per element, nothing contracted); a dot product keeps two running sums (even / odd elements) and
+// adds them at the end -- another summation order than the former element-by-element loop, like every order a fixed one against the reference's reduction.
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <int N> __device__ __forceinline__ f2v pk_at(const float (&a)[N], int i) { f2v v; v.x = a[2 * i]; v.y = a[2 * i + 1]; return v; }
+template <int N> __device__ __forceinline__ void pk_put(float (&a)[N], int i, f2v v) { a[2 * i] = v.x; a[2 * i + 1] = v.y; }
+template <int N> __device__ __forceinline__ float pk_dot(const float (&a)[N], const float (&b)[N]) {
+  static_assert(N % 2 == 0, "rows are held in pairs of elements");
+  f2v acc = pk_at(a, 0) * pk_at(b, 0);
+#pragma unroll
+  for (int i = 1; i < N / 2; ++i) acc += pk_at(a, i) * pk_at(b, i);
+  return acc.x + acc.y;
+}
+template <int N> __device__ __forceinline__ void pk_scale(float (&o)[N], const float (&a)[N], float k) {       // o = a * k
+  const f2v kk = {k, k};
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i) pk_put(o, i, pk_at(a, i) * kk);
+}
+template <int N> __device__ __forceinline__ void pk_axpby(float (&o)[N], float ca, const float (&a)[N], float cb, const float (&b)[N]) {   // o = ca a + cb b
+  const f2v va = {ca, ca}, vb = {cb, cb};
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i) pk_put(o, i, va * pk_at(a, i) + vb * pk_at(b, i));
+}
+
 // ---- T == 1 (one lane per pair, D <= 16): rows move between HBM/L2 and registers THROUGH LDS.  A lane-per-row global
 // access makes every load/atomic instruction touch 64 different cache lines (one dword each); staged, consecutive lanes
 // move consecutive elements of the gathered row list, so an instruction touches ~64/D rows in D-element runs, and each
@@ -136,13 +161,13 @@ __device__ __forceinline__ void load_project(const JointParams& P, int code, boo
   if (valid) src = row_src(P, code);
   const bool hyp = valid && is_label && P.label_proj == LEC_LABEL_HYP;
   const bool img = valid && (is_label ? P.label_proj == LEC_LABEL_SOFTCLIP_K : P.image_proj != LEC_IMAGE_RAW);   // soft_clip forms
-  float nn = 0.0f;
+  float nn;
   if (prefetched != nullptr) {
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
       float v = prefetched[i];
       if (hyp && (t + i * T) < P.D) v += 1e-15f;                                    // oe_h.py:79
-      r.e[i] = v; nn += v * v;
+      r.e[i] = v;
     }
   } else if (T == 1 && stage != nullptr) {
     wave_gather_rows<EPL>(P, valid ? code : kNoRow, stage, r.e);
@@ -150,7 +175,7 @@ __device__ __forceinline__ void load_project(const JointParams& P, int code, boo
     for (int i = 0; i < EPL; ++i) {
       float v = r.e[i];
       if (hyp && i < P.D) v += 1e-15f;                                              // oe_h.py:79
-      r.e[i] = v; nn += v * v;
+      r.e[i] = v;
     }
   } else {
 #pragma unroll
@@ -158,10 +183,10 @@ __device__ __forceinline__ void load_project(const JointParams& P, int code, boo
       int d = t + i * T;
       float v = 0.0f;
       if (valid && d < P.D) { v = row_ld(src, d); if (hyp) v += 1e-15f; }          // oe_h.py:79
-      r.e[i] = v; nn += v * v;
+      r.e[i] = v;
     }
   }
-  nn = group_sum<T>(nn);
+  nn = group_sum<T>(pk_dot(r.e, r.e));
   const float n = sqrtf(nn);                                                       // oe_h.py:81 / :327
   const float den = fmaxf(n, 1e-12f);                                              // F.normalize eps
   const float denp = n >= 1e-12f ? 1.0f : 0.0f;
@@ -178,26 +203,14 @@ __device__ __forceinline__ void load_project(const JointParams& P, int code, boo
     mul = sc; A = sc / den;
     Bc = n > 0.0f ? (1.0f / den - sc * denp / (den * den)) / n : 0.0f;
   }
-  float pp = 0.0f;
   const float mul_over_den = mul / den;                 // one correctly rounded divide per row, then multiplies
-#pragma unroll
-  for (int i = 0; i < EPL; ++i) {
-    float v = (hyp || img) ? r.e[i] * mul_over_den : r.e[i];
-    r.p[i] = v; pp += v * v;
-  }
+  pk_scale(r.p, r.e, (hyp || img) ? mul_over_den : 1.0f);                          // (raw rows: times 1, exact)
   // no-grad clip of label points into [r_in, 1-1e-5] (oe_h.py:100-103); images are NOT clipped (:323-328)
-  pp = group_sum<T>(pp);
+  const float pp = group_sum<T>(pk_dot(r.p, r.p));
   if (hyp) {
     float no = sqrtf(pp);
-    if (no <= P.r_in) {
-      const float k = P.r_in / no;
-#pragma unroll
-      for (int i = 0; i < EPL; ++i) r.p[i] = r.p[i] * k;
-    } else if (no >= 1.0f) {
-      const float k = (float)(1.0 - 1e-5) / no;
-#pragma unroll
-      for (int i = 0; i < EPL; ++i) r.p[i] = r.p[i] * k;
-    }
+    if (no <= P.r_in) pk_scale(r.p, r.p, P.r_in / no);
+    else if (no >= 1.0f) pk_scale(r.p, r.p, (float)(1.0 - 1e-5) / no);
   }
   r.A = A; r.Bc = Bc;
 }
@@ -206,26 +219,20 @@ __device__ __forceinline__ void load_project(const JointParams& P, int code, boo
 template <int T, int EPL>
 __device__ __forceinline__ void scatter_row_grad(const JointParams& P, int code, bool active, int t,
                                                  const Row<EPL>& r, const float (&go)[EPL], float* stage) {
-  float dot = 0.0f;
-#pragma unroll
-  for (int i = 0; i < EPL; ++i) dot += r.e[i] * go[i];
-  dot = group_sum<T>(dot);
+  const float dot = group_sum<T>(pk_dot(r.e, go));
+  float graw[EPL];
+  pk_axpby(graw, r.A, go, r.Bc * dot, r.e);
   if (T == 1 && stage != nullptr) {
     if (__ballot(active) == 0ull) return;                                           // wave-uniform: nothing to add
-    float graw[EPL];
-    const float cc = r.Bc * dot;
-#pragma unroll
-    for (int i = 0; i < EPL; ++i) graw[i] = r.A * go[i] + cc * r.e[i];
     wave_scatter_rows<EPL>(P, active ? code : kNoRow, stage, graw);
     return;
   }
   if (!active) return;
   float* dst = code >= 0 ? P.grad_table + (int64_t)code * P.ld_table : P.grad_feat + (int64_t)(-1 - code) * P.ld_feat;
-  const float c = r.Bc * dot;
 #pragma unroll
   for (int i = 0; i < EPL; ++i) {
     int d = t + i * T;
-    if (d < P.D) atomicAdd(dst + d, r.A * go[i] + c * r.e[i]);
+    if (d < P.D) atomicAdd(dst + d, graw[i]);
   }
 }
 
@@ -296,13 +303,10 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
     ConeFwd cf;
     ConeEval ev;
     if (ENERGY == LEC_ENERGY_HYP_CONE) {
-      float xx = 0.f, yy = 0.f, s = 0.f, dd = 0.f;
+      float df[EPL];
 #pragma unroll
-      for (int i = 0; i < EPL; ++i) {
-        float df = x[i] - y[i];
-        xx += x[i] * x[i]; yy += y[i] * y[i]; s += x[i] * y[i]; dd += df * df;
-      }
-      xx = group_sum<T>(xx); yy = group_sum<T>(yy); s = group_sum<T>(s); dd = group_sum<T>(dd);
+      for (int i = 0; i < EPL / 2; ++i) pk_put(df, i, pk_at(x, i) - pk_at(y, i));
+      const float xx = group_sum<T>(pk_dot(x, x)), yy = group_sum<T>(pk_dot(y, y)), s = group_sum<T>(pk_dot(x, y)), dd = group_sum<T>(pk_dot(df, df));
       cf = cone_forward(xx, yy, s, dd, P.K_cone);
       E = cf.E;
     } else if (ENERGY == LEC_ENERGY_EUC_CONE) {                                    // oe.py:721-739
@@ -341,13 +345,18 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
           if (ENERGY == LEC_ENERGY_HYP_CONE) cone_grad_coeffs(cf, P.K_cone, cxx, cxy, cyy);
           else { cxx = ev.cxx; cxy = ev.cxy; cyy = ev.cyy; }
           cxx *= g; cxy *= g; cyy *= g;
+          // (g = 0 for pairs that are not live: their coefficients are zero, their sums add zeros)
+          float gx[EPL], gy[EPL];
+          pk_axpby(gx, cxx, x, cxy, y); pk_axpby(gy, cxy, x, cyy, y);
+          const float mu_ = kind != 2 ? 1.0f : 0.0f, mv_ = kind != 1 ? 1.0f : 0.0f;
+          const f2v mu2 = {mu_, mu_}, mv2 = {mv_, mv_};
 #pragma unroll
-          for (int i = 0; i < EPL; ++i) {
-            const float gxi = cxx * x[i] + cxy * y[i], gyi = cxy * x[i] + cyy * y[i];
-            if (act && kind != 2) gu[i] += gxi;
-            if (act && kind != 1) gv[i] += gyi;
-            go[i] = kind == 1 ? gyi : gxi;
+          for (int i = 0; i < EPL / 2; ++i) {
+            pk_put(gu, i, pk_at(gu, i) + pk_at(gx, i) * mu2);
+            pk_put(gv, i, pk_at(gv, i) + pk_at(gy, i) * mv2);
           }
+#pragma unroll
+          for (int i = 0; i < EPL; ++i) go[i] = kind == 1 ? gy[i] : gx[i];
         } else {
 #pragma unroll
           for (int i = 0; i < EPL; ++i) {
