@@ -237,7 +237,18 @@ __device__ __forceinline__ void scatter_row_grad(const JointParams& P, int code,
 }
 
 template <int T, int EPL, int ENERGY, bool GRAD, bool STAGE>
-__global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
+// LEC_JL_WAVES (build-time experiment, `make EXTRA=-DLEC_JL_WAVES=3`): cap the registers for that many waves per SIMD.  The lane-per-pair instance (T = 1, 12 elements
+// per lane) holds 181 registers = 2 waves per SIMD.  MEASURED (round 4, same box, us per launch, no cap / 3 waves (168 registers, 9 spilled) / 4 waves (128, 53 spilled)):
+// 256 x 256 x 10: 22.1 / 22.8 / 27.0; 4 096 x 256 x 10: 89.0 / 97.1 / 112.4; 256 x 256 x 128: 58.8 / 58.8 / 60.8 -- the spills cost more than the third wave hides.  Off.
+#ifndef LEC_JL_WAVES
+#define LEC_JL_WAVES 0
+#endif
+#if LEC_JL_WAVES > 0
+#define LEC_JL_OCC __attribute__((amdgpu_waves_per_eu(LEC_JL_WAVES, LEC_JL_WAVES)))
+#else
+#define LEC_JL_OCC
+#endif
+__global__ __launch_bounds__(256) LEC_JL_OCC void joint_loss_kernel(JointParams P) {
   constexpr int PPW = kWave / T;                      // pairs per wave iteration
   const int lane = threadIdx.x & 63;
   const int t = lane % T, slot = lane / T;
