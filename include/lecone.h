@@ -484,7 +484,7 @@ int lec_maxpool3x3s2_bwd_f32(const void* dy, const uint8_t* argmax, int N, int H
  * (d gamma, d beta as lec_bn_bwd_f32 leaves them -- `accumulate` as there -- and dx, the gradient of the convolution output x); the pooling's input gradient
  * is never written either.  C / 8 must divide 256 (C <= 512); H, W even. */
 int lec_bn_relu_maxpool_fwd_f32(const void* x, int N, int H, int W, int C, const float* scale, const float* shift, void* p, uint8_t* argmax, lec_stream_t stream);
-int lec_bn_relu_maxpool_bwd_f32(const void* dp, const uint8_t* argmax, const void* x, int N, int H, int W, int C, const float* gamma, const float* beta,
+int lec_bn_relu_maxpool_bwd_f32(const void* dp, const void* dp2 /* or NULL: a second gradient of p (it fed two branches), added on load */, const uint8_t* argmax, const void* x, int N, int H, int W, int C, const float* gamma, const float* beta,
                                 const float* save_mean, const float* save_invstd, void* dx, float* dgamma, float* dbeta, void* workspace,
                                 int64_t workspace_bytes, int accumulate, lec_stream_t stream);
 

@@ -118,7 +118,7 @@ def _load():
         'lec_maxpool3x3s2_bwd': (i32, [p, p, i32, i32, i32, i32, p, p]),
         'lec_image_gather_u8': (i32, [p, i64, p, p, i32, i32, i32, i32, p, p]),
         'lec_bn_relu_maxpool_fwd_f32': (i32, [p, i32, i32, i32, i32, p, p, p, p, p]),
-        'lec_bn_relu_maxpool_bwd_f32': (i32, [p, p, p, i32, i32, i32, i32, p, p, p, p, p, p, p, p, i64, i32, p]),
+        'lec_bn_relu_maxpool_bwd_f32': (i32, [p, p, p, p, i32, i32, i32, i32, p, p, p, p, p, p, p, p, i64, i32, p]),
     }
     for base in ('lec_bn_fwd', 'lec_bn_bwd', 'lec_bn_bwd_pass1', 'lec_bn_bwd_apply', 'lec_bn_bwd_prereduced', 'lec_bn_fwd_prestat',
                  'lec_maxpool3x3s2_fwd', 'lec_maxpool3x3s2_bwd'):

@@ -510,7 +510,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_relu_pool_fwd_kernel(const void
 }
 
 // g (the gradient of the BatchNorm OUTPUT) and x for the 2 x 2 input patch (rows 2i, 2i+1; columns 2j, 2j+1) of one channel vector
-__device__ __forceinline__ void bn_pool_patch(const void* __restrict__ dp, const u8x8v* __restrict__ idx, const void* __restrict__ x, int n, int i, int j, int cv,
+__device__ __forceinline__ void bn_pool_patch(const void* __restrict__ dp, const void* __restrict__ dp2, const u8x8v* __restrict__ idx, const void* __restrict__ x, int n, int i, int j, int cv,
                                               int H, int W, int CV, const float (&sc)[8], const float (&sh)[8], float (&g)[4][8], float (&xv)[4][8]) {
   const int Ho = H / 2, Wo = W / 2;
 #pragma unroll
@@ -529,6 +529,12 @@ __device__ __forceinline__ void bn_pool_patch(const void* __restrict__ dp, const
       const u8x8v am = idx[o];
       float d[8];
       EF32::ld(dp, o, d, cv, CV);
+      if (dp2) {                                                // the pooled activation fed two branches: their gradients are added here, not by a pass of their own
+        float d2[8];
+        EF32::ld(dp2, o, d2, cv, CV);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) d[c] += d2[c];
+      }
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {                          // window (ho, wo) covers rows 2 ho - 1 .. 2 ho + 1: patch row pr sits at kh = pr + 1 - 2 a
         const int kh = pr + 1 - 2 * a;
@@ -551,7 +557,7 @@ __device__ __forceinline__ void bn_pool_patch(const void* __restrict__ dp, const
 }
 
 // pass 1: partial sums of g and g * xhat per block -> part[block][2][C]  (bn_bwd_reduce_kernel's layout: bn_bwd_finalize_kernel takes it from there)
-__global__ __launch_bounds__(kBnThreads) void bn_pool_bwd_reduce_kernel(const void* __restrict__ dp, const u8x8v* __restrict__ idx, const void* __restrict__ x,
+__global__ __launch_bounds__(kBnThreads) void bn_pool_bwd_reduce_kernel(const void* __restrict__ dp, const void* __restrict__ dp2, const u8x8v* __restrict__ idx, const void* __restrict__ x,
                                                                         int N, int H, int W, int C, int CV, const float* __restrict__ gamma,
                                                                         const float* __restrict__ beta, const float* __restrict__ mean,
                                                                         const float* __restrict__ invstd, float* __restrict__ part) {
@@ -571,7 +577,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_pool_bwd_reduce_kernel(const vo
     const int j = (int)(r % Wo); r /= Wo;
     const int i = (int)(r % Ho); const int n = (int)(r / Ho);
     float g[4][8], xv[4][8];
-    bn_pool_patch(dp, idx, x, n, i, j, cv, H, W, CV, sc, sh, g, xv);
+    bn_pool_patch(dp, dp2, idx, x, n, i, j, cv, H, W, CV, sc, sh, g, xv);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -586,7 +592,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_pool_bwd_reduce_kernel(const vo
 }
 
 // pass 2: dx = gamma invstd (g - c1 - xhat c2) for the four positions of the patch
-__global__ __launch_bounds__(kBnThreads) void bn_pool_bwd_apply_kernel(const void* __restrict__ dp, const u8x8v* __restrict__ idx, const void* __restrict__ x,
+__global__ __launch_bounds__(kBnThreads) void bn_pool_bwd_apply_kernel(const void* __restrict__ dp, const void* __restrict__ dp2, const u8x8v* __restrict__ idx, const void* __restrict__ x,
                                                                        int N, int H, int W, int CV, const float* __restrict__ gamma,
                                                                        const float* __restrict__ beta, const float* __restrict__ mean,
                                                                        const float* __restrict__ invstd, const float* __restrict__ c1,
@@ -605,7 +611,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_pool_bwd_apply_kernel(const voi
     const int j = (int)(r % Wo); r /= Wo;
     const int i = (int)(r % Ho); const int n = (int)(r / Ho);
     float g[4][8], xv[4][8];
-    bn_pool_patch(dp, idx, x, n, i, j, cv, H, W, CV, sc, sh, g, xv);
+    bn_pool_patch(dp, dp2, idx, x, n, i, j, cv, H, W, CV, sc, sh, g, xv);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float o[8];
@@ -901,7 +907,7 @@ extern "C" int lec_bn_relu_maxpool_fwd_f32(const void* x, int N, int H, int W, i
   return LEC_OK;
 }
 
-extern "C" int lec_bn_relu_maxpool_bwd_f32(const void* dp, const uint8_t* argmax, const void* x, int N, int H, int W, int C, const float* gamma, const float* beta,
+extern "C" int lec_bn_relu_maxpool_bwd_f32(const void* dp, const void* dp2, const uint8_t* argmax, const void* x, int N, int H, int W, int C, const float* gamma, const float* beta,
                                            const float* save_mean, const float* save_invstd, void* dx, float* dgamma, float* dbeta, void* workspace,
                                            int64_t workspace_bytes, int accumulate, lec_stream_t stream) {
   using namespace lec;
@@ -915,11 +921,11 @@ extern "C" int lec_bn_relu_maxpool_bwd_f32(const void* dp, const uint8_t* argmax
   float* c1 = part + (int64_t)kBnMaxRows * 2 * C; float* c2 = c1 + C;
   int64_t nb = (total + kBnThreads - 1) / kBnThreads;
   const int nred = (int)(nb > kBnMaxBlocks ? kBnMaxBlocks : nb);
-  hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(nred), dim3(kBnThreads), 0, st, dp, (const u8x8v*)argmax, x, N, H, W, C, C / 8, gamma, beta, save_mean,
+  hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(nred), dim3(kBnThreads), 0, st, dp, dp2, (const u8x8v*)argmax, x, N, H, W, C, C / 8, gamma, beta, save_mean,
                      save_invstd, part);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinThreads), 0, st, part, nred, C, M, dgamma, dbeta, c1, c2, accumulate ? 1 : 0);
   const int napp = (int)(nb > 16384 ? 16384 : nb);
-  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(napp), dim3(kBnThreads), 0, st, dp, (const u8x8v*)argmax, x, N, H, W, C / 8, gamma, beta, save_mean, save_invstd,
+  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(napp), dim3(kBnThreads), 0, st, dp, dp2, (const u8x8v*)argmax, x, N, H, W, C / 8, gamma, beta, save_mean, save_invstd,
                      c1, c2, dx);
   LEC_CHECK_LAUNCH("bn_relu_maxpool_bwd kernels");
   return LEC_OK;

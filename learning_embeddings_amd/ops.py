@@ -1050,7 +1050,9 @@ class BNReluPoolFn(torch.autograd.Function):
     BNActFn + MaxPool3x3s2Fn, bit for bit; the gradients agree to summation order."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, sink=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, sink=None, fork=False):
+        """fork=True returns (p, p_alias), two handles on the same memory for the two branches of the first block: backward then receives the two branch
+        gradients separately and the kernels add them on load (no accumulation pass over the pooled gradient)."""
         N, Cc, H, W = x.shape
         M = N * H * W
         ctx.fc = fusion()
@@ -1078,17 +1080,26 @@ class BNReluPoolFn(torch.autograd.Function):
             order[0][(running_mean.data_ptr(), order[1])] = done_ev
         ctx.save_for_backward(x, arg, weight, bias, save_mean, save_invstd)
         ctx.sink = sink
+        if fork:
+            return p, p.as_strided(p.size(), p.stride())
         return p
 
     @staticmethod
     @_with_ctx_fusion
-    def backward(ctx, dp):
+    def backward(ctx, dp, dp2=None):
         x, arg, weight, bias, save_mean, save_invstd = ctx.saved_tensors
         N, Cc, H, W = x.shape
-        if dp.dtype != x.dtype:
-            dp = dp.to(x.dtype)
-        if not dp.is_contiguous(memory_format=torch.channels_last):
-            dp = dp.contiguous(memory_format=torch.channels_last)
+        if dp is None:
+            dp, dp2 = dp2, None
+        if dp is None:
+            raise RuntimeError('BNReluPoolFn.backward: no incoming gradient')
+
+        def nhwc(t):
+            if t is None:
+                return None
+            t = t.to(x.dtype) if t.dtype != x.dtype else t
+            return t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
+        dp, dp2 = nhwc(dp), nhwc(dp2)
         dx = torch.empty_like(x)
         sink = ctx.sink
         if sink is not None and sink[0].grad is not None and sink[1].grad is not None:
@@ -1100,14 +1111,14 @@ class BNReluPoolFn(torch.autograd.Function):
         fusion().ws_owner[0] = 0
         acc = 1 if fusion().accumulate else 0
         el = N * H * W * Cc
-        _bn_timed(lambda: check(lib.lec_bn_relu_maxpool_bwd_f32(dptr(dp), dptr(arg), dptr(x), N, H, W, Cc, dptr(weight), dptr(bias), dptr(save_mean),
+        _bn_timed(lambda: check(lib.lec_bn_relu_maxpool_bwd_f32(dptr(dp), dptr(dp2), dptr(arg), dptr(x), N, H, W, Cc, dptr(weight), dptr(bias), dptr(save_mean),
                                                                 dptr(save_invstd), dptr(dx), dptr(dgamma), dptr(dbeta), dptr(ws), ws.numel(), acc,
                                                                 stream_ptr())), el * 4 * 3 + (el // 4) * 5 * 2)   # x twice, dx; dp + argmax twice
         if sink is not None:
             if sink[2] is not None:
                 sink[2].mark_ready(sink[0]); sink[2].mark_ready(sink[1])
-            return dx, None, None, None, None, None, None, None
-        return dx, dgamma, dbeta, None, None, None, None, None
+            return dx, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ stem max pooling

@@ -336,7 +336,8 @@ def conv_bn_pool(conv, bn, pool, x):
         if ops.stem_pool_supported(y, bn):
             ov = ops.overlap()
             sink = (bn.weight, bn.bias, ov.reducer) if (ov is not None and ov.enabled and ov.arena is not None and not ov.accumulate) else None
-            return ops.BNReluPoolFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, sink)
+            # (two handles on p: the first block's conv path and its identity / downsample path -- the two gradients meet inside the fused backward)
+            return ops.BNReluPoolFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, sink, True)
         return pool(bn(y))
     return pool(conv_bn(conv, bn, x))
 

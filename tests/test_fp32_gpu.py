@@ -873,14 +873,15 @@ def test_stem_tail_kernels_against_torch():
     assert torch.allclose(p.double(), pd.detach(), rtol=1e-5, atol=1e-6)
     dx = torch.empty_like(x); dgamma = torch.zeros(C_, device=DEV); dbeta = torch.zeros(C_, device=DEV)
     ws = torch.zeros(_lib.lib.lec_bn_workspace_bytes(C_), dtype=torch.uint8, device=DEV)
-    _lib.check(_lib.lib.lec_bn_relu_maxpool_bwd_f32(_lib.dptr(dp), _lib.dptr(arg), _lib.dptr(x), N, H, W, C_, _lib.dptr(gamma), _lib.dptr(beta), _lib.dptr(save_mean),
+    _lib.check(_lib.lib.lec_bn_relu_maxpool_bwd_f32(_lib.dptr(dp), None, _lib.dptr(arg), _lib.dptr(x), N, H, W, C_, _lib.dptr(gamma), _lib.dptr(beta), _lib.dptr(save_mean),
                                                     _lib.dptr(save_invstd), _lib.dptr(dx), _lib.dptr(dgamma), _lib.dptr(dbeta), _lib.dptr(ws), ws.numel(), 0,
                                                     _lib.stream_ptr()))
     torch.cuda.synchronize()
     assert torch.allclose(dx.double(), xd.grad, rtol=1e-4, atol=2e-5), (dx.double() - xd.grad).abs().max()
     assert torch.allclose(dgamma.double(), gd.grad, rtol=1e-4, atol=1e-4) and torch.allclose(dbeta.double(), bd.grad, rtol=1e-4, atol=1e-4)
-    # accumulate = 1 ADDS into the parameter gradients
-    _lib.check(_lib.lib.lec_bn_relu_maxpool_bwd_f32(_lib.dptr(dp), _lib.dptr(arg), _lib.dptr(x), N, H, W, C_, _lib.dptr(gamma), _lib.dptr(beta), _lib.dptr(save_mean),
+    # accumulate = 1 ADDS into the parameter gradients; the pooled gradient handed over as two branch gradients (dp = dp_a + dp_b, added on load)
+    dp_b = (torch.randn(dp.shape, device=DEV, generator=g) * 0.5).contiguous(memory_format=torch.channels_last); dp_a = (dp - dp_b).contiguous(memory_format=torch.channels_last)
+    _lib.check(_lib.lib.lec_bn_relu_maxpool_bwd_f32(_lib.dptr(dp_a), _lib.dptr(dp_b), _lib.dptr(arg), _lib.dptr(x), N, H, W, C_, _lib.dptr(gamma), _lib.dptr(beta), _lib.dptr(save_mean),
                                                     _lib.dptr(save_invstd), _lib.dptr(dx), _lib.dptr(dgamma), _lib.dptr(dbeta), _lib.dptr(ws), ws.numel(), 1,
                                                     _lib.stream_ptr()))
     torch.cuda.synchronize()
