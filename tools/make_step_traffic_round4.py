@@ -22,7 +22,7 @@ for k, v in W['bytes_per_step'].items(): w[fam(k)] += v
 native = {k: (2 * f[k] / 1e9, w[k] / 1e9) for k in set(f) | set(w)}
 CS = os.path.join(ROOT, 'learning_embeddings_amd', 'csrc')
 out = {'native': native, 'ms_per_step': ms,
-       'kernel_sources_sha256': {x: hashlib.sha256(open(os.path.join(CS, x), 'rb').read()).hexdigest() for x in ('conv_f32.hip', 'conv_geo.h', 'bn.hip')}}
+       'kernel_sources_sha256': {x: hashlib.sha256(open(os.path.join(CS, x), 'rb').read()).hexdigest() for x in ('conv_f32.hip', 'conv_f32_act_body.inc', 'conv_geo.h', 'bn.hip')}}
 json.dump(out, open(os.path.join(ROOT, 'profiles', 'r04_step_traffic.json'), 'w'), indent=1)
 md = ['# HBM traffic of the whole fp32 bench step, all kernels (rocprofv3 PMC, round 4, MI355X)', '',
       '`bash tools/prof_round4.sh` then `python tools/make_step_traffic_round4.py <ms per step>`: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes) over',
