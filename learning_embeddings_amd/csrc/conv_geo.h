@@ -47,8 +47,11 @@ __device__ __forceinline__ f32x4v bload4(rsrc_t rsrc, unsigned voff) {
   const u32x4r v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0);
   return __builtin_bit_cast(f32x4v, v);
 }
+#ifndef LEC_CF_STORE_AUX
+#define LEC_CF_STORE_AUX 0          // cache policy of the convolutions' output stores (gfx942+ aux bits: 1 = sc0, 2 = nt, 16 = sc1): see bstore1
+#endif
 __device__ __forceinline__ void bstore1(float v, rsrc_t rsrc, unsigned voff) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)voff, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)voff, 0, LEC_CF_STORE_AUX);
 }
 
 // geometry of an "activation-gather" GEMM (forward, or one parity class of a data gradient)
