@@ -10,7 +10,8 @@ dev = 'cuda'
 x = torch.randn(256, 256, 28, 28, device=dev).contiguous(memory_format=torch.channels_last)
 w = torch.randn(256, 256, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
 big = torch.randn(256, 256, 56, 56, device=dev).contiguous(memory_format=torch.channels_last)
-C = 256
+C = int(os.environ.get('FIN_C', '256'))                       # channels of the finalize launch: C / 8 workgroups
+ROWS = int(os.environ.get('FIN_ROWS', '512'))
 ws = torch.zeros(_lib.lib.lec_bn_workspace_bytes(C), dtype=torch.uint8, device=dev)
 gamma = torch.ones(C, device=dev); beta = torch.zeros(C, device=dev); rm = torch.zeros(C, device=dev); rv = torch.ones(C, device=dev)
 sm = torch.empty(C, device=dev); si = torch.empty(C, device=dev)
@@ -33,12 +34,12 @@ def small_fill():
 
 
 def small_finalize():
-    _lib.check(_lib.lib.lec_bn_fwd_finalize(256 * 28 * 28, C, _lib.dptr(gamma), _lib.dptr(beta), 1e-5, 0.1, _lib.dptr(rm), _lib.dptr(rv), 512, _lib.dptr(sm), _lib.dptr(si),
+    _lib.check(_lib.lib.lec_bn_fwd_finalize(256 * 28 * 28, C, _lib.dptr(gamma), _lib.dptr(beta), 1e-5, 0.1, _lib.dptr(rm), _lib.dptr(rv), ROWS, _lib.dptr(sm), _lib.dptr(si),
                                             _lib.dptr(ws), ws.numel(), _lib.stream_ptr()))
 
 
 for lname, load in (('nothing', None), ('fp32 3x3 convolutions', load_conv), ('streaming elementwise passes', load_bn)):
-    for sname, small in (('one-element fill', small_fill), ('bn_fwd_finalize 512 x 256', small_finalize)):
+    for sname, small in (('one-element fill', small_fill), ('bn_fwd_finalize %d x %d' % (ROWS, C), small_finalize)):
         torch.cuda.synchronize()
         if load is not None:
             with torch.cuda.stream(A):
