@@ -16,7 +16,7 @@ ws = torch.zeros(_lib.lib.lec_bn_workspace_bytes(C), dtype=torch.uint8, device=d
 gamma = torch.ones(C, device=dev); beta = torch.zeros(C, device=dev); rm = torch.zeros(C, device=dev); rv = torch.ones(C, device=dev)
 sm = torch.empty(C, device=dev); si = torch.empty(C, device=dev)
 one = torch.zeros(1, device=dev)
-A, B = torch.cuda.Stream(), torch.cuda.Stream()
+A, B = torch.cuda.Stream(), torch.cuda.Stream(priority=-1 if os.environ.get("B_HIGH") else 0)
 
 
 def load_conv(n):
@@ -38,12 +38,26 @@ def small_finalize():
                                             _lib.dptr(ws), ws.numel(), _lib.stream_ptr()))
 
 
+sc_ = torch.empty(C, device=dev); sh_ = torch.empty(C, device=dev)
+small_vec = torch.zeros(8192, device=dev)
+
+
+def small_coeffs():                                             # one workgroup of 256 threads, 13 registers, no LDS (bn_eval_coeff_kernel)
+    _lib.check(_lib.lib.lec_bn_eval_coeffs_f32(C, _lib.dptr(gamma), _lib.dptr(beta), 1e-5, _lib.dptr(rm), _lib.dptr(rv), _lib.dptr(sc_), _lib.dptr(sh_), _lib.stream_ptr()))
+
+
+def small_add():                                                # a framework elementwise kernel over 32 KB
+    small_vec.add_(1.0)
+
+
 for lname, load in (('nothing', None), ('fp32 3x3 convolutions', load_conv), ('streaming elementwise passes', load_bn)):
-    for sname, small in (('one-element fill', small_fill), ('bn_fwd_finalize %d x %d' % (ROWS, C), small_finalize)):
+    for sname, small in (('one-element fill', small_fill), ('32 KB framework add', small_add), ('bn_eval_coeffs (1 workgroup, no LDS)', small_coeffs), ('bn_fwd_finalize %d x %d' % (ROWS, C), small_finalize)):
         torch.cuda.synchronize()
+        a0 = torch.cuda.Event(enable_timing=True); a1 = torch.cuda.Event(enable_timing=True)
+        nA = 60 if load is load_conv else 200
         if load is not None:
             with torch.cuda.stream(A):
-                load(60 if load is load_conv else 200)
+                a0.record(); load(nA); a1.record()
         time.sleep(0.002)
         with torch.cuda.stream(B):
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -54,4 +68,13 @@ for lname, load in (('nothing', None), ('fp32 3x3 convolutions', load_conv), ('s
         e1.synchronize()
         busy = not A.query()
         torch.cuda.synchronize()
-        print('stream A: %-30s stream B: %-28s %.1f us per launch%s' % (lname, sname, e0.elapsed_time(e1) * 1e3 / 200, '' if (load is None or busy) else '  (stream A ran dry before B finished)'))
+        print('stream A: %-30s stream B: %-40s %.1f us per launch%s%s' % (lname, sname, e0.elapsed_time(e1) * 1e3 / 200, '' if (load is None or busy) else '  (stream A ran dry before B finished)',
+              '' if load is None else ';  stream A: %.0f us per kernel' % (a0.elapsed_time(a1) * 1e3 / nA)))
+if True:                                                        # stream A alone, for the per-kernel baseline
+    for lname, load, nA in (('fp32 3x3 convolutions', load_conv, 60), ('streaming elementwise passes', load_bn, 200)):
+        torch.cuda.synchronize()
+        a0 = torch.cuda.Event(enable_timing=True); a1 = torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(A):
+            a0.record(); load(nA); a1.record()
+        torch.cuda.synchronize()
+        print('stream A alone: %-30s %.0f us per kernel' % (lname, a0.elapsed_time(a1) * 1e3 / nA))
