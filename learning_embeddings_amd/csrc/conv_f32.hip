@@ -829,10 +829,8 @@ static int launch_act(const float* src, const float* wgt, float* dst, const ActG
   int gx = mtiles;
   if (STATS || (FUSE & 2)) { const int cap = kCfMaxPart; if (gx > cap) gx = cap; }
   else { const int cap = 2048 / (ntiles > 8 ? 8 : ntiles); if (gx > cap) gx = cap; }
-  // LEC_CF_WGS (experiment): cap on the launch's TOTAL workgroups (gx x ntiles) -- 512 = the chip's resident slots, so that every workgroup is placed at once and
-  // the dispatcher is not left holding a queue of pending ones (see tools/microbench/small_launch_under_load.py)
-  static const int cf_wgs = [] { const char* e = getenv("LEC_CF_WGS"); return e ? atoi(e) : 0; }();
-  if (cf_wgs > 0) { const int cap = cf_wgs / ntiles > 0 ? cf_wgs / ntiles : 1; if (gx > cap) gx = cap; }
+  // (Grid size and small launches of ANOTHER stream, round 4: next to this kernel a one-workgroup launch of the other pass takes 60 - 90 us and a 32-workgroup one 510, whether
+  // the grid is 512 workgroups (all resident), 2 048 (this cap) or one per tile -- profiles/EXPERIMENTS.md, tools/microbench/small_launch_under_load.py.)
   if (gx < 1) gx = 1;
   // XCD-contiguous tile runs (LEC_CF_XCD=1; default off): the grid becomes a multiple of 8 so that a workgroup's slots stay on its XCD.
   // MEASURED (round 3, same box, alternating runs, 512 images): forward / data gradient of nine layer shapes identical to +-1 % with and

@@ -29,6 +29,20 @@ def load_bn(n):
         torch.add(big, 1.0, out=big)
 
 
+ma = torch.randn(8192, 8192, device=dev); mb = torch.randn(8192, 8192, device=dev); mc = torch.empty(8192, 8192, device=dev)
+xl = x.clone(); wl = w.clone()
+
+
+def load_gemm(n):                                               # the library's fp32 GEMM (hipBLASLt / rocBLAS): someone else's MFMA kernel
+    for _ in range(n):
+        torch.matmul(ma, mb, out=mc)
+
+
+def load_libconv(n):                                            # MIOpen's fp32 convolution on the same shape
+    for _ in range(n):
+        torch.nn.functional.conv2d(xl, wl, padding=1)
+
+
 def small_fill():
     one.fill_(1.0)
 
@@ -50,11 +64,11 @@ def small_add():                                                # a framework el
     small_vec.add_(1.0)
 
 
-for lname, load in (('nothing', None), ('fp32 3x3 convolutions', load_conv), ('streaming elementwise passes', load_bn)):
+for lname, load in (('nothing', None), ('fp32 3x3 convolutions', load_conv), ('library fp32 GEMM 8192^3', load_gemm), ('library fp32 3x3 convolution', load_libconv), ('streaming elementwise passes', load_bn)):
     for sname, small in (('one-element fill', small_fill), ('32 KB framework add', small_add), ('bn_eval_coeffs (1 workgroup, no LDS)', small_coeffs), ('bn_fwd_finalize %d x %d' % (ROWS, C), small_finalize)):
         torch.cuda.synchronize()
         a0 = torch.cuda.Event(enable_timing=True); a1 = torch.cuda.Event(enable_timing=True)
-        nA = 60 if load is load_conv else 200
+        nA = 200 if load is load_bn else 60
         if load is not None:
             with torch.cuda.stream(A):
                 a0.record(); load(nA); a1.record()
