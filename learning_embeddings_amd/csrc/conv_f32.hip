@@ -49,6 +49,12 @@
 #define LEC_WG_XF_BLOCKS 2             // workgroups per CU the on-load weight gradient is compiled for (4: 128 registers, a few spills)
 #endif
 
+#ifdef LEC_CF_NUM_VGPR                                        // build-time experiment: cap the forward / data-gradient kernels' registers
+#define LEC_CF_ACT_ATTR __attribute__((amdgpu_num_vgpr(LEC_CF_NUM_VGPR)))
+#else
+#define LEC_CF_ACT_ATTR
+#endif
+
 namespace lec {
 
 
@@ -123,7 +129,7 @@ struct ActFuse {
 };
 
 template <bool B_KC, int WM, int WN, int TM, int TN, bool STATS, bool TAPV, int FUSE = 0>
-__global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
+__global__ __launch_bounds__(kCfThreads, 2) LEC_CF_ACT_ATTR void conv_f32_act_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
                                                                      float* __restrict__ dst, ActGeo g, float* __restrict__ part,
                                                                      ActFuse fz) {
 #include "conv_f32_act_body.inc"
@@ -829,8 +835,8 @@ static int launch_act(const float* src, const float* wgt, float* dst, const ActG
   int gx = mtiles;
   if (STATS || (FUSE & 2)) { const int cap = kCfMaxPart; if (gx > cap) gx = cap; }
   else { const int cap = 2048 / (ntiles > 8 ? 8 : ntiles); if (gx > cap) gx = cap; }
-  // (Grid size and small launches of ANOTHER stream, round 4: next to this kernel a one-workgroup launch of the other pass takes 60 - 90 us and a 32-workgroup one 510, whether
-  // the grid is 512 workgroups (all resident), 2 048 (this cap) or one per tile -- profiles/EXPERIMENTS.md, tools/microbench/small_launch_under_load.py.)
+  // (Small launches of ANOTHER stream, round 4, tools/microbench/small_launch_under_load.py: next to this tile-walk kernel they are placed as fast as on an idle chip (a fill 4 us,
+  // a one-workgroup kernel 8); next to the balanced form below -- 512 workgroups resident for the whole kernel -- they wait 60 - 500 us each.  Multi-stream steps take the tile walk.)
   if (gx < 1) gx = 1;
   // XCD-contiguous tile runs (LEC_CF_XCD=1; default off): the grid becomes a multiple of 8 so that a workgroup's slots stay on its XCD.
   // MEASURED (round 3, same box, alternating runs, 512 images): forward / data gradient of nine layer shapes identical to +-1 % with and

@@ -7,8 +7,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from learning_embeddings_amd import ops, _lib
 dev = 'cuda'
+# which form of the forward kernel stream A runs: the tile walk (what a two-pass step uses) unless CONV_SCHEDULE=auto (then the balanced / stream-K kernel takes this shape)
+if os.environ.get('CONV_SCHEDULE', 'tile_walk') == 'tile_walk':
+    ops.fusion().schedule = _lib.SCHEDULE_TILE_WALK
+COUT = int(os.environ.get('CONV_COUT', '256'))                # 64: the narrow tile (128 x 64, 55 KB of LDS per workgroup instead of 74)
 x = torch.randn(256, 256, 28, 28, device=dev).contiguous(memory_format=torch.channels_last)
-w = torch.randn(256, 256, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
+w = torch.randn(COUT, 256, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
 big = torch.randn(256, 256, 56, 56, device=dev).contiguous(memory_format=torch.channels_last)
 C = int(os.environ.get('FIN_C', '256'))                       # channels of the finalize launch: C / 8 workgroups
 ROWS = int(os.environ.get('FIN_ROWS', '512'))
