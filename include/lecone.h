@@ -181,6 +181,9 @@ int  lec_sampler_create(lec_sampler** out, const int32_t* level_sizes, int n_lev
 void lec_sampler_destroy(lec_sampler* s);
 int  lec_sampler_seed(lec_sampler* s, uint64_t seed);                    /* random.seed(seed)                       */
 int  lec_sampler_set_levels_to_hide(lec_sampler* s, const int32_t* levels, int n);   /* oe_h.py:764-765, 850-854   */
+/* The slot ids left after hiding, in the order oe_h.py:854 indexes them: `list(set(range(L+1)) - set(hidden))` is in CPython's set
+ * iteration order, which is NOT ascending for L + 1 > 8 slots with fewer than 5 left (restated from setobject.c).  out: L + 1 entries. */
+int  lec_sampler_visible_slots(const lec_sampler* s, int32_t* out, int* n);
 /* One call of sample_negative_edge: side 0 = `u` fixed (corrupt the "to" end), side 1 = `v` fixed. */
 int  lec_sampler_draw(lec_sampler* s, int side, int32_t node, int32_t level_id, int32_t* out);
 /* The criterion's host loop (oe_h.py:940-957): for b < B: for p < K: draw(0, from[b], p) -> neg[b,p];

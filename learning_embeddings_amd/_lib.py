@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LEC_LIB_PATH') or os.path.join(_HERE, 'liblecone.so')     # LEC_LIB_PATH: A/B builds of the same ABI
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 OK, E_ARG, E_HIP, E_EMPTY, E_STATE = 0, -1, -2, -3, -4
 ENERGY_HYP_CONE, ENERGY_ORDER, ENERGY_EUC_CONE = 0, 1, 2
@@ -61,6 +61,7 @@ def _load():
         'lec_sampler_destroy': (None, [p]),
         'lec_sampler_seed': (i32, [p, u64]),
         'lec_sampler_set_levels_to_hide': (i32, [p, p, i32]),
+        'lec_sampler_visible_slots': (i32, [p, p, p]),
         'lec_sampler_draw': (i32, [p, i32, i32, i32, p]),
         'lec_sampler_draw_batch': (i32, [p, p, p, i32, i32, p]),
         'lec_sampler_next_u32': (i32, [p, p]),

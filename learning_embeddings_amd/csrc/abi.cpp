@@ -16,4 +16,4 @@ int hip_fail(hipError_t e, const char* what) {
 }  // namespace lec
 
 extern "C" const char* lec_last_error(void) { return lec::g_err; }
-extern "C" int lec_abi_version(void) { return 27; }
+extern "C" int lec_abi_version(void) { return 28; }

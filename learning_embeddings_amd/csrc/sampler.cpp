@@ -191,12 +191,65 @@ extern "C" int lec_sampler_seed(lec_sampler* s, uint64_t seed) {
   s->rng.seed(seed); return LEC_OK;
 }
 
+// oe_h.py:854 indexes `list(set(list(range(L+1))) - set(self.levels_to_hide))`: the ORDER of that list is CPython's set iteration
+// order, which is ascending only while no two keys share a slot of the hash table.  With L + 1 > 8 slot ids and few of them left
+// (the result set still has its initial 8-slot table) key 8 lands in slot 0: hidden {0,4,5,6,7} of 8 levels leaves [8, 1, 2, 3], not
+// [1, 2, 3, 8] (fixture F4b).  Restated from CPython's Objects/setobject.c (3.7 - 3.12: same table policy): open addressing,
+// hash(int) = int, LINEAR_PROBES = 9 following slots when they fit below the mask, then i = 5 i + 1 + (perturb >>= 5); growth to
+// the first power of two above 4 x used once fill * 5 >= mask * 3; set_difference builds a NEW set by walking `so` in table order unless
+// len(so) >> 2 > len(other), where it copies `so` and discards.  Pinned in tests against this interpreter's own sets.
+namespace lec {
+struct PySet {
+  std::vector<int64_t> table; size_t mask = 7, fill = 0;
+  PySet() : table(8, -1) {}
+  static size_t find_free(const std::vector<int64_t>& t, size_t mask, int64_t key) {
+    size_t perturb = (size_t)key, i = (size_t)key & mask;
+    for (;;) {
+      if (t[i] < 0) return i;
+      if (i + 9 <= mask) for (size_t j = 1; j <= 9; ++j) if (t[i + j] < 0) return i + j;
+      perturb >>= 5; i = (i * 5 + 1 + perturb) & mask;
+    }
+  }
+  void resize(size_t minused) {
+    size_t n = 8; while (n <= minused) n <<= 1;
+    std::vector<int64_t> t(n, -1);
+    for (int64_t k : table) if (k >= 0) t[find_free(t, n - 1, k)] = k;         // set_insert_clean in old table order
+    table.swap(t); mask = n - 1;
+  }
+  void add(int64_t key) {                                                       // distinct keys only (set_add_entry without the compare)
+    table[find_free(table, mask, key)] = key; ++fill;
+    if (fill * 5 >= mask * 3) resize(fill > 50000 ? fill * 2 : fill * 4);
+  }
+};
+}  // namespace lec
+
 extern "C" int lec_sampler_set_levels_to_hide(lec_sampler* s, const int32_t* levels, int n) {
   if (!s || n < 0 || (n && !levels)) { lec::set_error("sampler_set_levels_to_hide: bad arguments"); return LEC_E_ARG; }
   s->hidden.assign(levels, levels + n);
   s->visible.clear();
-  for (int32_t l = 0; l <= s->L; ++l)
-    if (std::find(s->hidden.begin(), s->hidden.end(), l) == s->hidden.end()) s->visible.push_back(l);
+  std::vector<int32_t> uniq(s->hidden); std::sort(uniq.begin(), uniq.end()); uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+  auto is_hidden = [&](int64_t k) { return std::binary_search(uniq.begin(), uniq.end(), (int32_t)k); };
+  lec::PySet so;
+  for (int32_t l = 0; l <= s->L; ++l) so.add(l);                                // set(list(range(L + 1)))
+  if ((so.fill >> 2) > uniq.size()) {                                           // set_copy_and_difference: a copy of `so`, the hidden ids discarded
+    lec::PySet cp;
+    if ((cp.fill + so.fill) * 5 >= cp.mask * 3) cp.resize(so.fill * 2);        // set_merge into an empty set
+    if (cp.mask == so.mask) cp.table = so.table;
+    else for (int64_t k : so.table) if (k >= 0) cp.table[lec::PySet::find_free(cp.table, cp.mask, k)] = k;
+    for (int64_t k : cp.table) if (k >= 0 && !is_hidden(k)) s->visible.push_back((int32_t)k);
+  } else {                                                                      // a new set, filled in `so`'s iteration order
+    lec::PySet res;
+    for (int64_t k : so.table) if (k >= 0 && !is_hidden(k)) res.add(k);
+    for (int64_t k : res.table) if (k >= 0) s->visible.push_back((int32_t)k);
+  }
+  return LEC_OK;
+}
+
+// The slot ids left after hiding, in the order oe_h.py:854 indexes them (see above).  out: up to L + 1 entries; returns their count in *n.
+extern "C" int lec_sampler_visible_slots(const lec_sampler* s, int32_t* out, int* n) {
+  if (!s || !out || !n) { lec::set_error("sampler_visible_slots: bad arguments"); return LEC_E_ARG; }
+  if (s->hidden.empty()) { for (int32_t l = 0; l <= s->L; ++l) out[l] = l; *n = s->L + 1; return LEC_OK; }
+  std::copy(s->visible.begin(), s->visible.end(), out); *n = (int)s->visible.size();
   return LEC_OK;
 }
 

@@ -136,6 +136,12 @@ class NegativeGraph:
         a = np.ascontiguousarray(list(levels), dtype=np.int32)
         check(lib.lec_sampler_set_levels_to_hide(self._h, a.ctypes.data, len(a)))
 
+    def visible_slots(self):
+        """The level slots a draw's `level_id` is mapped onto, in the reference's order (oe_h.py:854: CPython set order)."""
+        out = np.empty(len(self.levels) + 1, dtype=np.int32); n = C.c_int()
+        check(lib.lec_sampler_visible_slots(self._h, out.ctypes.data, C.byref(n)))
+        return out[:n.value].tolist()
+
     def draw(self, side, node, level_id=0):
         """side 0: `u` fixed, corrupt the "to" end (row of A); side 1: `v` fixed (column of A)."""
         out = C.c_int32()

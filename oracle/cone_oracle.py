@@ -469,16 +469,24 @@ class DenseSampler:
     def seed(self, s):
         self.rng.seed(s)
 
+    def _row(self, ix):
+        return self.A[ix, :]
+
+    def _col(self, ix):
+        return self.A[:, ix]
+
     def candidates(self, side, ix, level_id):
         L = len(self.levels)
         if self.labels_only:
             level_id = level_id % L
         elif len(self.levels_to_hide) > 0:
             level_id = level_id % (L - len(self.levels_to_hide) + 1)
-            level_id = sorted(set(range(L + 1)) - set(self.levels_to_hide))[level_id]
+            # the reference's own expression (oe_h.py:854): the list is in CPython's set ITERATION order -- ascending for the 4-level ETHEC,
+            # not for 8 levels with fewer than five slots left (fixture F4b: [8, 1, 2, 3]); the oracle is Python, so it evaluates the same expression
+            level_id = list(set(list(range(L + 1))) - set(self.levels_to_hide))[level_id]
         else:
             level_id = level_id % (L + 1)
-        c = np.where(self.A[ix, :] == 1)[0] if side == 0 else np.where(self.A[:, ix] == 1)[0]
+        c = np.where(self._row(ix) == 1)[0] if side == 0 else np.where(self._col(ix) == 1)[0]
         if self.pick_per_level:
             if level_id < L:
                 c = c[(c >= self.level_start[level_id]) & (c < self.level_stop[level_id])]
@@ -502,6 +510,59 @@ class DenseSampler:
                 neg[b, p] = self.draw(0, int(pos_from[b]), p)
                 neg[b, p + K] = self.draw(1, int(pos_to[b]), p)
         return neg
+
+
+class LazyDenseSampler(DenseSampler):
+    """DenseSampler without the matrix in memory: row `ix` / column `ix` of A = 1 - TC - I (oe_h.py:554-561) are written out per draw from the
+    node's descendant / ancestor set -- the same np.where scan over N + M bools as the reference, for hierarchies whose dense A (2.9 GB at
+    config 5's 54 096 nodes) should not travel with a test.  Pinned against the reference's own run over the real dense matrix: fixture F4b."""
+
+    def __init__(self, levels, label_edges, image_leaf=None, **kw):
+        N = int(sum(levels))
+        M = 0 if image_leaf is None else len(image_leaf)
+        self.n = N + M
+        par = [[] for _ in range(N)]
+        for u, v in label_edges:
+            par[int(v)].append(int(u))
+        memo = {}
+
+        def anc(v):                                          # iterative (an 8-level chain is shallow, a general DAG may not be)
+            stack = [v]
+            while stack:
+                w = stack[-1]
+                todo = [p for p in par[w] if p not in memo]
+                if todo:
+                    stack.extend(todo); continue
+                stack.pop()
+                if w not in memo:
+                    s = set()
+                    for p in par[w]:
+                        s.add(p); s |= memo[p]
+                    memo[w] = s
+            return memo[v]
+
+        self.anc = [None] * self.n
+        self.desc = [[] for _ in range(self.n)]
+        for v in range(N):
+            self.anc[v] = np.fromiter(sorted(anc(v)), dtype=np.int64)
+        for j in range(M):
+            leaf = int(image_leaf[j])
+            self.anc[N + j] = np.fromiter(sorted(anc(leaf) | {leaf}), dtype=np.int64)
+        for v in range(self.n):
+            for a in self.anc[v]:
+                self.desc[int(a)].append(v)
+        self.desc = [np.asarray(d, dtype=np.int64) for d in self.desc]
+        super().__init__(np.zeros((0, 0), dtype=bool), levels, n_labels=N, **kw)
+
+    def _row(self, ix):                                      # A[ix, :]: 0 at ix and at every v with a TC edge ix -> v
+        r = np.ones(self.n, dtype=bool)
+        r[self.desc[ix]] = 0; r[ix] = 0
+        return r
+
+    def _col(self, ix):                                      # A[:, ix]: 0 at ix and at every ancestor of ix
+        c = np.ones(self.n, dtype=bool)
+        c[self.anc[ix]] = 0; c[ix] = 0
+        return c
 
 
 def dense_negative_adjacency(n_labels, label_edges, image_leaf=None):

@@ -549,9 +549,9 @@ def test_config5_as_stated_b256_k256_fp16_table_chunked_cnn(dtype):
     """BASELINE.json configs[4] at its stated size on ONE GPU: 50 000-node 8-level hierarchy, 256 negatives per positive, ResNet-50,
     B = 256, "fp16+fp32-master" (the label table read from its fp16 shadow, bf16 conv stack with fp32 master weights).  K = 256 over
     8 levels draws 28 image negatives per positive: 7 424 CNN rows per step, pushed through the backbone in chunks (cnn_chunk).
-    Negatives bit-equal to the reference's stream (dense sampler restated on the same DAG would need a 2.9 GB matrix: the CSR
-    sampler is pinned against it at smaller sizes, here only the slot layout is asserted); loss / energies against the oracle
-    evaluated on the fp16-rounded table at the embedding boundary."""
+    Negatives of the WHOLE first batch (256 x 512) bit-equal to the reference's own stream over the real dense 54 096^2 matrix of this DAG (fixture
+    F4b, tests/golden/make_golden_sampler_s5.py), the second step's against the oracle's matrix-free sampler walking the same MT19937 stream on;
+    loss / energies against the oracle evaluated on the fp16-rounded table at the embedding boundary."""
     eng = StepEngine('cfg5', n_images=4096, dtype=dtype, table_dtype='fp16')
     assert eng.B == 256 and eng.K == 256 and eng.N == 50000 and eng.cnt == 28 and eng.n_rows == 256 * 29
     assert eng.cnn_chunk is not None and eng.table_h is not None
@@ -561,6 +561,12 @@ def test_config5_as_stated_b256_k256_fp16_table_chunked_cnn(dtype):
     B, N = eng.B, eng.N
     cols = np.asarray(eng.img_passes)
     assert (neg[:, cols] >= N).all() and (np.delete(neg, cols, axis=1)[:, :eng.K - len(cols)] < N).all()
+    z = np.load(os.path.join(GOLDEN, 'F4b_sampler_s5_step0.npz'))
+    assert np.array_equal(eng.img_leaf, z['image_leaf']) and np.array_equal(frm, z['pos_from']) and np.array_equal(to, z['pos_to'])
+    assert np.array_equal(neg, z['neg']), 'config 5: negatives of the first batch differ from the reference stream'
+    lazy = O.LazyDenseSampler(eng.labelmap.levels, sorted(eng.labelmap.edges), eng.labelmap.level_start[-1] + eng.img_leaf, pick_per_level=True)
+    lazy.rng.seed(0)
+    assert np.array_equal(lazy.draw_batch(frm, to, eng.K), neg)                   # the oracle walks step 0 (and stands where step 1 starts)
     neg_o = neg.astype(np.int64).copy()
     neg_o[:, cols] = N + B + np.arange(B)[:, None] * eng.cnt + np.arange(eng.cnt)[None, :]
     o = O.joint_loss_fwd_bwd(W16, eng.last_feats.float().cpu().numpy(), frm, N + np.arange(B), neg_o, eng.alpha, eng.K_cone)
@@ -569,6 +575,9 @@ def test_config5_as_stated_b256_k256_fp16_table_chunked_cnn(dtype):
     assert torch.equal(eng.table_h, eng.table.to(torch.float16))                  # the shadow follows the updated master
     l2 = eng.step(); torch.cuda.synchronize()
     assert torch.isfinite(l2)
+    frm1, to1, neg1 = eng.last[3:]
+    nb = 64
+    assert np.array_equal(lazy.draw_batch(frm1[:nb], to1[:nb], eng.K), neg1[:nb]), 'config 5: negatives of the second batch differ from the oracle stream'
     eng.close()
 
 

@@ -86,6 +86,34 @@ def test_F4_dense_sampler():
         assert got == case['out'], (case['hierarchy'], case['pick_per_level'], case['levels_to_hide'])
 
 
+def test_F4b_lazy_sampler_config5_hierarchy():
+    """The oracle's matrix-free mode (a row / column of A written out per draw) against the reference's run over the REAL dense 54 096^2 matrix of
+    config 5's hierarchy: every scripted case (level slots 0..8, both sides, labels and images, hidden-level remaps in CPython's set order) and the
+    first 24 positives x 512 draws of the engine's first batch.  Also: lazy == dense on a hierarchy small enough to hold both."""
+    f = json.load(open(os.path.join(GOLDEN, 'F4b_sampler_s5.json')))
+    z = np.load(os.path.join(GOLDEN, 'F4b_sampler_s5_step0.npz'))
+    levels = f['levels']; N = sum(levels)
+    edges = [(sum(levels[:l - 1]) + (c * levels[l - 1]) // levels[l], sum(levels[:l]) + c) for l in range(1, len(levels)) for c in range(levels[l])]
+    leaf = (N - levels[-1]) + z['image_leaf'].astype(np.int64)
+    assert np.array_equal(z['image_leaf'], (np.arange(f['n_images'], dtype=np.int64) * levels[-1]) // f['n_images'])
+    s = O.LazyDenseSampler(levels, edges, leaf)
+    for case in f['cases']:
+        s.pick_per_level = case['pick_per_level']; s.levels_to_hide = case['levels_to_hide']; s.seed(0)
+        got = [s.draw(side, ix, lvl) for side, ix, lvl in case['calls']]
+        assert got == case['out'], (case['pick_per_level'], case['levels_to_hide'])
+    s.pick_per_level = True; s.levels_to_hide = []; s.seed(0)
+    nb = 24
+    assert np.array_equal(s.draw_batch(z['pos_from'][:nb], z['pos_to'][:nb], int(z['K'])), z['neg'][:nb])
+    # lazy rows / columns == the dense matrix's
+    lv = [3, 7, 20]; n = sum(lv)
+    ed = [(sum(lv[:l - 1]) + (c * lv[l - 1]) // lv[l], sum(lv[:l]) + c) for l in range(1, 3) for c in range(lv[l])]
+    lf = [n - lv[-1] + (j * 7) % lv[-1] for j in range(31)]
+    A = O.dense_negative_adjacency(n, ed, lf)
+    lz = O.LazyDenseSampler(lv, ed, lf)
+    for ix in range(n + 31):
+        assert np.array_equal(lz._row(ix), A[ix, :]) and np.array_equal(lz._col(ix), A[:, ix])
+
+
 @pytest.mark.parametrize('tag', ['s3', 'ethec'])
 def test_F5_criterion(tag):
     f = load('F5_criterion.npz')

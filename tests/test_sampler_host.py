@@ -28,6 +28,54 @@ def test_F4_reference_stream():
         assert got == case['out'], (case['hierarchy'], case['pick_per_level'], case['levels_to_hide'])
 
 
+def _s5_graph(ppl=True):
+    f = json.load(open(os.path.join(GOLDEN, 'F4b_sampler_s5.json')))
+    z = np.load(os.path.join(GOLDEN, 'F4b_sampler_s5_step0.npz'))
+    lm = SyntheticLabelMap(f['levels'])
+    g = NegativeGraph.from_labelmap(lm, image_leaf=lm.level_start[-1] + z['image_leaf'].astype(np.int64), pick_per_level=ppl, seed=0)
+    return f, z, lm, g
+
+
+def test_F4b_reference_stream_config5_hierarchy():
+    """Config 5's DAG (8 levels, 50 000 labels, 4 096 images spread over the leaves as engine.StepEngine spreads them): the reference's own
+    sample_negative_edge over the real 54 096^2 dense matrix (tests/golden/make_golden_sampler_s5.py), every level slot 0..8 on both sides,
+    label and image end points, pick_per_level on / off, hidden-level remaps incl. the ones CPython's set iterates out of ascending order."""
+    f, z, lm, _ = _s5_graph()
+    assert lm.levels == SYNTHETIC['S5']
+    for case in f['cases']:
+        g = _s5_graph(case['pick_per_level'])[3]
+        g.set_levels_to_hide(case['levels_to_hide'])
+        got = [g.draw(side, ix, lvl) for side, ix, lvl in case['calls']]
+        assert got == case['out'], (case['pick_per_level'], case['levels_to_hide'])
+
+
+def test_F4b_reference_stream_config5_first_batch():
+    """The whole first batch of config 5 (B = 256 positives x 2K = 512 draws, random.seed(0)) as the reference's loop oe_h.py:940-957 drew it,
+    and the state of the MT19937 stream after it."""
+    f, z, lm, g = _s5_graph()
+    neg = g.draw_batch(z['pos_from'], z['pos_to'], int(z['K']))
+    assert neg.shape == (256, 512) and np.array_equal(neg, z['neg'])
+    assert [g.next_u32() for _ in range(4)] == z['stream_after'].tolist()
+
+
+def test_hidden_level_slot_order_is_cpythons_set_order():
+    """oe_h.py:854 indexes list(set(range(L+1)) - set(hidden)): the sampler reproduces CPython's iteration order of that set (checked against
+    this interpreter, which is the one the reference's fixtures were made with), for every hide set of 8 levels and samples of deeper ones."""
+    import itertools
+    assert list(set(list(range(9))) - {0, 4, 5, 6, 7}) == [8, 1, 2, 3]              # the case that is not ascending (F4b holds its stream)
+    for L in (2, 4, 8, 9, 16, 40):
+        g = NegativeGraph.from_labelmap(SyntheticLabelMap([2] * L))
+        assert g.visible_slots() == list(range(L + 1))
+        if L <= 9:
+            sets = [h for r in range(1, L + 1) for h in itertools.combinations(range(L + 1), r)]
+        else:
+            rs = random.Random(L)
+            sets = [tuple(rs.sample(range(L + 1), rs.randint(1, L))) for _ in range(1500)]
+        for hide in sets:
+            g.set_levels_to_hide(list(hide))
+            assert g.visible_slots() == list(set(list(range(L + 1))) - set(hide)), (L, hide)
+
+
 @pytest.mark.parametrize('tag', ['s3', 'ethec'])
 def test_F5_batch_negatives(tag):
     f = np.load(os.path.join(GOLDEN, 'F5_criterion.npz'))
