@@ -90,8 +90,11 @@ def cpu_baseline(eng, budget_s=25.0, rows=64):
     M = min(eng.M, 2048)                                       # dense (N+M)^2 bool matrix must stay small
     lm = eng.labelmap
     leaf = [lm.level_start[-1] + (j % lm.levels[-1]) for j in range(M)]
-    A = O.dense_negative_adjacency(N, sorted(lm.edges), leaf)
-    smp = O.DenseSampler(A, lm.levels, pick_per_level=True, seed=0)
+    if N + M <= 20000:
+        A = O.dense_negative_adjacency(N, sorted(lm.edges), leaf)
+        smp = O.DenseSampler(A, lm.levels, pick_per_level=True, seed=0)
+    else:                                                      # config 5's hierarchy: the dense matrix would be 2.7 GB; the same row / column scan, matrix-free
+        smp = O.LazyDenseSampler(lm.levels, sorted(lm.edges), leaf, pick_per_level=True, seed=0)
     W = eng.table.cpu().numpy().copy()
     m = np.zeros_like(W); v = np.zeros_like(W)
     cores = min(os.cpu_count() or 1, 32)                      # threads actually used (more only adds sync overhead at this size)
@@ -150,8 +153,9 @@ def measure(args, dtype, rank, world, stamp, primary):
     from learning_embeddings_amd import _lib
     from learning_embeddings_amd.engine import StepEngine, WORKLOADS
     from learning_embeddings_amd.resnet import conv_macs
+    table_dtype = args.table_dtype or ('fp16' if args.workload == 'cfg5' else 'fp32')
     eng = StepEngine(args.workload, dtype=dtype, sampler_mode=args.sampler, batch=args.batch, overlap_wgrad=False if args.no_overlap_wgrad else args.overlap_wgrad,
-                     use_graph=args.launch != 'eager', passes=args.passes)
+                     use_graph=args.launch != 'eager', passes=args.passes, table_dtype=table_dtype)
     dev = eng.device
     stamp('%s: engine built' % dtype)
     for i in range(args.warmup):
@@ -215,6 +219,12 @@ def measure(args, dtype, rank, world, stamp, primary):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
     stamp('%s: timed steps done' % dtype)
+    # per-step durations of the timed region: start-to-start intervals of consecutive steps' first HIP event (one stream, one clock) -> median beside the mean
+    step_ms = None
+    recs = eng.timers['records'][-args.steps:] if eng.timers is not None else []
+    if len(recs) >= 3:
+        iv = sorted(recs[i][0].elapsed_time(recs[i + 1][0]) for i in range(len(recs) - 1))
+        step_ms = {'median': round(iv[len(iv) // 2], 3), 'min': round(iv[0], 3), 'max': round(iv[-1], 3), 'p10': round(iv[len(iv) // 10], 3), 'p90': round(iv[(len(iv) * 9) // 10], 3), 'n': len(iv)}
     replicas_identical = None
     if world > 1 and not args.no_check_replicas:
         replicas_identical = True
@@ -371,7 +381,7 @@ def measure(args, dtype, rank, world, stamp, primary):
             for r_ in (roof_conv, roof_bn):
                 if r_ is not None:
                     r_['traffic_note'] = 'null: %s (re-run tools/prof_round4.sh + tools/make_step_traffic_round4.py)' % e
-    res = {'value': round(ips, 2), 'ms_per_step': round(dt / args.steps * 1e3, 3), 'dtype': 'f32' if f32 else dtype,
+    res = {'value': round(ips, 2), 'ms_per_step': round(dt / args.steps * 1e3, 3), 'step_ms': step_ms, 'dtype': 'f32' if f32 else dtype,
            'launch_mode': ('hipgraph (forward + loss + backward of a step replayed as one graph)' if graph_mode else 'eager')
                           + (' -- the faster of the two on this box in the warm-up probe: hipGraph %.2f, eager %.2f ms/step' % (launch_probe['hipgraph_ms_per_step'], launch_probe['eager_ms_per_step'])
                              if launch_probe else ''),
@@ -632,8 +642,8 @@ def measure_trainer(args, dtype, stamp, n_steps, n_warm):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)             # 10 warm-up + 50 timed steps
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='cfg3')
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'], help='precision of the headline measurement (fp32 = the reference\'s)')
     ap.add_argument('--secondary', default='bf16', choices=['bf16', 'none'], help='a second, disclosed measurement at narrower precision')
@@ -641,10 +651,13 @@ def main():
                     help='fp32 convolutions of the headline run: native = f32-input MFMA (exact fp32 fmaf chains); x3 = the same products on the bf16 matrix cores '
                          '(three bf16 pieces per operand, six exact products; fp32-grade error, see tests). Default native; x3 is reported as secondary_f32_split')
     ap.add_argument('--batch', type=int, default=None)
+    ap.add_argument('--table-dtype', default=None, choices=['fp32', 'fp16'],
+                    help='what the loss kernel reads the label rows from: the fp32 table, or its fp16 shadow (fp32 master, gradients and Adam moments). '
+                         'Default: fp16 for cfg5 (BASELINE.json configs[4]: "fp16+fp32-master"), fp32 otherwise')
     ap.add_argument('--sampler', default='replicated', choices=['replicated', 'per_rank'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-baseline-rows', type=int, default=64, help='CNN rows of the cpu_baseline step (64: the bounded sample of the default run; 512: the full workload, minutes)')
-    ap.add_argument('--cpu-baseline-budget', type=float, default=25.0, help='seconds of CPU work the cpu_baseline leg may spend after its warm-up step')
+    ap.add_argument('--cpu-baseline-rows', type=int, default=128, help='CNN rows of the cpu_baseline step (128: the bounded sample of the default run; 512: the full workload, minutes)')
+    ap.add_argument('--cpu-baseline-budget', type=float, default=40.0, help='seconds of CPU work the cpu_baseline leg may spend after its warm-up step')
     ap.add_argument('--no-stress', action='store_true')
     ap.add_argument('--no-overlap-wgrad', action='store_true', help='keep the conv weight-gradient kernels in line')
     ap.add_argument('--overlap-wgrad', action='store_true', default=None, help='weight gradients on their own HIP stream (default: only when the step runs as ONE pass)')
@@ -747,6 +760,8 @@ def main():
                           'parallelism': 'dp%d' % world, 'sampler': args.sampler,
                           'cnn_passes': ('%d concurrent passes of %d rows, one HIP stream each (BatchNorm batch = a pass: positives | image negatives, the reference\'s own separate forwards)' % (eng.passes, eng.n_rows // eng.passes)) if eng.passes > 1 else '1 pass of %d rows' % eng.n_rows,
                           'hbm_peak_allocated_gb': res['hbm_peak_allocated_gb'], 'launch_mode': res['launch_mode'], 'mean_loss': res['mean_loss']},
+               # per-step durations inside the timed region (HIP events, start to start): `ms_per_step` above is the wall-clock MEAN the contract asks for
+               'ms_per_step_median': (res['step_ms'] or {}).get('median'), 'step_ms': res['step_ms'],
                'phases_ms': res['phases_ms'],
                # `roofline`: the kernel family that dominates the step's time at this precision; the others ride along
                'roofline': dominant, 'roofline_conv': res['roofline_conv'], 'roofline_bn': res['roofline_bn'], 'roofline_cone': roof_cone,
@@ -783,6 +798,16 @@ def main():
             out['roofline_stress'] = st
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(eng, budget_s=args.cpu_baseline_budget, rows=args.cpu_baseline_rows)
+            if args.workload == 'cfg3' and args.cpu_baseline_rows < eng.n_rows:
+                # the same leg at the workload's FULL batch (512 CNN rows, one step of 43 s): measured once on an MI355X box's host, committed
+                try:
+                    full = json.load(open(os.path.join(ROOT, 'profiles', 'r04_cpu_baseline_full_512_rows.json')))
+                    full = full.get('cpu_baseline', full)
+                    out['cpu_baseline']['full_size_run'] = {'value': full['value'], 'unit': full['unit'], 'cores': full['cores'], 's_per_step': full['s_per_step'],
+                                                            'cnn_rows_per_step': full['cnn_rows_per_step'],
+                                                            'provenance': 'profiles/r04_cpu_baseline_full_512_rows.json: `python bench.py --cpu-baseline-rows 512 --cpu-baseline-budget 300` on a gpurun box in round 4 (not re-measured in this run)'}
+                except Exception:                              # noqa: BLE001
+                    pass
     eng.close()
     del eng
     torch.cuda.empty_cache()

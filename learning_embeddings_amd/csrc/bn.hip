@@ -15,31 +15,17 @@
 #include <hip/hip_bf16.h>
 #include <cstdlib>
 #include "lec_common.h"
+#include "tuning.h"
 
 namespace lec {
 
 struct alignas(16) bf16x8 { unsigned short v[8]; };
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// 16-byte streaming accesses.  They are non-temporal by default (LEC_BN_NT=0 to disable; measured +2.4 % on the bench step) (activations are touched once per pass and are far
-// larger than L2 / Infinity Cache; keeping them out of the caches leaves room for the small per-channel vectors).
-#ifndef LEC_BN_NT
-#define LEC_BN_NT 1
-#endif
-__device__ __forceinline__ u32x4 ld16(const void* p) {
-#if LEC_BN_NT
-  return __builtin_nontemporal_load((const u32x4*)p);
-#else
-  return *(const u32x4*)p;
-#endif
-}
-__device__ __forceinline__ void st16(void* p, u32x4 r) {
-#if LEC_BN_NT
-  __builtin_nontemporal_store(r, (u32x4*)p);
-#else
-  *(u32x4*)p = r;
-#endif
-}
+// 16-byte streaming accesses, non-temporal (measured: plain accesses cost the bench step 2.4 %): activations are touched once per pass and are far
+// larger than L2 / Infinity Cache; keeping them out of the caches leaves room for the small per-channel vectors.
+__device__ __forceinline__ u32x4 ld16(const void* p) { return __builtin_nontemporal_load((const u32x4*)p); }
+__device__ __forceinline__ void st16(void* p, u32x4 r) { __builtin_nontemporal_store(r, (u32x4*)p); }
 
 __device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float(((unsigned int)u) << 16); }
 __device__ __forceinline__ unsigned short f2bf(float f) {
@@ -90,14 +76,8 @@ struct EF32 {
   static __device__ __forceinline__ float rnd(float v) { return v; }
 };
 
-// LEC_BN_NUM_VGPR (build-time experiment, `make EXTRA=-DLEC_BN_NUM_VGPR=64`): cap the streaming kernels' registers so that their waves fit beside the two
-// 192 - 256-register convolution waves a SIMD of the OTHER pass stream holds.  MEASURED (round 3, same box, alternating, bench step): no cap 131.5 / 131.0 ms, 64 registers
-// 131.3, 96 registers 131.5 (no spills either way) -- room in the register file is not what keeps the step at the sum of its kernels' chip-time.  Off.
-#ifdef LEC_BN_NUM_VGPR
-#define LEC_BN_REGS __attribute__((amdgpu_num_vgpr(LEC_BN_NUM_VGPR)))
-#else
-#define LEC_BN_REGS
-#endif
+// (Register caps on the streaming kernels -- so that their waves fit beside the two 192 - 256-register convolution waves a SIMD of the OTHER pass stream holds --
+// were measured in round 3: 64 / 96 registers, no spills, bench step 131.3 / 131.5 ms against 131.0 - 131.5 uncapped.  Removed.)
 constexpr int kBnThreads = 256;
 constexpr int kBnMaxBlocks = 512;           // blocks of a reduction pass of this file
 constexpr int kBnMaxRows = 2048;            // partial rows the workspace holds (layout constant): a convolution's balanced form leaves one row per m-tile
@@ -110,8 +90,7 @@ constexpr int kBnMaxRows = 2048;            // partial rows the workspace holds 
 // theirs is placed (finalize launches of 230 us in the step's trace).  With 1536 blocks 8 slots per CU stay free.  MEASURED (round 4, same box, bench
 // step, three alternating runs each, ms): 2048: 126.45, 125.87, 125.56; 1536: 125.59, 125.27, 125.47; 1280: 125.24, 125.90, 125.29; 1024: 125.90, 125.97, 125.62.)
 static inline int bn_apply_cap() {                         // blocks of an apply pass (experiments: LEC_BN_BLOCKS)
-  static const int v = [] { const char* e = getenv("LEC_BN_BLOCKS"); const int x = e ? atoi(e) : 1536; return x > 0 ? x : 1536; }();
-  return v;
+  return tuning().bn_apply_blocks;
 }
 struct BnGeom { int CV, RPI, CVB, NCH, RPIB, nrb; };
 static inline BnGeom bn_geom(int64_t M, int C) {
@@ -149,7 +128,7 @@ __device__ __forceinline__ void block_reduce_rows(float (&acc)[NV][8], int CV, i
 // ---------------------------------------------------------------------------------------------------------------
 // forward, pass 1: per-block partial sum / sum of squares per channel -> part[rb][2][C]
 template <typename E>
-__global__ __launch_bounds__(kBnThreads) LEC_BN_REGS void bn_stats_kernel(const void* __restrict__ x, int64_t M, int C, int CV, int CVB,
+__global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const void* __restrict__ x, int64_t M, int C, int CV, int CVB,
                                                               int RPIB, float* __restrict__ part) {
   __shared__ float smem[kBnThreads * 8];
   const int tid = threadIdx.x;
@@ -192,10 +171,7 @@ __global__ __launch_bounds__(kBnThreads) LEC_BN_REGS void bn_stats_kernel(const 
 // Small blocks on purpose: these kernels are a few microseconds of latency-bound work that must find a free slot on a
 // GPU whose CUs are full of weight-gradient workgroups from the second stream; a 1024-thread block waited 30-60 us
 // for one CU to drain (rocprof, profiles/r01_*_final.md), a 4-wave block is placed at once.
-#ifndef LEC_BN_FIN_SPLIT
-#define LEC_BN_FIN_SPLIT 32
-#endif
-constexpr int kFinCh = 8, kFinSplit = LEC_BN_FIN_SPLIT, kFinThreads = kFinCh * kFinSplit;
+constexpr int kFinCh = 8, kFinSplit = 32, kFinThreads = kFinCh * kFinSplit;
 __device__ __forceinline__ void reduce_partials_256(const float* __restrict__ part, int nblk, int C, int c, int split,
                                                     double& s, double& q) {
   __shared__ double sh[2][kFinSplit][kFinCh + 1];
@@ -262,7 +238,7 @@ __global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, con
 // forward, pass 2: y = [relu]( x * scale + shift [+ residual] )
 // `mask` (optional, RELU only): one byte per thread-vector, bit j = [y_j > 0] -- backward reads it instead of y (1/16 the bytes)
 template <typename E, bool RES, bool RELU>
-__global__ __launch_bounds__(kBnThreads) LEC_BN_REGS void bn_apply_kernel(const void* __restrict__ x, const void* __restrict__ res,
+__global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const void* __restrict__ x, const void* __restrict__ res,
                                                               int64_t M, int CV, int RPI, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, void* __restrict__ y,
                                                               unsigned char* __restrict__ mask) {
@@ -315,7 +291,7 @@ __global__ __launch_bounds__(kBnThreads) LEC_BN_REGS void bn_apply_kernel(const 
 // pass 2 then reads this one tensor instead of dy, dy2 and the mask again (8.1 -> 7.1 bytes-units per element on the
 // forked block outputs).  The sums are taken over the rounded g so that both passes see the same values.
 template <typename E, int RELU>
-__global__ __launch_bounds__(kBnThreads) LEC_BN_REGS void bn_bwd_reduce_kernel(const void* __restrict__ dy, const void* __restrict__ dy2,
+__global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const void* __restrict__ dy, const void* __restrict__ dy2,
                                                                    const void* __restrict__ y,
                                                                    const void* __restrict__ x, int64_t M, int C, int CV,
                                                                    int CVB, int RPI, const float* __restrict__ mean,
@@ -414,7 +390,7 @@ __global__ void bn_bwd_coeffs_kernel(const float* __restrict__ part, int nblk, i
 
 // backward, pass 2: dx = gamma*invstd * (g - mean(g) - xhat * mean(g*xhat));  d residual = g
 template <typename E, bool RES, int RELU>
-__global__ __launch_bounds__(kBnThreads) LEC_BN_REGS void bn_bwd_apply_kernel(const void* __restrict__ dy, const void* __restrict__ dy2,
+__global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(const void* __restrict__ dy, const void* __restrict__ dy2,
                                                                   const void* __restrict__ y,
                                                                   const void* __restrict__ x, int64_t M, int CV, int RPI,
                                                                   const float* __restrict__ gamma, const float* __restrict__ mean,

@@ -34,26 +34,13 @@
 //
 // Roofline: MFMA (f32).  Algorithmic flops 2*M*N*K per launch; bytes are noise except for layer1's 1x1 layers.
 #include "conv_geo.h"
+#include "tuning.h"
 #include <mutex>
 #include <atomic>
 #include <map>
 #include <utility>
 
-#ifndef LEC_CF_UNCOND
-#define LEC_CF_UNCOND 0
-#endif
-#ifndef LEC_CF_PF2
-#define LEC_CF_PF2 0                   // forward / data gradient: operands fetched two chunks ahead (two register sets)
-#endif
-#ifndef LEC_WG_XF_BLOCKS
-#define LEC_WG_XF_BLOCKS 2             // workgroups per CU the on-load weight gradient is compiled for (4: 128 registers, a few spills)
-#endif
-
-#ifdef LEC_CF_NUM_VGPR                                        // build-time experiment: cap the forward / data-gradient kernels' registers
-#define LEC_CF_ACT_ATTR __attribute__((amdgpu_num_vgpr(LEC_CF_NUM_VGPR)))
-#else
-#define LEC_CF_ACT_ATTR
-#endif
+constexpr int kWgXfBlocks = 2;         // workgroups per CU the on-load weight gradient is compiled for (4: 128 registers, a few spills -- measured slower)
 
 namespace lec {
 
@@ -129,7 +116,7 @@ struct ActFuse {
 };
 
 template <bool B_KC, int WM, int WN, int TM, int TN, bool STATS, bool TAPV, int FUSE = 0>
-__global__ __launch_bounds__(kCfThreads, 2) LEC_CF_ACT_ATTR void conv_f32_act_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
+__global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
                                                                      float* __restrict__ dst, ActGeo g, float* __restrict__ part,
                                                                      ActFuse fz) {
 #include "conv_f32_act_body.inc"
@@ -166,17 +153,11 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_classes_kernel(con
 // them with sc1 loads only (CDNA4 guide 6 G16, form R1 -- an agent-scope release fence per slab writes back the XCD's whole L2 and cost 100 - 160 us
 // per launch on the 1x1 layers).  Scratch: 2 slots of BM x BN floats per workgroup + one counter per tile, registered per stream
 // (lec_conv_f32_scratch); counters are zero between launches (the finalizer re-arms its tile's counter).
-// (LEC_SK_LOAD_AUX / LEC_SK_STORE_AUX = 17: sc0 sc1 on the slab accesses, LEC_SK_ACQ = 1: an agent-scope acquire in front of the finalizer's loads -- built while
+// (sc0 sc1 on the slab accesses and the acquire below were first built while
 // chasing a 5.5e-3 gradient discrepancy that turned out to be ONE ReLU decision flipped by the different summation order; all three gave the same bits as the defaults.)
-#ifndef LEC_SK_LOAD_AUX
-#define LEC_SK_LOAD_AUX 16
-#endif
-#ifndef LEC_SK_STORE_AUX
-#define LEC_SK_STORE_AUX 16
-#endif
-#ifndef LEC_SK_ACQ
-#define LEC_SK_ACQ 1        // the finalizer's agent-scope ACQUIRE (round 4): it only invalidates this CU's L1 and runs in at most one workgroup per
-#endif                      // tile; with it the hand-off no longer leans on the sc1 loads alone (the relaxed ticket orders nothing by itself)
+constexpr int kSkLoadAux = 16, kSkStoreAux = 16;      // sc1 on the slab accesses
+// The finalizer takes an agent-scope ACQUIRE in front of its loads (round 4): it only invalidates this CU's L1 and runs in at most one workgroup per
+// tile; with it the hand-off no longer leans on the sc1 loads alone (the relaxed ticket orders nothing by itself).
 struct SkArgs { float* slots; unsigned int* counters; int ntn; int tiles; };
 
 template <bool B_KC, int TM, int TN, bool STATS, int FUSE>
@@ -306,7 +287,7 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_sk_kernel(const fl
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             f32x4v v; v[0] = acc[it][jt][4 * q]; v[1] = acc[it][jt][4 * q + 1]; v[2] = acc[it][jt][4 * q + 2]; v[3] = acc[it][jt][4 * q + 3];
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4r, v), rs_slots, (int)(mine + (unsigned)(((it * TN + jt) * 4 + q) * kCfThreads * 16)), 0, LEC_SK_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4r, v), rs_slots, (int)(mine + (unsigned)(((it * TN + jt) * 4 + q) * kCfThreads * 16)), 0, kSkStoreAux);
           }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -319,10 +300,8 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_sk_kernel(const fl
       __syncthreads();
       finalize = s_last != 0;
       if (finalize) {
-#if LEC_SK_ACQ
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         // the last arriver: every slab of the tile is in memory; EVERY load of them is an sc1 load (past this CU's L1, which no other CU's store
         // refreshes).  Fixed order: the sum does not depend on who finalizes.
 #pragma unroll
@@ -350,16 +329,16 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_sk_kernel(const fl
           const unsigned s0 = slab(w), s1 = slab(w + 1);
           f32x4v v0[NQ], v1[NQ];
 #pragma unroll
-          for (int i = 0; i < NQ; ++i) v0[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_slots, (int)(s0 + (unsigned)(i * kCfThreads * 16)), 0, LEC_SK_LOAD_AUX));
+          for (int i = 0; i < NQ; ++i) v0[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_slots, (int)(s0 + (unsigned)(i * kCfThreads * 16)), 0, kSkLoadAux));
 #pragma unroll
-          for (int i = 0; i < NQ; ++i) v1[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_slots, (int)(s1 + (unsigned)(i * kCfThreads * 16)), 0, LEC_SK_LOAD_AUX));
+          for (int i = 0; i < NQ; ++i) v1[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_slots, (int)(s1 + (unsigned)(i * kCfThreads * 16)), 0, kSkLoadAux));
           add(v0); add(v1);
         }
         if (w <= wb_) {
           const unsigned s0 = slab(w);
           f32x4v v0[NQ];
 #pragma unroll
-          for (int i = 0; i < NQ; ++i) v0[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_slots, (int)(s0 + (unsigned)(i * kCfThreads * 16)), 0, LEC_SK_LOAD_AUX));
+          for (int i = 0; i < NQ; ++i) v0[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_slots, (int)(s0 + (unsigned)(i * kCfThreads * 16)), 0, kSkLoadAux));
           add(v0);
         }
       }
@@ -525,7 +504,7 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_sk_kernel(const fl
 // the source pixel of output pixel m = (n, ho, wo) under tap (r, s) is 4 m - 2 wo + const -- affine in m but for the column wo, which every B piece
 // reads from a second wrapped table ((i mod Wo) * bytes) at "scalar column of the chunk's first row + own row", one chunk ahead like the A side.
 template <int WM, int WN, int TM, int TN, int WBK, bool DENSE, bool XF = false, bool SM = false, int SH = 0>
-__global__ __launch_bounds__(kCfThreads, (XF && WM <= 2 && TM * TN == 4) ? LEC_WG_XF_BLOCKS : 2) void conv_f32_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(kCfThreads, (XF && WM <= 2 && TM * TN == 4) ? kWgXfBlocks : 2) void conv_f32_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                        float* __restrict__ dw, WgGeo g, const float* __restrict__ xsrc = nullptr,
                                                                        const float* __restrict__ coef = nullptr) {
   static_assert(!XF || DENSE, "the on-load BatchNorm form serves the dense (1x1 / stride 1) layers");
@@ -737,15 +716,9 @@ __global__ __launch_bounds__(kCfThreads, (XF && WM <= 2 && TM * TN == 4) ? LEC_W
     for (int ch = ch_lo; ch < ch_hi; ++ch) {
       const int buf = (ch - ch_lo) & 1;
       const float* sA = smem + buf * (SA + SB);
-#if LEC_CF_UNCOND
-      load_chunk(ch + 1);                                       // (past ch_hi: the next split's rows, or out of range; never read back)
-      mma_chunk<false, false, BM, BN, TM, TN, WBK>(sA, sA + SA, wm0, wn0, lane, acc);
-      store_chunk(buf ^ 1);
-#else
       if (ch + 1 < ch_hi) load_chunk(ch + 1);
       mma_chunk<false, false, BM, BN, TM, TN, WBK>(sA, sA + SA, wm0, wn0, lane, acc);
       if (ch + 1 < ch_hi) store_chunk(buf ^ 1);
-#endif
       __syncthreads();
     }
     const int l31 = lane & 31, h = lane >> 5;
@@ -790,11 +763,10 @@ static inline bool sk_lookup(hipStream_t st, SkScratch* out) {
 // the kernel applies (tests).
 // The entry points' `schedule` argument (LEC_SCHEDULE_*) decides per call; LEC_SCHEDULE_DEFAULT (-1) defers to the environment.
 static inline int sk_mode(int schedule) {
-  static const int env = [] { const char* e = getenv("LEC_CF_SK"); return e ? atoi(e) : 1; }();
-  return schedule >= 0 ? (schedule > 2 ? 2 : schedule) : env;
+  return schedule >= 0 ? (schedule > 2 ? 2 : schedule) : tuning().cf_sk;
 }
-static inline double sk_fill() { static const double v = [] { const char* e = getenv("LEC_CF_SK_FILL"); return e ? atof(e) : 0.92; }(); return v; }
-static inline int sk_min_chunks() { static const int v = [] { const char* e = getenv("LEC_CF_SK_MIN_CHUNKS"); return e ? atoi(e) : 8; }(); return v; }
+static inline double sk_fill() { return tuning().cf_sk_fill; }
+static inline int sk_min_chunks() { return tuning().cf_sk_min_chunks; }
 
 template <bool B_KC, bool STATS, int FUSE = 0>
 static int launch_act(const float* src, const float* wgt, float* dst, const ActGeo& g, float* part, int* nparts, hipStream_t st,
@@ -842,7 +814,7 @@ static int launch_act(const float* src, const float* wgt, float* dst, const ActG
   // MEASURED (round 3, same box, alternating runs, 512 images): forward / data gradient of nine layer shapes identical to +-1 % with and
   // without (3x3 128 -> 128 @28: 961 / 966 us forward, 961 / 960 us data gradient; 256 -> 256 @14: 1012 / 1013, 1019 / 1019), bench step 131.3 - 131.6 ms
   // with, 130.9 without: the re-reads the round-robin order causes are served by the Infinity Cache at no cost to the matrix pipe.
-  static const int cf_xcd = [] { const char* e = getenv("LEC_CF_XCD"); return e ? atoi(e) : 0; }();
+  const int cf_xcd = tuning().cf_xcd;
   ActGeo gg = g;
   gg.xcd_per = 0;
   if (cf_xcd && mtiles >= 64) {
@@ -853,7 +825,7 @@ static int launch_act(const float* src, const float* wgt, float* dst, const ActG
     if (gx > 8 * gg.xcd_per) gx = 8 * gg.xcd_per;
   }
   size_t lds = (size_t)2 * (BM * kCfLdk + (B_KC ? BN * kCfLdk : kCfBK * BN)) * 4;      // 74 / 55 KB: two workgroups per CU
-  if (const char* e = getenv("LEC_CF_LDS_PAD")) lds += (size_t)atoi(e);                // experiments: force one workgroup per CU
+  if (tuning().cf_lds_pad > 0) lds += (size_t)tuning().cf_lds_pad;                     // experiments: force one workgroup per CU
   const bool tapv = g.Cs % kCfBK != 0;                          // source channels narrower than a chunk (the stem)
   LEC_CHECK_ARG(tapv || g.na * g.nb <= 32, "conv_f32: more than 32 taps per launch need the per-piece tap path");
   if constexpr (FUSE == 4) {
@@ -952,7 +924,7 @@ extern "C" int lec_conv_f32_dgrad(const float* dy, const float* w, int N, int H,
   // a 1x1 / stride-2 layer with an even input grid: only the (0, 0) parity class has a tap; its launch also writes the zeros of the other three
   const bool one_launch = stride == 2 && R == 1 && S == 1 && pad == 0 && H % 2 == 0 && W % 2 == 0;
   // every other strided layer whose chunks lie inside one tap: its parity classes as ONE grid (conv_f32_act_classes_kernel).  LEC_DGRAD_CLASSES=0: one launch per class
-  static const int dg_classes = [] { const char* e = getenv("LEC_DGRAD_CLASSES"); return e ? atoi(e) : 1; }();
+  const int dg_classes = tuning().dgrad_classes;
   const bool merged = dg_classes && stride == 2 && !one_launch && Cout % kCfBK == 0;
   ActGeoSet gs; int ncls = 0;
   for (int ph = 0; ph < (one_launch ? 1 : stride); ++ph) {
@@ -1071,7 +1043,7 @@ static int conv_f32_wgrad_impl(const float* dy, const float* x, int N, int H, in
   const bool dense = R == 1 && S == 1 && stride == 1 && pad == 0;
   // tile (BM over Cout) x (BN over R*S*Cin), chunk width WBK: gathered layers 64 x 256; dense 1x1 layers whatever fits their shape
   int BM = 64, BN = 256, WBK = kWgBK;
-  static const int wg_dense_tile = [] { const char* e = getenv("LEC_WGRAD_DENSE_TILE"); return e ? atoi(e) : 1; }();
+  const int wg_dense_tile = tuning().wg_dense_tile;
   // dense 1x1 layers: 128 x 128 wherever it fits (round 4: 2 - 4 % under the 64 x 256 tile on all eleven shapes of ResNet-50, e.g. 256 -> 128 @56 910 -> 881 us,
   // 512 -> 128 @28 453 -> 435, 1024 -> 512 @14 811 -> 781).  LEC_WGRAD_DENSE_TILE: 0 = the round-3 rule, 2 = 128 x 256 (experiment).
   if (dense && !xf && wg_dense_tile == 2 && Cout % 128 == 0 && g.Ng % 256 == 0) { BM = 128; BN = 256; }
@@ -1088,11 +1060,11 @@ static int conv_f32_wgrad_impl(const float* dy, const float* x, int N, int H, in
   // strided 1x1 (downsample) 920 -> 870 / 898 -> 869; 3x3 512 -> 512 @7 1126 -> 1154 (worse: left on the 64-row tile).  223 VGPRs instead
   // of 128: beside this variant no BatchNorm wave fits a SIMD, so the step gains less than the kernels (144.4 -> 144.0 ms).
   // LEC_WGRAD_BM128 = 0: off, 2: every eligible layer.
-  static const int wg_bm128 = [] { const char* e = getenv("LEC_WGRAD_BM128"); return e ? atoi(e) : 1; }();
+  const int wg_bm128 = tuning().wg_bm128;
   // Shifted-dense form (see the kernel): stride-1 layers whose output grid is their input grid, tile inside one tap.  LEC_WGRAD_SHIFT=0: off.
-  static const int wg_shift = [] { const char* e = getenv("LEC_WGRAD_SHIFT"); return e ? atoi(e) : 1; }();
+  const int wg_shift = tuning().wg_shift;
   const bool same1 = stride == 1 && g.Ho == H && g.Wo == W && R * S > 1, half2 = stride == 2 && H == 2 * g.Ho && W == 2 * g.Wo;
-  static const int wg_shift64 = [] { const char* e = getenv("LEC_WGRAD_SHIFT64"); return e ? atoi(e) : 1; }();       // the 64 -> 64 3x3 layers on a 64 x 64 tile: 1376 - 1412 -> 1103 - 1122 us @56 (library 1290 - 1305)
+  const int wg_shift64 = tuning().wg_shift64;       // the 64 -> 64 3x3 layers on a 64 x 64 tile: 1376 - 1412 -> 1103 - 1122 us @56 (library 1290 - 1305)
   const bool shifted = wg_shift && !dense && !xf && (same1 || (half2 && wg_shift != 3)) && R * S <= 16 && (Cin >= 128 || (wg_shift64 && Cin == 64 && Cout == 64 && stride == 1)) && dCin == Cin
                        && g.HoWo >= 32 && g.Wo >= 2 && Cout % 64 == 0 && (Cout % 128 == 0 || Cin >= 256 || Cin == 64);      // (the column tile must lie inside one tap)
   if (shifted) {
@@ -1103,12 +1075,12 @@ static int conv_f32_wgrad_impl(const float* dy, const float* x, int N, int H, in
   if (big) BM = 128;
   const int tiles = ((Cout + BM - 1) / BM) * ((g.Ng + BN - 1) / BN);
   const int nchunks = (g.Mpix + WBK - 1) / WBK;
-  static const int wg_target = [] { const char* e = getenv("LEC_WGRAD_ITEMS"); const int v = e ? atoi(e) : 1024; return v > 0 ? v : 1024; }();
+  const int wg_target = tuning().wg_items;
   // K split: work items = tiles x split.  The items of a launch should fill the resident workgroup slots a WHOLE number of times: with
   // split = ceil(target / tiles) (round 2) 18 tiles gave 18 x 57 = 1 026 items for 1 024 slots -- two items alone in a third round, a fifth
   // of the launch -- and 5 tiles 1 025.  Round DOWN (LEC_WGRAD_SPLIT_FLOOR=0: the old rule): at most `target` items, and `target` is a
   // multiple of the slots of every variant (512 for the 223-register 128 x 256 tile, 1 024 for the others).
-  static const int wg_floor = [] { const char* e = getenv("LEC_WGRAD_SPLIT_FLOOR"); return e ? atoi(e) : 1; }();
+  const int wg_floor = tuning().wg_split_floor;
   int split = wg_floor ? wg_target / tiles : (wg_target + tiles - 1) / tiles;
   if (split > nchunks) split = nchunks;
   if (split < 1) split = 1;
@@ -1120,15 +1092,15 @@ static int conv_f32_wgrad_impl(const float* dy, const float* x, int N, int H, in
   // HBM-bound BatchNorm kernels (this kernel runs on the side stream) find no registers to land on.  14336 extra bytes keep it at two workgroups
   // per CU: BatchNorm 61.6 -> 52.2 ms inside the step, these kernels 44 -> 47.5 ms, the step 157.5 -> 155.8 ms (same-box A/B, 1 %); left off by
   // default: within the box-to-box spread, and it stretches every convolution's in-step duration.
-  static const int wg_lds_pad = [] { const char* e = getenv("LEC_WGRAD_LDS_PAD"); return e ? atoi(e) : 0; }();
+  const int wg_lds_pad = tuning().wg_lds_pad;
   if (wg_lds_pad > 0) lds += (size_t)wg_lds_pad;
-  static const int wg_cap = [] { const char* e = getenv("LEC_WGRAD_WGS"); const int v = e ? atoi(e) : (1 << 30); return v > 0 ? v : (1 << 30); }();
+  const int wg_cap = tuning().wg_wgs;
   const int total = 8 * ((tiles * split + 7) / 8);              // slots (see the kernel's slot -> item map)
   const dim3 grid(total < wg_cap ? total : wg_cap), blk(kCfThreads);
   hipStream_t st = (hipStream_t)stream;
   const float* nof = nullptr;
   // scalar bounds masks: a 256-column tile must span at most 4 taps (Cin >= 64; the stem's 4 channels keep the vector test)
-  static const int wg_sm = [] { const char* e = getenv("LEC_WGRAD_SMASK"); return e ? atoi(e) : 0; }();
+  const int wg_sm = tuning().wg_smask;
   const bool sm = !dense && Cin >= 64 && wg_sm != 0;
   if (xf) {
     LEC_CHECK_ARG(dense, "conv_f32_wgrad_fused: dense layers only");

@@ -32,6 +32,7 @@
 // Roofline: MFMA (bf16 dense, 2.5 PFLOP/s) on 6x the algorithmic flops.
 #include <type_traits>
 #include "conv_geo.h"
+#include "tuning.h"
 
 namespace lec {
 
@@ -44,15 +45,7 @@ constexpr int kX3Row = 32;                // bytes of an LDS row of one plane (1
 constexpr int kX3Threads = 512;           // 4 consumer + 4 producer waves
 constexpr int kX3ActProd = 256;            // producer threads of the activation-gather kernel (two producer waves per SIMD were tried: no gain)
 constexpr int kX3ActThreads = 256 + kX3ActProd;
-#ifndef LEC_X3_PRIO
-#define LEC_X3_PRIO 1
-#endif
-#ifndef LEC_X3_TRUNC
-#define LEC_X3_TRUNC 1                    // pieces by truncation (default) or by round-to-nearest (0): see split_pair
-#endif
-#ifndef LEC_X3_DBG
-#define LEC_X3_DBG 0                      // experiments (wrong results): 1 no split arithmetic, 2 producers idle, 4 no MFMAs, 8 no fragment reads
-#endif
+constexpr int kX3Prio = 1;                // s_setprio of the consumer waves (the second-dispatched half of a workgroup loses the VALU arbitration otherwise)
 constexpr int kX3KQ = kX3BK / 4;          // 16-byte fp32 pieces per row of an activation tile
 
 // Pre-split weights are stored TILE-MAJOR: [n tile][k chunk][plane h|m|l][BN rows][16 k] bf16, so that the B operand of one step is one
@@ -60,34 +53,17 @@ constexpr int kX3KQ = kX3BK / 4;          // 16-byte fp32 pieces per row of an a
 struct X3Wgt { int KC; };                 // k chunks per n tile
 static inline int x3_bn(int cols) { return cols <= 64 ? 64 : 128; }
 
-// Round-to-nearest-even bf16 of two floats, packed (v_cvt_pk_bf16_f32): lo -> bits 0..15, hi -> bits 16..31
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-  f32x2v v; v[0] = lo; v[1] = hi;
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
-}
-
 // (x0, x1) -> the packed h | m | l pieces of both: x = h + m + l exactly (every subtraction is exact in fp32).  11 vector instructions
-// per pair.  Default: TRUNCATED pieces (v_and_b32 to cut, v_perm_b32 to pack): the products the kernels drop (m*l, l*m, l*l) are below
-// 2^-23 of the product.  LEC_X3_TRUNC=0 rounds each piece to nearest (v_cvt_pk_bf16_f32 + shifts): dropped products below 2^-25 and of
-// either sign, but 12-20 % slower kernels (measured: the convert and the unpack shifts cost more issue time than and / perm) for no
-// measurable change of the error against fp64 (tests/test_fp32_gpu.py): truncation is the default.
+// per pair.  TRUNCATED pieces (v_and_b32 to cut, v_perm_b32 to pack): the products the kernels drop (m*l, l*m, l*l) are below
+// 2^-23 of the product.  (Pieces rounded to nearest -- v_cvt_pk_bf16_f32 + shifts: dropped products below 2^-25 and of either sign -- made the
+// kernels 12-20 % slower for no measurable change of the error against fp64; removed.)
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-#if LEC_X3_TRUNC
   const unsigned a0 = __float_as_uint(x0), a1 = __float_as_uint(x1);
   const float q0 = x0 - __uint_as_float(a0 & 0xffff0000u), q1 = x1 - __uint_as_float(a1 & 0xffff0000u);
   const unsigned b0 = __float_as_uint(q0), b1 = __float_as_uint(q1);
   const float s0 = q0 - __uint_as_float(b0 & 0xffff0000u), s1 = q1 - __uint_as_float(b1 & 0xffff0000u);
   h = __builtin_amdgcn_perm(a1, a0, 0x07060302u); m = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
   l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
-  return;
-#endif
-  h = cvt_pk_bf16(x0, x1);
-  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-  m = cvt_pk_bf16(r0, r1);
-  const float l0 = r0 - __uint_as_float(m << 16), l1 = r1 - __uint_as_float(m & 0xffff0000u);
-  l = cvt_pk_bf16(l0, l1);
 }
 
 // x[0..3] -> three planes of 4 bf16 (2 dwords each)
@@ -98,12 +74,9 @@ __device__ __forceinline__ void split4(const f32x4v x, u32x2v& h, u32x2v& m, u32
   split_pair(x2, x3, a, b, c); h[1] = a; m[1] = b; l[1] = c;
 }
 
-// LEC_X3_NPROD: 6 (default) drops m l, l m (<= 2^-24 of the product each, truncated pieces) and l l (2^-32); 8 keeps the first two, so that
-// every dropped term is below 2^-32 -- far under one fp32 rounding (A/B builds: make EXTRA=-DLEC_X3_NPROD=8).
-#ifndef LEC_X3_NPROD
-#define LEC_X3_NPROD 6
-#endif
-constexpr int kX3NP = LEC_X3_NPROD;
+// Six products: m l, l m (<= 2^-24 of the product each, truncated pieces) and l l (2^-32) are dropped.  (Eight -- every dropped term below 2^-32,
+// far under one fp32 rounding -- gives the same error against fp64 in every digit: tests/test_fp32_gpu.py's bound is the fp32 accumulation's.)
+constexpr int kX3NP = 6;
 static_assert(kX3NP == 6 || kX3NP == 8, "six or eight products");
 // the products of one 32 x 32 x 16 step, small terms first
 __device__ __forceinline__ f32x16 mma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
@@ -170,7 +143,7 @@ __device__ __forceinline__ void x3_consumer_loop(const char* __restrict__ smem, 
   // prologue / tail steps: every part conditional, barrier at the end of odd steps
   auto slow_step = [&](int t, auto j_c) __attribute__((always_inline)) {
     constexpr int J = decltype(j_c)::value;                     // = t & 3; fragments of chunk t - 2 go to set J & 1, chunk t - 3's are in set (J & 1) ^ 1
-    if (t >= 2 && t <= Q + 1 && !(LEC_X3_DBG & 8)) {
+    if (t >= 2 && t <= Q + 1) {
       const char* sA = chunk_base(j_c);
       x3_read_frags<BM, BN, TM, TN>(sA, sA + SA, wm0, wn0, lane, fa[J & 1], fb[J & 1]);
     }
@@ -179,7 +152,7 @@ __device__ __forceinline__ void x3_consumer_loop(const char* __restrict__ smem, 
       for (int it = 0; it < TM; ++it)
 #pragma unroll
         for (int jt = 0; jt < TN; ++jt)
-          if (!(LEC_X3_DBG & 4)) acc[it][jt] = mma6(fa[(J & 1) ^ 1][it], fb[(J & 1) ^ 1][jt], acc[it][jt]);
+          acc[it][jt] = mma6(fa[(J & 1) ^ 1][it], fb[(J & 1) ^ 1][jt], acc[it][jt]);
       tile_end();
     }
     if (J & 1) x3_barrier();
@@ -190,7 +163,7 @@ __device__ __forceinline__ void x3_consumer_loop(const char* __restrict__ smem, 
     constexpr int J = decltype(j_c)::value;
     constexpr int RS = J & 1, MS = RS ^ 1;                      // register sets: read into RS, multiply from MS
     const char* sA = chunk_base(j_c);
-    if (!(LEC_X3_DBG & 8)) x3_read_frags<BM, BN, TM, TN>(sA, sA + SA, wm0, wn0, lane, fa[RS], fb[RS]);
+    x3_read_frags<BM, BN, TM, TN>(sA, sA + SA, wm0, wn0, lane, fa[RS], fb[RS]);
     constexpr int PA[8] = {1, 2, 2, 0, 1, 1, 0, 0}, PB[8] = {2, 1, 0, 2, 1, 0, 1, 0};   // small terms first (as mma6); six products: from index 2
     constexpr int P0 = 8 - kX3NP;
 #pragma unroll
@@ -199,7 +172,7 @@ __device__ __forceinline__ void x3_consumer_loop(const char* __restrict__ smem, 
       for (int it = 0; it < TM; ++it)
 #pragma unroll
         for (int jt = 0; jt < TN; ++jt)
-          if (!(LEC_X3_DBG & 4)) acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[MS][it][PA[p]], fb[MS][jt][PB[p]], acc[it][jt], 0, 0, 0);
+          acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[MS][it][PA[p]], fb[MS][jt][PB[p]], acc[it][jt], 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 3 * (TM + TN); ++i) {                    // one LDS read, one MFMA, ...
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -215,7 +188,7 @@ __device__ __forceinline__ void x3_consumer_loop(const char* __restrict__ smem, 
     for (int it = 0; it < TM; ++it)
 #pragma unroll
       for (int jt = 0; jt < TN; ++jt)
-        if (!(LEC_X3_DBG & 4)) acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[MS][it][PA[7]], fb[MS][jt][PB[7]], acc[it][jt], 0, 0, 0);
+        acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[MS][it][PA[7]], fb[MS][jt][PB[7]], acc[it][jt], 0, 0, 0);
     tile_end();
   };
   using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
@@ -259,7 +232,7 @@ __global__ __launch_bounds__(kX3ActThreads) void conv_f32x3_act_kernel(const flo
 
   if (producer) {
     if (Q == 0) return;
-    if (LEC_X3_PRIO) __builtin_amdgcn_s_setprio(LEC_X3_PRIO);  // the second-dispatched half of a workgroup loses the VALU arbitration otherwise
+    __builtin_amdgcn_s_setprio(kX3Prio);  // the second-dispatched half of a workgroup loses the VALU arbitration otherwise
     const int ptid = tid - kCfThreads;
     const int kqA = ptid & (kX3KQ - 1), rowA = ptid / kX3KQ;
     const rsrc_t rs_src = make_rsrc(src, g.src_bytes), rs_wgt = make_rsrc(wpl, g.wgt_bytes);
@@ -371,7 +344,7 @@ __global__ __launch_bounds__(kX3ActThreads) void conv_f32x3_act_kernel(const flo
     // stay four chunks ahead -- with a guard it falls back to vmcnt(0) at every step.
     auto step = [&](auto i_c) __attribute__((always_inline)) {
       constexpr int I = decltype(i_c)::value;
-      if (!(LEC_X3_DBG & 2)) {
+      {
         char* base = smem_x3 + I * SBUF;                         // stage I >> 1, half I & 1 (a stage = two chunks)
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
@@ -389,7 +362,7 @@ __global__ __launch_bounds__(kX3ActThreads) void conv_f32x3_act_kernel(const flo
       }
       if (I & 1) x3_barrier();                                  // a stage is complete
     };
-    if (!(LEC_X3_DBG & 2)) {                                    // the first four chunks, in the order the loop issues them
+    {                                    // the first four chunks, in the order the loop issues them
       using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
             using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
       issueB(I0{}); if (TAPV) issueA_tapv(I0{}, I0{});
@@ -554,7 +527,7 @@ __global__ __launch_bounds__(kX3Threads) void conv_f32x3_wgrad_kernel(const floa
   if (Q == 0) return;
 
   if (wave >= 4) {
-    if (LEC_X3_PRIO) __builtin_amdgcn_s_setprio(LEC_X3_PRIO);
+    __builtin_amdgcn_s_setprio(kX3Prio);
     const int pw = wave - 4;
     const bool isB = pw >= 2;                                   // (wave-uniform)
     const int oct = pw & 1;
@@ -727,7 +700,7 @@ static int launch_act_x3(const float* src, const uint16_t* wpl, float* dst, cons
   const bool narrow = g.Cd <= 64;
   const int BM = narrow ? 256 : 128, BN = narrow ? 64 : 128;
   const int mtiles = (g.Mg + BM - 1) / BM, ntiles = (g.Cd + BN - 1) / BN;
-  static const int wgs = [] { const char* e = getenv("LEC_X3_WGS"); const int v = e ? atoi(e) : 256; return v > 0 ? v : 256; }();
+  const int wgs = tuning().x3_wgs;
   int gx = (wgs + ntiles - 1) / ntiles;
   if (gx > mtiles) gx = mtiles;
   if (STATS && gx > kCfMaxPart) gx = kCfMaxPart;
@@ -843,14 +816,14 @@ extern "C" int lec_conv_f32x3_wgrad(const float* dy, const float* x, int N, int 
   g.dWo = make_fastdiv(g.Wo); g.dHo = make_fastdiv(g.Ho); g.dS = make_fastdiv(S);
   const bool dense = R == 1 && S == 1 && stride == 1 && pad == 0;
   g.tiles_n = (g.Ng + 127) / 128; g.tiles = ((Cout + 127) / 128) * g.tiles_n;
-  static const bool force_narrow = getenv("LEC_X3_FORCE_NARROW") != nullptr;   // experiments
+  const bool force_narrow = tuning().x3_force_narrow != 0;   // experiments
   const bool narrow = Cin < 128 || Cout < 128 || force_narrow;   // 64-channel layers: half-empty tiles, two taps per column tile
   const int nchunks = (g.Mpix + kX3BK - 1) / kX3BK;
-  static const int wgs = [] { const char* e = getenv("LEC_X3_WGS"); const int v = e ? atoi(e) : 256; return v > 0 ? v : 256; }();
+  const int wgs = tuning().x3_wgs;
   // K split: accumulation chains of at most 512 chunks (8192 pixels: the rounding error of a longer fp32 chain shows against fp64),
   // and among the splits up to ~2048 work items the one that fills the last round of workgroups best (fewest atomics on a tie)
   int best = 1; double best_eff = -1.0;
-  static const int chain = [] { const char* e = getenv("LEC_X3_CHAIN"); const int v = e ? atoi(e) : 512; return v > 0 ? v : 512; }();
+  const int chain = tuning().x3_chain;
   const int smin = (nchunks + chain - 1) / chain;
   for (int sp = smin < 1 ? 1 : smin; sp <= nchunks && (sp == smin || (int64_t)g.tiles * sp <= 2048); ++sp) {
     const int items = g.tiles * sp;

@@ -18,10 +18,7 @@ constexpr int kCfRP = 256 / kCfKQ;        // rows staged per pass of the 256 thr
 constexpr int kCfThreads = 256;
 constexpr int kCfMaxPart = 512;           // statistics partial rows of the tile-walk kernels (the buffer a caller passes holds this many)
 constexpr int kCfMaxRows = 2048;          // = kBnMaxRows: rows the BatchNorm workspace holds; the balanced kernel leaves one row per m-tile
-#ifndef LEC_WG_BK
-#define LEC_WG_BK 16
-#endif
-constexpr int kWgBK = LEC_WG_BK;          // K chunk of the weight gradient (pixels): 16 -> 40 KB of LDS per workgroup
+constexpr int kWgBK = 16;                 // K chunk of the weight gradient (pixels): 16 -> 40 KB of LDS per workgroup
 constexpr unsigned kOob = 0x80000000u;    // a byte offset no tensor reaches (num_records < 2^31): the load returns zeros, the store is dropped
 
 // exact unsigned division by a launch-invariant divisor (Granlund-Montgomery round-up form: exact for every 32-bit dividend)
@@ -47,11 +44,9 @@ __device__ __forceinline__ f32x4v bload4(rsrc_t rsrc, unsigned voff) {
   const u32x4r v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0);
   return __builtin_bit_cast(f32x4v, v);
 }
-#ifndef LEC_CF_STORE_AUX
-#define LEC_CF_STORE_AUX 0          // cache policy of the convolutions' output stores (gfx942+ aux bits: 1 = sc0, 2 = nt, 16 = sc1): see bstore1
-#endif
+constexpr int kCfStoreAux = 0;      // cache policy of the convolutions' output stores (gfx942+ aux bits: 1 = sc0, 2 = nt, 16 = sc1; none changed the finalize waits: EXPERIMENTS.md)
 __device__ __forceinline__ void bstore1(float v, rsrc_t rsrc, unsigned voff) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)voff, 0, LEC_CF_STORE_AUX);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)voff, 0, kCfStoreAux);
 }
 
 // geometry of an "activation-gather" GEMM (forward, or one parity class of a data gradient)

@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <hip/hip_bf16.h>
 #include "lec_common.h"
+#include "tuning.h"
+#include <atomic>
 
 namespace lec {
 
@@ -273,11 +275,11 @@ static int launch_conv1x1(const void* x, const void* w, int64_t M, int Ntot, voi
   constexpr int WAVES = (FOLD != 1 && K <= 128 && ((size_t)N * (K + 8) + 8 * 32 * (64 + 8)) * sizeof(unsigned short) <= 160 * 1024) ? 8 : 4;
   static_assert(WAVES * 2 * N * sizeof(float) <= WAVES * 32 * (64 + 8) * sizeof(unsigned short), "statistics staging must fit the Y tiles");
   const size_t smem = ((size_t)N * (K + 8) + WAVES * 32 * (64 + 8)) * sizeof(unsigned short) + ((FOLD == 1 || FOLD == 2) ? 2 * N * sizeof(float) : 0);
-  static bool attr_set = false;
-  if (smem > 64 * 1024 && !attr_set) {
+  static std::atomic<bool> attr_set{false};
+  if (smem > 64 * 1024 && !attr_set.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute((const void*)conv1x1_fwd_stats_kernel<K, N, STATS, WAVES, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv1x1)");
-    attr_set = true;
+    attr_set.store(true, std::memory_order_release);
   }
   const int64_t nstrips = M / 32;
   int64_t nb = (nstrips + WAVES - 1) / WAVES;
@@ -436,11 +438,11 @@ template <int K, int N, bool STATS>
 static int launch_conv1x1_bigk(const void* x, const void* w, int64_t M, int Ntot, void* y, float* part, int* nblk_out, int wtrans, hipStream_t st) {
   static_assert(4 * 2 * N * sizeof(float) <= 4 * 32 * (64 + 8) * sizeof(unsigned short), "statistics staging must fit the Y tiles");
   const size_t smem = ((size_t)N * (K + 8) + 4 * 32 * (64 + 8)) * sizeof(unsigned short);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute((const void*)conv1x1_bigk_kernel<K, N, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv1x1_bigk)");
-    attr_set = true;
+    attr_set.store(true, std::memory_order_release);
   }
   const int64_t nstrips = M / 32;
   int64_t nb = (nstrips + 3) / 4;
@@ -789,25 +791,25 @@ extern "C" int lec_conv3x3_c64_fwd(const void* x, const void* w, int w_transpose
   LEC_CHECK_ARG((partials == nullptr) == (n_partials == nullptr), "conv3x3_c64_fwd: pass partials and n_partials together");
   LEC_CHECK_ARG(!partials || partials_bytes >= (int64_t)kC1MaxBlocks * 2 * 64 * (int64_t)sizeof(float), "conv3x3_c64_fwd: partials buffer too small");
   const size_t smem = ((size_t)9 * 64 * (64 + 8) + 4 * 32 * (64 + 8)) * sizeof(unsigned short);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3x3_c64)");
-    attr_set = true;
+    attr_set.store(true, std::memory_order_release);
   }
   const int64_t nstrips = M / 32;
   int64_t nb = (nstrips + 3) / 4;
   const int nblk = (int)(nb > kC1MaxBlocks ? kC1MaxBlocks : nb);
   hipStream_t st = (hipStream_t)stream;
-  if (H % 4 == 0 && W % 8 == 0 && !getenv("LEC_C3_STRIP")) {             // 4 x 8-pixel tiles: the LDS-halo kernel
+  if (H % 4 == 0 && W % 8 == 0 && !tuning().c3_strip) {             // 4 x 8-pixel tiles: the LDS-halo kernel
     const size_t hsm = ((size_t)9 * 64 * (64 + 8) + 8 * kHaloPix * kHaloLd) * sizeof(unsigned short);
-    static bool hattr8 = false;
-    if (!hattr8) {
+    static std::atomic<bool> hattr8{false};
+    if (!hattr8.load(std::memory_order_acquire)) {
       hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_halo_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hsm);
       if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_c64_halo_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hsm);
       if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3x3_c64_halo_w8)");
-      hattr8 = true;
+      hattr8.store(true, std::memory_order_release);
     }
     const int64_t nt8 = (int64_t)Nimg * (H / 4) * (W / 8);
     int64_t nb8 = (nt8 + 7) / 8;
@@ -1007,12 +1009,12 @@ extern "C" int lec_conv3x3_c128_fwd(const void* x, const void* w, int Nimg, int 
   LEC_CHECK_ARG((partials == nullptr) == (n_partials == nullptr), "conv3x3_c128_fwd: pass partials and n_partials together");
   LEC_CHECK_ARG(!partials || partials_bytes >= (int64_t)kC1MaxBlocks * 2 * 128 * (int64_t)sizeof(float), "conv3x3_c128_fwd: partials buffer too small");
   const size_t smem = ((size_t)2 * 128 * 136 + 4 * kHaloPix * 136) * sizeof(unsigned short);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_c128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3x3_c128)");
-    attr_set = true;
+    attr_set.store(true, std::memory_order_release);
   }
   const int64_t ntiles = (int64_t)Nimg * ((H + 3) / 4) * ((W + 7) / 8);
   int64_t nb = (ntiles + 3) / 4;
@@ -1184,11 +1186,11 @@ template <int KO, int KI, int WCO, int NW, bool SPLIT_CO, bool XF = false>
 static int launch_wgrad1x1(const void* dy, int CoutTot, const void* x, int CinTot, int64_t M, float* dW, hipStream_t st,
                            XfArgs xf = XfArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}) {
   const size_t smem = (size_t)2 * (KO + KI) * 64 * sizeof(unsigned short) + (XF ? 5 * KO * sizeof(float) : 0);
-  static bool attr_set = false;
-  if (smem > 64 * 1024 && !attr_set) {
+  static std::atomic<bool> attr_set{false};
+  if (smem > 64 * 1024 && !attr_set.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute((const void*)wgrad1x1_kernel<KO, KI, WCO, NW, SPLIT_CO, XF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(wgrad1x1)");
-    attr_set = true;
+    attr_set.store(true, std::memory_order_release);
   }
   const int ny = SPLIT_CO ? CoutTot / KO : CinTot / KI;
   const int64_t nchunks = M / 64;
@@ -1418,11 +1420,11 @@ extern "C" int lec_conv3x3_c64_wgrad(const void* dy, const void* x, int N, int H
   LEC_CHECK_ARG(dy && x && dw, "conv3x3_c64_wgrad: null pointer");
   LEC_CHECK_ARG(lec_conv3x3_c64_wgrad_supported(N, H, W), "conv3x3_c64_wgrad: H and W must be multiples of 8 (N=%d H=%d W=%d)", N, H, W);
   const size_t smem = (size_t)2 * kW3BufElems * sizeof(unsigned short);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(wgrad3x3_c64)");
-    attr_set = true;
+    attr_set.store(true, std::memory_order_release);
   }
   const int64_t ntiles = (int64_t)N * (H / 8) * (W / 8);
   const int nblk = (int)(ntiles < 256 ? ntiles : 256);

@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "lec_common.h"
+#include "tuning.h"
 
 namespace lec {
 
@@ -237,18 +238,10 @@ __device__ __forceinline__ void scatter_row_grad(const JointParams& P, int code,
 }
 
 template <int T, int EPL, int ENERGY, bool GRAD, bool STAGE>
-// LEC_JL_WAVES (build-time experiment, `make EXTRA=-DLEC_JL_WAVES=3`): cap the registers for that many waves per SIMD.  The lane-per-pair instance (T = 1, 12 elements
-// per lane) holds 181 registers = 2 waves per SIMD.  MEASURED (round 4, same box, us per launch, no cap / 3 waves (168 registers, 9 spilled) / 4 waves (128, 53 spilled)):
-// 256 x 256 x 10: 22.1 / 22.8 / 27.0; 4 096 x 256 x 10: 89.0 / 97.1 / 112.4; 256 x 256 x 128: 58.8 / 58.8 / 60.8 -- the spills cost more than the third wave hides.  Off.
-#ifndef LEC_JL_WAVES
-#define LEC_JL_WAVES 0
-#endif
-#if LEC_JL_WAVES > 0
-#define LEC_JL_OCC __attribute__((amdgpu_waves_per_eu(LEC_JL_WAVES, LEC_JL_WAVES)))
-#else
-#define LEC_JL_OCC
-#endif
-__global__ __launch_bounds__(256) LEC_JL_OCC void joint_loss_kernel(JointParams P) {
+// (Occupancy caps were measured in round 4: the lane-per-pair instance (T = 1, 12 elements per lane) holds 181 registers = 2 waves per SIMD; capped to 3 waves (168
+// registers, 9 spilled) / 4 waves (128, 53 spilled), us per launch: 256 x 256 x 10: 22.1 / 22.8 / 27.0; 4 096 x 256 x 10: 89.0 / 97.1 / 112.4; 256 x 256 x 128:
+// 58.8 / 58.8 / 60.8 -- the spills cost more than the third wave hides.  Removed.)
+__global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
   constexpr int PPW = kWave / T;                      // pairs per wave iteration
   const int lane = threadIdx.x & 63;
   const int t = lane % T, slot = lane / T;
@@ -434,11 +427,8 @@ static bool joint_geometry(int B, int K, int D, JointGeom& g) {
   else if (D <= 1024) { g.T = 64; g.EPL = 16; }
   else return false;
   int iters_override = 0;
-  if (const char* e = getenv("LEC_JOINT_GEOM")) {            // tuning hook: "T,EPL[,iters]"
-    int t = 0, epl = 0, it = 0;
-    if (sscanf(e, "%d,%d,%d", &t, &epl, &it) >= 2 && t * epl >= D) {
-      for (auto& c : kGeoms) if (c[0] == t && c[1] == epl) { g.T = t; g.EPL = epl; iters_override = it; }
-    }
+  if (tuning().jl_T > 0 && tuning().jl_T * tuning().jl_EPL >= D) {            // sweep hook (LEC_JOINT_GEOM="T,EPL[,iters]", resolved at load: tuning.h)
+    for (auto& c : kGeoms) if (c[0] == tuning().jl_T && c[1] == tuning().jl_EPL) { g.T = c[0]; g.EPL = c[1]; iters_override = tuning().jl_iters; }
   }
   const int ppw = 64 / g.T, NP = 1 + 2 * K;
   const int64_t group_iters = (NP + ppw - 1) / ppw;                      // wave iterations one group needs
@@ -515,8 +505,7 @@ static int joint_loss_impl(int energy, int label_proj, int image_proj,
   P.e_pos = e_pos; P.e_neg = e_neg; P.loss = loss; P.grad_table = grad_table; P.grad_feat = grad_feat;
   P.counter = (unsigned int*)workspace; P.partials = (float*)((char*)workspace + 256);
   P.iters = g.iters; P.tasks_per_group = g.tasks_per_group;
-  static const int stage_env = [] { const char* e = getenv("LEC_JOINT_STAGE"); return e ? atoi(e) : 0; }();   // read once, not per launch
-  P.lds_stage = stage_env;
+  P.lds_stage = tuning().jl_stage;
   const bool grad = grad_table != nullptr;
   return dispatch(g, P, grad, energy, st);
 }

@@ -335,9 +335,13 @@ class FusionContext:
         self.bn_timer = None            # lists of (start event, end event, bytes | flops) per launch when the owner profiles its step
         self.conv_timer = None
         self.in_flight = False          # a training forward has run and its backward has not reached the stem yet
+        self.graph_ref = None           # weakref to the stem convolution's autograd node of that forward: dead = the graph was freed, no backward can come
 
     def busy(self):
-        """A forward whose backward has not finished yet owns this context (its records and its BatchNorm workspace)."""
+        """A forward whose backward has not finished yet owns this context (its records and its BatchNorm workspace).  A forward whose autograd graph
+        has been freed without a backward (its output dropped, an exception) no longer does: the stem node's weak reference tells."""
+        if self.graph_ref is not None and self.graph_ref() is None:
+            self.reset()
         return bool(self.in_flight or self.forks or self.folded or self.deferred or self.lazy_ok or self.lazy_dx)
 
     def reset(self):
@@ -346,6 +350,7 @@ class FusionContext:
             d.clear()
         self.ws_owner[0] = 0
         self.in_flight = False
+        self.graph_ref = None
 
     def workspace(self, device):
         key = (device.type, device.index)

@@ -346,6 +346,9 @@ class _OverlapConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, conv):
         ctx.fc = _ops().fusion()                  # the owning backbone's fusion records (ops.FusionContext); backward restores it
+        if getattr(conv, 'is_stem', False):
+            import weakref
+            ctx.fc.graph_ref = weakref.ref(ctx)   # this node lives exactly as long as the forward's autograd graph (FusionContext.busy)
         w16 = _ops().overlap().weight_lp(conv, x.dtype)
         nhwc = x.is_contiguous(memory_format=torch.channels_last)
         if nhwc and w16.dim() == 4 and not w16.is_contiguous(memory_format=torch.channels_last):
@@ -624,6 +627,7 @@ class ResNet(nn.Module):
     bn_grad_accumulate = False      # BatchNorm backward ADDS d gamma / d beta (a step of several backward passes zeroes the slots once)
     conv_schedule = -1              # LEC_SCHEDULE_* of the fp32 forward / data-gradient launches (-1: the library default)
     step_timers = None              # {'bn': [], 'conv': []}: per-launch HIP events while the owner profiles its step (bench.py)
+    max_forwards_in_flight = 64     # training forwards of one backbone that may wait for their backward at once (each holds a fusion context + BatchNorm workspace)
 
     def forward(self, x, pooled_only=False, pass_order=None):
         """pooled_only: stop after the global average pooling ([n, 512 * expansion] features); `self.fc` is then the caller's to apply --
@@ -640,10 +644,17 @@ class ResNet(nn.Module):
         track = self.training and torch.is_grad_enabled()
         fc = next((c for c in pool if not c.busy()), None)
         if fc is None:
-            if len(pool) < 4:
+            # every context belongs to a forward whose backward can still come: the pool GROWS (reference_exact_batches keeps four forwards in flight; a
+            # fifth used to take over the oldest one's BatchNorm workspace and records silently).  Contexts whose graph cannot be tracked (stock autograd
+            # convolutions: no stem node of ours) are the only ones ever recycled, oldest first, and only once the pool is large.
+            if len(pool) >= self.max_forwards_in_flight:
+                old = next((c for c in pool if c.graph_ref is None), None)
+                if old is None:
+                    raise RuntimeError('%d forwards of this backbone are waiting for their backward (max_forwards_in_flight): run backward, drop the outputs, '
+                                       'or use torch.no_grad() for forwards that need no gradient' % len(pool))
+                pool.remove(old); pool.append(old); fc = old
+            else:
                 fc = _ops().FusionContext(); pool.append(fc)
-            else:                                               # forwards whose backward never ran (or raised): recycle the oldest
-                fc = pool.pop(0); pool.append(fc)
         fc.reset()
         fc.overlap, fc.accumulate, fc.schedule, fc.pass_order = self.wgrad_overlap, bool(self.bn_grad_accumulate), int(self.conv_schedule), pass_order
         tm = self.step_timers
@@ -654,7 +665,7 @@ class ResNet(nn.Module):
         if not track:
             fc.reset()                                          # no backward will come for these records
         else:
-            fc.in_flight = True                                 # until the stem's backward has run (or the pool recycles it)
+            fc.in_flight = True                                 # until the stem's backward has run (or the forward's graph is freed: FusionContext.busy)
         return y
 
     def __deepcopy__(self, memo):

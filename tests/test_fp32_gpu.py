@@ -904,3 +904,64 @@ def test_global_avgpool_backward_is_channels_last_and_equals_the_framework_op():
     ya.backward(gy); yb.backward(gy)
     assert xa.grad.is_contiguous(memory_format=torch.channels_last)
     assert torch.allclose(xa.grad, xb.grad, rtol=1e-6, atol=0)
+
+
+def test_six_forwards_before_any_backward_keep_their_own_fusion_context():
+    """the backbone's pool of fusion contexts (hand-off records + BatchNorm workspace of ONE forward / backward pair) used to be capped
+    at four and silently handed the OLDEST in-flight context to a fifth forward.  Six training forwards (different batches) before any backward, backwards in a
+    scrambled order: every input gradient must equal the one of that forward run alone, the parameter gradients their sum.  Then: a forward whose output is
+    dropped without a backward frees its context (no growth), and the cap raises instead of recycling."""
+    torch.manual_seed(0)
+    net = resnet50(num_classes=10).to(DEV).to(memory_format=torch.channels_last).train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 0.0                                        # (running statistics play no part in a training forward; keep both runs from the same state)
+    xs = [_cl(torch.rand(4, 3, 64, 64)) for _ in range(6)]
+    gs = None
+    WgradOverlap.instance = WgradOverlap()
+    try:
+        def zero():
+            for p_ in net.parameters():
+                p_.grad = torch.zeros_like(p_)
+        # alone, one after the other
+        alone_dx, alone_y = [], []
+        zero()
+        for i, x0 in enumerate(xs):
+            x = x0.clone().requires_grad_(True)
+            y = net(x)
+            if gs is None:
+                gs = [torch.randn_like(y) for _ in xs]
+            y.backward(gs[i]); WgradOverlap.instance.join()
+            alone_dx.append(x.grad.clone()); alone_y.append(y.detach().clone())
+        torch.cuda.synchronize()
+        alone_p = {k: p_.grad.clone() for k, p_ in net.named_parameters()}
+        assert len(net._fusions) == 1
+        # all six forwards first
+        zero()
+        ins = [x0.clone().requires_grad_(True) for x0 in xs]
+        outs = [net(x) for x in ins]
+        assert len(net._fusions) == 6 and all(c.busy() for c in net._fusions)
+        for i in (3, 0, 5, 1, 4, 2):
+            outs[i].backward(gs[i]); WgradOverlap.instance.join()
+        torch.cuda.synchronize()
+        assert not any(c.busy() for c in net._fusions)
+        cos = lambda a, b: float(a.double().flatten() @ b.double().flatten() / (a.double().norm() * b.double().norm() + 1e-300))
+        for i in range(6):
+            assert torch.equal(outs[i].detach(), alone_y[i])
+            assert cos(ins[i].grad, alone_dx[i]) > 0.999999, (i, cos(ins[i].grad, alone_dx[i]))
+        for k, p_ in net.named_parameters():
+            if alone_p[k].norm() > 0:
+                assert cos(p_.grad, alone_p[k]) > 0.99999, (k, cos(p_.grad, alone_p[k]))
+        # outputs dropped without a backward: the graph is freed, the context is free again
+        del outs, ins
+        for _ in range(10):
+            y = net(xs[0].clone().requires_grad_(True)); del y
+        assert len(net._fusions) == 6
+        # the cap raises
+        net.max_forwards_in_flight = 7
+        held = [net(xs[0].clone().requires_grad_(True)) for _ in range(7)]
+        with pytest.raises(RuntimeError, match='waiting for their backward'):
+            net(xs[0].clone().requires_grad_(True))
+        del held
+    finally:
+        WgradOverlap.instance = None
