@@ -118,6 +118,23 @@ int lec_joint_loss_fwd_bwd_f16(int energy, int label_proj, int image_proj,
                                float* grad_table, float* grad_feat,
                                void* workspace, int64_t workspace_bytes, lec_stream_t stream);
 
+/* The same loss for a step whose image embeddings come into being CHUNK BY CHUNK (the reference embeds the four groups of a step in separate
+ * forwards, oe_h.py:980-1009, and keeps every activation; config 5's 7 424 CNN rows per step do not fit one pass): one launch per chunk, right
+ * behind that chunk's CNN forward, evaluates exactly the pairs whose image row (the feature row -1-code of its image end point) lies in
+ * [row_lo, row_hi) -- plus, when labels_too != 0, the pairs between two labels (pass it with one chunk of the step).  Over a step's launches every
+ * pair of criterion.forward is evaluated once: e_pos / e_neg fill up entry by entry, each launch writes the sum of ITS terms to loss[0] (the caller
+ * adds them), gradients add into grad_table / grad_feat.  Rows of `feat` outside the window are never read into a result.  table_f16 != NULL:
+ * the label rows are read from the fp16 shadow (as lec_joint_loss_fwd_bwd_f16), else from `table`. */
+int lec_joint_loss_fwd_bwd_window(int energy, int label_proj, int image_proj,
+                                  const float* table, const void* table_f16, int64_t ld_table, int n_labels,
+                                  const float* feat, int64_t ld_feat, int n_feat,
+                                  const int32_t* pos_from, const int32_t* pos_to, const int32_t* neg, const float* weights,
+                                  int B, int K, int D, float K_cone, float alpha,
+                                  int row_lo, int row_hi, int labels_too,
+                                  float* e_pos, float* e_neg, float* loss,
+                                  float* grad_table, float* grad_feat,
+                                  void* workspace, int64_t workspace_bytes, lec_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * (3) Stand-alone projections (used outside the fused loss: evaluation, metrics, FeatCNN18.forward itself).
  *     lec_label_project_fwd  = Embedder.forward (oe_h.py:77-104): out[i] = project(table[idx[i]]).

@@ -40,7 +40,23 @@ struct JointParams {
   int iters;            // pair iterations per task
   int tasks_per_group;
   int lds_stage;        // T == 1 only: move rows through LDS (coalesced gather/scatter)
+  // Row window (lec_joint_loss_fwd_bwd_window): this launch evaluates only the pairs it OWNS -- a pair with an image end point whose feature row r lies in
+  // [row_lo, row_hi), and, when labels_too is set, the pairs between two labels.  A step whose CNN rows go through the backbone in chunks launches the
+  // loss once per chunk, right behind that chunk's forward: every pair is evaluated exactly once over the launches, rows outside the window are never trusted
+  // (they may not have been computed yet), e_pos / e_neg entries of pairs owned by other launches are left alone.  The plain entry: [0, INT_MAX), labels_too.
+  int row_lo, row_hi, labels_too;
 };
+
+// the launch owning the pair (a, b) of node codes: the window holding its image row (with two image rows -- negatives of trainers that do not pick per level --
+// the larger one: the caller then guarantees both rows are valid by the time that window's launch runs)
+__device__ __forceinline__ bool pair_owned(const JointParams& P, int a, int b) {
+  const int ra = a < 0 ? -1 - a : -1, rb = b < 0 ? -1 - b : -1;
+  const int r = ra > rb ? ra : rb;
+  return r < 0 ? P.labels_too != 0 : (r >= P.row_lo && r < P.row_hi);
+}
+__device__ __forceinline__ bool row_in_window(const JointParams& P, int code) {       // may this launch read / add to the row of node `code`?
+  return code >= 0 || ((-1 - code) >= P.row_lo && (-1 - code) < P.row_hi);
+}
 
 // One projected row held across T lanes: raw e (after the +1e-15 of Embedder.forward), projected p, and the two
 // scalars of the projection's Jacobian:  d/d e = A * go + Bc * <e, go> * e.
@@ -166,7 +182,7 @@ __device__ __forceinline__ void load_project(const JointParams& P, int code, boo
   if (prefetched != nullptr) {
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
-      float v = prefetched[i];
+      float v = valid ? prefetched[i] : 0.0f;                                       // (a pair this launch does not own: its row may not exist yet)
       if (hyp && (t + i * T) < P.D) v += 1e-15f;                                    // oe_h.py:79
       r.e[i] = v;
     }
@@ -262,8 +278,8 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
     if (P.weights) w = P.weights[b];
   }
   Row<EPL> U, V;
-  load_project<T, EPL>(P, ucode, task_valid, t, U, nullptr);     // every lane needs u_b, v_b: broadcast loads
-  load_project<T, EPL>(P, vcode, task_valid, t, V, nullptr);
+  load_project<T, EPL>(P, ucode, task_valid && row_in_window(P, ucode), t, U, nullptr);     // every lane needs u_b, v_b: broadcast loads
+  load_project<T, EPL>(P, vcode, task_valid && row_in_window(P, vcode), t, V, nullptr);     // (an image row outside this launch's window stays zeros: it may not exist yet)
   float gu[EPL], gv[EPL];
 #pragma unroll
   for (int i = 0; i < EPL; ++i) { gu[i] = 0.0f; gv[i] = 0.0f; }
@@ -282,8 +298,10 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
   if (pipelined) fetch_row<T, EPL>(P, code_a, t, raw_a);
   for (int it = 0; it < P.iters; ++it) {
     const int q = q0 + it * PPW + slot;               // pair index in the group: 0 = positive, 1+k = negative slot k
-    const bool valid = task_valid && q < NP;
-    const int kind = !valid ? 0 : (q == 0 ? 0 : (q - 1 < P.K ? 1 : 2));   // 1: u fixed (corrupt `to`), 2: v fixed
+    const int kind_q = (!task_valid || q >= NP) ? 0 : (q == 0 ? 0 : (q - 1 < P.K ? 1 : 2));
+    // (whole-batch launches own every pair; a windowed launch skips the pairs of other windows: their rows may not exist yet)
+    const bool valid = task_valid && q < NP && pair_owned(P, kind_q == 2 ? (code_a == kNoRow ? 0 : code_a) : ucode, kind_q == 1 ? (code_a == kNoRow ? 0 : code_a) : vcode);
+    const int kind = !valid ? 0 : kind_q;   // 1: u fixed (corrupt `to`), 2: v fixed
     const int code_c = fetch_code(it + 2);
     float raw_b[EPL];
     if (pipelined) fetch_row<T, EPL>(P, code_b, t, raw_b);
@@ -348,8 +366,8 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
           float cxx, cxy, cyy;
           if (ENERGY == LEC_ENERGY_HYP_CONE) cone_grad_coeffs(cf, P.K_cone, cxx, cxy, cyy);
           else { cxx = ev.cxx; cxy = ev.cxy; cyy = ev.cyy; }
-          cxx *= g; cxy *= g; cyy *= g;
-          // (g = 0 for pairs that are not live: their coefficients are zero, their sums add zeros)
+          // (pairs that are not live carry exact zeros -- selected, not multiplied: a pair another window owns may hold a row that is not computed yet)
+          cxx = act ? cxx * g : 0.0f; cxy = act ? cxy * g : 0.0f; cyy = act ? cyy * g : 0.0f;
           float gx[EPL], gy[EPL];
           pk_axpby(gx, cxx, x, cxy, y); pk_axpby(gy, cxy, x, cyy, y);
           const float mu_ = kind != 2 ? 1.0f : 0.0f, mv_ = kind != 1 ? 1.0f : 0.0f;
@@ -382,8 +400,8 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
 #pragma unroll
       for (int i = 0; i < EPL; ++i) { gu[i] += __shfl_xor(gu[i], m, kWave); gv[i] += __shfl_xor(gv[i], m, kWave); }
     }
-    scatter_row_grad<T, EPL>(P, ucode, task_valid && slot == 0, t, U, gu, stage);
-    scatter_row_grad<T, EPL>(P, vcode, task_valid && slot == 0, t, V, gv, stage);
+    scatter_row_grad<T, EPL>(P, ucode, task_valid && slot == 0 && row_in_window(P, ucode), t, U, gu, stage);
+    scatter_row_grad<T, EPL>(P, vcode, task_valid && slot == 0 && row_in_window(P, vcode), t, V, gv, stage);
   }
 
   lsum = group_sum<64>(lsum);
@@ -476,7 +494,8 @@ static int joint_loss_impl(int energy, int label_proj, int image_proj,
                                       const int32_t* pos_from, const int32_t* pos_to, const int32_t* neg,
                                       const float* weights, int B, int K, int D, float K_cone, float alpha,
                                       float* e_pos, float* e_neg, float* loss, float* grad_table, float* grad_feat,
-                                      void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+                                      void* workspace, int64_t workspace_bytes, lec_stream_t stream,
+                                      int row_lo = 0, int row_hi = INT_MAX, int labels_too = 1) {
   using namespace lec;
   LEC_CHECK_ARG(energy >= LEC_ENERGY_HYP_CONE && energy <= LEC_ENERGY_EUC_CONE, "joint_loss: unknown energy %d", energy);
   LEC_CHECK_ARG(label_proj >= LEC_LABEL_RAW && label_proj <= LEC_LABEL_SOFTCLIP_K, "joint_loss: unknown label_proj %d", label_proj);
@@ -506,6 +525,8 @@ static int joint_loss_impl(int energy, int label_proj, int image_proj,
   P.counter = (unsigned int*)workspace; P.partials = (float*)((char*)workspace + 256);
   P.iters = g.iters; P.tasks_per_group = g.tasks_per_group;
   P.lds_stage = tuning().jl_stage;
+  LEC_CHECK_ARG(row_lo >= 0 && row_hi >= row_lo, "joint_loss: row window [%d, %d)", row_lo, row_hi);
+  P.row_lo = row_lo; P.row_hi = row_hi; P.labels_too = labels_too ? 1 : 0;
   const bool grad = grad_table != nullptr;
   return dispatch(g, P, grad, energy, st);
 }
@@ -535,4 +556,22 @@ extern "C" int lec_joint_loss_fwd_bwd_f16(int energy, int label_proj, int image_
   LEC_CHECK_ARG(table_f16, "joint_loss_f16: table null");
   return joint_loss_impl(energy, label_proj, image_proj, nullptr, table_f16, ld_table, n_labels, feat, ld_feat, n_feat, pos_from, pos_to, neg, weights,
                          B, K, D, K_cone, alpha, e_pos, e_neg, loss, grad_table, grad_feat, workspace, workspace_bytes, stream);
+}
+
+// The loss of a step whose CNN rows exist CHUNK BY CHUNK (config 5: 7 424 rows per step do not fit one pass): one launch per chunk, right behind the chunk's
+// forward, evaluates the pairs whose image row lies in [row_lo, row_hi) -- and the label-label pairs when labels_too != 0 (pass it with exactly one chunk).
+// Over the launches of a step every pair is evaluated once: e_pos / e_neg fill up, the loss values add up (one scalar per launch), gradients add into
+// grad_table / grad_feat as always.  feat rows outside the window are never read into a result.  table_f16 != NULL: the label rows are read from the
+// fp16 shadow (as lec_joint_loss_fwd_bwd_f16); else from `table`.
+extern "C" int lec_joint_loss_fwd_bwd_window(int energy, int label_proj, int image_proj,
+                                             const float* table, const void* table_f16, int64_t ld_table, int n_labels,
+                                             const float* feat, int64_t ld_feat, int n_feat,
+                                             const int32_t* pos_from, const int32_t* pos_to, const int32_t* neg,
+                                             const float* weights, int B, int K, int D, float K_cone, float alpha,
+                                             int row_lo, int row_hi, int labels_too,
+                                             float* e_pos, float* e_neg, float* loss, float* grad_table, float* grad_feat,
+                                             void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
+  LEC_CHECK_ARG(table || table_f16, "joint_loss_window: table null");
+  return joint_loss_impl(energy, label_proj, image_proj, table_f16 ? nullptr : table, table_f16, ld_table, n_labels, feat, ld_feat, n_feat, pos_from, pos_to, neg,
+                         weights, B, K, D, K_cone, alpha, e_pos, e_neg, loss, grad_table, grad_feat, workspace, workspace_bytes, stream, row_lo, row_hi, labels_too);
 }

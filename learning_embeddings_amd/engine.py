@@ -322,31 +322,22 @@ class StepEngine:
         return loss
 
     def _core_chunked(self, ev=None):
-        """The same step with the CNN rows in chunks (see `cnn_chunk`): forward of every chunk without saved activations, ONE fused
-        loss launch over all raw outputs, then a second forward + backward per chunk."""
-        import torch.nn as nn
+        """The same step with the CNN rows in chunks (see `cnn_chunk`), ONE forward per chunk: forward of a chunk, the fused loss over the pairs whose image lies
+        in that chunk (lec_joint_loss_fwd_bwd_window: every pair of the step has at most one image end point -- `step()` checks the negative layout -- so a
+        chunk's loss terms need that chunk's embeddings and the label table only), backward of the chunk with the gradient the launch left, next chunk.
+        Activations of one chunk are alive at a time; BatchNorm batch statistics are per chunk, as the reference's own separate forwards of positives and
+        negatives have them (oe_h.py:980-985, 1003-1009).  (Round 4 ran every chunk's forward TWICE -- once without saved activations to have all embeddings
+        before one loss launch, once more in front of its backward: a quarter of the step.)"""
         codes = self.codes_dev
         pos_from = codes[:, 0].contiguous(); pos_to = codes[:, 1].contiguous(); negc = codes[:, 2:].contiguous()
         self.arena.zero_grad(); self.table_grad.zero_(); self.gfeat.zero_()
         if ev: ev[0].record()
         R, C = self.n_rows_pad, self.cnn_chunk
-        feats = torch.empty(R, self.D, device=self.device)
-        bns = [m for m in self.img_feat_net.modules() if isinstance(m, nn.BatchNorm2d)]
-        saved = [m.momentum for m in bns]
-        for m in bns:
-            m.momentum = 0.0                           # the running statistics move once per chunk: in the second pass
-        try:
-            with torch.no_grad():
-                for lo in range(0, R, C):
-                    feats[lo:lo + C] = self.img_feat_net.forward_raw(_gather_images(self.pool, self.idx_dev[lo:lo + C]))
-        finally:
-            for m, mom in zip(bns, saved):
-                m.momentum = mom
-        self.last_feats = feats
-        if ev: ev[1].record()
-        loss, e_pos, e_neg = ops.joint_loss_raw(self.table, feats, pos_from, pos_to, negc, None, self.K_cone, self.alpha, _lib.ENERGY_HYP_CONE,
-                                                _lib.LABEL_HYP, _lib.IMAGE_SOFTCLIP, self.table_grad, self.gfeat, table_f16=self.table_h)
-        if ev: ev[2].record()
+        if getattr(self, '_chunk_feats', None) is None:
+            self._chunk_feats = torch.zeros(R, self.D, device=self.device)           # rows of later chunks hold the previous step's (finite) values: never read into a result
+            self._chunk_out = (torch.zeros(self.B, device=self.device), torch.zeros(self.B, 2 * self.K, device=self.device))
+        feats, out = self._chunk_feats, self._chunk_out
+        loss = torch.zeros(1, device=self.device)
         # Several backward passes add into the same gradient slots: the reducer's per-parameter hooks stay muted for all of them (a
         # parameter reports in EVERY chunk; a bucket launched after chunk 0 would reduce a partial sum and race with the later chunks'
         # atomics) and the buckets are reduced once, by step()'s reducer.finish(), after the last chunk's weight gradients have joined.
@@ -355,13 +346,20 @@ class StepEngine:
         try:
             for lo in range(0, R, C):
                 f = self.img_feat_net.forward_raw(_gather_images(self.pool, self.idx_dev[lo:lo + C]))
+                feats[lo:lo + C] = f.detach()
+                l_c, e_pos, e_neg = ops.joint_loss_raw(self.table, feats, pos_from, pos_to, negc, None, self.K_cone, self.alpha, _lib.ENERGY_HYP_CONE,
+                                                       _lib.LABEL_HYP, _lib.IMAGE_SOFTCLIP, self.table_grad, self.gfeat, table_f16=self.table_h,
+                                                       window=(lo, lo + C, lo == 0), out=out)
+                loss += l_c
                 f.backward(self.gfeat[lo:lo + C])
                 if self.overlap is not None:
                     self.overlap.join()
         finally:
             self.reducer.live = live
             self.reducer.reset()                       # nothing launched: finish() reduces every bucket and the table gradient
-        if ev: ev[3].record()
+        self.last_feats = feats
+        if ev:
+            ev[1].record(); ev[2].record(); ev[3].record()        # (forward, loss and backward interleave per chunk: the whole step is "cnn_fwd" in phases_ms)
         return loss, e_pos, e_neg
 
     def _core(self, ev=None):

@@ -143,10 +143,12 @@ class ImageSoftClipFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------------ fused joint loss
 def joint_loss_raw(table, feat, pos_from, pos_to, neg, weights, K_cone, alpha, energy, label_proj, image_proj,
-                   grad_table=None, grad_feat=None, table_f16=None):
+                   grad_table=None, grad_feat=None, table_f16=None, window=None, out=None):
     """One launch of lec_joint_loss_fwd_bwd.  table [N,D], feat [n_feat,D] (or None): contiguous float32; index tensors:
     contiguous int32 device tensors of node codes (>= 0 label row, < 0 feature row -1-code).  Gradients are ADDED into
-    grad_table / grad_feat when given (same shapes, contiguous).  Returns (loss[1], e_pos[B], e_neg[B,2K])."""
+    grad_table / grad_feat when given (same shapes, contiguous).  Returns (loss[1], e_pos[B], e_neg[B,2K]).
+    window = (row_lo, row_hi, labels_too): lec_joint_loss_fwd_bwd_window -- only the pairs whose image row lies in [row_lo, row_hi) (and the label-label pairs
+    when labels_too) are evaluated; `out` = (e_pos, e_neg) buffers the launches of one step share (entries of other windows' pairs are left alone)."""
     def chk(t, name, like=None):
         if t.dtype != torch.float32 or t.dim() != 2 or not t.is_contiguous():
             raise ValueError('%s must be a contiguous 2-D float32 tensor' % name)
@@ -174,8 +176,14 @@ def joint_loss_raw(table, feat, pos_from, pos_to, neg, weights, K_cone, alpha, e
             raise TypeError('%s must be a contiguous int32 tensor of node codes' % name)
     if weights is not None and (weights.dtype != torch.float32 or weights.numel() != B or not weights.is_contiguous()):
         raise ValueError('weights must be float32 [B]')
-    e_pos = torch.empty(B, dtype=torch.float32, device=dev)
-    e_neg = torch.empty(B, 2 * K, dtype=torch.float32, device=dev)
+    if out is not None:
+        e_pos, e_neg = out
+        if (e_pos.shape != (B,) or e_neg.shape != (B, 2 * K) or e_pos.dtype != torch.float32 or e_neg.dtype != torch.float32
+                or not e_pos.is_contiguous() or not e_neg.is_contiguous()):
+            raise ValueError('out must be contiguous float32 (e_pos [B], e_neg [B, 2K])')
+    else:
+        e_pos = torch.empty(B, dtype=torch.float32, device=dev)
+        e_neg = torch.empty(B, 2 * K, dtype=torch.float32, device=dev)
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     need = lib.lec_loss_workspace_bytes(B, K, D)
     if need < 0:
@@ -186,6 +194,15 @@ def joint_loss_raw(table, feat, pos_from, pos_to, neg, weights, K_cone, alpha, e
         if table_f16.dtype != torch.float16 or table_f16.shape != table.shape or not table_f16.is_contiguous():
             raise ValueError('table_f16 must be a contiguous float16 tensor of the table\'s shape')
         fn, tbl = lib.lec_joint_loss_fwd_bwd_f16, table_f16
+    if window is not None:
+        lo, hi, labels_too = window
+        check(lib.lec_joint_loss_fwd_bwd_window(energy, label_proj, image_proj, dptr(table), dptr(table_f16) if table_f16 is not None else None, D, N,
+                                                dptr(feat), D, n_feat, dptr(pos_from), dptr(pos_to), dptr(neg) if K else None,
+                                                dptr(weights), B, K, D, float(K_cone), float(alpha), int(lo), int(hi), int(bool(labels_too)),
+                                                dptr(e_pos), dptr(e_neg) if K else None, dptr(loss),
+                                                dptr(grad_table), dptr(grad_feat) if feat is not None else dptr(grad_table),
+                                                dptr(ws), ws.numel(), stream_ptr()))
+        return loss, e_pos, e_neg
     check(fn(energy, label_proj, image_proj, dptr(tbl), D, N,
                                      dptr(feat), D, n_feat, dptr(pos_from), dptr(pos_to), dptr(neg) if K else None,
                                      dptr(weights), B, K, D, float(K_cone), float(alpha),
@@ -335,11 +352,11 @@ class FusionContext:
         self.bn_timer = None            # lists of (start event, end event, bytes | flops) per launch when the owner profiles its step
         self.conv_timer = None
         self.in_flight = False          # a training forward has run and its backward has not reached the stem yet
-        self.graph_ref = None           # weakref to the stem convolution's autograd node of that forward: dead = the graph was freed, no backward can come
+        self.graph_ref = None           # weakref to the LAST autograd node of that forward (the global average pooling's): dead = the output was dropped, no backward can come
 
     def busy(self):
         """A forward whose backward has not finished yet owns this context (its records and its BatchNorm workspace).  A forward whose autograd graph
-        has been freed without a backward (its output dropped, an exception) no longer does: the stem node's weak reference tells."""
+        has been freed without a backward (its output dropped, an exception) no longer does: the last node's weak reference tells."""
         if self.graph_ref is not None and self.graph_ref() is None:
             self.reset()
         return bool(self.in_flight or self.forks or self.folded or self.deferred or self.lazy_ok or self.lazy_dx)

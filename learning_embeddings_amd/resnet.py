@@ -310,6 +310,10 @@ class _GlobalAvgPoolFn(torch.autograd.Function):
     def forward(ctx, x):
         ctx.shape = x.shape
         ctx.cl = x.is_contiguous(memory_format=torch.channels_last)
+        # this node is the LAST one of the backbone's graph: it dies when the caller drops the forward's output without a backward -- the fusion context's
+        # own records (block outputs) keep every node upstream of it alive, so it is the one witness of "a backward can still come" (FusionContext.busy)
+        import weakref
+        _ops().fusion().graph_ref = weakref.ref(ctx)
         return torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)
 
     @staticmethod
@@ -346,9 +350,6 @@ class _OverlapConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, conv):
         ctx.fc = _ops().fusion()                  # the owning backbone's fusion records (ops.FusionContext); backward restores it
-        if getattr(conv, 'is_stem', False):
-            import weakref
-            ctx.fc.graph_ref = weakref.ref(ctx)   # this node lives exactly as long as the forward's autograd graph (FusionContext.busy)
         w16 = _ops().overlap().weight_lp(conv, x.dtype)
         nhwc = x.is_contiguous(memory_format=torch.channels_last)
         if nhwc and w16.dim() == 4 and not w16.is_contiguous(memory_format=torch.channels_last):

@@ -833,3 +833,56 @@ def test_order_embeddings_embedder_soft_clip_runs_the_kernel_and_matches_the_ora
     y.backward(g)
     gW = torch.zeros_like(W).index_add_(0, idx.reshape(-1), x.grad.reshape(-1, 10))
     assert (emb.embeddings.weight.grad - gW).abs().max().item() < 5e-6
+
+
+@pytest.mark.parametrize('B,K,D,M,chunk', [(32, 5, 10, 96, 32), (16, 40, 10, 300, 64), (24, 9, 128, 50, 16), (8, 256, 10, 240, 100)])
+def test_joint_loss_row_windows_add_up_to_the_whole_batch_launch(B, K, D, M, chunk):
+    """lec_joint_loss_fwd_bwd_window (the chunked step of config 5): one launch per window of feature rows evaluates the pairs whose image row lies in the
+    window (label-label pairs ride with the first).  Over the windows: every energy equals the whole-batch launch's BIT FOR BIT, the loss values add up to
+    its loss, the gradients to its gradients; and rows OUTSIDE a launch's window are never read into a result -- they hold NaN while that launch runs."""
+    rs = np.random.RandomState(B + K + D)
+    N = 400
+    W = rs.randn(N, D).astype(np.float32)
+    W *= (rs.uniform(0.1, 0.6, (N, 1)) / np.linalg.norm(W, axis=1, keepdims=True)).astype(np.float32)
+    R = (rs.randn(M, D) * 0.3).astype(np.float32)
+    # at most one image end point per pair (what a pick_per_level trainer draws): (label, image) positives; u-fixed negatives corrupt `to` with a label or an
+    # image, v-fixed negatives corrupt `from` with a label
+    frm = rs.randint(0, N, B); to = N + rs.permutation(M)[:B]
+    neg = np.empty((B, 2 * K), dtype=np.int64)
+    neg[:, :K] = np.where(rs.rand(B, K) < 0.5, rs.randint(0, N, (B, K)), N + rs.randint(0, M, (B, K)))
+    neg[:, K:] = rs.randint(0, N, (B, K))
+    to[:B // 4] = rs.randint(0, N, B // 4)                                     # a few label-label positives: their u-fixed negatives may still be images
+    for b in range(B):
+        for k in range(2 * K):
+            other = frm[b] if k < K else to[b]
+            while neg[b, k] == other:
+                neg[b, k] = rs.randint(0, N)
+        while frm[b] == to[b]:
+            frm[b] = rs.randint(0, N)
+    code = lambda a: torch.tensor(np.where(a < N, a, -1 - (a - N)), dtype=torch.int32, device=DEV).contiguous()
+    Wt, Rt = T(W), T(R)
+    cf, ct, cn = code(frm), code(to), code(neg)
+    alpha = 1.5
+    gW0 = torch.zeros_like(Wt); gR0 = torch.zeros_like(Rt)
+    l0, p0, n0 = ops.joint_loss_raw(Wt, Rt, cf, ct, cn, None, 0.1, alpha, 0, 1, 1, gW0, gR0)
+    gW = torch.zeros_like(Wt); gR = torch.zeros_like(Rt)
+    out = (torch.full((B,), float('nan'), device=DEV), torch.full((B, 2 * K), float('nan'), device=DEV))
+    total = 0.0
+    for lo in range(0, M, chunk):
+        hi = min(lo + chunk, M)
+        Rw = torch.full_like(Rt, float('nan')); Rw[lo:hi] = Rt[lo:hi]        # only this window's rows exist
+        l_c, _, _ = ops.joint_loss_raw(Wt, Rw, cf, ct, cn, None, 0.1, alpha, 0, 1, 1, gW, gR, window=(lo, hi, lo == 0), out=out)
+        assert torch.isfinite(l_c).all()
+        total += float(l_c.item())
+    assert torch.equal(out[0], p0) and torch.equal(out[1], n0)
+    assert abs(total - float(l0.item())) <= 1e-5 * max(1.0, abs(float(l0.item())))
+    assert torch.isfinite(gW).all() and torch.isfinite(gR).all()
+    assert (gW - gW0).abs().max().item() <= 1e-4 * gW0.abs().max().item() + 1e-7
+    assert (gR - gR0).abs().max().item() <= 1e-4 * gR0.abs().max().item() + 1e-7
+    # and with the fp16 shadow of the table
+    W16 = Wt.to(torch.float16)
+    l1, p1, n1 = ops.joint_loss_raw(Wt, Rt, cf, ct, cn, None, 0.1, alpha, 0, 1, 1, table_f16=W16)
+    out2 = (torch.zeros(B, device=DEV), torch.zeros(B, 2 * K, device=DEV))
+    for lo in range(0, M, chunk):
+        ops.joint_loss_raw(Wt, Rt, cf, ct, cn, None, 0.1, alpha, 0, 1, 1, table_f16=W16, window=(lo, min(lo + chunk, M), lo == 0), out=out2)
+    assert torch.equal(out2[0], p1) and torch.equal(out2[1], n1)
