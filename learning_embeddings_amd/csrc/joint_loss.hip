@@ -45,7 +45,22 @@ struct JointParams {
   // loss once per chunk, right behind that chunk's forward: every pair is evaluated exactly once over the launches, rows outside the window are never trusted
   // (they may not have been computed yet), e_pos / e_neg entries of pairs owned by other launches are left alone.  The plain entry: [0, INT_MAX), labels_too.
   int row_lo, row_hi, labels_too;
+#ifdef LEC_JL_STAMP
+  unsigned long long* stamps;   // instrumentation build only (tools/cone_timeline.sh): 10 words per wave, see jl_stamp below
+#endif
 };
+
+// Instrumentation (NOT a kernel variant: the arithmetic is untouched).  `hipcc -DLEC_JL_STAMP` -- tools/cone_timeline.sh builds this file alone into its own
+// library -- makes every wave record where its time goes: the constant 100 MHz clock at entry and exit (launch ramp, tail), and shader-clock cycles per phase.
+#ifdef LEC_JL_STAMP
+__device__ __forceinline__ unsigned long long jl_cycles() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
+__device__ __forceinline__ unsigned long long jl_realtime() { unsigned long long t; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
+#define JL_STAMP(var) const unsigned long long var = jl_cycles()
+#define JL_ACC(acc, a, b) acc += (b) - (a)
+#else
+#define JL_STAMP(var)
+#define JL_ACC(acc, a, b)
+#endif
 
 // the launch owning the pair (a, b) of node codes: the window holding its image row (with two image rows -- negatives of trainers that do not pick per level --
 // the larger one: the caller then guarantees both rows are valid by the time that window's launch runs)
@@ -156,17 +171,71 @@ __device__ __forceinline__ void wave_scatter_rows(const JointParams& P, int code
   wave_sync();
 }
 
-// raw row elements of node `code` owned by this lane (d = t, t+T, ...); kNoRow -> zeros, no memory access
+// raw row elements of node `code` owned by this lane (d = t, t+T, ...); kNoRow -> zeros, no memory access.
+// Lane-per-row geometries (T == 1): every load instruction of the wave touches 64 different rows, so the texture path sees one request per lane per
+// instruction: fp32 rows are fetched as 8-byte pairs when the row pitch keeps them aligned (D = 10: five requests per row instead of ten --
+// profiles/r05_cone_timeline.md: the row phase was 44 % of a wave's life at 4 096 x 256 x 10).
 template <int T, int EPL>
 __device__ __forceinline__ void fetch_row(const JointParams& P, int code, int t, float (&raw)[EPL]) {
   const bool ok = code != kNoRow && code_in_range(P, code);
   RowSrc src; src.f = P.table; src.h = nullptr;
   if (ok) src = row_src(P, code);
+  if (T == 1 && EPL % 2 == 0) {
+    const int64_t ld = code >= 0 ? P.ld_table : P.ld_feat;
+    if (src.h == nullptr && (ld & 1) == 0 && (P.D & 1) == 0) {             // (wave-uniform but for mixed label / image rows with different pitches: both even here)
+      // 16-byte pieces at 8-byte alignment (gfx950 global loads need dword alignment only), then an 8-byte tail: D = 10 -> 16 + 16 + 8: three requests per row
+      typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
+      constexpr int NQ = EPL / 4;
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        if (ok && 4 * i + 4 <= P.D) {
+          const f4u v = *(const f4u*)(src.f + 4 * i);
+          raw[4 * i] = v.x; raw[4 * i + 1] = v.y; raw[4 * i + 2] = v.z; raw[4 * i + 3] = v.w;
+        } else {
+          f2v a = {0.0f, 0.0f}, b2 = {0.0f, 0.0f};
+          if (ok && 4 * i < P.D) a = *(const f2v*)(src.f + 4 * i);
+          if (ok && 4 * i + 2 < P.D) b2 = *(const f2v*)(src.f + 4 * i + 2);
+          raw[4 * i] = a.x; raw[4 * i + 1] = a.y; raw[4 * i + 2] = b2.x; raw[4 * i + 3] = b2.y;
+        }
+      }
+#pragma unroll
+      for (int i = 2 * NQ; i < EPL / 2; ++i) {
+        f2v v = {0.0f, 0.0f};
+        if (ok && 2 * i < P.D) v = *(const f2v*)(src.f + 2 * i);
+        raw[2 * i] = v.x; raw[2 * i + 1] = v.y;
+      }
+      return;
+    }
+    if (src.h != nullptr && (P.ld_table & 1) == 0 && (P.D & 1) == 0) {     // fp16 shadow rows (config 5): two elements per 4-byte request
+      typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int i = 0; i < EPL / 2; ++i) {
+        h2v v = {(_Float16)0.0f, (_Float16)0.0f};
+        if (ok && 2 * i < P.D) v = *(const h2v*)(src.h + 2 * i);
+        raw[2 * i] = (float)v.x; raw[2 * i + 1] = (float)v.y;
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < EPL; ++i) {
     const int d = t + i * T;
     raw[i] = (ok && d < P.D) ? row_ld(src, d) : 0.0f;
   }
+}
+
+// sum over the wave's pair slots (lanes l, l + T, l + 2T, ...) for every t: the total lands in EVERY lane.  Inside a 16-lane row the steps are DPP rotations
+// (full-rate vector instructions, no LDS crossbar); the two cross-row steps stay ds_bpermute butterflies.  (Was: six ds_bpermute butterflies per value --
+// 144 of them for the two gradient rows of a lane-per-pair wave: 1.95 us of a 15.6 us wave at config 5, profiles/r05_cone_timeline.md.)
+template <int T>
+__device__ __forceinline__ float slot_sum(float v) {
+  if (T <= 1) v += dpp_move<0x121>(v);                 // row_ror:1
+  if (T <= 2) v += dpp_move<0x122>(v);                 // row_ror:2
+  if (T <= 4) v += dpp_move<0x124>(v);                 // row_ror:4
+  if (T <= 8) v += dpp_move<0x128>(v);                 // row_ror:8
+  if (T <= 16) v += __shfl_xor(v, 16, kWave);
+  if (T <= 32) v += __shfl_xor(v, 32, kWave);
+  return v;
 }
 
 template <int T, int EPL>
@@ -257,7 +326,7 @@ template <int T, int EPL, int ENERGY, bool GRAD, bool STAGE>
 // (Occupancy caps were measured in round 4: the lane-per-pair instance (T = 1, 12 elements per lane) holds 181 registers = 2 waves per SIMD; capped to 3 waves (168
 // registers, 9 spilled) / 4 waves (128, 53 spilled), us per launch: 256 x 256 x 10: 22.1 / 22.8 / 27.0; 4 096 x 256 x 10: 89.0 / 97.1 / 112.4; 256 x 256 x 128:
 // 58.8 / 58.8 / 60.8 -- the spills cost more than the third wave hides.  Removed.)
-__global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
+__global__ __launch_bounds__(512) void joint_loss_kernel(JointParams P) {
   constexpr int PPW = kWave / T;                      // pairs per wave iteration
   const int lane = threadIdx.x & 63;
   const int t = lane % T, slot = lane / T;
@@ -267,8 +336,13 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
   const bool task_valid = b < P.B;
   const int NP = 1 + 2 * P.K;
   float lsum = 0.0f;
+#ifdef LEC_JL_STAMP
+  const unsigned long long rt0 = jl_realtime();
+  unsigned long long c_rows = 0, c_energy = 0, c_bwd = 0;
+#endif
+  JL_STAMP(ck0);
   constexpr int kStage = (T == 1 && STAGE) ? kWave * (EPL + 1) : 1;
-  __shared__ float s_stage[4 * kStage];
+  __shared__ float s_stage[8 * kStage];
   float* stage = (T == 1 && STAGE) ? s_stage + (threadIdx.x >> 6) * kStage : nullptr;
 
   // NOTE: every lane of the wave walks the same control flow (butterflies need all 64 lanes); validity is a predicate.
@@ -277,9 +351,6 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
     ucode = P.pos_from[b]; vcode = P.pos_to[b];
     if (P.weights) w = P.weights[b];
   }
-  Row<EPL> U, V;
-  load_project<T, EPL>(P, ucode, task_valid && row_in_window(P, ucode), t, U, nullptr);     // every lane needs u_b, v_b: broadcast loads
-  load_project<T, EPL>(P, vcode, task_valid && row_in_window(P, vcode), t, V, nullptr);     // (an image row outside this launch's window stays zeros: it may not exist yet)
   float gu[EPL], gv[EPL];
 #pragma unroll
   for (int i = 0; i < EPL; ++i) { gu[i] = 0.0f; gv[i] = 0.0f; }
@@ -293,10 +364,19 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
     return (task_valid && it < P.iters && q > 0 && q < NP) ? P.neg[(int64_t)b * 2 * P.K + (q - 1)] : kNoRow;
   };
   constexpr bool pipelined = !(T == 1 && STAGE);
+  // the first two iterations' codes and the first iteration's rows are requested BEFORE u_b / v_b are projected: their two dependent round trips ride under the
+  // projection's own (code -> row -> sqrt / tanh / divide chain), instead of starting after it (config 5: 3.5 us + 2.8 us back to back in a 15.6 us wave)
+  // (Rows TWO iterations ahead, codes three, were tried in round 5: same launch times at 4 waves per block, 5 % slower at 8 (197 registers instead of 181):
+  // the row phase is bound by the texture path's one-address-per-lane rate, not by the distance of the prefetch.)
   int code_a = fetch_code(0), code_b = fetch_code(1);
   float raw_a[EPL];
   if (pipelined) fetch_row<T, EPL>(P, code_a, t, raw_a);
+  Row<EPL> U, V;
+  load_project<T, EPL>(P, ucode, task_valid && row_in_window(P, ucode), t, U, nullptr);     // every lane needs u_b, v_b: broadcast loads
+  load_project<T, EPL>(P, vcode, task_valid && row_in_window(P, vcode), t, V, nullptr);     // (an image row outside this launch's window stays zeros: it may not exist yet)
+  JL_STAMP(ck1);                                      // u_b, v_b gathered and projected
   for (int it = 0; it < P.iters; ++it) {
+    JL_STAMP(ci0);
     const int q = q0 + it * PPW + slot;               // pair index in the group: 0 = positive, 1+k = negative slot k
     const int kind_q = (!task_valid || q >= NP) ? 0 : (q == 0 ? 0 : (q - 1 < P.K ? 1 : 2));
     // (whole-batch launches own every pair; a windowed launch skips the pairs of other windows: their rows may not exist yet)
@@ -320,6 +400,8 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
       x[i] = kind == 2 ? O.p[i] : U.p[i];
       y[i] = kind == 1 ? O.p[i] : V.p[i];
     }
+    JL_STAMP(ci1);                                    // the iteration's rows have arrived (issued one iteration ahead) and are projected
+    JL_ACC(c_rows, ci0, ci1);
     // ---- forward: energy of every pair of this iteration
     float E;
     ConeFwd cf;
@@ -355,6 +437,8 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
         lsum += w * (h < 0.0f ? 0.0f : h);                                         // oe_h.py:839,846
       }
     }
+    JL_STAMP(ci2);                                    // energies evaluated and stored
+    JL_ACC(c_energy, ci1, ci2);
     // ---- backward: only pairs whose loss term is live carry gradient (positives; negatives inside the margin).
     // The whole wave skips the gradient arithmetic, the Jacobian chain and the scatter when none of its pairs is live.
     if (GRAD) {
@@ -391,27 +475,40 @@ __global__ __launch_bounds__(256) void joint_loss_kernel(JointParams P) {
         scatter_row_grad<T, EPL>(P, ocode, act && kind != 0, t, O, go, stage);
       }
     }
+    JL_STAMP(ci3);                                    // gradient coefficients, Jacobian chain, atomics issued
+    JL_ACC(c_bwd, ci2, ci3);
   }
+  JL_STAMP(ck2);
 
   if (GRAD) {
     // sum the per-slot partial gradients of u_b and v_b across the wave's pair slots, then one row-add each
 #pragma unroll
-    for (int m = T; m < kWave; m <<= 1) {
-#pragma unroll
-      for (int i = 0; i < EPL; ++i) { gu[i] += __shfl_xor(gu[i], m, kWave); gv[i] += __shfl_xor(gv[i], m, kWave); }
-    }
+    for (int i = 0; i < EPL; ++i) { gu[i] = slot_sum<T>(gu[i]); gv[i] = slot_sum<T>(gv[i]); }
+    // (Re-fetching the raw rows of u_b / v_b here instead of carrying them through the pair loop -- 181 -> 159 registers, a third wave per SIMD -- was measured in
+    // round 5: 18.4 -> 20.4 us at config 5, 73.5 -> 76.5 at 4 096 x 256 x 10: one more dependent round trip in every wave's tail costs more than the wave buys.)
     scatter_row_grad<T, EPL>(P, ucode, task_valid && slot == 0 && row_in_window(P, ucode), t, U, gu, stage);
     scatter_row_grad<T, EPL>(P, vcode, task_valid && slot == 0 && row_in_window(P, vcode), t, V, gv, stage);
   }
 
+  JL_STAMP(ck3);                                      // u_b / v_b gradients reduced over the wave and added
   lsum = group_sum<64>(lsum);
   block_publish_and_finalize(lsum, P.partials, P.counter, P.loss, 1.0f);
+#ifdef LEC_JL_STAMP
+  if (P.stamps && lane == 0) {
+    const unsigned long long ck4 = jl_cycles(), rt1 = jl_realtime();
+    unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* o = P.stamps + (size_t)wave_global * 10;
+    o[0] = rt0; o[1] = rt1; o[2] = ck1 - ck0; o[3] = c_rows; o[4] = c_energy; o[5] = c_bwd; o[6] = ck3 - ck2; o[7] = ck4 - ck3; o[8] = ck4 - ck0;
+    o[9] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
 template <int T, int EPL>
-static int launch(const JointParams& P, bool grad, int energy, int nblocks, hipStream_t st) {
-#define LEC_JL(E_, G_, S_) hipLaunchKernelGGL((joint_loss_kernel<T, EPL, E_, G_, S_>), dim3(nblocks), dim3(256), 0, st, P)
+static int launch(const JointParams& P, bool grad, int energy, int nblocks, int wpb, hipStream_t st) {
+#define LEC_JL(E_, G_, S_) hipLaunchKernelGGL((joint_loss_kernel<T, EPL, E_, G_, S_>), dim3(nblocks), dim3(64 * wpb), 0, st, P)
   if (T == 1 && P.lds_stage) {
     if (energy == LEC_ENERGY_HYP_CONE) { if (grad) LEC_JL(LEC_ENERGY_HYP_CONE, true, (T == 1)); else LEC_JL(LEC_ENERGY_HYP_CONE, false, (T == 1)); }
     else if (energy == LEC_ENERGY_EUC_CONE) { if (grad) LEC_JL(LEC_ENERGY_EUC_CONE, true, (T == 1)); else LEC_JL(LEC_ENERGY_EUC_CONE, false, (T == 1)); }
@@ -426,7 +523,7 @@ static int launch(const JointParams& P, bool grad, int energy, int nblocks, hipS
   return LEC_OK;
 }
 
-struct JointGeom { int T, EPL, iters, tasks_per_group, nblocks; };
+struct JointGeom { int T, EPL, iters, tasks_per_group, nblocks, wpb; };
 
 // (T lanes per pair, EPL row elements per lane) candidates: T*EPL >= D.  Small T = less redundant scalar math per pair
 // (the cone evaluation is computed by every lane of the T-group) and fewer butterflies; large T = coalesced row loads
@@ -467,12 +564,15 @@ static bool joint_geometry(int B, int K, int D, JointGeom& g) {
   g.iters = (int)iters;
   g.tasks_per_group = (int)((group_iters + iters - 1) / iters);
   int64_t waves = (int64_t)B * g.tasks_per_group;
-  g.nblocks = (int)((waves + 3) / 4);
+  // waves per block: every block ends with ONE returning atomic on the launch's ticket, and same-address atomics serialize (~15 ns each): 320 blocks of 4 waves
+  // spend ~4.6 us of a 19 us launch there (profiles/r05_cone_timeline.md).  Lane-per-pair instances (2 waves per SIMD fit) take 8-wave blocks.
+  g.wpb = tuning().jl_wpb > 0 ? tuning().jl_wpb : (g.T <= 2 ? 8 : 4);
+  g.nblocks = (int)((waves + g.wpb - 1) / g.wpb);
   return true;
 }
 
 static int dispatch(const JointGeom& g, const JointParams& P, bool grad, int energy, hipStream_t st) {
-#define LEC_G(T_, E_) if (g.T == T_ && g.EPL == E_) return launch<T_, E_>(P, grad, energy, g.nblocks, st)
+#define LEC_G(T_, E_) if (g.T == T_ && g.EPL == E_) return launch<T_, E_>(P, grad, energy, g.nblocks, g.wpb, st)
   LEC_G(1, 4); LEC_G(1, 12); LEC_G(1, 16); LEC_G(2, 8); LEC_G(4, 4); LEC_G(4, 8); LEC_G(8, 8); LEC_G(16, 4); LEC_G(16, 8);
   LEC_G(32, 8); LEC_G(64, 4); LEC_G(64, 8); LEC_G(64, 16);
 #undef LEC_G
@@ -487,6 +587,18 @@ extern "C" int64_t lec_loss_workspace_bytes(int B, int K, int D) {
   if (B < 0 || K < 0 || !lec::joint_geometry(B > 0 ? B : 1, K, D > 0 ? D : 1, g)) return LEC_E_ARG;
   return 256 + (int64_t)g.nblocks * sizeof(float);
 }
+
+#ifdef LEC_JL_STAMP
+static unsigned long long* g_jl_stamps = nullptr;
+static unsigned long long* lec_jl_stamp_target() { return g_jl_stamps; }
+extern "C" void lec_jl_set_stamp_buffer(void* p) { g_jl_stamps = (unsigned long long*)p; }      // 10 x waves 64-bit words, device memory (instrumentation build only)
+extern "C" int lec_jl_geometry(int B, int K, int D, int* T, int* EPL, int* iters, int* tasks_per_group, int* waves) {
+  lec::JointGeom g;
+  if (!lec::joint_geometry(B, K, D, g)) return -1;
+  *T = g.T; *EPL = g.EPL; *iters = g.iters; *tasks_per_group = g.tasks_per_group; *waves = B * g.tasks_per_group;
+  return 0;
+}
+#endif
 
 static int joint_loss_impl(int energy, int label_proj, int image_proj,
                                       const float* table, const void* table_f16, int64_t ld_table, int n_labels,
@@ -527,6 +639,9 @@ static int joint_loss_impl(int energy, int label_proj, int image_proj,
   P.lds_stage = tuning().jl_stage;
   LEC_CHECK_ARG(row_lo >= 0 && row_hi >= row_lo, "joint_loss: row window [%d, %d)", row_lo, row_hi);
   P.row_lo = row_lo; P.row_hi = row_hi; P.labels_too = labels_too ? 1 : 0;
+#ifdef LEC_JL_STAMP
+  P.stamps = lec_jl_stamp_target();
+#endif
   const bool grad = grad_table != nullptr;
   return dispatch(g, P, grad, energy, st);
 }
