@@ -162,7 +162,7 @@ def measure(args, dtype, rank, world, stamp, primary):
         eng.step()
         if i < 2:
             torch.cuda.synchronize(); stamp('%s: warm-up step %d done' % (dtype, i))
-    while eng.use_graph and eng.hip_graph is None and eng.graph_error is None:
+    while ((eng.use_graph and eng.hip_graph is None) or (eng.use_chunk_graph and eng.chunk_graph is None)) and eng.graph_error is None:
         eng.step()                                              # fewer warm-up steps than the capture needs: finish them untimed
     launch_probe = None
     if args.launch == 'auto' and eng.hip_graph is not None:
@@ -382,7 +382,9 @@ def measure(args, dtype, rank, world, stamp, primary):
                 if r_ is not None:
                     r_['traffic_note'] = 'null: %s (re-run tools/prof_round4.sh + tools/make_step_traffic_round4.py)' % e
     res = {'value': round(ips, 2), 'ms_per_step': round(dt / args.steps * 1e3, 3), 'step_ms': step_ms, 'dtype': 'f32' if f32 else dtype,
-           'launch_mode': ('hipgraph (forward + loss + backward of a step replayed as one graph)' if graph_mode else 'eager')
+           'launch_mode': ('hipgraph (forward + loss + backward of a step replayed as one graph)' if graph_mode else
+                           ('hipgraph per chunk (gather + forward + windowed loss + backward of %d CNN rows as ONE graph, replayed %d times per step)' % (eng.cnn_chunk, eng.n_rows_pad // eng.cnn_chunk)
+                            if getattr(eng, 'chunk_graph', None) is not None else 'eager'))
                           + (' -- the faster of the two on this box in the warm-up probe: hipGraph %.2f, eager %.2f ms/step' % (launch_probe['hipgraph_ms_per_step'], launch_probe['eager_ms_per_step'])
                              if launch_probe else ''),
            'launch_probe': launch_probe,
@@ -758,6 +760,8 @@ def main():
                           'global_batch': B * world, 'cnn_rows_per_step_per_gpu': eng.n_rows, 'cone_loss_dtype': 'f32',
                           'cnn_dtype': ('f32 activations and weights; every fp32 product computed as six exact bf16 x bf16 products on the matrix cores, fp32 accumulation (csrc/conv_f32x3.hip)' if args.conv_f32 == 'x3' else 'f32 activations, weights and accumulation (v_mfma_f32_32x32x2_f32: exact fp32)') if f32 else 'bf16 activations, fp32 master weights and accumulation',
                           'parallelism': 'dp%d' % world, 'sampler': args.sampler,
+                          'cnn_chunks': ('%d chunks of %d rows per step, one forward + windowed loss launch + backward each (BatchNorm batch = a chunk)' % (eng.n_rows_pad // eng.cnn_chunk, eng.cnn_chunk)) if eng.cnn_chunk else None,
+                          'table_dtype': 'fp16 shadow read by the loss kernel, fp32 master / gradients / Adam moments' if eng.table_h is not None else 'fp32',
                           'cnn_passes': ('%d concurrent passes of %d rows, one HIP stream each (BatchNorm batch = a pass: positives | image negatives, the reference\'s own separate forwards)' % (eng.passes, eng.n_rows // eng.passes)) if eng.passes > 1 else '1 pass of %d rows' % eng.n_rows,
                           'hbm_peak_allocated_gb': res['hbm_peak_allocated_gb'], 'launch_mode': res['launch_mode'], 'mean_loss': res['mean_loss']},
                # per-step durations inside the timed region (HIP events, start to start): `ms_per_step` above is the wall-clock MEAN the contract asks for

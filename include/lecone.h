@@ -124,13 +124,16 @@ int lec_joint_loss_fwd_bwd_f16(int energy, int label_proj, int image_proj,
  * [row_lo, row_hi) -- plus, when labels_too != 0, the pairs between two labels (pass it with one chunk of the step).  Over a step's launches every
  * pair of criterion.forward is evaluated once: e_pos / e_neg fill up entry by entry, each launch writes the sum of ITS terms to loss[0] (the caller
  * adds them), gradients add into grad_table / grad_feat.  Rows of `feat` outside the window are never read into a result.  table_f16 != NULL:
- * the label rows are read from the fp16 shadow (as lec_joint_loss_fwd_bwd_f16), else from `table`. */
+ * the label rows are read from the fp16 shadow (as lec_joint_loss_fwd_bwd_f16), else from `table`.
+ * window_dev != NULL (device int32[4] = {row_lo, row_hi, labels_too, feat_base}): the window is read from device memory at kernel start (the three
+ * arguments are ignored) and `feat` / `grad_feat` are chunk-sized buffers whose row 0 is feature row feat_base (n_feat = their row count) -- one launch,
+ * captured once into a hipGraph, then serves every chunk of every step; the host rewrites four integers per chunk. */
 int lec_joint_loss_fwd_bwd_window(int energy, int label_proj, int image_proj,
                                   const float* table, const void* table_f16, int64_t ld_table, int n_labels,
                                   const float* feat, int64_t ld_feat, int n_feat,
                                   const int32_t* pos_from, const int32_t* pos_to, const int32_t* neg, const float* weights,
                                   int B, int K, int D, float K_cone, float alpha,
-                                  int row_lo, int row_hi, int labels_too,
+                                  int row_lo, int row_hi, int labels_too, const int32_t* window_dev,
                                   float* e_pos, float* e_neg, float* loss,
                                   float* grad_table, float* grad_feat,
                                   void* workspace, int64_t workspace_bytes, lec_stream_t stream);

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LEC_LIB_PATH') or os.path.join(_HERE, 'liblecone.so')     # LEC_LIB_PATH: A/B builds of the same ABI
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 OK, E_ARG, E_HIP, E_EMPTY, E_STATE = 0, -1, -2, -3, -4
 ENERGY_HYP_CONE, ENERGY_ORDER, ENERGY_EUC_CONE = 0, 1, 2
@@ -49,7 +49,7 @@ def _load():
                                          p, p, p, p, p, p, i64, p]),
         'lec_joint_loss_fwd_bwd_f16': (i32, [i32, i32, i32, p, i64, i32, p, i64, i32, p, p, p, p, i32, i32, i32, f32, f32,
                                              p, p, p, p, p, p, i64, p]),
-        'lec_joint_loss_fwd_bwd_window': (i32, [i32, i32, i32, p, p, i64, i32, p, i64, i32, p, p, p, p, i32, i32, i32, f32, f32, i32, i32, i32,
+        'lec_joint_loss_fwd_bwd_window': (i32, [i32, i32, i32, p, p, i64, i32, p, i64, i32, p, p, p, p, i32, i32, i32, f32, f32, i32, i32, i32, p,
                                                 p, p, p, p, p, p, i64, p]),
         'lec_table_step_adam_f16': (i32, [p, p, p, p, i64, i32, i32, f32, f32, f32, f32, i32, f32, i32, i32, p, p]),
         'lec_label_project_fwd': (i32, [i32, p, i64, i32, p, i64, i32, f32, p, i64, p]),

@@ -45,6 +45,8 @@ struct JointParams {
   // loss once per chunk, right behind that chunk's forward: every pair is evaluated exactly once over the launches, rows outside the window are never trusted
   // (they may not have been computed yet), e_pos / e_neg entries of pairs owned by other launches are left alone.  The plain entry: [0, INT_MAX), labels_too.
   int row_lo, row_hi, labels_too;
+  int feat_base;        // feature row r of a node code lives at feat / grad_feat row r - feat_base (a chunk-sized buffer: feat_base = row_lo; else 0)
+  const int32_t* window_dev;   // optional {row_lo, row_hi, labels_too, feat_base} in DEVICE memory, read at kernel start: one captured launch serves every chunk of a step
 #ifdef LEC_JL_STAMP
   unsigned long long* stamps;   // instrumentation build only (tools/cone_timeline.sh): 10 words per wave, see jl_stamp below
 #endif
@@ -116,12 +118,14 @@ constexpr int kNoRow = INT_MIN;
 // A row of the label table (fp32 master, or its fp16 shadow when one is given) or of the image features; reads element d.
 struct RowSrc { const float* f; const _Float16* h; };
 __device__ __forceinline__ bool code_in_range(const JointParams& P, int code) {      // a stale / corrupt node code must not become an
-  return code >= 0 ? code < P.n_labels : (-1 - code) < P.n_feat;                      // out-of-bounds read or atomic: it is skipped
+  if (code >= 0) return code < P.n_labels;                                            // out-of-bounds read or atomic: it is skipped
+  const int r = (-1 - code) - P.feat_base;
+  return r >= 0 && r < P.n_feat;
 }
 __device__ __forceinline__ RowSrc row_src(const JointParams& P, int code) {
   RowSrc r; r.f = nullptr; r.h = nullptr;
   if (code >= 0) { if (P.table_h) r.h = P.table_h + (int64_t)code * P.ld_table; else r.f = P.table + (int64_t)code * P.ld_table; }
-  else r.f = P.feat + (int64_t)(-1 - code) * P.ld_feat;
+  else r.f = P.feat + (int64_t)(-1 - code - P.feat_base) * P.ld_feat;
   return r;
 }
 __device__ __forceinline__ float row_ld(const RowSrc& r, int d) { return r.h ? (float)r.h[d] : r.f[d]; }
@@ -164,7 +168,7 @@ __device__ __forceinline__ void wave_scatter_rows(const JointParams& P, int code
     const int r = eidx / EPL, d = eidx - r * EPL;
     const int rc = __shfl(code_or_norow, r, kWave);
     if (rc != kNoRow && d < P.D && code_in_range(P, rc)) {
-      float* dst = rc >= 0 ? P.grad_table + (int64_t)rc * P.ld_table : P.grad_feat + (int64_t)(-1 - rc) * P.ld_feat;
+      float* dst = rc >= 0 ? P.grad_table + (int64_t)rc * P.ld_table : P.grad_feat + (int64_t)(-1 - rc - P.feat_base) * P.ld_feat;
       atomicAdd(dst + d, stage[r * LDW + d]);
     }
   }
@@ -314,7 +318,7 @@ __device__ __forceinline__ void scatter_row_grad(const JointParams& P, int code,
     return;
   }
   if (!active) return;
-  float* dst = code >= 0 ? P.grad_table + (int64_t)code * P.ld_table : P.grad_feat + (int64_t)(-1 - code) * P.ld_feat;
+  float* dst = code >= 0 ? P.grad_table + (int64_t)code * P.ld_table : P.grad_feat + (int64_t)(-1 - code - P.feat_base) * P.ld_feat;
 #pragma unroll
   for (int i = 0; i < EPL; ++i) {
     int d = t + i * T;
@@ -326,7 +330,11 @@ template <int T, int EPL, int ENERGY, bool GRAD, bool STAGE>
 // (Occupancy caps were measured in round 4: the lane-per-pair instance (T = 1, 12 elements per lane) holds 181 registers = 2 waves per SIMD; capped to 3 waves (168
 // registers, 9 spilled) / 4 waves (128, 53 spilled), us per launch: 256 x 256 x 10: 22.1 / 22.8 / 27.0; 4 096 x 256 x 10: 89.0 / 97.1 / 112.4; 256 x 256 x 128:
 // 58.8 / 58.8 / 60.8 -- the spills cost more than the third wave hides.  Removed.)
-__global__ __launch_bounds__(512) void joint_loss_kernel(JointParams P) {
+__global__ __launch_bounds__(512) void joint_loss_kernel(JointParams P_in) {
+  JointParams P = P_in;
+  if (P.window_dev) {                                 // (uniform scalar loads; the arguments' own window is the fallback)
+    P.row_lo = P.window_dev[0]; P.row_hi = P.window_dev[1]; P.labels_too = P.window_dev[2]; P.feat_base = P.window_dev[3];
+  }
   constexpr int PPW = kWave / T;                      // pairs per wave iteration
   const int lane = threadIdx.x & 63;
   const int t = lane % T, slot = lane / T;
@@ -607,7 +615,7 @@ static int joint_loss_impl(int energy, int label_proj, int image_proj,
                                       const float* weights, int B, int K, int D, float K_cone, float alpha,
                                       float* e_pos, float* e_neg, float* loss, float* grad_table, float* grad_feat,
                                       void* workspace, int64_t workspace_bytes, lec_stream_t stream,
-                                      int row_lo = 0, int row_hi = INT_MAX, int labels_too = 1) {
+                                      int row_lo = 0, int row_hi = INT_MAX, int labels_too = 1, const int32_t* window_dev = nullptr) {
   using namespace lec;
   LEC_CHECK_ARG(energy >= LEC_ENERGY_HYP_CONE && energy <= LEC_ENERGY_EUC_CONE, "joint_loss: unknown energy %d", energy);
   LEC_CHECK_ARG(label_proj >= LEC_LABEL_RAW && label_proj <= LEC_LABEL_SOFTCLIP_K, "joint_loss: unknown label_proj %d", label_proj);
@@ -639,6 +647,7 @@ static int joint_loss_impl(int energy, int label_proj, int image_proj,
   P.lds_stage = tuning().jl_stage;
   LEC_CHECK_ARG(row_lo >= 0 && row_hi >= row_lo, "joint_loss: row window [%d, %d)", row_lo, row_hi);
   P.row_lo = row_lo; P.row_hi = row_hi; P.labels_too = labels_too ? 1 : 0;
+  P.feat_base = 0; P.window_dev = window_dev;
 #ifdef LEC_JL_STAMP
   P.stamps = lec_jl_stamp_target();
 #endif
@@ -677,16 +686,18 @@ extern "C" int lec_joint_loss_fwd_bwd_f16(int energy, int label_proj, int image_
 // forward, evaluates the pairs whose image row lies in [row_lo, row_hi) -- and the label-label pairs when labels_too != 0 (pass it with exactly one chunk).
 // Over the launches of a step every pair is evaluated once: e_pos / e_neg fill up, the loss values add up (one scalar per launch), gradients add into
 // grad_table / grad_feat as always.  feat rows outside the window are never read into a result.  table_f16 != NULL: the label rows are read from the
-// fp16 shadow (as lec_joint_loss_fwd_bwd_f16); else from `table`.
+// fp16 shadow (as lec_joint_loss_fwd_bwd_f16); else from `table`.  window_dev != NULL: {row_lo, row_hi, labels_too, feat_base} are read from DEVICE memory at
+// kernel start instead (the arguments are ignored) and feat / grad_feat are CHUNK buffers whose row 0 is feature row feat_base: the launch can be captured once
+// into a hipGraph and replayed for every chunk of every step, the host only rewrites four integers.
 extern "C" int lec_joint_loss_fwd_bwd_window(int energy, int label_proj, int image_proj,
                                              const float* table, const void* table_f16, int64_t ld_table, int n_labels,
                                              const float* feat, int64_t ld_feat, int n_feat,
                                              const int32_t* pos_from, const int32_t* pos_to, const int32_t* neg,
                                              const float* weights, int B, int K, int D, float K_cone, float alpha,
-                                             int row_lo, int row_hi, int labels_too,
+                                             int row_lo, int row_hi, int labels_too, const int32_t* window_dev,
                                              float* e_pos, float* e_neg, float* loss, float* grad_table, float* grad_feat,
                                              void* workspace, int64_t workspace_bytes, lec_stream_t stream) {
   LEC_CHECK_ARG(table || table_f16, "joint_loss_window: table null");
   return joint_loss_impl(energy, label_proj, image_proj, table_f16 ? nullptr : table, table_f16, ld_table, n_labels, feat, ld_feat, n_feat, pos_from, pos_to, neg,
-                         weights, B, K, D, K_cone, alpha, e_pos, e_neg, loss, grad_table, grad_feat, workspace, workspace_bytes, stream, row_lo, row_hi, labels_too);
+                         weights, B, K, D, K_cone, alpha, e_pos, e_neg, loss, grad_table, grad_feat, workspace, workspace_bytes, stream, row_lo, row_hi, labels_too, window_dev);
 }

@@ -211,7 +211,9 @@ class StepEngine:
         # static device inputs of the step (the captured graph reads these addresses)
         self.codes_dev = torch.zeros((self.B, 2 + 2 * K), dtype=torch.int32, device=self.device)
         self.idx_dev = torch.zeros(self.n_rows_pad, dtype=torch.int64, device=self.device)
-        self.use_graph = bool(use_graph) and self.cnn_chunk is None      # the chunked step launches eagerly
+        self.use_graph = bool(use_graph) and self.cnn_chunk is None      # the chunked step replays ONE graph per chunk instead (use_chunk_graph)
+        self.use_chunk_graph = bool(use_graph) and self.cnn_chunk is not None
+        self.chunk_graph = None
         if self.passes > 1 and self.overlap is not None and self.overlap.side is not None:
             # concurrent passes AND a weight-gradient side stream (an opt-in combination that measures slower: 130.5 against 125 ms): capturing it
             # aborts inside the runtime (the side stream is forked from two capturing pass streams at once), so this combination launches eagerly
@@ -321,46 +323,86 @@ class StepEngine:
         done = torch.cuda.Event(); done.record(); self._in_flight.append(done)
         return loss
 
+    def _chunk_body(self):
+        """ONE chunk of the chunked step on static device inputs (idx_chunk, win_dev): gather, backbone forward, the fused loss over the pairs whose image lies
+        in the chunk (lec_joint_loss_fwd_bwd_window reading its window from device memory), backbone backward with the gradient that launch left.  This is the region
+        the per-chunk hipGraph captures: the same graph is replayed for every chunk of every step."""
+        codes = self.codes_dev
+        pos_from = codes[:, 0].contiguous(); pos_to = codes[:, 1].contiguous(); negc = codes[:, 2:].contiguous()
+        f = self.img_feat_net.forward_raw(_gather_images(self.pool, self.idx_chunk))
+        self.feats_c.copy_(f.detach())
+        self.gfeat_c.zero_()
+        l_c, _, _ = ops.joint_loss_raw(self.table, self.feats_c, pos_from, pos_to, negc, None, self.K_cone, self.alpha, _lib.ENERGY_HYP_CONE,
+                                       _lib.LABEL_HYP, _lib.IMAGE_SOFTCLIP, self.table_grad, self.gfeat_c, table_f16=self.table_h,
+                                       window_dev=self.win_dev, out=self._chunk_out)
+        self.loss_buf += l_c
+        f.backward(self.gfeat_c)
+        if self.overlap is not None:
+            self.overlap.join()
+
+    def _capture_chunk(self):
+        """Capture `_chunk_body` into a hipGraph (after eager steps have sized every workspace).  On any capture error the engine keeps launching eagerly and says so."""
+        saved_timers = self.backbone.step_timers
+        try:
+            torch.cuda.synchronize()
+            self.backbone.step_timers = None
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                self._chunk_body()
+            torch.cuda.synchronize()
+            self.chunk_graph = g
+        except Exception as e:                                     # noqa: BLE001  (launch mode only; the kernels are the same)
+            self.graph_error = '%s: %s' % (type(e).__name__, e)
+            self.chunk_graph = None
+            import sys
+            print('[StepEngine] per-chunk hipGraph capture failed, staying in eager launch mode: %s' % self.graph_error, file=sys.stderr)
+            torch.cuda.synchronize()
+        finally:
+            self.backbone.step_timers = saved_timers
+
     def _core_chunked(self, ev=None):
         """The same step with the CNN rows in chunks (see `cnn_chunk`), ONE forward per chunk: forward of a chunk, the fused loss over the pairs whose image lies
         in that chunk (lec_joint_loss_fwd_bwd_window: every pair of the step has at most one image end point -- `step()` checks the negative layout -- so a
         chunk's loss terms need that chunk's embeddings and the label table only), backward of the chunk with the gradient the launch left, next chunk.
         Activations of one chunk are alive at a time; BatchNorm batch statistics are per chunk, as the reference's own separate forwards of positives and
         negatives have them (oe_h.py:980-985, 1003-1009).  (Round 4 ran every chunk's forward TWICE -- once without saved activations to have all embeddings
-        before one loss launch, once more in front of its backward: a quarter of the step.)"""
-        codes = self.codes_dev
-        pos_from = codes[:, 0].contiguous(); pos_to = codes[:, 1].contiguous(); negc = codes[:, 2:].contiguous()
-        self.arena.zero_grad(); self.table_grad.zero_(); self.gfeat.zero_()
+        before one loss launch, once more in front of its backward: a quarter of the step.)  Launch mode: the chunk is ONE hipGraph, captured once and replayed
+        for every chunk of every step (the host rewrites the chunk's image indices and four integers of window): ~2 000 launches per chunk -> 3."""
+        self.arena.zero_grad(); self.table_grad.zero_()
         if ev: ev[0].record()
         R, C = self.n_rows_pad, self.cnn_chunk
-        if getattr(self, '_chunk_feats', None) is None:
-            self._chunk_feats = torch.zeros(R, self.D, device=self.device)           # rows of later chunks hold the previous step's (finite) values: never read into a result
-            self._chunk_out = (torch.zeros(self.B, device=self.device), torch.zeros(self.B, 2 * self.K, device=self.device))
-        feats, out = self._chunk_feats, self._chunk_out
-        loss = torch.zeros(1, device=self.device)
+        if getattr(self, 'feats_c', None) is None:
+            dev = self.device
+            self.feats_c = torch.zeros(C, self.D, device=dev); self.gfeat_c = torch.zeros(C, self.D, device=dev)
+            self.idx_chunk = torch.zeros(C, dtype=torch.int64, device=dev)
+            self.win_dev = torch.zeros(4, dtype=torch.int32, device=dev)
+            self.win_table = torch.tensor([[lo, lo + C, 1 if lo == 0 else 0, lo] for lo in range(0, R, C)], dtype=torch.int32, device=dev)
+            self._chunk_feats = torch.zeros(R, self.D, device=dev)                   # every chunk's raw CNN outputs of the step (tests, smoke)
+            self._chunk_out = (torch.zeros(self.B, device=dev), torch.zeros(self.B, 2 * self.K, device=dev))
+            self.loss_buf = torch.zeros(1, device=dev)
+        self.loss_buf.zero_()
         # Several backward passes add into the same gradient slots: the reducer's per-parameter hooks stay muted for all of them (a
         # parameter reports in EVERY chunk; a bucket launched after chunk 0 would reduce a partial sum and race with the later chunks'
         # atomics) and the buckets are reduced once, by step()'s reducer.finish(), after the last chunk's weight gradients have joined.
         live = self.reducer.live
         self.reducer.live = False
         try:
-            for lo in range(0, R, C):
-                f = self.img_feat_net.forward_raw(_gather_images(self.pool, self.idx_dev[lo:lo + C]))
-                feats[lo:lo + C] = f.detach()
-                l_c, e_pos, e_neg = ops.joint_loss_raw(self.table, feats, pos_from, pos_to, negc, None, self.K_cone, self.alpha, _lib.ENERGY_HYP_CONE,
-                                                       _lib.LABEL_HYP, _lib.IMAGE_SOFTCLIP, self.table_grad, self.gfeat, table_f16=self.table_h,
-                                                       window=(lo, lo + C, lo == 0), out=out)
-                loss += l_c
-                f.backward(self.gfeat[lo:lo + C])
-                if self.overlap is not None:
-                    self.overlap.join()
+            if (self.use_chunk_graph and self.chunk_graph is None and self.graph_error is None and self.step_no >= self.graph_after):
+                self._capture_chunk()                  # (hooks muted: a collective must not be issued into the capture)
+            for i, lo in enumerate(range(0, R, C)):
+                self.idx_chunk.copy_(self.idx_dev[lo:lo + C]); self.win_dev.copy_(self.win_table[i])
+                if self.chunk_graph is not None:
+                    self.chunk_graph.replay()
+                else:
+                    self._chunk_body()
+                self._chunk_feats[lo:lo + C].copy_(self.feats_c)
         finally:
             self.reducer.live = live
             self.reducer.reset()                       # nothing launched: finish() reduces every bucket and the table gradient
-        self.last_feats = feats
+        self.last_feats = self._chunk_feats
         if ev:
             ev[1].record(); ev[2].record(); ev[3].record()        # (forward, loss and backward interleave per chunk: the whole step is "cnn_fwd" in phases_ms)
-        return loss, e_pos, e_neg
+        return self.loss_buf.clone(), self._chunk_out[0], self._chunk_out[1]
 
     def _core(self, ev=None):
         """Forward + fused loss + backward of one step on the static device inputs (codes_dev, idx_dev).  This is the
@@ -537,6 +579,9 @@ def _release_graphs(eng):
     if getattr(eng, 'hip_graph', None) is not None or getattr(eng, '_graph_saved', None) is not None:
         torch.cuda.synchronize()
     eng.hip_graph = None
+    if getattr(eng, 'chunk_graph', None) is not None:
+        torch.cuda.synchronize()
+        eng.chunk_graph = None
     if hasattr(eng, '_graph_saved'):
         eng._graph_saved = None
     eng.graph_out = None

@@ -143,12 +143,14 @@ class ImageSoftClipFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------------ fused joint loss
 def joint_loss_raw(table, feat, pos_from, pos_to, neg, weights, K_cone, alpha, energy, label_proj, image_proj,
-                   grad_table=None, grad_feat=None, table_f16=None, window=None, out=None):
+                   grad_table=None, grad_feat=None, table_f16=None, window=None, out=None, window_dev=None):
     """One launch of lec_joint_loss_fwd_bwd.  table [N,D], feat [n_feat,D] (or None): contiguous float32; index tensors:
     contiguous int32 device tensors of node codes (>= 0 label row, < 0 feature row -1-code).  Gradients are ADDED into
     grad_table / grad_feat when given (same shapes, contiguous).  Returns (loss[1], e_pos[B], e_neg[B,2K]).
     window = (row_lo, row_hi, labels_too): lec_joint_loss_fwd_bwd_window -- only the pairs whose image row lies in [row_lo, row_hi) (and the label-label pairs
-    when labels_too) are evaluated; `out` = (e_pos, e_neg) buffers the launches of one step share (entries of other windows' pairs are left alone)."""
+    when labels_too) are evaluated; `out` = (e_pos, e_neg) buffers the launches of one step share (entries of other windows' pairs are left alone).
+    window_dev: int32[4] DEVICE tensor {row_lo, row_hi, labels_too, feat_base} read by the kernel itself; feat / grad_feat are then chunk buffers whose row 0 is
+    feature row feat_base (a launch that can be captured once and replayed for every chunk)."""
     def chk(t, name, like=None):
         if t.dtype != torch.float32 or t.dim() != 2 or not t.is_contiguous():
             raise ValueError('%s must be a contiguous 2-D float32 tensor' % name)
@@ -194,11 +196,15 @@ def joint_loss_raw(table, feat, pos_from, pos_to, neg, weights, K_cone, alpha, e
         if table_f16.dtype != torch.float16 or table_f16.shape != table.shape or not table_f16.is_contiguous():
             raise ValueError('table_f16 must be a contiguous float16 tensor of the table\'s shape')
         fn, tbl = lib.lec_joint_loss_fwd_bwd_f16, table_f16
+    if window_dev is not None:
+        if window_dev.dtype != torch.int32 or window_dev.numel() != 4 or not window_dev.is_cuda:
+            raise ValueError('window_dev must be a device int32[4] tensor {row_lo, row_hi, labels_too, feat_base}')
+        window = (0, 0, 0)
     if window is not None:
         lo, hi, labels_too = window
         check(lib.lec_joint_loss_fwd_bwd_window(energy, label_proj, image_proj, dptr(table), dptr(table_f16) if table_f16 is not None else None, D, N,
                                                 dptr(feat), D, n_feat, dptr(pos_from), dptr(pos_to), dptr(neg) if K else None,
-                                                dptr(weights), B, K, D, float(K_cone), float(alpha), int(lo), int(hi), int(bool(labels_too)),
+                                                dptr(weights), B, K, D, float(K_cone), float(alpha), int(lo), int(hi), int(bool(labels_too)), dptr(window_dev),
                                                 dptr(e_pos), dptr(e_neg) if K else None, dptr(loss),
                                                 dptr(grad_table), dptr(grad_feat) if feat is not None else dptr(grad_table),
                                                 dptr(ws), ws.numel(), stream_ptr()))

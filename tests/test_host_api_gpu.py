@@ -552,7 +552,7 @@ def test_config5_as_stated_b256_k256_fp16_table_chunked_cnn(dtype):
     Negatives of the WHOLE first batch (256 x 512) bit-equal to the reference's own stream over the real dense 54 096^2 matrix of this DAG (fixture
     F4b, tests/golden/make_golden_sampler_s5.py), the second step's against the oracle's matrix-free sampler walking the same MT19937 stream on;
     loss / energies against the oracle evaluated on the fp16-rounded table at the embedding boundary."""
-    eng = StepEngine('cfg5', n_images=4096, dtype=dtype, table_dtype='fp16')
+    eng = StepEngine('cfg5', n_images=4096, dtype=dtype, table_dtype='fp16', use_graph=True, graph_after=1)      # step 0 launches its chunks eagerly, step 1 replays the chunk graph
     assert eng.B == 256 and eng.K == 256 and eng.N == 50000 and eng.cnt == 28 and eng.n_rows == 256 * 29
     assert eng.cnn_chunk is not None and eng.table_h is not None
     W16 = eng.table_h.float().cpu().numpy().copy()
@@ -574,11 +574,31 @@ def test_config5_as_stated_b256_k256_fp16_table_chunked_cnn(dtype):
     assert np.abs(e_pos.cpu().numpy() - o[1]).max() <= 1e-4 and np.abs(e_neg.cpu().numpy() - o[2]).max() <= 1e-4
     assert torch.equal(eng.table_h, eng.table.to(torch.float16))                  # the shadow follows the updated master
     l2 = eng.step(); torch.cuda.synchronize()
-    assert torch.isfinite(l2)
+    assert torch.isfinite(l2) and eng.chunk_graph is not None, eng.graph_error
     frm1, to1, neg1 = eng.last[3:]
     nb = 64
     assert np.array_equal(lazy.draw_batch(frm1[:nb], to1[:nb], eng.K), neg1[:nb]), 'config 5: negatives of the second batch differ from the oracle stream'
     eng.close()
+
+
+def test_chunked_step_replayed_as_one_graph_per_chunk_equals_eager_chunks():
+    """The chunked step's launch mode: ONE hipGraph of (gather, forward, windowed loss, backward) captured once and replayed for every chunk of every step --
+    the loss kernel reads its row window from device memory (lec_joint_loss_fwd_bwd_window's window_dev).  Same losses, energies and label table as the
+    eagerly launched chunks; the image network's gradients equal to float-atomic order."""
+    a = StepEngine('tiny', n_images=64, dtype='fp32', cnn_chunk=8, use_graph=False)
+    b = StepEngine('tiny', n_images=64, dtype='fp32', cnn_chunk=8, use_graph=True, graph_after=1)
+    assert a.cnn_chunk == 8 and b.cnn_chunk == 8 and a.n_rows_pad // 8 >= 2
+    for s_ in range(4):
+        la = a.step(); lb = b.step()
+        torch.cuda.synchronize()
+        assert (b.chunk_graph is not None) == (s_ >= 1), b.graph_error
+        assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, abs(float(la))), (s_, float(la), float(lb))
+        assert np.array_equal(a.last[5], b.last[5])
+        assert (a.last[1] - b.last[1]).abs().max().item() <= 1e-5 and (a.last[2] - b.last[2]).abs().max().item() <= 1e-5
+    assert (a.table - b.table).abs().max().item() < 1e-5
+    d = (a.arena.grad - b.arena.grad).double().norm().item() / a.arena.grad.double().norm().item()
+    assert d < 1e-3, d
+    a.close(); b.close()
 
 
 def test_config5_deep_hierarchy_256_negatives_loss_path():
@@ -894,19 +914,19 @@ def _dp_engine_worker(rank, world, port, overlap, q, graph=False, chunk=None):
     for _ in range(3):
         eng.step(); negs.append(eng.last[5].copy())
     t.cuda.synchronize()
-    assert (eng.hip_graph is not None) == graph, eng.graph_error
+    assert ((eng.hip_graph if chunk is None else eng.chunk_graph) is not None) == graph, eng.graph_error
     q.put((rank, eng.arena.data.cpu().numpy(), eng.table.cpu().numpy(), negs))
     t.distributed.barrier(); eng.close(); t.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize('overlap,graph,chunk', [(False, False, None), (True, False, None), (True, True, None), (True, False, 8)])
+@pytest.mark.parametrize('overlap,graph,chunk', [(False, False, None), (True, False, None), (True, True, None), (True, False, 8), (True, True, 8)])
 def test_step_engine_data_parallel_replicas_stay_identical(overlap, graph, chunk):
     """StepEngine under DP (2 ranks sharing the GPU over gloo), with the shadow-weight / direct-gradient path and with the
     side-stream weight gradients, and with the hipGraph launch mode (all-reduce after the replay): after 3 steps both ranks
     hold bit-identical CNN parameters and label table, and each rank's negatives are its slice of the single-process
     global stream.  chunk=8: the CNN rows in two chunks per step (engine.cnn_chunk, fp32) -- one backward per chunk into the same
     gradient slots: the buckets are reduced ONCE, after the last chunk (a reducer that fires after chunk 0 leaves the later chunks'
-    gradients local and the replicas drift apart)."""
+    gradients local and the replicas drift apart); with graph=True the chunk is ONE hipGraph replayed per chunk (engine._chunk_body)."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
