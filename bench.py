@@ -155,7 +155,7 @@ def measure(args, dtype, rank, world, stamp, primary):
     from learning_embeddings_amd.resnet import conv_macs
     table_dtype = args.table_dtype or ('fp16' if args.workload == 'cfg5' else 'fp32')
     eng = StepEngine(args.workload, dtype=dtype, sampler_mode=args.sampler, batch=args.batch, overlap_wgrad=False if args.no_overlap_wgrad else args.overlap_wgrad,
-                     use_graph=args.launch != 'eager', passes=args.passes, table_dtype=table_dtype)
+                     use_graph=args.launch != 'eager', passes=args.passes, table_dtype=table_dtype, cnn_chunk=args.cnn_chunk)
     dev = eng.device
     stamp('%s: engine built' % dtype)
     for i in range(args.warmup):
@@ -653,6 +653,7 @@ def main():
                     help='fp32 convolutions of the headline run: native = f32-input MFMA (exact fp32 fmaf chains); x3 = the same products on the bf16 matrix cores '
                          '(three bf16 pieces per operand, six exact products; fp32-grade error, see tests). Default native; x3 is reported as secondary_f32_split')
     ap.add_argument('--batch', type=int, default=None)
+    ap.add_argument('--cnn-chunk', type=int, default=None, help='CNN rows per chunk of a chunked step (config 5; default: the engine\'s rule, 512)')
     ap.add_argument('--table-dtype', default=None, choices=['fp32', 'fp16'],
                     help='what the loss kernel reads the label rows from: the fp32 table, or its fp16 shadow (fp32 master, gradients and Adam moments). '
                          'Default: fp16 for cfg5 (BASELINE.json configs[4]: "fp16+fp32-master"), fp32 otherwise')
