@@ -87,10 +87,11 @@ def cpu_baseline(eng, budget_s=25.0, rows=64):
     K, D, N = eng.K, eng.D, eng.N
     cnt = eng.cnt
     Bs = max(1, rows // (1 + cnt)); rows = Bs * (1 + cnt)
-    M = min(eng.M, 2048)                                       # dense (N+M)^2 bool matrix must stay small
     lm = eng.labelmap
-    leaf = [lm.level_start[-1] + (j % lm.levels[-1]) for j in range(M)]
-    if N + M <= 20000:
+    lazy = N + min(eng.M, 2048) > 20000
+    M = eng.M if lazy else min(eng.M, 2048)                    # (dense (N+M)^2 bool matrix must stay small)
+    leaf = [lm.level_start[-1] + int(eng.img_leaf[j]) for j in range(M)] if lazy else [lm.level_start[-1] + (j % lm.levels[-1]) for j in range(M)]
+    if not lazy:
         A = O.dense_negative_adjacency(N, sorted(lm.edges), leaf)
         smp = O.DenseSampler(A, lm.levels, pick_per_level=True, seed=0)
     else:                                                      # config 5's hierarchy: the dense matrix would be 2.7 GB; the same row / column scan, matrix-free
@@ -648,7 +649,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='cfg3')
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'], help='precision of the headline measurement (fp32 = the reference\'s)')
-    ap.add_argument('--secondary', default='bf16', choices=['bf16', 'none'], help='a second, disclosed measurement at narrower precision')
+    ap.add_argument('--secondary', default=None, choices=['bf16', 'none'], help='a second, disclosed measurement at narrower precision (default: bf16 on one GPU, none at N > 1: a scaling run measures the headline step only)')
     ap.add_argument('--conv-f32', default='native', choices=['native', 'x3'],
                     help='fp32 convolutions of the headline run: native = f32-input MFMA (exact fp32 fmaf chains); x3 = the same products on the bf16 matrix cores '
                          '(three bf16 pieces per operand, six exact products; fp32-grade error, see tests). Default native; x3 is reported as secondary_f32_split')
@@ -706,6 +707,8 @@ def main():
 
     torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
     rank, local_rank, world = parallel.init_process_group()
+    if args.secondary is None:
+        args.secondary = 'bf16' if world == 1 else 'none'
     if world != args.gpus:
         raise SystemExit('bench.py --gpus %d but WORLD_SIZE=%d: launch N > 1 as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`'
                          % (args.gpus, world))
@@ -744,6 +747,12 @@ def main():
         sampler_us = (time.perf_counter() - t_s) / n_rep / (len(frm) * 2 * K) * 1e6
         # ---- the fused cone-loss kernel at the workload's size (latency-bound there; see roofline_stress)
         cone_s = res['phases_ms'].get('eager_probe_cone_loss', res['phases_ms'].get('cone_loss', 0.0)) * 1e-3
+        if eng.cnn_chunk:
+            # the chunked step launches the loss once per chunk on a row window, inside the chunk's graph: no events around it.  Time the whole-batch launch of the
+            # same shape alone instead (HIP events over graph-replayed launches, tools/bench_cone.py)
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            import bench_cone
+            cone_s = bench_cone.time_joint(B, K, D, eng.N, B, iters=30)['us'] * 1e-6
         ab = cone_alg_bytes(B, K, D)
         c_tr, c_note = cone_traffic(B, K, D, eng.N)
         roof_cone = {'kernel': 'joint_loss_kernel (fused cone loss fwd+bwd, f32)', 'bound': 'hbm',
