@@ -45,6 +45,7 @@ static Tuning load_tuning() {
   t.jl_T = t.jl_EPL = t.jl_iters = 0;
   if (const char* e = env("LEC_JOINT_GEOM")) { if (sscanf(e, "%d,%d,%d", &t.jl_T, &t.jl_EPL, &t.jl_iters) < 2) t.jl_T = t.jl_EPL = t.jl_iters = 0; }
   t.jl_stage = i("LEC_JOINT_STAGE", 0);
+  t.jl_fixed_point = i("LEC_JOINT_FIXED_POINT", 1);
   t.jl_wpb = i("LEC_JOINT_WPB", 0); if (t.jl_wpb < 0 || t.jl_wpb > 8) t.jl_wpb = 0;
   return t;
 }

@@ -37,6 +37,9 @@ struct JointParams {
   float* e_pos; float* e_neg; float* loss;
   float* grad_table; float* grad_feat;
   float* partials; unsigned int* counter;
+  // fixed-point hand-off of the loss (lec_common.h block_publish_fixed_point): used when an upper bound of the loss is known at launch (no per-positive weights,
+  // a bounded energy) and the grid has fewer than 4096 blocks; fx_scale == 0: the ticket form
+  unsigned long long* fx_acc; unsigned int* fx_flag; double fx_scale, fx_inv; float fx_bound;
   int iters;            // pair iterations per task
   int tasks_per_group;
   int lds_stage;        // T == 1 only: move rows through LDS (coalesced gather/scatter)
@@ -500,7 +503,8 @@ __global__ __launch_bounds__(512) void joint_loss_kernel(JointParams P_in) {
 
   JL_STAMP(ck3);                                      // u_b / v_b gradients reduced over the wave and added
   lsum = group_sum<64>(lsum);
-  block_publish_and_finalize(lsum, P.partials, P.counter, P.loss, 1.0f);
+  if (P.fx_scale != 0.0) block_publish_fixed_point(lsum, P.fx_acc, P.fx_flag, P.loss, P.fx_scale, P.fx_inv, P.fx_bound);
+  else block_publish_and_finalize(lsum, P.partials, P.counter, P.loss, 1.0f);
 #ifdef LEC_JL_STAMP
   if (P.stamps && lane == 0) {
     const unsigned long long ck4 = jl_cycles(), rt1 = jl_realtime();
@@ -643,6 +647,17 @@ static int joint_loss_impl(int energy, int label_proj, int image_proj,
   P.lab_add = K_cone; P.img_add = image_proj == LEC_IMAGE_SOFTCLIP_K ? K_cone : P.r_in;
   P.e_pos = e_pos; P.e_neg = e_neg; P.loss = loss; P.grad_table = grad_table; P.grad_feat = grad_feat;
   P.counter = (unsigned int*)workspace; P.partials = (float*)((char*)workspace + 256);
+  // The loss as ONE integer atomic per block when its total is bounded at launch: sum_b (E+_b + sum_k max(0, alpha - E-_bk)) <= B (E_max + 2K alpha), with
+  // E_max = pi + pi/2 for the hyperbolic cone (acos - asin, oe_h.py:826-833) and 2 for the Euclidean cone (theta in [-1, 1], psi in [-1, 0], oe.py:733-739); the
+  // order-embedding energy is unbounded and per-positive weights are the caller's: both keep the ticket form.  (workspace bytes 16..31: accumulator + flag.)
+  P.fx_acc = (unsigned long long*)((char*)workspace + 16); P.fx_flag = (unsigned int*)((char*)workspace + 24);
+  P.fx_scale = 0.0; P.fx_inv = 0.0; P.fx_bound = 0.0f;
+  if (weights == nullptr && energy != LEC_ENERGY_ORDER && g.nblocks < 4096 && alpha >= 0.0f && tuning().jl_fixed_point) {
+    const double e_max = energy == LEC_ENERGY_HYP_CONE ? 4.7123889803846899 + 1e-3 : 2.0 + 1e-3;
+    const double bound = (double)B * (e_max + 2.0 * (double)K * (double)alpha) * 1.0001 + 1.0;
+    int bits = 1; while (bits < 40 && (double)(1ull << bits) <= bound) ++bits;      // integer bits of the total
+    if (bits < 40) { const int F = 51 - bits; P.fx_scale = (double)(1ull << F); P.fx_inv = 1.0 / P.fx_scale; P.fx_bound = (float)bound; }
+  }
   P.iters = g.iters; P.tasks_per_group = g.tasks_per_group;
   P.lds_stage = tuning().jl_stage;
   LEC_CHECK_ARG(row_lo >= 0 && row_hi >= row_lo, "joint_loss: row window [%d, %d)", row_lo, row_hi);

@@ -194,6 +194,39 @@ __device__ __forceinline__ void block_publish_and_finalize(float wave_value /*va
     }
   }
 }
+
+// The same reduction with ONE returning atomic per block and no partial store, release, acquire or summation loop (round 5; the ticket form above costs the fused
+// loss 4.4 us of a 15.6 us wave at config 5: profiles/r05_cone_timeline.md).  A block's partial p >= 0 enters a 64-bit word as an INTEGER: bits 63..52 count the
+// blocks, bits 51..0 hold llrint(p * scale) -- integer addition is associative, so the total does not depend on the order the blocks arrive in, and the block that
+// finds count == gridDim.x - 1 in the value its own add returned knows the whole sum without reading anything else.  The caller picks `scale` = 2^F from an upper
+// bound of the total so that 52 bits cannot overflow (the quantisation, 2^-F per block, is far below one float rounding of the result).  A partial that is NaN,
+// infinite, negative or above the bound (the reference's loss is NaN / inf there too) sets bit 0 of `flag` first; the result is then NaN.
+// `acc` and `flag` (8-byte aligned, consecutive) are zero at launch; the last block re-arms them.  gridDim.x < 4096.  Call with all threads of the block.
+__device__ __forceinline__ void block_publish_fixed_point(float wave_value /*valid in lane 0 of each wave*/, unsigned long long* acc, unsigned int* flag,
+                                                          float* out, double scale, double inv_scale, float bound) {
+  __shared__ float s_wave_fx[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  if (lane == 0) s_wave_fx[wave] = wave_value;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  float p = 0.0f;
+  for (int w = 0; w < nwave; ++w) p += s_wave_fx[w];
+  const bool ok = p >= 0.0f && p <= bound;                                        // (false for NaN)
+  if (!ok) {
+    __hip_atomic_fetch_or(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // returning: performed before the ticket below is issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  const unsigned long long mask = (1ull << 52) - 1ull;
+  const unsigned long long add = (1ull << 52) | (ok ? ((unsigned long long)__double2ll_rn((double)p * scale) & mask) : 0ull);
+  const unsigned long long prev = __hip_atomic_fetch_add(acc, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((prev >> 52) == (unsigned long long)(gridDim.x - 1)) {
+    const unsigned long long total = (prev & mask) + (add & mask);
+    const unsigned int bad = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[0] = bad ? __builtin_nanf("") : (float)((double)total * inv_scale);
+    __hip_atomic_store(acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // re-arm for the next (stream-ordered) launch
+    if (bad) __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 #endif  // __HIPCC__
 
 }  // namespace lec

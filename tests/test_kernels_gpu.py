@@ -886,3 +886,31 @@ def test_joint_loss_row_windows_add_up_to_the_whole_batch_launch(B, K, D, M, chu
     for lo in range(0, M, chunk):
         ops.joint_loss_raw(Wt, Rt, cf, ct, cn, None, 0.1, alpha, 0, 1, 1, table_f16=W16, window=(lo, min(lo + chunk, M), lo == 0), out=out2)
     assert torch.equal(out2[0], p1) and torch.equal(out2[1], n1)
+
+
+def test_joint_loss_fixed_point_hand_off_equals_the_ticket_form_and_carries_nan():
+    """Round 5: where the loss is bounded at launch (no per-positive weights, cone energies) every block hands its partial over as ONE 64-bit integer atomic
+    (count in the top bits, llrint(partial * 2^F) below: integer addition does not depend on the order of arrival).  Against the ticket form (selected by passing
+    unit weights): the same loss to float rounding, run-to-run identical bits; a NaN energy (a NaN image embedding: torch.sum keeps NaN, oe_h.py:843-846) still makes the
+    loss NaN, and the launch after it is clean again (the accumulator and the flag are re-armed)."""
+    rs = np.random.RandomState(11)
+    N, M, D = 300, 64, 10
+    W = rs.randn(N, D).astype(np.float32); W *= (rs.uniform(0.1, 0.6, (N, 1)) / np.linalg.norm(W, axis=1, keepdims=True)).astype(np.float32)
+    R = (rs.randn(M, D) * 0.3).astype(np.float32)
+    Wt, Rt = T(W), T(R)
+    for B, K in ((64, 5), (256, 64), (32, 256)):
+        frm = torch.tensor(rs.randint(0, N, B), dtype=torch.int32, device=DEV)
+        to = torch.tensor(-1 - rs.randint(0, M, B), dtype=torch.int32, device=DEV)
+        neg = torch.tensor(rs.randint(0, N, (B, 2 * K)), dtype=torch.int32, device=DEV)
+        neg[:, :K] += (neg[:, :K] == frm[:, None]).int()                          # never (u, u): x == y is 0 / 0 in the reference too
+        neg[:, :K] -= 2 * (neg[:, :K] >= N).int()
+        neg = neg.contiguous()
+        ones = torch.ones(B, device=DEV)
+        fx = [ops.joint_loss_raw(Wt, Rt, frm, to, neg, None, 0.1, 0.5, 0, 1, 1)[0].item() for _ in range(4)]
+        tk = ops.joint_loss_raw(Wt, Rt, frm, to, neg, ones, 0.1, 0.5, 0, 1, 1)[0].item()
+        assert len(set(fx)) == 1 and np.isfinite(fx[0])
+        assert abs(fx[0] - tk) <= 2e-6 * abs(tk), (B, K, fx[0], tk)
+        Rz = Rt.clone(); Rz[int(-1 - to[0].item())] = float('nan')                # a NaN image embedding (a diverged CNN): its pairs' energies are NaN
+        assert np.isnan(ops.joint_loss_raw(Wt, Rz, frm, to, neg, None, 0.1, 0.5, 0, 1, 1)[0].item())
+        assert np.isnan(ops.joint_loss_raw(Wt, Rz, frm, to, neg, ones, 0.1, 0.5, 0, 1, 1)[0].item())
+        assert ops.joint_loss_raw(Wt, Rt, frm, to, neg, None, 0.1, 0.5, 0, 1, 1)[0].item() == fx[0]
