@@ -807,10 +807,10 @@ def main():
                                                 'note': 'table of %.1f MB resident in %s' % (tbl_mb, 'L2' if tbl_mb <= 4.0 else 'the Infinity Cache')},
                                'binding_resource': 'latency of dependent round trips and per-wave fixed costs, not issue or bandwidth (profiles/r05_cone_timeline.md, per-wave s_memtime stamps): at 256 x 256 x 10 a wave lives ~15 us -- '
                                                    '4.7 us kernel arguments -> node codes -> u_b / v_b rows -> projection, 2.6 us waiting for the iteration rows, 1.2 us for its 128 cone energies (the acos / asin / sqrt / divide chain), '
-                                                   '0.9 us gradient reduction + row adds, 3.7 us loss hand-off (partial, release, one returning atomic per block on ONE ticket address); at 4 096 x 256 x 10 the row phase is 40 % of a wave '
+                                                   '0.8 us gradient reduction + row adds, 2.0 us loss hand-off (one returning integer atomic per block + the block barrier); at 4 096 x 256 x 10 the row phase is 44 % of a wave '
                                                    '(64 different row addresses per load instruction: the texture path retires about one address per cycle per CU) and vector-ALU issue about half of the launch; '
                                                    'L2 atomics are 26 k - 83 k requests per launch and HBM traffic 0.14 - 0.8 x the algorithmic bytes (profiles/r04_cone_pmc.md): neither binds',
-                               'launch_floor_us': 14.4, 'note': 'forward-only launch of the cfg5 shape: 14.4 us (tools/cone_timeline.py): at 256 positives the launch is a dependent chain on a partly filled chip'}}
+                               'launch_floor_us': 13.0, 'note': 'forward-only launch of the cfg5 shape: 13.0 us (tools/cone_timeline.py): at 256 positives the launch is a dependent chain on a partly filled chip'}}
             out['roofline_stress'] = st
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(eng, budget_s=args.cpu_baseline_budget, rows=args.cpu_baseline_rows)
