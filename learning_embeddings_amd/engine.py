@@ -162,7 +162,9 @@ class StepEngine:
             raise ValueError('passes=%d needs an unchunked step whose %d CNN rows divide evenly' % (passes, self.n_rows))
         self.passes = int(passes)
         if overlap_wgrad is None:
-            overlap_wgrad = self.passes == 1
+            # (the chunked step keeps its weight gradients in line: same box, config 5, 645.4 / 646.0 ms with the side stream, 639.3 without -- inside a replayed chunk
+            # graph the side stream's kernels mostly stretch the BatchNorm finalize launches of the main chain)
+            overlap_wgrad = self.passes == 1 and self.cnn_chunk is None
         torch.manual_seed(0)                                              # oe_h.py:1338: table init from seed 0
         self.criterion = EuclideanConesWithImagesHypernymLoss(lm, K, {}, alpha, pick_per_level=True, K=K_cone, use_CNN=True)
         self.model = Embedder(D, lm, None, K=K_cone).to(self.device)
