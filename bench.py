@@ -362,10 +362,10 @@ def measure(args, dtype, rank, world, stamp, primary):
             roof_conv['isolated'] = {'ms_per_step': round(conv_isolated, 3), 'achieved': round(eng.conv_flops_per_step / conv_isolated / 1e9, 2),
                                      'frac': round(eng.conv_flops_per_step / conv_isolated / 1e9 / 157.3, 4)}
     if f32:
-        # HBM bytes per launch from the committed PMC passes (profiles/r04_step_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, whole family per step / launches)
+        # HBM bytes per launch from the committed PMC passes (profiles/r05_step_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, whole family per step / launches)
         try:
             import hashlib
-            allm = json.load(open(os.path.join(ROOT, 'profiles', 'r04_step_traffic.json')))
+            allm = json.load(open(os.path.join(ROOT, 'profiles', 'r05_step_traffic.json')))
             csrc = os.path.join(ROOT, 'learning_embeddings_amd', 'csrc')
             stale = [f for f, h in allm.get('kernel_sources_sha256', {'missing': ''}).items()
                      if not os.path.exists(os.path.join(csrc, f)) or hashlib.sha256(open(os.path.join(csrc, f), 'rb').read()).hexdigest() != h]
@@ -375,13 +375,13 @@ def measure(args, dtype, rank, world, stamp, primary):
             fam = lambda *keys: sum(sum(tr[k]) for k in keys if k in tr) * 1e9
             if roof_conv is not None:
                 roof_conv['traffic'] = int(fam('convolution forward / data gradient', 'convolution weight gradients') / max(eng.conv_launches_per_step, 1))
-                roof_conv['traffic_note'] = 'HBM bytes per launch, family average: rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE over a profiled run of this command (profiles/r04_step_traffic.md); the bound is the matrix pipe'
+                roof_conv['traffic_note'] = 'HBM bytes per launch, family average: rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE over a profiled run of this command (profiles/r05_step_traffic.md); the bound is the matrix pipe'
             if roof_bn is not None:
                 roof_bn['traffic'] = int(fam('BatchNorm family (bn.hip)') / max(eng.bn_launch_groups_per_step, 1))
         except Exception as e:                                  # noqa: BLE001
             for r_ in (roof_conv, roof_bn):
                 if r_ is not None:
-                    r_['traffic_note'] = 'null: %s (re-run tools/prof_round4.sh + tools/make_step_traffic_round4.py)' % e
+                    r_['traffic_note'] = 'null: %s (re-run tools/step_traffic_round5.sh + tools/make_step_traffic_round5.py)' % e
     res = {'value': round(ips, 2), 'ms_per_step': round(dt / args.steps * 1e3, 3), 'step_ms': step_ms, 'dtype': 'f32' if f32 else dtype,
            'launch_mode': ('hipgraph (forward + loss + backward of a step replayed as one graph)' if graph_mode else
                            ('hipgraph per chunk (gather + forward + windowed loss + backward of %d CNN rows as ONE graph, replayed %d times per step)' % (eng.cnn_chunk, eng.n_rows_pad // eng.cnn_chunk)
