@@ -310,37 +310,40 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_sk_kernel(const fl
           for (int jt = 0; jt < TN; ++jt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[it][jt][r] = 0.f;
-        // two slabs' loads in flight at a time (32 x 16 bytes per lane), added in workgroup order
-        constexpr int NQ = TM * TN * 4;
+        // The slabs are added in workgroup order, one 32 x 32 sub-tile of the wave at a time, two slabs' loads of that sub-tile in flight (8 x 16 bytes per lane).
+        // (Rounds 3 - 4 kept two WHOLE slabs in flight: 128 registers on top of the accumulators made every instance a 251 - 256-register kernel -- two waves per
+        // SIMD then fill the register file and no wave of another stream's kernel fits beside them (profiles/EXPERIMENTS.md, round 5).  Element by element the
+        // order of the additions is the same: same bits.)
         auto slab = [&](long long w) { return (unsigned)(((int)w * 2 + (wg_start(w) > T0 ? 0 : 1)) * (BM * BN * 4)) + (unsigned)tid * 16u; };
-        auto add = [&](const f32x4v (&v)[NQ]) {
 #pragma unroll
-          for (int it = 0; it < TM; ++it)
+        for (int it = 0; it < TM; ++it)
 #pragma unroll
-            for (int jt = 0; jt < TN; ++jt)
+          for (int jt = 0; jt < TN; ++jt) {
+            const unsigned sub = (unsigned)((it * TN + jt) * 4 * kCfThreads * 16);
+            auto add4 = [&](const f32x4v (&v)[4]) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                const f32x4v& x = v[(it * TN + jt) * 4 + q];
-                acc[it][jt][4 * q] += x[0]; acc[it][jt][4 * q + 1] += x[1]; acc[it][jt][4 * q + 2] += x[2]; acc[it][jt][4 * q + 3] += x[3];
+                acc[it][jt][4 * q] += v[q][0]; acc[it][jt][4 * q + 1] += v[q][1]; acc[it][jt][4 * q + 2] += v[q][2]; acc[it][jt][4 * q + 3] += v[q][3];
               }
-        };
-        long long w = wa;
-        for (; w + 1 <= wb_; w += 2) {
-          const unsigned s0 = slab(w), s1 = slab(w + 1);
-          f32x4v v0[NQ], v1[NQ];
+            };
+            long long w = wa;
+            for (; w + 1 <= wb_; w += 2) {
+              const unsigned s0 = slab(w) + sub, s1 = slab(w + 1) + sub;
+              f32x4v v0[4], v1[4];
 #pragma unroll
-          for (int i = 0; i < NQ; ++i) v0[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_slots, (int)(s0 + (unsigned)(i * kCfThreads * 16)), 0, kSkLoadAux));
+              for (int q = 0; q < 4; ++q) v0[q] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_slots, (int)(s0 + (unsigned)(q * kCfThreads * 16)), 0, kSkLoadAux));
 #pragma unroll
-          for (int i = 0; i < NQ; ++i) v1[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_slots, (int)(s1 + (unsigned)(i * kCfThreads * 16)), 0, kSkLoadAux));
-          add(v0); add(v1);
-        }
-        if (w <= wb_) {
-          const unsigned s0 = slab(w);
-          f32x4v v0[NQ];
+              for (int q = 0; q < 4; ++q) v1[q] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_slots, (int)(s1 + (unsigned)(q * kCfThreads * 16)), 0, kSkLoadAux));
+              add4(v0); add4(v1);
+            }
+            if (w <= wb_) {
+              const unsigned s0 = slab(w) + sub;
+              f32x4v v0[4];
 #pragma unroll
-          for (int i = 0; i < NQ; ++i) v0[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_slots, (int)(s0 + (unsigned)(i * kCfThreads * 16)), 0, kSkLoadAux));
-          add(v0);
-        }
+              for (int q = 0; q < 4; ++q) v0[q] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_slots, (int)(s0 + (unsigned)(q * kCfThreads * 16)), 0, kSkLoadAux));
+              add4(v0);
+            }
+          }
       }
     }
     if (!finalize) continue;
@@ -409,10 +412,11 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_sk_kernel(const fl
 #pragma unroll
       for (int it = 0; it < TM; ++it) {
 #pragma unroll
-        for (int r8 = 0; r8 < 16; r8 += 8) {
-          float dv[8][TN], xv[8][TN]; unsigned mb[8][TN];
+        for (int r8 = 0; r8 < 16; r8 += 2) {
+          __builtin_amdgcn_sched_barrier(0);     // one small batch of loads live at a time: hoisted, they made this a 254-register instance
+          float dv[2][TN], xv[2][TN]; unsigned mb[2][TN];
 #pragma unroll
-          for (int rr = 0; rr < 8; ++rr) {
+          for (int rr = 0; rr < 2; ++rr) {
             const int r = r8 + rr;
             const int m = m0 + wm0 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             const unsigned poff = m < g.Mg ? (unsigned)m * rowbytes : kOob;
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_sk_kernel(const fl
             }
           }
 #pragma unroll
-          for (int rr = 0; rr < 8; ++rr) {
+          for (int rr = 0; rr < 2; ++rr) {
             const int r = r8 + rr;
             const int m = m0 + wm0 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             const unsigned poff = m < g.Mg ? (unsigned)m * rowbytes : kOob;
