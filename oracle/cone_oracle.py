@@ -6,8 +6,9 @@ and bench.py's `cpu_baseline` leg may import this module, and only as the checke
 CPU baseline -- never as a fallback for the HIP path.
 
 Parity status: PINNED.  Every function here is checked in tests/test_oracle_golden.py against
-fixtures F1..F8 under tests/golden/, which were produced by importing the reference itself in
-the build container (tests/golden/make_golden.py).
+fixtures F1..F14 (+ F4b: the negative stream on config 5's 8-level 50 000-label hierarchy) under
+tests/golden/, which were produced by importing the reference itself in the build container
+(tests/golden/make_golden*.py).
 
 Each function cites the reference file:line it restates (paths relative to the reference root).
 Forward arithmetic is done in float32 in the reference's operation order; analytic backward
