@@ -11,6 +11,7 @@ import torch.nn.functional as F
 from learning_embeddings_amd import ops
 
 ap = argparse.ArgumentParser(); ap.add_argument('--rows', type=int, default=512); ap.add_argument('--iters', type=int, default=5)
+ap.add_argument('--schedule', default='default', choices=['default', 'tile_walk', 'balanced'], help='which form of the forward / data gradient (default: the library\'s rule; tile_walk: what a two-pass step runs)')
 ap.add_argument('--json', default=None); ap.add_argument('--no-lib', action='store_true'); ap.add_argument('--only', default='', help='comma-separated layer names')
 a = ap.parse_args()
 # (name, Cin, H, Cout, R, stride, pad): the distinct conv shapes of ResNet-50 at 224x224
@@ -23,6 +24,9 @@ SHAPES = [('stem', 4, 224, 64, 7, 2, 3),
           ('l4.c1a', 1024, 14, 512, 1, 1, 0), ('l4.c2s', 512, 14, 512, 3, 2, 1), ('l4.c3', 512, 7, 2048, 1, 1, 0), ('l4.ds', 1024, 14, 2048, 1, 2, 0),
           ('l4.c1', 2048, 7, 512, 1, 1, 0), ('l4.c2', 512, 7, 512, 3, 1, 1)]
 dev = 'cuda'
+if a.schedule != 'default':
+    from learning_embeddings_amd import ops as _ops, _lib as _l
+    _ops.fusion().schedule = _l.SCHEDULE_TILE_WALK if a.schedule == 'tile_walk' else _l.SCHEDULE_BALANCED
 
 
 def timeit(fn, iters):
