@@ -491,6 +491,34 @@ int lec_conv_f32x3_wgrad(const float* dy, const float* x, int N, int H, int W, i
                          float* dw, lec_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * (7d) The ResNet convolutions on bf16 activations (csrc/conv_bf16.hip): BASELINE config 5's 16-bit conv stack -- torchvision's resnet50
+ *     inside FeatCNN (oe_h.py:331-351; finetuner.py:122 for the classifier experiments) -- as ONE implicit-GEMM family on
+ *     v_mfma_f32_32x32x16_bf16, fp32 accumulation: every layer shape, stride (1, 2) and direction; no library convolution is left on the
+ *     16-bit path.  Tensors NHWC bf16: x [N, H, W, Cin], y [N, Ho, Wo, Cout]; weights w [Cout][R*S][Cin] bf16 (a channels_last
+ *     [Cout, Cin, R, S] tensor); Cin, Cout powers of two >= 8 (the 3-channel stem: x and w carry zero channels 3..7); tensors < 2 GiB.
+ *     lec_conv_bf16_fwd: `partials` (optional, >= 512 * 2 * Cout floats) receives n_partials (HOST int) rows of per-channel
+ *       [sum y, sum y^2] over the bf16-ROUNDED output, lec_bn_fwd_prestat's layout: the BatchNorm statistics pass disappears.
+ *     lec_conv_bf16_wt_transpose: w [Cout][RS][Cin] -> wt [Cin][RS][Cout], the data gradient's k-contiguous operand (after every
+ *       optimizer step; tens of KB .. 4.7 MB per layer).
+ *     lec_conv_bf16_dgrad: dx from dy [N, Ho, Wo, Cout] and wt (Cout % 64 == 0); a strided layer's parity classes run as one launch.
+ *       With xbn / mean / invstd / partials / n_partials (all or none; stride 1) the result is not dx but g = mask * (dx + dres), rounded to
+ *       bf16 -- pass 1 of the backward of the BatchNorm whose output this layer consumed (dres: that output's other consumer's gradient or
+ *       NULL; mask: lec_bn_fwd's ReLU bitmask or NULL; xbn: that BatchNorm's input) -- and `partials` receives n_partials rows of
+ *       [sum g, sum g * xhat] per channel (lec_bn_bwd_prereduced's input).
+ *     lec_conv_bf16_wgrad: dw [Cout][R*S][dw_cin] fp32 += (float atomics over the K split; dw_cin = Cin, or the real channel count of a
+ *       zero-padded stem input).
+ * ------------------------------------------------------------------------------------------------------------- */
+int lec_conv_bf16_supported(int Cin, int Cout, int R, int S, int stride, int pad);
+int lec_conv_bf16_wt_transpose(const void* w, void* wt, int Cout, int RS, int Cin, lec_stream_t stream);
+int lec_conv_bf16_fwd(const void* x, const void* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                      void* y, float* partials, int64_t partials_bytes, int* n_partials, lec_stream_t stream);
+int lec_conv_bf16_dgrad(const void* dy, const void* wt, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                        void* dx, const void* dres, const void* xbn, const uint8_t* mask, const float* mean, const float* invstd,
+                        float* partials, int64_t partials_bytes, int* n_partials, lec_stream_t stream);
+int lec_conv_bf16_wgrad(const void* dy, const void* x, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                        float* dw, int dw_cin, lec_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * (8) 3x3 / stride 2 / pad 1 max pooling on NHWC bf16 (the ResNet stem's `maxpool`, oe_h.py:311 -> torchvision).
  *     x: [N, H, W, C] bf16 (H, W even, C % 8 == 0); y: [N, H/2, W/2, C]; argmax: one byte per pooled element (window
  *     position kh*3+kw; first maximum wins, NaN propagates, like the framework op).  Backward is a gather over the <= 4

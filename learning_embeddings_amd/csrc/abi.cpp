@@ -53,4 +53,4 @@ const Tuning& tuning() { static const Tuning t = load_tuning(); return t; }
 }  // namespace lec
 
 extern "C" const char* lec_last_error(void) { return lec::g_err; }
-extern "C" int lec_abi_version(void) { return 30; }
+extern "C" int lec_abi_version(void) { return 31; }

@@ -125,7 +125,6 @@ __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_kernel(const float
 // The parity classes of a STRIDED data gradient as ONE launch (round 4): blockIdx.z = class, the classes ordered by their tap count, longest first.
 // As four launches of one stream every class ended in a round of workgroup slots of its own (3x3 / stride 2 at 512 images: 784 tiles on 512 slots, four
 // times over); as one grid the hardware deals 1-, 2- and 4-tap tiles to whichever slot frees up, longest first, and the launch has one tail.
-struct ActGeoSet { ActGeo g[4]; };
 template <int TN>
 __global__ __launch_bounds__(kCfThreads, 2) void conv_f32_act_classes_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
                                                                              float* __restrict__ dst, ActGeoSet gs) {

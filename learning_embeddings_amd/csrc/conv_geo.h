@@ -68,6 +68,8 @@ struct ActGeo {
   FastDiv dWm, dHm, dnb;                   // divisions by Wm, Hm, nb
 };
 
+struct ActGeoSet { ActGeo g[4]; };      // the parity classes of a strided data gradient (one launch, blockIdx.z = class)
+
 struct WgGeo {
   int Mpix;                                // N * Ho * Wo
   int Ho, Wo, H, W, Cin, lgCin, Cout;

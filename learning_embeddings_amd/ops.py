@@ -979,6 +979,87 @@ def conv_f32_wgrad(dy, x, dw, stride, pad, xf=None):
     return dw
 
 
+# ------------------------------------------------------------------------------------------------ bf16 convolutions (csrc/conv_bf16.hip)
+def _nhwc_bf16(t, name):
+    if t.dtype != torch.bfloat16 or t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError('%s must be a 4-D channels_last bfloat16 tensor' % name)
+    return t
+
+
+def conv_bf16_supported(conv):
+    """Layers lec_conv_bf16_* serve: every layer of ResNet-18 / -50 (the 3-channel stem through zero channels 3..7)."""
+    cin = 8 if conv.in_channels == 3 else conv.in_channels
+    return (conv.groups == 1 and conv.dilation == (1, 1) and conv.stride[0] == conv.stride[1] and conv.bias is None
+            and conv.padding[0] == conv.padding[1] and conv.kernel_size[0] == conv.kernel_size[1]
+            and bool(lib.lec_conv_bf16_supported(cin, conv.out_channels, conv.kernel_size[0], conv.kernel_size[1], conv.stride[0], conv.padding[0])))
+
+
+def conv_bf16_wt(w):
+    """w [Cout, Cin, R, S] channels_last bf16 (memory [Cout][RS][Cin]) -> the data gradient's operand, memory [Cin][RS][Cout], returned as a
+    channels_last [Cin, Cout, R, S] tensor (lec_conv_bf16_wt_transpose)."""
+    _nhwc_bf16(w, 'w')
+    cout, cin, r, s_ = w.shape
+    wt = torch.empty((cin, cout, r, s_), dtype=torch.bfloat16, device=w.device, memory_format=torch.channels_last)
+    check(lib.lec_conv_bf16_wt_transpose(dptr(w), dptr(wt), cout, r * s_, cin, stream_ptr()))
+    return wt
+
+
+def conv_bf16_fwd(x, w, stride, pad, want_stats=False):
+    """y = conv2d(x, w) on bf16 NHWC tensors, fp32 accumulation (lec_conv_bf16_fwd).  want_stats: the BatchNorm statistics partials of the
+    (rounded) output are left in the BatchNorm workspace."""
+    _nhwc_bf16(x, 'x'); _nhwc_bf16(w, 'w')
+    n, cin, h, wd = x.shape; cout, _, r, s_ = w.shape
+    ho, wo = (h + 2 * pad - r) // stride + 1, (wd + 2 * pad - s_) // stride + 1
+    y = torch.empty((n, cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    flops = 2.0 * n * ho * wo * cout * cin * r * s_
+    if want_stats:
+        ws = _bn_workspace(x.device); k = C.c_int(0)
+        _conv_timed(lambda: check(lib.lec_conv_bf16_fwd(dptr(x), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), dptr(ws), ws.numel(),
+                                                        C.byref(k), stream_ptr())), flops)
+        fusion().ws_owner[0], fusion().ws_owner[1] = y.data_ptr(), k.value
+    else:
+        _conv_timed(lambda: check(lib.lec_conv_bf16_fwd(dptr(x), dptr(w), n, h, wd, cin, cout, r, s_, stride, pad, dptr(y), None, 0, None, stream_ptr())), flops)
+    return y
+
+
+def conv_bf16_dgrad(dy, wt, x_shape, stride, pad, fold=None):
+    """dx of the same convolution from the TRANSPOSED weights wt (conv_bf16_wt).  fold = a FusionContext.forks record {'x', 'mask', 'mean',
+    'invstd', 'dres'} (stride-1 layers): the result is g = mask * (dx + dres) of the BatchNorm whose output this layer consumed, tagged for
+    BNActFn.backward, its partial sums in the BatchNorm workspace."""
+    _nhwc_bf16(dy, 'dy'); _nhwc_bf16(wt, 'wt')
+    n, cin, h, wd = x_shape; _, cout, r, s_ = wt.shape
+    if wt.shape[0] != cin or dy.shape[1] != cout:
+        raise ValueError('conv_bf16_dgrad: wt %s does not match Cin %d / Cout %d' % (tuple(wt.shape), cin, dy.shape[1]))
+    dx = torch.empty((n, cin, h, wd), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+    a = [None] * 5; ws = None; k = C.c_int(0)
+    if fold is not None:
+        xb = _nhwc_bf16(fold['x'], 'fold x')
+        if tuple(xb.shape) != (n, cin, h, wd) or (fold['dres'] is not None and tuple(_nhwc_bf16(fold['dres'], 'dres').shape) != (n, cin, h, wd)):
+            raise ValueError('fold record does not match the layer input')
+        ws = _bn_workspace(dy.device)
+        a = [dptr(fold['dres']), dptr(xb), dptr(fold['mask']), dptr(fold['mean']), dptr(fold['invstd'])]
+    _conv_timed(lambda: check(lib.lec_conv_bf16_dgrad(dptr(dy), dptr(wt), n, h, wd, cin, cout, r, s_, stride, pad, dptr(dx), a[0], a[1], a[2], a[3], a[4],
+                                                      dptr(ws), ws.numel() if ws is not None else 0, C.byref(k) if ws is not None else None, stream_ptr())),
+                2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * cout * cin * r * s_)
+    if fold is not None:
+        fc = fusion()
+        fc.ws_owner[0], fc.ws_owner[1] = dx.data_ptr(), k.value
+        fc.folded.clear(); fc.folded[dx.data_ptr()] = k.value
+    return dx
+
+
+def conv_bf16_wgrad(dy, x, dw, stride, pad):
+    """dw += weight gradient (lec_conv_bf16_wgrad, float atomics).  dw [Cout, Cin', R, S] channels_last fp32 with Cin' = x's channels, or fewer
+    for a zero-padded stem input (x [N, 8, H, W], dw [Cout, 3, R, S])."""
+    _nhwc_bf16(dy, 'dy'); _nhwc_bf16(x, 'x')
+    if dw.dtype != torch.float32 or dw.dim() != 4 or not dw.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError('dw must be a 4-D channels_last float32 tensor')
+    n, cin, h, wd = x.shape; cout, dcin, r, s_ = dw.shape
+    _conv_timed(lambda: check(lib.lec_conv_bf16_wgrad(dptr(dy), dptr(x), n, h, wd, cin, cout, r, s_, stride, pad, dptr(dw), dcin, stream_ptr())),
+                2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * cout * cin * r * s_)
+    return dw
+
+
 class X3Planes:
     """Pre-split bf16 planes of one conv weight (lec_conv_f32x3_split_weights): `fwd` feeds conv_f32x3_fwd, `t` conv_f32x3_dgrad."""
     __slots__ = ('shape', 'fwd', 't')

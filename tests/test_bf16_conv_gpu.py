@@ -1,0 +1,140 @@
+"""The bf16 convolution family (csrc/conv_bf16.hip: config 5's 16-bit conv stack, oe_h.py:331-351 -> torchvision resnet50) against plain fp32
+PyTorch on bf16-rounded operands: every ResNet-50 layer shape, stride and direction.  Small-integer operands make every product and partial sum
+exactly representable (bf16 holds integers up to 256, fp32 accumulation up to 2^24), so forward and gradients must EQUAL the reference whatever the
+summation order (outputs: that exact sum rounded once to bf16) -- a wrong operand layout, tap, parity class or transposed read is a mismatch, not noise."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from learning_embeddings_amd import ops  # noqa: E402
+
+DEV = 'cuda'
+
+
+def _cl(t):
+    return t.to(DEV).contiguous(memory_format=torch.channels_last)
+
+
+# (N, Cin, H, W, Cout, R, stride, pad): the layer shapes of ResNet-50 / -18 at small pixel counts + ragged sizes (row tails, channel tails of a tile)
+BF16_CASES = [
+    (2, 64, 8, 8, 64, 1, 1, 0), (3, 64, 7, 5, 256, 1, 1, 0), (2, 256, 6, 6, 64, 1, 1, 0), (2, 256, 8, 8, 128, 1, 1, 0), (2, 512, 4, 4, 128, 1, 1, 0),
+    (2, 1024, 5, 5, 256, 1, 1, 0), (2, 256, 7, 7, 1024, 1, 1, 0), (2, 2048, 3, 3, 512, 1, 1, 0), (3, 512, 4, 4, 2048, 1, 1, 0), (2, 1024, 4, 4, 512, 1, 1, 0),
+    (2, 64, 8, 8, 64, 3, 1, 1), (3, 128, 9, 7, 128, 3, 1, 1), (2, 256, 6, 6, 256, 3, 1, 1), (2, 512, 7, 7, 512, 3, 1, 1), (33, 128, 12, 12, 128, 3, 1, 1),
+    (3, 128, 12, 8, 128, 3, 2, 1), (2, 256, 10, 10, 256, 3, 2, 1), (2, 512, 14, 14, 512, 3, 2, 1), (2, 64, 9, 9, 128, 3, 2, 1),
+    (2, 256, 8, 8, 512, 1, 2, 0), (2, 512, 6, 6, 1024, 1, 2, 0), (2, 1024, 4, 4, 2048, 1, 2, 0), (2, 64, 8, 8, 128, 1, 2, 0),
+    (2, 8, 20, 20, 64, 7, 2, 3), (3, 8, 17, 13, 64, 7, 2, 3), (2, 8, 12, 12, 64, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize('N,Cin,H,W,Cout,R,stride,pad', BF16_CASES)
+def test_conv_bf16_fwd_dgrad_wgrad_exact_on_integers_and_vs_fp32(N, Cin, H, W, Cout, R, stride, pad):
+    g = torch.Generator(device='cpu').manual_seed(Cin * 31 + Cout + R)
+    for kind in ('int', 'rand'):
+        if kind == 'int':
+            x = torch.randint(-3, 4, (N, Cin, H, W), generator=g).float(); w = torch.randint(-2, 3, (Cout, Cin, R, R), generator=g).float()
+        else:
+            x = torch.randn(N, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, R, R, generator=g) / (Cin * R * R) ** 0.5
+        x = _cl(x.bfloat16()); w = _cl(w.bfloat16())
+        xr = x.double().requires_grad_(True); wr = w.double().requires_grad_(True)
+        yr = F.conv2d(xr, wr, None, stride, pad)
+        dy = (torch.randint(-2, 3, yr.shape, generator=g).float() if kind == 'int' else torch.randn(yr.shape, generator=g))
+        dy = _cl(dy.bfloat16())
+        yr.backward(dy.double())
+        y = ops.conv_bf16_fwd(x, w, stride, pad, want_stats=True)
+        ws = ops._bn_workspace(x.device).view(torch.float32)
+        k = ops._BN_WS_OWNER[1]; ops._BN_WS_OWNER[0] = 0
+        part = ws[:k * 2 * Cout].view(k, 2, Cout).double().sum(0)
+        y2 = ops.conv_bf16_fwd(x, w, stride, pad)
+        assert torch.equal(y, y2), 'the statistics epilogue must not change the output'
+        assert y.shape == yr.shape and y.is_contiguous(memory_format=torch.channels_last) and y.dtype == torch.bfloat16
+        dw = torch.zeros_like(w, dtype=torch.float32)
+        ops.conv_bf16_wgrad(dy, x, dw, stride, pad)
+        dx = None
+        if Cout % 64 == 0:
+            wt = ops.conv_bf16_wt(w)
+            assert torch.equal(wt.permute(1, 0, 2, 3), w), 'transposed weights'
+            dx = ops.conv_bf16_dgrad(dy, wt, x.shape, stride, pad)
+        if kind == 'int':
+            # exact integer sums in fp32, ONE rounding to bf16 on the way out (round to nearest even, as torch's cast)
+            assert torch.equal(y, yr.detach().float().bfloat16()), 'forward'
+            if dx is not None:
+                assert torch.equal(dx, xr.grad.float().bfloat16()), 'data gradient'
+            assert torch.equal(dw.double(), wr.grad), 'weight gradient'
+            yb = y.double()
+            assert torch.allclose(part[0], yb.sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-3) and torch.allclose(part[1], (yb ** 2).sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-3)
+        else:
+            # outputs are rounded to bf16 (8 significant bits): half an ulp of the largest value + fp32 accumulation noise
+            tolb = lambda ref: 2.0 ** -8 * ref.abs().max().item()
+            assert (y.double() - yr.detach()).abs().max().item() <= tolb(yr.detach())
+            if dx is not None:
+                assert (dx.double() - xr.grad).abs().max().item() <= tolb(xr.grad)
+            assert (dw.double() - wr.grad).abs().max().item() <= 2e-5 * wr.grad.abs().max().item() + 1e-4     # fp32 output
+            yb = y.double()
+            assert torch.allclose(part[0], yb.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2), 'statistics are those of the ROUNDED output'
+            assert torch.allclose(part[1], (yb ** 2).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+
+
+def test_conv_bf16_stem_three_channel_weight_gradient_slot():
+    """The stem: x carries zero channels 3..7 and the gradient slot has 3 channels."""
+    g = torch.Generator(device='cpu').manual_seed(5)
+    x3 = torch.randint(-3, 4, (2, 3, 18, 18), generator=g).float()
+    x8 = torch.zeros(2, 8, 18, 18); x8[:, :3] = x3
+    dy = torch.randint(-2, 3, (2, 64, 9, 9), generator=g).float()
+    xr = x3.double(); wr = torch.zeros(64, 3, 7, 7, dtype=torch.double, requires_grad=True)
+    F.conv2d(xr, wr, None, 2, 3).backward(dy.double())
+    dw = torch.zeros(64, 3, 7, 7, device=DEV).contiguous(memory_format=torch.channels_last)
+    ops.conv_bf16_wgrad(_cl(dy.bfloat16()), _cl(x8.bfloat16()), dw, 2, 3)
+    assert torch.equal(dw.double().cpu(), wr.grad)
+
+
+@pytest.mark.parametrize('N,C,H,W,Cout,R,relu,res', [(2, 128, 8, 8, 128, 3, True, True), (3, 256, 5, 7, 64, 1, True, False), (2, 64, 8, 8, 64, 3, True, True),
+                                                    (2, 512, 4, 4, 128, 1, False, True), (2, 64, 6, 6, 256, 1, True, True), (33, 128, 12, 12, 128, 3, True, False)])
+def test_conv_bf16_dgrad_fold_is_pass1_of_the_batchnorm_backward(N, C, H, W, Cout, R, relu, res):
+    """lec_conv_bf16_dgrad with the fold: g = mask * (dx + dres) rounded to bf16 and the partial sums (sum g, sum g xhat) -- what lec_bn_bwd_pass1 computes
+    from the unfused data gradient."""
+    g = torch.Generator(device='cpu').manual_seed(C + Cout + R)
+    pad = R // 2
+    xbn = _cl((torch.randn(N, C, H, W, generator=g)).bfloat16())                        # the BatchNorm's input
+    mean = xbn.float().mean(dim=(0, 2, 3)); invstd = 1.0 / (xbn.float().var(dim=(0, 2, 3), unbiased=False) + 1e-5).sqrt()
+    bits = (torch.rand(N, C, H, W, generator=g) > 0.4).to(DEV)
+    mask = None
+    if relu:
+        b = bits.permute(0, 2, 3, 1).reshape(-1, C // 8, 8).to(torch.uint8)
+        mask = (b * (2 ** torch.arange(8, device=DEV, dtype=torch.uint8))).sum(-1).to(torch.uint8).reshape(-1).contiguous()
+    dres = _cl(torch.randn(N, C, H, W, generator=g).bfloat16()) if res else None
+    dy = _cl(torch.randn(N, Cout, H, W, generator=g).bfloat16())
+    w = _cl((torch.randn(Cout, C, R, R, generator=g) / (C * R * R) ** 0.5).bfloat16())
+    wt = ops.conv_bf16_wt(w)
+    dx = ops.conv_bf16_dgrad(dy, wt, xbn.shape, 1, pad)
+    rec = {'x': xbn, 'mask': mask, 'mean': mean, 'invstd': invstd, 'dres': dres}
+    gk = ops.conv_bf16_dgrad(dy, wt, xbn.shape, 1, pad, fold=rec)
+    k = ops._BN_WS_OWNER[1]; ops._BN_WS_OWNER[0] = 0; ops.fusion().folded.clear()
+    part = ops._bn_workspace(xbn.device).view(torch.float32)[:k * 2 * C].view(k, 2, C).double().sum(0)
+    gr = dx.float() + (dres.float() if res else 0.0)
+    if relu:
+        gr = torch.where(bits, gr, torch.zeros_like(gr))
+    gr = gr.bfloat16()
+    assert torch.equal(gk, gr), 'g'
+    xhat = (xbn.float() - mean.view(1, C, 1, 1)) * invstd.view(1, C, 1, 1)
+    s1 = gr.double().sum(dim=(0, 2, 3)); s2 = (gr.float() * xhat).double().sum(dim=(0, 2, 3))
+    assert torch.allclose(part[0], s1, rtol=1e-4, atol=1e-2) and torch.allclose(part[1], s2, rtol=1e-4, atol=2e-2)
+
+
+def test_conv_bf16_full_size_layers_match_fp32_reference_on_rounded_operands():
+    """Config 5's chunk size: 3x3 128 -> 128 @28 and the stride-2 256 -> 512 downsample at 64 rows, against fp32 F.conv2d on the GPU."""
+    g = torch.Generator(device='cpu').manual_seed(11)
+    for (N, Cin, H, W, Cout, R, stride, pad) in [(64, 128, 28, 28, 128, 3, 1, 1), (64, 256, 56, 56, 512, 1, 2, 0), (32, 128, 56, 56, 128, 3, 2, 1)]:
+        x = _cl(torch.randn(N, Cin, H, W, generator=g).bfloat16()); w = _cl((torch.randn(Cout, Cin, R, R, generator=g) / (Cin * R * R) ** 0.5).bfloat16())
+        xr = x.float().requires_grad_(True); wr = w.float().requires_grad_(True)
+        yr = F.conv2d(xr, wr, None, stride, pad)
+        dy = _cl(torch.randn(yr.shape, generator=g).bfloat16())
+        yr.backward(dy.float())
+        y = ops.conv_bf16_fwd(x, w, stride, pad)
+        dx = ops.conv_bf16_dgrad(dy, ops.conv_bf16_wt(w), x.shape, stride, pad)
+        dw = torch.zeros_like(w, dtype=torch.float32); ops.conv_bf16_wgrad(dy, x, dw, stride, pad)
+        assert (y.float() - yr.detach()).abs().max().item() <= 2.0 ** -8 * yr.abs().max().item()
+        assert (dx.float() - xr.grad).abs().max().item() <= 2.0 ** -8 * xr.grad.abs().max().item()
+        assert (dw - wr.grad).abs().max().item() <= 1e-3 * wr.grad.abs().max().item()
