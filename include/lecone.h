@@ -510,6 +510,10 @@ int lec_conv_f32x3_wgrad(const float* dy, const float* x, int N, int H, int W, i
  * ------------------------------------------------------------------------------------------------------------- */
 int lec_conv_bf16_supported(int Cin, int Cout, int R, int S, int stride, int pad);
 int lec_conv_bf16_wt_transpose(const void* w, void* wt, int Cout, int RS, int Cin, lec_stream_t stream);
+/*     ... and every convolution weight of a flat bf16 arena in ONE launch (after the Adam kernel has refreshed the arena): base / base_t = the arena and its
+ *       transposed twin (same element offsets), table = DEVICE int32 [n_layers][5] {element offset, Cout, RS, Cin, first tile}, a layer owning
+ *       RS * ceil(Cout / 64) * ceil(Cin / 64) consecutive tiles. */
+int lec_conv_bf16_wt_transpose_flat(const void* base, void* base_t, const int32_t* table, int n_layers, int total_tiles, lec_stream_t stream);
 int lec_conv_bf16_fwd(const void* x, const void* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                       void* y, float* partials, int64_t partials_bytes, int* n_partials, lec_stream_t stream);
 int lec_conv_bf16_dgrad(const void* dy, const void* wt, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,

@@ -119,6 +119,7 @@ def _load():
         'lec_conv_f32x3_wgrad': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p]),
         'lec_conv_bf16_supported': (i32, [i32, i32, i32, i32, i32, i32]),
         'lec_conv_bf16_wt_transpose': (i32, [p, p, i32, i32, i32, p]),
+        'lec_conv_bf16_wt_transpose_flat': (i32, [p, p, p, i32, i32, p]),
         'lec_conv_bf16_fwd': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p, i64, p, p]),
         'lec_conv_bf16_dgrad': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p, p, p, p, p, p, i64, p, p]),
         'lec_conv_bf16_wgrad': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, i32, p]),

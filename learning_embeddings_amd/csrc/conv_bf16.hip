@@ -374,6 +374,33 @@ __global__ __launch_bounds__(256) void wt_transpose_kernel(const unsigned short*
   }
 }
 
+// the same for EVERY convolution weight of a flat bf16 arena in one launch: table[l] = {element offset of the layer inside both arenas, Cout, RS, Cin,
+// first tile of the layer}; a block finds its layer by bisection over the tile starts
+__global__ __launch_bounds__(256) void wt_transpose_flat_kernel(const unsigned short* __restrict__ base, unsigned short* __restrict__ base_t,
+                                                                const int* __restrict__ table, int nlayers) {
+  __shared__ unsigned short t[64][64 + 2];
+  const int b = blockIdx.x;
+  int lo = 0, hi = nlayers - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (table[5 * mid + 4] <= b) lo = mid; else hi = mid - 1; }
+  const int off = table[5 * lo], Cout = table[5 * lo + 1], RS = table[5 * lo + 2], Cin = table[5 * lo + 3];
+  int rel = b - table[5 * lo + 4];
+  const int nci = (Cin + 63) / 64, nco = (Cout + 63) / 64;
+  const int tci = rel % nci; rel /= nci; const int tco = rel % nco; const int tap = rel / nco;
+  const unsigned short* w = base + off; unsigned short* wt = base_t + off;
+  const int co0 = tco * 64, ci0 = tci * 64;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    const int co = co0 + r, ci = ci0 + c;
+    t[r][c] = (co < Cout && ci < Cin) ? w[((int64_t)co * RS + tap) * Cin + ci] : (unsigned short)0;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    const int ci = ci0 + r, co = co0 + c;
+    if (ci < Cin && co < Cout) wt[((int64_t)ci * RS + tap) * Cout + co] = t[c][r];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // weight gradient.  Tile BM output channels x BN columns (tap, ci); K = pixels in chunks of 32.  LDS images as in memory: A [32 px][BM + 32],
 // B [32 px][BN + 32] bf16; fragments by ds_read_b64_tr_b16: a 16-lane group reads a 4 (k) x 16 (column) block, lane 4 q + p supplying the
@@ -594,6 +621,17 @@ extern "C" int lec_conv_bf16_wt_transpose(const void* w, void* wt, int Cout, int
   hipLaunchKernelGGL(wt_transpose_kernel, dim3((Cin + 63) / 64, (Cout + 63) / 64, RS), dim3(256), 0, (hipStream_t)stream,
                      (const unsigned short*)w, (unsigned short*)wt, Cout, RS, Cin);
   LEC_CHECK_LAUNCH("wt_transpose_kernel");
+  return LEC_OK;
+}
+
+// Every layer of a flat arena at once: base / base_t are the bf16 arena and its transposed twin (same offsets), table DEVICE int32 [n_layers][5] =
+// {element offset, Cout, RS, Cin, first tile}, tiles of a layer = RS * ceil(Cout / 64) * ceil(Cin / 64), total_tiles their sum.
+extern "C" int lec_conv_bf16_wt_transpose_flat(const void* base, void* base_t, const int32_t* table, int n_layers, int total_tiles, lec_stream_t stream) {
+  using namespace lec;
+  LEC_CHECK_ARG(base && base_t && table && n_layers > 0 && total_tiles > 0, "conv_bf16_wt_transpose_flat: bad arguments");
+  hipLaunchKernelGGL(wt_transpose_flat_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)base, (unsigned short*)base_t,
+                     (const int*)table, n_layers);
+  LEC_CHECK_LAUNCH("wt_transpose_flat_kernel");
   return LEC_OK;
 }
 

@@ -187,7 +187,7 @@ class StepEngine:
         self.overlap = None
         if self.compute_dtype in (torch.bfloat16, torch.float32):
             if self.compute_dtype == torch.bfloat16:
-                self.arena.enable_lowp_shadow()
+                self.arena.enable_lowp_transposed()     # bf16 shadow + its transposed twin (the data gradients' operand)
             # fp32 (the reference's precision): the convolutions read the arena's master weights directly
             self.overlap = WgradOverlap(self.reducer, self.arena, side_stream=overlap_wgrad)
         # this engine's settings travel with ITS backbone (resnet.ResNet.wgrad_overlap / bn_grad_accumulate / conv_schedule -> the

@@ -129,7 +129,7 @@ class ETHECExperiment(Experiment):
         self.overlap = None
         if fast_path and compute_dtype in (torch.float32, torch.bfloat16):
             if compute_dtype == torch.bfloat16:
-                self.arena.enable_lowp_shadow()
+                self.arena.enable_lowp_transposed()     # bf16 shadow + its transposed twin (the data gradients' operand)
             self.overlap = WgradOverlap(self.reducer, self.arena, side_stream=True)
         self.model.wgrad_overlap = self.overlap if self.overlap is not None else False    # this trainer's own (resnet.ResNet.wgrad_overlap)
 

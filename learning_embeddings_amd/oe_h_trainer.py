@@ -532,7 +532,7 @@ class JointEmbeddings:
         self.overlap = None
         if self.use_CNN and fast_path and compute_dtype in (torch.float32, torch.bfloat16):
             if compute_dtype == torch.bfloat16:
-                self.arena.enable_lowp_shadow()
+                self.arena.enable_lowp_transposed()     # bf16 shadow + its transposed twin (the data gradients' operand)
             # fp32: the CNN batch of a step goes through the backbone as two concurrent halves, one HIP stream each -- one half's HBM-bound
             # BatchNorm passes under the other's matrix-bound convolutions (engine.StepEngine) -- with the weight
             # gradients in line; bf16 (HBM-bound everywhere): one pass, weight gradients on a side stream.  cnn_passes overrides.

@@ -448,6 +448,7 @@ FOLD_BN_BWD = _os.environ.get('LEC_FOLD_BN_BWD', '1') != '0'
 # fp32 counterparts (round 3): pass 1 of a BatchNorm backward in the epilogue of the fp32 data gradient that produces its gradient
 # (lec_conv_f32_dgrad_fused), pass 2 on the operand load of the 1x1 convolution behind the BatchNorm (data and weight gradient)
 FOLD_BN_BWD_F32 = _os.environ.get('LEC_FOLD_BN_BWD_F32', '1') != '0'
+FOLD_BN_BWD_BF16 = _os.environ.get('LEC_FOLD_BN_BWD_BF16', '1') != '0'      # ... and of the bf16 family's data gradients (csrc/conv_bf16.hip)
 LAZY_BN_PASS2_F32 = _os.environ.get('LEC_LAZY_BN_PASS2_F32', '1') != '0'
 # Where the two forms pay (tools/bench_conv_f32_fused.py, one MI355X, 512 rows; the step now runs as two concurrent half-batch passes, so a
 # BatchNorm pass that stays a kernel is about half hidden under the other pass's convolutions, while every microsecond added to a
@@ -566,9 +567,10 @@ class BNActFn(torch.autograd.Function):
                     fusion().forks.clear()
                 # what the consumer convolution's data gradient needs to run pass 1 of THIS layer's backward in its epilogue
                 fusion().forks[y.data_ptr()] = {'x': x, 'mask': mask, 'mean': save_mean, 'invstd': save_invstd, 'dres': None}
-            elif (not fork and FOLD_BN_BWD_F32 and x.dtype == torch.float32 and ctx.needs_input_grad[0]):
-                # fp32: an output with ONE consumer (bn1 -> conv2, bn2 -> conv3): that convolution's data gradient can run pass 1 in
-                # its epilogue with no second gradient to wait for
+            elif (not fork and ctx.needs_input_grad[0] and ((FOLD_BN_BWD_F32 and x.dtype == torch.float32) or (FOLD_BN_BWD_BF16 and x.dtype == torch.bfloat16))):
+                # an output with ONE consumer (bn1 -> conv2, bn2 -> conv3): that convolution's data gradient can run pass 1 in its epilogue with
+                # no second gradient to wait for (fp32: lec_conv_f32_dgrad_fused; bf16: lec_conv_bf16_dgrad's fold -- a consumer that cannot, e.g. a
+                # strided layer or a special-case kernel, ignores the record and this layer runs its own pass 1)
                 if len(fusion().forks) > 64:
                     fusion().forks.clear()
                 fusion().forks[y.data_ptr()] = {'x': x, 'mask': mask, 'mean': save_mean, 'invstd': save_invstd, 'dres': None, 'single': True}

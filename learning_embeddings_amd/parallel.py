@@ -66,9 +66,45 @@ class FlatArena:
     def lowp_view(self, p):
         return self._lp_views.get(id(p)) if self.data_lp is not None else None
 
+    def enable_lowp_transposed(self):
+        """Keep, beside the bf16 shadow, a TRANSPOSED twin of every convolution weight -- memory [Cin][RS][Cout], the k-contiguous operand of the
+        bf16 data-gradient kernels (lec_conv_bf16_dgrad) -- refreshed by ONE launch right after the Adam kernel (lec_conv_bf16_wt_transpose_flat).
+        `lowp_t_view(p)` is parameter p's slot: a channels_last [Cin, Cout, R, S] tensor."""
+        self.enable_lowp_shadow()
+        if getattr(self, 'data_lp_t', None) is not None:
+            return self
+        rows = []; views = {}; tile = 0
+        self.data_lp_t = torch.zeros_like(self.data_lp)
+        for k, p in enumerate(self.params):
+            if p.dim() != 4:
+                continue
+            cout, cin, r, s_ = p.shape
+            nhwc = p.data.is_contiguous(memory_format=torch.channels_last) or (r == 1 and s_ == 1)
+            if not nhwc or cin % 8 or cout % 64:
+                continue
+            o = self.offsets[k]
+            rows.append([o, cout, r * s_, cin, tile])
+            tile += r * s_ * ((cout + 63) // 64) * ((cin + 63) // 64)
+            views[id(p)] = self.data_lp_t[o:o + p.numel()].view(cin, r, s_, cout).permute(0, 3, 1, 2)
+        self._lpt_views = views
+        self._lpt_table = torch.tensor(rows, dtype=torch.int32, device=self.data.device).contiguous() if rows else None
+        self._lpt_tiles = tile
+        self.refresh_lowp_t()
+        return self
+
+    def lowp_t_view(self, p):
+        return self._lpt_views.get(id(p)) if getattr(self, 'data_lp_t', None) is not None else None
+
+    def refresh_lowp_t(self):
+        if getattr(self, 'data_lp_t', None) is not None and self._lpt_table is not None:
+            from . import _lib
+            _lib.check(_lib.lib.lec_conv_bf16_wt_transpose_flat(_lib.dptr(self.data_lp), _lib.dptr(self.data_lp_t), _lib.dptr(self._lpt_table),
+                                                                int(self._lpt_table.shape[0]), int(self._lpt_tiles), _lib.stream_ptr()))
+
     def refresh_lowp(self):
         if self.data_lp is not None:
             self.data_lp.copy_(self.data)
+            self.refresh_lowp_t()
 
     def zero_grad(self):
         self.grad.zero_()
@@ -119,6 +155,7 @@ class FlatArena:
             self.exp_avg = torch.zeros_like(self.data); self.exp_avg_sq = torch.zeros_like(self.data)
         self.step += 1
         ops.adam_flat(self.data, self.grad, self.exp_avg, self.exp_avg_sq, self.step, lr, betas, eps, grad_scale, self.data_lp)
+        self.refresh_lowp_t()                                   # the data gradients' transposed bf16 weights follow (one launch; no-op without them)
 
 
 # ------------------------------------------------------------------------------------------------ process group

@@ -89,6 +89,16 @@ class WgradOverlap:
         w16 = self.arena.lowp_view(conv.weight) if (self.arena is not None and dtype == torch.bfloat16) else None
         return w16 if w16 is not None else conv.weight.to(dtype)
 
+    def weight_lp_t(self, conv, w16):
+        """The bf16 weights of `conv` in the data gradient's layout [Cin][RS][Cout]: the arena's transposed twin where it keeps one
+        (FlatArena.enable_lowp_transposed: refreshed once per optimizer step, by one launch behind the Adam kernel), else transposed per call."""
+        if self.arena is not None:
+            lp = self.arena.lowp_view(conv.weight)
+            wt = self.arena.lowp_t_view(conv.weight) if lp is not None and lp.data_ptr() == w16.data_ptr() else None
+            if wt is not None:
+                return wt
+        return _ops().conv_bf16_wt(w16)
+
     def _finish_wgrad(self, gw, conv):
         w = conv.weight
         if w.grad is None:
@@ -125,6 +135,8 @@ class WgradOverlap:
             if self.reducer is not None:
                 self.reducer.mark_ready(w)
             return True
+        if self._bf16_family_wgrad(gy, x, conv, first=True):
+            return True
         if (MFMA_WGRAD_3X3 and self.arena is not None and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
                 and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels == 64 and conv.out_channels == 64
                 and w.grad is not None and w.grad.dtype == torch.float32 and w.grad.is_contiguous(memory_format=torch.channels_last)
@@ -136,17 +148,42 @@ class WgradOverlap:
                 self.reducer.mark_ready(w)
             return True
         if not (MFMA_WGRAD and self.arena is not None and _is_pointwise(conv) and w.grad is not None and w.grad.dtype == torch.float32
-                and gy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
+                and gy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and CONV_BF16 != '2'
                 and gy.is_contiguous(memory_format=torch.channels_last) and x.is_contiguous(memory_format=torch.channels_last)):
-            return False
+            return self._bf16_family_wgrad(gy, x, conv)
         ops = _ops()
         m = gy.shape[0] * gy.shape[2] * gy.shape[3]
         if not ops.conv1x1_wgrad_supported(conv.in_channels, conv.out_channels, m) or (max(conv.in_channels, conv.out_channels) > 512 and not MFMA_WGRAD_L3):
-            return False
+            return self._bf16_family_wgrad(gy, x, conv)
         gw = w.grad.view(conv.out_channels, conv.in_channels)      # a 1x1 weight is [Cout][Cin] in memory in either layout
         ops.conv1x1_wgrad_rows(_rows(gy), _rows(x), gw)
         if self.reducer is not None:
             self.reducer.mark_ready(w)
+        return True
+
+    def _bf16_family_wgrad(self, gy, x, conv, first=False):
+        """The bf16 implicit-GEMM family's weight gradient (lec_conv_bf16_wgrad: float atomics into the arena's fp32 slot, or into a fresh fp32
+        buffer that is then added like a library result).  first=True: asked BEFORE the special-case kernels (LEC_CONV_BF16=2 only)."""
+        if CONV_BF16 == '0' or (first and CONV_BF16 != '2'):
+            return False
+        w = conv.weight
+        if not (gy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and gy.dim() == 4 and _ops().conv_bf16_supported(conv) and _bf16_conv_fits(conv, x)
+                and gy.is_contiguous(memory_format=torch.channels_last) and x.is_contiguous(memory_format=torch.channels_last)):
+            return False
+        slot = w.grad if (w.grad is not None and w.grad.dtype == torch.float32 and w.grad.shape == w.shape
+                          and (w.grad.is_contiguous(memory_format=torch.channels_last) or _is_pointwise(conv))) else None
+        if slot is not None:
+            tgt = slot if slot.is_contiguous(memory_format=torch.channels_last) else slot.view(w.shape).contiguous(memory_format=torch.channels_last)
+            if tgt.data_ptr() != slot.data_ptr():
+                slot = None
+        if slot is not None:
+            _ops().conv_bf16_wgrad(gy, x, tgt, conv.stride[0], conv.padding[0])
+            if self.reducer is not None:
+                self.reducer.mark_ready(w)
+            return True
+        gw = torch.zeros(w.shape, dtype=torch.float32, device=w.device).contiguous(memory_format=torch.channels_last)
+        _ops().conv_bf16_wgrad(gy, x, gw, conv.stride[0], conv.padding[0])
+        self._finish_wgrad(gw, conv)
         return True
 
     def submit(self, gy, x, w16, conv, xf=None):
@@ -156,6 +193,9 @@ class WgradOverlap:
                 return
             if xf is not None:
                 gy = self._materialise(gy, xf)
+            if x.shape[1] != conv.in_channels:
+                x = x[:, :conv.in_channels]                     # (a zero-padded stem input)
+            _lib_launch('wgrad')
             gw = torch.ops.aten.convolution_backward(gy, x, w16, None, conv.stride, conv.padding, conv.dilation, False,
                                                      [0, 0], conv.groups, [False, True, False])[1]
             self._finish_wgrad(gw, conv)
@@ -171,8 +211,9 @@ class WgradOverlap:
             if not own and xf is not None:
                 gy = self._materialise(gy, xf)
             if not own:
-                gw = torch.ops.aten.convolution_backward(gy, x, w16, None, conv.stride, conv.padding, conv.dilation, False,
-                                                         [0, 0], conv.groups, [False, True, False])[1]
+                _lib_launch('wgrad')
+                gw = torch.ops.aten.convolution_backward(gy, x[:, :conv.in_channels] if x.shape[1] != conv.in_channels else x, w16, None, conv.stride, conv.padding,
+                                                         conv.dilation, False, [0, 0], conv.groups, [False, True, False])[1]
             for t in (gy, x, w16):
                 t.record_stream(self.side)                 # the caching allocator must not recycle them under the side stream
                                                            # (under hipGraph capture such blocks are held until the capture ends)
@@ -222,6 +263,26 @@ MFMA_F32 = os.environ.get('LEC_CONV_F32', '1') != '0'
 F32_MODE = os.environ.get('LEC_CONV_F32_MODE', 'native')
 GEMM_FWD_MIN_CIN = 1024
 GEMM_DGRAD_MIN_CIN = 256
+# bf16 activations (config 5's 16-bit conv stack): every layer that has no special-case kernel above runs liblecone's bf16 implicit-GEMM family
+# (csrc/conv_bf16.hip: forward with BatchNorm statistics, data gradient with the BatchNorm-backward fold, weight gradient) -- no library convolution is
+# left on the 16-bit path.  '1' (default): special-case kernels where they exist, the family elsewhere; '2': the family everywhere (A/B runs);
+# '0': the library (MIOpen / CK / hipBLASLt) for everything the special cases do not serve, as until round 5 (A/B runs only).
+CONV_BF16 = os.environ.get('LEC_CONV_BF16', '1')
+# Convolutions / GEMMs handed to a LIBRARY (aten.convolution, aten.convolution_backward, torch.mm) by this module since the last reset, by direction.
+# A step captured into a hipGraph counts once, at capture.  bench.py prints it per step; the fp32 and bf16 config tests assert zero.
+LIBRARY_LAUNCHES = {'fwd': 0, 'dgrad': 0, 'wgrad': 0}
+
+
+def library_launches(reset=False):
+    n = dict(LIBRARY_LAUNCHES)
+    if reset:
+        for k in LIBRARY_LAUNCHES:
+            LIBRARY_LAUNCHES[k] = 0
+    return n
+
+
+def _lib_launch(kind):
+    LIBRARY_LAUNCHES[kind] += 1
 
 
 def _ops():
@@ -256,6 +317,24 @@ def _pad_c4(t):
     out = torch.empty((t.shape[0], 4, t.shape[2], t.shape[3]), dtype=t.dtype, device=t.device, memory_format=torch.channels_last)
     out[:, 3:].zero_(); out[:, :3] = t
     return out
+
+
+def _pad_c8(t):
+    """[N, 3, H, W] -> [N, 8, H, W] channels_last with zero channels 3..7 (the bf16 family's 16-byte piece is 8 channels)."""
+    if t.shape[1] == 8:
+        return t
+    out = torch.zeros((t.shape[0], 8, t.shape[2], t.shape[3]), dtype=t.dtype, device=t.device).contiguous(memory_format=torch.channels_last)
+    out[:, :t.shape[1]] = t
+    return out
+
+
+def _bf16_conv_fits(conv, x):
+    """lec_conv_bf16_* address a tensor with 32-bit byte offsets: input and output must stay below 2 GiB (ResNet-50 at 224 x 224 in bf16: 1 337 rows)."""
+    n, c, h, w = x.shape
+    c = max(c, 8)
+    k, st, pd = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    ho, wo = (h + 2 * pd - k) // st + 1, (w + 2 * pd - k) // st + 1
+    return n * h * w * c * 2 < (1 << 31) and n * ho * wo * conv.out_channels * 2 < (1 << 31)
 
 
 def _is_pointwise(conv):
@@ -377,16 +456,20 @@ class _OverlapConvFn(torch.autograd.Function):
                         lz_ok.clear()
                     lz_ok[y.data_ptr()] = conv.in_channels
             ctx.save_for_backward(x, w16); ctx.conv = conv
-            ctx.pointwise = ctx.own = ctx.own3 = False
+            ctx.pointwise = ctx.own = ctx.own3 = ctx.gen = False
             return y
         ctx.pointwise = GEMM_1X1 and nhwc and _is_pointwise(conv)
-        ctx.own = ctx.pointwise and MFMA_1X1 and x.dtype == torch.bfloat16
+        ctx.own = ctx.pointwise and MFMA_1X1 and x.dtype == torch.bfloat16 and CONV_BF16 != '2'
         ctx.own3 = (MFMA_3X3 and nhwc and x.dtype == torch.bfloat16 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
-                    and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+                    and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and CONV_BF16 != '2'
                     and conv.in_channels == conv.out_channels and conv.in_channels in (64, 128)
                     and (x.shape[0] * x.shape[2] * x.shape[3]) % 32 == 0)
         if ctx.own3 and conv.in_channels == 128 and MFMA_3X3_C128 == '0':
             ctx.own3 = False
+        # the bf16 implicit-GEMM family: every layer shape (the stem through zero channels 3..7)
+        ctx.gen = (CONV_BF16 != '0' and nhwc and x.dtype == torch.bfloat16 and w16.dtype == torch.bfloat16 and w16.dim() == 4
+                   and w16.is_contiguous(memory_format=torch.channels_last) and _ops().conv_bf16_supported(conv) and _bf16_conv_fits(conv, x))
+        ctx.stem = False
         if ctx.own3 and (conv.in_channels == 64 or MFMA_3X3_C128 == '1'):                                            # layer1's conv2: liblecone's MFMA kernel, statistics in the epilogue
             y = _ops().conv3x3_c64(x, w16, want_stats=True)
         elif ctx.own and _ops().conv1x1_supported(conv.in_channels, conv.out_channels, x.shape[0] * x.shape[2] * x.shape[3]):
@@ -400,10 +483,17 @@ class _OverlapConvFn(torch.autograd.Function):
                 y = _from_rows(ops.conv1x1_stats_rows(_rows(x), w16.reshape(conv.out_channels, conv.in_channels)), n, h, wd)
             else:
                 y = _from_rows(ops.conv1x1_rows(_rows(x), w16.reshape(conv.out_channels, conv.in_channels), want_stats=True), n, h, wd)
+        elif ctx.gen:
+            ctx.stem = conv.in_channels == 3
+            if ctx.stem:
+                x, w16 = _pad_c8(x), _pad_c8(w16)
+            y = _ops().conv_bf16_fwd(x, w16, conv.stride[0], conv.padding[0], want_stats=True)
         elif ctx.pointwise and conv.in_channels >= GEMM_FWD_MIN_CIN:
             n, _, h, wd = x.shape
+            _lib_launch('fwd')
             y = _from_rows(torch.mm(_rows(x), w16.reshape(conv.out_channels, conv.in_channels).t()), n, h, wd)
         else:
+            _lib_launch('fwd')
             y = torch.ops.aten.convolution(x, w16, None, conv.stride, conv.padding, conv.dilation, False, [0, 0], conv.groups)
         ctx.save_for_backward(x, w16); ctx.conv = conv
         return y
@@ -479,10 +569,22 @@ class _OverlapConvFn(torch.autograd.Function):
                     gx = _from_rows(ops.conv1x1_dgrad_bnfold_rows(_rows(gy), w16.reshape(conv.out_channels, conv.in_channels), fork), n, h, wd)
                 else:
                     gx = _from_rows(ops.conv1x1_rows(_rows(gy), w16.reshape(conv.out_channels, conv.in_channels), w_transposed=True), n, h, wd)
+            elif ctx.gen and nhwc_g and not ctx.stem and conv.out_channels % 64 == 0 and gy.dtype == torch.bfloat16:
+                ops = _ops()
+                # pass 1 of the backward of the BatchNorm whose output this layer consumed, in the epilogue (stride-1 layers): a block output with
+                # the other consumer's gradient already there, or an output with this one consumer
+                rec = ops.fusion().forks.get(x.data_ptr()) if (ops.FOLD_BN_BWD and conv.stride[0] == 1) else None
+                if rec is not None and not (rec['x'].dtype == torch.bfloat16 and rec['x'].shape == x.shape and (rec.get('single') or rec['dres'] is not None)
+                                            and (rec['dres'] is None or (rec['dres'].dtype == torch.bfloat16 and rec['dres'].shape == x.shape
+                                                                         and rec['dres'].is_contiguous(memory_format=torch.channels_last)))):
+                    rec = None
+                gx = ops.conv_bf16_dgrad(gy, ops.overlap().weight_lp_t(conv, w16), x.shape, conv.stride[0], conv.padding[0], fold=rec)
             elif (ctx.pointwise and conv.in_channels >= GEMM_DGRAD_MIN_CIN and nhwc_g):
                 n, _, h, wd = gy.shape
+                _lib_launch('dgrad')
                 gx = _from_rows(torch.mm(_rows(gy), w16.reshape(conv.out_channels, conv.in_channels)), n, h, wd)
             else:
+                _lib_launch('dgrad')
                 gx = torch.ops.aten.convolution_backward(gy, x, w16, None, conv.stride, conv.padding, conv.dilation, False,
                                                          [0, 0], conv.groups, [True, False, False])[0]
         fc = _ops().fusion()
