@@ -393,7 +393,8 @@ def measure(args, dtype, rank, world, stamp, primary):
            'phases_ms': dict({('eager_probe_' + k if graph_mode and k in ('cnn_fwd', 'cone_loss', 'cnn_bwd', 'allreduce_wait', 'fused_bn', 'conv_f32') else k): round(v, 3)
                               for k, v in phases.items() if not k.endswith('_busy')}, host_enqueue=round(host_busy_s / args.steps * 1e3, 3)),
            'roofline_cnn': roof_cnn, 'roofline_bn': roof_bn, 'roofline_conv': roof_conv,
-           'allreduce_ms': round(phases.get('allreduce', phases.get('allreduce_wait', 0.0)), 3), 'data_parallel': dp_info}
+           'allreduce_ms': round(phases.get('allreduce', phases.get('allreduce_wait', 0.0)), 3), 'data_parallel': dp_info,
+           'library_conv_launches_per_step': sum((getattr(eng, 'library_conv_launches_per_step', None) or {'-': -1}).values())}
     return res, eng
 
 
@@ -673,7 +674,6 @@ def main():
                          'auto = probe both on this box during warm-up and keep the faster for the timed steps.  Default graph: with the two concurrent '
                          'half-batch passes the replay runs at the eager step\'s speed (132.9 vs 132.8 ms) with 4 ms of host time per step instead of 25 and 44 GB of HBM')
     ap.add_argument('--no-graph', action='store_true', help='same as --launch eager')
-    ap.add_argument('--cudnn-benchmark', action='store_true', help='let MIOpen benchmark every solver per conv shape (slow start)')
     ap.add_argument('--through-trainer', type=int, default=16, help='also time N steps of the same workload driven through JointEmbeddings.train_step (0: skip)')
     ap.add_argument('--through-trainer-files', type=int, default=4096,
                     help='also run the trainer from this many synthetic JPEG FILES through the HBM image store, three epochs (0: skip)')
@@ -696,8 +696,6 @@ def main():
     def stamp(what):
         if int(os.environ.get('RANK', 0)) == 0:
             print('[bench %7.1f s] %s' % (time.time() - t_start, what), file=sys.stderr, flush=True)
-    from learning_embeddings_amd import miopen_tuning
-    miopen_tuning.setup()                                       # before the first convolution
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -705,7 +703,6 @@ def main():
     from learning_embeddings_amd import parallel
     from learning_embeddings_amd.engine import WORKLOADS
 
-    torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
     rank, local_rank, world = parallel.init_process_group()
     if args.secondary is None:
         args.secondary = 'bf16' if world == 1 else 'none'
@@ -780,6 +777,8 @@ def main():
                # `roofline`: the kernel family that dominates the step's time at this precision; the others ride along
                'roofline': dominant, 'roofline_conv': res['roofline_conv'], 'roofline_bn': res['roofline_bn'], 'roofline_cone': roof_cone,
                'roofline_cnn': res['roofline_cnn'],
+               # convolutions / GEMMs this step handed to a LIBRARY (MIOpen / CK / hipBLASLt) instead of liblecone's kernels (counted on the engine's first, eager step)
+               'library_conv_launches_per_step': res.get('library_conv_launches_per_step'),
                'sampler_us_per_negative': round(sampler_us, 4), 'allreduce_ms': res['allreduce_ms'],
                # gradient exchange time the step does NOT hide: graph launch mode reduces every bucket in one sweep after the replay (all of it exposed);
                # eager launches reduce bucket by bucket from backward hooks and this is the wait for the last handles

@@ -154,10 +154,14 @@ __device__ __forceinline__ void bf16_act_body(const unsigned short* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[jt][it][r] = 0.f;
 
-    u32x4q ra[NA], rb[NB];
+    // Operands travel global -> registers -> LDS.  Plain instances keep TWO chunks in flight (register sets 0 / 1 by chunk parity): a chunk's 16 MFMAs per
+    // wave last ~0.5 us at two waves per SIMD, a load under full traffic 1 - 2 us (same box, 512 rows: 3x3 data gradients 167 -> 153 / 166 -> 157 us); the
+    // statistics and fold instances keep one (a second set spills: 1x1 forward layers 5 - 25 % slower).
+    constexpr bool PF2 = !STATS && !FOLD && !TAPV;            // (the statistics / fold instances have no registers for a second set: measured slower with spills)
+    u32x4q ra0[NA], rb0[NB], ra1[PF2 ? NA : 1], rb1[PF2 ? NB : 1];
     unsigned cur[NA];
     int cur_tap = -1;
-    auto load_chunk = [&](int ch) {
+    auto load_chunk = [&](int ch, auto& ra, auto& rb) {
       const int k0 = ch * kBfBK;
       if constexpr (!TAPV) {
         const int tap = k0 >> g.lgCs, c0 = k0 & (g.Cs - 1);
@@ -197,56 +201,95 @@ __device__ __forceinline__ void bf16_act_body(const unsigned short* __restrict__
         rb[u] = bload16(rs_wgt, (tap_ok && co < g.Cd) ? (unsigned)((co * g.RS + tw) * g.Cs + cA) * 2u : kOob);
       }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, const auto& ra, const auto& rb) {
       char* base = (char*)smem + buf * (SA + SB) * 2;
 #pragma unroll
       for (int u = 0; u < NA; ++u) *(u32x4q*)(base + ldsA + u * kBfRP * kBfLdk * 2) = ra[u];
 #pragma unroll
       for (int u = 0; u < NB; ++u) *(u32x4q*)(base + ldsB + u * kBfRP * kBfLdk * 2) = rb[u];
     };
-
-    // FOLD: the epilogue's operands of this tile, requested before the K loop (they do not depend on it): rows r0 + 8 i of the wave's 32 TM
-    u32x4q f_d[FOLD ? 4 * TM : 1], f_x[FOLD ? 4 * TM : 1]; unsigned f_m[FOLD ? 4 * TM : 1];
-    if (FOLD) {
-      const rsrc_t rs_dres = make_rsrc(fz.dres ? fz.dres : dst, fz.dres ? g.dst_bytes : 0u), rs_xbn = make_rsrc(fz.xbn, g.dst_bytes);
-      const rsrc_t rs_mask = make_rsrc(fz.mask ? (const void*)fz.mask : (const void*)dst, fz.mask ? fz.mask_bytes : 0u);
-      const int c = n0 + wn0 + cc * 8;
+    auto mma_chunk = [&](int buf) {
+      const unsigned short* sA = smem + buf * (SA + SB);
+      const unsigned short* sB = sA + SA;
 #pragma unroll
-      for (int i = 0; i < 4 * TM; ++i) {
-        const int m = m0 + wm0 + r0 + 8 * i;
-        const bool ok = m < g.Mg && c < g.Cd;
-        const unsigned off = ok ? (unsigned)(m * g.Cd + c) * 2u : kOob;
-        f_d[i] = bload16(rs_dres, off); f_x[i] = bload16(rs_xbn, off);
-        f_m[i] = fz.mask ? (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_mask, (int)(ok ? (unsigned)(m * (g.Cd >> 3) + (c >> 3)) : kOob), 0, 0) : (ok ? 0xffu : 0u);
+      for (int q = 0; q < kBfBK / 16; ++q) {
+        bfrag xa[TM], wb_[TN];
+#pragma unroll
+        for (int it = 0; it < TM; ++it) xa[it] = *(const bfrag*)(sA + (wm0 + it * 32 + l31) * kBfLdk + 16 * q + 8 * h);
+#pragma unroll
+        for (int jt = 0; jt < TN; ++jt) wb_[jt] = *(const bfrag*)(sB + (wn0 + jt * 32 + l31) * kBfLdk + 16 * q + 8 * h);
+#pragma unroll
+        for (int jt = 0; jt < TN; ++jt)
+#pragma unroll
+          for (int it = 0; it < TM; ++it) acc[jt][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb_[jt], xa[it], acc[jt][it], 0, 0, 0);
       }
-    }
+    };
+
+    // FOLD: the epilogue's operands of this tile (rows r0 + 8 i of the wave's 32 TM) are requested in front of the LAST chunk's MFMAs: by then the
+    // staging registers are free (requested ahead of the K loop they made this a 256-register kernel) and a chunk still covers their latency
+    u32x4q f_d[FOLD ? 4 * TM : 1], f_x[FOLD ? 4 * TM : 1]; unsigned f_m[FOLD ? 4 * TM : 1];
+    auto fold_loads = [&]() {
+      if constexpr (FOLD) {
+        const rsrc_t rs_dres = make_rsrc(fz.dres ? fz.dres : dst, fz.dres ? g.dst_bytes : 0u), rs_xbn = make_rsrc(fz.xbn, g.dst_bytes);
+        const rsrc_t rs_mask = make_rsrc(fz.mask ? (const void*)fz.mask : (const void*)dst, fz.mask ? fz.mask_bytes : 0u);
+        const int c = n0 + wn0 + cc * 8;
+#pragma unroll
+        for (int i = 0; i < 4 * TM; ++i) {
+          const int m = m0 + wm0 + r0 + 8 * i;
+          const bool ok = m < g.Mg && c < g.Cd;
+          const unsigned off = ok ? (unsigned)(m * g.Cd + c) * 2u : kOob;
+          f_d[i] = bload16(rs_dres, off); f_x[i] = bload16(rs_xbn, off);
+          f_m[i] = fz.mask ? (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_mask, (int)(ok ? (unsigned)(m * (g.Cd >> 3) + (c >> 3)) : kOob), 0, 0) : (ok ? 0xffu : 0u);
+        }
+      }
+    };
 
     if (nchunks > 0) {
-      load_chunk(0);
-      __syncthreads();                                          // the previous m-tile's LDS reads (K loop and epilogue image) are done
-      store_chunk(0);
-      __syncthreads();
-      for (int ch = 0; ch < nchunks; ++ch) {
-        const int buf = ch & 1;
-        const unsigned short* sA = smem + buf * (SA + SB);
-        const unsigned short* sB = sA + SA;
-        if (ch + 1 < nchunks) load_chunk(ch + 1);
-#pragma unroll
-        for (int q = 0; q < kBfBK / 16; ++q) {
-          bfrag xa[TM], wb_[TN];
-#pragma unroll
-          for (int it = 0; it < TM; ++it) xa[it] = *(const bfrag*)(sA + (wm0 + it * 32 + l31) * kBfLdk + 16 * q + 8 * h);
-#pragma unroll
-          for (int jt = 0; jt < TN; ++jt) wb_[jt] = *(const bfrag*)(sB + (wn0 + jt * 32 + l31) * kBfLdk + 16 * q + 8 * h);
-#pragma unroll
-          for (int jt = 0; jt < TN; ++jt)
-#pragma unroll
-            for (int it = 0; it < TM; ++it) acc[jt][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb_[jt], xa[it], acc[jt][it], 0, 0, 0);
+      if constexpr (PF2) {
+        load_chunk(0, ra0, rb0);
+        if (nchunks > 1) load_chunk(1, ra1, rb1);
+        __syncthreads();                                        // the previous m-tile's LDS reads (K loop and epilogue image) are done
+        store_chunk(0, ra0, rb0);
+        __syncthreads();
+        // chunk ch is computed from LDS buffer ch & 1 while chunk ch + 1 sits in the other register set (stored at the end of this iteration) and
+        // chunk ch + 2 is requested into the set chunk ch came from
+        int ch = 0;
+        for (; ch + 2 < nchunks; ch += 2) {
+          load_chunk(ch + 2, ra0, rb0);
+          mma_chunk(0);
+          store_chunk(1, ra1, rb1);
+          __syncthreads();
+          if (ch + 3 < nchunks) load_chunk(ch + 3, ra1, rb1);
+          mma_chunk(1);
+          store_chunk(0, ra0, rb0);
+          __syncthreads();
         }
-        if (ch + 1 < nchunks) store_chunk(buf ^ 1);
+        if (ch + 1 < nchunks) {                                 // one or two chunks left, nothing more to request
+          mma_chunk(0);
+          store_chunk(1, ra1, rb1);
+          __syncthreads();
+          mma_chunk(1);
+        } else {
+          mma_chunk(0);
+        }
+        __syncthreads();
+      } else {
+        load_chunk(0, ra0, rb0);
+        __syncthreads();
+        store_chunk(0, ra0, rb0);
+        __syncthreads();
+        for (int ch = 0; ch + 1 < nchunks; ++ch) {
+          load_chunk(ch + 1, ra0, rb0);
+          mma_chunk(ch & 1);
+          store_chunk((ch & 1) ^ 1, ra0, rb0);
+          __syncthreads();
+        }
+        fold_loads();                                           // (the staging registers are free from here on)
+        mma_chunk((nchunks - 1) & 1);
         __syncthreads();
       }
     } else {
+      fold_loads();
       __syncthreads();                                          // (a class without taps: zeros are stored; keep the image hand-off ordered)
     }
 

@@ -26,6 +26,7 @@ from . import _lib, ops, parallel
 from .hierarchy import NegativeGraph, SyntheticLabelMap, SYNTHETIC
 from .oe_h import Embedder, FeatCNN18, FeatCNN, EuclideanConesWithImagesHypernymLoss
 from .resnet import WgradOverlap
+from . import resnet as resnet_mod
 
 # BASELINE.json configs[3]: ETHEC, resnet50, multi-level cross-entropy head over the 723 labels, batch 512 per GPU
 CLASSIFIER_WORKLOADS = {'cfg4': ('ETHEC', 'resnet50', 512, 224), 'tiny4': ('ETHEC', 'resnet18', 8, 32)}
@@ -62,7 +63,12 @@ def _resident_pool(pool, device, compute_dtype, backbone, rows):
     from . import resnet
     pool = pool.to(device).contiguous(memory_format=torch.channels_last)
     if compute_dtype != torch.float32:
-        return _rows_first(pool.to(compute_dtype))            # the backbone's first op would cast it anyway; same values
+        pool = pool.to(compute_dtype)                         # the backbone's first op would cast it anyway; same values
+        conv1 = getattr(backbone, 'conv1', None)
+        if (compute_dtype == torch.bfloat16 and resnet.CONV_BF16 != '0' and isinstance(conv1, resnet.Conv2d) and conv1.in_channels == 3 and conv1.bias is None
+                and getattr(backbone, 'wgrad_overlap', None) not in (None, False) and rows * pool.shape[2] * pool.shape[3] * 16 < (1 << 31)):
+            pool = resnet._pad_c8(pool)                       # the bf16 stem's operand itself: 16-byte pixels, zero channels 3..7 (no pad / cast kernels per step)
+        return _rows_first(pool)
     conv1 = getattr(backbone, 'conv1', None)
     ov = getattr(backbone, 'wgrad_overlap', None)
     if ov is None:
@@ -261,6 +267,8 @@ class StepEngine:
 
     def step(self):
         B, K = self.B, self.K
+        if self.step_no == 0:
+            resnet_mod.library_launches(reset=True)             # step 0 is always launched eagerly: its count is the step's (a replayed graph repeats it)
         frm, to, neg = self.prefetch.next()
         slot = self.step_no & 1
         if self.pin_ev[slot] is not None:
@@ -318,6 +326,8 @@ class StepEngine:
         if ev:
             ev[-1].record(); T['records'].append(ev)
         self.loss_acc += loss[0]
+        if self.step_no == 0:
+            self.library_conv_launches_per_step = dict(resnet_mod.library_launches())    # convolutions / GEMMs handed to MIOpen / hipBLASLt by this step: 0 on liblecone's paths
         self.step_no += 1
         self.last = (loss, e_pos, e_neg, frm, to, neg)
         # at most two whole steps in flight (the pinned-buffer wait above bounds the run-ahead by the START of step s - 2 only): what the side

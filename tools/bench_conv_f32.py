@@ -4,8 +4,6 @@
 usage: python tools/bench_conv_f32.py [--rows 512] [--iters 5] [--json out.json]"""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from learning_embeddings_amd import miopen_tuning
-miopen_tuning.setup()
 import torch
 import torch.nn.functional as F
 from learning_embeddings_amd import ops

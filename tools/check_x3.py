@@ -3,8 +3,6 @@
 usage: python tools/check_x3.py [--rows 64] [--iters 3]"""
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from learning_embeddings_amd import miopen_tuning
-miopen_tuning.setup()
 import torch
 import torch.nn.functional as F
 from learning_embeddings_amd import ops

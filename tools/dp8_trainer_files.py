@@ -35,8 +35,7 @@ def main():
     faulthandler.dump_traceback_later(int(os.environ.get('LEC_DP8_WATCHDOG_S', '150')), exit=True)      # a hung rank says where, and the box is released
     import numpy as np, torch, torch.distributed as dist
     import psutil
-    from learning_embeddings_amd import miopen_tuning, parallel
-    miopen_tuning.setup()
+    from learning_embeddings_amd import parallel
     d = a.dir or tempfile.mkdtemp(prefix='lec_dp8_')
     if a.dir is None:
         bench.write_image_files(d, a.images + 80)

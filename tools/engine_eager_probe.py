@@ -4,8 +4,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 ap = argparse.ArgumentParser(); ap.add_argument('--batch', type=int, default=None); ap.add_argument('--no-reducer-hooks', action='store_true'); ap.add_argument('--flips', type=int, default=0); ap.add_argument('--sleep-us', type=int, default=0)
 a = ap.parse_args()
-from learning_embeddings_amd import miopen_tuning
-miopen_tuning.setup()
 from learning_embeddings_amd.engine import StepEngine
 eng = StepEngine('cfg3', dtype='fp32', use_graph=False, batch=a.batch)
 if a.no_reducer_hooks:

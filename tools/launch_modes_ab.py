@@ -16,8 +16,6 @@ def main():
     ap.add_argument('--side-priority', type=int, default=None)
     ap.add_argument('--main-high', action='store_true', help='run every step on a high-priority stream')
     a = ap.parse_args()
-    from learning_embeddings_amd import miopen_tuning
-    miopen_tuning.setup()
     from learning_embeddings_amd.engine import StepEngine
     eng = StepEngine('cfg3', dtype=a.dtype, use_graph=True, batch=a.batch)
     print('rows per step', eng.n_rows, flush=True)

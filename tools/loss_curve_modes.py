@@ -4,8 +4,6 @@ fp32 on the f32-input MFMA, fp32 with split products on the bf16 matrix cores, b
 usage: python tools/loss_curve_modes.py [--steps 100]"""
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from learning_embeddings_amd import miopen_tuning
-miopen_tuning.setup()
 import torch
 from learning_embeddings_amd import resnet as R
 from learning_embeddings_amd.engine import StepEngine

@@ -23,8 +23,6 @@ def main():
     except Exception as e:
         print('THP: ?', e)
     import torch
-    from learning_embeddings_amd import miopen_tuning
-    miopen_tuning.setup()
     d = tempfile.mkdtemp(prefix='lec_probe_')
     paths = bench.write_image_files(d, a.images + 80)
     tr, crit, dl, cfg = bench._bench_trainer(a, 'fp32', a.images, 64, lambda j: paths[j], a.workers)

@@ -3,8 +3,6 @@ varying CNN row count per batch (500-508 rows) keeps the allocator going back to
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from learning_embeddings_amd import miopen_tuning
-miopen_tuning.setup()
 import bench
 ns = argparse.Namespace(workload='cfg3', batch=None)
 for i in range(3):
