@@ -127,7 +127,11 @@ int lec_joint_loss_fwd_bwd_f16(int energy, int label_proj, int image_proj,
  * the label rows are read from the fp16 shadow (as lec_joint_loss_fwd_bwd_f16), else from `table`.
  * window_dev != NULL (device int32[4] = {row_lo, row_hi, labels_too, feat_base}): the window is read from device memory at kernel start (the three
  * arguments are ignored) and `feat` / `grad_feat` are chunk-sized buffers whose row 0 is feature row feat_base (n_feat = their row count) -- one launch,
- * captured once into a hipGraph, then serves every chunk of every step; the host rewrites four integers per chunk. */
+ * captured once into a hipGraph, then serves every chunk of every step; the host rewrites four integers per chunk.
+ * CONTRACT: a pair has at most ONE image end point, or both of its image rows lie in the same window (the reference's pick_per_level sampler
+ * draws a label or an image AGAINST a label: oe_h.py:880-898; without pick_per_level two images can meet).  A pair whose two image rows fall into
+ * different windows cannot be evaluated by either launch: the launch owning the larger row writes NaN to that pair's energy and to loss[0] -- loud,
+ * never a finite number computed from a row that is not there.  Callers with such pairs use the whole-batch entry (lec_joint_loss_fwd_bwd). */
 int lec_joint_loss_fwd_bwd_window(int energy, int label_proj, int image_proj,
                                   const float* table, const void* table_f16, int64_t ld_table, int n_labels,
                                   const float* feat, int64_t ld_feat, int n_feat,

@@ -47,7 +47,6 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 constexpr int kBfBK = 64;                 // K chunk (bf16 elements): 128 bytes per row
 constexpr int kBfLdk = kBfBK + 8;         // LDS row stride (elements): 144 B, conflict-free ds_read_b128
 constexpr int kBfKQ = kBfBK / 8;          // 16-byte pieces per row
-constexpr int kBfRP = 256 / kBfKQ;        // rows staged per pass of the 256 threads
 constexpr int kBfThreads = 256;
 constexpr int kBfWBK = 32;                // K chunk of the weight gradient (pixels)
 
@@ -89,10 +88,13 @@ template <int WM, int WN, int TM, bool STATS, bool TAPV, bool FOLD>
 __device__ __forceinline__ void bf16_act_body(const unsigned short* __restrict__ src, const unsigned short* __restrict__ wgt,
                                               unsigned short* __restrict__ dst, const ActGeo& g, float* __restrict__ part, const BfFuse& fz,
                                               const int bx, const int gdx, const int by) {
-  static_assert(WM * WN == 4 && !(FOLD && STATS) && !(FOLD && TAPV), "four waves; one statistics epilogue at a time");
+  static_assert((WM * WN == 4 || WM * WN == 8) && !(FOLD && STATS) && !(FOLD && TAPV), "four or eight waves; one statistics epilogue at a time");
   constexpr int TN = 2;
+  constexpr int NT = 64 * WM * WN;                            // threads of the workgroup
+  constexpr int RP = NT / kBfKQ;                              // rows staged per pass
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  constexpr int NA = BM * kBfKQ / kBfThreads, NB = BN * kBfKQ / kBfThreads;
+  constexpr int NA = BM * kBfKQ / NT, NB = BN * kBfKQ / NT;
+  static_assert(NA >= 1 && NB >= 1, "tile too small for the workgroup");
   constexpr int SA = BM * kBfLdk, SB = BN * kBfLdk;           // elements
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -105,7 +107,7 @@ __device__ __forceinline__ void bf16_act_body(const unsigned short* __restrict__
   const int rsc = g.RS * g.Cs;                                 // weight row (one destination channel): RS taps x Cs source channels, k-contiguous
   unsigned wB[NB];
 #pragma unroll
-  for (int u = 0; u < NB; ++u) { const int co = n0 + rowA + kBfRP * u; wB[u] = co < g.Cd ? (unsigned)(co * rsc + 8 * kqA) * 2u : kOob; }
+  for (int u = 0; u < NB; ++u) { const int co = n0 + rowA + RP * u; wB[u] = co < g.Cd ? (unsigned)(co * rsc + 8 * kqA) * 2u : kOob; }
   const unsigned ldsA = (unsigned)((rowA * kBfLdk + 8 * kqA) * 2);
   const unsigned ldsB = (unsigned)((SA + rowA * kBfLdk + 8 * kqA) * 2);
   const bool dense_dst = g.dst_st == 1;
@@ -124,12 +126,17 @@ __device__ __forceinline__ void bf16_act_body(const unsigned short* __restrict__
     }
   }
 
-  for (int mt = bx; mt < mtiles; mt += gdx) {
-    const int m0 = mt * BM;
-    int rowoff[NA]; unsigned tapmask[NA]; int hb[TAPV ? NA : 1], wb[TAPV ? NA : 1], pixn[TAPV ? NA : 1];
+  // Per-tile loader state, set up by tile_setup(mt): source byte offset of each staged row at tap (0, 0) and a bit per tap (the row exists and the
+  // tap's source pixel lies inside the image).
+  int rowoff[NA]; unsigned tapmask[NA]; int hb[TAPV ? NA : 1], wb[TAPV ? NA : 1], pixn[TAPV ? NA : 1];
+  unsigned cur[NA];
+  int cur_tap = -1;
+  auto tile_setup = [&](int mt_) {
+    const int m0_ = mt_ * BM;
+    cur_tap = -1;
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
-      const int m = m0 + rowA + kBfRP * u;
+      const int m = m0_ + rowA + RP * u;
       const bool live = m < g.Mg;
       const int mm = live ? m : 0;
       const int t2 = fdiv(mm, g.dWm); const int mw = mm - t2 * g.Wm; const int n = fdiv(t2, g.dHm); const int mh = t2 - n * g.Hm;
@@ -146,6 +153,63 @@ __device__ __forceinline__ void bf16_act_body(const unsigned short* __restrict__
       }
       tapmask[u] = live ? msk : 0u;
     }
+  };
+  // Operands travel global -> registers (one chunk ahead) -> LDS (two buffers, one barrier per chunk).
+  // MEASURED and removed (round 6, same box, 512 rows, every ResNet-50 layer; profiles/EXPERIMENTS.md "bf16 loader pipeline"): two chunks in flight in two
+  // register sets (3x3 layers -1 .. -5 %, every other data gradient +20 .. +60 %: the second set spills), the next tile's first chunk requested under
+  // this tile's epilogue (+-1 %), the requests pinned above the MFMA block (+-2 %).  None moves the compute-bound layers off ~150 us: at a
+  // 128 x 128 tile the matrix pipe, the LDS array (64 KB read + 32 KB written per chunk) and the vector-memory path (32 KB per chunk) each need
+  // ~512 cycles per chunk and overlap imperfectly -- a third of the bf16 matrix peak is this tile's ceiling, memory latency is not what binds.
+  u32x4q ra0[NA], rb0[NB];
+  auto load_chunk = [&](int ch, auto& ra, auto& rb) {
+    const int k0 = ch * kBfBK;
+    if constexpr (!TAPV) {
+      const int tap = k0 >> g.lgCs, c0 = k0 & (g.Cs - 1);
+      const int ta = fdiv(tap, g.dnb), tb = tap - ta * g.nb;
+      if (tap != cur_tap) {
+        cur_tap = tap;
+        const int toff = (((g.sg * ta) * g.Ws + g.sg * tb) << g.lgCs) * 2;
+        const unsigned tapbit = tap < 32 ? 1u << tap : 0u;
+#pragma unroll
+        for (int u = 0; u < NA; ++u) cur[u] = (tapmask[u] & tapbit) ? (unsigned)(rowoff[u] + toff) : kOob;
+      }
+      const int tw = (g.r0 + g.rstep * ta) * g.S + g.s0 + g.sstep * tb;
+      const unsigned wsc = (unsigned)(tw * g.Cs + c0) * 2u;
+      const unsigned c0b = (unsigned)c0 * 2u;
+#pragma unroll
+      for (int u = 0; u < NA; ++u) ra[u] = bload16(rs_src, cur[u] + c0b);
+#pragma unroll
+      for (int u = 0; u < NB; ++u) rb[u] = bload16(rs_wgt, wB[u] + wsc);
+      return;
+    }
+    // one tap / channel position per 16-byte piece
+    const int kA = k0 + 8 * kqA;
+    const int tapA = kA >> g.lgCs, cA = kA & (g.Cs - 1);
+    const int ta = fdiv(tapA, g.dnb), tb = tapA - ta * g.nb;
+    const int dh = g.sg * ta, dw = g.sg * tb;
+    const bool tap_ok = tapA < ntaps;
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int hs = hb[u] + dh, ws = wb[u] + dw;
+      const bool ok = tap_ok && pixn[u] >= 0 && (unsigned)hs < (unsigned)g.Hs && (unsigned)ws < (unsigned)g.Ws;
+      ra[u] = bload16(rs_src, ok ? (unsigned)(((pixn[u] + hs * g.Ws + ws) << g.lgCs) + cA) * 2u : kOob);
+    }
+    const int tw = (g.r0 + g.rstep * ta) * g.S + g.s0 + g.sstep * tb;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int co = n0 + rowA + RP * u;
+      rb[u] = bload16(rs_wgt, (tap_ok && co < g.Cd) ? (unsigned)((co * g.RS + tw) * g.Cs + cA) * 2u : kOob);
+    }
+  };
+  auto store_chunk = [&](int buf, const auto& ra, const auto& rb) {
+    char* base = (char*)smem + buf * (SA + SB) * 2;
+#pragma unroll
+    for (int u = 0; u < NA; ++u) *(u32x4q*)(base + ldsA + u * RP * kBfLdk * 2) = ra[u];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) *(u32x4q*)(base + ldsB + u * RP * kBfLdk * 2) = rb[u];
+  };
+  for (int mt = bx; mt < mtiles; mt += gdx) {
+    const int m0 = mt * BM;
     f32x16 acc[TN][TM];
 #pragma unroll
     for (int jt = 0; jt < TN; ++jt)
@@ -154,60 +218,6 @@ __device__ __forceinline__ void bf16_act_body(const unsigned short* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[jt][it][r] = 0.f;
 
-    // Operands travel global -> registers -> LDS.  Plain instances keep TWO chunks in flight (register sets 0 / 1 by chunk parity): a chunk's 16 MFMAs per
-    // wave last ~0.5 us at two waves per SIMD, a load under full traffic 1 - 2 us (same box, 512 rows: 3x3 data gradients 167 -> 153 / 166 -> 157 us); the
-    // statistics and fold instances keep one (a second set spills: 1x1 forward layers 5 - 25 % slower).
-    constexpr bool PF2 = !STATS && !FOLD && !TAPV;            // (the statistics / fold instances have no registers for a second set: measured slower with spills)
-    u32x4q ra0[NA], rb0[NB], ra1[PF2 ? NA : 1], rb1[PF2 ? NB : 1];
-    unsigned cur[NA];
-    int cur_tap = -1;
-    auto load_chunk = [&](int ch, auto& ra, auto& rb) {
-      const int k0 = ch * kBfBK;
-      if constexpr (!TAPV) {
-        const int tap = k0 >> g.lgCs, c0 = k0 & (g.Cs - 1);
-        const int ta = fdiv(tap, g.dnb), tb = tap - ta * g.nb;
-        if (tap != cur_tap) {
-          cur_tap = tap;
-          const int toff = (((g.sg * ta) * g.Ws + g.sg * tb) << g.lgCs) * 2;
-          const unsigned tapbit = tap < 32 ? 1u << tap : 0u;
-#pragma unroll
-          for (int u = 0; u < NA; ++u) cur[u] = (tapmask[u] & tapbit) ? (unsigned)(rowoff[u] + toff) : kOob;
-        }
-        const int tw = (g.r0 + g.rstep * ta) * g.S + g.s0 + g.sstep * tb;
-        const unsigned wsc = (unsigned)(tw * g.Cs + c0) * 2u;
-        const unsigned c0b = (unsigned)c0 * 2u;
-#pragma unroll
-        for (int u = 0; u < NA; ++u) ra[u] = bload16(rs_src, cur[u] + c0b);
-#pragma unroll
-        for (int u = 0; u < NB; ++u) rb[u] = bload16(rs_wgt, wB[u] + wsc);
-        return;
-      }
-      // one tap / channel position per 16-byte piece
-      const int kA = k0 + 8 * kqA;
-      const int tapA = kA >> g.lgCs, cA = kA & (g.Cs - 1);
-      const int ta = fdiv(tapA, g.dnb), tb = tapA - ta * g.nb;
-      const int dh = g.sg * ta, dw = g.sg * tb;
-      const bool tap_ok = tapA < ntaps;
-#pragma unroll
-      for (int u = 0; u < NA; ++u) {
-        const int hs = hb[u] + dh, ws = wb[u] + dw;
-        const bool ok = tap_ok && pixn[u] >= 0 && (unsigned)hs < (unsigned)g.Hs && (unsigned)ws < (unsigned)g.Ws;
-        ra[u] = bload16(rs_src, ok ? (unsigned)(((pixn[u] + hs * g.Ws + ws) << g.lgCs) + cA) * 2u : kOob);
-      }
-      const int tw = (g.r0 + g.rstep * ta) * g.S + g.s0 + g.sstep * tb;
-#pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        const int co = n0 + rowA + kBfRP * u;
-        rb[u] = bload16(rs_wgt, (tap_ok && co < g.Cd) ? (unsigned)((co * g.RS + tw) * g.Cs + cA) * 2u : kOob);
-      }
-    };
-    auto store_chunk = [&](int buf, const auto& ra, const auto& rb) {
-      char* base = (char*)smem + buf * (SA + SB) * 2;
-#pragma unroll
-      for (int u = 0; u < NA; ++u) *(u32x4q*)(base + ldsA + u * kBfRP * kBfLdk * 2) = ra[u];
-#pragma unroll
-      for (int u = 0; u < NB; ++u) *(u32x4q*)(base + ldsB + u * kBfRP * kBfLdk * 2) = rb[u];
-    };
     auto mma_chunk = [&](int buf) {
       const unsigned short* sA = smem + buf * (SA + SB);
       const unsigned short* sB = sA + SA;
@@ -244,50 +254,21 @@ __device__ __forceinline__ void bf16_act_body(const unsigned short* __restrict__
       }
     };
 
+    tile_setup(mt);
     if (nchunks > 0) {
-      if constexpr (PF2) {
-        load_chunk(0, ra0, rb0);
-        if (nchunks > 1) load_chunk(1, ra1, rb1);
-        __syncthreads();                                        // the previous m-tile's LDS reads (K loop and epilogue image) are done
-        store_chunk(0, ra0, rb0);
-        __syncthreads();
-        // chunk ch is computed from LDS buffer ch & 1 while chunk ch + 1 sits in the other register set (stored at the end of this iteration) and
-        // chunk ch + 2 is requested into the set chunk ch came from
-        int ch = 0;
-        for (; ch + 2 < nchunks; ch += 2) {
-          load_chunk(ch + 2, ra0, rb0);
-          mma_chunk(0);
-          store_chunk(1, ra1, rb1);
-          __syncthreads();
-          if (ch + 3 < nchunks) load_chunk(ch + 3, ra1, rb1);
-          mma_chunk(1);
-          store_chunk(0, ra0, rb0);
-          __syncthreads();
-        }
-        if (ch + 1 < nchunks) {                                 // one or two chunks left, nothing more to request
-          mma_chunk(0);
-          store_chunk(1, ra1, rb1);
-          __syncthreads();
-          mma_chunk(1);
-        } else {
-          mma_chunk(0);
-        }
-        __syncthreads();
-      } else {
-        load_chunk(0, ra0, rb0);
-        __syncthreads();
-        store_chunk(0, ra0, rb0);
-        __syncthreads();
-        for (int ch = 0; ch + 1 < nchunks; ++ch) {
-          load_chunk(ch + 1, ra0, rb0);
-          mma_chunk(ch & 1);
-          store_chunk((ch & 1) ^ 1, ra0, rb0);
-          __syncthreads();
-        }
-        fold_loads();                                           // (the staging registers are free from here on)
-        mma_chunk((nchunks - 1) & 1);
+      load_chunk(0, ra0, rb0);
+      __syncthreads();                                          // the previous m-tile's LDS reads (K loop and epilogue image) are done
+      store_chunk(0, ra0, rb0);
+      __syncthreads();
+      for (int ch = 0; ch + 1 < nchunks; ++ch) {
+        load_chunk(ch + 1, ra0, rb0);
+        mma_chunk(ch & 1);
+        store_chunk((ch & 1) ^ 1, ra0, rb0);
         __syncthreads();
       }
+      fold_loads();                                             // (the staging registers are free from here on)
+      mma_chunk((nchunks - 1) & 1);
+      __syncthreads();
     } else {
       fold_loads();
       __syncthreads();                                          // (a class without taps: zeros are stored; keep the image hand-off ordered)
@@ -375,7 +356,7 @@ __device__ __forceinline__ void bf16_act_body(const unsigned short* __restrict__
       }
     }
     __syncthreads();
-    for (int i = tid; i < 2 * BN; i += kBfThreads) {
+    for (int i = tid; i < 2 * BN; i += NT) {
       const int s = i / BN, cidx = i - s * BN;
       float v = 0.f;
 #pragma unroll
@@ -386,7 +367,7 @@ __device__ __forceinline__ void bf16_act_body(const unsigned short* __restrict__
 }
 
 template <int WM, int WN, int TM, bool STATS, bool TAPV, bool FOLD>
-__global__ __launch_bounds__(kBfThreads, 2) void conv_bf16_act_kernel(const unsigned short* __restrict__ src, const unsigned short* __restrict__ wgt,
+__global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_bf16_act_kernel(const unsigned short* __restrict__ src, const unsigned short* __restrict__ wgt,
                                                                       unsigned short* __restrict__ dst, ActGeo g, float* __restrict__ part, BfFuse fz) {
   bf16_act_body<WM, WN, TM, STATS, TAPV, FOLD>(src, wgt, dst, g, part, fz, blockIdx.x, gridDim.x, blockIdx.y);
 }
@@ -397,6 +378,289 @@ __global__ __launch_bounds__(kBfThreads, 2) void conv_bf16_act_classes_kernel(co
                                                                               unsigned short* __restrict__ dst, ActGeoSet gs) {
   const ActGeo g = gs.g[blockIdx.z];
   bf16_act_body<WM, WN, TM, false, false, false>(src, wgt, dst, g, nullptr, BfFuse{}, blockIdx.x, gridDim.x, blockIdx.y);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same forward / data gradient with the operands travelling global -> LDS DIRECTLY (buffer_load_dwordx4 ... lds, "LDS-DMA") through a ring of
+// kDmNS stages, kDmNS - 1 of them in flight.
+//
+// Why (profiles/r06_conv_bf16_pmc.md): in the register-staged kernel above a wave spends 52 % of its cycles parked in s_waitcnt / s_barrier -- its 16
+// MFMAs per chunk last ~0.5 us while a load that misses the XCD's L2 (31 % do on the 3x3 layers) takes 1 - 2 us, and one chunk of look-ahead is all
+// the staging registers allow (a second register set spills).  LDS-DMA needs no staging registers, so the look-ahead is a matter of LDS: four stages
+// of 32 k (64-byte rows, 16 KB per stage at 128 x 128) = 64 KB, two workgroups per CU as before.
+//   * a DMA wave-instruction writes 64 lanes x 16 bytes = 1 KiB of LDS LINEARLY (M0 base + 16 lane) from PER-LANE source offsets: lane i lands in
+//     row i >> 2, 16-byte slot i & 3 of a 16-row piece.  The rows cannot be padded, so the bank spread comes from the SOURCE: slot p of row R holds
+//     the row's logical piece p ^ ((R >> 2) & 3), and the fragment reads (row = lane & 31, logical piece 2 q + h) apply the same XOR: every
+//     ds_read_b128 quarter-wave touches all 64 banks once;
+//   * out-of-range offsets (padding taps, row tails, channel tails: bit 31) make the DMA write ZEROS (measured: tools/microbench/lds_dma_oob.hip), so
+//     the 32-bit offset scheme of the register-staged loader carries over unchanged;
+//   * a stage is ready when every wave has waited for ITS pieces (counted s_waitcnt vmcnt: the younger stages stay in flight) and the workgroup has
+//     met at ONE raw s_barrier, which also retires the stage read an iteration ago -- its buffer is the one the next request targets.
+constexpr int kDmBK = 32;                 // k per stage: 64-byte rows
+constexpr int kDmNS = 4;                  // stages in the ring
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else static_assert(N < 0, "add the count");
+}
+__device__ __forceinline__ void lds_barrier() {                // LDS traffic of this wave is done; meet the workgroup (vmcnt untouched)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int WM, int WN, int TM, bool STATS, bool FOLD>
+__device__ __forceinline__ void bf16_act_dma_body(const unsigned short* __restrict__ src, const unsigned short* __restrict__ wgt,
+                                                  unsigned short* __restrict__ dst, const ActGeo& g, float* __restrict__ part, const BfFuse& fz,
+                                                  const int bx, const int gdx, const int by) {
+  static_assert(WM * WN == 4 && !(FOLD && STATS), "four waves; one statistics epilogue at a time");
+  constexpr int TN = 2;
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  constexpr int PA = BM / 16 / 4, PB = BN / 16 / 4;           // DMA pieces (16 rows x 64 B) of A / B per wave and stage
+  constexpr int IPW = PA + PB;                                // DMA instructions per wave and stage
+  constexpr int SA = BM * 64, SB = BN * 64;                   // bytes of a stage's A / B image
+  constexpr int SS = SA + SB;
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  char* const lds = (char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave / WN) * 32 * TM, wn0 = (wave % WN) * 32 * TN;
+  const int n0 = by * BN;
+  const int nst = g.Kg / kDmBK;                                // stages per tile (Cs % 32 == 0: a stage lies inside one tap)
+  const int mtiles = (g.Mg + BM - 1) / BM;
+  const rsrc_t rs_src = make_rsrc(src, g.src_bytes), rs_wgt = make_rsrc(wgt, g.wgt_bytes), rs_dst = make_rsrc(dst, g.dst_bytes);
+  const int rsc = g.RS * g.Cs;
+  // DMA side: this lane's row inside a piece and its logical 16-byte slot (the XOR of the image, applied to the SOURCE)
+  const int prow = lane >> 2, pslot = (lane & 3) ^ ((lane >> 4) & 3);
+  unsigned wB[PB];
+#pragma unroll
+  for (int u = 0; u < PB; ++u) { const int co = n0 + 16 * (wave + 4 * u) + prow; wB[u] = co < g.Cd ? (unsigned)(co * rsc + 8 * pslot) * 2u : kOob; }
+  // fragment side: byte offset of (row lane & 31, logical slot 2 q + h) inside an image
+  const int l31 = lane & 31, h = lane >> 5;
+  const int fswz = (l31 >> 2) & 3;
+  const unsigned fo0 = (unsigned)(l31 * 64 + 16 * ((0 + h) ^ fswz)), fo1 = (unsigned)(l31 * 64 + 16 * ((2 + h) ^ fswz));
+  const bool dense_dst = g.dst_st == 1;
+  const int ntaps = g.na * g.nb;
+  const int cc = lane & 7, r0 = lane >> 3;
+  float st_s[8], st_q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; }
+  float f_mu[8], f_is[8];
+  if (FOLD) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = n0 + wn0 + cc * 8 + j; const bool okc = c < g.Cd;
+      f_mu[j] = okc ? fz.mean[c] : 0.f; f_is[j] = okc ? fz.invstd[c] : 0.f;
+    }
+  }
+
+  for (int mt = bx; mt < mtiles; mt += gdx) {
+    const int m0 = mt * BM;
+    // rows this lane requests: piece wave + 4 u of the A image, row prow
+    int rowoff[PA]; unsigned tapmask[PA];
+#pragma unroll
+    for (int u = 0; u < PA; ++u) {
+      const int m = m0 + 16 * (wave + 4 * u) + prow;
+      const bool live = m < g.Mg;
+      const int mm = live ? m : 0;
+      const int t2 = fdiv(mm, g.dWm); const int mw = mm - t2 * g.Wm; const int n = fdiv(t2, g.dHm); const int mh = t2 - n * g.Hm;
+      const int hb_ = mh * g.sst + g.oh0, wb_ = mw * g.sst + g.ow0;
+      rowoff[u] = (((n * g.Hs + hb_) * g.Ws + wb_) << g.lgCs) * 2 + 16 * pslot;
+      unsigned msk = 0;
+      for (int t = 0; t < ntaps; ++t) {
+        const int ta = fdiv(t, g.dnb), tb = t - ta * g.nb;
+        const int hs = hb_ + g.sg * ta, ws = wb_ + g.sg * tb;
+        msk |= ((unsigned)hs < (unsigned)g.Hs && (unsigned)ws < (unsigned)g.Ws ? 1u : 0u) << t;
+      }
+      tapmask[u] = live ? msk : 0u;
+    }
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int jt = 0; jt < TN; ++jt)
+#pragma unroll
+      for (int it = 0; it < TM; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[jt][it][r] = 0.f;
+
+    unsigned cur[PA];
+    int cur_tap = -1;
+    auto issue = [&](int st) {                                  // request stage st into ring slot st % kDmNS
+      const int k0 = st * kDmBK;
+      const int tap = k0 >> g.lgCs, c0 = k0 & (g.Cs - 1);
+      const int ta = fdiv(tap, g.dnb), tb = tap - ta * g.nb;
+      if (tap != cur_tap) {
+        cur_tap = tap;
+        const int toff = (((g.sg * ta) * g.Ws + g.sg * tb) << g.lgCs) * 2;
+        const unsigned tapbit = tap < 32 ? 1u << tap : 0u;
+#pragma unroll
+        for (int u = 0; u < PA; ++u) cur[u] = (tapmask[u] & tapbit) ? (unsigned)(rowoff[u] + toff) : kOob;
+      }
+      const int tw = (g.r0 + g.rstep * ta) * g.S + g.s0 + g.sstep * tb;
+      const unsigned wsc = (unsigned)(tw * g.Cs + c0) * 2u;
+      const unsigned c0b = (unsigned)c0 * 2u;
+      char* base = lds + (st & (kDmNS - 1)) * SS;
+#pragma unroll
+      for (int u = 0; u < PA; ++u)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(base + (wave + 4 * u) * 1024), 16, (int)(cur[u] + c0b), 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < PB; ++u)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_void*)(base + SA + (wave + 4 * u) * 1024), 16, (int)(wB[u] + wsc), 0, 0, 0);
+    };
+    auto compute = [&](int st) {
+      const char* sA = lds + (st & (kDmNS - 1)) * SS;
+      const char* sB = sA + SA;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const unsigned fo = q ? fo1 : fo0;
+        bfrag xa[TM], wb_[TN];
+#pragma unroll
+        for (int it = 0; it < TM; ++it) xa[it] = *(const bfrag*)(sA + (wm0 + it * 32) * 64 + fo);
+#pragma unroll
+        for (int jt = 0; jt < TN; ++jt) wb_[jt] = *(const bfrag*)(sB + (wn0 + jt * 32) * 64 + fo);
+#pragma unroll
+        for (int jt = 0; jt < TN; ++jt)
+#pragma unroll
+          for (int it = 0; it < TM; ++it) acc[jt][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb_[jt], xa[it], acc[jt][it], 0, 0, 0);
+      }
+    };
+    u32x4q f_d[FOLD ? 4 * TM : 1], f_x[FOLD ? 4 * TM : 1]; unsigned f_m[FOLD ? 4 * TM : 1];
+    auto fold_loads = [&]() {
+      if constexpr (FOLD) {
+        const rsrc_t rs_dres = make_rsrc(fz.dres ? fz.dres : dst, fz.dres ? g.dst_bytes : 0u), rs_xbn = make_rsrc(fz.xbn, g.dst_bytes);
+        const rsrc_t rs_mask = make_rsrc(fz.mask ? (const void*)fz.mask : (const void*)dst, fz.mask ? fz.mask_bytes : 0u);
+        const int c = n0 + wn0 + cc * 8;
+#pragma unroll
+        for (int i = 0; i < 4 * TM; ++i) {
+          const int m = m0 + wm0 + r0 + 8 * i;
+          const bool ok = m < g.Mg && c < g.Cd;
+          const unsigned off = ok ? (unsigned)(m * g.Cd + c) * 2u : kOob;
+          f_d[i] = bload16(rs_dres, off); f_x[i] = bload16(rs_xbn, off);
+          f_m[i] = fz.mask ? (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_mask, (int)(ok ? (unsigned)(m * (g.Cd >> 3) + (c >> 3)) : kOob), 0, 0) : (ok ? 0xffu : 0u);
+        }
+      }
+    };
+
+    lds_barrier();                                              // the previous tile's epilogue image has been read by every wave: the ring is free
+#pragma unroll
+    for (int st = 0; st < kDmNS - 1; ++st) if (st < nst) issue(st);
+    for (int c = 0; c < nst; ++c) {
+      // stage c has landed for THIS wave once at most the younger stages' requests are outstanding
+      if (c + 2 < nst) wait_vmcnt<2 * IPW>(); else if (c + 1 < nst) wait_vmcnt<IPW>(); else wait_vmcnt<0>();
+      lds_barrier();                                            // ... for every wave; and everyone is done reading stage c - 1
+      if (c + kDmNS - 1 < nst) issue(c + kDmNS - 1);             // into the slot stage c - 1 occupied
+      if (c + 1 == nst) fold_loads();
+      compute(c);
+    }
+    if (nst == 0) fold_loads();
+    lds_barrier();                                              // every wave is done with the last stage: the epilogue image may overwrite the ring
+
+    // ---- epilogue (as in the register-staged kernel): D'[channel][pixel] -> per-wave LDS image [32 TM pixels][64 channels] -> 16-byte row segments
+    unsigned short* ep = smem + wave * (32 * TM) * kBfLdk;
+#pragma unroll
+    for (int it = 0; it < TM; ++it)
+#pragma unroll
+      for (int jt = 0; jt < TN; ++jt)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          u32x2q pk;
+          pk[0] = pk_bf16(acc[jt][it][4 * gq + 0], acc[jt][it][4 * gq + 1]);
+          pk[1] = pk_bf16(acc[jt][it][4 * gq + 2], acc[jt][it][4 * gq + 3]);
+          *(u32x2q*)(ep + (it * 32 + l31) * kBfLdk + jt * 32 + 8 * gq + 4 * h) = pk;
+        }
+    wave_lds_sync();
+    const int c = n0 + wn0 + cc * 8;
+    const unsigned coff = c < g.Cd ? (unsigned)c * 2u : kOob;
+#pragma unroll
+    for (int i = 0; i < 4 * TM; ++i) {
+      const int row = r0 + 8 * i;
+      const int m = m0 + wm0 + row;
+      u32x4q v = *(const u32x4q*)(ep + row * kBfLdk + cc * 8);
+      if (FOLD) {
+        u32x4q o;
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) {
+          float a0 = bf_lo(v[j2]) + bf_lo(f_d[i][j2]), a1 = bf_hi(v[j2]) + bf_hi(f_d[i][j2]);
+          a0 = (f_m[i] >> (2 * j2)) & 1u ? a0 : 0.f; a1 = (f_m[i] >> (2 * j2 + 1)) & 1u ? a1 : 0.f;
+          const unsigned w = pk_bf16(a0, a1);
+          a0 = bf_lo(w); a1 = bf_hi(w);
+          st_s[2 * j2] += a0; st_s[2 * j2 + 1] += a1;
+          st_q[2 * j2] += a0 * ((bf_lo(f_x[i][j2]) - f_mu[2 * j2]) * f_is[2 * j2]);
+          st_q[2 * j2 + 1] += a1 * ((bf_hi(f_x[i][j2]) - f_mu[2 * j2 + 1]) * f_is[2 * j2 + 1]);
+          o[j2] = w;
+        }
+        v = o;
+      } else if (STATS) {
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) {
+          const float a0 = bf_lo(v[j2]), a1 = bf_hi(v[j2]);
+          st_s[2 * j2] += a0; st_q[2 * j2] += a0 * a0; st_s[2 * j2 + 1] += a1; st_q[2 * j2 + 1] += a1 * a1;
+        }
+      }
+      unsigned poff;
+      if (dense_dst) {
+        poff = m < g.Mg ? (unsigned)(m * g.Cd) * 2u : kOob;
+      } else {
+        const int mm = m < g.Mg ? m : 0;
+        const int t2 = fdiv(mm, g.dWm); const int mw = mm - t2 * g.Wm; const int n = fdiv(t2, g.dHm); const int mh = t2 - n * g.Hm;
+        const int pix = (n * g.Hd + mh * g.dst_st + g.dph) * g.Wd + mw * g.dst_st + g.dpw;
+        poff = m < g.Mg ? (unsigned)(pix * g.Cd) * 2u : kOob;
+      }
+      const unsigned off = (poff + coff) | ((poff | coff) & kOob);
+      bstore16(v, rs_dst, off);
+      if (g.zfill) {
+        const unsigned rowb = (unsigned)g.Cd * 2u, lineb = (unsigned)g.Wd * rowb;
+        u32x4q z; z[0] = 0u; z[1] = 0u; z[2] = 0u; z[3] = 0u;
+        bstore16(z, rs_dst, off + rowb); bstore16(z, rs_dst, off + lineb); bstore16(z, rs_dst, off + lineb + rowb);
+      }
+    }
+  }
+
+  if (STATS || FOLD) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a = st_s[j], b = st_q[j];
+      a += __shfl_xor(a, 8, kWave); b += __shfl_xor(b, 8, kWave);
+      a += __shfl_xor(a, 16, kWave); b += __shfl_xor(b, 16, kWave);
+      a += __shfl_xor(a, 32, kWave); b += __shfl_xor(b, 32, kWave);
+      st_s[j] = a; st_q[j] = b;
+    }
+    lds_barrier();
+    float* red = (float*)smem;                                  // [WM][2][BN]
+    if (lane < 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        red[((wave / WN) * 2 + 0) * BN + wn0 + lane * 8 + j] = st_s[j];
+        red[((wave / WN) * 2 + 1) * BN + wn0 + lane * 8 + j] = st_q[j];
+      }
+    }
+    lds_barrier();
+    for (int i = tid; i < 2 * BN; i += kBfThreads) {
+      const int sidx = i / BN, cidx = i - sidx * BN;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) v += red[(w * 2 + sidx) * BN + cidx];
+      if (n0 + cidx < g.Cd) part[((int64_t)bx * 2 + sidx) * g.Cd + n0 + cidx] = v;
+    }
+  }
+}
+
+template <int WM, int WN, int TM, bool STATS, bool FOLD>
+__global__ __launch_bounds__(kBfThreads, 2) void conv_bf16_act_dma_kernel(const unsigned short* __restrict__ src, const unsigned short* __restrict__ wgt,
+                                                                          unsigned short* __restrict__ dst, ActGeo g, float* __restrict__ part, BfFuse fz) {
+  bf16_act_dma_body<WM, WN, TM, STATS, FOLD>(src, wgt, dst, g, part, fz, blockIdx.x, gridDim.x, blockIdx.y);
+}
+template <int WM, int WN, int TM>
+__global__ __launch_bounds__(kBfThreads, 2) void conv_bf16_act_dma_classes_kernel(const unsigned short* __restrict__ src, const unsigned short* __restrict__ wgt,
+                                                                                  unsigned short* __restrict__ dst, ActGeoSet gs) {
+  const ActGeo g = gs.g[blockIdx.z];
+  bf16_act_dma_body<WM, WN, TM, false, false>(src, wgt, dst, g, nullptr, BfFuse{}, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -607,6 +871,7 @@ template <bool STATS, bool FOLD>
 static int launch_bf16_act(const unsigned short* src, const unsigned short* wgt, unsigned short* dst, const ActGeo& g, float* part, int* nparts,
                            hipStream_t st, const BfFuse& fz = BfFuse{}) {
   const bool narrow = g.Cd <= 64;
+  const bool tapv = g.Cs % kBfBK != 0;
   const int BM = 128, BN = narrow ? 64 : 128;
   const int mtiles = (g.Mg + BM - 1) / BM, ntiles = (g.Cd + BN - 1) / BN;
   // grid: the column tiles of one m-tile are co-resident (and, gx a multiple of 8, on ONE XCD: the activation tile they share is fetched from
@@ -616,12 +881,21 @@ static int launch_bf16_act(const unsigned short* src, const unsigned short* wgt,
   if (STATS || FOLD) { if (gx > kCfMaxPart) gx = kCfMaxPart; }
   if (gx > mtiles) gx = mtiles;
   if (gx < 1) gx = 1;
-  const bool tapv = g.Cs % kBfBK != 0;
   LEC_CHECK_ARG(tapv || g.na * g.nb <= 32, "conv_bf16: more than 32 taps per launch need the per-piece tap path");
   LEC_CHECK_ARG(!(FOLD && tapv), "conv_bf16: the fold needs source channels that are a multiple of the K chunk (%d)", kBfBK);
   const size_t lds = (size_t)2 * (BM + BN) * kBfLdk * 2;
   const dim3 grid(gx, ntiles), blk(kBfThreads);
   ActGeo gg = g; gg.xcd_per = 0;
+  if (!tapv && tuning().bf_dma && g.Cs % kDmBK == 0) {
+    // the LDS-DMA ring: max(ring, epilogue image) bytes of LDS
+    const size_t ring = (size_t)kDmNS * (BM + BN) * 64, epi = (size_t)4 * (narrow ? 32 : 64) * kBfLdk * 2;
+    const size_t ldsd = ring > epi ? ring : epi;
+    if (narrow) hipLaunchKernelGGL((conv_bf16_act_dma_kernel<4, 1, 1, STATS, FOLD>), grid, blk, ldsd, st, src, wgt, dst, gg, part, fz);
+    else hipLaunchKernelGGL((conv_bf16_act_dma_kernel<2, 2, 2, STATS, FOLD>), grid, blk, ldsd, st, src, wgt, dst, gg, part, fz);
+    if (nparts) *nparts = gx;
+    LEC_CHECK_LAUNCH("conv_bf16_act_dma_kernel");
+    return LEC_OK;
+  }
   if constexpr (FOLD) {
     if (narrow) hipLaunchKernelGGL((conv_bf16_act_kernel<4, 1, 1, false, false, true>), grid, blk, lds, st, src, wgt, dst, gg, part, fz);
     else hipLaunchKernelGGL((conv_bf16_act_kernel<2, 2, 2, false, false, true>), grid, blk, lds, st, src, wgt, dst, gg, part, fz);
@@ -745,7 +1019,13 @@ extern "C" int lec_conv_bf16_dgrad(const void* dy, const void* wt, int N, int H,
     int cap = (512 / ntiles) & ~7; if (cap < 8) cap = 8;
     if (gx > cap) gx = cap;
     const size_t lds = (size_t)2 * (BM + BN) * kBfLdk * 2;
-    if (narrow) hipLaunchKernelGGL((conv_bf16_act_classes_kernel<4, 1, 1>), dim3(gx, ntiles, ncls), dim3(kBfThreads), lds, st, src, wg, dst, gs);
+    if (tuning().bf_dma) {
+      const size_t ring = (size_t)kDmNS * (BM + BN) * 64, epi = (size_t)4 * (narrow ? 32 : 64) * kBfLdk * 2;
+      const size_t ldsd = ring > epi ? ring : epi;
+      if (narrow) hipLaunchKernelGGL((conv_bf16_act_dma_classes_kernel<4, 1, 1>), dim3(gx, ntiles, ncls), dim3(kBfThreads), ldsd, st, src, wg, dst, gs);
+      else hipLaunchKernelGGL((conv_bf16_act_dma_classes_kernel<2, 2, 2>), dim3(gx, ntiles, ncls), dim3(kBfThreads), ldsd, st, src, wg, dst, gs);
+    }
+    else if (narrow) hipLaunchKernelGGL((conv_bf16_act_classes_kernel<4, 1, 1>), dim3(gx, ntiles, ncls), dim3(kBfThreads), lds, st, src, wg, dst, gs);
     else hipLaunchKernelGGL((conv_bf16_act_classes_kernel<2, 2, 2>), dim3(gx, ntiles, ncls), dim3(kBfThreads), lds, st, src, wg, dst, gs);
     LEC_CHECK_LAUNCH("conv_bf16_act_classes_kernel");
   }

@@ -67,8 +67,10 @@ __device__ __forceinline__ unsigned long long jl_realtime() { unsigned long long
 #define JL_ACC(acc, a, b)
 #endif
 
-// the launch owning the pair (a, b) of node codes: the window holding its image row (with two image rows -- negatives of trainers that do not pick per level --
-// the larger one: the caller then guarantees both rows are valid by the time that window's launch runs)
+// the launch owning the pair (a, b) of node codes: the window holding its image row.  CONTRACT of the windowed entry (include/lecone.h): a pair has AT MOST ONE
+// image end point -- or both image rows lie in the SAME window.  A pair of two image rows in different windows (negatives of a trainer that does not pick per
+// level) cannot be evaluated by any single window's launch (the other row is not addressable / not computed yet): the launch owning the larger row
+// POISONS the loss with a NaN instead of returning energies from a zero row (pair_splits_windows below).
 __device__ __forceinline__ bool pair_owned(const JointParams& P, int a, int b) {
   const int ra = a < 0 ? -1 - a : -1, rb = b < 0 ? -1 - b : -1;
   const int r = ra > rb ? ra : rb;
@@ -76,6 +78,9 @@ __device__ __forceinline__ bool pair_owned(const JointParams& P, int a, int b) {
 }
 __device__ __forceinline__ bool row_in_window(const JointParams& P, int code) {       // may this launch read / add to the row of node `code`?
   return code >= 0 || ((-1 - code) >= P.row_lo && (-1 - code) < P.row_hi);
+}
+__device__ __forceinline__ bool pair_splits_windows(const JointParams& P, int a, int b) {    // two image rows, not both inside this launch's window
+  return a < 0 && b < 0 && !(row_in_window(P, a) && row_in_window(P, b));
 }
 
 // One projected row held across T lanes: raw e (after the +1e-15 of Embedder.forward), projected p, and the two
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(512) void joint_loss_kernel(JointParams P_in) {
   if (pipelined) fetch_row<T, EPL>(P, code_a, t, raw_a);
   Row<EPL> U, V;
   load_project<T, EPL>(P, ucode, task_valid && row_in_window(P, ucode), t, U, nullptr);     // every lane needs u_b, v_b: broadcast loads
-  load_project<T, EPL>(P, vcode, task_valid && row_in_window(P, vcode), t, V, nullptr);     // (an image row outside this launch's window stays zeros: it may not exist yet)
+  load_project<T, EPL>(P, vcode, task_valid && row_in_window(P, vcode), t, V, nullptr);     // (an image row outside this launch's window stays zeros: it may not exist yet; no owned pair uses it -- pair_splits_windows)
   JL_STAMP(ck1);                                      // u_b, v_b gathered and projected
   for (int it = 0; it < P.iters; ++it) {
     JL_STAMP(ci0);
@@ -440,6 +445,7 @@ __global__ __launch_bounds__(512) void joint_loss_kernel(JointParams P_in) {
       for (int i = 0; i < EPL; ++i) { float m = fmaxf(x[i] - y[i], 0.0f); e += m * m; }
       E = group_sum<T>(e);
     }
+    if (valid && pair_splits_windows(P, kind == 2 ? ocode : ucode, kind == 1 ? ocode : vcode)) E = __builtin_nanf("");    // contract violation: loud, not silently wrong
     if (valid && t == 0) {
       if (q == 0) { P.e_pos[b] = E; lsum += w * E; }
       else {

@@ -139,7 +139,13 @@ class StepEngine:
         # oe_h.py:980-985,1003-1009).  Picked automatically when the whole batch would not fit.
         self.cnn_chunk = cnn_chunk
         if self.cnn_chunk is None and self.n_rows * per_row_gb > 240:
-            self.cnn_chunk = 512                       # the bench batch: every library convolution shape is in the shipped find-db
+            # Chunk size by measurement of the own kernels (round 6, config 5 = 7 424 rows, bf16, same box): 15 x 512 rows (256 padding rows) 603.8 ms,
+            # 16 x 464 587.6, 8 x 928 553.2 -- larger chunks amortise the per-chunk launch boundaries and fill the chip better, and a chunk size that
+            # DIVIDES the row count leaves no padding rows in the last chunk's BatchNorm batch.  Bounds: the 2 GiB tensor limit of the
+            # 32-bit offsets (bf16: 1 337 rows of ResNet-50 at 224 x 224) and ~50 GB of activations per chunk.
+            cap = 1024 if dtype != 'fp32' else min(512, max_rows_f32(hw))
+            divs = [d for d in range(cap, 255, -1) if self.n_rows % d == 0]
+            self.cnn_chunk = divs[0] if divs else min(cap, 512)
         # liblecone's fp32 convolutions address a tensor with 32-bit byte offsets (conv_geo.h conv_check): the largest activation of the
         # backbone (the stem's output, (hw/2)^2 x 64 floats per row) must stay below 2 GiB -- 668 rows of ResNet at 224 x 224
         rows_2g = max_rows_f32(hw)

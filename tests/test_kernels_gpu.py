@@ -888,6 +888,36 @@ def test_joint_loss_row_windows_add_up_to_the_whole_batch_launch(B, K, D, M, chu
     assert torch.equal(out2[0], p1) and torch.equal(out2[1], n1)
 
 
+def test_joint_loss_window_rejects_image_image_pairs_that_straddle_two_windows():
+    """The windowed entry's contract (include/lecone.h): a pair of TWO image rows in DIFFERENT windows cannot be evaluated by any single launch (the
+    other row is not there) -- the owning launch must answer NaN (that pair's energy and its loss), never a finite energy computed from a zero row; the same pair
+    with both rows inside ONE window is evaluated normally, bit for bit like the whole-batch launch."""
+    rs = np.random.RandomState(3)
+    N, M, D, B, K = 50, 64, 10, 8, 3
+    W = rs.randn(N, D).astype(np.float32); W *= (rs.uniform(0.1, 0.6, (N, 1)) / np.linalg.norm(W, axis=1, keepdims=True)).astype(np.float32)
+    R = (rs.randn(M, D) * 0.3).astype(np.float32)
+    Wt, Rt = T(W), T(R)
+    frm = torch.tensor(rs.randint(0, N, B), dtype=torch.int32, device=DEV)
+    to = torch.tensor(-1 - np.arange(B), dtype=torch.int32, device=DEV)                   # image rows 0 .. B-1 (first window)
+    neg = torch.tensor(rs.randint(0, N, (B, 2 * K)), dtype=torch.int32, device=DEV)
+    neg[:, :K] += (neg[:, :K] == frm[:, None]).int()
+    neg[2, K + 1] = -1 - 40                                                               # v-fixed negative of positive 2: (image row 40, image row 2)
+    l0, p0, n0 = ops.joint_loss_raw(Wt, Rt, frm, to, neg, None, 0.1, 1.5, 0, 1, 1)
+    assert torch.isfinite(l0).all() and torch.isfinite(n0).all()
+    # one window over everything: fine, identical
+    out = (torch.zeros(B, device=DEV), torch.zeros(B, 2 * K, device=DEV))
+    l1, _, _ = ops.joint_loss_raw(Wt, Rt, frm, to, neg, None, 0.1, 1.5, 0, 1, 1, window=(0, M, True), out=out)
+    assert torch.equal(out[1], n0) and abs(float(l1.item()) - float(l0.item())) <= 1e-5 * abs(float(l0.item()))
+    # two windows [0, 32) | [32, 64): rows 2 and 40 never meet
+    out = (torch.zeros(B, device=DEV), torch.zeros(B, 2 * K, device=DEV))
+    la, _, _ = ops.joint_loss_raw(Wt, Rt, frm, to, neg, None, 0.1, 1.5, 0, 1, 1, window=(0, 32, True), out=out)
+    lb, _, _ = ops.joint_loss_raw(Wt, Rt, frm, to, neg, None, 0.1, 1.5, 0, 1, 1, window=(32, 64, False), out=out)
+    assert torch.isfinite(la).all(), 'the first window owns none of the offending pair'
+    assert torch.isnan(lb).all() and torch.isnan(out[1][2, K + 1]), 'the launch owning the larger row must poison the pair, not invent an energy'
+    ok = torch.ones_like(out[1], dtype=torch.bool); ok[2, K + 1] = False
+    assert torch.equal(out[1][ok], n0[ok])
+
+
 def test_joint_loss_fixed_point_hand_off_equals_the_ticket_form_and_carries_nan():
     """Round 5: where the loss is bounded at launch (no per-positive weights, cone energies) every block hands its partial over as ONE 64-bit integer atomic
     (count in the top bits, llrint(partial * 2^F) below: integer addition does not depend on the order of arrival).  Against the ticket form (selected by passing
