@@ -456,6 +456,7 @@ def measure_classifier(args, dtype, rank, world, stamp):
             'mean_loss': round(float(eng.loss_acc.item()) / max(eng.step_no, 1), 4),
             'B': eng.B, 'arch': eng.arch, 'hw': eng.hw, 'n_classes': eng.labelmap.n_classes,
             'hbm_peak_allocated_gb': round(torch.cuda.max_memory_allocated() / 1e9, 1),
+            'library_conv_launches_per_step': sum((getattr(eng, 'library_conv_launches_per_step', None) or {'-': -1}).values()),
             'roofline': {'kernel': '%s fwd+bwd + MultiLevelCELoss + Adam (whole step; analytic conv/fc flops / step time)' % eng.arch, 'bound': 'mfma',
                          'achieved': round(flops / step_s / 1e12, 3), 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': round(flops / step_s / 1e12 / peak_tf, 5), 'traffic': None}}
 

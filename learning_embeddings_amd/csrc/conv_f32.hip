@@ -857,6 +857,18 @@ static int launch_act(const float* src, const float* wgt, float* dst, const ActG
 }
 
 
+
+// Batches whose tensors reach 2 GiB (32-bit byte offsets, conv_check) run as several launches over GROUPS of images: a convolution is independent per
+// image, so the entry points below hand each group its own base pointers (forward / data gradient: outputs of disjoint images; weight gradient: atomics
+// into the same slot; statistics / fold partials: consecutive rows of the caller's buffer, the BatchNorm finalize sums whatever rows it is given).
+// fp32 ResNet-50 at 224 x 224: 668 rows per launch -- the reference's own separate forwards of a step (B K = 1 280 / 2 560 rows at B = 256: oe_h.py:980-985,
+// 1003-1009, `reference_exact_batches`) used to fall back to the library silently.
+static inline int conv_group_images(int N, int64_t in_img_bytes, int64_t out_img_bytes) {
+  const int64_t lim = (1ll << 31) - 1;
+  const int64_t big = in_img_bytes > out_img_bytes ? in_img_bytes : out_img_bytes;
+  const int64_t gmax = big > 0 ? lim / big : N;
+  return (int)(gmax < 1 ? 0 : (gmax < N ? gmax : N));
+}
 }  // namespace lec
 
 // Scratch of the balanced forward / data-gradient kernel for the launches of ONE stream: `buf` holds lec_conv_f32_scratch_bytes() bytes, ZEROED
@@ -875,8 +887,8 @@ extern "C" int lec_conv_f32_scratch(lec_stream_t stream, void* buf, int64_t byte
   return LEC_OK;
 }
 
-extern "C" int lec_conv_f32_fwd(const float* x, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
-                                float* y, float* partials, int64_t partials_bytes, int* n_partials, int schedule, lec_stream_t stream) {
+static int conv_f32_fwd_one(const float* x, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                           float* y, float* partials, int64_t partials_bytes, int* n_partials, int schedule, lec_stream_t stream) {
   using namespace lec;
   if (int rc = conv_check("conv_f32_fwd", N, H, W, Cin, Cout, R, S, stride, pad)) return rc;
   LEC_CHECK_ARG(x && w && y, "conv_f32_fwd: null pointer");
@@ -899,8 +911,8 @@ extern "C" int lec_conv_f32_fwd(const float* x, const float* w, int N, int H, in
 
 // Forward with an eval-mode BatchNorm (+ residual, + ReLU) in the epilogue: y = [relu](conv(x, w) * scale[c] + shift[c] [+ res]) -- see ActFuse AFF.
 // scale / shift: Cout floats each (gamma / sqrt(running_var + eps), beta - running_mean * scale); res: null or a tensor of y's shape.
-extern "C" int lec_conv_f32_fwd_affine(const float* x, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
-                                       float* y, const float* scale, const float* shift, const float* res, int relu, int schedule, lec_stream_t stream) {
+static int conv_f32_fwd_affine_one(const float* x, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                                  float* y, const float* scale, const float* shift, const float* res, int relu, int schedule, lec_stream_t stream) {
   using namespace lec;
   if (int rc = conv_check("conv_f32_fwd_affine", N, H, W, Cin, Cout, R, S, stride, pad)) return rc;
   LEC_CHECK_ARG(x && w && y && scale && shift, "conv_f32_fwd_affine: null pointer");
@@ -918,8 +930,8 @@ extern "C" int lec_conv_f32_fwd_affine(const float* x, const float* w, int N, in
   return launch_act<true, false, 4>(x, w, y, g, nullptr, nullptr, (hipStream_t)stream, fz, kCfMaxPart, schedule);
 }
 
-extern "C" int lec_conv_f32_dgrad(const float* dy, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
-                                  float* dx, int schedule, lec_stream_t stream) {
+static int conv_f32_dgrad_one(const float* dy, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                             float* dx, int schedule, lec_stream_t stream) {
   using namespace lec;
   if (int rc = conv_check("conv_f32_dgrad", N, H, W, Cin, Cout, R, S, stride, pad)) return rc;
   LEC_CHECK_ARG(dy && w && dx, "conv_f32_dgrad: null pointer");
@@ -973,10 +985,10 @@ extern "C" int lec_conv_f32_dgrad(const float* dy, const float* w, int N, int H,
 //                xsrc with the per-channel coefficients coef[3][Cout] (lec_bn_bwd_coeffs_f32) while loading;
 //   xbn .. partials (all or none): the result is not dx but g = mask * (dx + dres), and the partial sums of pass 1 of the backward of
 //                the BatchNorm whose output this layer consumed are left in `partials` (n_partials rows of [2][Cin]).
-extern "C" int lec_conv_f32_dgrad_fused(const float* dy, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
-                                        float* dx, const float* xsrc, const float* coef, const float* dres, const float* xbn, const uint8_t* mask,
-                                        const float* mean, const float* invstd, float* partials, int64_t partials_bytes, int* n_partials,
-                                        int schedule, lec_stream_t stream) {
+static int conv_f32_dgrad_fused_one(const float* dy, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                                   float* dx, const float* xsrc, const float* coef, const float* dres, const float* xbn, const uint8_t* mask,
+                                   const float* mean, const float* invstd, float* partials, int64_t partials_bytes, int* n_partials,
+                                   int schedule, lec_stream_t stream) {
   using namespace lec;
   if (int rc = conv_check("conv_f32_dgrad_fused", N, H, W, Cin, Cout, R, S, stride, pad)) return rc;
   LEC_CHECK_ARG(dy && w && dx, "conv_f32_dgrad_fused: null pointer");
@@ -1029,8 +1041,8 @@ extern "C" int lec_conv_f32_wgrad_c3(const float* dy, const float* x4, int N, in
   return conv_f32_wgrad_impl(dy, x4, N, H, W, 4, Cout, R, S, stride, pad, dw3, nullptr, nullptr, 3, stream);
 }
 
-static int conv_f32_wgrad_impl(const float* dy, const float* x, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
-                               float* dw, const float* xsrc, const float* coef, int dCin, lec_stream_t stream) {
+static int conv_f32_wgrad_one(const float* dy, const float* x, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                              float* dw, const float* xsrc, const float* coef, int dCin, lec_stream_t stream) {
   using namespace lec;
   if (int rc = conv_check("conv_f32_wgrad", N, H, W, Cin, Cout, R, S, stride, pad)) return rc;
   LEC_CHECK_ARG(dy && x && dw, "conv_f32_wgrad: null pointer");
@@ -1128,4 +1140,80 @@ static int conv_f32_wgrad_impl(const float* dy, const float* x, int N, int H, in
   else hipLaunchKernelGGL((conv_f32_wgrad_kernel<2, 2, 1, 1, 32, true>), grid, blk, lds, st, dy, x, dw, g, nof, nof);
   LEC_CHECK_LAUNCH("conv_f32_wgrad_kernel");
   return LEC_OK;
+}
+
+// ---- exported entry points: one launch, or one per group of images when a tensor of the whole batch would reach 2 GiB
+#define LEC_CONV_GROUPS(who, in_c, out_c)                                                                                         \
+  const int64_t Ho_ = (H + 2 * pad - R) / stride + 1, Wo_ = (W + 2 * pad - S) / stride + 1;                                       \
+  const int64_t in_img = (int64_t)H * W * (in_c) * 4, out_img = Ho_ * Wo_ * (int64_t)(out_c) * 4;                                 \
+  const int G_ = N > 0 && H > 0 && W > 0 && Ho_ > 0 && Wo_ > 0 ? lec::conv_group_images(N, in_img, out_img) : N;                  \
+  LEC_CHECK_ARG(G_ > 0 || N <= 0, who ": one image of this layer reaches 2 GiB")
+
+extern "C" int lec_conv_f32_fwd(const float* x, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                                float* y, float* partials, int64_t partials_bytes, int* n_partials, int schedule, lec_stream_t stream) {
+  LEC_CONV_GROUPS("conv_f32_fwd", Cin, Cout);
+  if (G_ >= N) return conv_f32_fwd_one(x, w, N, H, W, Cin, Cout, R, S, stride, pad, y, partials, partials_bytes, n_partials, schedule, stream);
+  int rows = 0;
+  for (int n0 = 0; n0 < N; n0 += G_) {
+    const int n = N - n0 < G_ ? N - n0 : G_;
+    int k = 0;
+    const int64_t used = (int64_t)rows * 2 * Cout * (int64_t)sizeof(float);
+    if (int rc = conv_f32_fwd_one(x + n0 * (in_img / 4), w, n, H, W, Cin, Cout, R, S, stride, pad, y + n0 * (out_img / 4),
+                                  partials ? partials + (int64_t)rows * 2 * Cout : nullptr, partials ? partials_bytes - used : 0, partials ? &k : nullptr, schedule, stream)) return rc;
+    rows += k;
+  }
+  if (n_partials) *n_partials = rows;
+  return LEC_OK;
+}
+
+extern "C" int lec_conv_f32_fwd_affine(const float* x, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                                       float* y, const float* scale, const float* shift, const float* res, int relu, int schedule, lec_stream_t stream) {
+  LEC_CONV_GROUPS("conv_f32_fwd_affine", Cin, Cout);
+  for (int n0 = 0; n0 < N; n0 += (G_ > 0 ? G_ : N)) {
+    const int n = N - n0 < G_ ? N - n0 : G_;
+    if (int rc = conv_f32_fwd_affine_one(x + n0 * (in_img / 4), w, n, H, W, Cin, Cout, R, S, stride, pad, y + n0 * (out_img / 4), scale, shift,
+                                         res ? res + n0 * (out_img / 4) : nullptr, relu, schedule, stream)) return rc;
+  }
+  return N > 0 ? LEC_OK : conv_f32_fwd_affine_one(x, w, N, H, W, Cin, Cout, R, S, stride, pad, y, scale, shift, res, relu, schedule, stream);
+}
+
+extern "C" int lec_conv_f32_dgrad(const float* dy, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                                  float* dx, int schedule, lec_stream_t stream) {
+  LEC_CONV_GROUPS("conv_f32_dgrad", Cin, Cout);
+  for (int n0 = 0; n0 < N; n0 += (G_ > 0 ? G_ : N)) {
+    const int n = N - n0 < G_ ? N - n0 : G_;
+    if (int rc = conv_f32_dgrad_one(dy + n0 * (out_img / 4), w, n, H, W, Cin, Cout, R, S, stride, pad, dx + n0 * (in_img / 4), schedule, stream)) return rc;
+  }
+  return N > 0 ? LEC_OK : conv_f32_dgrad_one(dy, w, N, H, W, Cin, Cout, R, S, stride, pad, dx, schedule, stream);
+}
+
+extern "C" int lec_conv_f32_dgrad_fused(const float* dy, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                                        float* dx, const float* xsrc, const float* coef, const float* dres, const float* xbn, const uint8_t* mask,
+                                        const float* mean, const float* invstd, float* partials, int64_t partials_bytes, int* n_partials,
+                                        int schedule, lec_stream_t stream) {
+  LEC_CONV_GROUPS("conv_f32_dgrad_fused", Cin, Cout);
+  if (G_ >= N) return conv_f32_dgrad_fused_one(dy, w, N, H, W, Cin, Cout, R, S, stride, pad, dx, xsrc, coef, dres, xbn, mask, mean, invstd, partials, partials_bytes, n_partials, schedule, stream);
+  int rows = 0;
+  const int64_t mask_img = (int64_t)H * W * (Cin / 8);
+  for (int n0 = 0; n0 < N; n0 += G_) {
+    const int n = N - n0 < G_ ? N - n0 : G_;
+    int k = 0;
+    const int64_t used = (int64_t)rows * 2 * Cin * (int64_t)sizeof(float);
+    if (int rc = conv_f32_dgrad_fused_one(dy + n0 * (out_img / 4), w, n, H, W, Cin, Cout, R, S, stride, pad, dx + n0 * (in_img / 4), xsrc ? xsrc + n0 * (out_img / 4) : nullptr, coef,
+                                          dres ? dres + n0 * (in_img / 4) : nullptr, xbn ? xbn + n0 * (in_img / 4) : nullptr, mask ? mask + n0 * mask_img : nullptr, mean, invstd,
+                                          partials ? partials + (int64_t)rows * 2 * Cin : nullptr, partials ? partials_bytes - used : 0, partials ? &k : nullptr, schedule, stream)) return rc;
+    rows += k;
+  }
+  if (n_partials) *n_partials = rows;
+  return LEC_OK;
+}
+
+static int conv_f32_wgrad_impl(const float* dy, const float* x, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                               float* dw, const float* xsrc, const float* coef, int dCin, lec_stream_t stream) {
+  LEC_CONV_GROUPS("conv_f32_wgrad", Cin, Cout);
+  for (int n0 = 0; n0 < N; n0 += (G_ > 0 ? G_ : N)) {
+    const int n = N - n0 < G_ ? N - n0 : G_;
+    if (int rc = conv_f32_wgrad_one(dy + n0 * (out_img / 4), x + n0 * (in_img / 4), n, H, W, Cin, Cout, R, S, stride, pad, dw, xsrc ? xsrc + n0 * (out_img / 4) : nullptr, coef, dCin, stream)) return rc;
+  }
+  return N > 0 ? LEC_OK : conv_f32_wgrad_one(dy, x, N, H, W, Cin, Cout, R, S, stride, pad, dw, xsrc, coef, dCin, stream);
 }

@@ -658,6 +658,8 @@ class ClassifierEngine:
 
     def step(self):
         slot = self.step_no & 1
+        if self.step_no == 0:
+            resnet_mod.library_launches(reset=True)             # (step 0 is launched eagerly: its count is the step's)
         if self.pin_ev[slot] is not None:
             self.pin_ev[slot].synchronize()
         rs = np.random.RandomState(self.step_no * 7919 + self.rank)
@@ -689,6 +691,8 @@ class ClassifierEngine:
             self.exp.reducer.finish()
         self.exp.arena.adam_step(self.exp.lr, grad_scale=1.0 / self.world)
         self.loss_acc += loss
+        if self.step_no == 0:
+            self.library_conv_launches_per_step = dict(resnet_mod.library_launches())
         self.step_no += 1
         self.last = (loss, outputs)
         return loss

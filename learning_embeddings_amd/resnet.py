@@ -193,8 +193,8 @@ class WgradOverlap:
                 return
             if xf is not None:
                 gy = self._materialise(gy, xf)
-            if x.shape[1] != conv.in_channels:
-                x = x[:, :conv.in_channels]                     # (a zero-padded stem input)
+            if x.shape[1] != conv.in_channels:                  # (a zero-padded stem input: the library sees the layer's own 3 channels)
+                x = x[:, :conv.in_channels]; w16 = w16[:, :conv.in_channels]
             _lib_launch('wgrad')
             gw = torch.ops.aten.convolution_backward(gy, x, w16, None, conv.stride, conv.padding, conv.dilation, False,
                                                      [0, 0], conv.groups, [False, True, False])[1]
@@ -212,7 +212,8 @@ class WgradOverlap:
                 gy = self._materialise(gy, xf)
             if not own:
                 _lib_launch('wgrad')
-                gw = torch.ops.aten.convolution_backward(gy, x[:, :conv.in_channels] if x.shape[1] != conv.in_channels else x, w16, None, conv.stride, conv.padding,
+                pad_ = x.shape[1] != conv.in_channels
+                gw = torch.ops.aten.convolution_backward(gy, x[:, :conv.in_channels] if pad_ else x, w16[:, :conv.in_channels] if pad_ else w16, None, conv.stride, conv.padding,
                                                          conv.dilation, False, [0, 0], conv.groups, [False, True, False])[1]
             for t in (gy, x, w16):
                 t.record_stream(self.side)                 # the caching allocator must not recycle them under the side stream
@@ -301,13 +302,18 @@ def _f32_conv_ok(conv):
 
 
 def _f32_conv_fits(conv, x):
-    """lec_conv_f32_* address a tensor with 32-bit byte offsets (conv_geo.h conv_check): input and output must stay below 2 GiB
-    (ResNet at 224 x 224 in fp32: 668 rows).  Larger batches take the library convolution (or are chunked by the caller: engine.cnn_chunk)."""
+    """lec_conv_f32_* address a tensor with 32-bit byte offsets: one launch serves the images whose input and output stay below 2 GiB (ResNet at 224 x 224 in
+    fp32: 668 rows), and the entry points split a larger batch into groups of images themselves (csrc/conv_f32.hip, LEC_CONV_GROUPS) -- up to four groups:
+    the statistics / fold partials of all groups share the BatchNorm workspace's 2 048 rows.  The split (x3) mode has no group form: one launch only."""
     n, c, h, w = x.shape
     c = max(c, 4)
     k, st, pd = conv.kernel_size[0], conv.stride[0], conv.padding[0]
     ho, wo = (h + 2 * pd - k) // st + 1, (w + 2 * pd - k) // st + 1
-    return n * h * w * c * 4 < (1 << 31) and n * ho * wo * conv.out_channels * 4 < (1 << 31)
+    per_img = max(h * w * c * 4, ho * wo * conv.out_channels * 4)
+    g = ((1 << 31) - 1) // max(per_img, 1)
+    if g < 1:
+        return False
+    return -(-n // g) <= (1 if F32_MODE == 'x3' else 4)
 
 
 def _pad_c4(t):

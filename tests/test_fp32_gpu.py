@@ -965,3 +965,50 @@ def test_six_forwards_before_any_backward_keep_their_own_fusion_context():
         del held
     finally:
         WgradOverlap.instance = None
+
+
+def test_conv_f32_batches_beyond_two_gib_run_as_image_groups_on_the_own_kernels():
+    """lec_conv_f32_* with tensors of 2 GiB and more (such batches -- the reference's own B K-row forwards, oe_h.py:980-985, 1003-1009 -- used to fall
+    back to the library silently): the entry points split the batch into groups of images.  A convolution is independent per image, so the result must EQUAL, bit
+    for bit, the two halves run as separate calls; the statistics partials of all groups add up to the sums over the whole output; the weight gradient to the sum
+    of the halves'."""
+    g = torch.Generator(device='cpu').manual_seed(3)
+    N, Cin, H, W, Cout = 10, 64, 224, 224, 64                      # input 10 x 12.8 MB ... small; force groups with a large pixel count instead
+    N, Cin, H, W, Cout, R, st, pd = 44, 64, 224, 224, 256, 1, 1, 0  # output 44 x 224 x 224 x 256 x 4 B = 2.26 GiB: 41 images per launch
+    x = _cl(torch.randn(N, Cin, H, W, generator=g)); w = _cl(torch.randn(Cout, Cin, R, R, generator=g) / 8.0)
+    assert N * H * W * Cout * 4 >= (1 << 31)
+    y = ops.conv_f32_fwd(x, w, st, pd, want_stats=True)
+    k = ops._BN_WS_OWNER[1]; ops._BN_WS_OWNER[0] = 0
+    part = ops._bn_workspace(x.device).view(torch.float32)[:k * 2 * Cout].view(k, 2, Cout).double().sum(0)
+    ya = ops.conv_f32_fwd(x[:41].contiguous(memory_format=torch.channels_last), w, st, pd)
+    yb = ops.conv_f32_fwd(x[41:].contiguous(memory_format=torch.channels_last), w, st, pd)
+    assert torch.equal(y[:41], ya) and torch.equal(y[41:], yb)
+    assert torch.allclose(part[0], y.double().sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-2) and torch.allclose(part[1], (y.double() ** 2).sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-2)
+    del ya, yb
+    dy = y; dy.normal_(generator=None)
+    dx = ops.conv_f32_dgrad(dy, w, x.shape, st, pd)
+    dxa = ops.conv_f32_dgrad(dy[:41].contiguous(memory_format=torch.channels_last), w, (41, Cin, H, W), st, pd)
+    assert torch.equal(dx[:41], dxa)
+    del dx, dxa
+    dw = torch.zeros_like(w); ops.conv_f32_wgrad(dy, x, dw, st, pd)
+    dwa = torch.zeros_like(w); ops.conv_f32_wgrad(dy[:41].contiguous(memory_format=torch.channels_last), x[:41].contiguous(memory_format=torch.channels_last), dwa, st, pd)
+    dwb = torch.zeros_like(w); ops.conv_f32_wgrad(dy[41:].contiguous(memory_format=torch.channels_last), x[41:].contiguous(memory_format=torch.channels_last), dwb, st, pd)
+    assert (dw - (dwa + dwb)).abs().max().item() <= 1e-4 * dw.abs().max().item()
+
+
+def test_resnet_fp32_forward_backward_above_668_rows_launches_no_library_convolution():
+    """A 700-row fp32 forward + backward of ResNet-18 at 224 x 224 (the stem's output alone is 2.25 GB): every convolution runs on liblecone's kernels -- the
+    library-launch counter of resnet.py stays at zero -- and the result is finite."""
+    from learning_embeddings_amd import resnet as R
+    torch.manual_seed(0)
+    from learning_embeddings_amd import parallel
+    net = resnet18(10).to(DEV).to(memory_format=torch.channels_last).train()
+    arena = parallel.FlatArena(net.parameters(), DEV)               # (as every trainer / engine has: gradients land in the arena's fp32 slots)
+    ov = WgradOverlap(None, arena, side_stream=False); net.wgrad_overlap = ov
+    x = _cl(torch.rand(700, 3, 224, 224))
+    R.library_launches(reset=True)
+    out = net(x)
+    out.square().mean().backward()
+    torch.cuda.synchronize()
+    assert R.library_launches() == {'fwd': 0, 'dgrad': 0, 'wgrad': 0}, R.library_launches()
+    assert torch.isfinite(out).all() and all(torch.isfinite(p.grad).all() for p in net.parameters())

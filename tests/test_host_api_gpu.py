@@ -131,6 +131,7 @@ def test_config4_full_size_step_resnet50_b512(dtype):
         assert abs(float(loss) - ol) <= 2e-4 * ol, (s, float(loss), ol)
         losses.append(float(l))
     assert eng.hip_graph is not None, eng.graph_error
+    assert sum(eng.library_conv_launches_per_step.values()) == 0, eng.library_conv_launches_per_step
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
 
 
@@ -472,6 +473,7 @@ def _engine_vs_oracle(eng, n_images, steps=2, check_table=True):
     for s in range(steps):
         W0 = eng.table.cpu().numpy().copy()
         eng.step(); torch.cuda.synchronize()
+        assert sum(eng.library_conv_launches_per_step.values()) == 0, ('a convolution of this step went to a library', eng.library_conv_launches_per_step)
         got = {'f': eng.last_feats.float().cpu().numpy()}                   # the raw CNN outputs of THIS step (static buffer under replay)
         loss, e_pos, e_neg, frm, to, neg = eng.last
         assert np.array_equal(neg, smp.draw_batch(frm, to, eng.K)), 'negatives differ from the reference stream at step %d' % s
@@ -557,6 +559,7 @@ def test_config5_as_stated_b256_k256_fp16_table_chunked_cnn(dtype):
     assert eng.cnn_chunk is not None and eng.table_h is not None
     W16 = eng.table_h.float().cpu().numpy().copy()
     eng.step(); torch.cuda.synchronize()
+    assert sum(eng.library_conv_launches_per_step.values()) == 0, ('config 5: a convolution went to a library', eng.library_conv_launches_per_step)
     loss, e_pos, e_neg, frm, to, neg = eng.last
     B, N = eng.B, eng.N
     cols = np.asarray(eng.img_passes)
