@@ -20,12 +20,38 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def self_launch(n, script=None, argv=None, extra_env=None):
+def count_gpus_no_hip():
+    """GPUs visible to this process WITHOUT initialising HIP (no torch import, no hipGetDeviceCount): the launcher parent's only job is to spawn the ranks,
+    and a process that has touched the GPU must never be the one that execs / forks GPU programs on this pool.  Sources, in order: the visibility
+    variables (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES: a comma list), else the KFD topology in sysfs (a node with simd_count > 0
+    is a GPU; CPU nodes have 0).  Returns None when neither says anything."""
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(',') if t.strip() != ''])
+    root = os.environ.get('LEC_KFD_TOPOLOGY', '/sys/class/kfd/kfd/topology/nodes')
+    try:
+        n = 0
+        for node in sorted(os.listdir(root)):
+            try:
+                props = open(os.path.join(root, node, 'properties')).read()
+            except OSError:
+                continue
+            for line in props.splitlines():
+                f = line.split()
+                if len(f) == 2 and f[0] == 'simd_count' and int(f[1]) > 0:
+                    n += 1
+        return n
+    except OSError:
+        return None
+
+
+def self_launch(n, script=None, argv=None, extra_env=None, timeout=None):
     """`python bench.py --gpus N` with no torchrun environment: start the N ranks ourselves, the way the reference goes multi-GPU
-    from one plain command (oe_h.py:301,1434: nn.DataParallel inside `python oe_h.py ...`).  The caller has made NO GPU call yet (this
-    runs before torch / the HIP library are even imported): the ranks are CHILD processes of `python -m torch.distributed.run`, never
-    an exec of a process that touched the GPU.  Rank 0's single JSON line reaches stdout through the inherited descriptor; the exit
-    code is the launcher's (non-zero if any rank failed)."""
+    from one plain command (oe_h.py:301,1434: nn.DataParallel inside `python oe_h.py ...`).  This parent makes NO GPU call and never imports
+    torch (count_gpus_no_hip reads sysfs / the visibility variables; tests/test_host_cpu.py asserts 'torch' not in sys.modules at the spawn): the ranks
+    are CHILD processes of `python -m torch.distributed.run`, never an exec of a process that touched the GPU.  Rank 0's single JSON line reaches stdout
+    through the inherited descriptor; the exit code is the launcher's (non-zero if any rank failed)."""
     import socket, subprocess
     with socket.socket() as s_:
         s_.bind(('127.0.0.1', 0)); port = s_.getsockname()[1]
@@ -35,18 +61,88 @@ def self_launch(n, script=None, argv=None, extra_env=None):
         env.pop(k, None)
     if 'LEC_DIST_BACKEND' not in env and not env.get('LEC_BENCH_NO_GPU_PROBE'):
         # fewer GPUs on the box than ranks asked for (a 1-GPU test box): RCCL refuses two ranks on one device, gloo reduces device tensors
-        try:
-            import torch
-            n_dev = torch.cuda.device_count()                   # (on ROCm this calls hipGetDeviceCount; harmless here: the ranks are fresh CHILD processes, nothing is exec'd)
-        except Exception:                                       # noqa: BLE001
-            n_dev = n
-        if 0 < n_dev < n:
+        n_dev = count_gpus_no_hip()
+        if n_dev is not None and 0 < n_dev < n:
             env['LEC_DIST_BACKEND'] = 'gloo'
             print('[bench] %d ranks on %d GPU(s): ranks share devices, gradient exchange over gloo (LEC_DIST_BACKEND=gloo)' % (n, n_dev), file=sys.stderr, flush=True)
+    assert 'torch' not in sys.modules, 'the launcher parent must not import torch (it would initialise HIP in a process that only spawns children)'
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
            '--master-port', str(port), script or os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
     print('[bench] starting %d ranks: %s' % (n, ' '.join(cmd)), file=sys.stderr, flush=True)
-    return subprocess.run(cmd, env=env).returncode
+    if os.environ.get('LEC_BENCH_DRY_LAUNCH'):                  # tests: everything but the spawn
+        print(json.dumps({'dry_launch': cmd, 'dist_backend': env.get('LEC_DIST_BACKEND'), 'torch_imported': 'torch' in sys.modules}))
+        return 0
+    try:
+        return subprocess.run(cmd, env=env, timeout=timeout).returncode
+    except subprocess.TimeoutExpired:
+        print('[bench] the %d-rank run did not finish within %s s: killed' % (n, timeout), file=sys.stderr, flush=True)
+        return 124
+
+
+def self_launch_compare_exchange(n):
+    """`python bench.py --gpus N` on a box with >= N devices: the standard run (torch.distributed's RCCL all-reduce, one sweep after the graph replay), then -- in
+    FRESH child processes, under a timeout, after the first result is safely in hand -- the same run with liblecone's own RCCL layer captured into the step graph
+    (LEC_DP_BACKEND=lecone: never exercised on N real devices before; DESIGN.md section 7 could only estimate the difference).  ONE JSON line: the standard
+    run's, plus `exchange_comparison`.  A second run that fails or hangs costs its timeout and is reported as such; the headline line is untouched."""
+    import subprocess
+    def run(extra_env, timeout):
+        import socket
+        with socket.socket() as s_:
+            s_.bind(('127.0.0.1', 0)); port = s_.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'); env.update(extra_env)
+        for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+            env.pop(k, None)
+        assert 'torch' not in sys.modules
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1', '--master-port', str(port),
+               os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != '--compare-exchange']
+        try:
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=timeout)
+        except subprocess.TimeoutExpired:
+            return 124, None
+        line = next((l for l in reversed(r.stdout.splitlines()) if l.startswith('{')), None)
+        return r.returncode, (json.loads(line) if line else None)
+    rc, main = run({}, None)
+    if rc != 0 or main is None:
+        if main is not None:
+            print(json.dumps(main), flush=True)
+        return rc or 1
+    pick = lambda d: {'value': d['value'], 'ms_per_step': d['ms_per_step'], 'allreduce_exposed_ms': d.get('allreduce_exposed_ms'),
+                      'exchange': (d.get('data_parallel') or {}).get('exchange'), 'rccl_ranks': d.get('rccl_ranks')}
+    cmp_ = {'torch_distributed': pick(main)}
+    rc2, alt = run({'LEC_DP_BACKEND': 'lecone'}, 900)
+    cmp_['lecone_captured'] = pick(alt) if (rc2 == 0 and alt is not None) else {'error': 'exit code %d%s' % (rc2, ' (timeout)' if rc2 == 124 else '')}
+    main['exchange_comparison'] = cmp_
+    print(json.dumps(main), flush=True)
+    return 0
+
+
+def start_watchdog(limit_s, what):
+    """A rank that is still inside `what` after limit_s seconds (a collective that never completes, a rank that died and left the others waiting) prints
+    where it is and EXITS non-zero (os._exit: no destructors that could wait on the GPU again) -- instead of holding the box until the driver's limit.
+    Fresh child processes only; nothing is re-executed.  Returns a function that disarms it."""
+    import threading
+    done = threading.Event()
+    def run():
+        if not done.wait(limit_s):
+            print('[bench] WATCHDOG: rank %s still in "%s" after %d s -- exiting 3' % (os.environ.get('RANK', '0'), what, limit_s), file=sys.stderr, flush=True)
+            os._exit(3)
+    threading.Thread(target=run, daemon=True).start()
+    return done.set
+
+
+def device_bus_id(dev):
+    """PCI bus id of a torch device ('0000:c1:00.0'), through the HIP runtime torch has loaded (hipDeviceGetPCIBusId); falls back to the device's UUID / index."""
+    import ctypes, torch
+    idx = dev.index if getattr(dev, 'index', None) is not None else torch.cuda.current_device()
+    try:
+        hip = ctypes.CDLL('libamdhip64.so')
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(idx)) == 0:
+            return buf.value.decode()
+    except OSError:
+        pass
+    p = torch.cuda.get_device_properties(idx)
+    return str(getattr(p, 'uuid', None) or getattr(p, 'pci_bus_id', None) or idx)
 
 
 def cone_traffic(B, K, D, N):
@@ -159,10 +255,17 @@ def measure(args, dtype, rank, world, stamp, primary):
                      use_graph=args.launch != 'eager', passes=args.passes, table_dtype=table_dtype, cnn_chunk=args.cnn_chunk)
     dev = eng.device
     stamp('%s: engine built' % dtype)
+    # (a watchdog over the warm-up too: the first collective of an N-rank run happens here)
+    disarm_w = start_watchdog(900.0, 'warm-up (%s)' % dtype) if world > 1 else (lambda: None)
+    warm_ms_per_step = 0.0
     for i in range(args.warmup):
+        t_w0 = time.perf_counter()
         eng.step()
         if i < 2:
             torch.cuda.synchronize(); stamp('%s: warm-up step %d done' % (dtype, i))
+            if i == 1:
+                warm_ms_per_step = (time.perf_counter() - t_w0) * 1e3
+    disarm_w()
     while ((eng.use_graph and eng.hip_graph is None) or (eng.use_chunk_graph and eng.chunk_graph is None)) and eng.graph_error is None:
         eng.step()                                              # fewer warm-up steps than the capture needs: finish them untimed
     launch_probe = None
@@ -201,6 +304,8 @@ def measure(args, dtype, rank, world, stamp, primary):
     auto_eager = launch_probe is not None and launch_probe['chosen'] == 'eager'
     if auto_eager:
         eng.kernel_timers(False)                                # per-kernel events only in the probe steps after the timed region
+    # a multi-rank run that stops making progress (a collective that never completes) exits non-zero instead of holding the box: generous bound from the warm-up
+    disarm = start_watchdog(max(300.0, 60.0 + 20.0 * args.steps * max(warm_ms_per_step, 1.0) / 1e3), 'timed region (%s)' % dtype) if world > 1 else (lambda: None)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -215,6 +320,7 @@ def measure(args, dtype, rank, world, stamp, primary):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    disarm()
     host_busy_s = host_s - eng.host_wait_s
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -239,7 +345,18 @@ def measure(args, dtype, rank, world, stamp, primary):
     dp_info = None
     if eng.reducer.enabled:
         one = torch.ones(1, device=dev); dist.all_reduce(one)
+        # which physical device every rank sits on: PCI bus ids gathered over the group; with as many devices on the box as ranks they must all differ
+        # (two ranks on one device would still add up to `world` in the collective above)
+        bus = device_bus_id(dev)
+        ids = [None] * world
+        dist.all_gather_object(ids, (rank, int(os.environ.get('LOCAL_RANK', 0)), bus))
+        print('[bench] rank %d local_rank %s device %s pci %s' % (rank, os.environ.get('LOCAL_RANK', '0'), dev, bus), file=sys.stderr, flush=True)
+        n_box = torch.cuda.device_count()
+        distinct = len({b for _, _, b in ids})
+        if rank == 0 and n_box >= world:
+            assert distinct == world, 'ranks share a device although the box has %d: %s' % (n_box, ids)
         dp_info = {'rccl_ranks': int(one.item()), 'world_size': dist.get_world_size(), 'backend': dist.get_backend(),
+                   'devices_on_box': n_box, 'distinct_devices': distinct, 'rank_devices': [list(t) for t in ids],
                    'exchange': ('liblecone RCCL layer (lec_dp_allreduce_sum), captured into the step graph' if eng.reducer.comm is not None
                                 else 'torch.distributed all-reduce: per-bucket from backward hooks (eager launches) / after the replay (hipGraph)'),
                    'buckets': eng.reducer.time_buckets(), 'replicas_identical_after_run': replicas_identical}
@@ -670,6 +787,7 @@ def main():
     ap.add_argument('--passes', type=int, default=None, help='concurrent parts the CNN rows of a step go through the backbone in (default: 2 at fp32 -- positives | image negatives, one stream each -- 1 at bf16)')
     ap.add_argument('--check-replicas', action='store_true', help='(default at N > 1) after the run, assert that every rank holds identical parameters')
     ap.add_argument('--no-check-replicas', action='store_true', help='skip the replica comparison at N > 1')
+    ap.add_argument('--compare-exchange', action='store_true', help='(plain `python bench.py --gpus N` on a box with >= N devices) run twice: torch.distributed exchange, then liblecone\'s RCCL layer captured into the graph; one JSON line with `exchange_comparison`')
     ap.add_argument('--launch', default='graph', choices=['auto', 'graph', 'eager'],
                     help='how the kernels of forward+loss+backward reach the GPU: graph = replay the captured hipGraph; eager = launch each one; '
                          'auto = probe both on this box during warm-up and keep the faster for the timed steps.  Default graph: with the two concurrent '
@@ -682,7 +800,10 @@ def main():
     if args.no_graph:
         args.launch = 'eager'
     if args.gpus > 1 and 'LOCAL_RANK' not in os.environ and int(os.environ.get('WORLD_SIZE', '1')) == 1:
-        sys.exit(self_launch(args.gpus))                        # nothing has touched the GPU yet
+        n_dev = count_gpus_no_hip()
+        if args.compare_exchange and n_dev is not None and n_dev >= args.gpus and not os.environ.get('LEC_BENCH_DRY_LAUNCH'):
+            sys.exit(self_launch_compare_exchange(args.gpus))   # both gradient-exchange forms, each in fresh children
+        sys.exit(self_launch(args.gpus))                        # nothing has touched the GPU yet (nor imported torch)
     from learning_embeddings_amd import resnet as _resnet
     _resnet.F32_MODE = args.conv_f32
 

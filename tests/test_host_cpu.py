@@ -389,6 +389,42 @@ def test_bench_self_launch_starts_the_ranks_as_children(tmp_path):
     assert bad.returncode != 0
 
 
+def test_bench_launcher_parent_counts_gpus_without_torch_and_never_imports_it(tmp_path):
+    """the parent of `python bench.py --gpus N` only spawns children -- it must not initialise HIP.  It counts GPUs from the visibility
+    variables or the KFD topology in sysfs (count_gpus_no_hip), picks gloo when the ranks outnumber the devices, and 'torch' is not in sys.modules at the spawn
+    (self_launch asserts it; the dry-launch record says so)."""
+    import subprocess
+    topo = tmp_path / 'nodes'
+    for i, simd in enumerate([0, 0, 1024, 1024, 1024]):          # two CPU nodes, three GPUs
+        (topo / str(i)).mkdir(parents=True)
+        (topo / str(i) / 'properties').write_text('cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n' % (64 if simd == 0 else 0, simd))
+    code = ('import sys, json; sys.path.insert(0, %r); import bench\n'
+            'print(json.dumps({"n": bench.count_gpus_no_hip(), "torch": "torch" in sys.modules}))\n'
+            'sys.exit(bench.self_launch(4, script="x.py", argv=["--gpus", "4"]))' % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES', 'LEC_DIST_BACKEND')}
+    env.update(LEC_KFD_TOPOLOGY=str(topo), LEC_BENCH_DRY_LAUNCH='1')
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    recs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{')]
+    assert recs[0] == {'n': 3, 'torch': False}
+    assert recs[1]['torch_imported'] is False and recs[1]['dist_backend'] == 'gloo'          # 4 ranks on 3 devices: they share, gloo reduces
+    assert recs[1]['dry_launch'][1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in recs[1]['dry_launch']
+    env['HIP_VISIBLE_DEVICES'] = '0,1,2,3,4,5,6,7'                  # the visibility variable wins over the topology
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120, env=env)
+    recs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{')]
+    assert recs[0]['n'] == 8 and recs[1]['dist_backend'] is None and recs[1]['torch_imported'] is False
+
+
+def test_bench_watchdog_exits_nonzero_when_a_region_never_finishes():
+    """#5(d): a rank stuck in a region (a collective that never completes) exits 3 by itself; a region that finishes disarms the watchdog."""
+    import subprocess
+    code = ('import sys, time; sys.path.insert(0, %r); import bench\n'
+            'd = bench.start_watchdog(0.3, "ok region"); d(); time.sleep(0.6)\n'
+            'bench.start_watchdog(0.3, "stuck region"); time.sleep(30)' % ROOT)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3 and 'WATCHDOG' in r.stderr and 'stuck region' in r.stderr and 'ok region' not in r.stderr
+
+
 def test_conv_macs_matches_the_analytic_resnet_figures():
     """resnet.conv_macs (the denominator of bench.py's whole-CNN roofline line): SURVEY.md 8(d) quotes 1.8136 GMAC (ResNet-18) and 4.0872 GMAC
     (ResNet-50) per forward at 224 x 224, convolutions + the classifier's 1000-way fc excluded / included as the walk finds it."""
