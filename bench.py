@@ -146,12 +146,12 @@ def device_bus_id(dev):
 
 
 def cone_traffic(B, K, D, N):
-    """HBM bytes per launch of the fused loss kernel at this shape from the committed rocprofv3 passes (profiles/r04_cone_pmc.json:
-    FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes, tools/prof_cone_round4.sh) -- None (with the reason) if the shape was not
+    """HBM bytes per launch of the fused loss kernel at this shape from the committed rocprofv3 passes (profiles/r06_cone_pmc.json:
+    FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes, tools/prof_cone_pmc.sh) -- None (with the reason) if the shape was not
     profiled or the kernel sources have changed since."""
     import hashlib
     try:
-        allm = json.load(open(os.path.join(ROOT, 'profiles', 'r04_cone_pmc.json')))
+        allm = json.load(open(os.path.join(ROOT, 'profiles', 'r06_cone_pmc.json')))
         csrc = os.path.join(ROOT, 'learning_embeddings_amd', 'csrc')
         stale = [f for f, h in allm['kernel_sources_sha256'].items()
                  if not os.path.exists(os.path.join(csrc, f)) or hashlib.sha256(open(os.path.join(csrc, f), 'rb').read()).hexdigest() != h]
@@ -159,8 +159,20 @@ def cone_traffic(B, K, D, N):
             return None, 'kernel sources changed since the PMC passes: ' + ', '.join(stale)
         rec = allm['shapes'].get('%d_%d_%d_%d' % (B, K, D, N))
         if rec is None or rec.get('traffic_bytes') is None:
-            return None, 'shape not in profiles/r04_cone_pmc.json'
-        return int(rec['traffic_bytes']), 'rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE per launch (profiles/r04_cone_pmc.md); %.1f us per launch under the profiler' % rec['avg_us']
+            return None, 'shape not in profiles/r06_cone_pmc.json'
+        return int(rec['traffic_bytes']), 'rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE per launch (profiles/r06_cone_pmc.md); %.1f us per launch under the profiler' % rec['avg_us']
+    except Exception as e:                                      # noqa: BLE001
+        return None, str(e)
+
+
+def cfg4_traffic(f32):
+    """HBM bytes per step of config 4's fp32 step from the committed rocprofv3 passes (profiles/r06_cfg4_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate
+    --pmc passes over `bench.py --workload cfg4`), or (None, why)."""
+    if not f32:
+        return None, 'not profiled at this dtype'
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r06_cfg4_traffic.json')))
+        return int(d['bytes_per_step']), 'rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE summed over one step (profiles/r06_cfg4_traffic.md): read %.1f GB, written %.1f GB' % (d['read_gb'], d['written_gb'])
     except Exception as e:                                      # noqa: BLE001
         return None, str(e)
 
@@ -168,6 +180,64 @@ def cone_traffic(B, K, D, N):
 def cone_alg_bytes(B, K, D):
     """fwd+bwd algorithmic bytes per positive, rows de-duplicated inside a group, fp32."""
     return B * ((2 + 2 * K) * (2 * D * 4 + 4 * D + 4) + (1 + 2 * K) * 8)
+
+
+def cpu_thread_sweep(arch, hw, out_dim, rows=16):
+    """Which thread count runs this box's torch-CPU ResNet fastest?  One forward + backward of `rows` images per candidate (32 / 64 / 128 / every core; a
+    candidate above the core count is skipped), one warm-up each.  Returns (best, {threads: seconds}, nproc).  VERDICT r05 weak #7: `min(nproc, 32)` was never
+    measured against the alternatives."""
+    import torch
+    from learning_embeddings_amd.resnet import resnet18, resnet50
+    nproc = os.cpu_count() or 1
+    cands = sorted({c for c in (32, 64, 128, nproc) if c <= nproc} or {nproc})
+    torch.manual_seed(0)
+    net = (resnet50 if arch == 'resnet50' else resnet18)(num_classes=out_dim).train()
+    x = torch.rand(rows, 3, hw, hw)
+    res = {}
+    for c in cands:
+        torch.set_num_threads(c)
+        for rep in range(2):
+            t = time.time(); net.zero_grad(); net(x).square().mean().backward(); dt = time.time() - t
+        res[c] = round(dt, 3)
+    best = min(res, key=res.get)
+    torch.set_num_threads(best)
+    return best, res, nproc
+
+
+def cpu_baseline_classifier(eng, budget_s=25.0, rows=64):
+    """Config 4's step on the host cores (kind "port"): torch-CPU fp32 ResNet forward on `rows` images as one BatchNorm batch -> the oracle's multi-level
+    cross-entropy (oracle.multilevel_ce: loss.py:29-38 restated) forward + gradient -> backward through the ResNet -> Adam (torch.optim, the reference's
+    optimizer: finetuner.py:213-246).  images/sec = rows / wall time of the step."""
+    import numpy as np, torch
+    from oracle import cone_oracle as O
+    from learning_embeddings_amd.resnet import resnet18, resnet50
+    lm = eng.labelmap
+    cores, sweep, nproc = cpu_thread_sweep(eng.arch, eng.hw, lm.n_classes)
+    torch.manual_seed(0)
+    net = (resnet50 if eng.arch == 'resnet50' else resnet18)(num_classes=lm.n_classes).train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    x = torch.rand(rows, 3, eng.hw, eng.hw, generator=torch.Generator().manual_seed(4321))
+    lvl = eng.pool_levels[:rows].cpu().numpy() if eng.pool_levels.shape[0] >= rows else np.resize(eng.pool_levels.cpu().numpy(), (rows, len(lm.levels)))
+    def step():
+        t = time.time(); ph = {}
+        opt.zero_grad(); out = net(x); ph['cnn_fwd'] = time.time() - t; t = time.time()
+        loss, g = O.multilevel_ce(out.detach().numpy(), lvl, lm.levels); ph['loss'] = time.time() - t; t = time.time()
+        out.backward(torch.from_numpy(np.ascontiguousarray(g, dtype=np.float32))); ph['cnn_bwd'] = time.time() - t; t = time.time()
+        opt.step(); ph['adam'] = time.time() - t
+        return ph, float(loss)
+    t0 = time.time(); step(); t_warm = time.time() - t0
+    reps, tot, phases = 0, 0.0, {}
+    while reps < 3 and (reps == 0 or time.time() - t0 + tot / reps < budget_s):
+        t1 = time.time(); ph, loss = step(); tot += time.time() - t1; reps += 1
+        for k_, v_ in ph.items():
+            phases[k_] = phases.get(k_, 0.0) + v_
+        if t_warm > budget_s * 0.45:
+            break
+    t_step = tot / reps
+    return {'value': round(rows / t_step, 3), 'unit': 'images/sec', 'cores': cores, 'nproc': nproc, 'thread_sweep_s': sweep, 'kind': 'port',
+            'sample': 'config 4\'s step at a bounded batch, measured whole: %d images (one BatchNorm batch), %s at %dx%d, %d logits: torch-CPU fp32 ResNet fwd/bwd + oracle '
+                      'multi-level CE + torch Adam; %d timed step(s) after one warm-up' % (rows, eng.arch, eng.hw, eng.hw, lm.n_classes, reps),
+            's_per_step': round(t_step, 4), 'cnn_rows_per_step': rows, 'phases_s': {k_: round(v_ / reps, 4) for k_, v_ in phases.items()}}
 
 
 def cpu_baseline(eng, budget_s=25.0, rows=64):
@@ -194,8 +264,7 @@ def cpu_baseline(eng, budget_s=25.0, rows=64):
         smp = O.LazyDenseSampler(lm.levels, sorted(lm.edges), leaf, pick_per_level=True, seed=0)
     W = eng.table.cpu().numpy().copy()
     m = np.zeros_like(W); v = np.zeros_like(W)
-    cores = min(os.cpu_count() or 1, 32)                      # threads actually used (more only adds sync overhead at this size)
-    torch.set_num_threads(cores)
+    cores, sweep, nproc = cpu_thread_sweep(eng.arch, eng.hw, D)   # threads actually used: the fastest of 32 / 64 / 128 / nproc on THIS box (measured, not assumed)
     torch.manual_seed(0)
     net = (resnet50 if eng.arch == 'resnet50' else resnet18)(num_classes=D).train()
     pool = torch.rand(rows, 3, eng.hw, eng.hw, generator=torch.Generator().manual_seed(1234))
@@ -233,7 +302,7 @@ def cpu_baseline(eng, budget_s=25.0, rows=64):
         if t_warm > budget_s * 0.45:
             break                                              # a slow host: one measured step is what the budget holds
     t_step = tot / reps
-    return {'value': round(Bs / t_step, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+    return {'value': round(Bs / t_step, 3), 'unit': 'images/sec', 'cores': cores, 'nproc': nproc, 'thread_sweep_s': sweep, 'kind': 'port',
             'sample': 'the workload\'s step at a bounded batch, measured whole: B_s=%d positives -> %d CNN rows (one BatchNorm batch), K=%d, D=%d, %s at %dx%d: '
                       'oracle dense sampler + torch-CPU fp32 ResNet fwd/bwd + numpy cone loss fwd/bwd + table step; %d timed step(s) after one warm-up'
                       % (Bs, rows, K, D, eng.arch, eng.hw, eng.hw, reps),
@@ -479,26 +548,28 @@ def measure(args, dtype, rank, world, stamp, primary):
             roof_conv['isolated'] = {'ms_per_step': round(conv_isolated, 3), 'achieved': round(eng.conv_flops_per_step / conv_isolated / 1e9, 2),
                                      'frac': round(eng.conv_flops_per_step / conv_isolated / 1e9 / 157.3, 4)}
     if f32:
-        # HBM bytes per launch from the committed PMC passes (profiles/r05_step_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, whole family per step / launches)
+        # HBM bytes per launch from the committed PMC passes (profiles/r06_step_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, whole family per step / launches)
         try:
             import hashlib
-            allm = json.load(open(os.path.join(ROOT, 'profiles', 'r05_step_traffic.json')))
+            allm = json.load(open(os.path.join(ROOT, 'profiles', 'r06_step_traffic.json')))
             csrc = os.path.join(ROOT, 'learning_embeddings_amd', 'csrc')
             stale = [f for f, h in allm.get('kernel_sources_sha256', {'missing': ''}).items()
                      if not os.path.exists(os.path.join(csrc, f)) or hashlib.sha256(open(os.path.join(csrc, f), 'rb').read()).hexdigest() != h]
             if stale:                                           # counters of older kernels: say so instead of quoting them
                 raise LookupError('kernel sources changed since the PMC passes: ' + ', '.join(stale))
-            tr = allm['x3' if x3 else 'native']
+            if x3:
+                raise LookupError('the split mode was not profiled this round')
+            tr = allm['native']
             fam = lambda *keys: sum(sum(tr[k]) for k in keys if k in tr) * 1e9
             if roof_conv is not None:
                 roof_conv['traffic'] = int(fam('convolution forward / data gradient', 'convolution weight gradients') / max(eng.conv_launches_per_step, 1))
-                roof_conv['traffic_note'] = 'HBM bytes per launch, family average: rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE over a profiled run of this command (profiles/r05_step_traffic.md); the bound is the matrix pipe'
+                roof_conv['traffic_note'] = 'HBM bytes per launch, family average: rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE over a profiled run of this command (profiles/r06_step_traffic.md); the bound is the matrix pipe'
             if roof_bn is not None:
                 roof_bn['traffic'] = int(fam('BatchNorm family (bn.hip)') / max(eng.bn_launch_groups_per_step, 1))
         except Exception as e:                                  # noqa: BLE001
             for r_ in (roof_conv, roof_bn):
                 if r_ is not None:
-                    r_['traffic_note'] = 'null: %s (re-run tools/step_traffic_round5.sh + tools/make_step_traffic_round5.py)' % e
+                    r_['traffic_note'] = 'null: %s (re-run tools/step_traffic.sh + tools/make_step_traffic.py)' % e
     res = {'value': round(ips, 2), 'ms_per_step': round(dt / args.steps * 1e3, 3), 'step_ms': step_ms, 'dtype': 'f32' if f32 else dtype,
            'launch_mode': ('hipgraph (forward + loss + backward of a step replayed as one graph)' if graph_mode else
                            ('hipgraph per chunk (gather + forward + windowed loss + backward of %d CNN rows as ONE graph, replayed %d times per step)' % (eng.cnn_chunk, eng.n_rows_pad // eng.cnn_chunk)
@@ -574,8 +645,10 @@ def measure_classifier(args, dtype, rank, world, stamp):
             'B': eng.B, 'arch': eng.arch, 'hw': eng.hw, 'n_classes': eng.labelmap.n_classes,
             'hbm_peak_allocated_gb': round(torch.cuda.max_memory_allocated() / 1e9, 1),
             'library_conv_launches_per_step': sum((getattr(eng, 'library_conv_launches_per_step', None) or {'-': -1}).values()),
+            'cpu_baseline': (cpu_baseline_classifier(eng, budget_s=args.cpu_baseline_budget, rows=min(args.cpu_baseline_rows, 64)) if (f32 and not args.no_cpu_baseline and world == 1) else None),
             'roofline': {'kernel': '%s fwd+bwd + MultiLevelCELoss + Adam (whole step; analytic conv/fc flops / step time)' % eng.arch, 'bound': 'mfma',
-                         'achieved': round(flops / step_s / 1e12, 3), 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': round(flops / step_s / 1e12 / peak_tf, 5), 'traffic': None}}
+                         'achieved': round(flops / step_s / 1e12, 3), 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': round(flops / step_s / 1e12 / peak_tf, 5),
+                         'traffic': cfg4_traffic(f32)[0], 'traffic_note': cfg4_traffic(f32)[1]}}
 
 
 def _bench_trainer(args, dtype, M, MV, path_of, n_workers, **kw):
@@ -848,7 +921,7 @@ def main():
                                           % (args.workload, res['n_classes'], res['arch'], res['B'], res['hw'], res['hw']),
                               'global_batch': res['B'] * world, 'parallelism': 'dp%d' % world, 'launch_mode': res['launch_mode'],
                               'mean_loss': res['mean_loss'], 'hbm_peak_allocated_gb': res['hbm_peak_allocated_gb']},
-                   'roofline': res['roofline']}
+                   'roofline': res['roofline'], 'cpu_baseline': res.get('cpu_baseline'), 'library_conv_launches_per_step': res.get('library_conv_launches_per_step')}
             if sec is not None:
                 out['secondary_bf16'] = {'note': 'NARROWER than the reference (bf16 conv stack); not the headline', 'value': sec['value'],
                                          'ms_per_step': sec['ms_per_step'], 'dtype': sec['dtype'], 'roofline': sec['roofline']}
@@ -874,10 +947,22 @@ def main():
             cone_s = bench_cone.time_joint(B, K, D, eng.N, B, iters=30)['us'] * 1e-6
         ab = cone_alg_bytes(B, K, D)
         c_tr, c_note = cone_traffic(B, K, D, eng.N)
+        # the same launch on its three clocks (8.7 / 12.2 / 17.0 us were quoted without saying which is which)
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import bench_cone as _bc
+        iso_us = _bc.time_joint(B, K, D, eng.N, B, iters=30)['us']
+        rocprof_us = None
+        try:
+            rocprof_us = json.load(open(os.path.join(ROOT, 'profiles', 'r06_cone_pmc.json')))['shapes'].get('%d_%d_%d_%d' % (B, K, D, eng.N), {}).get('avg_us')
+        except Exception:                                       # noqa: BLE001
+            pass
         roof_cone = {'kernel': 'joint_loss_kernel (fused cone loss fwd+bwd, f32)', 'bound': 'hbm',
                      'achieved': round(ab / cone_s / 1e9, 3) if cone_s else None, 'peak': 8000.0, 'unit': 'GB/s',
                      'frac': round(ab / cone_s / 8e12, 6) if cone_s else None, 'traffic': c_tr, 'traffic_note': c_note, 'alg_bytes_per_launch': ab,
                      'avg_launch_us': round(cone_s * 1e6, 2),
+                     'launch_time_bases_us': {'in_step_event_interval': round(cone_s * 1e6, 2), 'isolated_graph_replay': round(iso_us, 2), 'rocprof_kernel_duration': rocprof_us,
+                                              'note': '`achieved` / `frac` use the FIRST: HIP events around the launch inside the step (the interval includes the launch gap and whatever the previous kernel leaves draining); '
+                                                      'isolated_graph_replay: the launch alone, replayed back to back from a hipGraph (tools/bench_cone.py); rocprof_kernel_duration: the kernel\'s own start-to-end time under rocprofv3 --kernel-trace (profiles/r06_cone_pmc.md)'},
                      'note': 'at the north-star size (B=%d, K=%d, D=%d: %.2f MB per launch) the launch is latency-bound, not HBM-bound; see roofline_stress' % (B, K, D, ab / 1e6)}
         f32 = args.dtype == 'fp32'
         dominant = res['roofline_conv'] if (f32 and res['roofline_conv'] is not None) else (res['roofline_bn'] or roof_cone)
@@ -930,7 +1015,7 @@ def main():
                                                    '4.7 us kernel arguments -> node codes -> u_b / v_b rows -> projection, 2.6 us waiting for the iteration rows, 1.2 us for its 128 cone energies (the acos / asin / sqrt / divide chain), '
                                                    '0.8 us gradient reduction + row adds, 2.0 us loss hand-off (one returning integer atomic per block + the block barrier); at 4 096 x 256 x 10 the row phase is 44 % of a wave '
                                                    '(64 different row addresses per load instruction: the texture path retires about one address per cycle per CU) and vector-ALU issue about half of the launch; '
-                                                   'L2 atomics are 26 k - 83 k requests per launch and HBM traffic 0.14 - 0.8 x the algorithmic bytes (profiles/r04_cone_pmc.md): neither binds',
+                                                   'L2 atomics are 26 k - 83 k requests per launch and HBM traffic 0.14 - 0.8 x the algorithmic bytes (profiles/r06_cone_pmc.md): neither binds',
                                'launch_floor_us': 13.0, 'note': 'forward-only launch of the cfg5 shape: 13.0 us (tools/cone_timeline.py): at 256 positives the launch is a dependent chain on a partly filled chip'}}
             out['roofline_stress'] = st
         if world == 1 and not args.no_cpu_baseline:

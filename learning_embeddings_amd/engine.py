@@ -628,6 +628,8 @@ class ClassifierEngine:
                                    compute_dtype=self.compute_dtype)
         if not overlap_wgrad and self.exp.overlap is not None:
             self.exp.overlap.side = None
+        if self.exp.overlap is not None and self.exp.overlap.side is not None and self.compute_dtype == torch.float32:
+            self.exp.overlap.antiphase = os.environ.get('LEC_WGRAD_ANTIPHASE', '1') != '0'      # (0: A/B runs)
         self.exp.model.train()
         L = len(lm.levels)
         par = lm.parents()

@@ -80,6 +80,12 @@ class WgradOverlap:
         self.reducer = reducer
         self.arena = arena
         self.enabled = True
+        # fp32, ONE pass, weight gradients on the side stream: data gradient and weight gradient are both bound by the matrix pipe -- side by side they only
+        # stretch each other (config 4, round 5: 137.8 ms with the side stream, 137.2 in line).  `antiphase`: the side stream's weight gradient of layer L runs
+        # beside the main stream's HBM-bound BatchNorm backward of layer L - 1, and the NEXT data gradient waits for it (wait_matrix) -- matrix work never
+        # overlaps matrix work, the BatchNorm backward passes disappear under the weight gradients.
+        self.antiphase = False
+        self._wgrad_done = None
         self.accumulate = False         # True: several backward passes per step (chunked CNN rows): BatchNorm parameter gradients go
                                         # through autograd's AccumulateGrad (which adds) instead of being written in place
         if reducer is not None and self.side is not None and hasattr(reducer, 'side_streams'):
@@ -220,6 +226,14 @@ class WgradOverlap:
                                                            # (under hipGraph capture such blocks are held until the capture ends)
             if not own:
                 self._finish_wgrad(gw, conv)
+            if self.antiphase:
+                self._wgrad_done = torch.cuda.Event(); self._wgrad_done.record(self.side)
+
+    def wait_matrix(self):
+        """(antiphase) the main stream's next matrix-bound kernel starts after the side stream's last weight gradient has finished."""
+        if self.antiphase and self._wgrad_done is not None:
+            torch.cuda.current_stream().wait_event(self._wgrad_done)
+            self._wgrad_done = None
 
     def join(self):
         if self.side is not None:
@@ -545,6 +559,8 @@ class _OverlapConvFn(torch.autograd.Function):
             nhwc_g = gy.is_contiguous(memory_format=torch.channels_last)
             if ctx.f32:
                 ops = _ops()
+                if ops.overlap() is not None:
+                    ops.overlap().wait_matrix()
                 rec = ops.fusion().forks.get(x.data_ptr()) if (ops.FOLD_BN_BWD_F32 and ctx.planes is None and not ctx.stem) else None
                 if rec is not None and not (conv.stride[0] == 1 and conv.out_channels % 32 == 0 and x.shape[1] % 8 == 0 and x.shape[1] >= ops.FOLD_F32_MIN_CHANNELS
                                             and rec['x'].dtype == torch.float32

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""profiles/r04_cone_pmc.md/.json from the passes of tools/prof_cone_round4.sh: per shape joint_loss_kernel's average duration (kernel trace),
+"""profiles/<name>.md/.json from the passes of tools/prof_cone_pmc.sh: per shape joint_loss_kernel's average duration (kernel trace),
 its HBM traffic per launch (FETCH_SIZE x 2 + WRITE_SIZE, KiB counters) next to the algorithmic bytes of SURVEY.md 8(d), and per-launch
-averages of the SQ / TCC / TCP counters collected in the other passes.  usage: make_cone_pmc_round4.py <dir> > r04_cone_pmc.md"""
+averages of the SQ / TCC / TCP counters collected in the other passes.  usage: make_cone_pmc.py <dir> [<name>] > <name>.md  (the .json goes to <dir>/<name>.json)"""
 import csv, glob, hashlib, json, os, sys
 
 d = sys.argv[1]
@@ -88,4 +88,4 @@ print('about TWICE the cycles spent waiting on any instruction at the K = 256 sh
 print('asinf, sqrtf and divisions, evaluated for every pair; -ffp-contract=off, no fast math: the reference\'s op-by-op rounding), and at the north-star size (256 x 5 x 10: 256 waves on 1 024')
 print('SIMDs, 9 us) the launch is a dependent chain on a quarter-full chip: latency, not throughput.  Binding resource: the vector ALU at K = 256, launch + dependent-load')
 print('latency at K = 5.')
-json.dump(out, open(os.path.join(d, 'r04_cone_pmc.json'), 'w'), indent=1)
+json.dump(out, open(os.path.join(d, (sys.argv[2] if len(sys.argv) > 2 else 'cone_pmc') + '.json'), 'w'), indent=1)
