@@ -26,6 +26,7 @@ static Tuning load_tuning() {
   t.cf_sk = i("LEC_CF_SK", 1);
   { const char* e = env("LEC_CF_SK_FILL"); t.cf_sk_fill = e ? atof(e) : 0.92; }
   t.cf_sk_min_chunks = i("LEC_CF_SK_MIN_CHUNKS", 8);
+  t.cf_sk_wgs = pos("LEC_CF_SK_WGS", 512);
   t.cf_xcd = i("LEC_CF_XCD", 0);
   t.cf_lds_pad = i("LEC_CF_LDS_PAD", 0);
   t.dgrad_classes = i("LEC_DGRAD_CLASSES", 1);

@@ -791,12 +791,15 @@ static int launch_act(const float* src, const float* wgt, float* dst, const ActG
       const long long iters = tiles * nchunks;
       long long gmax = mode == 2 ? iters : iters / sk_min_chunks();
       if (gmax < 1) gmax = 1;
-      const int G = (int)(gmax < kSkWgs ? gmax : kSkWgs);
+      // (LEC_CF_SK_WGS: workgroups of a balanced launch.  512 = every resident slot of the chip; 256 = ONE per CU, so that the balanced launches of two
+      // concurrent passes sit side by side -- 2 x 74 KB of LDS, 2 x 190 registers per SIMD lane -- instead of queueing behind each other)
+      const int kw = tuning().cf_sk_wgs < kSkWgs ? tuning().cf_sk_wgs : kSkWgs;
+      const int G = (int)(gmax < kw ? gmax : kw);
       const double rounds = (double)tiles / kSkWgs;
       const double fill = rounds / (double)((tiles + kSkWgs - 1) / kSkWgs);
       // ... taken where the tile walk's last round is poorly filled AND the cut gives more parallel work than whole tiles would (tiles < 512), or
       // the same 512 workgroups an even share (tiles > 512)
-      if (mode == 2 || (fill < sk_fill() && (tiles >= kSkWgs ? G == kSkWgs : (long long)G * 4 >= tiles * 5))) {
+      if (mode == 2 || (fill < sk_fill() && (tiles >= kSkWgs ? G == kw : (long long)G * 4 >= tiles * 5))) {
         const size_t lds = (size_t)2 * (BM * kCfLdk + (B_KC ? BN * kCfLdk : kCfBK * BN)) * 4;
         SkArgs sk{sc.slots, sc.counters, ntiles, (int)tiles};
         ActGeo gg = g; gg.xcd_per = 0;

@@ -468,7 +468,7 @@ class StepEngine:
         # concurrent parts fill each other's last rounds of workgroup slots: the balanced (stream-K) convolution kernel buys nothing here (131.0 ms
         # with the tile walk, 131.5 with it) and moves 32 GB more per step (slabs, operand re-reads: profiles/r03_conv_f32_balanced.md): tile walk
         schedule = self.backbone.conv_schedule
-        self.backbone.conv_schedule = _lib.SCHEDULE_TILE_WALK
+        self.backbone.conv_schedule = int(os.environ.get('LEC_PASS_SCHEDULE', _lib.SCHEDULE_TILE_WALK))    # (A/B runs: 1 = balanced where it pays, 2 = wherever it applies)
         try:
             for p, st in enumerate(self.pass_streams):
                 st.wait_stream(cur)
