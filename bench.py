@@ -974,7 +974,7 @@ def main():
                           'global_batch': B * world, 'cnn_rows_per_step_per_gpu': eng.n_rows, 'cone_loss_dtype': 'f32',
                           'cnn_dtype': ('f32 activations and weights; every fp32 product computed as six exact bf16 x bf16 products on the matrix cores, fp32 accumulation (csrc/conv_f32x3.hip)' if args.conv_f32 == 'x3' else 'f32 activations, weights and accumulation (v_mfma_f32_32x32x2_f32: exact fp32)') if f32 else 'bf16 activations, fp32 master weights and accumulation',
                           'parallelism': 'dp%d' % world, 'sampler': args.sampler,
-                          'cnn_chunks': ('%d chunks of %d rows per step, one forward + windowed loss launch + backward each (BatchNorm batch = a chunk)' % (eng.n_rows_pad // eng.cnn_chunk, eng.cnn_chunk)) if eng.cnn_chunk else None,
+                          'cnn_chunks': ('%d chunks of %d rows per step, one forward + windowed loss launch + backward each, %s' % (eng.n_rows_pad // eng.cnn_chunk, eng.cnn_chunk, ('every chunk as %d concurrent parts of %d rows (one HIP stream and one BatchNorm batch each)' % (eng.chunk_lanes, eng.cnn_chunk // eng.chunk_lanes)) if getattr(eng, 'chunk_lanes', 1) > 1 else 'BatchNorm batch = a chunk')) if eng.cnn_chunk else None,
                           'table_dtype': 'fp16 shadow read by the loss kernel, fp32 master / gradients / Adam moments' if eng.table_h is not None else 'fp32',
                           'cnn_passes': ('%d concurrent passes of %d rows, one HIP stream each (BatchNorm batch = a pass: positives | image negatives, the reference\'s own separate forwards)' % (eng.passes, eng.n_rows // eng.passes)) if eng.passes > 1 else '1 pass of %d rows' % eng.n_rows,
                           'hbm_peak_allocated_gb': res['hbm_peak_allocated_gb'], 'launch_mode': res['launch_mode'], 'mean_loss': res['mean_loss']},

@@ -169,7 +169,9 @@ class StepEngine:
         # tools/exp_two_streams_f32.py).  The weight gradients then run in line (a third stream adds nothing once the matrix pipe is
         # busy all the time: 137.1 ms).  The bf16 stack is HBM-bound everywhere and keeps one pass (measured in round 1: 53.5 vs 51.8 ms).
         if passes is None:
-            passes = 2 if (dtype == 'fp32' and self.cnn_chunk is None and self.n_rows % 2 == 0 and self.n_rows >= 16) else 1
+            # (bf16 too since round 6: with the own bf16 convolution family -- bound by L2 request throughput in layer3 / layer4, not by HBM -- two concurrent
+            # half-batch passes hide BatchNorm traffic as at fp32: 40.35 -> 38.56 ms per step, same box; the round-1 measurement on library kernels said the opposite)
+            passes = 2 if (dtype in ('fp32', 'bf16') and self.cnn_chunk is None and self.n_rows % 2 == 0 and self.n_rows >= 16) else 1
         if passes > 1 and (self.cnn_chunk is not None or self.n_rows % passes):
             raise ValueError('passes=%d needs an unchunked step whose %d CNN rows divide evenly' % (passes, self.n_rows))
         self.passes = int(passes)
@@ -232,9 +234,16 @@ class StepEngine:
             # concurrent passes AND a weight-gradient side stream (an opt-in combination that measures slower: 130.5 against 125 ms): capturing it
             # aborts inside the runtime (the side stream is forked from two capturing pass streams at once), so this combination launches eagerly
             self.use_graph = False
+        # A chunk of the chunked step as `chunk_lanes` concurrent parts (one HIP stream and one BatchNorm batch each), like the passes of the unchunked step: bf16,
+        # even chunk sizes.  LEC_CHUNK_LANES=1: one part per chunk (A/B runs).
+        self.chunk_lanes = 1
+        if self.cnn_chunk is not None and self.compute_dtype == torch.bfloat16 and self.cnn_chunk % 2 == 0 and self.overlap is not None and self.overlap.side is None:
+            self.chunk_lanes = int(os.environ.get('LEC_CHUNK_LANES', '2'))
         if self.cnn_chunk is not None and self.overlap is not None:
-            self.overlap.accumulate = True
-        self.pass_streams = [torch.cuda.Stream() for _ in range(self.passes)] if self.passes > 1 else []
+            self.overlap.accumulate = self.chunk_lanes == 1          # (lanes: BatchNorm parameter gradients are ADDED by the kernels themselves, atomics, as in the multi-pass step)
+        self.pass_streams = [torch.cuda.Stream() for _ in range(max(self.passes, self.chunk_lanes))] if max(self.passes, self.chunk_lanes) > 1 else []
+        if self.chunk_lanes > 1:
+            self.backbone.bn_grad_accumulate = True
         if self.passes > 1:
             # several backward passes add into the same gradient slots from concurrent streams: BatchNorm's d gamma / d beta are ADDED
             # with atomics (like the weight gradients); the arena is zeroed once per step
@@ -347,6 +356,8 @@ class StepEngine:
         the per-chunk hipGraph captures: the same graph is replayed for every chunk of every step."""
         codes = self.codes_dev
         pos_from = codes[:, 0].contiguous(); pos_to = codes[:, 1].contiguous(); negc = codes[:, 2:].contiguous()
+        if self.chunk_lanes > 1:
+            return self._chunk_body_lanes(pos_from, pos_to, negc)
         f = self.img_feat_net.forward_raw(_gather_images(self.pool, self.idx_chunk))
         self.feats_c.copy_(f.detach())
         self.gfeat_c.zero_()
@@ -357,6 +368,47 @@ class StepEngine:
         f.backward(self.gfeat_c)
         if self.overlap is not None:
             self.overlap.join()
+
+    def _chunk_body_lanes(self, pos_from, pos_to, negc):
+        """`_chunk_body` with the chunk's rows as `chunk_lanes` concurrent parts (the structure of `_core_passes`): backbone forward of every part up to the pooled
+        features on its own stream, join, the fully connected layer over the chunk's rows + the windowed loss launch + the layer's backward on the main stream,
+        backbone backward of every part, join.  BatchNorm batch = a part; convolution / BatchNorm parameter gradients add up in the arena (atomics), the fully connected
+        layer's go through AccumulateGrad on ONE stream."""
+        cur = torch.cuda.current_stream()
+        images = _gather_images(self.pool, self.idx_chunk)
+        L = self.chunk_lanes
+        h = self.cnn_chunk // L
+        parts, order = [], {}
+        lanes = self.pass_streams[:L]
+        for p, st in enumerate(lanes):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                f = self.img_feat_net.forward_pooled(images[p * h:(p + 1) * h], pass_order=(order, p))
+                parts.append(f)
+                f.record_stream(cur)
+        for st in lanes:
+            images.record_stream(st)
+        for st in lanes:
+            cur.wait_stream(st)
+        pooled = torch.cat([f.detach() for f in parts]).requires_grad_(True)
+        feats = self.img_feat_net.head(pooled)
+        self.feats_c.copy_(feats.detach())
+        self.gfeat_c.zero_()
+        l_c, _, _ = ops.joint_loss_raw(self.table, self.feats_c, pos_from, pos_to, negc, None, self.K_cone, self.alpha, _lib.ENERGY_HYP_CONE,
+                                       _lib.LABEL_HYP, _lib.IMAGE_SOFTCLIP, self.table_grad, self.gfeat_c, table_f16=self.table_h,
+                                       window_dev=self.win_dev, out=self._chunk_out)
+        self.loss_buf += l_c
+        feats.backward(self.gfeat_c)
+        gp = pooled.grad
+        for p, st in enumerate(lanes):
+            st.wait_stream(cur)
+            gp.record_stream(st)
+            with torch.cuda.stream(st):
+                parts[p].backward(gp[p * h:(p + 1) * h])
+                if self.overlap is not None:
+                    self.overlap.join()
+        for st in lanes:
+            cur.wait_stream(st)
 
     def _capture_chunk(self):
         """Capture `_chunk_body` into a hipGraph (after eager steps have sized every workspace).  On any capture error the engine keeps launching eagerly and says so."""

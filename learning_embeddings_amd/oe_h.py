@@ -166,15 +166,19 @@ class _ImageNetBase(nn.Module):
         return y.float()
 
     def forward_pooled(self, x, pass_order=None):
-        """The backbone up to its global average pooling, fp32 [n, fc.in_features]; `head` finishes forward_raw.  (fp32 only: the
-        engine's concurrent passes, which pool per pass and apply the fully connected layer once.)"""
+        """The backbone up to its global average pooling, [n, fc.in_features]; `head` finishes forward_raw.  (the
+        engine's concurrent passes, which pool per pass and apply the fully connected layer once; 16-bit backbones run it under autocast.)"""
         if self.channels_last and x.dim() == 4:
             x = x.contiguous(memory_format=torch.channels_last)
         if self.compute_dtype != torch.float32:
-            raise NotImplementedError('forward_pooled serves the fp32 backbone')
+            with torch.autocast('cuda', dtype=self.compute_dtype):
+                return self.model(x, pooled_only=True, pass_order=pass_order)
         return self.model(x, pooled_only=True, pass_order=pass_order)
 
     def head(self, pooled):
+        if self.compute_dtype != torch.float32:
+            with torch.autocast('cuda', dtype=self.compute_dtype):
+                return self.model.fc(pooled).float()
         return self.model.fc(pooled).float()
 
     def forward(self, x):
