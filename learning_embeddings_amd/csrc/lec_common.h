@@ -212,15 +212,22 @@ __device__ __forceinline__ void block_publish_fixed_point(float wave_value /*val
   float p = 0.0f;
   for (int w = 0; w < nwave; ++w) p += s_wave_fx[w];
   const bool ok = p >= 0.0f && p <= bound;                                        // (false for NaN)
+  // Ordering of the flag hand-off: hardware -- the bad block's fetch_or is a RETURNING agent-scope atomic and the wave waits for it (vmcnt(0)) before it
+  // issues its ticket, and the last block's flag load is issued only after its own ticket has RETURNED (the branch below depends on the returned value; both are
+  // agent-scope accesses performed at the coherence point, past the CU's L1); compiler -- the signal fences keep the three accesses in this program order (a relaxed
+  // atomic may otherwise be moved across another address's atomic).  An agent-scope acq_rel on the ticket would say the same in the memory model's own words, at the
+  // price of an L2 write-back + L1 invalidate in EVERY block (1.7 - 3.5 us each next to a 17 us launch): not taken.
   if (!ok) {
     __hip_atomic_fetch_or(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // returning: performed before the ticket below is issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
   }
   const unsigned long long mask = (1ull << 52) - 1ull;
   const unsigned long long add = (1ull << 52) | (ok ? ((unsigned long long)__double2ll_rn((double)p * scale) & mask) : 0ull);
   const unsigned long long prev = __hip_atomic_fetch_add(acc, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if ((prev >> 52) == (unsigned long long)(gridDim.x - 1)) {
     const unsigned long long total = (prev & mask) + (add & mask);
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
     const unsigned int bad = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     out[0] = bad ? __builtin_nanf("") : (float)((double)total * inv_scale);
     __hip_atomic_store(acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // re-arm for the next (stream-ordered) launch

@@ -7,6 +7,7 @@ the GEMM-friendly layout, bf16 compute under autocast with fp32 master weights h
 (parallel.FlatArena) so the data-parallel all-reduce is a single RCCL collective and Adam a single launch.
 """
 import os
+import weakref
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -411,7 +412,6 @@ class _GlobalAvgPoolFn(torch.autograd.Function):
         ctx.cl = x.is_contiguous(memory_format=torch.channels_last)
         # this node is the LAST one of the backbone's graph: it dies when the caller drops the forward's output without a backward -- the fusion context's
         # own records (block outputs) keep every node upstream of it alive, so it is the one witness of "a backward can still come" (FusionContext.busy)
-        import weakref
         _ops().fusion().graph_ref = weakref.ref(ctx)
         return torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)
 
@@ -775,8 +775,8 @@ class ResNet(nn.Module):
             if len(pool) >= self.max_forwards_in_flight:
                 old = next((c for c in pool if c.graph_ref is None), None)
                 if old is None:
-                    raise RuntimeError('%d forwards of this backbone are waiting for their backward (max_forwards_in_flight): run backward, drop the outputs, '
-                                       'or use torch.no_grad() for forwards that need no gradient' % len(pool))
+                    raise RuntimeError('%d forwards of this backbone are waiting for their backward (ResNet.max_forwards_in_flight = %d; each holds a fusion context and a '
+                                       'BatchNorm workspace): run backward, drop the outputs, use torch.no_grad() for forwards that need no gradient, or raise the limit' % (len(pool), self.max_forwards_in_flight))
                 pool.remove(old); pool.append(old); fc = old
             else:
                 fc = _ops().FusionContext(); pool.append(fc)
