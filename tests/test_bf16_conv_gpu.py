@@ -138,3 +138,80 @@ def test_conv_bf16_full_size_layers_match_fp32_reference_on_rounded_operands():
         assert (y.float() - yr.detach()).abs().max().item() <= 2.0 ** -8 * yr.abs().max().item()
         assert (dx.float() - xr.grad).abs().max().item() <= 2.0 ** -8 * xr.grad.abs().max().item()
         assert (dw - wr.grad).abs().max().item() <= 1e-3 * wr.grad.abs().max().item()
+
+
+def test_resnet50_bf16_family_everywhere_vs_special_cases_vs_library():
+    """A bottleneck ResNet with every layer kind of ResNet-50 (stem, four stages with their strided and downsample layers) at bf16 (autocast), forward + backward with a flat arena, three ways on the same weights and batch: the default routing (round-1 special cases
+    where they exist, the family elsewhere), the family for EVERY layer (LEC_CONV_BF16=2: stem, strided layers, parity classes, fold epilogues, transposed weights -- all in
+    one network) and the library for everything the special cases do not serve (LEC_CONV_BF16=0: MIOpen / hipBLASLt).  Outputs and every parameter gradient agree to bf16
+    noise; a wrong layout anywhere shows up as a cosine near zero in every layer upstream of it.  The own routings launch no library convolution."""
+    from learning_embeddings_amd import resnet as R, parallel
+    torch.manual_seed(0)
+    x0 = torch.rand(16, 3, 128, 128).to(DEV).contiguous(memory_format=torch.channels_last)
+    gsave = None; res = {}
+    state = None
+    for mode in ('1', '2', '0'):
+        torch.manual_seed(1)
+        net = R.ResNet(R.Bottleneck, [1, 1, 1, 1], 10).to(DEV).to(memory_format=torch.channels_last).train()   # every layer KIND of ResNet-50 once (a 16-block random-init net in
+        if state is None:                                                                                   # bf16 is chaotic: any two correct implementations decorrelate)
+            state = {k: v.clone() for k, v in net.state_dict().items()}
+        net.load_state_dict(state)
+        arena = parallel.FlatArena(net.parameters(), DEV); arena.enable_lowp_transposed()
+        net.wgrad_overlap = R.WgradOverlap(None, arena, side_stream=False)
+        old = R.CONV_BF16; R.CONV_BF16 = mode
+        try:
+            R.library_launches(reset=True)
+            arena.zero_grad()
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                y = net(x0)
+            if gsave is None:
+                gsave = torch.randn_like(y.float())
+            y.float().backward(gsave)
+            torch.cuda.synchronize()
+            libs = R.library_launches()
+        finally:
+            R.CONV_BF16 = old
+        if mode != '0':
+            assert sum(libs.values()) == 0, (mode, libs)
+        else:
+            assert sum(libs.values()) > 0
+        res[mode] = (y.detach().float().clone(), [p.grad.float().clone() for p in net.parameters()])
+    cos = lambda a, b: F.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0).item()
+    stats = {}
+    for a_, b_ in (('1', '2'), ('1', '0'), ('2', '0')):
+        cs = [cos(a, b) for a, b in zip(res[a_][1], res[b_][1]) if a.numel() > 64]
+        stats[(a_, b_)] = (cos(res[a_][0], res[b_][0]), min(cs), sum(cs) / len(cs))
+    print('output / min / mean parameter-gradient cosines:', stats)
+    # measured: the two own routings 0.99999 / 0.992 / 0.995 (output / min / mean); either against the library 0.9998 / 0.885 / 0.933 (another accumulation order in every layer)
+    co, mn, me = stats[('1', '2')]
+    assert co > 0.999 and mn > 0.97 and me > 0.985, stats
+    for k in (('1', '0'), ('2', '0')):
+        co, mn, me = stats[k]
+        assert co > 0.99 and mn > 0.7 and me > 0.88, stats
+
+
+def test_transposed_bf16_weight_arena_follows_the_adam_step():
+    """FlatArena.enable_lowp_transposed: the data gradients' operand ([Cin][RS][Cout] per layer, one launch behind the Adam kernel) equals the bf16 shadow transposed, at
+    construction and after optimizer steps, for every convolution weight of ResNet-18 (1x1 downsample, 3x3, strided; the 3-channel stem has no data gradient and no twin)."""
+    from learning_embeddings_amd import resnet as R, parallel
+    torch.manual_seed(0)
+    net = R.resnet18(10).to(DEV).to(memory_format=torch.channels_last).train()
+    arena = parallel.FlatArena(net.parameters(), DEV); arena.enable_lowp_transposed()
+    convs = [m for m in net.modules() if isinstance(m, torch.nn.Conv2d)]
+    def check():
+        n = 0
+        for c in convs:
+            wt = arena.lowp_t_view(c.weight); w = arena.lowp_view(c.weight)
+            if c.in_channels % 8 or c.out_channels % 64:
+                assert wt is None
+                continue
+            assert wt is not None and tuple(wt.shape) == (c.in_channels, c.out_channels) + tuple(c.kernel_size)
+            assert torch.equal(wt.permute(1, 0, 2, 3), w), c
+            assert torch.equal(w.float(), c.weight.data.bfloat16().float())
+            n += 1
+        assert n >= 19
+    check()
+    for step in range(2):
+        arena.grad.normal_()
+        arena.adam_step(1e-2)
+        check()
