@@ -956,7 +956,7 @@ def main():
         # the same launch on its three clocks (8.7 / 12.2 / 17.0 us were quoted without saying which is which)
         sys.path.insert(0, os.path.join(ROOT, 'tools'))
         import bench_cone as _bc
-        iso_us = _bc.time_joint(B, K, D, eng.N, B, iters=30)['us']
+        iso_us = _bc.time_joint(B, K, D, eng.N, B, iters=30)['us'] if not args.no_stress else None      # (--no-stress: profiled runs count steps by this kernel's launches)
         rocprof_us = None
         try:
             rocprof_us = json.load(open(os.path.join(ROOT, 'profiles', 'r06_cone_pmc.json')))['shapes'].get('%d_%d_%d_%d' % (B, K, D, eng.N), {}).get('avg_us')
@@ -966,7 +966,7 @@ def main():
                      'achieved': round(ab / cone_s / 1e9, 3) if cone_s else None, 'peak': 8000.0, 'unit': 'GB/s',
                      'frac': round(ab / cone_s / 8e12, 6) if cone_s else None, 'traffic': c_tr, 'traffic_note': c_note, 'alg_bytes_per_launch': ab,
                      'avg_launch_us': round(cone_s * 1e6, 2),
-                     'launch_time_bases_us': {'in_step_event_interval': round(cone_s * 1e6, 2), 'isolated_graph_replay': round(iso_us, 2), 'rocprof_kernel_duration': rocprof_us,
+                     'launch_time_bases_us': {'in_step_event_interval': round(cone_s * 1e6, 2), 'isolated_graph_replay': round(iso_us, 2) if iso_us is not None else None, 'rocprof_kernel_duration': rocprof_us,
                                               'note': '`achieved` / `frac` use the FIRST: HIP events around the launch inside the step (the interval includes the launch gap and whatever the previous kernel leaves draining); '
                                                       'isolated_graph_replay: the launch alone, replayed back to back from a hipGraph (tools/bench_cone.py); rocprof_kernel_duration: the kernel\'s own start-to-end time under rocprofv3 --kernel-trace (profiles/r06_cone_pmc.md)'},
                      'note': 'at the north-star size (B=%d, K=%d, D=%d: %.2f MB per launch) the launch is latency-bound, not HBM-bound; see roofline_stress' % (B, K, D, ab / 1e6)}

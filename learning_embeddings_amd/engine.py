@@ -212,7 +212,7 @@ class StepEngine:
         P = pool_images or min(n_images, 2 * self.B)
         g = torch.Generator(device='cpu').manual_seed(1234 + self.rank)
         pool = torch.rand(P, 3, hw, hw, generator=g)
-        self.pool = _resident_pool(pool, self.device, self.compute_dtype, self.backbone, self.n_rows_pad)
+        self.pool = _resident_pool(pool, self.device, self.compute_dtype, self.backbone, self.cnn_chunk or self.n_rows_pad)    # (rows of ONE gathered batch: a chunk, or the step)
         self.P = P
         self.gfeat = torch.zeros(self.n_rows_pad, D, device=self.device)
         self.pin = [torch.empty((self.B, 2 + 2 * K), dtype=torch.int32).pin_memory() for _ in range(2)]

@@ -344,8 +344,8 @@ def _pad_c8(t):
     """[N, 3, H, W] -> [N, 8, H, W] channels_last with zero channels 3..7 (the bf16 family's 16-byte piece is 8 channels)."""
     if t.shape[1] == 8:
         return t
-    out = torch.zeros((t.shape[0], 8, t.shape[2], t.shape[3]), dtype=t.dtype, device=t.device).contiguous(memory_format=torch.channels_last)
-    out[:, :t.shape[1]] = t
+    out = torch.empty((t.shape[0], 8, t.shape[2], t.shape[3]), dtype=t.dtype, device=t.device, memory_format=torch.channels_last)
+    out[:, t.shape[1]:].zero_(); out[:, :t.shape[1]] = t
     return out
 
 
