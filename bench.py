@@ -553,7 +553,7 @@ def measure(args, dtype, rank, world, stamp, primary):
         if conv_isolated is not None:
             roof_conv['isolated'] = {'ms_per_step': round(conv_isolated, 3), 'achieved': round(eng.conv_flops_per_step / conv_isolated / 1e9, 2),
                                      'frac': round(eng.conv_flops_per_step / conv_isolated / 1e9 / 157.3, 4)}
-    if f32:
+    if f32 and args.workload.startswith('cfg3'):                # (the passes profiled THIS workload's step; other workloads carry no traffic figure)
         # HBM bytes per launch from the committed PMC passes (profiles/r06_step_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, whole family per step / launches)
         try:
             import hashlib
