@@ -171,7 +171,8 @@ class StepEngine:
         if passes is None:
             # (bf16 too since round 6: with the own bf16 convolution family -- bound by L2 request throughput in layer3 / layer4, not by HBM -- two concurrent
             # half-batch passes hide BatchNorm traffic as at fp32: 40.35 -> 38.56 ms per step, same box; the round-1 measurement on library kernels said the opposite)
-            passes = 2 if (dtype in ('fp32', 'bf16') and self.cnn_chunk is None and self.n_rows % 2 == 0 and self.n_rows >= 16) else 1
+            passes = 2 if (dtype in ('fp32', 'bf16') and self.cnn_chunk is None and self.n_rows % 2 == 0 and self.n_rows >= 16
+                           and not (dtype == 'bf16' and overlap_wgrad)) else 1      # (bf16 with side-stream weight gradients asked for: the one-pass arrangement)
         if passes > 1 and (self.cnn_chunk is not None or self.n_rows % passes):
             raise ValueError('passes=%d needs an unchunked step whose %d CNN rows divide evenly' % (passes, self.n_rows))
         self.passes = int(passes)

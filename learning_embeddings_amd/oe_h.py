@@ -98,7 +98,7 @@ class _ImageNetBase(nn.Module):
     def device(self):
         return next(self.parameters()).device
 
-    cnn_passes = 1           # > 1 (fp32, training): forward_raw pushes the batch through the backbone as that many concurrent parts
+    cnn_passes = 1           # > 1 (fp32 / bf16, training): forward_raw pushes the batch through the backbone as that many concurrent parts
 
     def __deepcopy__(self, memo):
         """copy.deepcopy of a network that has trained: the HIP streams of its concurrent passes are per-object launch resources, not state
@@ -135,12 +135,14 @@ class _ImageNetBase(nn.Module):
             st = streams[p]
             st.wait_stream(cur)
             with torch.cuda.stream(st):
-                f = self.model(xs, pooled_only=True, pass_order=(order, p))
+                with torch.autocast('cuda', dtype=self.compute_dtype, enabled=self.compute_dtype != torch.float32):
+                    f = self.model(xs, pooled_only=True, pass_order=(order, p))
             f.record_stream(cur); parts.append(f); used.append(st)
         for st in used:
             x.record_stream(st); cur.wait_stream(st)
         self.__dict__['_passes_in_flight'] = used                   # their backward runs on these streams: join_passes() after loss.backward()
-        return self.model.fc(torch.cat(parts)).float()
+        with torch.autocast('cuda', dtype=self.compute_dtype, enabled=self.compute_dtype != torch.float32):
+            return self.model.fc(torch.cat(parts)).float()
 
     def join_passes(self):
         """Make the current stream wait for the streams the concurrent passes' backward ran on.  Autograd only joins the streams on which an
@@ -155,7 +157,7 @@ class _ImageNetBase(nn.Module):
         """CNN output BEFORE soft_clip, fp32 [n, D] -- the fused loss applies soft_clip itself.  split: see _forward_raw_passes."""
         if self.channels_last and x.dim() == 4:
             x = x.contiguous(memory_format=torch.channels_last)
-        if (self.cnn_passes > 1 and x.is_cuda and self.compute_dtype == torch.float32 and self.training and torch.is_grad_enabled()
+        if (self.cnn_passes > 1 and x.is_cuda and self.compute_dtype in (torch.float32, torch.bfloat16) and self.training and torch.is_grad_enabled()
                 and x.dim() == 4 and x.shape[0] >= 4 * self.cnn_passes and (split is None or 2 <= split <= x.shape[0] - 2)):
             return self._forward_raw_passes(x, split)
         if self.compute_dtype != torch.float32:

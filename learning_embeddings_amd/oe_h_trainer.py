@@ -535,7 +535,8 @@ class JointEmbeddings:
                 self.arena.enable_lowp_transposed()     # bf16 shadow + its transposed twin (the data gradients' operand)
             # fp32: the CNN batch of a step goes through the backbone as two concurrent halves, one HIP stream each -- one half's HBM-bound
             # BatchNorm passes under the other's matrix-bound convolutions (engine.StepEngine) -- with the weight
-            # gradients in line; bf16 (HBM-bound everywhere): one pass, weight gradients on a side stream.  cnn_passes overrides.
+            # gradients in line; bf16: one pass, weight gradients on a side stream by default -- `cnn_passes=2` runs the bf16 backbone as two concurrent passes too
+            # (round 6: 4 % faster on the engine's step with the own bf16 convolution family).  cnn_passes overrides.
             if cnn_passes is None:
                 cnn_passes = 2 if compute_dtype == torch.float32 else 1
             self.cnn_passes = int(cnn_passes)
