@@ -131,18 +131,22 @@ def start_watchdog(limit_s, what):
 
 
 def device_bus_id(dev):
-    """PCI bus id of a torch device ('0000:c1:00.0'), through the HIP runtime torch has loaded (hipDeviceGetPCIBusId); falls back to the device's UUID / index."""
-    import ctypes, torch
+    """PCI address of a torch device ('0000:c1:00.0'): torch's own device properties (pci_domain_id / pci_bus_id / pci_device_id) where the build has them, else
+    hipDeviceGetPCIBusId through the HIP runtime the process has ALREADY loaded (dlopen by soname returns that handle), else the device's UUID / index."""
+    import torch
     idx = dev.index if getattr(dev, 'index', None) is not None else torch.cuda.current_device()
+    p = torch.cuda.get_device_properties(idx)
+    if all(hasattr(p, a) for a in ('pci_domain_id', 'pci_bus_id', 'pci_device_id')):
+        return '%04x:%02x:%02x.0' % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
     try:
+        import ctypes
         hip = ctypes.CDLL('libamdhip64.so')
         buf = ctypes.create_string_buffer(64)
         if hip.hipDeviceGetPCIBusId(buf, 64, int(idx)) == 0:
             return buf.value.decode()
-    except OSError:
+    except Exception:                                           # noqa: BLE001
         pass
-    p = torch.cuda.get_device_properties(idx)
-    return str(getattr(p, 'uuid', None) or getattr(p, 'pci_bus_id', None) or idx)
+    return str(getattr(p, 'uuid', None) or idx)
 
 
 def cone_traffic(B, K, D, N):

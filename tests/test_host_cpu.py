@@ -425,6 +425,33 @@ def test_bench_watchdog_exits_nonzero_when_a_region_never_finishes():
     assert r.returncode == 3 and 'WATCHDOG' in r.stderr and 'stuck region' in r.stderr and 'ok region' not in r.stderr
 
 
+def test_bench_py_calls_only_names_it_defines():
+    """bench.py is the driver's contract and most of it only runs on a GPU box: every plain-name call in it must resolve to a function the file defines, a name
+    it binds (assignment, import, argument, loop / with / comprehension target) or a builtin -- a helper lost in an edit is caught here, not at round end."""
+    import ast, builtins
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    tree = ast.parse(src)
+    bound = set(dir(builtins))
+    for n in ast.walk(tree):
+        if isinstance(n, (ast.FunctionDef, ast.ClassDef)):
+            bound.add(n.name)
+            if isinstance(n, ast.FunctionDef):
+                for a in n.args.args + n.args.kwonlyargs + ([n.args.vararg] if n.args.vararg else []) + ([n.args.kwarg] if n.args.kwarg else []):
+                    bound.add(a.arg)
+        elif isinstance(n, ast.Lambda):
+            for a in n.args.args:
+                bound.add(a.arg)
+        elif isinstance(n, (ast.Import, ast.ImportFrom)):
+            for a in n.names:
+                bound.add((a.asname or a.name).split('.')[0])
+        elif isinstance(n, ast.Name) and isinstance(n.ctx, ast.Store):
+            bound.add(n.id)
+        elif isinstance(n, ast.ExceptHandler) and n.name:
+            bound.add(n.name)
+    missing = sorted({n.func.id for n in ast.walk(tree) if isinstance(n, ast.Call) and isinstance(n.func, ast.Name) and n.func.id not in bound})
+    assert not missing, missing
+
+
 def test_conv_macs_matches_the_analytic_resnet_figures():
     """resnet.conv_macs (the denominator of bench.py's whole-CNN roofline line): SURVEY.md 8(d) quotes 1.8136 GMAC (ResNet-18) and 4.0872 GMAC
     (ResNet-50) per forward at 224 x 224, convolutions + the classifier's 1000-way fc excluded / included as the walk finds it."""
