@@ -40,6 +40,7 @@ static Tuning load_tuning() {
   t.wg_wgs = pos("LEC_WGRAD_WGS", 1 << 30);
   t.wg_smask = i("LEC_WGRAD_SMASK", 0);
   t.bf_dma = i("LEC_BF16_DMA", 1);
+  t.bf_tile = i("LEC_BF16_TILE", 1);
   t.x3_wgs = pos("LEC_X3_WGS", 256);
   t.x3_force_narrow = env("LEC_X3_FORCE_NARROW") != nullptr;
   t.x3_chain = pos("LEC_X3_CHAIN", 512);

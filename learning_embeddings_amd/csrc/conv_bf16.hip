@@ -382,22 +382,26 @@ __global__ __launch_bounds__(kBfThreads, 2) void conv_bf16_act_classes_kernel(co
 
 // ---------------------------------------------------------------------------------------------------------------
 // The same forward / data gradient with the operands travelling global -> LDS DIRECTLY (buffer_load_dwordx4 ... lds, "LDS-DMA") through a ring of
-// kDmNS stages, kDmNS - 1 of them in flight.
+// NS stages of kLnBK = 64 k each, NS - 1 of them in flight, multiplied on v_mfma_f32_16x16x32_bf16.
 //
-// Why (profiles/r06_conv_bf16_pmc.md): in the register-staged kernel above a wave spends 52 % of its cycles parked in s_waitcnt / s_barrier -- its 16
-// MFMAs per chunk last ~0.5 us while a load that misses the XCD's L2 (31 % do on the 3x3 layers) takes 1 - 2 us, and one chunk of look-ahead is all
-// the staging registers allow (a second register set spills).  LDS-DMA needs no staging registers, so the look-ahead is a matter of LDS: four stages
-// of 32 k (64-byte rows, 16 KB per stage at 128 x 128) = 64 KB, two workgroups per CU as before.
+// Why (profiles/r06_conv_bf16_pmc.md, profiles/EXPERIMENTS.md round 6 (3)): in the register-staged kernel above a wave spends 52 % of its cycles
+// parked in s_waitcnt / s_barrier, and a second register set for a deeper look-ahead spills.  LDS-DMA needs no staging registers.  What it needs is
+// WHOLE CACHE LINES per request: a first ring of four 32-k stages (64-byte rows) asked the L2 for every 128-byte line twice, a stage apart, and ran
+// no faster than the register-staged kernel; 128-byte rows in two stages (64 KB at 128 x 128, two workgroups per CU) are 13 - 16 % faster on the
+// layer3 / layer4 shapes, and the 16 x 16 x 32 MFMA shape -- same cycles per FLOP, higher clock held (MI355X_MICROARCH.md 'DVFS give-back' (7)) --
+// another 5 - 8 % on the 3x3 ones.
 //   * a DMA wave-instruction writes 64 lanes x 16 bytes = 1 KiB of LDS LINEARLY (M0 base + 16 lane) from PER-LANE source offsets: lane i lands in
-//     row i >> 2, 16-byte slot i & 3 of a 16-row piece.  The rows cannot be padded, so the bank spread comes from the SOURCE: slot p of row R holds
-//     the row's logical piece p ^ ((R >> 2) & 3), and the fragment reads (row = lane & 31, logical piece 2 q + h) apply the same XOR: every
-//     ds_read_b128 quarter-wave touches all 64 banks once;
+//     row i >> 3, 16-byte slot i & 7 of an 8-row piece.  The rows cannot be padded, so the bank spread comes from the SOURCE: slot p of row R holds
+//     the row's logical piece p ^ ((R >> 1) & 7), and the fragment reads (row = lane & 15, logical piece 4 q + (lane >> 4)) apply the same XOR: the
+//     16 lanes a ds_read_b128 serves per LDS cycle ({0-3, 12-15, 20-27}, ...) land on 16 distinct 16-byte columns of the 256-byte bank row;
 //   * out-of-range offsets (padding taps, row tails, channel tails: bit 31) make the DMA write ZEROS (measured: tools/microbench/lds_dma_oob.hip), so
 //     the 32-bit offset scheme of the register-staged loader carries over unchanged;
 //   * a stage is ready when every wave has waited for ITS pieces (counted s_waitcnt vmcnt: the younger stages stay in flight) and the workgroup has
 //     met at ONE raw s_barrier, which also retires the stage read an iteration ago -- its buffer is the one the next request targets.
-constexpr int kDmBK = 32;                 // k per stage: 64-byte rows
-constexpr int kDmNS = 4;                  // stages in the ring
+#ifndef LEC_BF_DBG
+#define LEC_BF_DBG 0                      // 1 / 2: what-if builds for tools/whatif_conv_bf16.sh (wrong results by design); the product build is 0
+#endif
+constexpr int kLnBK = 64;                 // k per stage: 128-byte rows, one cache line per request
 typedef __attribute__((address_space(3))) void lds_void;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -408,6 +412,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else static_assert(N < 0, "add the count");
 }
 __device__ __forceinline__ void lds_barrier() {                // LDS traffic of this wave is done; meet the workgroup (vmcnt untouched)
@@ -416,16 +421,20 @@ __device__ __forceinline__ void lds_barrier() {                // LDS traffic of
   asm volatile("" ::: "memory");
 }
 
-template <int WM, int WN, int TM, bool STATS, bool FOLD>
+template <int WM, int WN, int TM, bool STATS, bool FOLD, int NS>
 __device__ __forceinline__ void bf16_act_dma_body(const unsigned short* __restrict__ src, const unsigned short* __restrict__ wgt,
                                                   unsigned short* __restrict__ dst, const ActGeo& g, float* __restrict__ part, const BfFuse& fz,
                                                   const int bx, const int gdx, const int by) {
-  static_assert(WM * WN == 4 && !(FOLD && STATS), "four waves; one statistics epilogue at a time");
+  static_assert((WM * WN == 4 || WM * WN == 8) && !(FOLD && STATS), "four or eight waves; one statistics epilogue at a time");
+  static_assert(NS == 2 || NS == 3, "two or three stages");
+  constexpr int NW = WM * WN;
   constexpr int TN = 2;
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  constexpr int PA = BM / 16 / 4, PB = BN / 16 / 4;           // DMA pieces (16 rows x 64 B) of A / B per wave and stage
+  constexpr int BKS = kLnBK, RB = 2 * BKS;                    // a stage's row: 64 k = 128 bytes
+  constexpr int RPP = 1024 / RB;                              // rows per DMA piece
+  constexpr int PA = BM / RPP / NW, PB = BN / RPP / NW;       // DMA pieces (1 KiB) of A / B per wave and stage
   constexpr int IPW = PA + PB;                                // DMA instructions per wave and stage
-  constexpr int SA = BM * 64, SB = BN * 64;                   // bytes of a stage's A / B image
+  constexpr int SA = BM * RB, SB = BN * RB;                   // bytes of a stage's A / B image
   constexpr int SS = SA + SB;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   char* const lds = (char*)smem;
@@ -433,19 +442,22 @@ __device__ __forceinline__ void bf16_act_dma_body(const unsigned short* __restri
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave / WN) * 32 * TM, wn0 = (wave % WN) * 32 * TN;
   const int n0 = by * BN;
-  const int nst = g.Kg / kDmBK;                                // stages per tile (Cs % 32 == 0: a stage lies inside one tap)
+  const int nst = g.Kg / BKS;                                  // stages per tile (Cs % BKS == 0: a stage lies inside one tap)
   const int mtiles = (g.Mg + BM - 1) / BM;
   const rsrc_t rs_src = make_rsrc(src, g.src_bytes), rs_wgt = make_rsrc(wgt, g.wgt_bytes), rs_dst = make_rsrc(dst, g.dst_bytes);
   const int rsc = g.RS * g.Cs;
-  // DMA side: this lane's row inside a piece and its logical 16-byte slot (the XOR of the image, applied to the SOURCE)
-  const int prow = lane >> 2, pslot = (lane & 3) ^ ((lane >> 4) & 3);
+  // DMA side: this lane's row inside a piece and its logical 16-byte slot (the XOR of the image, applied to the SOURCE): row R = 8 piece + (lane >> 3)
+  const int prow = lane >> 3;
+  auto pslot_of = [&](int piece) { return (lane & 7) ^ (((8 * piece + (lane >> 3)) >> 1) & 7); };
   unsigned wB[PB];
 #pragma unroll
-  for (int u = 0; u < PB; ++u) { const int co = n0 + 16 * (wave + 4 * u) + prow; wB[u] = co < g.Cd ? (unsigned)(co * rsc + 8 * pslot) * 2u : kOob; }
-  // fragment side: byte offset of (row lane & 31, logical slot 2 q + h) inside an image
-  const int l31 = lane & 31, h = lane >> 5;
-  const int fswz = (l31 >> 2) & 3;
-  const unsigned fo0 = (unsigned)(l31 * 64 + 16 * ((0 + h) ^ fswz)), fo1 = (unsigned)(l31 * 64 + 16 * ((2 + h) ^ fswz));
+  for (int u = 0; u < PB; ++u) { const int co = n0 + RPP * (wave + NW * u) + prow; wB[u] = co < g.Cd ? (unsigned)(co * rsc + 8 * pslot_of(wave + NW * u)) * 2u : kOob; }
+  // fragment side (v_mfma_f32_16x16x32_bf16: row lane & 15, k = 8 (lane >> 4) ... + 7 of a 32-k step): byte offset of (row, logical slot 4 q + (lane >> 4))
+  // inside an image; the blocks start at multiples of 16 rows, which leave the XOR term alone
+  const int l15 = lane & 15, h4 = lane >> 4;
+  unsigned fo16[BKS / 32];
+#pragma unroll
+  for (int q = 0; q < BKS / 32; ++q) fo16[q] = (unsigned)(l15 * RB + 16 * ((4 * q + h4) ^ ((l15 >> 1) & 7)));
   const bool dense_dst = g.dst_st == 1;
   const int ntaps = g.na * g.nb;
   const int cc = lane & 7, r0 = lane >> 3;
@@ -467,12 +479,12 @@ __device__ __forceinline__ void bf16_act_dma_body(const unsigned short* __restri
     int rowoff[PA]; unsigned tapmask[PA];
 #pragma unroll
     for (int u = 0; u < PA; ++u) {
-      const int m = m0 + 16 * (wave + 4 * u) + prow;
+      const int m = m0 + RPP * (wave + NW * u) + prow;
       const bool live = m < g.Mg;
       const int mm = live ? m : 0;
       const int t2 = fdiv(mm, g.dWm); const int mw = mm - t2 * g.Wm; const int n = fdiv(t2, g.dHm); const int mh = t2 - n * g.Hm;
       const int hb_ = mh * g.sst + g.oh0, wb_ = mw * g.sst + g.ow0;
-      rowoff[u] = (((n * g.Hs + hb_) * g.Ws + wb_) << g.lgCs) * 2 + 16 * pslot;
+      rowoff[u] = (((n * g.Hs + hb_) * g.Ws + wb_) << g.lgCs) * 2 + 16 * pslot_of(wave + NW * u);
       unsigned msk = 0;
       for (int t = 0; t < ntaps; ++t) {
         const int ta = fdiv(t, g.dnb), tb = t - ta * g.nb;
@@ -481,18 +493,18 @@ __device__ __forceinline__ void bf16_act_dma_body(const unsigned short* __restri
       }
       tapmask[u] = live ? msk : 0u;
     }
-    f32x16 acc[TN][TM];
+    f32x4v acc16[2 * TN][2 * TM];                               // the wave's 64-channel x 32 TM-pixel tile as 16 x 16 blocks
 #pragma unroll
-    for (int jt = 0; jt < TN; ++jt)
+    for (int jb = 0; jb < 2 * TN; ++jb)
 #pragma unroll
-      for (int it = 0; it < TM; ++it)
+      for (int ib = 0; ib < 2 * TM; ++ib)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[jt][it][r] = 0.f;
+        for (int r = 0; r < 4; ++r) acc16[jb][ib][r] = 0.f;
 
     unsigned cur[PA];
     int cur_tap = -1;
-    auto issue = [&](int st) {                                  // request stage st into ring slot st % kDmNS
-      const int k0 = st * kDmBK;
+    auto issue = [&](int st) {                                  // request stage st into ring slot st % NS
+      const int k0 = st * BKS;
       const int tap = k0 >> g.lgCs, c0 = k0 & (g.Cs - 1);
       const int ta = fdiv(tap, g.dnb), tb = tap - ta * g.nb;
       if (tap != cur_tap) {
@@ -505,29 +517,28 @@ __device__ __forceinline__ void bf16_act_dma_body(const unsigned short* __restri
       const int tw = (g.r0 + g.rstep * ta) * g.S + g.s0 + g.sstep * tb;
       const unsigned wsc = (unsigned)(tw * g.Cs + c0) * 2u;
       const unsigned c0b = (unsigned)c0 * 2u;
-      char* base = lds + (st & (kDmNS - 1)) * SS;
+      char* base = lds + (st % NS) * SS;
 #pragma unroll
       for (int u = 0; u < PA; ++u)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(base + (wave + 4 * u) * 1024), 16, (int)(cur[u] + c0b), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (lds_void*)(base + (wave + NW * u) * 1024), 16, (int)(cur[u] + c0b), 0, 0, 0);
 #pragma unroll
       for (int u = 0; u < PB; ++u)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_void*)(base + SA + (wave + 4 * u) * 1024), 16, (int)(wB[u] + wsc), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (lds_void*)(base + SA + (wave + NW * u) * 1024), 16, (int)(wB[u] + wsc), 0, 0, 0);
     };
     auto compute = [&](int st) {
-      const char* sA = lds + (st & (kDmNS - 1)) * SS;
+      const char* sA = lds + (st % NS) * SS;
       const char* sB = sA + SA;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const unsigned fo = q ? fo1 : fo0;
-        bfrag xa[TM], wb_[TN];
+      for (int q = 0; q < BKS / 32; ++q) {
+        bfrag xa[2 * TM], wb_[2 * TN];
 #pragma unroll
-        for (int it = 0; it < TM; ++it) xa[it] = *(const bfrag*)(sA + (wm0 + it * 32) * 64 + fo);
+        for (int ib = 0; ib < 2 * TM; ++ib) xa[ib] = *(const bfrag*)(sA + (wm0 + ib * 16) * RB + fo16[q]);
 #pragma unroll
-        for (int jt = 0; jt < TN; ++jt) wb_[jt] = *(const bfrag*)(sB + (wn0 + jt * 32) * 64 + fo);
+        for (int jb = 0; jb < 2 * TN; ++jb) wb_[jb] = *(const bfrag*)(sB + (wn0 + jb * 16) * RB + fo16[q]);
 #pragma unroll
-        for (int jt = 0; jt < TN; ++jt)
+        for (int jb = 0; jb < 2 * TN; ++jb)                     // D'[channel][pixel]: the weights are the A operand
 #pragma unroll
-          for (int it = 0; it < TM; ++it) acc[jt][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb_[jt], xa[it], acc[jt][it], 0, 0, 0);
+          for (int ib = 0; ib < 2 * TM; ++ib) acc16[jb][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb_[jb], xa[ib], acc16[jb][ib], 0, 0, 0);
       }
     };
     u32x4q f_d[FOLD ? 4 * TM : 1], f_x[FOLD ? 4 * TM : 1]; unsigned f_m[FOLD ? 4 * TM : 1];
@@ -549,14 +560,22 @@ __device__ __forceinline__ void bf16_act_dma_body(const unsigned short* __restri
 
     lds_barrier();                                              // the previous tile's epilogue image has been read by every wave: the ring is free
 #pragma unroll
-    for (int st = 0; st < kDmNS - 1; ++st) if (st < nst) issue(st);
+    for (int st = 0; st < NS - 1; ++st) if (st < nst) issue(st);
     for (int c = 0; c < nst; ++c) {
       // stage c has landed for THIS wave once at most the younger stages' requests are outstanding
-      if (c + 2 < nst) wait_vmcnt<2 * IPW>(); else if (c + 1 < nst) wait_vmcnt<IPW>(); else wait_vmcnt<0>();
+#if LEC_BF_DBG == 1                                              // what-if build (tools/whatif_conv_bf16.sh): no operand traffic after the ring's first fill
+      if (c == 0) wait_vmcnt<0>();
+      lds_barrier();
+#else
+      if constexpr (NS == 3) { if (c + 1 < nst) wait_vmcnt<IPW>(); else wait_vmcnt<0>(); }
+      else wait_vmcnt<0>();
       lds_barrier();                                            // ... for every wave; and everyone is done reading stage c - 1
-      if (c + kDmNS - 1 < nst) issue(c + kDmNS - 1);             // into the slot stage c - 1 occupied
+      if (c + NS - 1 < nst) issue(c + NS - 1);                   // into the slot stage c - 1 occupied
+#endif
       if (c + 1 == nst) fold_loads();
+#if LEC_BF_DBG != 2                                              // what-if build 2: the operand traffic alone, no LDS reads, no MFMAs
       compute(c);
+#endif
     }
     if (nst == 0) fold_loads();
     lds_barrier();                                              // every wave is done with the last stage: the epilogue image may overwrite the ring
@@ -564,16 +583,14 @@ __device__ __forceinline__ void bf16_act_dma_body(const unsigned short* __restri
     // ---- epilogue (as in the register-staged kernel): D'[channel][pixel] -> per-wave LDS image [32 TM pixels][64 channels] -> 16-byte row segments
     unsigned short* ep = smem + wave * (32 * TM) * kBfLdk;
 #pragma unroll
-    for (int it = 0; it < TM; ++it)
+    for (int ib = 0; ib < 2 * TM; ++ib)                         // a block's lane holds D'[channel 4 (lane >> 4) + reg][pixel lane & 15]
 #pragma unroll
-      for (int jt = 0; jt < TN; ++jt)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          u32x2q pk;
-          pk[0] = pk_bf16(acc[jt][it][4 * gq + 0], acc[jt][it][4 * gq + 1]);
-          pk[1] = pk_bf16(acc[jt][it][4 * gq + 2], acc[jt][it][4 * gq + 3]);
-          *(u32x2q*)(ep + (it * 32 + l31) * kBfLdk + jt * 32 + 8 * gq + 4 * h) = pk;
-        }
+      for (int jb = 0; jb < 2 * TN; ++jb) {
+        u32x2q pk;
+        pk[0] = pk_bf16(acc16[jb][ib][0], acc16[jb][ib][1]);
+        pk[1] = pk_bf16(acc16[jb][ib][2], acc16[jb][ib][3]);
+        *(u32x2q*)(ep + (ib * 16 + l15) * kBfLdk + jb * 16 + 4 * h4) = pk;
+      }
     wave_lds_sync();
     const int c = n0 + wn0 + cc * 8;
     const unsigned coff = c < g.Cd ? (unsigned)c * 2u : kOob;
@@ -641,7 +658,7 @@ __device__ __forceinline__ void bf16_act_dma_body(const unsigned short* __restri
       }
     }
     lds_barrier();
-    for (int i = tid; i < 2 * BN; i += kBfThreads) {
+    for (int i = tid; i < 2 * BN; i += 64 * NW) {
       const int sidx = i / BN, cidx = i - sidx * BN;
       float v = 0.f;
 #pragma unroll
@@ -651,16 +668,16 @@ __device__ __forceinline__ void bf16_act_dma_body(const unsigned short* __restri
   }
 }
 
-template <int WM, int WN, int TM, bool STATS, bool FOLD>
-__global__ __launch_bounds__(kBfThreads, 2) void conv_bf16_act_dma_kernel(const unsigned short* __restrict__ src, const unsigned short* __restrict__ wgt,
+template <int WM, int WN, int TM, bool STATS, bool FOLD, int NS>
+__global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_bf16_act_dma_kernel(const unsigned short* __restrict__ src, const unsigned short* __restrict__ wgt,
                                                                           unsigned short* __restrict__ dst, ActGeo g, float* __restrict__ part, BfFuse fz) {
-  bf16_act_dma_body<WM, WN, TM, STATS, FOLD>(src, wgt, dst, g, part, fz, blockIdx.x, gridDim.x, blockIdx.y);
+  bf16_act_dma_body<WM, WN, TM, STATS, FOLD, NS>(src, wgt, dst, g, part, fz, blockIdx.x, gridDim.x, blockIdx.y);
 }
-template <int WM, int WN, int TM>
+template <int WM, int WN, int TM, int NS>
 __global__ __launch_bounds__(kBfThreads, 2) void conv_bf16_act_dma_classes_kernel(const unsigned short* __restrict__ src, const unsigned short* __restrict__ wgt,
                                                                                   unsigned short* __restrict__ dst, ActGeoSet gs) {
   const ActGeo g = gs.g[blockIdx.z];
-  bf16_act_dma_body<WM, WN, TM, false, false>(src, wgt, dst, g, nullptr, BfFuse{}, blockIdx.x, gridDim.x, blockIdx.y);
+  bf16_act_dma_body<WM, WN, TM, false, false, NS>(src, wgt, dst, g, nullptr, BfFuse{}, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -886,12 +903,24 @@ static int launch_bf16_act(const unsigned short* src, const unsigned short* wgt,
   const size_t lds = (size_t)2 * (BM + BN) * kBfLdk * 2;
   const dim3 grid(gx, ntiles), blk(kBfThreads);
   ActGeo gg = g; gg.xcd_per = 0;
-  if (!tapv && tuning().bf_dma && g.Cs % kDmBK == 0) {
-    // the LDS-DMA ring: max(ring, epilogue image) bytes of LDS
-    const size_t ring = (size_t)kDmNS * (BM + BN) * 64, epi = (size_t)4 * (narrow ? 32 : 64) * kBfLdk * 2;
-    const size_t ldsd = ring > epi ? ring : epi;
-    if (narrow) hipLaunchKernelGGL((conv_bf16_act_dma_kernel<4, 1, 1, STATS, FOLD>), grid, blk, ldsd, st, src, wgt, dst, gg, part, fz);
-    else hipLaunchKernelGGL((conv_bf16_act_dma_kernel<2, 2, 2, STATS, FOLD>), grid, blk, ldsd, st, src, wgt, dst, gg, part, fz);
+  if (!tapv && tuning().bf_dma) {
+    // A 1x1 layer with exactly 256 destination channels takes ONE 128 x 256 column tile (eight waves, one workgroup per CU, three stages): its activations are
+    // read once instead of twice and its K loop is too short to miss the second workgroup (same-box table in profiles/EXPERIMENTS.md round 6 (3): -8 ... -27 %
+    // on those layers, +5 ... +19 % on the 3x3 and wider ones).  LEC_BF16_TILE: 1 = that rule (default), 0 = 128 x 128 always, 2 = 128 x 256 wherever the layer
+    // has >= 256 destination channels.
+    const int bt = tuning().bf_tile;
+    if (!narrow && ((bt == 1 && g.Cd == 256 && g.na * g.nb == 1) || (bt == 2 && g.Cd >= 256))) {
+      const int BM2 = 128, BN2 = 256;
+      const int mt2 = (g.Mg + BM2 - 1) / BM2, nt2 = (g.Cd + BN2 - 1) / BN2;
+      int gx2 = (256 / nt2) & ~7; if (gx2 < 8) gx2 = 8; if (gx2 > mt2) gx2 = mt2;
+      hipLaunchKernelGGL((conv_bf16_act_dma_kernel<2, 4, 2, STATS, FOLD, 3>), dim3(gx2, nt2), dim3(512), (size_t)3 * (BM2 + BN2) * 2 * kLnBK, st, src, wgt, dst, gg, part, fz);
+      if (nparts) *nparts = gx2;
+      LEC_CHECK_LAUNCH("conv_bf16_act_dma_kernel");
+      return LEC_OK;
+    }
+    // two workgroups per CU: 2 stages x 32 KiB (128 x 128), 3 stages x 24 KiB (128 x 64); the epilogue image is smaller than either ring
+    if (narrow) hipLaunchKernelGGL((conv_bf16_act_dma_kernel<4, 1, 1, STATS, FOLD, 3>), grid, blk, (size_t)3 * (BM + BN) * 2 * kLnBK, st, src, wgt, dst, gg, part, fz);
+    else hipLaunchKernelGGL((conv_bf16_act_dma_kernel<2, 2, 2, STATS, FOLD, 2>), grid, blk, (size_t)2 * (BM + BN) * 2 * kLnBK, st, src, wgt, dst, gg, part, fz);
     if (nparts) *nparts = gx;
     LEC_CHECK_LAUNCH("conv_bf16_act_dma_kernel");
     return LEC_OK;
@@ -1020,10 +1049,8 @@ extern "C" int lec_conv_bf16_dgrad(const void* dy, const void* wt, int N, int H,
     if (gx > cap) gx = cap;
     const size_t lds = (size_t)2 * (BM + BN) * kBfLdk * 2;
     if (tuning().bf_dma) {
-      const size_t ring = (size_t)kDmNS * (BM + BN) * 64, epi = (size_t)4 * (narrow ? 32 : 64) * kBfLdk * 2;
-      const size_t ldsd = ring > epi ? ring : epi;
-      if (narrow) hipLaunchKernelGGL((conv_bf16_act_dma_classes_kernel<4, 1, 1>), dim3(gx, ntiles, ncls), dim3(kBfThreads), ldsd, st, src, wg, dst, gs);
-      else hipLaunchKernelGGL((conv_bf16_act_dma_classes_kernel<2, 2, 2>), dim3(gx, ntiles, ncls), dim3(kBfThreads), ldsd, st, src, wg, dst, gs);
+      if (narrow) hipLaunchKernelGGL((conv_bf16_act_dma_classes_kernel<4, 1, 1, 3>), dim3(gx, ntiles, ncls), dim3(kBfThreads), (size_t)3 * (BM + BN) * 2 * kLnBK, st, src, wg, dst, gs);
+      else hipLaunchKernelGGL((conv_bf16_act_dma_classes_kernel<2, 2, 2, 2>), dim3(gx, ntiles, ncls), dim3(kBfThreads), (size_t)2 * (BM + BN) * 2 * kLnBK, st, src, wg, dst, gs);
     }
     else if (narrow) hipLaunchKernelGGL((conv_bf16_act_classes_kernel<4, 1, 1>), dim3(gx, ntiles, ncls), dim3(kBfThreads), lds, st, src, wg, dst, gs);
     else hipLaunchKernelGGL((conv_bf16_act_classes_kernel<2, 2, 2>), dim3(gx, ntiles, ncls), dim3(kBfThreads), lds, st, src, wg, dst, gs);

@@ -91,7 +91,8 @@ def test_conv_bf16_stem_three_channel_weight_gradient_slot():
 
 
 @pytest.mark.parametrize('N,C,H,W,Cout,R,relu,res', [(2, 128, 8, 8, 128, 3, True, True), (3, 256, 5, 7, 64, 1, True, False), (2, 64, 8, 8, 64, 3, True, True),
-                                                    (2, 512, 4, 4, 128, 1, False, True), (2, 64, 6, 6, 256, 1, True, True), (33, 128, 12, 12, 128, 3, True, False)])
+                                                    (2, 512, 4, 4, 128, 1, False, True), (2, 64, 6, 6, 256, 1, True, True), (33, 128, 12, 12, 128, 3, True, False),
+                                                    (5, 256, 9, 9, 1024, 1, True, True)])      # 256 destination channels, 1x1: the 128 x 256 eight-wave tile
 def test_conv_bf16_dgrad_fold_is_pass1_of_the_batchnorm_backward(N, C, H, W, Cout, R, relu, res):
     """lec_conv_bf16_dgrad with the fold: g = mask * (dx + dres) rounded to bf16 and the partial sums (sum g, sum g xhat) -- what lec_bn_bwd_pass1 computes
     from the unfused data gradient."""
