@@ -284,6 +284,9 @@ GEMM_DGRAD_MIN_CIN = 256
 # left on the 16-bit path.  '1' (default): special-case kernels where they exist, the family elsewhere; '2': the family everywhere (A/B runs);
 # '0': the library (MIOpen / CK / hipBLASLt) for everything the special cases do not serve, as until round 5 (A/B runs only).
 CONV_BF16 = os.environ.get('LEC_CONV_BF16', '1')
+# 1x1 data gradients on maps of <= 28 x 28 pixels with >= 128 channels on both sides: the family's whole-line LDS-DMA kernel instead of the round-1 1x1 kernel
+# (same-box table at 256 rows, profiles/EXPERIMENTS.md round 6 (3): 48.8 vs 71.0 us at 512 -> 128, 57.6 vs 82.1 at 128 -> 512; the larger maps stay: 142 vs 113 at 56 x 56)
+FAMILY_DGRAD_SMALL_MAPS = os.environ.get('LEC_FAMILY_DGRAD_SMALL_MAPS', '1') == '1'
 # Convolutions / GEMMs handed to a LIBRARY (aten.convolution, aten.convolution_backward, torch.mm) by this module since the last reset, by direction.
 # A step captured into a hipGraph counts once, at capture.  bench.py prints it per step; the fp32 and bf16 config tests assert zero.
 LIBRARY_LAUNCHES = {'fwd': 0, 'dgrad': 0, 'wgrad': 0}
@@ -579,7 +582,8 @@ class _OverlapConvFn(torch.autograd.Function):
                     gx = gx[:, :3]
             elif ctx.own3 and nhwc_g:                             # dX = conv(dY, W flipped and transposed): the same kernel,
                 gx = _ops().conv3x3_c64(gy, w16, w_transposed=True)   # which flips / transposes the weight as it loads it
-            elif (ctx.own and nhwc_g and _ops().conv1x1_supported(conv.out_channels, conv.in_channels, gy.shape[0] * gy.shape[2] * gy.shape[3])):
+            elif (ctx.own and nhwc_g and not (FAMILY_DGRAD_SMALL_MAPS and ctx.gen and gy.shape[2] * gy.shape[3] <= 784 and conv.out_channels % 64 == 0 and min(conv.in_channels, conv.out_channels) >= 128)
+                  and _ops().conv1x1_supported(conv.out_channels, conv.in_channels, gy.shape[0] * gy.shape[2] * gy.shape[3])):
                 n, _, h, wd = gy.shape                          # dX = dY * W: the same kernel, W transposed as it is loaded
                 ops = _ops()
                 fork = ops.fusion().forks.get(x.data_ptr()) if ops.FOLD_BN_BWD else None

@@ -1,7 +1,7 @@
 """Per-layer timing of the bf16 convolution family (csrc/conv_bf16.hip) on the ResNet-50 layer shapes at `--rows` images, next to the library
 kernels the 16-bit step used until round 5 (aten.convolution / convolution_backward = MIOpen / CK / hipBLASLt) and, where one exists, the round-1
 special-case kernel (conv1x1 / conv3x3_c64).  Prints microseconds per launch and the algorithmic HBM rate (2 B x (input + output elements)).
-    python tools/bench_conv_bf16.py [--rows 512] [--iters 20] [--no-lib] [--json out.json]"""
+    python tools/bench_conv_bf16.py [--rows 512] [--iters 20] [--no-lib] [--special] [--json out.json]"""
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -40,7 +40,7 @@ def timeit(fn, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--rows', type=int, default=512); ap.add_argument('--iters', type=int, default=20)
-    ap.add_argument('--no-lib', action='store_true'); ap.add_argument('--json', default=None); ap.add_argument('--only', default=None)
+    ap.add_argument('--no-lib', action='store_true'); ap.add_argument('--special', action='store_true'); ap.add_argument('--json', default=None); ap.add_argument('--only', default=None)
     a = ap.parse_args()
     dev = 'cuda'
     rows = []
@@ -62,6 +62,25 @@ def main():
             wt = ops.conv_bf16_wt(w)
             t_d = timeit(lambda: ops.conv_bf16_dgrad(dy, wt, x.shape, st, pd), a.iters)
         t_w = timeit(lambda: ops.conv_bf16_wgrad(dy, x, dw, st, pd), a.iters)
+        # the round-1 special-case kernels where they serve the shape (1x1 stride 1: conv1x1_*; 3x3 stride 1 at 64 / 128 channels: conv3x3_c64)
+        s_f = s_d = s_w = float('nan')
+        M = N * ho * ho
+        if a.special and r == 1 and st == 1:
+            xr = x.permute(0, 2, 3, 1).reshape(M, cin); dyr = dy.permute(0, 2, 3, 1).reshape(M, cout); w2 = w.view(cout, cin)
+            if ops.conv1x1_supported(cin, cout, M):
+                s_f = timeit(lambda: ops.conv1x1_rows(xr, w2, want_stats=True), a.iters); ops._BN_WS_OWNER[0] = 0
+            if ops.conv1x1_supported(cout, cin, M):
+                s_d = timeit(lambda: ops.conv1x1_rows(dyr, w2, w_transposed=True), a.iters)
+            if ops.conv1x1_wgrad_supported(cin, cout, M):
+                dw2 = torch.zeros(cout, cin, device=dev)
+                s_w = timeit(lambda: ops.conv1x1_wgrad_rows(dyr, xr, dw2), a.iters)
+        if a.special and r == 3 and st == 1 and cin == cout and cin in (64, 128):
+            s_f = timeit(lambda: ops.conv3x3_c64(x, w, want_stats=True), a.iters); ops._BN_WS_OWNER[0] = 0
+            s_d = timeit(lambda: ops.conv3x3_c64(dy, w, w_transposed=True), a.iters)
+            if cin == 64:
+                s_w = timeit(lambda: ops.conv3x3_c64_wgrad(dy, x, dw), a.iters)
+        if a.special:
+            print('%-24s %9.1f %9.1f %9.1f   (special-case kernels)' % ('', s_f, s_d, s_w))
         l_f = l_d = l_w = float('nan')
         if not a.no_lib:
             l_f = timeit(lambda: torch.ops.aten.convolution(x, w, None, [st, st], [pd, pd], [1, 1], False, [0, 0], 1), a.iters)
@@ -75,7 +94,7 @@ def main():
         for k, v in (('own_fwd', t_f), ('own_dgrad', t_d), ('own_wgrad', t_w), ('lib_fwd', l_f), ('lib_dgrad', l_d), ('lib_wgrad', l_w)):
             if v == v:
                 tot[k] += c * v
-        rows.append({'layer': name, 'count': c, 'own_us': [t_f, t_d, t_w], 'lib_us': [l_f, l_d, l_w], 'io_bytes': bytes_io})
+        rows.append({'layer': name, 'count': c, 'own_us': [t_f, t_d, t_w], 'special_us': [s_f, s_d, s_w], 'lib_us': [l_f, l_d, l_w], 'io_bytes': bytes_io})
         del x, w, dy, dw
     print('network totals (ms, layer counts applied): ' + ', '.join('%s %.2f' % (k, v / 1000.0) for k, v in tot.items()))
     if a.json:
