@@ -497,7 +497,7 @@ int lec_conv_f32x3_wgrad(const float* dy, const float* x, int N, int H, int W, i
 /* ---------------------------------------------------------------------------------------------------------------
  * (7d) The ResNet convolutions on bf16 activations (csrc/conv_bf16.hip): BASELINE config 5's 16-bit conv stack -- torchvision's resnet50
  *     inside FeatCNN (oe_h.py:331-351; finetuner.py:122 for the classifier experiments) -- as ONE implicit-GEMM family on
- *     v_mfma_f32_32x32x16_bf16, fp32 accumulation: every layer shape, stride (1, 2) and direction; no library convolution is left on the
+ *     v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16, fp32 accumulation: every layer shape, stride (1, 2) and direction; no library convolution is left on the
  *     16-bit path.  Tensors NHWC bf16: x [N, H, W, Cin], y [N, Ho, Wo, Cout]; weights w [Cout][R*S][Cin] bf16 (a channels_last
  *     [Cout, Cin, R, S] tensor); Cin, Cout powers of two >= 8 (the 3-channel stem: x and w carry zero channels 3..7); tensors < 2 GiB.
  *     lec_conv_bf16_fwd: `partials` (optional, >= 512 * 2 * Cout floats) receives n_partials (HOST int) rows of per-channel
