@@ -974,6 +974,13 @@ def main():
                                               'note': '`achieved` / `frac` use the FIRST: HIP events around the launch inside the step (the interval includes the launch gap and whatever the previous kernel leaves draining); '
                                                       'isolated_graph_replay: the launch alone, replayed back to back from a hipGraph (tools/bench_cone.py); rocprof_kernel_duration: the kernel\'s own start-to-end time under rocprofv3 --kernel-trace (profiles/r06_cone_pmc.md)'},
                      'note': 'at the north-star size (B=%d, K=%d, D=%d: %.2f MB per launch) the launch is latency-bound, not HBM-bound; see roofline_stress' % (B, K, D, ab / 1e6)}
+        if eng.cnn_chunk:
+            # say what this object describes for a chunked step -- a whole-batch launch timed alone, not one of the step's windowed launches
+            n_win = eng.n_rows_pad // eng.cnn_chunk
+            roof_cone['launch_time_bases_us']['in_step_event_interval'] = None
+            roof_cone['note'] += ('; CHUNKED STEP: the step runs %d windowed launches of this kernel (one per row window, inside the chunks\' graphs, each walking all %d pairs and '
+                                  'computing the ones whose image row it owns); the figures here are ONE whole-batch launch of the same shape timed alone (tools/bench_cone.py), a proxy: '
+                                  'the windowed launches cannot carry events inside a replayed graph' % (n_win, B * (1 + 2 * K)))
         f32 = args.dtype == 'fp32'
         dominant = res['roofline_conv'] if (f32 and res['roofline_conv'] is not None) else (res['roofline_bn'] or roof_cone)
         out = {'metric': 'images/sec (joint CNN+cone-loss step)', 'value': res['value'], 'unit': 'images/sec',
