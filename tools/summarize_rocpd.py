@@ -58,7 +58,7 @@ for k, (d, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:a.top]:
 # ---- kernel FAMILIES: sum of launch durations AND the union of their launch intervals (launches of a family overlap when the step runs as
 # concurrent passes / streams: the sum then counts shared time once per stream, the union is the time the family had the GPU at all)
 def family(k):
-    if 'conv_f32' in k or 'conv1x1' in k or 'conv3x3' in k or 'wgrad' in k: return 'convolutions (conv_f32.hip / conv_mfma.hip / conv_f32x3.hip)'
+    if 'conv_f32' in k or 'conv_bf16' in k or 'conv1x1' in k or 'conv3x3' in k or 'wgrad' in k or 'wt_transpose' in k: return 'convolutions (conv_f32.hip / conv_bf16.hip / conv_mfma.hip / conv_f32x3.hip)'
     if 'lec::bn_' in k or 'lec::bn' in k: return 'BatchNorm family (bn.hip)'
     if 'joint_loss' in k: return 'fused cone loss (joint_loss.hip)'
     if 'lec::' in k: return 'other liblecone kernels'
