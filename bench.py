@@ -1003,6 +1003,8 @@ def main():
                'roofline_cnn': res['roofline_cnn'],
                # convolutions / GEMMs this step handed to a LIBRARY (MIOpen / CK / hipBLASLt) instead of liblecone's kernels (counted on the engine's first, eager step)
                'library_conv_launches_per_step': res.get('library_conv_launches_per_step'),
+               # every convolution / GEMM this process handed to MIOpen / hipBLASLt through resnet.py so far, in steps, probes and helper forwards alike (the FLOP-counting walk used to run one)
+               'library_conv_launches_whole_run': __import__('learning_embeddings_amd.resnet', fromlist=['x']).LIBRARY_LAUNCHES_TOTAL[0],
                'sampler_us_per_negative': round(sampler_us, 4), 'allreduce_ms': res['allreduce_ms'],
                # gradient exchange time the step does NOT hide: graph launch mode reduces every bucket in one sweep after the replay (all of it exposed);
                # eager launches reduce bucket by bucket from backward hooks and this is the wait for the last handles

@@ -289,7 +289,7 @@ CONV_BF16 = os.environ.get('LEC_CONV_BF16', '1')
 FAMILY_DGRAD_SMALL_MAPS = os.environ.get('LEC_FAMILY_DGRAD_SMALL_MAPS', '1') == '1'
 # Convolutions / GEMMs handed to a LIBRARY (aten.convolution, aten.convolution_backward, torch.mm) by this module since the last reset, by direction.
 # A step captured into a hipGraph counts once, at capture.  bench.py prints it per step; the fp32 and bf16 config tests assert zero.
-LIBRARY_LAUNCHES = {'fwd': 0, 'dgrad': 0, 'wgrad': 0}
+LIBRARY_LAUNCHES = {'fwd': 0, 'dgrad': 0, 'wgrad': 0, 'module': 0}
 
 
 def library_launches(reset=False):
@@ -300,8 +300,12 @@ def library_launches(reset=False):
     return n
 
 
+LIBRARY_LAUNCHES_TOTAL = [0]   # never reset: every library convolution / GEMM of the process, inside steps or not (bench.py prints it)
+
+
 def _lib_launch(kind):
     LIBRARY_LAUNCHES[kind] += 1
+    LIBRARY_LAUNCHES_TOTAL[0] += 1
 
 
 def _ops():
@@ -376,6 +380,9 @@ def _from_rows(m, n, h, w):
     return m.view(n, h, w, m.shape[1]).permute(0, 3, 1, 2)
 
 
+_WALK_MODULES = False       # conv_macs(): every convolution through its module's forward (hooks), none through the fused conv + BatchNorm call
+
+
 def _inference_f32(conv, x):
     """An fp32 channels_last CUDA forward that nobody will differentiate, of a layer lec_conv_f32_* serve."""
     return (MFMA_F32 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.weight.dtype == torch.float32
@@ -386,7 +393,7 @@ def _inference_f32(conv, x):
 def conv_bn(conv, bn, x, residual=None, fork=False):
     """bn(conv(x) [, residual]) -- in an eval-mode fp32 inference forward as ONE kernel: the BatchNorm is a per-channel affine map of its
     running statistics and runs, with the residual add and the ReLU, in the convolution's epilogue (lec_conv_f32_fwd_affine)."""
-    if (not bn.training and BatchNormAct2d.fused_enabled and isinstance(conv, Conv2d) and _inference_f32(conv, x) and bn.weight.dtype == torch.float32
+    if (not bn.training and not _WALK_MODULES and BatchNormAct2d.fused_enabled and isinstance(conv, Conv2d) and _inference_f32(conv, x) and bn.weight.dtype == torch.float32
             and bn.running_mean is not None and bn.running_mean.dtype == torch.float32
             and (residual is None or (residual.dtype == x.dtype and residual.is_contiguous(memory_format=torch.channels_last)))):
         scale, shift = bn.eval_affine()
@@ -643,6 +650,10 @@ class Conv2d(nn.Conv2d):
             if self.in_channels == 3:
                 x, w = _pad_c4(x), _pad_c4(w)
             return _ops().conv_f32_fwd(x, w, self.stride[0], self.padding[0], want_stats=self.training)
+        if x.is_cuda:
+            _lib_launch('module')                               # nn.Conv2d's own forward (and autograd's backward behind it): MIOpen
+            if os.environ.get('LEC_TRACE_LIBCONV'):
+                import traceback; traceback.print_stack(limit=14)
         return super().forward(x)
 
 
@@ -856,16 +867,16 @@ def conv_macs(model, hw):
             hooks.append(m.register_forward_hook(conv_hook))
         elif isinstance(m, nn.Linear):
             hooks.append(m.register_forward_hook(fc_hook))
-    global MFMA_F32
-    was, own = model.training, MFMA_F32
+    global _WALK_MODULES
+    was = model.training
     model.eval()
-    MFMA_F32 = False                                            # the inference forward calls liblecone directly (conv_bn): walk the MODULES
-    try:
+    _WALK_MODULES = True                                        # the inference forward calls liblecone's fused conv + affine kernel directly (conv_bn): walk the MODULES
+    try:                                                        # instead -- each Conv2d.forward still runs liblecone's kernel on the GPU (no library convolution for a FLOP count)
         with torch.no_grad():
             dev = next(model.parameters()).device
-            model(torch.zeros(1, 3, hw, hw, device=dev, dtype=next(model.parameters()).dtype))
+            model(torch.zeros(1, 3, hw, hw, device=dev, dtype=next(model.parameters()).dtype).contiguous(memory_format=torch.channels_last))
     finally:
-        MFMA_F32 = own
+        _WALK_MODULES = False
         model.train(was)
     for h in hooks:
         h.remove()

@@ -548,9 +548,12 @@ def test_conv_macs_walks_the_modules_on_the_gpu_too():
     """bench.py's analytic flops come from resnet.conv_macs, a forward with hooks on the convolution MODULES: the inference forward bypasses
     the modules (conv_bn calls liblecone directly), so the walk must take the module path (it once counted 0.7 instead of 24.5 GFLOP per image)."""
     from learning_embeddings_amd.resnet import conv_macs
+    from learning_embeddings_amd import resnet as R
     net = resnet50(num_classes=10).to(DEV).to(memory_format=torch.channels_last)
+    R.library_launches(reset=True)
     assert abs(conv_macs(net, 224) / 1e9 - 4.0872) < 0.05
     assert net.training
+    assert sum(R.library_launches().values()) == 0, 'the FLOP-counting walk must not hand a convolution to the library (it ran MIOpen\'s naive kernel 53 times until round 6)'
 
 
 # ------------------------------------------------------------------------------------------------ round 3: the balanced (stream-K) kernel
