@@ -1113,6 +1113,7 @@ def test_bench_gpus_2_self_launches_on_one_gpu():
     dp = out['data_parallel']
     assert dp['world_size'] == 2 and dp['replicas_identical_after_run'] is True and len(dp['buckets']) >= 2
     assert out['config']['global_batch'] == 2 * 8 and out['value'] > 0
+    assert out['library_conv_launches_per_step'] == 0 and out['library_conv_launches_whole_run'] == 0, 'no convolution of a bench run may go to a library, in the step or around it'
 
 
 def test_step_engine_concurrent_half_batch_passes_equal_the_same_passes_in_turn():
