@@ -931,7 +931,8 @@ def main():
                                           % (args.workload, res['n_classes'], res['arch'], res['B'], res['hw'], res['hw']),
                               'global_batch': res['B'] * world, 'parallelism': 'dp%d' % world, 'launch_mode': res['launch_mode'],
                               'mean_loss': res['mean_loss'], 'hbm_peak_allocated_gb': res['hbm_peak_allocated_gb']},
-                   'roofline': res['roofline'], 'cpu_baseline': res.get('cpu_baseline'), 'library_conv_launches_per_step': res.get('library_conv_launches_per_step')}
+                   'roofline': res['roofline'], 'cpu_baseline': res.get('cpu_baseline'), 'library_conv_launches_per_step': res.get('library_conv_launches_per_step'),
+                   'library_conv_launches_whole_run': __import__('learning_embeddings_amd.resnet', fromlist=['x']).LIBRARY_LAUNCHES_TOTAL[0]}
             if sec is not None:
                 out['secondary_bf16'] = {'note': 'NARROWER than the reference (bf16 conv stack); not the headline', 'value': sec['value'],
                                          'ms_per_step': sec['ms_per_step'], 'dtype': sec['dtype'], 'roofline': sec['roofline']}

@@ -1013,5 +1013,5 @@ def test_resnet_fp32_forward_backward_above_668_rows_launches_no_library_convolu
     out = net(x)
     out.square().mean().backward()
     torch.cuda.synchronize()
-    assert R.library_launches() == {'fwd': 0, 'dgrad': 0, 'wgrad': 0}, R.library_launches()
+    assert sum(R.library_launches().values()) == 0, R.library_launches()
     assert torch.isfinite(out).all() and all(torch.isfinite(p.grad).all() for p in net.parameters())
