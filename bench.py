@@ -867,7 +867,7 @@ def main():
     ap.add_argument('--no-stress', action='store_true')
     ap.add_argument('--no-overlap-wgrad', action='store_true', help='keep the conv weight-gradient kernels in line')
     ap.add_argument('--overlap-wgrad', action='store_true', default=None, help='weight gradients on their own HIP stream (default: only when the step runs as ONE pass)')
-    ap.add_argument('--passes', type=int, default=None, help='concurrent parts the CNN rows of a step go through the backbone in (default: 2 -- positives | image negatives, one stream and one BatchNorm batch each, the reference's own separate forwards; 1: one forward over all rows)')
+    ap.add_argument('--passes', type=int, default=None, help='concurrent parts the CNN rows of a step go through the backbone in (default: 2 -- positives | image negatives, one stream and one BatchNorm batch each, the two separate forwards of the reference; 1: one forward over all rows)')
     ap.add_argument('--check-replicas', action='store_true', help='(default at N > 1) after the run, assert that every rank holds identical parameters')
     ap.add_argument('--no-check-replicas', action='store_true', help='skip the replica comparison at N > 1')
     ap.add_argument('--compare-exchange', action='store_true', help='(plain `python bench.py --gpus N` on a box with >= N devices) run twice: torch.distributed exchange, then liblecone\'s RCCL layer captured into the graph; one JSON line with `exchange_comparison`')
