@@ -425,9 +425,11 @@ template <int WM, int WN, int TM, bool STATS, bool FOLD, int NS>
 __device__ __forceinline__ void bf16_act_dma_body(const unsigned short* __restrict__ src, const unsigned short* __restrict__ wgt,
                                                   unsigned short* __restrict__ dst, const ActGeo& g, float* __restrict__ part, const BfFuse& fz,
                                                   const int bx, const int gdx, const int by) {
-  static_assert((WM * WN == 4 || WM * WN == 8) && !(FOLD && STATS), "four or eight waves; one statistics epilogue at a time");
+  static_assert((WM * WN == 4 || WM * WN == 8 || WM * WN == 16) && !(FOLD && STATS), "four, eight or sixteen waves; one statistics epilogue at a time");
   static_assert(NS == 2 || NS == 3, "two or three stages");
   constexpr int NW = WM * WN;
+  constexpr bool PER_TILE = NW == 16;                          // sixteen waves: one partial row per m-TILE (row = the tile's index), no sums carried through the K loop
+  constexpr bool LATE_FOLD = FOLD && NW == 16;               // 128 VGPRs per wave at four waves per SIMD: the fold's operands are fetched after the K loop
   constexpr int TN = 2;
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr int BKS = kLnBK, RB = 2 * BKS;                    // a stage's row: 64 k = 128 bytes
@@ -465,16 +467,48 @@ __device__ __forceinline__ void bf16_act_dma_body(const unsigned short* __restri
 #pragma unroll
   for (int j = 0; j < 8; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; }
   float f_mu[8], f_is[8];
-  if (FOLD) {
+  auto load_moments = [&]() {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = n0 + wn0 + cc * 8 + j; const bool okc = c < g.Cd;
       f_mu[j] = okc ? fz.mean[c] : 0.f; f_is[j] = okc ? fz.invstd[c] : 0.f;
     }
-  }
+  };
+  if (FOLD && !LATE_FOLD) load_moments();
+  auto flush_stats = [&](const int prow_) {                     // the workgroup's sums -> partial row prow_ (fixed order: lanes, then the WM wave rows)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a = st_s[j], b = st_q[j];
+      a += __shfl_xor(a, 8, kWave); b += __shfl_xor(b, 8, kWave);
+      a += __shfl_xor(a, 16, kWave); b += __shfl_xor(b, 16, kWave);
+      a += __shfl_xor(a, 32, kWave); b += __shfl_xor(b, 32, kWave);
+      st_s[j] = a; st_q[j] = b;
+    }
+    lds_barrier();
+    float* red = (float*)smem;                                  // [WM][2][BN]
+    if (lane < 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        red[((wave / WN) * 2 + 0) * BN + wn0 + lane * 8 + j] = st_s[j];
+        red[((wave / WN) * 2 + 1) * BN + wn0 + lane * 8 + j] = st_q[j];
+      }
+    }
+    lds_barrier();
+    for (int i = tid; i < 2 * BN; i += 64 * NW) {
+      const int sidx = i / BN, cidx = i - sidx * BN;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) v += red[(w * 2 + sidx) * BN + cidx];
+      if (n0 + cidx < g.Cd) part[((int64_t)prow_ * 2 + sidx) * g.Cd + n0 + cidx] = v;
+    }
+  };
 
   for (int mt = bx; mt < mtiles; mt += gdx) {
     const int m0 = mt * BM;
+    if (PER_TILE && (STATS || FOLD)) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; }
+    }
     // rows this lane requests: piece wave + 4 u of the A image, row prow
     int rowoff[PA]; unsigned tapmask[PA];
 #pragma unroll
@@ -542,13 +576,14 @@ __device__ __forceinline__ void bf16_act_dma_body(const unsigned short* __restri
       }
     };
     u32x4q f_d[FOLD ? 4 * TM : 1], f_x[FOLD ? 4 * TM : 1]; unsigned f_m[FOLD ? 4 * TM : 1];
-    auto fold_loads = [&]() {
+    auto fold_loads = [&](const int i_lo = 0, const int i_hi = 4 * TM) {
       if constexpr (FOLD) {
         const rsrc_t rs_dres = make_rsrc(fz.dres ? fz.dres : dst, fz.dres ? g.dst_bytes : 0u), rs_xbn = make_rsrc(fz.xbn, g.dst_bytes);
         const rsrc_t rs_mask = make_rsrc(fz.mask ? (const void*)fz.mask : (const void*)dst, fz.mask ? fz.mask_bytes : 0u);
         const int c = n0 + wn0 + cc * 8;
 #pragma unroll
         for (int i = 0; i < 4 * TM; ++i) {
+          if (i < i_lo || i >= i_hi) continue;
           const int m = m0 + wm0 + r0 + 8 * i;
           const bool ok = m < g.Mg && c < g.Cd;
           const unsigned off = ok ? (unsigned)(m * g.Cd + c) * 2u : kOob;
@@ -572,12 +607,12 @@ __device__ __forceinline__ void bf16_act_dma_body(const unsigned short* __restri
       lds_barrier();                                            // ... for every wave; and everyone is done reading stage c - 1
       if (c + NS - 1 < nst) issue(c + NS - 1);                   // into the slot stage c - 1 occupied
 #endif
-      if (c + 1 == nst) fold_loads();
+      if (!LATE_FOLD && c + 1 == nst) fold_loads();
 #if LEC_BF_DBG != 2                                              // what-if build 2: the operand traffic alone, no LDS reads, no MFMAs
       compute(c);
 #endif
     }
-    if (nst == 0) fold_loads();
+    if (!LATE_FOLD && nst == 0) fold_loads();
     lds_barrier();                                              // every wave is done with the last stage: the epilogue image may overwrite the ring
 
     // ---- epilogue (as in the register-staged kernel): D'[channel][pixel] -> per-wave LDS image [32 TM pixels][64 channels] -> 16-byte row segments
@@ -592,10 +627,13 @@ __device__ __forceinline__ void bf16_act_dma_body(const unsigned short* __restri
         *(u32x2q*)(ep + (ib * 16 + l15) * kBfLdk + jb * 16 + 4 * h4) = pk;
       }
     wave_lds_sync();
+    if (LATE_FOLD) load_moments();
     const int c = n0 + wn0 + cc * 8;
     const unsigned coff = c < g.Cd ? (unsigned)c * 2u : kOob;
 #pragma unroll
     for (int i = 0; i < 4 * TM; ++i) {
+      // sixteen waves: the accumulators are in the image; the fold's operands come now, two rows' worth at a time (their registers are the accumulators')
+      if (LATE_FOLD && (i & 1) == 0) fold_loads(i, i + 2);
       const int row = r0 + 8 * i;
       const int m = m0 + wm0 + row;
       u32x4q v = *(const u32x4q*)(ep + row * kBfLdk + cc * 8);
@@ -637,35 +675,10 @@ __device__ __forceinline__ void bf16_act_dma_body(const unsigned short* __restri
         bstore16(z, rs_dst, off + rowb); bstore16(z, rs_dst, off + lineb); bstore16(z, rs_dst, off + lineb + rowb);
       }
     }
+    if (PER_TILE && (STATS || FOLD)) flush_stats(mt);
   }
 
-  if (STATS || FOLD) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float a = st_s[j], b = st_q[j];
-      a += __shfl_xor(a, 8, kWave); b += __shfl_xor(b, 8, kWave);
-      a += __shfl_xor(a, 16, kWave); b += __shfl_xor(b, 16, kWave);
-      a += __shfl_xor(a, 32, kWave); b += __shfl_xor(b, 32, kWave);
-      st_s[j] = a; st_q[j] = b;
-    }
-    lds_barrier();
-    float* red = (float*)smem;                                  // [WM][2][BN]
-    if (lane < 8) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        red[((wave / WN) * 2 + 0) * BN + wn0 + lane * 8 + j] = st_s[j];
-        red[((wave / WN) * 2 + 1) * BN + wn0 + lane * 8 + j] = st_q[j];
-      }
-    }
-    lds_barrier();
-    for (int i = tid; i < 2 * BN; i += 64 * NW) {
-      const int sidx = i / BN, cidx = i - sidx * BN;
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) v += red[(w * 2 + sidx) * BN + cidx];
-      if (n0 + cidx < g.Cd) part[((int64_t)bx * 2 + sidx) * g.Cd + n0 + cidx] = v;
-    }
-  }
+  if ((STATS || FOLD) && !PER_TILE) flush_stats(bx);
 }
 
 template <int WM, int WN, int TM, bool STATS, bool FOLD, int NS>
@@ -904,11 +917,26 @@ static int launch_bf16_act(const unsigned short* src, const unsigned short* wgt,
   const dim3 grid(gx, ntiles), blk(kBfThreads);
   ActGeo gg = g; gg.xcd_per = 0;
   if (!tapv && tuning().bf_dma) {
-    // A 1x1 layer with exactly 256 destination channels takes ONE 128 x 256 column tile (eight waves, one workgroup per CU, three stages): its activations are
-    // read once instead of twice and its K loop is too short to miss the second workgroup (same-box table in profiles/EXPERIMENTS.md round 6 (3): -8 ... -27 %
-    // on those layers, +5 ... +19 % on the 3x3 and wider ones).  LEC_BF16_TILE: 1 = that rule (default), 0 = 128 x 128 always, 2 = 128 x 256 wherever the layer
-    // has >= 256 destination channels.
+    // Tile policy (LEC_BF16_TILE: 1 = the two rules below (default), 0 = 128 x 128 always, 2 = 128 x 256 wherever >= 256 destination channels, 3 = 256 x 256
+    // wherever it fits; same-box tables in profiles/EXPERIMENTS.md round 6 (3) items 3 and 8).
     const int bt = tuning().bf_tile;
+    // (a) 256 x 256 tiles (sixteen waves, ONE workgroup per CU, two 64 KB stages): 128 FLOP per operand byte instead of 64 -- the CU's L1 stops being co-critical
+    // with its matrix pipe.  It pays where the K loop is long (>= 1 024: the 3x3 layers, 1x1 from >= 1 024 channels) and the launch still has a tile for most
+    // CUs (>= 160); the statistics / fold sums leave as one partial row per m-TILE, so there must be <= 512 of those.
+    {
+      const int mt2 = (g.Mg + 255) / 256, nt2 = (g.Cd + 255) / 256;
+      const bool fits = !narrow && g.Cd >= 256 && mt2 <= kCfMaxPart;
+      if (fits && (bt == 3 || (bt == 1 && g.Kg >= 1024 && mt2 * nt2 >= 160))) {
+        int gx2 = (256 / nt2) & ~7; if (gx2 < 8) gx2 = 8; if (gx2 > mt2) gx2 = mt2;
+        const size_t ring = (size_t)2 * 512 * 2 * kLnBK, epi = (size_t)16 * 64 * kBfLdk * 2;
+        hipLaunchKernelGGL((conv_bf16_act_dma_kernel<4, 4, 2, STATS, FOLD, 2>), dim3(gx2, nt2), dim3(1024), ring > epi ? ring : epi, st, src, wgt, dst, gg, part, fz);
+        if (nparts) *nparts = mt2;
+        LEC_CHECK_LAUNCH("conv_bf16_act_dma_kernel");
+        return LEC_OK;
+      }
+    }
+    // (b) a 1x1 layer with exactly 256 destination channels takes ONE 128 x 256 column tile (eight waves, one workgroup per CU, three stages): its activations
+    // are read once instead of twice and its K loop is too short to miss the second workgroup
     if (!narrow && ((bt == 1 && g.Cd == 256 && g.na * g.nb == 1) || (bt == 2 && g.Cd >= 256))) {
       const int BM2 = 128, BN2 = 256;
       const int mt2 = (g.Mg + BM2 - 1) / BM2, nt2 = (g.Cd + BN2 - 1) / BN2;

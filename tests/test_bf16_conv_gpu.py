@@ -141,6 +141,44 @@ def test_conv_bf16_full_size_layers_match_fp32_reference_on_rounded_operands():
         assert (dw - wr.grad).abs().max().item() <= 1e-3 * wr.grad.abs().max().item()
 
 
+def test_conv_bf16_sixteen_wave_tiles_statistics_and_fold_at_the_size_the_default_rule_picks_them():
+    """Layer3's 3x3 (256 -> 256 @14 x 14) at 212 rows = 41 552 pixels = 163 m-tiles of 256: K = 2 304 >= 1 024 and >= 160 tiles, so forward and data gradient run the 256 x 256
+    sixteen-wave kernel (one partial row per m-TILE, fold operands fetched after the K loop).  Exact on small integers; the statistics partials, the fold's g and its sums
+    against the unfused forms."""
+    N, C, H = 212, 256, 14
+    g = torch.Generator(device='cpu').manual_seed(5)
+    x = _cl(torch.randint(-2, 3, (N, C, H, H), generator=g).float().bfloat16()); w = _cl(torch.randint(-1, 2, (C, C, 3, 3), generator=g).float().bfloat16())
+    yr = F.conv2d(x.float(), w.float(), None, 1, 1)
+    y = ops.conv_bf16_fwd(x, w, 1, 1, want_stats=True)
+    k = ops._BN_WS_OWNER[1]; ops._BN_WS_OWNER[0] = 0
+    assert k == (N * H * H + 255) // 256, 'one partial row per 256-pixel tile: the sixteen-wave kernel ran'
+    part = ops._bn_workspace(x.device).view(torch.float32)[:k * 2 * C].view(k, 2, C).double().sum(0)
+    assert torch.equal(y, yr.bfloat16())
+    yb = y.double()
+    assert torch.allclose(part[0], yb.sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-2) and torch.allclose(part[1], (yb ** 2).sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-2)
+    # data gradient, plain and folded (mask + residual)
+    dy = _cl(torch.randint(-2, 3, (N, C, H, H), generator=g).float().bfloat16())
+    wt = ops.conv_bf16_wt(w)
+    dxr = torch.nn.grad.conv2d_input(x.shape, w.float(), dy.float(), 1, 1)
+    dx = ops.conv_bf16_dgrad(dy, wt, x.shape, 1, 1)
+    assert torch.equal(dx, dxr.bfloat16())
+    xbn = _cl(torch.randn(N, C, H, H, generator=g).bfloat16())
+    mean = xbn.float().mean(dim=(0, 2, 3)); invstd = 1.0 / (xbn.float().var(dim=(0, 2, 3), unbiased=False) + 1e-5).sqrt()
+    bits = (torch.rand(N, C, H, H, generator=g) > 0.4).to(DEV)
+    b = bits.permute(0, 2, 3, 1).reshape(-1, C // 8, 8).to(torch.uint8)
+    mask = (b * (2 ** torch.arange(8, device=DEV, dtype=torch.uint8))).sum(-1).to(torch.uint8).reshape(-1).contiguous()
+    dres = _cl(torch.randint(-2, 3, (N, C, H, H), generator=g).float().bfloat16())
+    gk = ops.conv_bf16_dgrad(dy, wt, x.shape, 1, 1, fold={'x': xbn, 'mask': mask, 'mean': mean, 'invstd': invstd, 'dres': dres})
+    k = ops._BN_WS_OWNER[1]; ops._BN_WS_OWNER[0] = 0; ops.fusion().folded.clear()
+    assert k == (N * H * H + 255) // 256
+    part = ops._bn_workspace(x.device).view(torch.float32)[:k * 2 * C].view(k, 2, C).double().sum(0)
+    gr = torch.where(bits, dx.float() + dres.float(), torch.zeros_like(dxr)).bfloat16()
+    assert torch.equal(gk, gr)
+    xhat = (xbn.float() - mean.view(1, C, 1, 1)) * invstd.view(1, C, 1, 1)
+    assert torch.allclose(part[0], gr.double().sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(part[1], (gr.float() * xhat).double().sum(dim=(0, 2, 3)), rtol=1e-4, atol=5e-2)
+
+
 def test_resnet50_bf16_family_everywhere_vs_special_cases_vs_library():
     """A bottleneck ResNet with every layer kind of ResNet-50 (stem, four stages with their strided and downsample layers) at bf16 (autocast), forward + backward with a flat arena, three ways on the same weights and batch: the default routing (round-1 special cases
     where they exist, the family elsewhere), the family for EVERY layer (LEC_CONV_BF16=2: stem, strided layers, parity classes, fold epilogues, transposed weights -- all in
