@@ -520,6 +520,13 @@ int lec_conv_bf16_wt_transpose(const void* w, void* wt, int Cout, int RS, int Ci
 int lec_conv_bf16_wt_transpose_flat(const void* base, void* base_t, const int32_t* table, int n_layers, int total_tiles, lec_stream_t stream);
 int lec_conv_bf16_fwd(const void* x, const void* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                       void* y, float* partials, int64_t partials_bytes, int* n_partials, lec_stream_t stream);
+/*     lec_conv_bf16_stem_fwd: torchvision's stem convolution (resnet.py conv1: 7x7 / stride 2 / pad 3, 3 -> 64 channels; FeatCNN, oe_h.py:331-351) on its own
+ *       kernel.  x [N, H, W, 8] and w [64][7][7][8] bf16 as lec_conv_bf16_fwd takes them; channels 0..3 enter the product (the caller keeps channel 3 zero),
+ *       channels 4..7 are never read; y [N, H/2, W/2, 64]; partials as lec_conv_bf16_fwd (up to 768 rows when the buffer holds them).
+ *       lec_conv_bf16_stem_supported: even H and W in {64, 128, 224}; other sizes go through lec_conv_bf16_fwd. */
+int lec_conv_bf16_stem_supported(int H, int W);
+int lec_conv_bf16_stem_fwd(const void* x, const void* w, int N, int H, int W, void* y, float* partials, int64_t partials_bytes, int* n_partials,
+                           lec_stream_t stream);
 int lec_conv_bf16_dgrad(const void* dy, const void* wt, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                         void* dx, const void* dres, const void* xbn, const uint8_t* mask, const float* mean, const float* invstd,
                         float* partials, int64_t partials_bytes, int* n_partials, lec_stream_t stream);

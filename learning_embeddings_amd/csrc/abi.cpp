@@ -41,6 +41,7 @@ static Tuning load_tuning() {
   t.wg_smask = i("LEC_WGRAD_SMASK", 0);
   t.bf_dma = i("LEC_BF16_DMA", 1);
   t.bf_tile = i("LEC_BF16_TILE", 1);
+  t.bf_stem = i("LEC_BF16_STEM", 1);
   t.x3_wgs = pos("LEC_X3_WGS", 256);
   t.x3_force_narrow = env("LEC_X3_FORCE_NARROW") != nullptr;
   t.x3_chain = pos("LEC_X3_CHAIN", 512);
@@ -56,4 +57,4 @@ const Tuning& tuning() { static const Tuning t = load_tuning(); return t; }
 }  // namespace lec
 
 extern "C" const char* lec_last_error(void) { return lec::g_err; }
-extern "C" int lec_abi_version(void) { return 31; }
+extern "C" int lec_abi_version(void) { return 32; }

@@ -884,6 +884,186 @@ __global__ __launch_bounds__(kBfThreads, 2) void conv_bf16_wgrad_kernel(const un
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The stem (7x7 / stride 2 / pad 3, 8 -> 64 channels, 3 of the 8 real) as its own forward kernel.  The generic kernel gathers every 16-byte piece (one
+// tap of one pixel) on its own: each input pixel travels through the L1 49 / 4 times and the layer runs at a quarter of what its bytes need (844 us against
+// an HBM floor of ~225 us at 512 rows).  Here a tile is ONE output row: the 7 input rows it needs are read once (8 bytes per pixel: channels 0..3, the
+// fourth a zero -- channels 4..7 of the padded input are never fetched) into a compact LDS patch, and every MFMA operand is one 16-byte LDS read.
+//   * patch [7 rows][W + 8 pixels] of 8 bytes, pixel column c at position c + 3: the 16 bytes at position 2 ow + 2 q are the pixels of taps (r, 2 q) and
+//     (r, 2 q + 1) of output pixel ow -- a k group of v_mfma_f32_16x16x32_bf16; the four groups of a K step are the four tap pairs of filter row r
+//     (tap (r, 7) does not exist: zero weights), so the 49 taps are SEVEN K steps instead of the thirteen the 8-channel pixels would take;
+//   * the pixels of the NEXT tile are requested into registers before this tile's products and written to the patch after them; a tile waits for them with
+//     a counted vmcnt that leaves its predecessor's output stores in flight;
+//   * wave v owns output channels 16 v .. 16 v + 15; its 7 weight fragments stay in registers for the whole launch (no LDS for the weights);
+//   * D'[channel][pixel] -> bf16 -> an LDS row image [Wo][64] -> 128-byte rows to memory; the BatchNorm statistics from the rounded values, one partial row
+//     per workgroup (lec_bn_fwd_prestat's layout), as in the family's epilogue.
+#ifndef LEC_STEM_DBG
+#define LEC_STEM_DBG 0                    // 1 / 3: what-if builds (no products / no output stores); the product build is 0
+#endif
+struct StemGeo {
+  int N, H, W, Ho, Wo, PC, tiles, npix;     // PC = W + 8 patch positions per row; npix = 7 * (W + 6) pixels a tile requests
+  uint32_t x_bytes, w_bytes, y_bytes;
+  FastDiv dRow, dHo;                        // / (W + 6), / Ho
+};
+typedef unsigned int u32x2r __attribute__((ext_vector_type(2)));
+
+template <bool STATS, int NPB>              // NPB = Wo / 16: 16-pixel blocks of an output row (7 at 224 x 224 images)
+__global__ __launch_bounds__(256, 3) void conv_bf16_stem_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
+                                                                unsigned short* __restrict__ y, StemGeo g, float* __restrict__ part) {
+  constexpr int NLD = (7 * (32 * NPB + 6) + 255) / 256;        // pixel loads per thread and tile
+  constexpr int PATCH = 7 * (32 * NPB + 8) * 8;                // bytes
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  char* const patch = (char*)smem;
+  char* const outimg = patch + ((PATCH + 255) & ~255);         // [Wo][64] bf16
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, kq = lane >> 4;
+  const rsrc_t rs_x = make_rsrc(x, g.x_bytes), rs_w = make_rsrc(w, g.w_bytes), rs_y = make_rsrc(y, g.y_bytes);
+  // weights: fragment r = taps (r, 2 kq), (r, 2 kq + 1) x channels 0..3 of output channel 16 wave + l15 (w [64][49][8])
+  bfrag wf[7];
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    const unsigned o0 = (unsigned)(((16 * wave + l15) * 49 + r * 7 + 2 * kq) * 16);
+    const u32x2r lo = __builtin_amdgcn_raw_buffer_load_b64(rs_w, (int)o0, 0, 0);
+    const u32x2r hi = __builtin_amdgcn_raw_buffer_load_b64(rs_w, (int)(2 * kq + 1 < 7 ? o0 + 16u : kOob), 0, 0);
+    u32x4q v; v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+    wf[r] = __builtin_bit_cast(bfrag, v);
+  }
+  // loader: pixel idx = tid + 256 u of the tile's 7 x (W + 6) window -> (row r, column c - 3)
+  int rel[NLD]; int rr[NLD]; unsigned pofs[NLD];
+#pragma unroll
+  for (int u = 0; u < NLD; ++u) {
+    const int idx = tid + 256 * u;
+    const int r = fdiv(idx, g.dRow); const int cpos = idx - r * (g.W + 6);     // position = column + 3
+    const int col = cpos - 3;
+    const bool ok = idx < g.npix && (unsigned)col < (unsigned)g.W;
+    rel[u] = ok ? (r * g.W + col) * 16 : -1;
+    rr[u] = r;
+    pofs[u] = idx < g.npix ? (unsigned)((r * g.PC + cpos) * 8) : 0xffffffffu;
+  }
+  u32x2r stg[NLD];
+  auto request = [&](int t) {
+    const int n = fdiv(t, g.dHo); const int oh = t - n * g.Ho;
+    const int row0 = 2 * oh - 3;
+    const int base = (n * g.H + row0) * g.W * 16;              // (may point before the image: the row test below covers it)
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const bool ok = rel[u] >= 0 && (unsigned)(row0 + rr[u]) < (unsigned)g.H;
+      stg[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_x, (int)(ok ? (unsigned)(base + rel[u]) : kOob), 0, 0);
+    }
+  };
+  const int cc = tid & 7, r0 = tid >> 3;
+  float st_s[8], st_q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; }
+  // zero the patch once: its last two positions of every row are never written (and never multiplied by a non-zero weight, but must not hold a NaN)
+  for (int i = tid; i < PATCH / 16; i += 256) { u32x4q z; z[0] = 0u; z[1] = 0u; z[2] = 0u; z[3] = 0u; *(u32x4q*)(patch + 16 * i) = z; }
+
+  // Tile walk: workgroup ids go round-robin over the 8 XCDs (one L2 each); XCD x owns the CONTIGUOUS run of output rows [x per, (x + 1) per), so the rows in
+  // flight on an XCD at any moment are neighbours and share their 7-row windows in that L2
+  const int per = (g.tiles + 7) >> 3;
+  auto tile_of = [&](int slot) { return (slot & 7) * per + (slot >> 3); };
+  const int nslots = 8 * per;
+  bool first = true;
+  { const int t0 = tile_of(blockIdx.x); if ((int)blockIdx.x < nslots && t0 < g.tiles) request(t0); }
+  for (int slot = blockIdx.x; slot < nslots; slot += gridDim.x) {
+    const int t = tile_of(slot);
+    const int tn = slot + (int)gridDim.x < nslots ? tile_of(slot + gridDim.x) : g.tiles;
+    if (t >= g.tiles) continue;                                 // (only the last run can be short: its tail slots have no tile, and neither have their successors)
+    // this tile's pixels were requested BEFORE the previous tile's output stores: wait for them and leave those stores (the wave's youngest 3 / 4, 2, 1
+    // operations) in flight
+    if (!first && LEC_STEM_DBG != 3) {
+      if (NPB == 7) { if (wave < 2) wait_vmcnt<4>(); else wait_vmcnt<3>(); }
+      else if (NPB == 4) wait_vmcnt<2>();
+      else wait_vmcnt<1>();
+    } else wait_vmcnt<0>();
+    first = false;
+    lds_barrier();                                              // the previous tile's patch and row image have been read by every wave
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) if (pofs[u] != 0xffffffffu) *(u32x2r*)(patch + pofs[u]) = stg[u];
+    lds_barrier();
+    if (tn < g.tiles) request(tn);
+    const char* pb = patch + l15 * 16 + kq * 16;
+    f32x4v acc[NPB];
+#pragma unroll
+    for (int ib = 0; ib < NPB; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[ib][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < (LEC_STEM_DBG == 1 ? 0 : 7); ++r) {
+      bfrag xa[NPB];
+#pragma unroll
+      for (int ib = 0; ib < NPB; ++ib) xa[ib] = *(const bfrag*)(pb + r * (32 * NPB + 8) * 8 + ib * 256);
+#pragma unroll
+      for (int ib = 0; ib < NPB; ++ib) acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[r], xa[ib], acc[ib], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);                        // (left alone the scheduler hoists every fragment read above the first MFMA and spills)
+    }
+    // D'[channel 4 kq + r][pixel l15] of block ib -> the row image
+#pragma unroll
+    for (int ib = 0; ib < NPB; ++ib) {
+      u32x2q pk;
+      pk[0] = pk_bf16(acc[ib][0], acc[ib][1]); pk[1] = pk_bf16(acc[ib][2], acc[ib][3]);
+      *(u32x2q*)(outimg + (16 * ib + l15) * 128 + (16 * wave + 4 * kq) * 2) = pk;
+    }
+    lds_barrier();
+    const int n = fdiv(t, g.dHo); const int oh = t - n * g.Ho;
+    const unsigned rowbase = (unsigned)((n * g.Ho + oh) * g.Wo) * 128u;
+    for (int px = r0; px < 16 * NPB; px += 32) {
+      const u32x4q v = *(const u32x4q*)(outimg + px * 128 + cc * 16);
+      if (LEC_STEM_DBG != 3) bstore16(v, rs_y, rowbase + (unsigned)px * 128u + (unsigned)cc * 16u);
+      if (STATS) {
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) {
+          const float a0 = bf_lo(v[j2]), a1 = bf_hi(v[j2]);
+          st_s[2 * j2] += a0; st_q[2 * j2] += a0 * a0; st_s[2 * j2 + 1] += a1; st_q[2 * j2 + 1] += a1 * a1;
+        }
+      }
+    }
+  }
+  if (STATS) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a = st_s[j], b = st_q[j];
+      a += __shfl_xor(a, 8, kWave); b += __shfl_xor(b, 8, kWave);
+      a += __shfl_xor(a, 16, kWave); b += __shfl_xor(b, 16, kWave);
+      a += __shfl_xor(a, 32, kWave); b += __shfl_xor(b, 32, kWave);
+      st_s[j] = a; st_q[j] = b;
+    }
+    lds_barrier();
+    float* red = (float*)smem;                                  // [4 waves][2][64]
+    if (lane < 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { red[(wave * 2 + 0) * 64 + lane * 8 + j] = st_s[j]; red[(wave * 2 + 1) * 64 + lane * 8 + j] = st_q[j]; }
+    }
+    lds_barrier();
+    if (tid < 128) {
+      const int sidx = tid >> 6, cidx = tid & 63;
+      part[((int64_t)blockIdx.x * 2 + sidx) * 64 + cidx] = red[(0 * 2 + sidx) * 64 + cidx] + red[(1 * 2 + sidx) * 64 + cidx] + red[(2 * 2 + sidx) * 64 + cidx] + red[(3 * 2 + sidx) * 64 + cidx];
+    }
+  }
+}
+
+
+static int launch_bf16_stem(const unsigned short* x, const unsigned short* w, unsigned short* y, int N, int H, int W, float* part, int64_t part_bytes, int* nparts, hipStream_t st) {
+  StemGeo g;
+  g.N = N; g.H = H; g.W = W; g.Ho = H / 2; g.Wo = W / 2; g.PC = W + 8; g.tiles = N * g.Ho; g.npix = 7 * (W + 6);
+  g.x_bytes = (uint32_t)((int64_t)N * H * W * 16); g.w_bytes = (uint32_t)(64 * 49 * 16); g.y_bytes = (uint32_t)((int64_t)N * g.Ho * g.Wo * 128);
+  g.dRow = make_fastdiv(W + 6); g.dHo = make_fastdiv(g.Ho);
+  // three workgroups per CU and more (27 KB of LDS at 224-pixel rows): 768 of them where the partial rows fit the caller's buffer (one row per workgroup)
+  int gx = 768;
+  if (part && part_bytes < (int64_t)gx * 2 * 64 * (int64_t)sizeof(float)) gx = kCfMaxPart;
+  if (gx > g.tiles) gx = g.tiles;
+  const size_t lds = (size_t)(((7 * (W + 8) * 8) + 255) & ~255) + (size_t)g.Wo * 128;
+#define LEC_STEM_LAUNCH(NPB_) do { if (part) hipLaunchKernelGGL((conv_bf16_stem_kernel<true, NPB_>), dim3(gx), dim3(256), lds, st, x, w, y, g, part); \
+                                   else hipLaunchKernelGGL((conv_bf16_stem_kernel<false, NPB_>), dim3(gx), dim3(256), lds, st, x, w, y, g, part); } while (0)
+  if (W == 224) LEC_STEM_LAUNCH(7); else if (W == 128) LEC_STEM_LAUNCH(4); else LEC_STEM_LAUNCH(2);
+#undef LEC_STEM_LAUNCH
+  if (nparts) *nparts = gx;
+  LEC_CHECK_LAUNCH("conv_bf16_stem_kernel");
+  return LEC_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 static inline int conv_bf16_check(const char* who, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad) {
   LEC_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && (stride == 1 || stride == 2) && pad >= 0 && pad < R && pad < S,
@@ -1020,6 +1200,22 @@ extern "C" int lec_conv_bf16_fwd(const void* x, const void* w, int N, int H, int
     return launch_bf16_act<true, false>((const unsigned short*)x, (const unsigned short*)w, (unsigned short*)y, g, partials, n_partials, (hipStream_t)stream);
   }
   return launch_bf16_act<false, false>((const unsigned short*)x, (const unsigned short*)w, (unsigned short*)y, g, nullptr, nullptr, (hipStream_t)stream);
+}
+
+// The ResNet stem (7x7 / stride 2 / pad 3, 64 output channels) on a 3-channel image stored with 8 channels per pixel: channels 0..3 of x and w enter the
+// product (the caller keeps channel 3 zero), channels 4..7 are never read.  Image widths 64, 128, 224 (conv_bf16_stem_kernel's instances); H even.
+extern "C" int lec_conv_bf16_stem_supported(int H, int W) {
+  return lec::tuning().bf_stem && H > 0 && H % 2 == 0 && (W == 224 || W == 128 || W == 64);
+}
+
+extern "C" int lec_conv_bf16_stem_fwd(const void* x, const void* w, int N, int H, int W, void* y, float* partials, int64_t partials_bytes, int* n_partials,
+                                      lec_stream_t stream) {
+  using namespace lec;
+  if (int rc = conv_bf16_check("conv_bf16_stem_fwd", N, H, W, 8, 64, 7, 7, 2, 3)) return rc;
+  LEC_CHECK_ARG(x && w && y, "conv_bf16_stem_fwd: null pointer");
+  LEC_CHECK_ARG(lec_conv_bf16_stem_supported(H, W), "conv_bf16_stem_fwd: image %d x %d is not one of the stem kernel's sizes (even height; width 64, 128 or 224)", H, W);
+  LEC_CHECK_ARG(!partials || (n_partials && partials_bytes >= (int64_t)kCfMaxPart * 2 * 64 * (int64_t)sizeof(float)), "conv_bf16_stem_fwd: partials buffer too small");
+  return launch_bf16_stem((const unsigned short*)x, (const unsigned short*)w, (unsigned short*)y, N, H, W, partials, partials_bytes, n_partials, (hipStream_t)stream);
 }
 
 // Data gradient from TRANSPOSED weights wt [Cin][R*S][Cout] (lec_conv_bf16_wt_transpose).  The fold arguments (all or none; stride 1 only):

@@ -23,6 +23,7 @@ struct Tuning {
   int wg_wgs;                 // LEC_WGRAD_WGS          cap on the weight-gradient grid
   int wg_smask;               // LEC_WGRAD_SMASK
   int bf_dma;                 // LEC_BF16_DMA           bf16 forward / data gradient: operands by LDS-DMA through a ring of whole-line stages (1) or staged through registers (0)
+  int bf_stem;                // LEC_BF16_STEM          the 7x7 / stride-2 stem forward on its own LDS-patch kernel (1) or on the generic per-piece-tap kernel (0: lec_conv_bf16_stem_supported says no)
   int bf_tile;                // LEC_BF16_TILE          bf16 forward / data gradient tile policy: 1 = 256 x 256 (long K, >= 160 tiles) and 128 x 256 (1x1, 256 destination channels) where they pay, 0 = 128 x 128 always, 2 / 3 = 128 x 256 / 256 x 256 wherever they fit
   int x3_wgs;                 // LEC_X3_WGS             workgroups of the split-product (x3) kernels
   int x3_force_narrow;        // LEC_X3_FORCE_NARROW

@@ -1006,6 +1006,29 @@ def conv_bf16_wt(w):
     return wt
 
 
+def conv_bf16_stem_supported(x):
+    """The stem's own forward kernel serves this input ([N, 8, H, W] channels_last bf16, 3 real channels): even H, W in {64, 128, 224}."""
+    return x.dim() == 4 and x.shape[1] == 8 and bool(lib.lec_conv_bf16_stem_supported(int(x.shape[2]), int(x.shape[3])))
+
+
+def conv_bf16_stem_fwd(x, w, want_stats=False):
+    """The ResNet stem (7x7 / stride 2 / pad 3, -> 64 channels) of a 3-channel image stored with 8 channels per pixel (lec_conv_bf16_stem_fwd): channels 0..3 of
+    x [N, 8, H, W] and w [64, 8, 7, 7] (channels_last bf16) enter the product -- channel 3 must be zero in one of them -- channels 4..7 are never read."""
+    _nhwc_bf16(x, 'x'); _nhwc_bf16(w, 'w')
+    n, cin, h, wd = x.shape
+    if cin != 8 or tuple(w.shape) != (64, 8, 7, 7):
+        raise ValueError('stem kernel: x [N, 8, H, W], w [64, 8, 7, 7]')
+    y = torch.empty((n, 64, h // 2, wd // 2), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    flops = 2.0 * n * (h // 2) * (wd // 2) * 64 * 3 * 49
+    if want_stats:
+        ws = _bn_workspace(x.device); k = C.c_int(0)
+        _conv_timed(lambda: check(lib.lec_conv_bf16_stem_fwd(dptr(x), dptr(w), n, h, wd, dptr(y), dptr(ws), ws.numel(), C.byref(k), stream_ptr())), flops)
+        fusion().ws_owner[0], fusion().ws_owner[1] = y.data_ptr(), k.value
+    else:
+        _conv_timed(lambda: check(lib.lec_conv_bf16_stem_fwd(dptr(x), dptr(w), n, h, wd, dptr(y), None, 0, None, stream_ptr())), flops)
+    return y
+
+
 def conv_bf16_fwd(x, w, stride, pad, want_stats=False):
     """y = conv2d(x, w) on bf16 NHWC tensors, fp32 accumulation (lec_conv_bf16_fwd).  want_stats: the BatchNorm statistics partials of the
     (rounded) output are left in the BatchNorm workspace."""

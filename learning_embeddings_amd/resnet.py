@@ -517,7 +517,11 @@ class _OverlapConvFn(torch.autograd.Function):
             ctx.stem = conv.in_channels == 3
             if ctx.stem:
                 x, w16 = _pad_c8(x), _pad_c8(w16)
-            y = _ops().conv_bf16_fwd(x, w16, conv.stride[0], conv.padding[0], want_stats=True)
+            if (ctx.stem and conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.out_channels == 64
+                    and _ops().conv_bf16_stem_supported(x)):
+                y = _ops().conv_bf16_stem_fwd(x, w16, want_stats=True)      # the stem's own kernel: the 7 input rows of an output row staged once, 7 K steps
+            else:
+                y = _ops().conv_bf16_fwd(x, w16, conv.stride[0], conv.padding[0], want_stats=True)
         elif ctx.pointwise and conv.in_channels >= GEMM_FWD_MIN_CIN:
             n, _, h, wd = x.shape
             _lib_launch('fwd')

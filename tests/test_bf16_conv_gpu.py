@@ -77,6 +77,33 @@ def test_conv_bf16_fwd_dgrad_wgrad_exact_on_integers_and_vs_fp32(N, Cin, H, W, C
             assert torch.allclose(part[1], (yb ** 2).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-2)
 
 
+@pytest.mark.parametrize('N,H,W', [(3, 64, 64), (2, 128, 128), (2, 224, 224), (5, 62, 64)])
+def test_conv_bf16_stem_forward_kernel_matches_the_three_channel_convolution(N, H, W):
+    """lec_conv_bf16_stem_fwd (the stem's own kernel: image widths 64 / 128 / 224, even heights) against F.conv2d on the 3 real channels: exact on small integers
+    (one rounding to bf16 on the way out), the statistics partials those of the rounded output, and identical to the generic kernel on the zero-padded operands.
+    Channels 4..7 are never read: garbage there must not matter."""
+    g = torch.Generator(device='cpu').manual_seed(H + W)
+    x3 = torch.randint(-3, 4, (N, 3, H, W), generator=g).float(); w3 = torch.randint(-2, 3, (64, 3, 7, 7), generator=g).float()
+    x8 = torch.zeros(N, 8, H, W); x8[:, :3] = x3; w8 = torch.zeros(64, 8, 7, 7); w8[:, :3] = w3
+    xg = x8.clone(); xg[:, 4:] = torch.randn(N, 4, H, W, generator=g) * 100.0                  # channels 4..7: never read
+    x8 = _cl(x8.bfloat16()); w8 = _cl(w8.bfloat16()); xg = _cl(xg.bfloat16())
+    assert ops.conv_bf16_stem_supported(x8)
+    yr = F.conv2d(x3.double(), w3.double(), None, 2, 3)
+    y = ops.conv_bf16_stem_fwd(xg, w8, want_stats=True)
+    k = ops._BN_WS_OWNER[1]; ops._BN_WS_OWNER[0] = 0
+    part = ops._bn_workspace(x8.device).view(torch.float32)[:k * 2 * 64].view(k, 2, 64).double().sum(0)
+    assert y.shape == yr.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(y.cpu(), yr.float().bfloat16())
+    yb = y.double()
+    assert torch.allclose(part[0], yb.sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-2) and torch.allclose(part[1], (yb ** 2).sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-1)
+    assert torch.equal(y, ops.conv_bf16_fwd(x8, w8, 2, 3)) and torch.equal(y, ops.conv_bf16_stem_fwd(xg, w8))
+    # random data: the same fp32 sums as the generic kernel up to summation order
+    xr = torch.zeros(N, 8, H, W); xr[:, :3] = torch.randn(N, 3, H, W, generator=g); wr = torch.zeros(64, 8, 7, 7); wr[:, :3] = torch.randn(64, 3, 7, 7, generator=g) / 12.0
+    xr = _cl(xr.bfloat16()); wr = _cl(wr.bfloat16())
+    ya = ops.conv_bf16_stem_fwd(xr, wr).float(); yb2 = ops.conv_bf16_fwd(xr, wr, 2, 3).float()
+    assert (ya - yb2).abs().max().item() <= 2.0 ** -7 * yb2.abs().max().item()
+
+
 def test_conv_bf16_stem_three_channel_weight_gradient_slot():
     """The stem: x carries zero channels 3..7 and the gradient slot has 3 channels."""
     g = torch.Generator(device='cpu').manual_seed(5)
