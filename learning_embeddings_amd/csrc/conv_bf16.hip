@@ -1064,6 +1064,135 @@ static int launch_bf16_stem(const unsigned short* x, const unsigned short* w, un
   return LEC_OK;
 }
 
+// The stem's weight gradient on the same compact patch: dw[co][(r, s)][ci] = sum over output pixels of dy[p][co] * x[2 oh + r - 3][2 ow + s - 3][ci].  A tile is
+// one output row; K = its pixels (zero rows up to a multiple of 32).  The "im2col" operand needs no copy: for filter row r, the 32 bf16 of pixel p -- 8 taps
+// x 4 channels, tap 7 and channel 3 without a slot in dw -- are the 64 bytes at patch[r][2 p ...], so the K-major matrix is the patch itself with a row stride
+// of 16 bytes, and ds_read_b64_tr_b16 transposes it on the way to the MFMA like any other K-major tile.  dY [pixel][64] is stored with its 32-byte granules
+// XORed by ((p >> 1) & 1) | (((p >> 3) & 1) << 1) so that the transposed reads of rows {0..3, 8..11} meet all 64 banks once.  7 rows x 2 blocks of 16 columns
+// = 14 column blocks over four waves (4, 4, 4, 2), 4 blocks of output channels each; sums stay in registers over the workgroup's tiles and leave as float atomics.
+template <int NPB>
+__global__ __launch_bounds__(256, 3) void conv_bf16_stem_wgrad_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
+                                                                      float* __restrict__ dw, StemGeo g, int dcin) {
+  constexpr int WO = 16 * NPB, KS = (WO + 31) / 32, KP = 32 * KS;
+  constexpr int NLD = (7 * (32 * NPB + 6) + 255) / 256, NDY = (WO * 8 + 255) / 256;
+  constexpr int ROWB = (32 * NPB + 8) * 8, PATCH = (7 * ROWB + 255) & ~255;
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  char* const patch = (char*)smem;
+  char* const dyt = patch + PATCH + 512;                       // [KP][64] bf16 (the 512 bytes between: the last K step's reads past the patch's end stay inside LDS)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = lane >> 4, li = lane & 15;
+  const rsrc_t rs_x = make_rsrc(x, g.x_bytes), rs_dy = make_rsrc(dy, g.y_bytes);
+  int rel[NLD]; int rr[NLD]; unsigned pofs[NLD];
+#pragma unroll
+  for (int u = 0; u < NLD; ++u) {
+    const int idx = tid + 256 * u;
+    const int r = fdiv(idx, g.dRow); const int cpos = idx - r * (g.W + 6);
+    const int col = cpos - 3;
+    const bool ok = idx < g.npix && (unsigned)col < (unsigned)g.W;
+    rel[u] = ok ? (r * g.W + col) * 16 : -1;
+    rr[u] = r;
+    pofs[u] = idx < g.npix ? (unsigned)(r * ROWB + cpos * 8) : 0xffffffffu;
+  }
+  unsigned dofs[NDY];                                           // LDS byte offset of this thread's dY pieces (pixel idx >> 3, channels 8 (idx & 7) ..)
+#pragma unroll
+  for (int u = 0; u < NDY; ++u) {
+    const int idx = tid + 256 * u; const int p = idx >> 3, c8 = idx & 7;
+    const int f = ((p >> 1) & 1) | (((p >> 3) & 1) << 1);
+    dofs[u] = idx < WO * 8 ? (unsigned)(p * 128 + ((((c8 >> 1) ^ f) << 1) | (c8 & 1)) * 16) : 0xffffffffu;
+  }
+  u32x2r stx[NLD]; u32x4q sty[NDY];
+  auto request = [&](int t) {
+    const int n = fdiv(t, g.dHo); const int oh = t - n * g.Ho;
+    const int row0 = 2 * oh - 3;
+    const int base = (n * g.H + row0) * g.W * 16;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const bool ok = rel[u] >= 0 && (unsigned)(row0 + rr[u]) < (unsigned)g.H;
+      stx[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_x, (int)(ok ? (unsigned)(base + rel[u]) : kOob), 0, 0);
+    }
+    const unsigned dbase = (unsigned)(t * WO) * 128u;
+#pragma unroll
+    for (int u = 0; u < NDY; ++u) sty[u] = bload16(rs_dy, dofs[u] != 0xffffffffu ? dbase + (unsigned)(tid + 256 * u) * 16u : kOob);
+  };
+  for (int i = tid; i < (PATCH + 512 + KP * 128) / 16; i += 256) { u32x4q z; z[0] = 0u; z[1] = 0u; z[2] = 0u; z[3] = 0u; *(u32x4q*)(patch + 16 * i) = z; }
+
+  // fragment addresses: dY^T block mb (rows = channels 16 mb ..), K step ks: k row 32 ks + 8 grp + (li >> 2) (+ 4), columns 4 (li & 3) ..
+  const int fA = ((li >> 3) & 1) | ((grp & 1) << 1);
+  const unsigned aoff = (unsigned)((8 * grp + (li >> 2)) * 128 + (li & 3) * 8);
+  const unsigned boff = (unsigned)((8 * grp + (li >> 2)) * 16 + (li & 3) * 8);
+  f32x4v acc[4][4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[mb][nb][r] = 0.f;
+
+  const int per = (g.tiles + 7) >> 3;
+  auto tile_of = [&](int slot) { return (slot & 7) * per + (slot >> 3); };
+  const int nslots = 8 * per;
+  { const int t0 = tile_of(blockIdx.x); if ((int)blockIdx.x < nslots && t0 < g.tiles) request(t0); }
+  for (int slot = blockIdx.x; slot < nslots; slot += gridDim.x) {
+    const int t = tile_of(slot);
+    const int tn = slot + (int)gridDim.x < nslots ? tile_of(slot + gridDim.x) : g.tiles;
+    if (t >= g.tiles) continue;
+    wait_vmcnt<0>();
+    lds_barrier();                                              // the previous tile's operands have been read by every wave
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) if (pofs[u] != 0xffffffffu) *(u32x2r*)(patch + pofs[u]) = stx[u];
+#pragma unroll
+    for (int u = 0; u < NDY; ++u) if (dofs[u] != 0xffffffffu) *(u32x4q*)(dyt + dofs[u]) = sty[u];
+    lds_barrier();
+    if (tn < g.tiles) request(tn);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bfrag fa[4], fb[4];
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) fa[mb] = tr_frag((const unsigned short*)(dyt + ks * 32 * 128 + aoff + ((mb ^ fA) * 32)), 4 * 64);
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const int nbg = 4 * wave + nb;                          // column block: filter row nbg >> 1, columns 16 (nbg & 1) .. of its 32
+        if (nbg < 14) fb[nb] = tr_frag((const unsigned short*)(patch + (nbg >> 1) * ROWB + ks * 32 * 16 + boff + (nbg & 1) * 32), 4 * 8);
+      }
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+          if (4 * wave + nb < 14) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mb], fb[nb], acc[mb][nb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // D[channel 16 mb + 4 grp + r][column li of block nbg]: column j = 16 (nbg & 1) + li = tap s = j >> 2, input channel j & 3 of filter row nbg >> 1
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    const int nbg = 4 * wave + nb;
+    if (nbg >= 14) continue;
+    const int j = 16 * (nbg & 1) + li; const int s = j >> 2, ci = j & 3;
+    if (s >= 7 || ci >= dcin) continue;
+    const int tap = (nbg >> 1) * 7 + s;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(dw + ((int64_t)(16 * mb + 4 * grp + r) * 49 + tap) * dcin + ci, acc[mb][nb][r]);
+  }
+}
+
+static int launch_bf16_stem_wgrad(const unsigned short* dy, const unsigned short* x, float* dw, int N, int H, int W, int dcin, hipStream_t st) {
+  StemGeo g;
+  g.N = N; g.H = H; g.W = W; g.Ho = H / 2; g.Wo = W / 2; g.PC = W + 8; g.tiles = N * g.Ho; g.npix = 7 * (W + 6);
+  g.x_bytes = (uint32_t)((int64_t)N * H * W * 16); g.w_bytes = 0; g.y_bytes = (uint32_t)((int64_t)N * g.Ho * g.Wo * 128);
+  g.dRow = make_fastdiv(W + 6); g.dHo = make_fastdiv(g.Ho);
+  int gx = 512; if (gx > g.tiles) gx = g.tiles;
+  const int KP = 32 * ((g.Wo + 31) / 32);
+  const size_t lds = (size_t)(((7 * (W + 8) * 8) + 255) & ~255) + 512 + (size_t)KP * 128;
+  if (W == 224) hipLaunchKernelGGL((conv_bf16_stem_wgrad_kernel<7>), dim3(gx), dim3(256), lds, st, dy, x, dw, g, dcin);
+  else if (W == 128) hipLaunchKernelGGL((conv_bf16_stem_wgrad_kernel<4>), dim3(gx), dim3(256), lds, st, dy, x, dw, g, dcin);
+  else hipLaunchKernelGGL((conv_bf16_stem_wgrad_kernel<2>), dim3(gx), dim3(256), lds, st, dy, x, dw, g, dcin);
+  LEC_CHECK_LAUNCH("conv_bf16_stem_wgrad_kernel");
+  return LEC_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 static inline int conv_bf16_check(const char* who, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad) {
   LEC_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && (stride == 1 || stride == 2) && pad >= 0 && pad < R && pad < S,
@@ -1290,6 +1419,8 @@ extern "C" int lec_conv_bf16_wgrad(const void* dy, const void* x, int N, int H, 
   using namespace lec;
   if (int rc = conv_bf16_check("conv_bf16_wgrad", N, H, W, Cin, Cout, R, S, stride, pad)) return rc;
   LEC_CHECK_ARG(dy && x && dw && dw_cin > 0 && dw_cin <= Cin, "conv_bf16_wgrad: bad arguments");
+  if (Cin == 8 && dw_cin <= 4 && Cout == 64 && R == 7 && S == 7 && stride == 2 && pad == 3 && tuning().bf_stem && H % 2 == 0 && (W == 224 || W == 128 || W == 64))
+    return launch_bf16_stem_wgrad((const unsigned short*)dy, (const unsigned short*)x, dw, N, H, W, dw_cin, (hipStream_t)stream);   // the stem: its own kernel (same sums)
   WgGeo g;
   g.Ho = (H + 2 * pad - R) / stride + 1; g.Wo = (W + 2 * pad - S) / stride + 1; g.Mpix = N * g.Ho * g.Wo;
   g.H = H; g.W = W; g.Cin = Cin; g.lgCin = ilog2_exact(Cin); g.Cout = Cout; g.S = S; g.RS = R * S; g.stride = stride; g.pad = pad;

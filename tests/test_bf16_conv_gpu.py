@@ -102,6 +102,13 @@ def test_conv_bf16_stem_forward_kernel_matches_the_three_channel_convolution(N, 
     xr = _cl(xr.bfloat16()); wr = _cl(wr.bfloat16())
     ya = ops.conv_bf16_stem_fwd(xr, wr).float(); yb2 = ops.conv_bf16_fwd(xr, wr, 2, 3).float()
     assert (ya - yb2).abs().max().item() <= 2.0 ** -7 * yb2.abs().max().item()
+    # the weight gradient of the same layer (lec_conv_bf16_wgrad hands these sizes to the stem's own kernel): exact integer sums in fp32, added to what is there
+    dyi = torch.randint(-2, 3, (N, 64, H // 2, W // 2), generator=g).float()
+    x3r = x3.double().requires_grad_(False); w3r = w3.double().requires_grad_(True)
+    F.conv2d(x3r, w3r, None, 2, 3).backward(dyi.double())
+    dw = torch.ones(64, 3, 7, 7, device=DEV).contiguous(memory_format=torch.channels_last)
+    ops.conv_bf16_wgrad(_cl(dyi.bfloat16()), xg, dw, 2, 3)
+    assert torch.equal(dw.double().cpu(), w3r.grad + 1.0)
 
 
 def test_conv_bf16_stem_three_channel_weight_gradient_slot():
