@@ -402,6 +402,13 @@ int lec_bn_fwd_prestat_f32(const void* x, const void* residual, int64_t M, int C
  * ------------------------------------------------------------------------------------------------------------- */
 int lec_conv_f32_fwd(const float* x, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                      float* y, float* partials, int64_t partials_bytes, int* n_partials, int schedule, lec_stream_t stream);
+/*     lec_conv_f32_stem_fwd (csrc/conv_stem_f32.hip): torchvision's stem convolution (conv1 of the resnet FeatCNN18 / FeatCNN wrap, oe_h.py:281-378: 7x7 /
+ *       stride 2 / pad 3, 3 -> 64 channels) on its own kernel, exact fp32.  x [N, H, W, 4] and w [64][7][7][4] fp32 as lec_conv_f32_fwd takes them for the stem;
+ *       channels 0..2 enter the product, channel 3 is never multiplied; y [N, H/2, W/2, 64]; partials as lec_conv_f32_fwd (one row per workgroup).
+ *       lec_conv_f32_stem_supported: even H, W in {64, 128, 224}, tensors below 2 GiB; anything else goes through lec_conv_f32_fwd. */
+int lec_conv_f32_stem_supported(int N, int H, int W);
+int lec_conv_f32_stem_fwd(const float* x, const float* w, int N, int H, int W, float* y, float* partials, int64_t partials_bytes, int* n_partials,
+                          lec_stream_t stream);
 int lec_conv_f32_dgrad(const float* dy, const float* w, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                        float* dx, int schedule, lec_stream_t stream);
 /*     lec_conv_f32_fwd_affine: the forward of an EVAL-mode network (FeatCNN.eval(): calculate_classification_metrics' image embedding in

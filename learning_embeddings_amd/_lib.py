@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LEC_LIB_PATH') or os.path.join(_HERE, 'liblecone.so')     # LEC_LIB_PATH: A/B builds of the same ABI
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 OK, E_ARG, E_HIP, E_EMPTY, E_STATE = 0, -1, -2, -3, -4
 ENERGY_HYP_CONE, ENERGY_ORDER, ENERGY_EUC_CONE = 0, 1, 2
@@ -100,6 +100,8 @@ def _load():
         'lec_conv3x3_c128_fwd': (i32, [p, p, i32, i32, i32, p, p, i64, p, p]),
         'lec_bn_fwd_prestat': (i32, [p, p, i64, i32, p, p, f32, f32, p, p, i32, p, p, p, i32, p, p, i64, p]),
         'lec_conv_f32_fwd': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p, i64, p, i32, p]),
+        'lec_conv_f32_stem_supported': (i32, [i32, i32, i32]),
+        'lec_conv_f32_stem_fwd': (i32, [p, p, i32, i32, i32, p, p, i64, p, p]),
         'lec_conv_f32_fwd_affine': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p, p, p, i32, i32, p]),
         'lec_conv_f32_dgrad': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, i32, p]),
         'lec_conv_f32_wgrad': (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, p]),

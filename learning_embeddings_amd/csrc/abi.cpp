@@ -27,6 +27,7 @@ static Tuning load_tuning() {
   { const char* e = env("LEC_CF_SK_FILL"); t.cf_sk_fill = e ? atof(e) : 0.92; }
   t.cf_sk_min_chunks = i("LEC_CF_SK_MIN_CHUNKS", 8);
   t.cf_sk_wgs = pos("LEC_CF_SK_WGS", 512);
+  t.cf_stem = i("LEC_CF_STEM", 1);
   t.cf_xcd = i("LEC_CF_XCD", 0);
   t.cf_lds_pad = i("LEC_CF_LDS_PAD", 0);
   t.dgrad_classes = i("LEC_DGRAD_CLASSES", 1);
@@ -57,4 +58,4 @@ const Tuning& tuning() { static const Tuning t = load_tuning(); return t; }
 }  // namespace lec
 
 extern "C" const char* lec_last_error(void) { return lec::g_err; }
-extern "C" int lec_abi_version(void) { return 32; }
+extern "C" int lec_abi_version(void) { return 33; }

@@ -880,6 +880,29 @@ def _conv_scratch():
         _conv_scratch_bufs[key] = buf
 
 
+def conv_f32_stem_supported(x):
+    """The fp32 stem's own forward kernel serves this input ([N, 4, H, W] channels_last fp32, 3 real channels): even H, W in {64, 128, 224}, tensors < 2 GiB."""
+    return x.dim() == 4 and x.shape[1] == 4 and bool(lib.lec_conv_f32_stem_supported(int(x.shape[0]), int(x.shape[2]), int(x.shape[3])))
+
+
+def conv_f32_stem_fwd(x, w, want_stats=False):
+    """The ResNet stem (7x7 / stride 2 / pad 3, -> 64 channels) of a 3-channel image stored with 4 channels per pixel, exact fp32 (lec_conv_f32_stem_fwd):
+    channels 0..2 of x [N, 4, H, W] and w [64, 4, 7, 7] (channels_last fp32) enter the product; channel 3 is never multiplied."""
+    _nhwc_f32(x, 'x'); _nhwc_f32(w, 'w')
+    n, cin, h, wd = x.shape
+    if cin != 4 or tuple(w.shape) != (64, 4, 7, 7):
+        raise ValueError('stem kernel: x [N, 4, H, W], w [64, 4, 7, 7]')
+    y = torch.empty((n, 64, h // 2, wd // 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    flops = 2.0 * n * (h // 2) * (wd // 2) * 64 * 3 * 49
+    if want_stats:
+        ws = _bn_workspace(x.device); k = C.c_int(0)
+        _conv_timed(lambda: check(lib.lec_conv_f32_stem_fwd(dptr(x), dptr(w), n, h, wd, dptr(y), dptr(ws), ws.numel(), C.byref(k), stream_ptr())), flops)
+        fusion().ws_owner[0], fusion().ws_owner[1] = y.data_ptr(), k.value
+    else:
+        _conv_timed(lambda: check(lib.lec_conv_f32_stem_fwd(dptr(x), dptr(w), n, h, wd, dptr(y), None, 0, None, stream_ptr())), flops)
+    return y
+
+
 def conv_f32_fwd(x, w, stride, pad, want_stats=False):
     """y = conv2d(x, w) in exact fp32 on the f32 MFMA (lec_conv_f32_fwd).  x [N, Cin, H, W], w [Cout, Cin, R, S], both
     channels_last fp32.  want_stats: the BatchNorm statistics partials of y are left in the BatchNorm workspace."""

@@ -478,6 +478,9 @@ class _OverlapConvFn(torch.autograd.Function):
                     planes = conv._x3_planes = _ops().X3Planes(w16.shape, w16.device)
                 ctx.planes = planes.update(w16)                 # the weights move every optimizer step: split again (tens of KB to a few MB)
                 y = _ops().conv_f32x3_fwd(x, planes, conv.stride[0], conv.padding[0], want_stats=True)
+            elif (ctx.stem and conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.out_channels == 64
+                  and _ops().conv_f32_stem_supported(x)):
+                y = _ops().conv_f32_stem_fwd(x, w16, want_stats=True)       # the stem's own kernel: the 7 input rows of an output row staged once, only the 3 real channels multiplied
             else:
                 y = _ops().conv_f32_fwd(x, w16, conv.stride[0], conv.padding[0], want_stats=True)
                 if _ops().LAZY_BN_PASS2_F32 and getattr(conv, 'bn_exclusive', False) and _is_pointwise(conv) and not ctx.stem and conv.out_channels % 32 == 0:

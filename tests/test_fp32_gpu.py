@@ -239,6 +239,34 @@ def test_conv_f32_fwd_dgrad_wgrad_exact_on_integers_and_vs_float64(N, Cin, H, W,
 X3_CASES = CONV_CASES[:11] + [(2, 32, 6, 6, 32, 3, 1, 1), (3, 256, 10, 10, 128, 3, 1, 1), (2, 128, 16, 16, 256, 1, 1, 0)]
 
 
+@pytest.mark.parametrize('N,H,W', [(3, 64, 64), (2, 128, 128), (2, 224, 224), (5, 62, 64)])
+def test_conv_f32_stem_forward_kernel_matches_the_three_channel_convolution(N, H, W):
+    """lec_conv_f32_stem_fwd (the fp32 stem's own kernel: image widths 64 / 128 / 224, even heights) against F.conv2d on the 3 real channels in float64: exact on
+    small integers, fp32-grade on random data, the statistics partials (sum y, sum y^2) those of its output, and equal to the generic kernel up to summation order.
+    Channel 3 is never multiplied: garbage there must not matter."""
+    g = torch.Generator(device='cpu').manual_seed(H + W)
+    x3 = torch.randint(-3, 4, (N, 3, H, W), generator=g).float(); w3 = torch.randint(-2, 3, (64, 3, 7, 7), generator=g).float()
+    x4 = torch.zeros(N, 4, H, W); x4[:, :3] = x3; w4 = torch.zeros(64, 4, 7, 7); w4[:, :3] = w3
+    xg = x4.clone(); xg[:, 3] = torch.randn(N, H, W, generator=g) * 100.0
+    x4 = _cl(x4); w4 = _cl(w4); xg = _cl(xg)
+    assert ops.conv_f32_stem_supported(x4)
+    yr = F.conv2d(x3.double(), w3.double(), None, 2, 3)
+    y = ops.conv_f32_stem_fwd(xg, w4, want_stats=True)
+    k = ops._BN_WS_OWNER[1]; ops._BN_WS_OWNER[0] = 0
+    part = ops._bn_workspace(x4.device).view(torch.float32)[:k * 2 * 64].view(k, 2, 64).double().sum(0)
+    assert y.shape == yr.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(y.double().cpu(), yr)
+    yb = y.double()
+    assert torch.allclose(part[0], yb.sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-2) and torch.allclose(part[1], (yb ** 2).sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-1)
+    assert torch.equal(y, ops.conv_f32_fwd(x4, w4, 2, 3)) and torch.equal(y, ops.conv_f32_stem_fwd(xg, w4))
+    xr = torch.zeros(N, 4, H, W); xr[:, :3] = torch.rand(N, 3, H, W, generator=g); wr = torch.zeros(64, 4, 7, 7); wr[:, :3] = torch.randn(64, 3, 7, 7, generator=g) / 12.0
+    yr2 = F.conv2d(xr[:, :3].double(), wr[:, :3].double(), None, 2, 3)
+    xr = _cl(xr); wr = _cl(wr)
+    ya = ops.conv_f32_stem_fwd(xr, wr).double().cpu()
+    assert (ya - yr2).abs().max().item() <= 2e-6 * yr2.abs().max().item() + 1e-6
+    assert torch.equal(ops.conv_f32_stem_fwd(xr, wr), ops.conv_f32_stem_fwd(xr, wr)), 'deterministic'
+
+
 @pytest.mark.parametrize('N,Cin,H,W,Cout,R,stride,pad', X3_CASES)
 def test_conv_f32x3_exact_on_integers_and_fp32_grade_vs_float64(N, Cin, H, W, Cout, R, stride, pad):
     """lec_conv_f32x3_{fwd,dgrad,wgrad} (fp32 products as six bf16 products on the matrix cores).

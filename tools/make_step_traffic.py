@@ -19,7 +19,7 @@ def fam(k):
 tag, ms, name = sys.argv[1], float(sys.argv[2]), sys.argv[3]
 title = sys.argv[4] if len(sys.argv) > 4 else tag
 kind = sys.argv[5] if len(sys.argv) > 5 else ('bf16' if 'bf16' in name or 'cfg5' in name else 'f32')
-SRCS = ('conv_f32.hip', 'conv_f32_act_body.inc', 'conv_f32x3.hip', 'conv_geo.h', 'bn.hip') if kind == 'f32' else ('conv_bf16.hip', 'conv_mfma.hip', 'conv_geo.h', 'bn.hip')
+SRCS = ('conv_f32.hip', 'conv_f32_act_body.inc', 'conv_f32x3.hip', 'conv_stem_f32.hip', 'conv_geo.h', 'bn.hip') if kind == 'f32' else ('conv_bf16.hip', 'conv_mfma.hip', 'conv_geo.h', 'bn.hip')
 F = json.load(open(os.path.join(D, tag + '_FETCH_SIZE.json'))); W = json.load(open(os.path.join(D, tag + '_WRITE_SIZE.json')))
 f = collections.defaultdict(float); w = collections.defaultdict(float)
 for k, v in F['bytes_per_step'].items(): f[fam(k)] += v
