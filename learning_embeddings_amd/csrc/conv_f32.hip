@@ -1041,6 +1041,8 @@ extern "C" int lec_conv_f32_wgrad_fused(const float* dy, const float* x, int N, 
 // into with float atomics like every other weight gradient (several backward passes of a step may run concurrently).
 extern "C" int lec_conv_f32_wgrad_c3(const float* dy, const float* x4, int N, int H, int W, int Cout, int R, int S, int stride, int pad,
                                      float* dw3, lec_stream_t stream) {
+  if (Cout == 64 && R == 7 && S == 7 && stride == 2 && pad == 3 && dy && x4 && dw3 && lec_conv_f32_stem_supported(N, H, W))
+    return lec::conv_f32_stem_wgrad_launch(dy, x4, N, H, W, dw3, (void*)stream);      // torchvision's stem at the image sizes its own kernel serves
   return conv_f32_wgrad_impl(dy, x4, N, H, W, 4, Cout, R, S, stride, pad, dw3, nullptr, nullptr, 3, stream);
 }
 

@@ -100,4 +100,8 @@ static inline int conv_check(const char* who, int N, int H, int W, int Cin, int 
   return LEC_OK;
 }
 
+
+// csrc/conv_stem_f32.hip: the fp32 stem's weight gradient on its own kernel (lec_conv_f32_wgrad_c3 hands it the sizes lec_conv_f32_stem_supported accepts)
+int conv_f32_stem_wgrad_launch(const float* dy, const float* x, int N, int H, int W, float* dw3, void* stream);
+
 }  // namespace lec

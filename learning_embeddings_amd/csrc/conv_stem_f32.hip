@@ -157,6 +157,117 @@ __global__ __launch_bounds__(256, 2) void conv_f32_stem_kernel(const float* __re
   }
 }
 
+// The stem's weight gradient on the same patch, exact fp32: dw[co][(r, s)][ci] = sum over output pixels of dy[p][co] * x[2 oh + r - 3][2 ow + s - 3][ci].
+// A tile is one output row, K = its pixels (4 per v_mfma_f32_16x16x4_f32).  Only the 147 real (tap, channel) columns are multiplied: column f = 21 r + 3 s + ci,
+// ten blocks of 16 (the last 13 columns of the tenth are idle), each lane keeping the patch offset of ITS column of every block; the operand of pixel p is then
+// the float at patch[offset + 32 p].  dY rows are stored 320 bytes apart, so that the four pixels of a K step (one per quarter-wave) read disjoint banks.
+// Wave v owns output channels 16 v .. 16 v + 15 and all ten column blocks (40 accumulator registers, the same work for every wave); sums stay in registers over
+// the workgroup's rows and leave as float atomics into the layer's [64][7][7][3] slot, like every other weight gradient.
+template <int NPB>
+__global__ __launch_bounds__(256, 2) void conv_f32_stem_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw, StemGeoF g) {
+  constexpr int WO = 16 * NPB, PC = 32 * NPB + 8, ROWB = PC * 16, PATCH = 7 * ROWB, DROW = 320;
+  constexpr int NLD = (7 * (32 * NPB + 6) + 255) / 256, NDY = WO * 16 / 256;
+  extern __shared__ __attribute__((aligned(16))) float smemf[];
+  char* const patch = (char*)smemf;
+  char* const dyt = patch + PATCH;                              // [WO] rows of 64 floats, 320 bytes apart
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, kq = lane >> 4;
+  const rsrc_t rs_x = make_rsrc(x, g.x_bytes), rs_dy = make_rsrc(dy, g.y_bytes);
+  int rel[NLD]; int rr[NLD]; unsigned pofs[NLD];
+#pragma unroll
+  for (int u = 0; u < NLD; ++u) {
+    const int idx = tid + 256 * u;
+    const int r = fdiv(idx, g.dRow); const int cpos = idx - r * (g.W + 6);
+    const int col = cpos - 3;
+    const bool ok = idx < g.npix && (unsigned)col < (unsigned)g.W;
+    rel[u] = ok ? (r * g.W + col) * 16 : -1;
+    rr[u] = r;
+    pofs[u] = idx < g.npix ? (unsigned)(r * ROWB + cpos * 16) : 0xffffffffu;
+  }
+  // this lane's column of block b: f = 16 b + l15 = 21 r + 3 s + ci -> byte offset of (row r, position s, channel ci) in the patch; idle columns read offset 0
+  unsigned boff[10];
+#pragma unroll
+  for (int b = 0; b < 10; ++b) {
+    const int f = 16 * b + l15;
+    const int r = f / 21, rem = f - 21 * r; const int s = rem / 3, ci = rem - 3 * s;
+    boff[b] = f < 147 ? (unsigned)(r * ROWB + s * 16 + ci * 4) : 0u;
+  }
+  f32x4v stx[NLD], sty[NDY];
+  auto request = [&](int t) {
+    const int n = fdiv(t, g.dHo); const int oh = t - n * g.Ho;
+    const int row0 = 2 * oh - 3;
+    const int base = (n * g.H + row0) * g.W * 16;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const bool ok = rel[u] >= 0 && (unsigned)(row0 + rr[u]) < (unsigned)g.H;
+      stx[u] = bload4(rs_x, ok ? (unsigned)(base + rel[u]) : kOob);
+    }
+    const unsigned dbase = (unsigned)(t * WO) * 256u;
+#pragma unroll
+    for (int u = 0; u < NDY; ++u) sty[u] = bload4(rs_dy, dbase + (unsigned)(tid + 256 * u) * 16u);
+  };
+  for (int i = tid; i < PATCH / 16; i += 256) { f32x4v z; z[0] = 0.f; z[1] = 0.f; z[2] = 0.f; z[3] = 0.f; *(f32x4v*)(patch + 16 * i) = z; }
+  f32x4v acc[10];
+#pragma unroll
+  for (int b = 0; b < 10; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[b][r] = 0.f;
+
+  const int per = (g.tiles + 7) >> 3;
+  auto tile_of = [&](int slot) { return (slot & 7) * per + (slot >> 3); };
+  const int nslots = 8 * per;
+  { const int t0 = tile_of(blockIdx.x); if ((int)blockIdx.x < nslots && t0 < g.tiles) request(t0); }
+  for (int slot = blockIdx.x; slot < nslots; slot += gridDim.x) {
+    const int t = tile_of(slot);
+    const int tn = slot + (int)gridDim.x < nslots ? tile_of(slot + gridDim.x) : g.tiles;
+    if (t >= g.tiles) continue;
+    stem_wait_vmcnt<0>();
+    __syncthreads();                                            // the previous tile's operands have been read by every wave
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) if (pofs[u] != 0xffffffffu) *(f32x4v*)(patch + pofs[u]) = stx[u];
+#pragma unroll
+    for (int u = 0; u < NDY; ++u) { const int idx = tid + 256 * u; *(f32x4v*)(dyt + (idx >> 4) * DROW + (idx & 15) * 16) = sty[u]; }
+    __syncthreads();
+    if (tn < g.tiles) request(tn);
+    const char* pa = dyt + kq * DROW + (16 * wave + l15) * 4;   // dY[pixel 4 j + kq][channel 16 wave + l15]
+    const char* pbx = patch + kq * 32;                           // the pixel's operand: 32 bytes (two positions) per output pixel
+#pragma unroll 2
+    for (int j = 0; j < WO / 4; ++j) {
+      const float a = *(const float*)(pa + j * 4 * DROW);
+      float bv[10];
+#pragma unroll
+      for (int b = 0; b < 10; ++b) bv[b] = *(const float*)(pbx + boff[b] + j * 128);
+#pragma unroll
+      for (int b = 0; b < 10; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[b], acc[b], 0, 0, 0);
+    }
+  }
+  // D[channel 16 wave + 4 kq + r][column l15 of block b]
+#pragma unroll
+  for (int b = 0; b < 10; ++b) {
+    const int f = 16 * b + l15;
+    if (f < 147) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(dw + (int64_t)(16 * wave + 4 * kq + r) * 147 + f, acc[b][r]);
+    }
+  }
+}
+
+int conv_f32_stem_wgrad_launch(const float* dy, const float* x, int N, int H, int W, float* dw3, void* stream) {
+  StemGeoF g;
+  g.N = N; g.H = H; g.W = W; g.Ho = H / 2; g.Wo = W / 2; g.tiles = N * g.Ho; g.npix = 7 * (W + 6);
+  g.x_bytes = (uint32_t)((int64_t)N * H * W * 16); g.w_bytes = 0; g.y_bytes = (uint32_t)((int64_t)N * g.Ho * g.Wo * 256);
+  g.dRow = make_fastdiv(W + 6); g.dHo = make_fastdiv(g.Ho);
+  int gx = 512; if (gx > g.tiles) gx = g.tiles;
+  const size_t lds = (size_t)7 * (W + 8) * 16 + (size_t)g.Wo * 320;
+  hipStream_t st = (hipStream_t)stream;
+  if (W == 224) hipLaunchKernelGGL((conv_f32_stem_wgrad_kernel<7>), dim3(gx), dim3(256), lds, st, dy, x, dw3, g);
+  else if (W == 128) hipLaunchKernelGGL((conv_f32_stem_wgrad_kernel<4>), dim3(gx), dim3(256), lds, st, dy, x, dw3, g);
+  else hipLaunchKernelGGL((conv_f32_stem_wgrad_kernel<2>), dim3(gx), dim3(256), lds, st, dy, x, dw3, g);
+  LEC_CHECK_LAUNCH("conv_f32_stem_wgrad_kernel");
+  return LEC_OK;
+}
+
 }  // namespace lec
 
 // torchvision's stem convolution (resnet.py conv1) on a 3-channel image stored with 4 channels per pixel: channels 0..2 of x [N, H, W, 4] and w [64][7][7][4]

@@ -9,7 +9,7 @@ struct Tuning {
   int cf_sk;                  // LEC_CF_SK              balanced (stream-K) forward / data gradient: 0 never, 1 where the last round of slots is under cf_sk_fill, 2 always
   double cf_sk_fill;          // LEC_CF_SK_FILL
   int cf_sk_min_chunks;       // LEC_CF_SK_MIN_CHUNKS
-  int cf_stem;                // LEC_CF_STEM            the fp32 7x7 / stride-2 stem forward on its own LDS-patch kernel (1) or on the generic kernel (0)
+  int cf_stem;                // LEC_CF_STEM            the fp32 7x7 / stride-2 stem (forward and weight gradient) on its own LDS-patch kernels (1) or on the generic kernels (0)
   int cf_sk_wgs;              // LEC_CF_SK_WGS          workgroups of a balanced launch (512: every resident slot; 256: one per CU -- two passes' launches side by side)
   int cf_xcd;                 // LEC_CF_XCD             XCD-contiguous tile runs (measured: no gain; off)
   int cf_lds_pad;             // LEC_CF_LDS_PAD         extra LDS bytes per workgroup of the forward / data-gradient kernels (experiments: residency)

@@ -265,6 +265,18 @@ def test_conv_f32_stem_forward_kernel_matches_the_three_channel_convolution(N, H
     ya = ops.conv_f32_stem_fwd(xr, wr).double().cpu()
     assert (ya - yr2).abs().max().item() <= 2e-6 * yr2.abs().max().item() + 1e-6
     assert torch.equal(ops.conv_f32_stem_fwd(xr, wr), ops.conv_f32_stem_fwd(xr, wr)), 'deterministic'
+    # the weight gradient of the same layer (lec_conv_f32_wgrad_c3 hands these sizes to the stem's own kernel): exact integer sums, added to what is there
+    dyi = torch.randint(-2, 3, (N, 64, H // 2, W // 2), generator=g).float()
+    w3r = w3.double().requires_grad_(True)
+    F.conv2d(x3.double(), w3r, None, 2, 3).backward(dyi.double())
+    dw = torch.ones(64, 3, 7, 7, device=DEV).contiguous(memory_format=torch.channels_last)
+    ops.conv_f32_wgrad_c3(_cl(dyi), xg, dw, 2, 3)
+    assert torch.equal(dw.double().cpu(), w3r.grad + 1.0)
+    dyr = torch.randn(N, 64, H // 2, W // 2, generator=g); wrr = wr.detach().cpu()[:, :3].double().requires_grad_(True)
+    F.conv2d(xr.cpu()[:, :3].double(), wrr, None, 2, 3).backward(dyr.double())
+    dw2 = torch.zeros(64, 3, 7, 7, device=DEV).contiguous(memory_format=torch.channels_last)
+    ops.conv_f32_wgrad_c3(_cl(dyr), xr, dw2, 2, 3)
+    assert (dw2.double().cpu() - wrr.grad).abs().max().item() <= 2e-5 * wrr.grad.abs().max().item() + 1e-5
 
 
 @pytest.mark.parametrize('N,Cin,H,W,Cout,R,stride,pad', X3_CASES)

@@ -14,3 +14,8 @@ for N in (256, 512):
     t1=timeit(lambda: ops.conv_f32_stem_fwd(x,w,want_stats=True)); ops._BN_WS_OWNER[0]=0
     t0=timeit(lambda: ops.conv_f32_fwd(x,w,2,3,want_stats=True)); ops._BN_WS_OWNER[0]=0
     print('rows %d: stem kernel %.1f us, generic %.1f us' % (N, t1, t0))
+for N in (256, 512):
+    x=torch.rand(N,4,224,224,device='cuda').contiguous(memory_format=torch.channels_last); x[:,3]=0
+    dy=torch.randn(N,64,112,112,device='cuda').contiguous(memory_format=torch.channels_last)
+    dw=torch.zeros(64,3,7,7,device='cuda').contiguous(memory_format=torch.channels_last)
+    print('rows %d: weight gradient (lec_conv_f32_wgrad_c3; LEC_CF_STEM=0 for the generic kernel) %.1f us' % (N, timeit(lambda: ops.conv_f32_wgrad_c3(dy, x, dw, 2, 3))))
