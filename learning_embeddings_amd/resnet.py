@@ -656,6 +656,8 @@ class Conv2d(nn.Conv2d):
             w = self.weight if self.weight.is_contiguous(memory_format=torch.channels_last) else self.weight.contiguous(memory_format=torch.channels_last)
             if self.in_channels == 3:
                 x, w = _pad_c4(x), _pad_c4(w)
+                if (self.kernel_size == (7, 7) and self.stride == (2, 2) and self.padding == (3, 3) and self.out_channels == 64 and _ops().conv_f32_stem_supported(x)):
+                    return _ops().conv_f32_stem_fwd(x, w, want_stats=self.training)         # the stem's own kernel (evaluation forwards too)
             return _ops().conv_f32_fwd(x, w, self.stride[0], self.padding[0], want_stats=self.training)
         if x.is_cuda:
             _lib_launch('module')                               # nn.Conv2d's own forward (and autograd's backward behind it): MIOpen

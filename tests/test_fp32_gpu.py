@@ -564,6 +564,8 @@ def test_inference_forward_runs_liblecone_kernels_and_matches_stock_torch(arch, 
     fa, ff = ops.conv_f32_fwd_affine, ops.conv_f32_fwd
     monkeypatch.setattr(ops, 'conv_f32_fwd_affine', lambda *a, **k: (calls.__setitem__('affine', calls['affine'] + 1), fa(*a, **k))[1])
     monkeypatch.setattr(ops, 'conv_f32_fwd', lambda *a, **k: (calls.__setitem__('fwd', calls['fwd'] + 1), ff(*a, **k))[1])
+    fs = ops.conv_f32_stem_fwd                                      # (the stem of 64 / 128 / 224-pixel images has its own forward kernel)
+    monkeypatch.setattr(ops, 'conv_f32_stem_fwd', lambda *a, **k: (calls.__setitem__('fwd', calls['fwd'] + 1), fs(*a, **k))[1])
     n_conv = sum(isinstance(m, torch.nn.Conv2d) for m in net.modules())
     for train in (False, True):
         ref_net = copy.deepcopy(net); net.train(train); ref_net.train(train)
